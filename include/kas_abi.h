@@ -1,0 +1,214 @@
+/*
+ * kas_abi.h — C ABI of the MI355X batch solver for kafka-assigner's minimal-movement,
+ * rack-aware rebalance path.
+ *
+ * This is the drop-in boundary for exactly one reference call site:
+ *
+ *   KafkaTopicAssigner.generateAssignment            KafkaTopicAssigner.java:42-72
+ *     -> KafkaAssignmentStrategy.getRackAwareAssignment
+ *                                                     KafkaAssignmentStrategy.java:40-63
+ *
+ * Everything the reference passes as boxed Java collections is passed here as flat,
+ * caller-owned int32 tables:
+ *
+ *   reference argument (KafkaAssignmentStrategy.java:40-43)     this ABI
+ *   ----------------------------------------------------------  ---------------------------------
+ *   String topicName                                            kas_topic_desc.name_hash
+ *                                                               (= topicName.hashCode(); only use
+ *                                                               of the name is KAS:190)
+ *   Map<Integer,List<Integer>> currentAssignment                cur pool: cur[P][cur_width] broker
+ *                                                               ids, rows in ascending partition
+ *                                                               id order (+ optional cur_len[P])
+ *   Map<Integer,String> nodeRackAssignment                      node_rack[N] dense rack index
+ *                                                               (rack-less broker = own unique
+ *                                                               index, KAS:82-86)
+ *   Set<Integer> nodes                                          node_id[N] strictly ascending
+ *   Set<Integer> partitions                                     implicit = rows of cur; optional
+ *                                                               in_partitions[P] flags for direct
+ *                                                               callers that pass a different set
+ *   int replicationFactor                                       kas_topic_desc.rf (resolved per
+ *                                                               KafkaTopicAssigner.java:49-62)
+ *   Context context                                             ctx pool: counter[N][ctx_width]
+ *                                                               (KAS:360-369, KAS:244-302)
+ *   return Map<Integer,List<Integer>>                           out pool: out[P][out_width] broker
+ *                                                               ids in preference order, -1 padded
+ *   IllegalStateException (KAS:183-184, KTA:65-69)              kas_topic_result.status/.fail_partition
+ *
+ * A *scenario* is one cluster snapshot: one broker set + rack map and an ordered list of
+ * topics that share one Context (what one `--mode PRINT_REASSIGNMENT` run of
+ * KafkaAssignmentGenerator.java:131-187 solves).  A *batch* is many independent scenarios;
+ * the GPU solves them concurrently, one wavefront per scenario.
+ *
+ * Rules: no C++ types, exceptions or longjmp cross this boundary; the library never
+ * retains caller pointers after a call returns (a plan copies what it needs); every
+ * function returns 0 or a negative KAS_E_* code and kas_last_error() gives thread-local
+ * detail.  There is no CPU fallback: without a HIP device the solve entry points fail.
+ */
+#ifndef KAS_ABI_H
+#define KAS_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAS_ABI_VERSION 1
+
+/* Longest replica list the kernels keep in registers: max(cur_width, rf) <= KAS_MAX_WIDTH. */
+#define KAS_MAX_WIDTH 8
+
+/* ---- return codes of the entry points (negative = call failed) ------------------------ */
+#define KAS_E_OK            0
+#define KAS_E_INVALID_ARG  (-1)  /* NULL pointer, negative size, inconsistent descriptor   */
+#define KAS_E_HIP          (-2)  /* a HIP runtime call failed or no gfx950 device present   */
+#define KAS_E_UNSUPPORTED  (-3)  /* shape beyond what the kernels hold in LDS / registers   */
+#define KAS_E_NOMEM        (-4)
+
+/* ---- per-topic status codes (the reference's exceptions, as data) --------------------- */
+#define KAS_OK                   0
+#define KAS_FAIL_UNASSIGNABLE    1  /* KAS:183-184 "Partition p could not be fully assigned!";
+                                       fail_partition = p                                   */
+#define KAS_FAIL_RF_NOT_POSITIVE 2  /* KTA:65-66                                            */
+#define KAS_FAIL_RF_GT_BROKERS   3  /* KTA:67-69                                            */
+#define KAS_FAIL_HASH_INDEX      4  /* topic.hashCode()==Integer.MIN_VALUE: Math.abs stays
+                                       negative -> ArrayIndexOutOfBounds at KAS:190-192      */
+#define KAS_FAIL_RF_MISMATCH     5  /* KTA:58-60; raised by the host mirror while resolving
+                                       rf, never by the kernels                              */
+#define KAS_SKIPPED              6  /* an earlier topic of the same scenario failed; the CLI
+                                       run would have aborted (KAG:173-184)                  */
+#define KAS_FAIL_BAD_NODES       7  /* node_id[] not strictly ascending (KAS:80 analogue),
+                                       a negative node id (-1 is the pad value of out rows;
+                                       Kafka broker ids are non-negative), or node_rack[]
+                                       outside [0, 32767]                                    */
+
+/* One topic of one scenario.  Offsets are in int32 elements into the named pool. */
+typedef struct kas_topic_desc {
+  int32_t name_hash;        /* Java String.hashCode() of the topic name (KAS:190)           */
+  int32_t n_partitions;     /* P = number of rows of cur (= |keys(currentAssignment)|)      */
+  int32_t cur_width;        /* columns of the cur table (longest current replica list)      */
+  int32_t rf;               /* replication factor handed to KAS:40-43                       */
+  int32_t out_width;        /* columns of the out table, >= max(cur_width, rf)              */
+  int32_t reserved;
+  int64_t cur_off;          /* cur pool: cur[P][cur_width], row-major, broker ids            */
+  int64_t out_off;          /* out pool: out[P][out_width]                                   */
+  int64_t cur_len_off;      /* aux pool: int32 len[P] (ragged lists), or -1 = all full width */
+  int64_t in_partitions_off;/* aux pool: int32 flag[P] (row is in `partitions`), or -1 = all */
+  int64_t part_id_off;      /* aux pool: ascending int32 partition ids[P], or -1 = 0..P-1    */
+} kas_topic_desc;
+
+/* One scenario = one broker set and an ordered run of topics sharing one Context. */
+typedef struct kas_scenario_desc {
+  int32_t n_nodes;          /* N                                                             */
+  int32_t topic_begin;      /* first topic (index into the topic descriptor array)           */
+  int32_t topic_count;      /* topics solved in this order against one Context               */
+  int32_t ctx_width;        /* columns of the Context counter table (0 = no Context in/out)  */
+  int64_t node_off;         /* node pools: node_id[N] (strictly ascending) and node_rack[N]  */
+  int64_t ctx_off;          /* ctx pool: counter[N][ctx_width] read at start, written at end;
+                               -1 = start from an empty Context and do not write it back     */
+} kas_scenario_desc;
+
+/* Per-topic outcome (what one generateAssignment call would have returned/thrown). */
+typedef struct kas_topic_result {
+  int32_t status;           /* KAS_OK or a KAS_FAIL_* / KAS_SKIPPED code                     */
+  int32_t fail_partition;   /* partition id for KAS_FAIL_UNASSIGNABLE, else -1               */
+  int32_t moved_replicas;   /* sum_p |set(new[p]) \ set(cur[p])|                             */
+  int32_t moved_partitions; /* #{p : set(new[p]) != set(cur[p])}                             */
+} kas_topic_result;
+
+/* Per-scenario record: fixed 32 bytes, the unit of the multi-GPU all-gather. */
+typedef struct kas_scenario_result {
+  int32_t  status;          /* status of the first failing topic, or KAS_OK                  */
+  int32_t  fail_topic;      /* index of that topic within the scenario, or -1                */
+  int32_t  fail_partition;  /* its fail_partition, or -1                                     */
+  int32_t  moved_replicas;  /* summed over the scenario's solved topics                      */
+  int32_t  moved_partitions;
+  int32_t  reserved;
+  uint64_t digest;          /* order-independent 64-bit checksum of every emitted
+                               (topic, partition row, replica slot, broker id); see
+                               kas_digest_cell()                                             */
+} kas_scenario_result;
+
+/* Host view of a batch: descriptors and node tables always live in HOST memory (a plan
+ * uploads them once); the bulk tables are passed separately per solve so they can be
+ * device resident. */
+typedef struct kas_batch_desc {
+  int32_t n_scenarios;
+  int32_t n_topics;
+  const kas_scenario_desc* scenarios;   /* [n_scenarios]                                     */
+  const kas_topic_desc*    topics;      /* [n_topics]                                        */
+  const int32_t* node_id;               /* node pool, host                                   */
+  const int32_t* node_rack;             /* rack pool, host (same offsets as node_id)         */
+  int64_t node_pool_len;                /* elements in each node pool                        */
+} kas_batch_desc;
+
+/* Bulk tables of one solve.  All pointers are DEVICE pointers for kas_solve_device and
+ * HOST pointers for kas_solve_host.  aux/ctx may be NULL when no descriptor refers to them. */
+typedef struct kas_tables {
+  const int32_t* cur;                   /* cur pool                                          */
+  int32_t*       out;                   /* out pool                                          */
+  const int32_t* aux;                   /* cur_len / in_partitions / part_id arrays          */
+  int32_t*       ctx;                   /* Context counters, in/out                          */
+  kas_topic_result*    topic_results;   /* [n_topics]                                        */
+  kas_scenario_result* scenario_results;/* [n_scenarios]                                     */
+  int64_t cur_len, out_len, aux_len, ctx_len; /* pool sizes in elements (host path copies
+                                                 exactly this much; device path ignores)      */
+} kas_tables;
+
+typedef struct kas_ctx  kas_ctx;    /* device context: HIP device + stream + scratch         */
+typedef struct kas_plan kas_plan;   /* validated batch shape: descriptors + node tables in HBM,
+                                       launch geometry, LDS carve-up                          */
+
+/* Contribution of one emitted cell to kas_scenario_result.digest (sum modulo 2^64 over all
+ * cells).  Pure function, usable by any checker.  topic = index within the scenario,
+ * row = partition row index, slot = position in the preference list. */
+static inline uint64_t kas_digest_cell(uint32_t topic, uint32_t row, uint32_t slot,
+                                       int32_t broker) {
+  uint64_t x = ((uint64_t)row << 32) | (uint32_t)broker;
+  x += 0x9E3779B97F4A7C15ull * (uint64_t)(slot + 1u);
+  x ^= 0xD6E8FEB86659FD93ull * (uint64_t)(topic + 1u);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+int         kas_abi_version(void);
+const char* kas_strerror(int code);          /* text for KAS_E_* return codes               */
+const char* kas_status_string(int status);   /* text for KAS_OK / KAS_FAIL_* status codes   */
+const char* kas_last_error(void);            /* thread-local detail of the last failure     */
+
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int kas_device_count(void);
+
+/* Create / destroy a device context on HIP device `device` (gfx950 required). */
+int  kas_ctx_create(int device, kas_ctx** out_ctx);
+void kas_ctx_destroy(kas_ctx* ctx);
+
+/* Validate a batch shape, upload descriptors + node tables, size scratch and LDS. */
+int  kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan);
+void kas_plan_destroy(kas_plan* plan);
+
+/* Bytes of HBM the path must move per solve of this plan:
+ * sum over topics 4*P*(cur_width + out_width) + sum over scenarios 8*N (+ ctx in/out). */
+int64_t kas_plan_algorithmic_bytes(const kas_plan* plan);
+
+/* Solve with every bulk table already resident in HBM.  `hip_stream` is a hipStream_t
+ * (NULL = the context's own stream).  Asynchronous: returns after enqueueing. */
+int kas_solve_device(kas_plan* plan, const kas_tables* device_tables, void* hip_stream);
+
+/* Block until everything enqueued on the context's own stream has finished. */
+int kas_ctx_synchronize(kas_ctx* ctx);
+
+/* Convenience for host callers (JNI / ctypes / C++ mirror): H2D, solve, D2H, blocking. */
+int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables);
+
+/* Average device time in microseconds of the solver kernel over the launches recorded since
+ * the last call (HIP events on the launch stream); resets the accumulator. Returns <0 on
+ * error, and *launches = 0 when nothing was recorded. */
+int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAS_ABI_H */

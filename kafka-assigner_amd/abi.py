@@ -1,0 +1,151 @@
+"""ctypes mirror of include/kas_abi.h (structs, constants, digest function).
+
+Pure declarations: nothing here loads a library.  Field order and types must match the header
+byte for byte; tests/test_abi_layout.py checks sizes and offsets against a C probe.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+KAS_ABI_VERSION = 1
+KAS_MAX_WIDTH = 8
+
+KAS_E_OK = 0
+KAS_E_INVALID_ARG = -1
+KAS_E_HIP = -2
+KAS_E_UNSUPPORTED = -3
+KAS_E_NOMEM = -4
+
+KAS_OK = 0
+KAS_FAIL_UNASSIGNABLE = 1
+KAS_FAIL_RF_NOT_POSITIVE = 2
+KAS_FAIL_RF_GT_BROKERS = 3
+KAS_FAIL_HASH_INDEX = 4
+KAS_FAIL_RF_MISMATCH = 5
+KAS_SKIPPED = 6
+KAS_FAIL_BAD_NODES = 7
+
+STATUS_NAMES = {
+    KAS_OK: "OK",
+    KAS_FAIL_UNASSIGNABLE: "FAIL_UNASSIGNABLE",
+    KAS_FAIL_RF_NOT_POSITIVE: "FAIL_RF_NOT_POSITIVE",
+    KAS_FAIL_RF_GT_BROKERS: "FAIL_RF_GT_BROKERS",
+    KAS_FAIL_HASH_INDEX: "FAIL_HASH_INDEX",
+    KAS_FAIL_RF_MISMATCH: "FAIL_RF_MISMATCH",
+    KAS_SKIPPED: "SKIPPED",
+    KAS_FAIL_BAD_NODES: "FAIL_BAD_NODES",
+}
+
+
+class TopicDesc(C.Structure):
+    _fields_ = [
+        ("name_hash", C.c_int32),
+        ("n_partitions", C.c_int32),
+        ("cur_width", C.c_int32),
+        ("rf", C.c_int32),
+        ("out_width", C.c_int32),
+        ("reserved", C.c_int32),
+        ("cur_off", C.c_int64),
+        ("out_off", C.c_int64),
+        ("cur_len_off", C.c_int64),
+        ("in_partitions_off", C.c_int64),
+        ("part_id_off", C.c_int64),
+    ]
+
+
+class ScenarioDesc(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32),
+        ("topic_begin", C.c_int32),
+        ("topic_count", C.c_int32),
+        ("ctx_width", C.c_int32),
+        ("node_off", C.c_int64),
+        ("ctx_off", C.c_int64),
+    ]
+
+
+class TopicResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("fail_partition", C.c_int32),
+        ("moved_replicas", C.c_int32),
+        ("moved_partitions", C.c_int32),
+    ]
+
+
+class ScenarioResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("fail_topic", C.c_int32),
+        ("fail_partition", C.c_int32),
+        ("moved_replicas", C.c_int32),
+        ("moved_partitions", C.c_int32),
+        ("reserved", C.c_int32),
+        ("digest", C.c_uint64),
+    ]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [
+        ("n_scenarios", C.c_int32),
+        ("n_topics", C.c_int32),
+        ("scenarios", C.POINTER(ScenarioDesc)),
+        ("topics", C.POINTER(TopicDesc)),
+        ("node_id", C.POINTER(C.c_int32)),
+        ("node_rack", C.POINTER(C.c_int32)),
+        ("node_pool_len", C.c_int64),
+    ]
+
+
+class Tables(C.Structure):
+    _fields_ = [
+        ("cur", C.c_void_p),
+        ("out", C.c_void_p),
+        ("aux", C.c_void_p),
+        ("ctx", C.c_void_p),
+        ("topic_results", C.c_void_p),
+        ("scenario_results", C.c_void_p),
+        ("cur_len", C.c_int64),
+        ("out_len", C.c_int64),
+        ("aux_len", C.c_int64),
+        ("ctx_len", C.c_int64),
+    ]
+
+
+# numpy structured dtypes with the same layout as TopicResult / ScenarioResult
+import numpy as _np  # noqa: E402
+
+TOPIC_RESULT_DTYPE = _np.dtype([
+    ("status", "<i4"), ("fail_partition", "<i4"),
+    ("moved_replicas", "<i4"), ("moved_partitions", "<i4")])
+SCENARIO_RESULT_DTYPE = _np.dtype([
+    ("status", "<i4"), ("fail_topic", "<i4"), ("fail_partition", "<i4"),
+    ("moved_replicas", "<i4"), ("moved_partitions", "<i4"), ("reserved", "<i4"),
+    ("digest", "<u8")])
+TOPIC_DESC_DTYPE = _np.dtype([
+    ("name_hash", "<i4"), ("n_partitions", "<i4"), ("cur_width", "<i4"), ("rf", "<i4"),
+    ("out_width", "<i4"), ("reserved", "<i4"), ("cur_off", "<i8"), ("out_off", "<i8"),
+    ("cur_len_off", "<i8"), ("in_partitions_off", "<i8"), ("part_id_off", "<i8")])
+SCENARIO_DESC_DTYPE = _np.dtype([
+    ("n_nodes", "<i4"), ("topic_begin", "<i4"), ("topic_count", "<i4"), ("ctx_width", "<i4"),
+    ("node_off", "<i8"), ("ctx_off", "<i8")])
+
+assert TOPIC_RESULT_DTYPE.itemsize == C.sizeof(TopicResult) == 16
+assert SCENARIO_RESULT_DTYPE.itemsize == C.sizeof(ScenarioResult) == 32
+assert TOPIC_DESC_DTYPE.itemsize == C.sizeof(TopicDesc) == 64
+assert SCENARIO_DESC_DTYPE.itemsize == C.sizeof(ScenarioDesc) == 32
+
+_M64 = (1 << 64) - 1
+
+
+def digest_cell(topic: int, row: int, slot: int, broker: int) -> int:
+    """Python twin of kas_digest_cell() in include/kas_abi.h."""
+    x = ((row & 0xFFFFFFFF) << 32) | (broker & 0xFFFFFFFF)
+    x = (x + 0x9E3779B97F4A7C15 * (slot + 1)) & _M64
+    x ^= (0xD6E8FEB86659FD93 * (topic + 1)) & _M64
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & _M64
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & _M64
+    x ^= x >> 31
+    return x
