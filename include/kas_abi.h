@@ -162,7 +162,10 @@ typedef struct kas_plan kas_plan;   /* validated batch shape: descriptors + node
 /* Contribution of one emitted cell to kas_scenario_result.digest (sum modulo 2^64 over all
  * cells).  Pure function, usable by any checker.  topic = index within the scenario,
  * row = partition row index, slot = position in the preference list. */
-static inline uint64_t kas_digest_cell(uint32_t topic, uint32_t row, uint32_t slot,
+#ifndef KAS_ABI_FN
+#define KAS_ABI_FN static inline   /* the HIP translation unit adds __host__ __device__ */
+#endif
+KAS_ABI_FN uint64_t kas_digest_cell(uint32_t topic, uint32_t row, uint32_t slot,
                                        int32_t broker) {
   uint64_t x = ((uint64_t)row << 32) | (uint32_t)broker;
   x += 0x9E3779B97F4A7C15ull * (uint64_t)(slot + 1u);

@@ -1,0 +1,338 @@
+// kas_hip.hip — gfx950 kernels + the C ABI of include/kas_abi.h (libkas_hip.so).
+//
+// One workgroup of one wavefront per scenario; the grid is the batch.  Scenarios share nothing,
+// so there is no inter-workgroup communication at all: each wavefront streams its own cur table
+// from HBM (coalesced 64-row tiles), keeps broker load / rack / Context counters in LDS and
+// writes its own out rows and one 32-byte result record.  Workgroup b lands on XCD b % 8; in the
+// what-if layout (many scenarios over one shared cur table) neighbouring scenarios therefore
+// spread the shared table over all eight L2s, and the 256 MiB Infinity Cache holds it once.
+#define KAS_ABI_FN __host__ __device__ static inline
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kas_abi.h"
+#include "kas_plan_math.h"
+#include "kas_solver_body.h"
+
+// ---------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64) void kas_solve_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
+    kas::solve_scenario<W>(a, s, kas_lds);
+}
+
+// widths the kernel is instantiated for; a batch uses the smallest one >= its widest list
+static int kas_width_class(int W) { return W <= 2 ? 2 : W <= 5 ? W : 8; }
+
+typedef void (*kas_kernel_fn)(KasLaunch);
+static kas_kernel_fn kas_kernel_for(int Wc) {
+  switch (Wc) {
+    case 2: return kas_solve_kernel<2>;
+    case 3: return kas_solve_kernel<3>;
+    case 4: return kas_solve_kernel<4>;
+    case 5: return kas_solve_kernel<5>;
+    default: return kas_solve_kernel<8>;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int set_error(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define KAS_HIP_TRY(expr)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return set_error(KAS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+struct kas_ctx {
+  int device;
+  hipStream_t stream;
+};
+
+#define KAS_TIMER_SLOTS 64
+
+struct kas_plan {
+  kas_ctx* ctx;
+  KasShape shape;
+  int Wc;                       // instantiated width class
+  KasLds lds;
+  int32_t n_scenarios, n_topics;
+  // device copies owned by the plan
+  kas_scenario_desc* d_scen;
+  kas_topic_desc* d_topics;
+  int32_t* d_node_id;
+  int32_t* d_node_rack;
+  int64_t* d_accmask_off;
+  uint64_t* d_accmask;
+  // kernel timing: event pairs recorded around every launch on the launch stream
+  hipEvent_t ev_start[KAS_TIMER_SLOTS], ev_stop[KAS_TIMER_SLOTS];
+  int timer_next, timer_count;
+};
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int kas_abi_version(void) { return KAS_ABI_VERSION; }
+
+const char* kas_strerror(int code) {
+  switch (code) {
+    case KAS_E_OK: return "ok";
+    case KAS_E_INVALID_ARG: return "invalid argument";
+    case KAS_E_HIP: return "HIP runtime error or no HIP device";
+    case KAS_E_UNSUPPORTED: return "batch shape not supported by the kernels";
+    case KAS_E_NOMEM: return "out of memory";
+    default: return "unknown error code";
+  }
+}
+
+const char* kas_status_string(int status) {
+  switch (status) {
+    case KAS_OK: return "OK";
+    case KAS_FAIL_UNASSIGNABLE: return "partition could not be fully assigned (KAS:183-184)";
+    case KAS_FAIL_RF_NOT_POSITIVE: return "replication factor is not positive (KTA:65-66)";
+    case KAS_FAIL_RF_GT_BROKERS: return "replication factor exceeds available brokers (KTA:67-69)";
+    case KAS_FAIL_HASH_INDEX: return "topic hashCode is Integer.MIN_VALUE: negative index (KAS:190-192)";
+    case KAS_FAIL_RF_MISMATCH: return "partition with unexpected replication factor (KTA:58-60)";
+    case KAS_SKIPPED: return "skipped: an earlier topic of the scenario failed";
+    case KAS_FAIL_BAD_NODES: return "node table not strictly ascending / non-negative, or rack out of range";
+    default: return "unknown status";
+  }
+}
+
+const char* kas_last_error(void) { return g_last_error.c_str(); }
+
+int kas_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int kas_ctx_create(int device, kas_ctx** out_ctx) {
+  if (!out_ctx) return set_error(KAS_E_INVALID_ARG, "out_ctx == NULL");
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(KAS_E_HIP, "no HIP device visible: this library has no CPU path");
+  if (device < 0 || device >= n) return set_error(KAS_E_INVALID_ARG, "device index out of range");
+  KAS_HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  KAS_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(KAS_E_HIP, std::string("device is ") + prop.gcnArchName +
+                                    ", the kernels are built for gfx950 only");
+  kas_ctx* c = new kas_ctx();
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return set_error(KAS_E_HIP, hipGetErrorString(e)); }
+  *out_ctx = c;
+  return KAS_E_OK;
+}
+
+void kas_ctx_destroy(kas_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int kas_ctx_synchronize(kas_ctx* ctx) {
+  if (!ctx) return set_error(KAS_E_INVALID_ARG, "ctx == NULL");
+  KAS_HIP_TRY(hipSetDevice(ctx->device));
+  KAS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return KAS_E_OK;
+}
+
+void kas_plan_destroy(kas_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  (void)hipFree(p->d_scen); (void)hipFree(p->d_topics);
+  (void)hipFree(p->d_node_id); (void)hipFree(p->d_node_rack);
+  (void)hipFree(p->d_accmask_off); (void)hipFree(p->d_accmask);
+  for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
+    if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
+    if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
+  }
+  delete p;
+}
+
+static int upload(void** dst, const void* src, size_t bytes, hipStream_t st) {
+  *dst = nullptr;
+  size_t alloc = bytes > 0 ? bytes : 16;
+  KAS_HIP_TRY(hipMalloc(dst, alloc));
+  if (bytes > 0) KAS_HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+  return KAS_E_OK;
+}
+
+int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan) {
+  if (!ctx || !batch || !out_plan) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  *out_plan = nullptr;
+  KasShape sh;
+  std::string err;
+  int rc = kas_shape_batch(batch, &sh, &err);
+  if (rc != KAS_E_OK) return set_error(rc, err);
+  KAS_HIP_TRY(hipSetDevice(ctx->device));
+
+  kas_plan* p = new kas_plan();
+  memset((void*)p->ev_start, 0, sizeof(p->ev_start));
+  memset((void*)p->ev_stop, 0, sizeof(p->ev_stop));
+  p->ctx = ctx; p->shape = sh;
+  p->Wc = kas_width_class(sh.W);
+  p->lds = kas_lds_layout(sh.n_max, p->Wc, sh.idmap_entries, sh.need_bsearch);
+  p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
+  p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
+  p->d_accmask_off = nullptr; p->d_accmask = nullptr;
+  p->timer_next = 0; p->timer_count = 0;
+  if (p->lds.total > KAS_LDS_LIMIT) {
+    delete p;
+    return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at the instantiated width");
+  }
+  hipStream_t st = ctx->stream;
+#define KAS_PLAN_TRY(call)                                  \
+  do { int rc_ = (call); if (rc_ != KAS_E_OK) { kas_plan_destroy(p); return rc_; } } while (0)
+  KAS_PLAN_TRY(upload((void**)&p->d_scen, batch->scenarios, sizeof(kas_scenario_desc) * (size_t)batch->n_scenarios, st));
+  KAS_PLAN_TRY(upload((void**)&p->d_topics, batch->topics, sizeof(kas_topic_desc) * (size_t)batch->n_topics, st));
+  KAS_PLAN_TRY(upload((void**)&p->d_node_id, batch->node_id, sizeof(int32_t) * (size_t)batch->node_pool_len, st));
+  KAS_PLAN_TRY(upload((void**)&p->d_node_rack, batch->node_rack, sizeof(int32_t) * (size_t)batch->node_pool_len, st));
+  KAS_PLAN_TRY(upload((void**)&p->d_accmask_off, sh.accmask_off.data(), sizeof(int64_t) * sh.accmask_off.size(), st));
+  {
+    hipError_t e = hipMalloc((void**)&p->d_accmask, sizeof(uint64_t) * (size_t)(sh.accmask_words + 1));
+    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "accept-mask scratch: " + std::string(hipGetErrorString(e))); }
+  }
+  for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
+    if (hipEventCreate(&p->ev_start[i]) != hipSuccess || hipEventCreate(&p->ev_stop[i]) != hipSuccess) {
+      kas_plan_destroy(p);
+      return set_error(KAS_E_HIP, "hipEventCreate failed");
+    }
+  }
+  {
+    hipError_t e = hipFuncSetAttribute((const void*)kas_kernel_for(p->Wc),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds.total);
+    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+    e = hipStreamSynchronize(st);   // descriptors are resident before the caller may free its copies
+    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_HIP, hipGetErrorString(e)); }
+  }
+#undef KAS_PLAN_TRY
+  *out_plan = p;
+  return KAS_E_OK;
+}
+
+int64_t kas_plan_algorithmic_bytes(const kas_plan* plan) {
+  return plan ? plan->shape.algorithmic_bytes : -1;
+}
+
+int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
+  if (!p || !t) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  if (p->n_scenarios == 0) return KAS_E_OK;
+  if (!t->out || !t->topic_results || !t->scenario_results || (p->shape.cur_need > 0 && !t->cur) ||
+      (p->shape.aux_need > 0 && !t->aux) || (p->shape.ctx_need > 0 && !t->ctx))
+    return set_error(KAS_E_INVALID_ARG, "a table the descriptors refer to is NULL");
+  KAS_HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : p->ctx->stream;
+  KasLaunch a;
+  a.scen = p->d_scen; a.topics = p->d_topics; a.node_id = p->d_node_id; a.node_rack = p->d_node_rack;
+  a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
+  a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
+  a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off;
+  a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
+  a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
+  const int slot = p->timer_next;
+  KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
+  hipLaunchKernelGGL(kas_kernel_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
+                     (size_t)p->lds.total, st, a);
+  KAS_HIP_TRY(hipGetLastError());
+  KAS_HIP_TRY(hipEventRecord(p->ev_stop[slot], st));
+  p->timer_next = (slot + 1) % KAS_TIMER_SLOTS;
+  if (p->timer_count < KAS_TIMER_SLOTS) p->timer_count += 1;
+  return KAS_E_OK;
+}
+
+int kas_plan_kernel_time_us(kas_plan* p, double* avg_us, int* launches) {
+  if (!p || !avg_us || !launches) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  *avg_us = 0.0; *launches = 0;
+  KAS_HIP_TRY(hipSetDevice(p->ctx->device));
+  double total_ms = 0.0;
+  int n = 0;
+  for (int i = 0; i < p->timer_count; ++i) {
+    int slot = (p->timer_next - 1 - i + 2 * KAS_TIMER_SLOTS) % KAS_TIMER_SLOTS;
+    KAS_HIP_TRY(hipEventSynchronize(p->ev_stop[slot]));
+    float ms = 0.f;
+    KAS_HIP_TRY(hipEventElapsedTime(&ms, p->ev_start[slot], p->ev_stop[slot]));
+    total_ms += ms; ++n;
+  }
+  p->timer_count = 0;
+  *launches = n;
+  *avg_us = n ? total_ms * 1000.0 / n : 0.0;
+  return KAS_E_OK;
+}
+
+int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h) {
+  if (!ctx || !batch || !h) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  kas_plan* plan = nullptr;
+  int rc = kas_plan_create(ctx, batch, &plan);
+  if (rc != KAS_E_OK) return rc;
+  const KasShape& sh = plan->shape;
+  if (h->cur_len < sh.cur_need || h->out_len < sh.out_need || h->aux_len < sh.aux_need ||
+      h->ctx_len < sh.ctx_need) {
+    kas_plan_destroy(plan);
+    return set_error(KAS_E_INVALID_ARG, "a descriptor offset reaches beyond the pool length given in kas_tables");
+  }
+  hipStream_t st = ctx->stream;
+  int32_t *d_cur = nullptr, *d_out = nullptr, *d_aux = nullptr, *d_ctx = nullptr;
+  kas_topic_result* d_tr = nullptr; kas_scenario_result* d_sr = nullptr;
+  kas_tables d;
+  memset(&d, 0, sizeof(d));
+  hipError_t e = hipSuccess;
+  auto H = [&](hipError_t x) { if (e == hipSuccess && x != hipSuccess) e = x; return x == hipSuccess; };
+  H(hipMalloc((void**)&d_cur, sizeof(int32_t) * (size_t)(sh.cur_need + 4)));
+  H(hipMalloc((void**)&d_out, sizeof(int32_t) * (size_t)(sh.out_need + 4)));
+  H(hipMalloc((void**)&d_aux, sizeof(int32_t) * (size_t)(sh.aux_need + 4)));
+  H(hipMalloc((void**)&d_ctx, sizeof(int32_t) * (size_t)(sh.ctx_need + 4)));
+  H(hipMalloc((void**)&d_tr, sizeof(kas_topic_result) * (size_t)(batch->n_topics + 1)));
+  H(hipMalloc((void**)&d_sr, sizeof(kas_scenario_result) * (size_t)(batch->n_scenarios + 1)));
+  if (e == hipSuccess) {
+    if (sh.cur_need) H(hipMemcpyAsync(d_cur, h->cur, sizeof(int32_t) * (size_t)sh.cur_need, hipMemcpyHostToDevice, st));
+    if (sh.aux_need) H(hipMemcpyAsync(d_aux, h->aux, sizeof(int32_t) * (size_t)sh.aux_need, hipMemcpyHostToDevice, st));
+    if (sh.ctx_need) H(hipMemcpyAsync(d_ctx, h->ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyHostToDevice, st));
+  }
+  rc = KAS_E_OK;
+  if (e == hipSuccess) {
+    d.cur = d_cur; d.out = d_out; d.aux = d_aux; d.ctx = d_ctx;
+    d.topic_results = d_tr; d.scenario_results = d_sr;
+    rc = kas_solve_device(plan, &d, st);
+  }
+  if (rc == KAS_E_OK && e == hipSuccess) {
+    if (sh.out_need) H(hipMemcpyAsync(h->out, d_out, sizeof(int32_t) * (size_t)sh.out_need, hipMemcpyDeviceToHost, st));
+    if (sh.ctx_need) H(hipMemcpyAsync(h->ctx, d_ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyDeviceToHost, st));
+    if (batch->n_topics) H(hipMemcpyAsync(h->topic_results, d_tr, sizeof(kas_topic_result) * (size_t)batch->n_topics, hipMemcpyDeviceToHost, st));
+    if (batch->n_scenarios) H(hipMemcpyAsync(h->scenario_results, d_sr, sizeof(kas_scenario_result) * (size_t)batch->n_scenarios, hipMemcpyDeviceToHost, st));
+    H(hipStreamSynchronize(st));
+  }
+  (void)hipFree(d_cur); (void)hipFree(d_out); (void)hipFree(d_aux); (void)hipFree(d_ctx);
+  (void)hipFree(d_tr); (void)hipFree(d_sr);
+  kas_plan_destroy(plan);
+  if (rc != KAS_E_OK) return rc;
+  if (e != hipSuccess) return set_error(KAS_E_HIP, hipGetErrorString(e));
+  return KAS_E_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

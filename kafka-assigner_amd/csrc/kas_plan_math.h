@@ -1,0 +1,155 @@
+// kas_plan_math.h — host-side shape validation, LDS carve-up and launch arguments.
+//
+// Pure C++ (no HIP calls) so that the exact same planning code runs in the product library
+// (kas_abi.cpp) and in the CPU emulation harness under tests/emu/.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "kas_abi.h"
+
+// Kernel arguments: every pointer is a device pointer (host pointer in the emulator).
+struct KasLaunch {
+  const kas_scenario_desc* scen;
+  const kas_topic_desc* topics;
+  const int32_t* node_id;
+  const int32_t* node_rack;
+  const int32_t* cur;
+  int32_t* out;
+  const int32_t* aux;
+  int32_t* ctx;
+  kas_topic_result* topic_results;
+  kas_scenario_result* scenario_results;
+  uint64_t* accmask;            // scratch: accept-mask ballot words, one region per scenario
+  const int64_t* accmask_off;   // [n_scenarios] offset of the region in 64-bit words
+  int32_t n_scenarios;
+  int32_t n_max;                // largest broker count in the batch (LDS array extent)
+  int32_t idmap_entries;        // entries of the direct broker-id -> node-index table
+  int32_t need_bsearch;         // some scenario's id range exceeds idmap_entries
+};
+
+// Byte offsets into the workgroup's dynamic LDS.  Region B (owner) aliases region A (load,
+// rack, live, idmap, ids, ring): A is live during P2-P4, B during P5, and the per-topic setup
+// rebuilds A.  Only the Context counters persist across the topics of a scenario.
+struct KasLds {
+  int32_t off_cnt;     // int32  [n_max * W]   Context counters (KAS:244-302)
+  int32_t off_owner;   // uint32 [n_max]       P5 conflict-round owner keys        (region B)
+  int32_t off_load;    // int32  [n_max]       |Node.assignedPartitions|           (region A)
+  int32_t off_rack;    // int16  [n_max]       dense rack index per node
+  int32_t off_live;    // int16  [n_max]       non-full nodes in processing order
+  int32_t off_idmap;   // int16  [idmap_entries] broker id - min_id -> node index
+  int32_t off_ids;     // int32  [n_max]       sorted ids for binary search (only if needed)
+  int32_t off_ring;    // orphan ring: p[128] int32, meta[128] int32, rack[W][128] int16
+  int32_t total;
+};
+
+#define KAS_RING_CAP 128
+#define KAS_LDS_LIMIT (160 * 1024)
+#define KAS_IDMAP_CAP 16384
+#define KAS_N_LIMIT 32767
+
+KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_t)15); }
+
+KAS_ABI_FN KasLds kas_lds_layout(int32_t n_max, int32_t W, int32_t idmap_entries,
+                                    int32_t need_bsearch) {
+  KasLds L;
+  int64_t n = n_max > 0 ? n_max : 1;
+  int64_t o = 0;
+  L.off_cnt = (int32_t)o;   o = kas_align16(o + 4 * n * W);
+  int64_t base = o;
+  L.off_owner = (int32_t)base;
+  int64_t endB = kas_align16(base + 4 * n);
+  L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n);
+  L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
+  L.off_live = (int32_t)o;  o = kas_align16(o + 2 * n);
+  L.off_idmap = (int32_t)o; o = kas_align16(o + 2 * (int64_t)(idmap_entries > 0 ? idmap_entries : 1));
+  L.off_ids = (int32_t)o;   if (need_bsearch) o = kas_align16(o + 4 * n);
+  L.off_ring = (int32_t)o;  o = kas_align16(o + KAS_RING_CAP * (4 + 4 + 2 * (int64_t)W));
+  L.total = (int32_t)(o > endB ? o : endB);
+  return L;
+}
+
+struct KasShape {
+  int32_t W = 1;                      // register list width: max out_width in the batch
+  int32_t n_max = 0;
+  int32_t idmap_entries = 0;
+  int32_t need_bsearch = 0;
+  std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
+  int64_t accmask_words = 0;
+  int64_t algorithmic_bytes = 0;
+  int64_t cur_need = 0, out_need = 0, aux_need = 0, ctx_need = 0;  // minimum pool lengths
+  KasLds lds{};
+};
+
+// Validate descriptors and derive everything a launch needs.  Returns KAS_E_* and fills err.
+static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::string* err) {
+  auto fail = [&](int code, const std::string& m) { if (err) *err = m; return code; };
+  if (!b || b->n_scenarios < 0 || b->n_topics < 0) return fail(KAS_E_INVALID_ARG, "null/negative batch");
+  if (b->n_scenarios > 0 && (!b->scenarios)) return fail(KAS_E_INVALID_ARG, "scenarios == NULL");
+  if (b->n_topics > 0 && !b->topics) return fail(KAS_E_INVALID_ARG, "topics == NULL");
+  KasShape s;
+  s.accmask_off.assign((size_t)b->n_scenarios, 0);
+  int64_t max_range_fit = 0;
+  for (int32_t i = 0; i < b->n_scenarios; ++i) {
+    const kas_scenario_desc& sd = b->scenarios[i];
+    if (sd.n_nodes < 0 || sd.topic_count < 0 || sd.topic_begin < 0 ||
+        (int64_t)sd.topic_begin + sd.topic_count > b->n_topics)
+      return fail(KAS_E_INVALID_ARG, "scenario " + std::to_string(i) + ": bad topic range / n_nodes");
+    if (sd.n_nodes > KAS_N_LIMIT)
+      return fail(KAS_E_UNSUPPORTED, "scenario " + std::to_string(i) + ": more than 32767 brokers");
+    if (sd.n_nodes > 0) {
+      if (sd.node_off < 0 || sd.node_off + sd.n_nodes > b->node_pool_len || !b->node_id || !b->node_rack)
+        return fail(KAS_E_INVALID_ARG, "scenario " + std::to_string(i) + ": node_off outside the node pool");
+      int64_t lo = b->node_id[sd.node_off], hi = b->node_id[sd.node_off + sd.n_nodes - 1];
+      int64_t range = hi - lo + 1;
+      if (range >= 1 && range <= KAS_IDMAP_CAP) { if (range > max_range_fit) max_range_fit = range; }
+      else s.need_bsearch = 1;      // sparse ids (or unsorted: the kernel reports BAD_NODES)
+    }
+    if (sd.ctx_off >= 0) {
+      if (sd.ctx_width < 1 || sd.ctx_width > KAS_MAX_WIDTH)
+        return fail(KAS_E_INVALID_ARG, "scenario " + std::to_string(i) + ": ctx_width outside [1,8]");
+      int64_t e = sd.ctx_off + (int64_t)sd.n_nodes * sd.ctx_width;
+      if (e > s.ctx_need) s.ctx_need = e;
+      s.algorithmic_bytes += 8ll * sd.n_nodes * sd.ctx_width;
+    }
+    if (sd.n_nodes > s.n_max) s.n_max = sd.n_nodes;
+    s.algorithmic_bytes += 8ll * sd.n_nodes;
+    int64_t words = 0;
+    for (int32_t k = 0; k < sd.topic_count; ++k) {
+      const kas_topic_desc& td = b->topics[sd.topic_begin + k];
+      std::string where = "scenario " + std::to_string(i) + " topic " + std::to_string(k) + ": ";
+      if (td.n_partitions < 0) return fail(KAS_E_INVALID_ARG, where + "negative n_partitions");
+      if (td.cur_width < 0 || td.cur_width > KAS_MAX_WIDTH)
+        return fail(KAS_E_UNSUPPORTED, where + "cur_width outside [0,8]");
+      if (td.out_width < 1 || td.out_width > KAS_MAX_WIDTH || td.out_width < td.cur_width)
+        return fail(KAS_E_UNSUPPORTED, where + "out_width outside [max(1,cur_width),8]");
+      if (td.rf >= 1 && td.rf <= sd.n_nodes && td.rf > td.out_width)
+        return fail(KAS_E_UNSUPPORTED, where + "rf exceeds out_width");
+      if (td.cur_off < 0 || td.out_off < 0) return fail(KAS_E_INVALID_ARG, where + "negative pool offset");
+      if (td.out_width > s.W) s.W = td.out_width;
+      int64_t P = td.n_partitions;
+      int64_t ce = td.cur_off + P * td.cur_width, oe = td.out_off + P * td.out_width;
+      if (ce > s.cur_need) s.cur_need = ce;
+      if (oe > s.out_need) s.out_need = oe;
+      const int64_t aux_offs[3] = {td.cur_len_off, td.in_partitions_off, td.part_id_off};
+      for (int64_t ao : aux_offs) {
+        if (ao < -1) return fail(KAS_E_INVALID_ARG, where + "aux offset < -1");
+        if (ao >= 0 && ao + P > s.aux_need) s.aux_need = ao + P;
+      }
+      int64_t w = (int64_t)td.cur_width * ((P + 63) / 64);
+      if (w > words) words = w;
+      s.algorithmic_bytes += 4ll * P * (td.cur_width + td.out_width);
+    }
+    s.accmask_off[(size_t)i] = s.accmask_words;
+    s.accmask_words += words > 0 ? words : 1;
+  }
+  s.idmap_entries = (int32_t)max_range_fit;
+  s.lds = kas_lds_layout(s.n_max, s.W, s.idmap_entries, s.need_bsearch);
+  if (s.lds.total > KAS_LDS_LIMIT)
+    return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +
+                std::to_string(s.W) + " needs " + std::to_string(s.lds.total) +
+                " B of LDS (limit 163840)");
+  *sh = s;
+  return KAS_E_OK;
+}

@@ -267,6 +267,43 @@ def uniform_batch(cur: np.ndarray, node_id: np.ndarray, node_rack: np.ndarray, r
                      row_ids=[])
 
 
+def node_set_batch(node_ids: Sequence[np.ndarray], node_racks: Sequence[np.ndarray], P: int, W: int,
+                   rf: int, name_hash: int = 3644, shared_cur: bool = False,
+                   cur: Optional[np.ndarray] = None) -> FlatBatch:
+    """Descriptors for S single-topic scenarios whose broker sets differ in size (each scenario
+    has its own node table) over cur tables of one shape [P, W].  `cur` may be None when the
+    table lives only in HBM (bench); offsets assume scenario s at s*P*W (or 0 if shared_cur)."""
+    S = len(node_ids)
+    ow = max(W, rf, 1)
+    scen = np.zeros(S, dtype=abi.SCENARIO_DESC_DTYPE)
+    topics = np.zeros(S, dtype=abi.TOPIC_DESC_DTYPE)
+    lens = np.asarray([len(x) for x in node_ids], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]) if S else np.zeros(0, np.int64)
+    scen["n_nodes"] = lens
+    scen["topic_begin"] = np.arange(S)
+    scen["topic_count"] = 1
+    scen["ctx_width"] = 0
+    scen["node_off"] = offs
+    scen["ctx_off"] = -1
+    topics["name_hash"] = name_hash
+    topics["n_partitions"] = P
+    topics["cur_width"] = W
+    topics["rf"] = rf
+    topics["out_width"] = ow
+    topics["cur_off"] = 0 if shared_cur else np.arange(S, dtype=np.int64) * (P * W)
+    topics["out_off"] = np.arange(S, dtype=np.int64) * (P * ow)
+    topics["cur_len_off"] = -1
+    topics["in_partitions_off"] = -1
+    topics["part_id_off"] = -1
+    return FlatBatch(
+        scen=scen, topics=topics,
+        node_id=np.concatenate(node_ids).astype(np.int32) if S else np.zeros(0, np.int32),
+        node_rack=np.concatenate(node_racks).astype(np.int32) if S else np.zeros(0, np.int32),
+        cur=(np.ascontiguousarray(cur, dtype=np.int32).reshape(-1) if cur is not None
+             else np.zeros(1, np.int32)),
+        aux=np.zeros(0, np.int32), ctx=np.zeros(0, np.int32), out_len=S * P * ow)
+
+
 def unflatten_topic(fb: FlatBatch, out: np.ndarray, topic_index: int) -> Dict[int, List[int]]:
     """Rebuild the reference's return value (TreeMap partition -> preference list, KAS:221-238)
     for one topic: rows that hold no replica at all are not keys of the map."""

@@ -1,0 +1,90 @@
+"""Synthetic cluster scenarios for the BASELINE.json configurations.
+
+G(seed, P, N, R, RF): brokers 0..N-1, broker b on rack b mod R; every partition picks RF distinct
+racks uniformly and one broker uniformly inside each -> a rack-diverse, load-UNbalanced start
+that forces cap evictions in the sticky fill.  Gcyc: cur[p][r] = (p + r) mod N (perfectly
+balanced).  A scenario perturbs the broker set (remove / add / replace) — exactly what
+--broker_hosts_to_remove / --integer_broker_ids do to the solver inputs (KAG:137-151).
+
+numpy versions here (tests, CPU baseline samples); torch_random_assignment() builds the same
+distribution directly in HBM for full-size bench batches.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def random_assignment(seed: int, P: int, N: int, R: int, RF: int) -> np.ndarray:
+    """G(seed, P, N, R, RF) -> int32 [P, RF] of broker ids."""
+    assert RF <= R <= N
+    rng = np.random.default_rng(seed)
+    racks = np.argsort(rng.random((P, R)), axis=1)[:, :RF].astype(np.int64)
+    per_rack = (N - np.arange(R) + R - 1) // R                  # brokers on rack k
+    pick = (rng.random((P, RF)) * per_rack[racks]).astype(np.int64)
+    pick = np.minimum(pick, per_rack[racks] - 1)
+    return (racks + R * pick).astype(np.int32)
+
+
+def cyclic_assignment(P: int, N: int, RF: int, shift: int = 0) -> np.ndarray:
+    """Gcyc: cur[p][r] = (p + shift + r) mod N."""
+    p = np.arange(P, dtype=np.int64)[:, None]
+    r = np.arange(RF, dtype=np.int64)[None, :]
+    return ((p + shift + r) % N).astype(np.int32)
+
+
+@dataclass
+class BrokerSet:
+    node_id: np.ndarray      # int32 [N'] ascending
+    node_rack: np.ndarray    # int32 [N'] dense rack index
+
+
+def perturb_brokers(N: int, R: int, remove: Sequence[int] = (), add: int = 0,
+                    rack_aware: bool = True) -> BrokerSet:
+    """Brokers 0..N-1 minus `remove`, plus `add` new brokers N..N+add-1 (rack id mod R).
+    rack_aware=False is --disable_rack_awareness: every broker is its own rack (KAG:241,
+    KAS:82-86)."""
+    ids = np.setdiff1d(np.arange(N + add, dtype=np.int32), np.asarray(list(remove), dtype=np.int32))
+    racks = (ids % R).astype(np.int32) if rack_aware else np.arange(ids.shape[0], dtype=np.int32)
+    return BrokerSet(ids.astype(np.int32), racks)
+
+
+ACTIONS = ("remove1", "remove_k", "add_k", "replace1")
+
+
+def scenario_action(seed: int, s: int, N: int, R: int, actions: Sequence[str] = ACTIONS,
+                    max_remove: int = 5, max_add: int = 50) -> Tuple[str, BrokerSet]:
+    """Per-scenario perturbation for config C3: drawn from {remove 1, remove k<=5, add k<=50,
+    replace 1}.  Every scenario of a batch keeps N' == N (+/- is folded into padding-free
+    per-scenario node tables), so N' varies per scenario."""
+    rng = np.random.default_rng([seed, s, 0xB0])
+    act = actions[int(rng.integers(len(actions)))]
+    if act == "remove1":
+        return act, perturb_brokers(N, R, remove=[int(rng.integers(N))])
+    if act == "remove_k":
+        k = int(rng.integers(2, max_remove + 1))
+        return act, perturb_brokers(N, R, remove=rng.choice(N, size=k, replace=False).tolist())
+    if act == "add_k":
+        return act, perturb_brokers(N, R, add=int(rng.integers(1, max_add + 1)))
+    if act == "replace1":
+        return act, perturb_brokers(N, R, remove=[int(rng.integers(N))], add=1)
+    raise ValueError(act)
+
+
+def torch_random_assignment(gen, S: int, P: int, N: int, R: int, RF: int, device):
+    """G for S scenarios at once as an int32 [S, P, RF] torch tensor on `device`."""
+    import torch
+    out = torch.empty((S, P, RF), dtype=torch.int32, device=device)
+    per_rack = ((N - torch.arange(R, device=device) + R - 1) // R).to(torch.float32)
+    chunk = max(1, min(S, (1 << 28) // max(1, P * R)))          # bound the temporary to ~1 GiB
+    for s0 in range(0, S, chunk):
+        s1 = min(S, s0 + chunk)
+        keys = torch.rand((s1 - s0, P, R), device=device, generator=gen)
+        racks = keys.topk(RF, dim=2).indices                   # RF distinct racks, uniform
+        u = torch.rand((s1 - s0, P, RF), device=device, generator=gen)
+        cnt = per_rack[racks]
+        pick = torch.minimum((u * cnt).floor(), cnt - 1).to(torch.int64)
+        out[s0:s1] = (racks + R * pick).to(torch.int32)
+    return out

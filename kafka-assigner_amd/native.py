@@ -1,0 +1,160 @@
+"""ctypes binding of the C ABI (include/kas_abi.h) implemented by csrc/libkas_hip.so.
+
+There is no fallback: if the library has not been built, or no gfx950 device is visible, every
+solve entry point raises.  The library is looked up in-tree only (kafka-assigner_amd/csrc/).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+from .flatten import FlatBatch, HostOutputs, batch_desc, host_tables
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libkas_hip.so")
+
+# every symbol include/kas_abi.h declares
+SYMBOLS = [
+    "kas_abi_version", "kas_strerror", "kas_status_string", "kas_last_error", "kas_device_count",
+    "kas_ctx_create", "kas_ctx_destroy", "kas_ctx_synchronize", "kas_plan_create",
+    "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
+    "kas_plan_kernel_time_us",
+]
+
+_LIB = None
+
+
+class KasError(RuntimeError):
+    def __init__(self, code: int, detail: str):
+        super().__init__(f"kas error {code}: {detail}")
+        self.code = code
+        self.detail = detail
+
+
+def load():
+    """dlopen csrc/libkas_hip.so and declare prototypes.  Raises if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m kafka_assigner_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.kas_abi_version.restype = C.c_int
+    L.kas_strerror.restype = C.c_char_p; L.kas_strerror.argtypes = [C.c_int]
+    L.kas_status_string.restype = C.c_char_p; L.kas_status_string.argtypes = [C.c_int]
+    L.kas_last_error.restype = C.c_char_p
+    L.kas_device_count.restype = C.c_int
+    L.kas_ctx_create.restype = C.c_int; L.kas_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.kas_ctx_destroy.restype = None; L.kas_ctx_destroy.argtypes = [C.c_void_p]
+    L.kas_ctx_synchronize.restype = C.c_int; L.kas_ctx_synchronize.argtypes = [C.c_void_p]
+    L.kas_plan_create.restype = C.c_int
+    L.kas_plan_create.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(C.c_void_p)]
+    L.kas_plan_destroy.restype = None; L.kas_plan_destroy.argtypes = [C.c_void_p]
+    L.kas_plan_algorithmic_bytes.restype = C.c_int64; L.kas_plan_algorithmic_bytes.argtypes = [C.c_void_p]
+    L.kas_solve_device.restype = C.c_int
+    L.kas_solve_device.argtypes = [C.c_void_p, C.POINTER(abi.Tables), C.c_void_p]
+    L.kas_solve_host.restype = C.c_int
+    L.kas_solve_host.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
+    L.kas_plan_kernel_time_us.restype = C.c_int
+    L.kas_plan_kernel_time_us.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    if L.kas_abi_version() != abi.KAS_ABI_VERSION:
+        raise ImportError("libkas_hip.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        L = load()
+        raise KasError(rc, (L.kas_last_error() or b"").decode() or L.kas_strerror(rc).decode())
+
+
+class DeviceContext:
+    """kas_ctx: one HIP device + stream."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        _check(self._lib.kas_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):
+        _check(self._lib.kas_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.kas_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """kas_plan: validated batch shape with descriptors and node tables resident in HBM."""
+
+    def __init__(self, ctx: DeviceContext, fb: FlatBatch):
+        self._lib = load()
+        self._ctx = ctx
+        self._fb = fb                      # keeps the host descriptor arrays alive
+        bd = batch_desc(fb)
+        self._h = C.c_void_p()
+        _check(self._lib.kas_plan_create(ctx._h, C.byref(bd), C.byref(self._h)))
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return int(self._lib.kas_plan_algorithmic_bytes(self._h))
+
+    def solve_device(self, cur: int, out: int, topic_results: int, scenario_results: int,
+                     aux: int = 0, ctx: int = 0, stream: int = 0):
+        """Enqueue one solve; every argument is a raw device pointer (int)."""
+        t = abi.Tables()
+        t.cur = cur or None; t.out = out or None; t.aux = aux or None; t.ctx = ctx or None
+        t.topic_results = topic_results or None; t.scenario_results = scenario_results or None
+        _check(self._lib.kas_solve_device(self._h, C.byref(t), C.c_void_p(stream) if stream else None))
+
+    def kernel_time_us(self):
+        avg = C.c_double(); n = C.c_int()
+        _check(self._lib.kas_plan_kernel_time_us(self._h, C.byref(avg), C.byref(n)))
+        return avg.value, n.value
+
+    def close(self):
+        if self._h:
+            self._lib.kas_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_CTX: Optional[DeviceContext] = None
+
+
+def default_context() -> DeviceContext:
+    global _DEFAULT_CTX
+    if _DEFAULT_CTX is None:
+        _DEFAULT_CTX = DeviceContext(int(os.environ.get("LOCAL_RANK", "0")) if
+                                     load().kas_device_count() > 1 else 0)
+    return _DEFAULT_CTX
+
+
+def solve_host(fb: FlatBatch, ctx: Optional[DeviceContext] = None) -> HostOutputs:
+    """kas_solve_host: copy in, solve on the GPU, copy out (blocking)."""
+    L = load()
+    ctx = ctx or default_context()
+    bd = batch_desc(fb)
+    t, ho = host_tables(fb)
+    _check(L.kas_solve_host(ctx._h, C.byref(bd), C.byref(t)))
+    return ho

@@ -1,0 +1,49 @@
+"""Loader for the CPU-fiber emulation of the kernel source (tests/emu).  Test infrastructure."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from kafka_assigner_amd import abi
+from kafka_assigner_amd.flatten import FlatBatch, HostOutputs, batch_desc, host_tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+CSRC = os.path.join(ROOT, "kafka-assigner_amd", "csrc")
+_LIB = None
+
+
+def build_emu() -> str:
+    so = os.path.join(EMU_DIR, "libkas_emu.so")
+    deps = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "kas_wave.h"),
+            os.path.join(CSRC, "kas_solver_body.h"), os.path.join(CSRC, "kas_plan_math.h"),
+            os.path.join(ROOT, "include", "kas_abi.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call([
+            "g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+            "-Wno-unused-parameter", "-Wno-unknown-pragmas",
+            "-I" + os.path.join(ROOT, "tests"), "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+            "-o", so, deps[0]])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build_emu())
+        L.kas_emu_solve_batch.restype = C.c_int
+        L.kas_emu_solve_batch.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
+                                          C.c_char_p, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def emu_solve(fb: FlatBatch) -> HostOutputs:
+    bd = batch_desc(fb)
+    t, ho = host_tables(fb)
+    err = C.create_string_buffer(512)
+    rc = lib().kas_emu_solve_batch(C.byref(bd), C.byref(t), err, 512)
+    if rc != 0:
+        raise RuntimeError(f"kas_emu_solve_batch rc={rc}: {err.value.decode()}")
+    return ho

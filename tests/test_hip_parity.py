@@ -1,0 +1,149 @@
+"""The parity tests proper: the HIP path, called through the C ABI on a real MI355X, must be
+bit-identical to the oracle — statuses, failing partition ids, every partition -> broker list,
+movement counts, digests and Context counters.  (-m gpu; the driver runs these on the GPU box.)"""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, seed, settings
+
+from kafka_assigner_amd import abi, native
+from kafka_assigner_amd import generator as G
+from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
+from oracle_lib import oracle_solve
+from parity_util import assert_same_outputs
+from test_emu_parity import _batch
+from test_oracle_vs_literal import scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_is_gfx950_and_library_loaded():
+    import torch
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    assert native.load().kas_device_count() >= 1
+    native.default_context()
+
+
+@seed(20260921)
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(scenarios())
+def test_hip_equals_oracle_small_odd_inputs(sc):
+    brokers, racks, topics = sc
+    fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=True,
+                           topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip")
+
+
+@pytest.mark.parametrize("P,N,R,RF,actions", [
+    (1000, 40, 8, 3, G.ACTIONS),
+    (3000, 100, 10, 3, ("remove1",)),
+    (2048, 64, 8, 2, ("add_k",)),
+    (777, 40, 10, 5, G.ACTIONS),
+    (640, 24, 8, 4, ("replace1", "remove1")),
+])
+def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
+    fb = _batch(1234, 6, P, N, R, RF, actions)
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip")
+
+
+def test_hip_rack_awareness_disabled_cyclic_and_sparse_ids():
+    fb = _batch(99, 4, 1500, 50, 10, 3, G.ACTIONS, rack_aware=False)
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip norack")
+    fb = _batch(7, 4, 1200, 60, 6, 3, ("add_k", "remove1"), cyclic=True)
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip cyclic")
+    cur = G.random_assignment(5, 500, 20, 5, 3).astype(np.int64) * 100003 + 7
+    ids = (np.arange(20, dtype=np.int64) * 100003 + 7).astype(np.int32)[None, :]
+    racks = (np.arange(20) % 5).astype(np.int32)[None, :]
+    fb = uniform_batch(cur.astype(np.int32)[None], ids[:, :19], racks[:, :19], 3)
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip sparse")
+
+
+def test_config2_single_scenario_10k_partitions_decommission_one():
+    """BASELINE.json config 2: 10k partitions x 100 brokers x 10 racks, RF 3, remove 1 broker."""
+    for seed_ in (0, 1, 2, 3):
+        cur = G.random_assignment(seed_, 10000, 100, 10, 3)
+        bs = G.perturb_brokers(100, 10, remove=[seed_ % 100])
+        fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], 3)
+        assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), f"C2 seed {seed_}")
+
+
+def test_config3_shape_full_size_scenarios():
+    """BASELINE.json config 3 shape (100k partitions x 1k brokers x 20 racks, RF 3): a handful
+    of full-size scenarios list-compared against the oracle, every action kind."""
+    fb = _batch(2024, 8, 100000, 1000, 20, 3, G.ACTIONS)
+    want = oracle_solve(fb)
+    got = native.solve_host(fb)
+    assert_same_outputs(fb, want, got, "C3")
+    assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 4
+
+
+def test_config5_shape_rf5_rack_on_and_off_scaled():
+    """BASELINE.json config 5 shape scaled to one GPU test: RF 5, 40 racks, mixed add+remove
+    broker set, rack awareness on and off (--disable_rack_awareness)."""
+    P, N, R, RF = 200000, 1000, 40, 5
+    cur = G.random_assignment(7, P, N, R, RF)
+    for rack_aware in (True, False):
+        bs = G.perturb_brokers(N, R, remove=list(range(0, N, 50)), add=40, rack_aware=rack_aware)
+        fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], RF)
+        assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), f"C5 rack_aware={rack_aware}")
+
+
+def test_device_resident_tables_and_what_if_shared_cur():
+    """kas_solve_device with torch-owned HBM tables, and the what-if layout: many broker-set
+    variants over ONE shared current assignment (SURVEY.md 8d, C4 'shared base cur')."""
+    import torch
+    P, N, R, RF, S = 20000, 200, 10, 3, 16
+    cur = G.random_assignment(11, P, N, R, RF)
+    sets = [G.scenario_action(5, s, N, R, max_add=10)[1] for s in range(S)]
+    nmax = max(b.node_id.shape[0] for b in sets)
+    # per-scenario node tables of different length: build descriptors by hand
+    fb = _batch(11, S, P, N, R, RF, G.ACTIONS)          # shapes/descriptors
+    fb.cur = cur.reshape(-1).copy()                      # one shared table ...
+    fb.topics["cur_off"] = 0                             # ... read by every scenario
+    want = oracle_solve(fb)
+    ctx = native.default_context()
+    plan = native.Plan(ctx, fb)
+    dev = torch.device("cuda", ctx.device)
+    d_cur = torch.from_numpy(fb.cur).to(dev)
+    d_out = torch.full((fb.out_len,), -7, dtype=torch.int32, device=dev)
+    d_tr = torch.zeros(fb.n_topics * 16, dtype=torch.uint8, device=dev)
+    d_sr = torch.zeros(fb.n_scenarios * 32, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
+                      stream=st.cuda_stream)
+    st.synchronize()
+    out = d_out.cpu().numpy()
+    tr = d_tr.cpu().numpy().view(abi.TOPIC_RESULT_DTYPE)
+    sr = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
+    np.testing.assert_array_equal(out, want.out[:fb.out_len])
+    for f in ("status", "fail_partition", "moved_replicas", "moved_partitions"):
+        np.testing.assert_array_equal(tr[f], want.topic_results[f])
+    np.testing.assert_array_equal(sr["digest"], want.scenario_results["digest"])
+    avg_us, n = plan.kernel_time_us()
+    assert n == 1 and avg_us > 0
+    assert plan.algorithmic_bytes == fb.algorithmic_bytes()
+    # idempotence: solving the solved assignment again moves nothing on unchanged broker sets
+    plan.close()
+
+
+def test_idempotent_on_own_output():
+    """Size-independent property: feeding a successful result back in as the current
+    assignment (same brokers) moves no replica."""
+    P, N, R, RF = 50000, 500, 20, 3
+    cur = G.random_assignment(3, P, N, R, RF)
+    bs = G.perturb_brokers(N, R, remove=[17])
+    fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], RF)
+    first = native.solve_host(fb)
+    assert first.scenario_results["status"][0] == abi.KAS_OK
+    fb2 = uniform_batch(first.out[:P * RF].reshape(1, P, RF), bs.node_id[None], bs.node_rack[None], RF)
+    second = native.solve_host(fb2)
+    assert second.scenario_results["status"][0] == abi.KAS_OK
+    assert second.scenario_results["moved_replicas"][0] == 0
+    assert second.scenario_results["moved_partitions"][0] == 0
+    # and the invariants of KafkaTopicAssignerTest.java:159-187 at full size
+    new = second.out[:P * RF].reshape(P, RF)
+    assert (np.sort(new, axis=1)[:, 1:] != np.sort(new, axis=1)[:, :-1]).all()   # no broker twice
+    loads = np.bincount(new.reshape(-1), minlength=N)
+    assert loads.max() <= -(-P * RF // bs.node_id.shape[0])                       # <= cap
+    racks = new % R
+    assert (np.sort(racks, axis=1)[:, 1:] != np.sort(racks, axis=1)[:, :-1]).all()  # distinct racks
