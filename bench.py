@@ -48,6 +48,7 @@ def main() -> int:
     ap.add_argument("--check", type=int, default=8, help="scenarios list-compared against the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stats", default="", help="write the per-phase device counters (JSON) here")
     args = ap.parse_args()
 
     import torch
@@ -84,7 +85,11 @@ def main() -> int:
     d_tr = torch.zeros(S * 16, dtype=torch.uint8, device=dev)
     d_sr = torch.zeros(S * 32, dtype=torch.uint8, device=dev)
     d_all = torch.zeros(world * S * 32, dtype=torch.uint8, device=dev) if world > 1 else d_sr
-    stream = torch.cuda.current_stream(dev)
+    # a dedicated HIP stream shared by the solver launches and the RCCL all-gather (handle 0,
+    # torch's default stream, would select the library's own stream instead)
+    stream = torch.cuda.Stream(dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))
+    torch.cuda.set_stream(stream)
 
     def step():
         plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
@@ -112,6 +117,14 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_us, kern_n = plan.kernel_time_us()
+    if args.stats and rank == 0:
+        st = plan.stats().astype(np.float64)
+        names = ["setup_us", "p2_us", "p3p4_us", "p5_us", "p4_windows", "p4_steps", "p5_rounds", "p2_overflow_tiles"]
+        scale = [0.01, 0.01, 0.01, 0.01, 1, 1, 1, 1]
+        summary = {n: {"mean": float(st[:, i].mean() * scale[i]), "max": float(st[:, i].max() * scale[i]),
+                       "min": float(st[:, i].min() * scale[i])} for i, n in enumerate(names)}
+        summary["kernel_avg_us"] = kern_us
+        json.dump(summary, open(args.stats, "w"), indent=1)
 
     # ---- results of this rank -------------------------------------------------------------------
     sr = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)

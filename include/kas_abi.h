@@ -211,6 +211,14 @@ int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* 
  * error, and *launches = 0 when nothing was recorded. */
 int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
 
+/* Per-scenario device counters of the plan's most recent solve (after it completed):
+ * out[s*8 + 0..3] = time spent in setup / P2 sticky fill / P3+P4 orphans / P5 preference order,
+ * in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
+ * [6] P5 conflict rounds, [7] P2 tiles that needed overflow ranking.  n = capacity of out in
+ * int64 elements (>= 8 * n_scenarios).  Blocks until the plan's last launch has finished. */
+#define KAS_STATS_PER_SCENARIO 8
+int kas_plan_stats(kas_plan* plan, int64_t* out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,8 @@ struct kas_plan {
   int32_t* d_node_rack;
   int64_t* d_accmask_off;
   uint64_t* d_accmask;
+  int64_t* d_stats;
+  hipStream_t last_stream;
   // kernel timing: event pairs recorded around every launch on the launch stream
   hipEvent_t ev_start[KAS_TIMER_SLOTS], ev_stop[KAS_TIMER_SLOTS];
   int timer_next, timer_count;
@@ -166,7 +168,7 @@ void kas_plan_destroy(kas_plan* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   (void)hipFree(p->d_scen); (void)hipFree(p->d_topics);
   (void)hipFree(p->d_node_id); (void)hipFree(p->d_node_rack);
-  (void)hipFree(p->d_accmask_off); (void)hipFree(p->d_accmask);
+  (void)hipFree(p->d_accmask_off); (void)hipFree(p->d_accmask); (void)hipFree(p->d_stats);
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
     if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
@@ -199,7 +201,7 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   p->lds = kas_lds_layout(sh.n_max, p->Wc, sh.idmap_entries, sh.need_bsearch);
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
-  p->d_accmask_off = nullptr; p->d_accmask = nullptr;
+  p->d_accmask_off = nullptr; p->d_accmask = nullptr; p->d_stats = nullptr; p->last_stream = ctx->stream;
   p->timer_next = 0; p->timer_count = 0;
   if (p->lds.total > KAS_LDS_LIMIT) {
     delete p;
@@ -216,6 +218,12 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   {
     hipError_t e = hipMalloc((void**)&p->d_accmask, sizeof(uint64_t) * (size_t)(sh.accmask_words + 1));
     if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "accept-mask scratch: " + std::string(hipGetErrorString(e))); }
+  }
+  {
+    size_t sb = sizeof(int64_t) * KAS_STATS_PER_SCENARIO * (size_t)(batch->n_scenarios + 1);
+    hipError_t e = hipMalloc((void**)&p->d_stats, sb);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_stats, 0, sb, st);
+    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "stats buffer: " + std::string(hipGetErrorString(e))); }
   }
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (hipEventCreate(&p->ev_start[i]) != hipSuccess || hipEventCreate(&p->ev_stop[i]) != hipSuccess) {
@@ -251,7 +259,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.scen = p->d_scen; a.topics = p->d_topics; a.node_id = p->d_node_id; a.node_rack = p->d_node_rack;
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
-  a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off;
+  a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off; a.stats = p->d_stats;
+  p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
   const int slot = p->timer_next;
@@ -281,6 +290,16 @@ int kas_plan_kernel_time_us(kas_plan* p, double* avg_us, int* launches) {
   p->timer_count = 0;
   *launches = n;
   *avg_us = n ? total_ms * 1000.0 / n : 0.0;
+  return KAS_E_OK;
+}
+
+int kas_plan_stats(kas_plan* p, int64_t* out, int64_t n) {
+  if (!p || !out) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  const int64_t need = (int64_t)KAS_STATS_PER_SCENARIO * p->n_scenarios;
+  if (n < need) return set_error(KAS_E_INVALID_ARG, "stats buffer too small");
+  KAS_HIP_TRY(hipSetDevice(p->ctx->device));
+  KAS_HIP_TRY(hipStreamSynchronize(p->last_stream));
+  if (need > 0) KAS_HIP_TRY(hipMemcpy(out, p->d_stats, sizeof(int64_t) * (size_t)need, hipMemcpyDeviceToHost));
   return KAS_E_OK;
 }
 

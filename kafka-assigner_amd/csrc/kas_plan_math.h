@@ -23,6 +23,7 @@ struct KasLaunch {
   kas_scenario_result* scenario_results;
   uint64_t* accmask;            // scratch: accept-mask ballot words, one region per scenario
   const int64_t* accmask_off;   // [n_scenarios] offset of the region in 64-bit words
+  int64_t* stats;               // [n_scenarios][KAS_STATS_PER_SCENARIO] device counters, or NULL
   int32_t n_scenarios;
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
   int32_t idmap_entries;        // entries of the direct broker-id -> node-index table

@@ -118,7 +118,7 @@ KAS_DEV void put(int32_t (&a)[W], int32_t i, int32_t v) {
 // ---------------------------------------------------------------------------------------------
 template <int W>
 KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t live_count,
-                          int32_t& head, int32_t* out, int32_t ow) {
+                          int32_t& head, int32_t* out, int32_t ow, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   const bool mine = lane < count;
   const int32_t p = mine ? L.ring_p[lane] : 0;
@@ -132,9 +132,11 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
 
   int32_t fail_lane = -1;
   int32_t j = head;
+  st[4] += 1;
   for (;;) {
     uint64_t pend = kasw::ballot(need > 0);
     if (pend == 0) break;
+    st[5] += 1;
     if (j >= live_count) { fail_lane = kasw::first_lane(pend); break; }
     const int32_t n = (int32_t)L.live[j];
     const int32_t slots = cap - L.load[n];
@@ -171,7 +173,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
 template <int W>
 KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, uint32_t topic_k,
                                  const LdsView& L, const NodeMap& nm, const int32_t* g_node_id,
-                                 const int32_t* g_node_rack, uint64_t* accmask) {
+                                 const int32_t* g_node_rack, uint64_t* accmask, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   const uint64_t lt = kasw::lanemask_lt();
   const int32_t N = nm.n;
@@ -191,6 +193,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
   res.status = KAS_OK; res.fail_partition = -1;
   res.moved_replicas = 0; res.moved_partitions = 0; res.digest = 0;
 
+  int64_t tmark = kasw::clock_ticks();
   // ---- P0: capacity (KAS:45, 65-71) over |partitions| ---------------------------------------
   int32_t n_in = P;
   if (inp_arr) {
@@ -214,6 +217,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
   }
   kasw::sync();
 
+  { const int64_t now = kasw::clock_ticks(); st[0] += now - tmark; tmark = now; }
   // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
   for (int32_t r = 0; r < cw; ++r) {
     for (int32_t tile = 0; tile < nt; ++tile) {
@@ -242,6 +246,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
       bool accepted = took;
       uint64_t todo = kasw::ballot(took && L.load[n] > cap);
       if (todo != 0) {
+        st[7] += 1;
         // some node overflowed inside this tile: keep its first (cap - load_before) lanes
         while (todo != 0) {
           const int leader = kasw::first_lane(todo);
@@ -262,6 +267,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
     kasw::sync();   // this sweep's mask words are visible to the next sweep's loads
   }
 
+  { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
   // ---- KAS:168: getNodeProcessingOrder(topic, all nodes); runs even with zero orphans -------
   const int32_t idxN = java_abs_mod(hash, N);
   if (idxN < 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }
@@ -343,7 +349,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
     ring_count += kasw::popc(om);
     kasw::sync();
     while (ring_count >= 64 && fail_row < 0) {
-      const int32_t fl = p4_window<W>(L, 64, cap, live_count, head, out, ow);
+      const int32_t fl = p4_window<W>(L, 64, cap, live_count, head, out, ow, st);
       if (fl >= 0) { fail_row = L.ring_p[fl]; break; }
       // shift the ring down by one window
       const int32_t rest = ring_count - 64;
@@ -364,9 +370,10 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
     }
   }
   if (fail_row < 0 && ring_count > 0) {
-    const int32_t fl = p4_window<W>(L, ring_count, cap, live_count, head, out, ow);
+    const int32_t fl = p4_window<W>(L, ring_count, cap, live_count, head, out, ow, st);
     if (fl >= 0) fail_row = L.ring_p[fl];
   }
+  { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
   if (fail_row >= 0) {                                       // KAS:183-184
     res.status = KAS_FAIL_UNASSIGNABLE;
     res.fail_partition = pid_arr ? pid_arr[fail_row] : fail_row;
@@ -421,6 +428,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
     for (;;) {
       if (kasw::ballot(pending) == 0) break;
       epoch += 1;
+      st[6] += 1;
       const uint32_t key = (epoch << 6) | (uint32_t)(63 - lane);
       if (pending) {
 #pragma unroll
@@ -486,6 +494,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
       }
     }
   }
+  { const int64_t now = kasw::clock_ticks(); st[3] += now - tmark; tmark = now; }
   if (hash_fail) { res.status = KAS_FAIL_HASH_INDEX; return res; }
   res.moved_replicas = kasw::wave_sum(moved_r);
   res.moved_partitions = kasw::wave_sum(moved_p);
@@ -520,6 +529,8 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
   int32_t* g_ctx = has_ctx ? a.ctx + sd.ctx_off : nullptr;
   const int32_t ctxw = sd.ctx_width;
 
+  int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t t_begin = kasw::clock_ticks();
   // node table checks (strictly ascending, non-negative ids; racks in int16 range) and the
   // Context counters (KAS:360-369) into LDS
   bool bad = false;
@@ -543,6 +554,7 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
   }
   kasw::sync();
 
+  st[0] += kasw::clock_ticks() - t_begin;
   uint64_t* accmask = a.accmask + a.accmask_off[s];
   int32_t scen_status = KAS_OK, fail_topic = -1, fail_part = -1;
   int32_t moved_r = 0, moved_p = 0;
@@ -556,7 +568,7 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = solve_topic<W>(a, td, (uint32_t)k, L, nm, g_node_id, g_node_rack, accmask);
+    else o = solve_topic<W>(a, td, (uint32_t)k, L, nm, g_node_id, g_node_rack, accmask, st);
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding
       int32_t* out = a.out + td.out_off;
@@ -588,6 +600,10 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     sr.moved_replicas = moved_r; sr.moved_partitions = moved_p; sr.reserved = 0;
     sr.digest = dsum;
     a.scenario_results[s] = sr;
+    if (a.stats) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a.stats[(int64_t)s * 8 + i] = st[i];
+    }
   }
 }
 

@@ -55,6 +55,9 @@ KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// constant 100 MHz device clock (s_memrealtime): 10 ns ticks
+KAS_DEV int64_t clock_ticks() { return (int64_t)wall_clock64(); }
+
 KAS_DEV int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

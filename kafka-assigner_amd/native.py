@@ -22,7 +22,7 @@ SYMBOLS = [
     "kas_abi_version", "kas_strerror", "kas_status_string", "kas_last_error", "kas_device_count",
     "kas_ctx_create", "kas_ctx_destroy", "kas_ctx_synchronize", "kas_plan_create",
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
-    "kas_plan_kernel_time_us",
+    "kas_plan_kernel_time_us", "kas_plan_stats",
 ]
 
 _LIB = None
@@ -44,6 +44,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m kafka_assigner_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 with the same SONAMEs as
+    # /opt/rocm's; whichever is loaded first serves the whole process, and mixing them (ours
+    # first, torch second) leaves HIP without devices.  Torch owns device memory and streams in
+    # this project, so its runtime must be the one: import it before the dlopen.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.kas_abi_version.restype = C.c_int
     L.kas_strerror.restype = C.c_char_p; L.kas_strerror.argtypes = [C.c_int]
@@ -63,6 +71,8 @@ def load():
     L.kas_solve_host.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
     L.kas_plan_kernel_time_us.restype = C.c_int
     L.kas_plan_kernel_time_us.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.kas_plan_stats.restype = C.c_int
+    L.kas_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64]
     if L.kas_abi_version() != abi.KAS_ABI_VERSION:
         raise ImportError("libkas_hip.so ABI version mismatch")
     _LIB = L
@@ -121,6 +131,15 @@ class Plan:
         t.cur = cur or None; t.out = out or None; t.aux = aux or None; t.ctx = ctx or None
         t.topic_results = topic_results or None; t.scenario_results = scenario_results or None
         _check(self._lib.kas_solve_device(self._h, C.byref(t), C.c_void_p(stream) if stream else None))
+
+    def stats(self) -> np.ndarray:
+        """Per-scenario device counters of the last solve: int64 [S, 8] =
+        (setup, P2, P3+P4, P5 time in 10 ns ticks; P4 windows, P4 node steps, P5 rounds,
+        P2 overflow tiles)."""
+        n = self._fb.n_scenarios
+        a = np.zeros((n, 8), dtype=np.int64)
+        _check(self._lib.kas_plan_stats(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size))
+        return a
 
     def kernel_time_us(self):
         avg = C.c_double(); n = C.c_int()

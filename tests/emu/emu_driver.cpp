@@ -88,7 +88,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, char* errb
   a.scen = b->scenarios; a.topics = b->topics; a.node_id = b->node_id; a.node_rack = b->node_rack;
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
-  a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data();
+  a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data(); a.stats = nullptr;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch;
   for (int32_t s = 0; s < b->n_scenarios; ++s) {

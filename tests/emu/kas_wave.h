@@ -75,6 +75,8 @@ KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (
 KAS_DEV uint64_t load_shared_u64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
 KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
 
+KAS_DEV int64_t clock_ticks() { return 0; }
+
 KAS_DEV int wave_sum(int v) {
   g_emu.slot[lane()] = (uint64_t)(int64_t)v;
   rendezvous(K_SUM);

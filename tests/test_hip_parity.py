@@ -94,9 +94,6 @@ def test_device_resident_tables_and_what_if_shared_cur():
     import torch
     P, N, R, RF, S = 20000, 200, 10, 3, 16
     cur = G.random_assignment(11, P, N, R, RF)
-    sets = [G.scenario_action(5, s, N, R, max_add=10)[1] for s in range(S)]
-    nmax = max(b.node_id.shape[0] for b in sets)
-    # per-scenario node tables of different length: build descriptors by hand
     fb = _batch(11, S, P, N, R, RF, G.ACTIONS)          # shapes/descriptors
     fb.cur = cur.reshape(-1).copy()                      # one shared table ...
     fb.topics["cur_off"] = 0                             # ... read by every scenario
@@ -108,7 +105,10 @@ def test_device_resident_tables_and_what_if_shared_cur():
     d_out = torch.full((fb.out_len,), -7, dtype=torch.int32, device=dev)
     d_tr = torch.zeros(fb.n_topics * 16, dtype=torch.uint8, device=dev)
     d_sr = torch.zeros(fb.n_scenarios * 32, dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream(dev)
+    # a real (non-default) stream: handle 0 would mean "the context's own stream"
+    st = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    assert st.cuda_stream != 0
     plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
                       stream=st.cuda_stream)
     st.synchronize()
@@ -122,7 +122,8 @@ def test_device_resident_tables_and_what_if_shared_cur():
     avg_us, n = plan.kernel_time_us()
     assert n == 1 and avg_us > 0
     assert plan.algorithmic_bytes == fb.algorithmic_bytes()
-    # idempotence: solving the solved assignment again moves nothing on unchanged broker sets
+    stats = plan.stats()
+    assert stats.shape == (S, 8) and (stats[:, 1] > 0).all()
     plan.close()
 
 
