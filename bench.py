@@ -48,6 +48,9 @@ def main() -> int:
     ap.add_argument("--check", type=int, default=8, help="scenarios list-compared against the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight: steps are issued round-robin on this many HIP streams, "
+                         "each with its own plan scratch and output tables")
     ap.add_argument("--stats", default="", help="write the per-phase device counters (JSON) here")
     args = ap.parse_args()
 
@@ -80,22 +83,33 @@ def main() -> int:
         actions.append(act); ids.append(bs.node_id); racks.append(bs.node_rack)
     fb = node_set_batch(ids, racks, P, RF, RF)
     ctx = native.DeviceContext(local_rank)
-    plan = native.Plan(ctx, fb)
-    d_out = torch.empty(fb.out_len, dtype=torch.int32, device=dev)
-    d_tr = torch.zeros(S * 16, dtype=torch.uint8, device=dev)
-    d_sr = torch.zeros(S * 32, dtype=torch.uint8, device=dev)
-    d_all = torch.zeros(world * S * 32, dtype=torch.uint8, device=dev) if world > 1 else d_sr
-    # a dedicated HIP stream shared by the solver launches and the RCCL all-gather (handle 0,
-    # torch's default stream, would select the library's own stream instead)
-    stream = torch.cuda.Stream(dev)
-    stream.wait_stream(torch.cuda.current_stream(dev))
-    torch.cuda.set_stream(stream)
+    # Each in-flight slot owns a plan (accept-mask scratch), output tables and a dedicated HIP
+    # stream shared by its solver launches and its RCCL all-gather (handle 0, torch's default
+    # stream, would select the library's own stream instead).  Consecutive steps go to
+    # consecutive slots, so independent batches overlap on the GPU; every step still solves the
+    # whole batch and produces its own full outputs.
+    n_slots = max(1, min(args.in_flight, args.steps))
+    slots = []
+    for _ in range(n_slots):
+        sl = {"plan": native.Plan(ctx, fb),
+              "out": torch.empty(fb.out_len, dtype=torch.int32, device=dev),
+              "tr": torch.zeros(S * 16, dtype=torch.uint8, device=dev),
+              "sr": torch.zeros(S * 32, dtype=torch.uint8, device=dev),
+              "stream": torch.cuda.Stream(dev)}
+        sl["all"] = torch.zeros(world * S * 32, dtype=torch.uint8, device=dev) if world > 1 else sl["sr"]
+        sl["stream"].wait_stream(torch.cuda.current_stream(dev))
+        slots.append(sl)
+    plan, d_out, d_tr, d_sr, d_all = (slots[0][k] for k in ("plan", "out", "tr", "sr", "all"))
+    step_no = [0]
 
     def step():
-        plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
-                          stream=stream.cuda_stream)
+        sl = slots[step_no[0] % n_slots]
+        step_no[0] += 1
+        sl["plan"].solve_device(d_cur.data_ptr(), sl["out"].data_ptr(), sl["tr"].data_ptr(),
+                                sl["sr"].data_ptr(), stream=sl["stream"].cuda_stream)
         if world > 1:                                   # the single data-path collective
-            dist.all_gather_into_tensor(d_all, d_sr)
+            with torch.cuda.stream(sl["stream"]):
+                dist.all_gather_into_tensor(sl["all"], sl["sr"])
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -106,7 +120,9 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     fence()
-    plan.kernel_time_us()                               # reset the kernel-event accumulator
+    for sl in slots:
+        sl["plan"].kernel_time_us()                     # reset the kernel-event accumulators
+    step_no[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -116,7 +132,11 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_us, kern_n = plan.kernel_time_us()
+    kern_us, kern_n = 0.0, 0
+    for sl in slots:
+        u, n = sl["plan"].kernel_time_us()
+        kern_us += u * n; kern_n += n
+    kern_us = kern_us / kern_n if kern_n else 0.0
     if args.stats and rank == 0:
         st = plan.stats().astype(np.float64)
         names = ["setup_us", "p2_us", "p3p4_us", "p5_us", "p4_windows", "p4_steps", "p5_rounds", "p2_overflow_tiles"]
@@ -199,6 +219,7 @@ def main() -> int:
                                "replace1: zero slack at N=1000, cap=300) and are parity-checked",
                 "parity_checked_scenarios": checked,
                 "collective": "all_gather of 32-byte result records per step" if world > 1 else "none (1 GPU)",
+                "batches_in_flight": n_slots,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -217,7 +238,8 @@ def main() -> int:
         except Exception:
             pass
         print(json.dumps(out_line), flush=True)
-    plan.close()
+    for sl in slots:
+        sl["plan"].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -216,6 +216,12 @@ int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
  * in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
  * [6] P5 conflict rounds, [7] P2 tiles that needed overflow ranking.  n = capacity of out in
  * int64 elements (>= 8 * n_scenarios).  Blocks until the plan's last launch has finished. */
+/* Behaviour switches of a plan (default 0).  KAS_PLAN_GENERIC_FILL: always run the general
+ * multi-sweep sticky fill instead of the rack-diverse single-scan form (same results; exists so
+ * both forms can be tested and timed on the same inputs). */
+#define KAS_PLAN_GENERIC_FILL 1u
+int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
+
 #define KAS_STATS_PER_SCENARIO 8
 int kas_plan_stats(kas_plan* plan, int64_t* out, int64_t n);
 

@@ -29,9 +29,6 @@ __global__ __launch_bounds__(64) void kas_solve_kernel(KasLaunch a) {
     kas::solve_scenario<W>(a, s, kas_lds);
 }
 
-// widths the kernel is instantiated for; a batch uses the smallest one >= its widest list
-static int kas_width_class(int W) { return W <= 2 ? 2 : W <= 5 ? W : 8; }
-
 typedef void (*kas_kernel_fn)(KasLaunch);
 static kas_kernel_fn kas_kernel_for(int Wc) {
   switch (Wc) {
@@ -71,6 +68,7 @@ struct kas_plan {
   kas_ctx* ctx;
   KasShape shape;
   int Wc;                       // instantiated width class
+  uint32_t flags;               // KAS_FLAG_*
   KasLds lds;
   int32_t n_scenarios, n_topics;
   // device copies owned by the plan
@@ -197,8 +195,9 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   memset((void*)p->ev_start, 0, sizeof(p->ev_start));
   memset((void*)p->ev_stop, 0, sizeof(p->ev_stop));
   p->ctx = ctx; p->shape = sh;
-  p->Wc = kas_width_class(sh.W);
-  p->lds = kas_lds_layout(sh.n_max, p->Wc, sh.idmap_entries, sh.need_bsearch);
+  p->Wc = sh.Wc;
+  p->lds = sh.lds;
+  p->flags = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
   p->d_accmask_off = nullptr; p->d_accmask = nullptr; p->d_stats = nullptr; p->last_stream = ctx->stream;
@@ -263,6 +262,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
+  a.hist_separate = p->shape.hist_separate; a.flags = p->flags;
   const int slot = p->timer_next;
   KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
   hipLaunchKernelGGL(kas_kernel_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
@@ -290,6 +290,12 @@ int kas_plan_kernel_time_us(kas_plan* p, double* avg_us, int* launches) {
   p->timer_count = 0;
   *launches = n;
   *avg_us = n ? total_ms * 1000.0 / n : 0.0;
+  return KAS_E_OK;
+}
+
+int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
+  if (!p) return set_error(KAS_E_INVALID_ARG, "plan == NULL");
+  p->flags = flags;
   return KAS_E_OK;
 }
 

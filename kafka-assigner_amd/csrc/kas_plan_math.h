@@ -28,14 +28,22 @@ struct KasLaunch {
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
   int32_t idmap_entries;        // entries of the direct broker-id -> node-index table
   int32_t need_bsearch;         // some scenario's id range exceeds idmap_entries
+  int32_t hist_separate;        // the sweep histogram has its own LDS (else it aliases cnt)
+  uint32_t flags;               // KAS_FLAG_*
 };
+
+#define KAS_FLAG_GENERIC_FILL 1u   // always use the general sticky fill (testing / comparison)
+// rows of the sweep histogram: one per replica index, at least 3 (reused as quota/running/r*)
+#define KAS_HIST_ROWS(W) ((W) < 3 ? 3 : (W))
 
 // Byte offsets into the workgroup's dynamic LDS.  Region B (owner) aliases region A (load,
 // rack, live, idmap, ids, ring): A is live during P2-P4, B during P5, and the per-topic setup
 // rebuilds A.  Only the Context counters persist across the topics of a scenario.
 struct KasLds {
-  int32_t off_cnt;     // int32  [n_max * W]   Context counters (KAS:244-302)
-  int32_t off_owner;   // uint32 [n_max]       P5 conflict-round owner keys        (region B)
+  int32_t off_cnt;     // int32  [n_max * CS]  Context counters (KAS:244-302), CS = kas_cnt_stride(W)
+  int32_t off_dep;     // uint64 [n_max]       P5 lane-sharing masks per node      (region B)
+  int32_t off_hist;    // int32  [max(W,3)*n_max] sweep histogram of the rack-diverse fill; aliases
+                       //                      off_cnt unless a scenario carries Context state
   int32_t off_load;    // int32  [n_max]       |Node.assignedPartitions|           (region A)
   int32_t off_rack;    // int16  [n_max]       dense rack index per node
   int32_t off_live;    // int16  [n_max]       non-full nodes in processing order
@@ -52,15 +60,25 @@ struct KasLds {
 
 KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_t)15); }
 
+// Counter row stride in ints: 3-wide rows are padded to 4 so a row is one 16-byte LDS read.
+KAS_ABI_FN int32_t kas_cnt_stride(int32_t W) { return W == 3 ? 4 : W; }
+
 KAS_ABI_FN KasLds kas_lds_layout(int32_t n_max, int32_t W, int32_t idmap_entries,
-                                    int32_t need_bsearch) {
+                                    int32_t need_bsearch, int32_t hist_separate) {
   KasLds L;
   int64_t n = n_max > 0 ? n_max : 1;
   int64_t o = 0;
-  L.off_cnt = (int32_t)o;   o = kas_align16(o + 4 * n * W);
+  const int64_t cnt_bytes = 4 * n * kas_cnt_stride(W), hist_bytes = 4 * n * KAS_HIST_ROWS(W);
+  L.off_cnt = (int32_t)o;
+  if (hist_separate) {
+    o = kas_align16(o + cnt_bytes);
+    L.off_hist = (int32_t)o; o = kas_align16(o + hist_bytes);
+  } else {
+    L.off_hist = (int32_t)o; o = kas_align16(o + (cnt_bytes > hist_bytes ? cnt_bytes : hist_bytes));
+  }
   int64_t base = o;
-  L.off_owner = (int32_t)base;
-  int64_t endB = kas_align16(base + 4 * n);
+  L.off_dep = (int32_t)base;
+  int64_t endB = kas_align16(base + 8 * n);
   L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n);
   L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
   L.off_live = (int32_t)o;  o = kas_align16(o + 2 * n);
@@ -71,11 +89,16 @@ KAS_ABI_FN KasLds kas_lds_layout(int32_t n_max, int32_t W, int32_t idmap_entries
   return L;
 }
 
+// widths the kernel is instantiated for; a batch uses the smallest one >= its widest list
+KAS_ABI_FN int32_t kas_width_class(int32_t W) { return W <= 2 ? 2 : W <= 5 ? W : 8; }
+
 struct KasShape {
-  int32_t W = 1;                      // register list width: max out_width in the batch
+  int32_t W = 1;                      // widest list in the batch: max out_width
+  int32_t Wc = 2;                     // instantiated kernel width class >= W
   int32_t n_max = 0;
   int32_t idmap_entries = 0;
   int32_t need_bsearch = 0;
+  int32_t hist_separate = 0;          // some scenario has several topics or a Context
   std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
   int64_t accmask_words = 0;
   int64_t algorithmic_bytes = 0;
@@ -107,6 +130,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (range >= 1 && range <= KAS_IDMAP_CAP) { if (range > max_range_fit) max_range_fit = range; }
       else s.need_bsearch = 1;      // sparse ids (or unsorted: the kernel reports BAD_NODES)
     }
+    if (sd.ctx_off >= 0 || sd.topic_count > 1) s.hist_separate = 1;
     if (sd.ctx_off >= 0) {
       if (sd.ctx_width < 1 || sd.ctx_width > KAS_MAX_WIDTH)
         return fail(KAS_E_INVALID_ARG, "scenario " + std::to_string(i) + ": ctx_width outside [1,8]");
@@ -146,10 +170,17 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     s.accmask_words += words > 0 ? words : 1;
   }
   s.idmap_entries = (int32_t)max_range_fit;
-  s.lds = kas_lds_layout(s.n_max, s.W, s.idmap_entries, s.need_bsearch);
+  s.Wc = kas_width_class(s.W);
+  s.lds = kas_lds_layout(s.n_max, s.Wc, s.idmap_entries, s.need_bsearch, s.hist_separate);
+  if (s.lds.total > KAS_LDS_LIMIT && s.hist_separate) {
+    // no room for a separate histogram: alias it with the counters; topics that carry Context
+    // state then use the general sticky fill
+    s.hist_separate = 0;
+    s.lds = kas_lds_layout(s.n_max, s.Wc, s.idmap_entries, s.need_bsearch, 0);
+  }
   if (s.lds.total > KAS_LDS_LIMIT)
     return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +
-                std::to_string(s.W) + " needs " + std::to_string(s.lds.total) +
+                std::to_string(s.Wc) + " needs " + std::to_string(s.lds.total) +
                 " B of LDS (limit 163840)");
   *sh = s;
   return KAS_E_OK;

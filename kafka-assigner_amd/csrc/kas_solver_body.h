@@ -23,10 +23,11 @@
 //      list of non-full nodes is walked (the reference spends >99% of its probes on them).
 //  P5  preference order (KAS:202-239): row p reads count[n][0..L) of its own nodes, picks, then
 //      increments L counters, so rows conflict only when they share a node.  64 ascending rows
-//      per tile; each round every pending lane claims its nodes with an LDS atomic max keyed
-//      (epoch, 63-lane); a lane that owns all its nodes has no earlier pending row sharing a
-//      node and commits; the rest retry.  Lane order == row order, so the result is the
-//      sequential one.
+//      per tile; once per tile every lane ors its lane bit into a 64-bit LDS mask per node it
+//      holds and reads those masks back, so it knows which LOWER lanes share a node with it.
+//      Each round a lane none of whose lower sharers is still pending commits; the rest retry.
+//      Lane order == row order, so the result is the sequential one.  The pick itself is the
+//      minimum of (count << 3 | visit position): "first strictly smaller in rotated order".
 //
 // Everything cross-lane goes through kas_wave.h; all control flow around those calls is
 // wave-uniform.  List positions live in registers through fully unrolled loops (W is a
@@ -50,8 +51,9 @@ struct TopicOutcome {
 
 struct LdsView {
   int32_t* cnt;
-  uint32_t* owner;
+  uint64_t* dep;
   int32_t* load;
+  int32_t* hist;     // [KAS_HIST_ROWS(W)][N]: sweep histogram, then quota / running / r*
   int16_t* rack;
   int16_t* live;
   int16_t* idmap;
@@ -100,10 +102,31 @@ KAS_DEV int32_t java_abs_mod(int32_t hash, int32_t n) {
 
 template <int W>
 KAS_DEV int32_t sel(const int32_t (&a)[W], int32_t i) {
-  int32_t v = a[0];
+  int32_t t[W];
 #pragma unroll
-  for (int j = 1; j < W; ++j) v = (i == j) ? a[j] : v;
+  for (int j = 0; j < W; ++j) t[j] = kasw::opaque(a[j]);   // launder first, select afterwards
+  int32_t v = t[0];
+#pragma unroll
+  for (int j = 1; j < W; ++j) v = (i == j) ? t[j] : v;
   return v;
+}
+
+template <int W>
+constexpr int cnt_stride() { return W == 3 ? 4 : W; }   // == kas_cnt_stride(W)
+
+struct alignas(16) CntRow4 { int32_t v[4]; };
+
+// one Context counter row (count[node][0..W)) from LDS; a 3-wide row is one 16-byte read
+template <int W>
+KAS_DEV void load_cnt_row(int32_t (&c)[W], const int32_t* row) {
+  if constexpr (W == 3 || W == 4) {
+    const CntRow4 q = *reinterpret_cast<const CntRow4*>(row);
+#pragma unroll
+    for (int r = 0; r < W; ++r) c[r] = q.v[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < W; ++r) c[r] = row[r];
+  }
 }
 
 template <int W>
@@ -128,7 +151,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
   int32_t hr[W];
 #pragma unroll
   for (int j = 0; j < W; ++j) hr[j] = mine ? (int32_t)L.ring_rack[j * KAS_RING_CAP + lane] : -1;
-  kasw::sync();   // ring fully read before the caller shifts it
+  kasw::lockstep();   // ring fully read before the caller shifts it
 
   int32_t fail_lane = -1;
   int32_t j = head;
@@ -155,9 +178,9 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
           need -= 1;
         }
         const int32_t takers = kasw::popc(w);
-        kasw::sync();                                    // every lane has read load[n]
+        kasw::lockstep();                                // every lane has read load[n]
         if (lane == 0) L.load[n] += takers < slots ? takers : slots;
-        kasw::sync();
+        kasw::lockstep();
       }
     }
     ++j;
@@ -167,64 +190,128 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
   return fail_lane;
 }
 
+// Everything a phase needs to know about the topic being solved.
+struct TopicView {
+  const int32_t* cur;
+  int32_t* out;
+  const int32_t* len_arr;
+  const int32_t* inp_arr;
+  const int32_t* pid_arr;
+  int32_t P, cw, rf, ow, hash, nt, N, cap;
+};
+
+// current replica list of row p (ids beyond cur_width read as -1; validity comes from len)
+template <int W>
+KAS_DEV void load_row(const TopicView& T, int32_t p, int32_t (&ids)[W], int32_t& len) {
+  const bool active = p < T.P;
+#pragma unroll
+  for (int r = 0; r < W; ++r) ids[r] = (active && r < T.cw) ? T.cur[(int64_t)p * T.cw + r] : -1;
+  len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
-// One topic == one getRackAwareAssignment call.
+// P3 for one tile (KAS:133-160): holders of the row from its accepted replicas, orphan count,
+// movement bookkeeping, the out row (node indices for now) and the orphan ring.
 // ---------------------------------------------------------------------------------------------
 template <int W>
-KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, uint32_t topic_k,
-                                 const LdsView& L, const NodeMap& nm, const int32_t* g_node_id,
-                                 const int32_t* g_node_rack, uint64_t* accmask, int64_t (&st)[8]) {
+KAS_DEV void p3_tile(const LdsView& L, const TopicView& T, int32_t p, int32_t len,
+                     const int32_t (&ids)[W], const int32_t (&idx)[W], uint32_t accbits,
+                     int32_t& ring_count, int32_t& moved_r, int32_t& moved_p) {
+  const bool active = p < T.P;
+  int32_t hold[W], hrack[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) { hold[k] = -1; hrack[k] = -1; }
+  int32_t hc = 0;
+#pragma unroll
+  for (int r = 0; r < W; ++r) {
+    const bool acc = (accbits >> r) & 1u;
+    const int32_t n = idx[r] >= 0 ? idx[r] : 0;
+    const int32_t rk = (int32_t)L.rack[n];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const bool here = acc && hc == k;
+      hold[k] = here ? n : hold[k];
+      hrack[k] = here ? rk : hrack[k];
+    }
+    hc += acc ? 1 : 0;
+  }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) if (k < T.ow) T.out[(int64_t)p * T.ow + k] = hold[k];
+  }
+  const bool in_parts = active && (T.inp_arr ? T.inp_arr[p] != 0 : true);
+  const int32_t need = in_parts ? (T.rf - hc > 0 ? T.rf - hc : 0) : 0;   // KAS:151-157
+  // a distinct current broker that was not kept => set(new) != set(cur)
+  uint32_t kept_else = 0;
+#pragma unroll
+  for (int r = 0; r < W; ++r)
+#pragma unroll
+    for (int r2 = 0; r2 < W; ++r2)
+      kept_else |= (((accbits >> r2) & 1u) != 0u && ids[r2] == ids[r]) ? (1u << r) : 0u;
+  const uint32_t present = len >= W ? ((1u << W) - 1u) : ((1u << len) - 1u);
+  const bool dropped = (present & ~accbits & ~kept_else) != 0u;
+  moved_r += need;
+  moved_p += (active && (dropped || need > 0)) ? 1 : 0;
+
+  const bool orphan = need > 0;
+  const uint64_t om = kasw::ballot(orphan);
+  if (orphan) {
+    const int32_t slot = ring_count + kasw::popc(om & kasw::lanemask_lt());
+    L.ring_p[slot] = p;
+    L.ring_meta[slot] = need | (hc << 8);
+#pragma unroll
+    for (int k = 0; k < W; ++k) L.ring_rack[k * KAS_RING_CAP + slot] = (int16_t)hrack[k];
+  }
+  ring_count += kasw::popc(om);
+  kasw::lockstep();
+}
+
+// Run P4 windows while the ring holds at least `min_fill` orphans (64 inside the row scan, 1 at
+// its end).  Returns the failing row (KAS:183-184) or -1.
+template <int W>
+KAS_DEV int32_t drain_ring(const LdsView& L, const TopicView& T, int32_t min_fill, int32_t live_count,
+                           int32_t& head, int32_t& ring_count, int64_t (&st)[8]) {
+  const int lane = kasw::lane();
+  while (ring_count >= min_fill && ring_count > 0) {
+    const int32_t n_win = ring_count < 64 ? ring_count : 64;
+    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.out, T.ow, st);
+    if (fl >= 0) return L.ring_p[fl];
+    const int32_t rest = ring_count - n_win;           // shift the ring down by one window
+    int32_t tp = 0, tm = 0; int32_t tr[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) tr[k] = 0;
+    if (lane < rest) {
+      tp = L.ring_p[64 + lane]; tm = L.ring_meta[64 + lane];
+#pragma unroll
+      for (int k = 0; k < W; ++k) tr[k] = L.ring_rack[k * KAS_RING_CAP + 64 + lane];
+    }
+    kasw::lockstep();
+    if (lane < rest) {
+      L.ring_p[lane] = tp; L.ring_meta[lane] = tm;
+#pragma unroll
+      for (int k = 0; k < W; ++k) L.ring_rack[k * KAS_RING_CAP + lane] = (int16_t)tr[k];
+    }
+    ring_count = rest;
+    kasw::lockstep();
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// P2, general form (KAS:101-131): one sweep per replica index, accept-mask words in HBM.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+KAS_DEV void fill_generic_sweeps(const LdsView& L, const TopicView& T, const NodeMap& nm,
+                                 uint64_t* accmask, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   const uint64_t lt = kasw::lanemask_lt();
-  const int32_t N = nm.n;
-  const int32_t P = td.n_partitions;
-  const int32_t cw = td.cur_width;
-  const int32_t rf = td.rf;
-  const int32_t ow = td.out_width;
-  const int32_t hash = td.name_hash;
-  const int32_t* cur = a.cur + td.cur_off;
-  int32_t* out = a.out + td.out_off;
-  const int32_t* len_arr = td.cur_len_off >= 0 ? a.aux + td.cur_len_off : nullptr;
-  const int32_t* inp_arr = td.in_partitions_off >= 0 ? a.aux + td.in_partitions_off : nullptr;
-  const int32_t* pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
-  const int32_t nt = (P + 63) >> 6;
-
-  TopicOutcome res;
-  res.status = KAS_OK; res.fail_partition = -1;
-  res.moved_replicas = 0; res.moved_partitions = 0; res.digest = 0;
-
-  int64_t tmark = kasw::clock_ticks();
-  // ---- P0: capacity (KAS:45, 65-71) over |partitions| ---------------------------------------
-  int32_t n_in = P;
-  if (inp_arr) {
-    int32_t c = 0;
-    for (int32_t p = lane; p < P; p += 64) c += inp_arr[p] != 0 ? 1 : 0;
-    n_in = kasw::wave_sum(c);
-  }
-  const int32_t cap = max_replicas_per_node(N, n_in, rf);
-
-  // ---- per-topic node state (KAS:46, 73-99): region A of the LDS carve-up -------------------
-  for (int32_t i = lane; i < N; i += 64) {
-    L.load[i] = 0;
-    L.rack[i] = (int16_t)g_node_rack[i];
-  }
-  if (nm.range != 0u) {
-    for (uint32_t i = (uint32_t)lane; i < nm.range; i += 64u) L.idmap[i] = (int16_t)-1;
-    kasw::sync();
-    for (int32_t i = lane; i < N; i += 64) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
-  } else {
-    for (int32_t i = lane; i < N; i += 64) L.ids[i] = g_node_id[i];
-  }
-  kasw::sync();
-
-  { const int64_t now = kasw::clock_ticks(); st[0] += now - tmark; tmark = now; }
-  // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
-  for (int32_t r = 0; r < cw; ++r) {
+  const int32_t cap = T.cap, nt = T.nt;
+  for (int32_t r = 0; r < T.cw; ++r) {
     for (int32_t tile = 0; tile < nt; ++tile) {
       const int32_t p = (tile << 6) + lane;
-      const bool active = p < P;
-      const int32_t len = active ? (len_arr ? len_arr[p] : cw) : 0;
-      const int32_t* row = cur + (int64_t)p * cw;
+      const bool active = p < T.P;
+      const int32_t len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
+      const int32_t* row = T.cur + (int64_t)p * T.cw;
       int32_t n = -1;
       if (r < len) n = node_lookup(L, nm, row[r]);         // node != null (KAS:119-120)
       bool elig = n >= 0;
@@ -242,7 +329,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
       const bool took = elig && L.load[n] < cap;            // size() < capacity (KAS:322)
       kasw::lockstep();                                     // every lane saw the pre-tile load
       if (took) kasw::lds_atomic_add(&L.load[n], 1);
-      kasw::sync();
+      kasw::lockstep();
       bool accepted = took;
       uint64_t todo = kasw::ballot(took && L.load[n] > cap);
       if (todo != 0) {
@@ -255,19 +342,250 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
           const uint64_t same = kasw::ballot(same_l);
           const int32_t before = L.load[t] - kasw::popc(same);
           if (same_l) accepted = before + kasw::popc(same & lt) < cap;
-          kasw::sync();                                     // all lanes read load[t]
+          kasw::lockstep();                                 // all lanes read load[t]
           if (lane == leader) L.load[t] = cap;
           todo &= ~same;
         }
-        kasw::sync();
+        kasw::lockstep();
       }
       const uint64_t accw = kasw::ballot(accepted);
       if (lane == 0) kasw::store_shared_u64(accmask + (int64_t)r * nt + tile, accw);
     }
     kasw::sync();   // this sweep's mask words are visible to the next sweep's loads
   }
+}
 
+// ---------------------------------------------------------------------------------------------
+// P2, rack-diverse form.  When every row's valid replicas sit on pairwise different racks, the
+// rack test of canAccept can never fail during the sticky fill (the only members of a rack's
+// set for row p are p's own earlier replicas), so a node simply keeps its first `cap`
+// candidates in (replica index, row) order, independently of every other node.
+//   pass A: hist[r][n] = candidates of sweep r on node n; also proves rack diversity
+//   quota : per node the one sweep r* in which it saturates and how many it still takes there
+//   pass B: replica (p, r) on n is kept iff r < r*(n), or r == r*(n) and its rank among n's
+//           sweep-r* candidates (row order) is below the quota — all replicas of a row at once,
+//           with P3 and P4 running in the same scan.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm) {
+  const int lane = kasw::lane();
+  const int32_t N = T.N;
+  for (int32_t i = lane; i < N * KAS_HIST_ROWS(W); i += 64) L.hist[i] = 0;
+  kasw::lockstep();
+  bool viol = false;
+  int32_t nx[W], nlen;
+  load_row<W>(T, lane, nx, nlen);
+  for (int32_t tile = 0; tile < T.nt; ++tile) {
+    const int32_t p = (tile << 6) + lane;
+    int32_t ids[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) ids[r] = nx[r];
+    const int32_t len = nlen;
+    load_row<W>(T, p + 64, nx, nlen);                       // prefetch the next tile
+    int32_t idx[W], rk[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
+      rk[r] = idx[r] >= 0 ? (int32_t)L.rack[idx[r]] : -1 - r;   // invalid: never equal
+    }
+#pragma unroll
+    for (int r = 1; r < W; ++r)
+#pragma unroll
+      for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[r] == rk[r2];
+#pragma unroll
+    for (int r = 0; r < W; ++r) if (idx[r] >= 0) kasw::lds_atomic_add(&L.hist[r * N + idx[r]], 1);
+  }
+  kasw::lockstep();
+  return kasw::ballot(viol) == 0;
+}
+
+// hist[0][n] <- quota in the saturating sweep, hist[1][n] <- running count (0), hist[2][n] <- r*
+template <int W>
+KAS_DEV void fill_quota(const LdsView& L, const TopicView& T) {
+  const int lane = kasw::lane();
+  const int32_t N = T.N;
+  for (int32_t n = lane; n < N; n += 64) {
+    int32_t cum = 0, rs = W, q = 0;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      const int32_t c = L.hist[r * N + n];
+      const bool sat = rs == W && c > T.cap - cum;          // cum + c > cap, overflow-safe
+      q = sat ? T.cap - cum : q;
+      cum = rs == W ? (sat ? T.cap : cum + c) : cum;
+      rs = sat ? r : rs;
+    }
+    L.load[n] = cum;
+    L.hist[n] = q;
+    L.hist[N + n] = 0;
+    L.hist[2 * N + n] = rs;
+  }
+  kasw::lockstep();
+}
+
+template <int W>
+KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t live_count,
+                            int32_t& head, int32_t& ring_count, int32_t& moved_r, int32_t& moved_p,
+                            int64_t (&st)[8]) {
+  const int lane = kasw::lane();
+  const uint64_t lt = kasw::lanemask_lt();
+  const int32_t N = T.N;
+  int32_t nx[W], nlen;
+  load_row<W>(T, lane, nx, nlen);
+  for (int32_t tile = 0; tile < T.nt; ++tile) {
+    const int32_t p = (tile << 6) + lane;
+    int32_t ids[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) ids[r] = nx[r];
+    const int32_t len = nlen;
+    load_row<W>(T, p + 64, nx, nlen);
+    int32_t idx[W], nn[W], q[W], before[W];
+    uint32_t sure = 0, counting = 0;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
+      nn[r] = idx[r] >= 0 ? idx[r] : 0;
+      const int32_t rs = L.hist[2 * N + nn[r]];
+      sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
+      counting |= (idx[r] >= 0 && r == rs) ? (1u << r) : 0u;
+      q[r] = L.hist[nn[r]];
+      before[r] = L.hist[N + nn[r]];
+    }
+    uint32_t accbits = sure;
+    if (kasw::ballot(counting != 0u) != 0) {
+      kasw::lockstep();                                     // every lane saw the pre-tile counts
+#pragma unroll
+      for (int r = 0; r < W; ++r) if ((counting >> r) & 1u) kasw::lds_atomic_add(&L.hist[N + nn[r]], 1);
+      kasw::lockstep();
+      uint32_t contested = 0;
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        const int32_t after = L.hist[N + nn[r]];
+        const bool cnt = (counting >> r) & 1u;
+        accbits |= (cnt && after <= q[r]) ? (1u << r) : 0u;
+        contested |= (cnt && before[r] < q[r] && after > q[r]) ? (1u << r) : 0u;
+      }
+      uint64_t todo = kasw::ballot(contested != 0u);
+      if (todo != 0) {
+        st[7] += 1;
+        // the quota boundary of some node falls inside this tile: rank its lanes (row order)
+        while (todo != 0) {
+          const int leader = kasw::first_lane(todo);
+          int32_t mine_t = -1;
+#pragma unroll
+          for (int r = W - 1; r >= 0; --r) mine_t = ((contested >> r) & 1u) ? nn[r] : mine_t;
+          const int32_t t = kasw::shfl(mine_t, leader);
+          uint32_t hit = 0;                                  // my replica counted on node t
+#pragma unroll
+          for (int r = 0; r < W; ++r) hit |= (((counting >> r) & 1u) && nn[r] == t) ? (1u << r) : 0u;
+          const uint64_t same = kasw::ballot(hit != 0u);
+          const int32_t rank = kasw::popc(same & lt);
+#pragma unroll
+          for (int r = 0; r < W; ++r)
+            accbits |= (((hit >> r) & 1u) && before[r] + rank < q[r]) ? (1u << r) : 0u;
+          contested &= ~hit;
+          todo = kasw::ballot(contested != 0u);
+        }
+      }
+    }
+    p3_tile<W>(L, T, p, len, ids, idx, accbits, ring_count, moved_r, moved_p);
+    const int32_t fr = drain_ring<W>(L, T, 64, live_count, head, ring_count, st);
+    if (fr >= 0) return fr;
+  }
+  return -1;
+}
+
+// P3 + P4 over the accept-mask words of the general sticky fill
+template <int W>
+KAS_DEV int32_t p3p4_generic(const LdsView& L, const TopicView& T, const NodeMap& nm,
+                             const uint64_t* accmask, int32_t live_count, int32_t& head,
+                             int32_t& ring_count, int32_t& moved_r, int32_t& moved_p,
+                             int64_t (&st)[8]) {
+  const int lane = kasw::lane();
+  for (int32_t tile = 0; tile < T.nt; ++tile) {
+    const int32_t p = (tile << 6) + lane;
+    int32_t ids[W], idx[W], len;
+    load_row<W>(T, p, ids, len);
+    uint32_t accbits = 0;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      idx[r] = -1;
+      if (r < T.cw) {                                       // wave-uniform
+        const uint64_t aw = kasw::load_shared_u64(accmask + (int64_t)r * T.nt + tile);
+        if (p < T.P && ((aw >> lane) & 1ull)) {
+          accbits |= 1u << r;
+          idx[r] = node_lookup(L, nm, ids[r]);
+        }
+      }
+    }
+    p3_tile<W>(L, T, p, len, ids, idx, accbits, ring_count, moved_r, moved_p);
+    const int32_t fr = drain_ring<W>(L, T, 64, live_count, head, ring_count, st);
+    if (fr >= 0) return fr;
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One topic == one getRackAwareAssignment call.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, uint32_t topic_k,
+                                 const LdsView& L, const NodeMap& nm, const int32_t* g_node_id,
+                                 const int32_t* g_node_rack, uint64_t* accmask, bool cnt_live,
+                                 int64_t (&st)[8]) {
+  const int lane = kasw::lane();
+  const uint64_t lt = kasw::lanemask_lt();
+  const int32_t N = nm.n;
+  TopicView T;
+  T.cur = a.cur + td.cur_off;
+  T.out = a.out + td.out_off;
+  T.len_arr = td.cur_len_off >= 0 ? a.aux + td.cur_len_off : nullptr;
+  T.inp_arr = td.in_partitions_off >= 0 ? a.aux + td.in_partitions_off : nullptr;
+  T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
+  T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
+  T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
+  const int32_t P = T.P, ow = T.ow, nt = T.nt, hash = T.hash;
+  int32_t* out = T.out;
+
+  TopicOutcome res;
+  res.status = KAS_OK; res.fail_partition = -1;
+  res.moved_replicas = 0; res.moved_partitions = 0; res.digest = 0;
+
+  int64_t tmark = kasw::clock_ticks();
+  // ---- P0: capacity (KAS:45, 65-71) over |partitions| ---------------------------------------
+  int32_t n_in = P;
+  if (T.inp_arr) {
+    int32_t c = 0;
+    for (int32_t p = lane; p < P; p += 64) c += T.inp_arr[p] != 0 ? 1 : 0;
+    n_in = kasw::wave_sum(c);
+  }
+  T.cap = max_replicas_per_node(N, n_in, T.rf);
+  const int32_t cap = T.cap;
+
+  // ---- per-topic node state (KAS:46, 73-99): region A of the LDS carve-up -------------------
+  for (int32_t i = lane; i < N; i += 64) {
+    L.load[i] = 0;
+    L.rack[i] = (int16_t)g_node_rack[i];
+  }
+  if (nm.range != 0u) {
+    for (uint32_t i = (uint32_t)lane; i < nm.range; i += 64u) L.idmap[i] = (int16_t)-1;
+    kasw::lockstep();
+    for (int32_t i = lane; i < N; i += 64) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
+  } else {
+    for (int32_t i = lane; i < N; i += 64) L.ids[i] = g_node_id[i];
+  }
+  kasw::lockstep();
+  { const int64_t now = kasw::clock_ticks(); st[0] += now - tmark; tmark = now; }
+
+  // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
+  // rack-diverse form when the histogram pass proves it applicable and its LDS table is free
+  // (it aliases the Context counters, which must then not carry state into this topic)
+  bool fast = false;
+  if (T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && (a.hist_separate || !cnt_live))
+    fast = fill_pass_a<W>(L, T, nm);
+  if (fast) fill_quota<W>(L, T);
+  else fill_generic_sweeps<W>(L, T, nm, accmask, st);
   { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
+
   // ---- KAS:168: getNodeProcessingOrder(topic, all nodes); runs even with zero orphans -------
   const int32_t idxN = java_abs_mod(hash, N);
   if (idxN < 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }
@@ -283,115 +601,41 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
     if (is_live) L.live[live_count + kasw::popc(m & lt)] = (int16_t)n;
     live_count += kasw::popc(m);
   }
-  kasw::sync();
+  kasw::lockstep();
 
   // ---- P3 + P4: orphans (KAS:52, 133-160) and first fit (KAS:56, 162-186) -------------------
   int32_t ring_count = 0, head = 0;
   int32_t moved_r = 0, moved_p = 0;
-  int32_t fail_row = -1;
-  for (int32_t tile = 0; tile < nt && fail_row < 0; ++tile) {
-    const int32_t p = (tile << 6) + lane;
-    const bool active = p < P;
-    const int32_t len = active ? (len_arr ? len_arr[p] : cw) : 0;
-    const int32_t* row = cur + (int64_t)p * cw;
-    int32_t ids[W];
-    int32_t hold[W], hrack[W];
-    uint32_t accbits = 0;
-    int32_t hc = 0;
-#pragma unroll
-    for (int r = 0; r < W; ++r) {
-      ids[r] = -1; hold[r] = -1; hrack[r] = -1;
-    }
-#pragma unroll
-    for (int r = 0; r < W; ++r) {
-      if (r < cw) {                                         // wave-uniform
-        const uint64_t aw = kasw::load_shared_u64(accmask + (int64_t)r * nt + tile);
-        if (r < len) ids[r] = row[r];
-        if (active && ((aw >> lane) & 1ull)) {
-          accbits |= 1u << r;
-          const int32_t n = node_lookup(L, nm, ids[r]);
-          put<W>(hold, hc, n);
-          put<W>(hrack, hc, (int32_t)L.rack[n]);
-          hc += 1;
-        }
-      }
-    }
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) if (k < ow) out[(int64_t)p * ow + k] = hold[k];   // node indices for now
-    }
-    const bool in_parts = active && (inp_arr ? inp_arr[p] != 0 : true);
-    const int32_t need = in_parts ? (rf - hc > 0 ? rf - hc : 0) : 0;   // KAS:151-157
-    // a distinct current broker that was not kept => set(new) != set(cur)
-    bool dropped = false;
-#pragma unroll
-    for (int r = 0; r < W; ++r) {
-      if (r < len && !((accbits >> r) & 1u)) {
-        bool kept_elsewhere = false;
-#pragma unroll
-        for (int r2 = 0; r2 < W; ++r2)
-          if (r2 < len && ((accbits >> r2) & 1u) && ids[r2] == ids[r]) kept_elsewhere = true;
-        if (!kept_elsewhere) dropped = true;
-      }
-    }
-    moved_r += need;
-    moved_p += (active && (dropped || need > 0)) ? 1 : 0;
-
-    const bool orphan = need > 0;
-    const uint64_t om = kasw::ballot(orphan);
-    if (orphan) {
-      const int32_t slot = ring_count + kasw::popc(om & lt);
-      L.ring_p[slot] = p;
-      L.ring_meta[slot] = need | (hc << 8);
-#pragma unroll
-      for (int k = 0; k < W; ++k) L.ring_rack[k * KAS_RING_CAP + slot] = (int16_t)hrack[k];
-    }
-    ring_count += kasw::popc(om);
-    kasw::sync();
-    while (ring_count >= 64 && fail_row < 0) {
-      const int32_t fl = p4_window<W>(L, 64, cap, live_count, head, out, ow, st);
-      if (fl >= 0) { fail_row = L.ring_p[fl]; break; }
-      // shift the ring down by one window
-      const int32_t rest = ring_count - 64;
-      int32_t tp = 0, tm = 0; int32_t tr[W];
-      if (lane < rest) {
-        tp = L.ring_p[64 + lane]; tm = L.ring_meta[64 + lane];
-#pragma unroll
-        for (int k = 0; k < W; ++k) tr[k] = L.ring_rack[k * KAS_RING_CAP + 64 + lane];
-      }
-      kasw::sync();
-      if (lane < rest) {
-        L.ring_p[lane] = tp; L.ring_meta[lane] = tm;
-#pragma unroll
-        for (int k = 0; k < W; ++k) L.ring_rack[k * KAS_RING_CAP + lane] = (int16_t)tr[k];
-      }
-      ring_count = rest;
-      kasw::sync();
-    }
-  }
-  if (fail_row < 0 && ring_count > 0) {
-    const int32_t fl = p4_window<W>(L, ring_count, cap, live_count, head, out, ow, st);
-    if (fl >= 0) fail_row = L.ring_p[fl];
-  }
+  int32_t fail_row = fast
+      ? fill_pass_b<W>(L, T, nm, live_count, head, ring_count, moved_r, moved_p, st)
+      : p3p4_generic<W>(L, T, nm, accmask, live_count, head, ring_count, moved_r, moved_p, st);
+  if (fail_row < 0) fail_row = drain_ring<W>(L, T, 1, live_count, head, ring_count, st);
   { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
   if (fail_row >= 0) {                                       // KAS:183-184
     res.status = KAS_FAIL_UNASSIGNABLE;
-    res.fail_partition = pid_arr ? pid_arr[fail_row] : fail_row;
+    res.fail_partition = T.pid_arr ? T.pid_arr[fail_row] : fail_row;
     return res;
   }
   kasw::sync();   // P4's out-row stores are visible to P5's loads; region A is dead from here
 
   // ---- P5: preference lists (KAS:62, 202-239) ------------------------------------------------
   // rotation offsets idx_m = Math.abs(hash) % m for every set size m (KAS:190, via KAS:267)
+  constexpr int CS = cnt_stride<W>();
   int32_t idxm[W + 1];
 #pragma unroll
   for (int m = 1; m <= W; ++m) idxm[m] = java_abs_mod(hash, m);
   idxm[0] = 0;
-  for (int32_t i = lane; i < N; i += 64) L.owner[i] = 0u;
-  kasw::sync();
-  uint32_t epoch = 0;
+  const bool hash_min = hash == (int32_t)0x80000000;
+  for (int32_t i = lane; i < N; i += 64) L.dep[i] = 0ull;
+  if (fast && !a.hist_separate)                  // the histogram lived in the counters' LDS
+    for (int32_t i = lane; i < N * CS; i += 64) L.cnt[i] = 0;
+  kasw::lockstep();
   bool hash_fail = false;
   uint64_t digest = 0;
+  const uint64_t mybit = 1ull << lane;
+  int32_t nx[W];                                  // next tile's out row (software prefetch)
+#pragma unroll
+  for (int k = 0; k < W; ++k) nx[k] = (lane < P && k < ow) ? out[(int64_t)lane * ow + k] : -1;
   for (int32_t tile = 0; tile < nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
     const bool active = p < P;
@@ -399,11 +643,13 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
     int32_t Lp = 0;
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      h[k] = 0x7fffffff;
-      if (active && k < ow) {
-        const int32_t v = out[(int64_t)p * ow + k];
-        if (v >= 0) { h[k] = v; Lp += 1; }
-      }
+      h[k] = nx[k] >= 0 ? nx[k] : 0x7fffffff;
+      Lp += nx[k] >= 0 ? 1 : 0;
+    }
+    {
+      const int32_t pn = p + 64;
+#pragma unroll
+      for (int k = 0; k < W; ++k) nx[k] = (pn < P && k < ow) ? out[(int64_t)pn * ow + k] : -1;
     }
     // Sets.newTreeSet(preferenceList) (KAS:228): ascending node index == ascending broker id
 #pragma unroll
@@ -415,72 +661,86 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
         h[k] = lo; h[k + 1] = hi;
       }
     }
-    // KAS:190 index error: some set size m <= L has a negative rotation offset
-    bool bad = false;
+    if (hash_min) {
+      // KAS:190 index error: some set size m <= L has a negative rotation offset
+      bool bad = false;
 #pragma unroll
-    for (int m = 1; m <= W; ++m) bad = bad || (m <= Lp && idxm[m] < 0);
-    if (kasw::ballot(bad) != 0) { hash_fail = true; break; }
-
+      for (int m = 1; m <= W; ++m) bad = bad || (m <= Lp && idxm[m] < 0);
+      if (kasw::ballot(bad) != 0) { hash_fail = true; break; }
+    }
     bool pending = active && Lp > 0;
+    // node index per list position, clamped so that unused positions address node 0
+    int32_t hn[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) hn[k] = (pending && k < Lp) ? h[k] : 0;
+
+    // Which lower lanes share a node with me?  One 64-bit lane mask per node, or-ed in by every
+    // lane holding that node; a row may commit once none of those lower lanes is still pending.
+    if (pending) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (k < Lp) kasw::lds_atomic_or_u64(&L.dep[hn[k]], mybit);
+    }
+    kasw::lockstep();
+    uint64_t share = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) share |= (pending && k < Lp) ? L.dep[hn[k]] : 0ull;
+    kasw::lockstep();
+    if (pending) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (k < Lp) L.dep[hn[k]] = 0ull;
+    }
+    const uint64_t depmask = share & lt;
+
     int32_t lst[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) lst[k] = -1;
     for (;;) {
-      if (kasw::ballot(pending) == 0) break;
-      epoch += 1;
+      const uint64_t pend = kasw::ballot(pending);
+      if (pend == 0) break;
       st[6] += 1;
-      const uint32_t key = (epoch << 6) | (uint32_t)(63 - lane);
-      if (pending) {
+      const bool ready = pending && (depmask & pend) == 0;
+      // count[node][0..W) of my nodes (KAS:280-301); every lane computes, ready lanes commit
+      int32_t c[W][W];
 #pragma unroll
-        for (int k = 0; k < W; ++k) if (k < Lp) kasw::lds_atomic_max(&L.owner[h[k]], key);
+      for (int k = 0; k < W; ++k) load_cnt_row<W>(c[k], L.cnt + hn[k] * CS);
+      uint32_t alive = pending ? ((1u << Lp) - 1u) : 0u;   // sorted-set positions still in nodeSet
+      int32_t pick[W], newc[W];
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        // getLeastSeenNodeForReplicaId (KAS:263-278): the element of sorted rank i is visited at
+        // position (i + idx_m) % m; the first visited strictly smallest count wins, i.e. the
+        // minimum of (count, visit position)
+        const int32_t m = __builtin_popcount(alive);
+        const int32_t idx = sel<W + 1>(idxm, m);
+        int32_t keys[W];
+        int32_t best = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          int32_t rr = __builtin_popcount(alive & ((1u << k) - 1u)) + idx;
+          rr -= rr >= m ? m : 0;
+          // arithmetic form of "alive bit k ? (count << 3 | rr) : INT_MAX" (no exec branches)
+          const int32_t dead = (int32_t)((((alive >> k) & 1u) - 1u) & 0x7fffffffu);
+          keys[k] = ((c[k][r] << 3) | rr) | dead;
+          best = keys[k] < best ? keys[k] : best;
+        }
+        int32_t pos = 0;
+#pragma unroll
+        for (int k = 1; k < W; ++k) pos = keys[k] == best ? k : pos;
+        pick[r] = sel<W>(hn, pos);
+        newc[r] = (best >> 3) + 1;
+        alive &= ~(1u << pos);                             // nodeSet.remove (KAS:232)
       }
-      kasw::sync();
-      bool ready = pending;
-#pragma unroll
-      for (int k = 0; k < W; ++k) if (k < Lp) ready = ready && (L.owner[pending ? h[k] : 0] == key);
       if (ready) {
-        int32_t c[W][W];
-#pragma unroll
-        for (int k = 0; k < W; ++k)
-#pragma unroll
-          for (int r = 0; r < W; ++r)
-            c[k][r] = (k < Lp && r < Lp) ? L.cnt[h[k] * W + r] : 0;
-        uint32_t alive = (1u << Lp) - 1u;                 // positions of the sorted set still in nodeSet
-        int32_t m = Lp;
 #pragma unroll
         for (int r = 0; r < W; ++r) {
           if (r < Lp) {
-            // getLeastSeenNodeForReplicaId (KAS:263-278): visit order[j] = S[(j + m - idx) % m]
-            const int32_t off = m - sel<W + 1>(idxm, m);
-            int32_t best_pos = -1, best_cnt = 0;
-#pragma unroll
-            for (int jj = 0; jj < W; ++jj) {
-              if (jj < m) {
-                int32_t q = jj + off; if (q >= m) q -= m;   // rank inside the remaining set
-                // position of the q-th alive element
-                int32_t pos = -1, seen = 0;
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                  const bool al = (alive >> k) & 1u;
-                  if (al && seen == q && pos < 0) pos = k;
-                  seen += al ? 1 : 0;
-                }
-                int32_t cv = 0;
-#pragma unroll
-                for (int k = 0; k < W; ++k) cv = (pos == k) ? c[k][r] : cv;
-                if (best_pos < 0 || cv < best_cnt) { best_pos = pos; best_cnt = cv; }   // KAS:270
-              }
-            }
-            alive &= ~(1u << best_pos);                    // nodeSet.remove (KAS:232)
-            m -= 1;
-            const int32_t node = sel<W>(h, best_pos);
-            lst[r] = node;
-            L.cnt[node * W + r] = best_cnt + 1;            // updateCountersFromList (KAS:254-261)
+            lst[r] = pick[r];
+            L.cnt[pick[r] * CS + r] = newc[r];             // updateCountersFromList (KAS:254-261)
           }
         }
         pending = false;
       }
-      kasw::sync();
+      kasw::lockstep();
     }
     if (active) {
 #pragma unroll
@@ -510,11 +770,12 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
   const int lane = kasw::lane();
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
-  const KasLds lay = kas_lds_layout(a.n_max, W, a.idmap_entries, a.need_bsearch);
+  const KasLds lay = kas_lds_layout(a.n_max, W, a.idmap_entries, a.need_bsearch, a.hist_separate);
   LdsView L;
   L.cnt = (int32_t*)(lds_raw + lay.off_cnt);
-  L.owner = (uint32_t*)(lds_raw + lay.off_owner);
+  L.dep = (uint64_t*)(lds_raw + lay.off_dep);
   L.load = (int32_t*)(lds_raw + lay.off_load);
+  L.hist = (int32_t*)(lds_raw + lay.off_hist);
   L.rack = (int16_t*)(lds_raw + lay.off_rack);
   L.live = (int16_t*)(lds_raw + lay.off_live);
   L.idmap = (int16_t*)(lds_raw + lay.off_idmap);
@@ -540,8 +801,8 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     const int32_t rk = g_node_rack[i];
     bad = bad || id <= prev || rk < 0 || rk > 32767;
 #pragma unroll
-    for (int r = 0; r < W; ++r)
-      L.cnt[i * W + r] = (has_ctx && r < ctxw) ? g_ctx[(int64_t)i * ctxw + r] : 0;
+    for (int r = 0; r < cnt_stride<W>(); ++r)
+      L.cnt[i * cnt_stride<W>() + r] = (has_ctx && r < W && r < ctxw) ? g_ctx[(int64_t)i * ctxw + r] : 0;
   }
   const bool nodes_bad = kasw::ballot(bad) != 0;
   NodeMap nm;
@@ -568,7 +829,8 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = solve_topic<W>(a, td, (uint32_t)k, L, nm, g_node_id, g_node_rack, accmask, st);
+    else o = solve_topic<W>(a, td, (uint32_t)k, L, nm, g_node_id, g_node_rack, accmask,
+                            /*cnt_live=*/has_ctx || k > 0, st);
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding
       int32_t* out = a.out + td.out_off;
@@ -591,7 +853,7 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     for (int32_t i = lane; i < N; i += 64)
 #pragma unroll
       for (int r = 0; r < W; ++r)
-        if (r < ctxw) g_ctx[(int64_t)i * ctxw + r] = L.cnt[i * W + r];
+        if (r < ctxw) g_ctx[(int64_t)i * ctxw + r] = L.cnt[i * cnt_stride<W>() + r];
   }
   const uint64_t dsum = kasw::wave_sum_u64(digest);
   if (lane == 0) {

@@ -35,6 +35,14 @@ KAS_DEV void lockstep() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Identity the optimiser cannot see through.  Used on the elements of small register tables
+// before a select chain: without it LLVM folds "select(i==j, a[j], ...)" back into a
+// dynamically indexed load and the table moves to scratch (= global memory).
+KAS_DEV int32_t opaque(int32_t v) {
+  asm("" : "+v"(v));
+  return v;
+}
+
 KAS_DEV int popc(uint64_t m) { return __popcll((unsigned long long)m); }
 
 // index of the lowest set bit; m must be non-zero
@@ -43,6 +51,10 @@ KAS_DEV int first_lane(uint64_t m) { return __ffsll((unsigned long long)m) - 1; 
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { return atomicAdd(p, v); }
+
+KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) {
+  __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 

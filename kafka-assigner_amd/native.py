@@ -22,7 +22,7 @@ SYMBOLS = [
     "kas_abi_version", "kas_strerror", "kas_status_string", "kas_last_error", "kas_device_count",
     "kas_ctx_create", "kas_ctx_destroy", "kas_ctx_synchronize", "kas_plan_create",
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
-    "kas_plan_kernel_time_us", "kas_plan_stats",
+    "kas_plan_kernel_time_us", "kas_plan_stats", "kas_plan_set_flags",
 ]
 
 _LIB = None
@@ -71,6 +71,8 @@ def load():
     L.kas_solve_host.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
     L.kas_plan_kernel_time_us.restype = C.c_int
     L.kas_plan_kernel_time_us.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.kas_plan_set_flags.restype = C.c_int
+    L.kas_plan_set_flags.argtypes = [C.c_void_p, C.c_uint32]
     L.kas_plan_stats.restype = C.c_int
     L.kas_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64]
     if L.kas_abi_version() != abi.KAS_ABI_VERSION:
@@ -132,6 +134,9 @@ class Plan:
         t.topic_results = topic_results or None; t.scenario_results = scenario_results or None
         _check(self._lib.kas_solve_device(self._h, C.byref(t), C.c_void_p(stream) if stream else None))
 
+    def set_flags(self, flags: int):
+        _check(self._lib.kas_plan_set_flags(self._h, flags))
+
     def stats(self) -> np.ndarray:
         """Per-scenario device counters of the last solve: int64 [S, 8] =
         (setup, P2, P3+P4, P5 time in 10 ns ticks; P4 windows, P4 node steps, P5 rounds,
@@ -176,4 +181,33 @@ def solve_host(fb: FlatBatch, ctx: Optional[DeviceContext] = None) -> HostOutput
     bd = batch_desc(fb)
     t, ho = host_tables(fb)
     _check(L.kas_solve_host(ctx._h, C.byref(bd), C.byref(t)))
+    return ho
+
+
+def solve_host_with_flags(fb: FlatBatch, flags: int, ctx: Optional[DeviceContext] = None) -> HostOutputs:
+    """Same as solve_host but through plan + device tables so plan flags can be set."""
+    import torch
+    ctx = ctx or default_context()
+    dev = torch.device("cuda", ctx.device)
+    plan = Plan(ctx, fb)
+    plan.set_flags(flags)
+    _, ho = host_tables(fb)
+    d_cur = torch.from_numpy(fb.cur).to(dev)
+    d_aux = torch.from_numpy(fb.aux).to(dev) if fb.aux.size else None
+    d_ctx = torch.from_numpy(ho.ctx).to(dev) if ho.ctx.size else None
+    d_out = torch.full((max(fb.out_len, 1),), -2, dtype=torch.int32, device=dev)
+    d_tr = torch.zeros(max(fb.n_topics, 1) * 16, dtype=torch.uint8, device=dev)
+    d_sr = torch.zeros(max(fb.n_scenarios, 1) * 32, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
+                      aux=d_aux.data_ptr() if d_aux is not None else 0,
+                      ctx=d_ctx.data_ptr() if d_ctx is not None else 0, stream=st.cuda_stream)
+    st.synchronize()
+    ho.out = d_out.cpu().numpy()
+    ho.topic_results = d_tr.cpu().numpy().view(abi.TOPIC_RESULT_DTYPE)
+    ho.scenario_results = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
+    if d_ctx is not None:
+        ho.ctx = d_ctx.cpu().numpy()
+    plan.close()
     return ho

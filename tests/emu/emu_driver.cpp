@@ -74,7 +74,7 @@ template <int W> void run_one(void* p) {
 }  // namespace
 
 extern "C" __attribute__((visibility("default")))
-int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, char* errbuf, int errlen) {
+int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen) {
   KasShape sh;
   std::string err;
   int rc = kas_shape_batch(b, &sh, &err);
@@ -90,23 +90,19 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, char* errb
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data(); a.stats = nullptr;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
-  a.need_bsearch = sh.need_bsearch;
+  a.need_bsearch = sh.need_bsearch; a.hist_separate = sh.hist_separate; a.flags = flags;
   for (int32_t s = 0; s < b->n_scenarios; ++s) {
     memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
     RunArgs ra{&a, s, lds.data(), sh.W};
     void (*fn)(void*) = nullptr;
-    switch (sh.W) {
-      case 1: case 2: fn = run_one<2>; break;
+    switch (sh.Wc) {                       // the same width classes the product launcher uses
+      case 2: fn = run_one<2>; break;
       case 3: fn = run_one<3>; break;
       case 4: fn = run_one<4>; break;
       case 5: fn = run_one<5>; break;
       default: fn = run_one<8>; break;
     }
-    // the kernel templates are instantiated for W in {2,3,4,5,8}; the LDS carve must use the
-    // instantiated width, exactly as the product launcher does
-    int Wi = sh.W <= 2 ? 2 : sh.W <= 5 ? sh.W : 8;
-    KasLds lay = kas_lds_layout(sh.n_max, Wi, sh.idmap_entries, sh.need_bsearch);
-    if ((size_t)lay.total + 64 > lds.size()) lds.resize((size_t)lay.total + 64, 0xCD);
+    if ((size_t)sh.lds.total + 64 > lds.size()) lds.resize((size_t)sh.lds.total + 64, 0xCD);
     ra.lds = lds.data();
     if (kasw::run_wave(fn, &ra) != 0) {
       if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence in scenario %d", s);

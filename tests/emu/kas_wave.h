@@ -65,11 +65,15 @@ KAS_DEV int shfl(int v, int src_lane) {
 KAS_DEV void sync() { rendezvous(K_SYNC); }
 KAS_DEV void lockstep() { rendezvous(K_LOCKSTEP); }
 
+KAS_DEV int32_t opaque(int32_t v) { return v; }
+
 KAS_DEV int popc(uint64_t m) { return __builtin_popcountll(m); }
 KAS_DEV int first_lane(uint64_t m) { return __builtin_ctzll(m); }
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
+
 KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 
 KAS_DEV uint64_t load_shared_u64(const uint64_t* p) { return *(const volatile uint64_t*)p; }

@@ -34,16 +34,16 @@ def lib():
         L = C.CDLL(build_emu())
         L.kas_emu_solve_batch.restype = C.c_int
         L.kas_emu_solve_batch.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
-                                          C.c_char_p, C.c_int]
+                                          C.c_uint, C.c_char_p, C.c_int]
         _LIB = L
     return _LIB
 
 
-def emu_solve(fb: FlatBatch) -> HostOutputs:
+def emu_solve(fb: FlatBatch, flags: int = 0) -> HostOutputs:
     bd = batch_desc(fb)
     t, ho = host_tables(fb)
     err = C.create_string_buffer(512)
-    rc = lib().kas_emu_solve_batch(C.byref(bd), C.byref(t), err, 512)
+    rc = lib().kas_emu_solve_batch(C.byref(bd), C.byref(t), flags, err, 512)
     if rc != 0:
         raise RuntimeError(f"kas_emu_solve_batch rc={rc}: {err.value.decode()}")
     return ho

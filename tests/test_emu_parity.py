@@ -22,7 +22,9 @@ def test_emu_equals_oracle_small_odd_inputs(sc):
     brokers, racks, topics = sc
     fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=True,
                            topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
-    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu")
+    want = oracle_solve(fb)
+    assert_same_outputs(fb, want, emu_solve(fb), "emu")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
 
 
 def _batch(seed, S, P, N, R, RF, actions, rack_aware=True, cyclic=False, name_hash=3644):
@@ -62,6 +64,7 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
     # the generator must produce solvable scenarios most of the time, else the test is vacuous
     assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 1
 

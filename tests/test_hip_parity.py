@@ -43,7 +43,10 @@ def test_hip_equals_oracle_small_odd_inputs(sc):
 ])
 def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
-    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip")
+    want = oracle_solve(fb)
+    assert_same_outputs(fb, want, native.solve_host(fb), "hip")
+    # the general multi-sweep sticky fill must agree with the rack-diverse single-scan form
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
 
 
 def test_hip_rack_awareness_disabled_cyclic_and_sparse_ids():
@@ -74,6 +77,7 @@ def test_config3_shape_full_size_scenarios():
     want = oracle_solve(fb)
     got = native.solve_host(fb)
     assert_same_outputs(fb, want, got, "C3")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 4
 
 
