@@ -5,7 +5,9 @@ One "step" = one solve of one batch of synthetic cluster scenarios by the HIP pa
 bulk table already resident in HBM.  At N=1 the workload is BASELINE.json configs[2] — the
 configuration the metric is quoted on: a batch of 1k independent scenarios of 100k partitions x
 1k brokers x 20 racks, RF 3, each with its own current assignment G(seed+s) and its own broker-set
-perturbation drawn from {remove 1, remove k<=5, add k<=50, replace 1}.  With
+perturbation drawn from {remove 1, remove k<=5, add k<=50, remove k<=5 + add j<=50} (SURVEY.md
+8d; 'replace 1' is excluded because the reference itself throws on most such scenarios, see
+generator.BENCH_ACTIONS).  With
 --gpus N every rank solves its own 1k scenarios (weak scaling) and each step ends with the ONE
 data-path collective of the design: an RCCL all-gather of the 32-byte per-scenario result records.
 
@@ -52,6 +54,9 @@ def main() -> int:
                     help="batches in flight: steps are issued round-robin on this many HIP streams, "
                          "each with its own plan scratch and output tables")
     ap.add_argument("--stats", default="", help="write the per-phase device counters (JSON) here")
+    ap.add_argument("--waves", type=int, default=int(os.environ.get("KAS_BENCH_WAVES", "0")),
+                    help="wavefronts per scenario workgroup (0 = the plan's choice)")
+    ap.add_argument("--plan-flags", type=int, default=0, help="KAS_PLAN_* switches (testing)")
     args = ap.parse_args()
 
     import torch
@@ -79,7 +84,7 @@ def main() -> int:
     d_cur = G.torch_random_assignment(gen, S, P, N, R, RF, dev)          # int32 [S, P, RF]
     actions, ids, racks = [], [], []
     for s in range(S):
-        act, bs = G.scenario_action(args.seed, first + s, N, R)
+        act, bs = G.scenario_action(args.seed, first + s, N, R, actions=G.BENCH_ACTIONS)
         actions.append(act); ids.append(bs.node_id); racks.append(bs.node_rack)
     fb = node_set_batch(ids, racks, P, RF, RF)
     ctx = native.DeviceContext(local_rank)
@@ -91,7 +96,10 @@ def main() -> int:
     n_slots = max(1, min(args.in_flight, args.steps))
     slots = []
     for _ in range(n_slots):
-        sl = {"plan": native.Plan(ctx, fb),
+        plan_ = native.Plan(ctx, fb)
+        if args.waves or args.plan_flags:
+            plan_.set_flags((args.waves << 8) | args.plan_flags)
+        sl = {"plan": plan_,
               "out": torch.empty(fb.out_len, dtype=torch.int32, device=dev),
               "tr": torch.zeros(S * 16, dtype=torch.uint8, device=dev),
               "sr": torch.zeros(S * 32, dtype=torch.uint8, device=dev),
@@ -139,7 +147,8 @@ def main() -> int:
     kern_us = kern_us / kern_n if kern_n else 0.0
     if args.stats and rank == 0:
         st = plan.stats().astype(np.float64)
-        names = ["setup_us", "p2_us", "p3p4_us", "p5_us", "p4_windows", "p4_steps", "p5_rounds", "p2_overflow_tiles"]
+        names = ["setup_us", "p2_hist_quota_us", "p2_keep_p3_p4_us", "p5_us", "p4_windows", "p4_steps",
+                 "p5_iterations_wave0", "p2_ranked_tiles_wave0"]
         scale = [0.01, 0.01, 0.01, 0.01, 1, 1, 1, 1]
         summary = {n: {"mean": float(st[:, i].mean() * scale[i]), "max": float(st[:, i].max() * scale[i]),
                        "min": float(st[:, i].min() * scale[i])} for i, n in enumerate(names)}
@@ -212,11 +221,11 @@ def main() -> int:
             "config": {
                 "workload": f"BASELINE.json configs[2]: batch of {S} independent scenarios per GPU, "
                             f"{P} partitions x {N} brokers x {R} racks, RF {RF}; per-scenario G(seed+s) "
-                            f"current assignment + action in {{remove1, remove<=5, add<=50, replace1}}",
+                            f"current assignment + action in {{remove1, remove<=5, add<=50, remove<=5+add<=50}}",
                 "scenarios_per_gpu": S, "partitions": P, "brokers": N, "racks": R, "rf": RF,
                 "ok_scenarios_rank0": ok, "failed_scenarios_rank0": S - ok,
-                "failed_note": "failures are the reference's own KAS:183-184 stranding (mostly "
-                               "replace1: zero slack at N=1000, cap=300) and are parity-checked",
+                "failed_note": "a failed scenario is the reference's own KAS:183-184 stranding, "
+                               "reproduced bit-exactly (status + partition id)",
                 "parity_checked_scenarios": checked,
                 "collective": "all_gather of 32-byte result records per step" if world > 1 else "none (1 GPU)",
                 "batches_in_flight": n_slots,

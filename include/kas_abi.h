@@ -212,14 +212,19 @@ int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* 
 int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
 
 /* Per-scenario device counters of the plan's most recent solve (after it completed):
- * out[s*8 + 0..3] = time spent in setup / P2 sticky fill / P3+P4 orphans / P5 preference order,
- * in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
- * [6] P5 conflict rounds, [7] P2 tiles that needed overflow ranking.  n = capacity of out in
+ * out[s*8 + 0..3] = time spent in setup / P2 histogram+quota / P2 keep-scan+P3+P4 / P5 preference
+ * order, in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
+ * [6] P5 loop iterations of wave 0, [7] P2 tiles of wave 0 that needed quota ranking.  n = capacity of out in
  * int64 elements (>= 8 * n_scenarios).  Blocks until the plan's last launch has finished. */
-/* Behaviour switches of a plan (default 0).  KAS_PLAN_GENERIC_FILL: always run the general
- * multi-sweep sticky fill instead of the rack-diverse single-scan form (same results; exists so
- * both forms can be tested and timed on the same inputs). */
+/* Behaviour switches of a plan (default 0); every combination produces identical results, they
+ * exist so that the alternative forms can be tested and timed on the same inputs.
+ *   KAS_PLAN_GENERIC_FILL  always run the general multi-sweep sticky fill instead of the
+ *                          rack-diverse histogram/quota form
+ *   KAS_PLAN_ROUND_ORDER   always run the tile-round preference ordering instead of the ticket form
+ *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup: 1, 2, 4 or 8 (0 = the plan's choice) */
 #define KAS_PLAN_GENERIC_FILL 1u
+#define KAS_PLAN_ROUND_ORDER  2u
+#define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
 
 #define KAS_STATS_PER_SCENARIO 8

@@ -1,15 +1,17 @@
 // kas_hip.hip — gfx950 kernels + the C ABI of include/kas_abi.h (libkas_hip.so).
 //
-// One workgroup of one wavefront per scenario; the grid is the batch.  Scenarios share nothing,
-// so there is no inter-workgroup communication at all: each wavefront streams its own cur table
-// from HBM (coalesced 64-row tiles), keeps broker load / rack / Context counters in LDS and
-// writes its own out rows and one 32-byte result record.  Workgroup b lands on XCD b % 8; in the
-// what-if layout (many scenarios over one shared cur table) neighbouring scenarios therefore
-// spread the shared table over all eight L2s, and the 256 MiB Infinity Cache holds it once.
+// One workgroup of NW wavefronts per scenario; the grid is the batch.  Scenarios share nothing,
+// so there is no inter-workgroup communication at all: each workgroup streams its own cur table
+// from HBM (coalesced 64-row tiles per wave), keeps broker load / rack / quota / Context counters
+// in LDS and writes its own out rows and one 32-byte result record.  Workgroup b lands on XCD
+// b % 8; in the what-if layout (many scenarios over one shared cur table) neighbouring scenarios
+// therefore spread the shared table over all eight L2s, and the 256 MiB Infinity Cache holds it
+// once.
 #define KAS_ABI_FN __host__ __device__ static inline
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -22,21 +24,30 @@
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(64) void kas_solve_kernel(KasLaunch a) {
+template <int W, int NW>
+__global__ __launch_bounds__(64 * NW) void kas_solve_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
-    kas::solve_scenario<W>(a, s, kas_lds);
+    kas::solve_scenario<W, NW>(a, s, kas_lds);
 }
 
 typedef void (*kas_kernel_fn)(KasLaunch);
-static kas_kernel_fn kas_kernel_for(int Wc) {
+template <int NW>
+static kas_kernel_fn kas_kernel_for_w(int Wc) {
   switch (Wc) {
-    case 2: return kas_solve_kernel<2>;
-    case 3: return kas_solve_kernel<3>;
-    case 4: return kas_solve_kernel<4>;
-    case 5: return kas_solve_kernel<5>;
-    default: return kas_solve_kernel<8>;
+    case 2: return kas_solve_kernel<2, NW>;
+    case 3: return kas_solve_kernel<3, NW>;
+    case 4: return kas_solve_kernel<4, NW>;
+    case 5: return kas_solve_kernel<5, NW>;
+    default: return kas_solve_kernel<8, NW>;
+  }
+}
+static kas_kernel_fn kas_kernel_for(int Wc, int NW) {
+  switch (NW) {
+    case 1: return kas_kernel_for_w<1>(Wc);
+    case 2: return kas_kernel_for_w<2>(Wc);
+    case 8: return kas_kernel_for_w<8>(Wc);
+    default: return kas_kernel_for_w<4>(Wc);
   }
 }
 
@@ -68,6 +79,7 @@ struct kas_plan {
   kas_ctx* ctx;
   KasShape shape;
   int Wc;                       // instantiated width class
+  int NW;                       // wavefronts per scenario workgroup
   uint32_t flags;               // KAS_FLAG_*
   KasLds lds;
   int32_t n_scenarios, n_topics;
@@ -78,6 +90,8 @@ struct kas_plan {
   int32_t* d_node_rack;
   int64_t* d_accmask_off;
   uint64_t* d_accmask;
+  int64_t* d_orph_off;
+  int32_t* d_orph;
   int64_t* d_stats;
   hipStream_t last_stream;
   // kernel timing: event pairs recorded around every launch on the launch stream
@@ -167,6 +181,7 @@ void kas_plan_destroy(kas_plan* p) {
   (void)hipFree(p->d_scen); (void)hipFree(p->d_topics);
   (void)hipFree(p->d_node_id); (void)hipFree(p->d_node_rack);
   (void)hipFree(p->d_accmask_off); (void)hipFree(p->d_accmask); (void)hipFree(p->d_stats);
+  (void)hipFree(p->d_orph_off); (void)hipFree(p->d_orph);
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
     if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
@@ -187,7 +202,7 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   *out_plan = nullptr;
   KasShape sh;
   std::string err;
-  int rc = kas_shape_batch(batch, &sh, &err);
+  int rc = kas_shape_batch(batch, &sh, &err, 0);
   if (rc != KAS_E_OK) return set_error(rc, err);
   KAS_HIP_TRY(hipSetDevice(ctx->device));
 
@@ -196,11 +211,13 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   memset((void*)p->ev_stop, 0, sizeof(p->ev_stop));
   p->ctx = ctx; p->shape = sh;
   p->Wc = sh.Wc;
+  p->NW = sh.NW;
   p->lds = sh.lds;
   p->flags = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
   p->d_accmask_off = nullptr; p->d_accmask = nullptr; p->d_stats = nullptr; p->last_stream = ctx->stream;
+  p->d_orph_off = nullptr; p->d_orph = nullptr;
   p->timer_next = 0; p->timer_count = 0;
   if (p->lds.total > KAS_LDS_LIMIT) {
     delete p;
@@ -218,6 +235,11 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
     hipError_t e = hipMalloc((void**)&p->d_accmask, sizeof(uint64_t) * (size_t)(sh.accmask_words + 1));
     if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "accept-mask scratch: " + std::string(hipGetErrorString(e))); }
   }
+  KAS_PLAN_TRY(upload((void**)&p->d_orph_off, sh.orph_off.data(), sizeof(int64_t) * sh.orph_off.size(), st));
+  {
+    hipError_t e = hipMalloc((void**)&p->d_orph, sizeof(int32_t) * (size_t)(sh.orph_ints + 64));
+    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "orphan-list scratch: " + std::string(hipGetErrorString(e))); }
+  }
   {
     size_t sb = sizeof(int64_t) * KAS_STATS_PER_SCENARIO * (size_t)(batch->n_scenarios + 1);
     hipError_t e = hipMalloc((void**)&p->d_stats, sb);
@@ -231,7 +253,7 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
     }
   }
   {
-    hipError_t e = hipFuncSetAttribute((const void*)kas_kernel_for(p->Wc),
+    hipError_t e = hipFuncSetAttribute((const void*)kas_kernel_for(p->Wc, p->NW),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p->lds.total);
     if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     e = hipStreamSynchronize(st);   // descriptors are resident before the caller may free its copies
@@ -259,13 +281,14 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off; a.stats = p->d_stats;
+  a.orph = p->d_orph; a.orph_off = p->d_orph_off; a.nw = p->NW;
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
   a.hist_separate = p->shape.hist_separate; a.flags = p->flags;
   const int slot = p->timer_next;
   KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
-  hipLaunchKernelGGL(kas_kernel_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
+  hipLaunchKernelGGL(kas_kernel_for(p->Wc, p->NW), dim3((unsigned)p->n_scenarios), dim3(64u * (unsigned)p->NW),
                      (size_t)p->lds.total, st, a);
   KAS_HIP_TRY(hipGetLastError());
   KAS_HIP_TRY(hipEventRecord(p->ev_stop[slot], st));
@@ -295,7 +318,21 @@ int kas_plan_kernel_time_us(kas_plan* p, double* avg_us, int* launches) {
 
 int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   if (!p) return set_error(KAS_E_INVALID_ARG, "plan == NULL");
-  p->flags = flags;
+  const int nw = (int)((flags >> 8) & 0xfu);
+  if (nw != 0 && nw != p->NW) {
+    if (nw != 1 && nw != 2 && nw != 4 && nw != 8)
+      return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_WAVES: waves per scenario must be 1, 2, 4 or 8");
+    const KasShape& sh = p->shape;
+    KasLds l = kas_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch, sh.hist_separate);
+    if (l.total > KAS_LDS_LIMIT)
+      return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at that many waves");
+    KAS_HIP_TRY(hipSetDevice(p->ctx->device));
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_kernel_for(p->Wc, nw),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, l.total));
+    p->lds = l;
+    p->NW = nw;
+  }
+  p->flags = flags & 0xffu;
   return KAS_E_OK;
 }
 

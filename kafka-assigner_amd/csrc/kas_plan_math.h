@@ -23,6 +23,8 @@ struct KasLaunch {
   kas_scenario_result* scenario_results;
   uint64_t* accmask;            // scratch: accept-mask ballot words, one region per scenario
   const int64_t* accmask_off;   // [n_scenarios] offset of the region in 64-bit words
+  int32_t* orph;                // scratch: orphan row lists, one region per scenario
+  const int64_t* orph_off;      // [n_scenarios] offset of the region in int32 elements
   int64_t* stats;               // [n_scenarios][KAS_STATS_PER_SCENARIO] device counters, or NULL
   int32_t n_scenarios;
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
@@ -30,26 +32,33 @@ struct KasLaunch {
   int32_t need_bsearch;         // some scenario's id range exceeds idmap_entries
   int32_t hist_separate;        // the sweep histogram has its own LDS (else it aliases cnt)
   uint32_t flags;               // KAS_FLAG_*
+  int32_t nw;                   // wavefronts per workgroup the kernel was launched with
 };
 
 #define KAS_FLAG_GENERIC_FILL 1u   // always use the general sticky fill (testing / comparison)
-// rows of the sweep histogram: one per replica index, at least 3 (reused as quota/running/r*)
-#define KAS_HIST_ROWS(W) ((W) < 3 ? 3 : (W))
+#define KAS_FLAG_ROUND_ORDER  2u   // always use the tile-round preference ordering (testing / comparison)
 
-// Byte offsets into the workgroup's dynamic LDS.  Region B (owner) aliases region A (load,
-// rack, live, idmap, ids, ring): A is live during P2-P4, B during P5, and the per-topic setup
-// rebuilds A.  Only the Context counters persist across the topics of a scenario.
+// Byte offsets into the workgroup's dynamic LDS (one workgroup of NW wavefronts per scenario).
+//   cnt     Context counters; the only state that persists across the topics of a scenario
+//   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]; aliases cnt unless a
+//           scenario carries Context state into a topic (hist_separate)
+//   region A (P2-P4): load, qrs, rack, live, idmap, ids, ring
+//   region T (P5, aliases region A): run, dep, nid
+//   ctl     control words + per-wave digest slots
 struct KasLds {
-  int32_t off_cnt;     // int32  [n_max * CS]  Context counters (KAS:244-302), CS = kas_cnt_stride(W)
-  int32_t off_dep;     // uint64 [n_max]       P5 lane-sharing masks per node      (region B)
-  int32_t off_hist;    // int32  [max(W,3)*n_max] sweep histogram of the rack-diverse fill; aliases
-                       //                      off_cnt unless a scenario carries Context state
-  int32_t off_load;    // int32  [n_max]       |Node.assignedPartitions|           (region A)
-  int32_t off_rack;    // int16  [n_max]       dense rack index per node
-  int32_t off_live;    // int16  [n_max]       non-full nodes in processing order
+  int32_t off_cnt;     // int32  [n_max * CS]   count[node][replica index] (KAS:244-302)
+  int32_t off_x;       // int32  [max(W,NW)][n_max]
+  int32_t off_load;    // int32  [n_max]        |Node.assignedPartitions|
+  int32_t off_qrs;     // int32  [n_max]        saturating sweep r* << 28 | quota in that sweep
+  int32_t off_rack;    // int16  [n_max]        dense rack index per node
+  int32_t off_live;    // int16  [n_max]        non-full nodes in processing order
   int32_t off_idmap;   // int16  [idmap_entries] broker id - min_id -> node index
-  int32_t off_ids;     // int32  [n_max]       sorted ids for binary search (only if needed)
-  int32_t off_ring;    // orphan ring: p[128] int32, meta[128] int32, rack[W][128] int16
+  int32_t off_ids;     // int32  [n_max]        sorted ids for binary search (only if needed)
+  int32_t off_ring;    // orphan window: p[128] int32, meta[128] int32, rack[W][128] int16
+  int32_t off_run;     // int32  [n_max]        tickets handed out per node          (region T)
+  int32_t off_dep;     // uint64 [n_max]        lane-sharing masks per node          (region T)
+  int32_t off_nid;     // int32  [n_max]        broker id per node index             (region T)
+  int32_t off_ctl;     // int32  [KAS_CTL_INTS] + uint64 [NW] digest slots
   int32_t total;
 };
 
@@ -57,35 +66,52 @@ struct KasLds {
 #define KAS_LDS_LIMIT (160 * 1024)
 #define KAS_IDMAP_CAP 16384
 #define KAS_N_LIMIT 32767
+#define KAS_MAX_WAVES 8
+#define KAS_CTL_INTS 32
+// control words
+#define KAS_CTL_VIOL 0        // some row's replicas are not rack-diverse
+#define KAS_CTL_FAILROW 1     // first row P4 could not place (KAS:183-184), or -1
+#define KAS_CTL_WM 2          // tiles the ticket pass has published
+#define KAS_CTL_MOVED_R 3
+#define KAS_CTL_MOVED_P 4
+#define KAS_CTL_MAXT 5        // largest ticket any row can get (decides the packed format)
+#define KAS_CTL_HASHFAIL 6
+#define KAS_CTL_OC 8          // [NW] orphans found per chunk
 
 KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_t)15); }
 
 // Counter row stride in ints: 3-wide rows are padded to 4 so a row is one 16-byte LDS read.
 KAS_ABI_FN int32_t kas_cnt_stride(int32_t W) { return W == 3 ? 4 : W; }
 
-KAS_ABI_FN KasLds kas_lds_layout(int32_t n_max, int32_t W, int32_t idmap_entries,
+KAS_ABI_FN KasLds kas_lds_layout(int32_t n_max, int32_t W, int32_t NW, int32_t idmap_entries,
                                     int32_t need_bsearch, int32_t hist_separate) {
   KasLds L;
   int64_t n = n_max > 0 ? n_max : 1;
   int64_t o = 0;
-  const int64_t cnt_bytes = 4 * n * kas_cnt_stride(W), hist_bytes = 4 * n * KAS_HIST_ROWS(W);
+  const int64_t xr = W > NW ? W : NW;
+  const int64_t cnt_bytes = 4 * n * kas_cnt_stride(W), x_bytes = 4 * n * xr;
   L.off_cnt = (int32_t)o;
   if (hist_separate) {
     o = kas_align16(o + cnt_bytes);
-    L.off_hist = (int32_t)o; o = kas_align16(o + hist_bytes);
+    L.off_x = (int32_t)o; o = kas_align16(o + x_bytes);
   } else {
-    L.off_hist = (int32_t)o; o = kas_align16(o + (cnt_bytes > hist_bytes ? cnt_bytes : hist_bytes));
+    L.off_x = (int32_t)o; o = kas_align16(o + (cnt_bytes > x_bytes ? cnt_bytes : x_bytes));
   }
-  int64_t base = o;
-  L.off_dep = (int32_t)base;
-  int64_t endB = kas_align16(base + 8 * n);
+  const int64_t base = o;
+  L.off_run = (int32_t)base;
+  L.off_dep = kas_align16(base + 4 * n);
+  L.off_nid = kas_align16((int64_t)L.off_dep + 8 * n);
+  const int64_t endT = kas_align16((int64_t)L.off_nid + 4 * n);
   L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n);
+  L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
   L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
   L.off_live = (int32_t)o;  o = kas_align16(o + 2 * n);
   L.off_idmap = (int32_t)o; o = kas_align16(o + 2 * (int64_t)(idmap_entries > 0 ? idmap_entries : 1));
   L.off_ids = (int32_t)o;   if (need_bsearch) o = kas_align16(o + 4 * n);
   L.off_ring = (int32_t)o;  o = kas_align16(o + KAS_RING_CAP * (4 + 4 + 2 * (int64_t)W));
-  L.total = (int32_t)(o > endB ? o : endB);
+  o = o > endT ? o : endT;
+  L.off_ctl = (int32_t)o;   o = kas_align16(o + 4 * KAS_CTL_INTS + 8 * KAS_MAX_WAVES);
+  L.total = (int32_t)o;
   return L;
 }
 
@@ -101,19 +127,26 @@ struct KasShape {
   int32_t hist_separate = 0;          // some scenario has several topics or a Context
   std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
   int64_t accmask_words = 0;
+  std::vector<int64_t> orph_off;      // per scenario, in int32 elements
+  int64_t orph_ints = 0;
+  int32_t NW = 1;                     // wavefronts per scenario workgroup (1, 2, 4 or 8)
   int64_t algorithmic_bytes = 0;
   int64_t cur_need = 0, out_need = 0, aux_need = 0, ctx_need = 0;  // minimum pool lengths
   KasLds lds{};
 };
 
 // Validate descriptors and derive everything a launch needs.  Returns KAS_E_* and fills err.
-static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::string* err) {
+static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::string* err,
+                                  int want_waves = 0) {
   auto fail = [&](int code, const std::string& m) { if (err) *err = m; return code; };
+  if (want_waves != 0 && want_waves != 1 && want_waves != 2 && want_waves != 4 && want_waves != 8)
+    return fail(KAS_E_INVALID_ARG, "waves per scenario must be 1, 2, 4 or 8");
   if (!b || b->n_scenarios < 0 || b->n_topics < 0) return fail(KAS_E_INVALID_ARG, "null/negative batch");
   if (b->n_scenarios > 0 && (!b->scenarios)) return fail(KAS_E_INVALID_ARG, "scenarios == NULL");
   if (b->n_topics > 0 && !b->topics) return fail(KAS_E_INVALID_ARG, "topics == NULL");
   KasShape s;
   s.accmask_off.assign((size_t)b->n_scenarios, 0);
+  s.orph_off.assign((size_t)b->n_scenarios, 0);
   int64_t max_range_fit = 0;
   for (int32_t i = 0; i < b->n_scenarios; ++i) {
     const kas_scenario_desc& sd = b->scenarios[i];
@@ -140,7 +173,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     }
     if (sd.n_nodes > s.n_max) s.n_max = sd.n_nodes;
     s.algorithmic_bytes += 8ll * sd.n_nodes;
-    int64_t words = 0;
+    int64_t words = 0, rows = 0;
     for (int32_t k = 0; k < sd.topic_count; ++k) {
       const kas_topic_desc& td = b->topics[sd.topic_begin + k];
       std::string where = "scenario " + std::to_string(i) + " topic " + std::to_string(k) + ": ";
@@ -164,23 +197,33 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       }
       int64_t w = (int64_t)td.cur_width * ((P + 63) / 64);
       if (w > words) words = w;
+      if (((P + 63) / 64) * 64 > rows) rows = ((P + 63) / 64) * 64;
       s.algorithmic_bytes += 4ll * P * (td.cur_width + td.out_width);
     }
     s.accmask_off[(size_t)i] = s.accmask_words;
     s.accmask_words += words > 0 ? words : 1;
+    s.orph_off[(size_t)i] = s.orph_ints;
+    s.orph_ints += rows > 0 ? rows : 64;
   }
   s.idmap_entries = (int32_t)max_range_fit;
   s.Wc = kas_width_class(s.W);
-  s.lds = kas_lds_layout(s.n_max, s.Wc, s.idmap_entries, s.need_bsearch, s.hist_separate);
-  if (s.lds.total > KAS_LDS_LIMIT && s.hist_separate) {
-    // no room for a separate histogram: alias it with the counters; topics that carry Context
-    // state then use the general sticky fill
-    s.hist_separate = 0;
-    s.lds = kas_lds_layout(s.n_max, s.Wc, s.idmap_entries, s.need_bsearch, 0);
+  // widest workgroup whose LDS carve-up fits: 4 wavefronts per scenario by default
+  int err_total = 0;
+  for (int nw = want_waves > 0 ? want_waves : 4; nw >= 1; nw >>= 1) {
+    int hs = s.hist_separate;
+    KasLds l = kas_lds_layout(s.n_max, s.Wc, nw, s.idmap_entries, s.need_bsearch, hs);
+    if (l.total > KAS_LDS_LIMIT && hs) {
+      // no room for a separate histogram: alias it with the counters; topics that carry Context
+      // state then use the general sticky fill
+      hs = 0;
+      l = kas_lds_layout(s.n_max, s.Wc, nw, s.idmap_entries, s.need_bsearch, 0);
+    }
+    err_total = l.total;
+    if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = nw; s.hist_separate = hs; err_total = 0; break; }
   }
-  if (s.lds.total > KAS_LDS_LIMIT)
+  if (err_total)
     return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +
-                std::to_string(s.Wc) + " needs " + std::to_string(s.lds.total) +
+                std::to_string(s.Wc) + " needs " + std::to_string(err_total) +
                 " B of LDS (limit 163840)");
   *sh = s;
   return KAS_E_OK;

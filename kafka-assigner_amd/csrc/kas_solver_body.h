@@ -1,37 +1,48 @@
-// kas_solver_body.h — the per-scenario solver, one 64-lane wavefront per scenario.
+// kas_solver_body.h — the per-scenario solver: one workgroup of NW 64-lane wavefronts per
+// scenario, all of the scenario's node state in that workgroup's LDS.
 //
 // Computes exactly what KafkaAssignmentStrategy.getRackAwareAssignment computes
 // (KafkaAssignmentStrategy.java:40-63, "KAS"), for every topic of a scenario in order, with the
 // pre-checks of KafkaTopicAssigner.generateAssignment (KafkaTopicAssigner.java:65-69, "KTA").
 // The reference is sequential; each phase below is an order-preserving parallel formulation
-// whose result is identical to the sequential one:
+// whose result is identical to the sequential one (DESIGN.md "Exact parallel formulations"):
 //
 //  P0  cap = (int)ceil((double)(int)(P*rf)/N)                                     KAS:65-71
-//  P2  sticky fill (KAS:101-131): sweep r = 0..cur_width-1 over 64-row tiles in ascending row
-//      order, lane = row.  A replica is eligible iff its broker is a node and its rack is not
-//      held by an earlier accepted replica of the same row.  Eligible lanes whose node is not
-//      yet full bump load[n] with one LDS atomic; only when a node overflows inside a tile are
-//      that node's lanes ranked by ballot (lane order == row order) and the first cap-load
-//      kept.  The accepted lanes of (sweep, tile) are one 64-bit ballot word in HBM scratch.
-//  P3  orphans (KAS:133-160): rf - accepted per row; rows are compacted in ascending order
-//      into an LDS ring of 64-orphan windows.
-//  P4  first fit (KAS:162-186): the reference walks order[0..] for each orphan in turn.  Cell
-//      (orphan i, node position j) depends only on (i, j'<j) and (i'<i, j), so the grid is
-//      evaluated position-major: for each non-full node in processing order, the lanes that
-//      still need a replica and may use that rack ballot, and the first cap-load[n] of them (in
-//      lane == orphan order) take it.  Full nodes never become non-full, so only a compacted
-//      list of non-full nodes is walked (the reference spends >99% of its probes on them).
-//  P5  preference order (KAS:202-239): row p reads count[n][0..L) of its own nodes, picks, then
-//      increments L counters, so rows conflict only when they share a node.  64 ascending rows
-//      per tile; once per tile every lane ors its lane bit into a 64-bit LDS mask per node it
-//      holds and reads those masks back, so it knows which LOWER lanes share a node with it.
-//      Each round a lane none of whose lower sharers is still pending commits; the rest retry.
-//      Lane order == row order, so the result is the sequential one.  The pick itself is the
-//      minimum of (count << 3 | visit position): "first strictly smaller in rotated order".
+//  P2  sticky fill (KAS:101-131), rack-diverse form.  When every row's valid replicas sit on
+//      pairwise different racks the rack test of canAccept can never fail during the fill, so a
+//      node keeps its first `cap` candidates in (replica index, row) order independently of
+//      every other node:
+//        A1  all waves, tiles interleaved: hist[r][n] = candidates of sweep r on node n (LDS
+//            atomics) and the proof of rack diversity
+//        Q   per node: the one sweep r* in which it saturates and its quota q there
+//        A2  row range cut into NW chunks, wave w counts chunk w's sweep-r* candidates per node;
+//            a prefix over chunks turns that into the quota left when chunk w starts
+//        B   wave w walks chunk w in row order: replica (p, r) on n is kept iff r < r*(n), or
+//            r == r*(n) and its rank among n's sweep-r* candidates is below the quota (ranked
+//            by ballot only in the one tile where the quota runs out).  P3 (KAS:133-160) runs
+//            in the same scan: holders -> out row (node indices), movement counts, and the
+//            orphan rows appended to the chunk's list in HBM scratch (ascending).
+//      General form (rows that are not rack-diverse, or no LDS for the histogram): one sweep per
+//      replica index over 64-row tiles by wave 0, accept masks as ballot words in HBM scratch.
+//  P4  first fit (KAS:162-186), wave 0: orphans in ascending row order, 64 per window, evaluated
+//      position-major over the compacted list of non-full nodes in processing order (a full
+//      node never becomes non-full; the reference spends >99% of its probes on them).
+//  P5  preference order (KAS:202-239).  Row p reads count[n][0..L) of its own nodes, picks, then
+//      increments one counter per node, so it only has to wait for the EARLIER rows that hold
+//      one of its nodes.  Ticket form: a scan in row order hands every (row, node) its ticket =
+//      how many earlier rows hold that node (+ the node's counter sum at topic start), packed
+//      into the out row next to the node index.  Since every committed row adds exactly 1 to
+//      the counter row of each of its nodes, "sum of count[n][*] == ticket" says that all
+//      earlier rows on n have committed: lanes then work on rows independently (row = lane +
+//      k * lanes), spin on their tickets, pick and commit — no tile-wide rounds, any number of
+//      waves.  The last wave of the workgroup hands out tickets and publishes a watermark; the
+//      other waves follow it.  Round form (kept for ticket overflow and the KAS:190 index
+//      error): 64 ascending rows per tile, a lane commits once no lower lane sharing a node
+//      is pending.
 //
-// Everything cross-lane goes through kas_wave.h; all control flow around those calls is
-// wave-uniform.  List positions live in registers through fully unrolled loops (W is a
-// template parameter) — no dynamically indexed private arrays.
+// Everything cross-lane goes through kas_wave.h; control flow around wave collectives is
+// wave-uniform and around kasw::sync() workgroup-uniform.  List positions live in registers
+// through fully unrolled loops (W is a template parameter).
 #pragma once
 #include <stdint.h>
 
@@ -46,14 +57,14 @@ struct TopicOutcome {
   int32_t fail_partition;
   int32_t moved_replicas;
   int32_t moved_partitions;
-  uint64_t digest;   // per-lane partial; summed over the wave by the caller
+  uint64_t digest;
 };
 
 struct LdsView {
   int32_t* cnt;
-  uint64_t* dep;
+  int32_t* x;           // hist[W][N], then qc[NW][N]
   int32_t* load;
-  int32_t* hist;     // [KAS_HIST_ROWS(W)][N]: sweep histogram, then quota / running / r*
+  int32_t* qrs;
   int16_t* rack;
   int16_t* live;
   int16_t* idmap;
@@ -61,6 +72,11 @@ struct LdsView {
   int32_t* ring_p;
   int32_t* ring_meta;
   int16_t* ring_rack;   // [W][KAS_RING_CAP]
+  int32_t* run;
+  uint64_t* dep;
+  int32_t* nid;
+  int32_t* ctl;
+  uint64_t* dig;        // [NW]
 };
 
 struct NodeMap {
@@ -135,6 +151,10 @@ KAS_DEV void put(int32_t (&a)[W], int32_t i, int32_t v) {
   for (int j = 0; j < W; ++j) a[j] = (i == j) ? v : a[j];
 }
 
+// first tile of chunk w when nt tiles are cut into NW contiguous chunks
+template <int NW>
+KAS_DEV int32_t chunk_begin(int32_t nt, int32_t w) { return (int32_t)(((int64_t)nt * w) / NW); }
+
 // ---------------------------------------------------------------------------------------------
 // P4 window: up to 64 orphans (lane = orphan, ascending row order), position-major first fit.
 // Returns -1, or the lane index of the first orphan that cannot be fully assigned (KAS:183).
@@ -151,7 +171,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
   int32_t hr[W];
 #pragma unroll
   for (int j = 0; j < W; ++j) hr[j] = mine ? (int32_t)L.ring_rack[j * KAS_RING_CAP + lane] : -1;
-  kasw::lockstep();   // ring fully read before the caller shifts it
+  kasw::lockstep();   // ring fully read before the caller refills it
 
   int32_t fail_lane = -1;
   int32_t j = head;
@@ -194,6 +214,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
 struct TopicView {
   const int32_t* cur;
   int32_t* out;
+  int32_t* orph;        // orphan row lists of this scenario (HBM scratch)
   const int32_t* len_arr;
   const int32_t* inp_arr;
   const int32_t* pid_arr;
@@ -210,18 +231,19 @@ KAS_DEV void load_row(const TopicView& T, int32_t p, int32_t (&ids)[W], int32_t&
 }
 
 // ---------------------------------------------------------------------------------------------
-// P3 for one tile (KAS:133-160): holders of the row from its accepted replicas, orphan count,
-// movement bookkeeping, the out row (node indices for now) and the orphan ring.
+// P3 for one row per lane (KAS:133-160): holders of the row from its accepted replicas, orphan
+// count, movement bookkeeping and the out row (node indices for now).
 // ---------------------------------------------------------------------------------------------
 template <int W>
-KAS_DEV void p3_tile(const LdsView& L, const TopicView& T, int32_t p, int32_t len,
+KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t len,
                      const int32_t (&ids)[W], const int32_t (&idx)[W], uint32_t accbits,
-                     int32_t& ring_count, int32_t& moved_r, int32_t& moved_p) {
+                     int32_t& need, int32_t& hc, int32_t (&hrack)[W], int32_t& moved_r,
+                     int32_t& moved_p) {
   const bool active = p < T.P;
-  int32_t hold[W], hrack[W];
+  int32_t hold[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) { hold[k] = -1; hrack[k] = -1; }
-  int32_t hc = 0;
+  hc = 0;
 #pragma unroll
   for (int r = 0; r < W; ++r) {
     const bool acc = (accbits >> r) & 1u;
@@ -240,7 +262,7 @@ KAS_DEV void p3_tile(const LdsView& L, const TopicView& T, int32_t p, int32_t le
     for (int k = 0; k < W; ++k) if (k < T.ow) T.out[(int64_t)p * T.ow + k] = hold[k];
   }
   const bool in_parts = active && (T.inp_arr ? T.inp_arr[p] != 0 : true);
-  const int32_t need = in_parts ? (T.rf - hc > 0 ? T.rf - hc : 0) : 0;   // KAS:151-157
+  need = in_parts ? (T.rf - hc > 0 ? T.rf - hc : 0) : 0;   // KAS:151-157
   // a distinct current broker that was not kept => set(new) != set(cur)
   uint32_t kept_else = 0;
 #pragma unroll
@@ -252,7 +274,12 @@ KAS_DEV void p3_tile(const LdsView& L, const TopicView& T, int32_t p, int32_t le
   const bool dropped = (present & ~accbits & ~kept_else) != 0u;
   moved_r += need;
   moved_p += (active && (dropped || need > 0)) ? 1 : 0;
+}
 
+// append this tile's orphans (ascending lane == ascending row) to the LDS ring
+template <int W>
+KAS_DEV void ring_push(const LdsView& L, int32_t p, int32_t need, int32_t hc,
+                       const int32_t (&hrack)[W], int32_t& ring_count) {
   const bool orphan = need > 0;
   const uint64_t om = kasw::ballot(orphan);
   if (orphan) {
@@ -299,6 +326,7 @@ KAS_DEV int32_t drain_ring(const LdsView& L, const TopicView& T, int32_t min_fil
 
 // ---------------------------------------------------------------------------------------------
 // P2, general form (KAS:101-131): one sweep per replica index, accept-mask words in HBM.
+// Executed by ONE wave (the other waves of the workgroup wait at the next barrier).
 // ---------------------------------------------------------------------------------------------
 template <int W>
 KAS_DEV void fill_generic_sweeps(const LdsView& L, const TopicView& T, const NodeMap& nm,
@@ -351,156 +379,17 @@ KAS_DEV void fill_generic_sweeps(const LdsView& L, const TopicView& T, const Nod
       const uint64_t accw = kasw::ballot(accepted);
       if (lane == 0) kasw::store_shared_u64(accmask + (int64_t)r * nt + tile, accw);
     }
-    kasw::sync();   // this sweep's mask words are visible to the next sweep's loads
+    kasw::wave_sync();   // this sweep's mask words are visible to the next sweep's loads
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// P2, rack-diverse form.  When every row's valid replicas sit on pairwise different racks, the
-// rack test of canAccept can never fail during the sticky fill (the only members of a rack's
-// set for row p are p's own earlier replicas), so a node simply keeps its first `cap`
-// candidates in (replica index, row) order, independently of every other node.
-//   pass A: hist[r][n] = candidates of sweep r on node n; also proves rack diversity
-//   quota : per node the one sweep r* in which it saturates and how many it still takes there
-//   pass B: replica (p, r) on n is kept iff r < r*(n), or r == r*(n) and its rank among n's
-//           sweep-r* candidates (row order) is below the quota — all replicas of a row at once,
-//           with P3 and P4 running in the same scan.
-// ---------------------------------------------------------------------------------------------
-template <int W>
-KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm) {
-  const int lane = kasw::lane();
-  const int32_t N = T.N;
-  for (int32_t i = lane; i < N * KAS_HIST_ROWS(W); i += 64) L.hist[i] = 0;
-  kasw::lockstep();
-  bool viol = false;
-  int32_t nx[W], nlen;
-  load_row<W>(T, lane, nx, nlen);
-  for (int32_t tile = 0; tile < T.nt; ++tile) {
-    const int32_t p = (tile << 6) + lane;
-    int32_t ids[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) ids[r] = nx[r];
-    const int32_t len = nlen;
-    load_row<W>(T, p + 64, nx, nlen);                       // prefetch the next tile
-    int32_t idx[W], rk[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) {
-      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
-      rk[r] = idx[r] >= 0 ? (int32_t)L.rack[idx[r]] : -1 - r;   // invalid: never equal
-    }
-#pragma unroll
-    for (int r = 1; r < W; ++r)
-#pragma unroll
-      for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[r] == rk[r2];
-#pragma unroll
-    for (int r = 0; r < W; ++r) if (idx[r] >= 0) kasw::lds_atomic_add(&L.hist[r * N + idx[r]], 1);
-  }
-  kasw::lockstep();
-  return kasw::ballot(viol) == 0;
-}
-
-// hist[0][n] <- quota in the saturating sweep, hist[1][n] <- running count (0), hist[2][n] <- r*
-template <int W>
-KAS_DEV void fill_quota(const LdsView& L, const TopicView& T) {
-  const int lane = kasw::lane();
-  const int32_t N = T.N;
-  for (int32_t n = lane; n < N; n += 64) {
-    int32_t cum = 0, rs = W, q = 0;
-#pragma unroll
-    for (int r = 0; r < W; ++r) {
-      const int32_t c = L.hist[r * N + n];
-      const bool sat = rs == W && c > T.cap - cum;          // cum + c > cap, overflow-safe
-      q = sat ? T.cap - cum : q;
-      cum = rs == W ? (sat ? T.cap : cum + c) : cum;
-      rs = sat ? r : rs;
-    }
-    L.load[n] = cum;
-    L.hist[n] = q;
-    L.hist[N + n] = 0;
-    L.hist[2 * N + n] = rs;
-  }
-  kasw::lockstep();
-}
-
-template <int W>
-KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t live_count,
-                            int32_t& head, int32_t& ring_count, int32_t& moved_r, int32_t& moved_p,
-                            int64_t (&st)[8]) {
-  const int lane = kasw::lane();
-  const uint64_t lt = kasw::lanemask_lt();
-  const int32_t N = T.N;
-  int32_t nx[W], nlen;
-  load_row<W>(T, lane, nx, nlen);
-  for (int32_t tile = 0; tile < T.nt; ++tile) {
-    const int32_t p = (tile << 6) + lane;
-    int32_t ids[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) ids[r] = nx[r];
-    const int32_t len = nlen;
-    load_row<W>(T, p + 64, nx, nlen);
-    int32_t idx[W], nn[W], q[W], before[W];
-    uint32_t sure = 0, counting = 0;
-#pragma unroll
-    for (int r = 0; r < W; ++r) {
-      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
-      nn[r] = idx[r] >= 0 ? idx[r] : 0;
-      const int32_t rs = L.hist[2 * N + nn[r]];
-      sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
-      counting |= (idx[r] >= 0 && r == rs) ? (1u << r) : 0u;
-      q[r] = L.hist[nn[r]];
-      before[r] = L.hist[N + nn[r]];
-    }
-    uint32_t accbits = sure;
-    if (kasw::ballot(counting != 0u) != 0) {
-      kasw::lockstep();                                     // every lane saw the pre-tile counts
-#pragma unroll
-      for (int r = 0; r < W; ++r) if ((counting >> r) & 1u) kasw::lds_atomic_add(&L.hist[N + nn[r]], 1);
-      kasw::lockstep();
-      uint32_t contested = 0;
-#pragma unroll
-      for (int r = 0; r < W; ++r) {
-        const int32_t after = L.hist[N + nn[r]];
-        const bool cnt = (counting >> r) & 1u;
-        accbits |= (cnt && after <= q[r]) ? (1u << r) : 0u;
-        contested |= (cnt && before[r] < q[r] && after > q[r]) ? (1u << r) : 0u;
-      }
-      uint64_t todo = kasw::ballot(contested != 0u);
-      if (todo != 0) {
-        st[7] += 1;
-        // the quota boundary of some node falls inside this tile: rank its lanes (row order)
-        while (todo != 0) {
-          const int leader = kasw::first_lane(todo);
-          int32_t mine_t = -1;
-#pragma unroll
-          for (int r = W - 1; r >= 0; --r) mine_t = ((contested >> r) & 1u) ? nn[r] : mine_t;
-          const int32_t t = kasw::shfl(mine_t, leader);
-          uint32_t hit = 0;                                  // my replica counted on node t
-#pragma unroll
-          for (int r = 0; r < W; ++r) hit |= (((counting >> r) & 1u) && nn[r] == t) ? (1u << r) : 0u;
-          const uint64_t same = kasw::ballot(hit != 0u);
-          const int32_t rank = kasw::popc(same & lt);
-#pragma unroll
-          for (int r = 0; r < W; ++r)
-            accbits |= (((hit >> r) & 1u) && before[r] + rank < q[r]) ? (1u << r) : 0u;
-          contested &= ~hit;
-          todo = kasw::ballot(contested != 0u);
-        }
-      }
-    }
-    p3_tile<W>(L, T, p, len, ids, idx, accbits, ring_count, moved_r, moved_p);
-    const int32_t fr = drain_ring<W>(L, T, 64, live_count, head, ring_count, st);
-    if (fr >= 0) return fr;
-  }
-  return -1;
-}
-
-// P3 + P4 over the accept-mask words of the general sticky fill
+// P3 + P4 over the accept-mask words of the general sticky fill (one wave)
 template <int W>
 KAS_DEV int32_t p3p4_generic(const LdsView& L, const TopicView& T, const NodeMap& nm,
-                             const uint64_t* accmask, int32_t live_count, int32_t& head,
-                             int32_t& ring_count, int32_t& moved_r, int32_t& moved_p,
-                             int64_t (&st)[8]) {
+                             const uint64_t* accmask, int32_t live_count, int32_t& moved_r,
+                             int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();
+  int32_t ring_count = 0, head = 0;
   for (int32_t tile = 0; tile < T.nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
     int32_t ids[W], idx[W], len;
@@ -517,121 +406,434 @@ KAS_DEV int32_t p3p4_generic(const LdsView& L, const TopicView& T, const NodeMap
         }
       }
     }
-    p3_tile<W>(L, T, p, len, ids, idx, accbits, ring_count, moved_r, moved_p);
+    int32_t need, hc, hrack[W];
+    p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p);
+    ring_push<W>(L, p, need, hc, hrack, ring_count);
     const int32_t fr = drain_ring<W>(L, T, 64, live_count, head, ring_count, st);
     if (fr >= 0) return fr;
+  }
+  return drain_ring<W>(L, T, 1, live_count, head, ring_count, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// P2, rack-diverse form: passes A1, Q, A2, prefix, B (see the header comment).
+// ---------------------------------------------------------------------------------------------
+// A1: tiles wave, wave+NW, ... ; returns this lane's "not rack-diverse" verdict
+template <int W, int NW>
+KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
+  const int lane = kasw::lane();
+  const int32_t N = T.N;
+  bool viol = false;
+  int32_t nx[W], nlen;
+  load_row<W>(T, (wave << 6) + lane, nx, nlen);
+  for (int32_t tile = wave; tile < T.nt; tile += NW) {
+    const int32_t p = (tile << 6) + lane;
+    int32_t ids[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) ids[r] = nx[r];
+    const int32_t len = nlen;
+    load_row<W>(T, p + 64 * NW, nx, nlen);                  // prefetch this wave's next tile
+    int32_t idx[W], rk[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
+      rk[r] = idx[r] >= 0 ? (int32_t)L.rack[idx[r]] : -1 - r;   // invalid: never equal
+    }
+#pragma unroll
+    for (int r = 1; r < W; ++r)
+#pragma unroll
+      for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[r] == rk[r2];
+#pragma unroll
+    for (int r = 0; r < W; ++r) if (idx[r] >= 0) kasw::lds_atomic_add(&L.x[r * N + idx[r]], 1);
+  }
+  return viol;
+}
+
+// Q: load[n] <- replicas the node keeps, qrs[n] <- r* << 28 | quota in sweep r*; the chunk rows
+// of x (which alias the histogram rows of the same node) are cleared, or set to the quota when
+// there is only one chunk.
+template <int W, int NW>
+KAS_DEV void fill_quota(const LdsView& L, const TopicView& T, int32_t tid) {
+  const int32_t N = T.N;
+  for (int32_t n = tid; n < N; n += 64 * NW) {
+    int32_t cum = 0, rs = W, q = 0;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      const int32_t c = L.x[r * N + n];
+      const bool sat = rs == W && c > T.cap - cum;          // cum + c > cap, overflow-safe
+      q = sat ? T.cap - cum : q;
+      cum = rs == W ? (sat ? T.cap : cum + c) : cum;
+      rs = sat ? r : rs;
+    }
+    L.load[n] = cum;
+    L.qrs[n] = (int32_t)(((uint32_t)rs << 28) | (uint32_t)q);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) L.x[w * N + n] = NW == 1 ? q : 0;
+  }
+}
+
+// A2: wave w counts the sweep-r* candidates of chunk w per node
+template <int W, int NW>
+KAS_DEV void fill_chunk_count(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
+  const int lane = kasw::lane();
+  const int32_t N = T.N;
+  const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
+  int32_t* qc = L.x + wave * N;
+  int32_t nx[W], nlen;
+  load_row<W>(T, (t0 << 6) + lane, nx, nlen);
+  for (int32_t tile = t0; tile < t1; ++tile) {
+    const int32_t p = (tile << 6) + lane;
+    int32_t ids[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) ids[r] = nx[r];
+    const int32_t len = nlen;
+    load_row<W>(T, p + 64, nx, nlen);
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      const int32_t i = r < len ? node_lookup(L, nm, ids[r]) : -1;
+      if (i >= 0 && (int32_t)((uint32_t)L.qrs[i] >> 28) == r) kasw::lds_atomic_add(&qc[i], 1);
+    }
+  }
+}
+
+// prefix over chunks: x[w][n] <- quota of node n still unused when chunk w starts
+template <int NW>
+KAS_DEV void fill_chunk_prefix(const LdsView& L, const TopicView& T, int32_t tid) {
+  const int32_t N = T.N;
+  for (int32_t n = tid; n < N; n += 64 * NW) {
+    int32_t rem = L.qrs[n] & 0x0fffffff;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int32_t c = L.x[w * N + n];
+      L.x[w * N + n] = rem;
+      rem -= c;
+    }
+  }
+}
+
+// B + P3 over chunk `wave`; orphans go to the chunk's list; returns the number of orphans
+template <int W, int NW>
+KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave,
+                            int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
+  const int lane = kasw::lane();
+  const uint64_t lt = kasw::lanemask_lt();
+  const int32_t N = T.N;
+  const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
+  int32_t* qc = L.x + wave * N;
+  int32_t* olist = T.orph + ((int64_t)t0 << 6);
+  int32_t ocount = 0;
+  int32_t nx[W], nlen;
+  load_row<W>(T, (t0 << 6) + lane, nx, nlen);
+  for (int32_t tile = t0; tile < t1; ++tile) {
+    const int32_t p = (tile << 6) + lane;
+    int32_t ids[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) ids[r] = nx[r];
+    const int32_t len = nlen;
+    load_row<W>(T, p + 64, nx, nlen);
+    int32_t idx[W], nn[W], before[W];
+    uint32_t sure = 0, counting = 0;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
+      nn[r] = idx[r] >= 0 ? idx[r] : 0;
+      const int32_t rs = (int32_t)((uint32_t)L.qrs[nn[r]] >> 28);
+      sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
+      counting |= (idx[r] >= 0 && r == rs) ? (1u << r) : 0u;
+      before[r] = qc[nn[r]];                                // quota left before this tile
+    }
+    uint32_t accbits = sure;
+    if (kasw::ballot(counting != 0u) != 0) {
+      kasw::lockstep();                                     // every lane saw the pre-tile quota
+#pragma unroll
+      for (int r = 0; r < W; ++r) if ((counting >> r) & 1u) kasw::lds_atomic_add(&qc[nn[r]], -1);
+      kasw::lockstep();
+      uint32_t contested = 0;
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        const int32_t after = qc[nn[r]];
+        const bool cnt = (counting >> r) & 1u;
+        accbits |= (cnt && after >= 0) ? (1u << r) : 0u;
+        contested |= (cnt && before[r] > 0 && after < 0) ? (1u << r) : 0u;
+      }
+      uint64_t todo = kasw::ballot(contested != 0u);
+      if (todo != 0) {
+        st[7] += 1;
+        // the quota of some node runs out inside this tile: rank its lanes (row order)
+        while (todo != 0) {
+          const int leader = kasw::first_lane(todo);
+          int32_t mine_t = -1;
+#pragma unroll
+          for (int r = W - 1; r >= 0; --r) mine_t = ((contested >> r) & 1u) ? nn[r] : mine_t;
+          const int32_t t = kasw::shfl(mine_t, leader);
+          uint32_t hit = 0;                                  // my replica counted on node t
+#pragma unroll
+          for (int r = 0; r < W; ++r) hit |= (((counting >> r) & 1u) && nn[r] == t) ? (1u << r) : 0u;
+          const uint64_t same = kasw::ballot(hit != 0u);
+          const int32_t rank = kasw::popc(same & lt);
+#pragma unroll
+          for (int r = 0; r < W; ++r)
+            accbits |= (((hit >> r) & 1u) && rank < before[r]) ? (1u << r) : 0u;
+          contested &= ~hit;
+          todo = kasw::ballot(contested != 0u);
+        }
+      }
+    }
+    int32_t need, hc, hrack[W];
+    p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p);
+    const uint64_t om = kasw::ballot(need > 0);
+    if (need > 0) olist[ocount + kasw::popc(om & lt)] = p;
+    ocount += kasw::popc(om);
+  }
+  return ocount;
+}
+
+// P4 over the chunk lists, in chunk order == ascending row order.  One wave.
+template <int W, int NW>
+KAS_DEV int32_t p4_lists(const LdsView& L, const TopicView& T, int32_t live_count, int64_t (&st)[8]) {
+  const int lane = kasw::lane();
+  int32_t oc[NW], total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { oc[w] = L.ctl[KAS_CTL_OC + w]; total += oc[w]; }
+  int32_t head = 0;
+  for (int32_t g0 = 0; g0 < total; g0 += 64) {
+    const int32_t g = g0 + lane;
+    const bool mine = g < total;
+    int32_t w = 0, base = 0;
+#pragma unroll
+    for (int k = 0; k < NW - 1; ++k) {
+      const bool next = w == k && g >= base + oc[k];
+      base += next ? oc[k] : 0;
+      w += next ? 1 : 0;
+    }
+    int32_t p = 0, hc = 0, hr[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) hr[k] = -1;
+    if (mine) {
+      p = T.orph[((int64_t)chunk_begin<NW>(T.nt, w) << 6) + (g - base)];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const int32_t c = k < T.ow ? T.out[(int64_t)p * T.ow + k] : -1;   // holders are a prefix
+        hr[k] = c >= 0 ? (int32_t)L.rack[c] : -1;
+        hc += c >= 0 ? 1 : 0;
+      }
+      L.ring_p[lane] = p;
+      L.ring_meta[lane] = (T.rf - hc) | (hc << 8);
+#pragma unroll
+      for (int k = 0; k < W; ++k) L.ring_rack[k * KAS_RING_CAP + lane] = (int16_t)hr[k];
+    }
+    kasw::lockstep();
+    const int32_t n_win = total - g0 < 64 ? total - g0 : 64;
+    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.out, T.ow, st);
+    if (fl >= 0) return L.ring_p[fl];
   }
   return -1;
 }
 
 // ---------------------------------------------------------------------------------------------
-// One topic == one getRackAwareAssignment call.
+// P5 helpers
 // ---------------------------------------------------------------------------------------------
+// The picks of one row (KAS:225-236).  hn[0..Lp) = the row's node indices ascending, c[k] = the
+// counter row of hn[k].  getLeastSeenNodeForReplicaId (KAS:263-278): the element of sorted rank i
+// is visited at position (i + idx_m) % m; the first visited strictly smallest count wins, i.e.
+// the minimum of (count, visit position).
 template <int W>
-KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, uint32_t topic_k,
-                                 const LdsView& L, const NodeMap& nm, const int32_t* g_node_id,
-                                 const int32_t* g_node_rack, uint64_t* accmask, bool cnt_live,
-                                 int64_t (&st)[8]) {
+KAS_DEV void pick_row(const int32_t (&hn)[W], const int32_t (&c)[W][W], int32_t Lp, bool valid,
+                      const int32_t (&idxm)[W + 1], int32_t (&pick)[W], int32_t (&newc)[W]) {
+  uint32_t alive = valid ? ((1u << Lp) - 1u) : 0u;       // sorted-set positions still in nodeSet
+#pragma unroll
+  for (int r = 0; r < W; ++r) {
+    const int32_t m = __builtin_popcount(alive);
+    const int32_t idx = sel<W + 1>(idxm, m);
+    int32_t keys[W];
+    int32_t best = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      int32_t rr = __builtin_popcount(alive & ((1u << k) - 1u)) + idx;
+      rr -= rr >= m ? m : 0;
+      // arithmetic form of "alive bit k ? (count << 3 | rr) : INT_MAX" (no exec branches)
+      const int32_t dead = (int32_t)((((alive >> k) & 1u) - 1u) & 0x7fffffffu);
+      keys[k] = ((c[k][r] << 3) | rr) | dead;
+      best = keys[k] < best ? keys[k] : best;
+    }
+    int32_t pos = 0;
+#pragma unroll
+    for (int k = 1; k < W; ++k) pos = keys[k] == best ? k : pos;
+    pick[r] = sel<W>(hn, pos);
+    newc[r] = (best >> 3) + 1;
+    alive &= ~(1u << pos);                               // nodeSet.remove (KAS:232)
+  }
+}
+
+// Sets.newTreeSet(preferenceList) (KAS:228): ascending node index == ascending broker id.
+// cells: node indices or -1; result h[0..Lp) ascending.
+template <int W>
+KAS_DEV void sort_holders(const int32_t (&cells)[W], int32_t (&h)[W], int32_t& Lp) {
+  Lp = 0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    h[k] = cells[k] >= 0 ? cells[k] : 0x7fffffff;
+    Lp += cells[k] >= 0 ? 1 : 0;
+  }
+#pragma unroll
+  for (int pass = 0; pass < W; ++pass) {
+#pragma unroll
+    for (int k = (pass & 1); k + 1 < W; k += 2) {
+      const int32_t lo = h[k] < h[k + 1] ? h[k] : h[k + 1];
+      const int32_t hi = h[k] < h[k + 1] ? h[k + 1] : h[k];
+      h[k] = lo; h[k + 1] = hi;
+    }
+  }
+}
+
+#define KAS_TICKET_SHIFT 15
+#define KAS_TICKET_LIMIT ((1 << 17) - 1)   // tickets must stay below this to fit next to a node index
+
+// Ticket pass (one wave, rows in ascending order): out row <- node index | ticket << 15 per
+// holder, ascending node index; publishes the number of finished tiles in ctl[WM].
+template <int W>
+KAS_DEV void ticket_pass(const LdsView& L, const TopicView& T) {
   const int lane = kasw::lane();
   const uint64_t lt = kasw::lanemask_lt();
-  const int32_t N = nm.n;
-  TopicView T;
-  T.cur = a.cur + td.cur_off;
-  T.out = a.out + td.out_off;
-  T.len_arr = td.cur_len_off >= 0 ? a.aux + td.cur_len_off : nullptr;
-  T.inp_arr = td.in_partitions_off >= 0 ? a.aux + td.in_partitions_off : nullptr;
-  T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
-  T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
-  T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
-  const int32_t P = T.P, ow = T.ow, nt = T.nt, hash = T.hash;
+  const uint64_t mybit = 1ull << lane;
+  const int32_t P = T.P, ow = T.ow;
   int32_t* out = T.out;
-
-  TopicOutcome res;
-  res.status = KAS_OK; res.fail_partition = -1;
-  res.moved_replicas = 0; res.moved_partitions = 0; res.digest = 0;
-
-  int64_t tmark = kasw::clock_ticks();
-  // ---- P0: capacity (KAS:45, 65-71) over |partitions| ---------------------------------------
-  int32_t n_in = P;
-  if (T.inp_arr) {
-    int32_t c = 0;
-    for (int32_t p = lane; p < P; p += 64) c += T.inp_arr[p] != 0 ? 1 : 0;
-    n_in = kasw::wave_sum(c);
-  }
-  T.cap = max_replicas_per_node(N, n_in, T.rf);
-  const int32_t cap = T.cap;
-
-  // ---- per-topic node state (KAS:46, 73-99): region A of the LDS carve-up -------------------
-  for (int32_t i = lane; i < N; i += 64) {
-    L.load[i] = 0;
-    L.rack[i] = (int16_t)g_node_rack[i];
-  }
-  if (nm.range != 0u) {
-    for (uint32_t i = (uint32_t)lane; i < nm.range; i += 64u) L.idmap[i] = (int16_t)-1;
-    kasw::lockstep();
-    for (int32_t i = lane; i < N; i += 64) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
-  } else {
-    for (int32_t i = lane; i < N; i += 64) L.ids[i] = g_node_id[i];
-  }
-  kasw::lockstep();
-  { const int64_t now = kasw::clock_ticks(); st[0] += now - tmark; tmark = now; }
-
-  // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
-  // rack-diverse form when the histogram pass proves it applicable and its LDS table is free
-  // (it aliases the Context counters, which must then not carry state into this topic)
-  bool fast = false;
-  if (T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && (a.hist_separate || !cnt_live))
-    fast = fill_pass_a<W>(L, T, nm);
-  if (fast) fill_quota<W>(L, T);
-  else fill_generic_sweeps<W>(L, T, nm, accmask, st);
-  { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
-
-  // ---- KAS:168: getNodeProcessingOrder(topic, all nodes); runs even with zero orphans -------
-  const int32_t idxN = java_abs_mod(hash, N);
-  if (idxN < 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }
-  const int32_t start = (N - idxN) % N;        // order[j] = sorted[(j + start) % N]
-
-  // non-full nodes in processing order (full nodes can never accept again)
-  int32_t live_count = 0;
-  for (int32_t base = 0; base < N; base += 64) {
-    const int32_t j = base + lane;
-    int32_t n = j + start; if (n >= N) n -= N;
-    const bool is_live = j < N && L.load[n] < cap;
-    const uint64_t m = kasw::ballot(is_live);
-    if (is_live) L.live[live_count + kasw::popc(m & lt)] = (int16_t)n;
-    live_count += kasw::popc(m);
-  }
-  kasw::lockstep();
-
-  // ---- P3 + P4: orphans (KAS:52, 133-160) and first fit (KAS:56, 162-186) -------------------
-  int32_t ring_count = 0, head = 0;
-  int32_t moved_r = 0, moved_p = 0;
-  int32_t fail_row = fast
-      ? fill_pass_b<W>(L, T, nm, live_count, head, ring_count, moved_r, moved_p, st)
-      : p3p4_generic<W>(L, T, nm, accmask, live_count, head, ring_count, moved_r, moved_p, st);
-  if (fail_row < 0) fail_row = drain_ring<W>(L, T, 1, live_count, head, ring_count, st);
-  { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
-  if (fail_row >= 0) {                                       // KAS:183-184
-    res.status = KAS_FAIL_UNASSIGNABLE;
-    res.fail_partition = T.pid_arr ? T.pid_arr[fail_row] : fail_row;
-    return res;
-  }
-  kasw::sync();   // P4's out-row stores are visible to P5's loads; region A is dead from here
-
-  // ---- P5: preference lists (KAS:62, 202-239) ------------------------------------------------
-  // rotation offsets idx_m = Math.abs(hash) % m for every set size m (KAS:190, via KAS:267)
-  constexpr int CS = cnt_stride<W>();
-  int32_t idxm[W + 1];
+  int32_t nx[W];
 #pragma unroll
-  for (int m = 1; m <= W; ++m) idxm[m] = java_abs_mod(hash, m);
-  idxm[0] = 0;
-  const bool hash_min = hash == (int32_t)0x80000000;
-  for (int32_t i = lane; i < N; i += 64) L.dep[i] = 0ull;
-  if (fast && !a.hist_separate)                  // the histogram lived in the counters' LDS
-    for (int32_t i = lane; i < N * CS; i += 64) L.cnt[i] = 0;
-  kasw::lockstep();
-  bool hash_fail = false;
-  uint64_t digest = 0;
+  for (int k = 0; k < W; ++k) nx[k] = (lane < P && k < ow) ? out[(int64_t)lane * ow + k] : -1;
+  for (int32_t tile = 0; tile < T.nt; ++tile) {
+    const int32_t p = (tile << 6) + lane;
+    const bool active = p < P;
+    int32_t h[W], Lp;
+    sort_holders<W>(nx, h, Lp);
+    {
+      const int32_t pn = p + 64;
+#pragma unroll
+      for (int k = 0; k < W; ++k) nx[k] = (pn < P && k < ow) ? out[(int64_t)pn * ow + k] : -1;
+    }
+    const bool holds = active && Lp > 0;
+    int32_t hn[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) hn[k] = (holds && k < Lp) ? h[k] : 0;
+    if (holds) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (k < Lp) kasw::lds_atomic_or_u64(&L.dep[hn[k]], mybit);
+    }
+    kasw::lockstep();
+    uint64_t m[W];
+    int32_t s[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const bool on = holds && k < Lp;
+      m[k] = on ? L.dep[hn[k]] : 0ull;
+      s[k] = on ? L.run[hn[k]] : 0;
+    }
+    kasw::lockstep();
+    if (holds) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if (k < Lp && (m[k] & lt) == 0ull) {               // lowest lane holding this node
+          L.run[hn[k]] = s[k] + kasw::popc(m[k]);
+          L.dep[hn[k]] = 0ull;
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if (k < ow) {
+          const int32_t ticket = s[k] + kasw::popc(m[k] & lt);
+          out[(int64_t)p * ow + k] = (holds && k < Lp) ? (hn[k] | (ticket << KAS_TICKET_SHIFT)) : -1;
+        }
+      }
+    }
+    kasw::wave_sync();                                     // rows + counters of this tile are out
+    if (lane == 0) kasw::publish(&L.ctl[KAS_CTL_WM], tile + 1);
+  }
+}
+
+// Ticket form of P5: this lane owns rows first, first + stride, ...; waits for each row's
+// tickets, picks (KAS:225-233) and commits (KAS:236, 254-261).
+template <int W>
+KAS_DEV void order_rows(const LdsView& L, const TopicView& T, const int32_t (&idxm)[W + 1],
+                        int32_t first, int32_t stride, uint32_t topic_k, uint64_t& digest,
+                        int64_t (&st)[8]) {
+  constexpr int CS = cnt_stride<W>();
+  const int32_t P = T.P, ow = T.ow;
+  int32_t* out = T.out;
+  bool cv = false, nv = false;
+  int32_t cp = 0, np = 0, nxp = first;
+  int32_t hn[W], tk[W], nc[W], Lp = 0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) { hn[k] = 0; tk[k] = 0; nc[k] = -1; }
+  for (;;) {
+    kasw::lockstep();                                      // LDS / global are re-read below
+    const int32_t wm = kasw::observe(&L.ctl[KAS_CTL_WM]);
+    if (!cv && nv) {                                       // next row becomes the current one
+      Lp = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const bool on = nc[k] >= 0;
+        hn[k] = on ? (nc[k] & ((1 << KAS_TICKET_SHIFT) - 1)) : 0;
+        tk[k] = on ? (int32_t)((uint32_t)nc[k] >> KAS_TICKET_SHIFT) : 0;
+        Lp += on ? 1 : 0;
+      }
+      cp = np;
+      cv = Lp > 0;
+      nv = false;
+    }
+    if (!nv && nxp < P && (nxp >> 6) < wm) {               // fetch the row after that
+#pragma unroll
+      for (int k = 0; k < W; ++k) nc[k] = k < ow ? out[(int64_t)nxp * ow + k] : -1;
+      np = nxp;
+      nv = true;
+      nxp += stride;
+    }
+    if (kasw::ballot(cv || nv || nxp < P) == 0) break;
+    if (kasw::ballot(cv) == 0) { kasw::spin_pause(); continue; }
+    st[6] += 1;
+    int32_t c[W][W];
+    bool ready = cv;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      load_cnt_row<W>(c[k], L.cnt + hn[k] * CS);
+      int32_t sum = 0;
+#pragma unroll
+      for (int r = 0; r < W; ++r) sum += c[k][r];
+      ready = ready && (k >= Lp || sum == tk[k]);         // every earlier row on hn[k] committed
+    }
+    if (kasw::ballot(ready) == 0) { kasw::spin_pause(); continue; }   // all waiting on other waves
+    int32_t pick[W], newc[W];
+    pick_row<W>(hn, c, Lp, cv, idxm, pick, newc);
+    if (ready) {
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        if (r < Lp) {
+          L.cnt[pick[r] * CS + r] = newc[r];               // updateCountersFromList (KAS:254-261)
+          const int32_t id = L.nid[pick[r]];
+          out[(int64_t)cp * ow + r] = id;
+          digest += kas_digest_cell(topic_k, (uint32_t)cp, (uint32_t)r, id);
+        }
+      }
+      cv = false;
+    }
+  }
+}
+
+// Round form of P5 (one wave): 64 ascending rows per tile; once per tile every lane ors its
+// lane bit into a 64-bit LDS mask per node it holds and reads those masks back, so it knows
+// which LOWER lanes share a node with it; each round a lane none of whose lower sharers is
+// still pending commits.  Returns true on the KAS:190 index error.
+template <int W>
+KAS_DEV bool order_rounds(const LdsView& L, const TopicView& T, const int32_t (&idxm)[W + 1],
+                          const int32_t* g_node_id, uint32_t topic_k, uint64_t& digest,
+                          int64_t (&st)[8]) {
+  constexpr int CS = cnt_stride<W>();
+  const int lane = kasw::lane();
+  const uint64_t lt = kasw::lanemask_lt();
+  const int32_t P = T.P, ow = T.ow, nt = T.nt;
+  int32_t* out = T.out;
+  const bool hash_min = T.hash == (int32_t)0x80000000;
   const uint64_t mybit = 1ull << lane;
   int32_t nx[W];                                  // next tile's out row (software prefetch)
 #pragma unroll
@@ -639,43 +841,25 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
   for (int32_t tile = 0; tile < nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
     const bool active = p < P;
-    int32_t h[W];
-    int32_t Lp = 0;
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-      h[k] = nx[k] >= 0 ? nx[k] : 0x7fffffff;
-      Lp += nx[k] >= 0 ? 1 : 0;
-    }
+    int32_t h[W], Lp;
+    sort_holders<W>(nx, h, Lp);
     {
       const int32_t pn = p + 64;
 #pragma unroll
       for (int k = 0; k < W; ++k) nx[k] = (pn < P && k < ow) ? out[(int64_t)pn * ow + k] : -1;
-    }
-    // Sets.newTreeSet(preferenceList) (KAS:228): ascending node index == ascending broker id
-#pragma unroll
-    for (int pass = 0; pass < W; ++pass) {
-#pragma unroll
-      for (int k = (pass & 1); k + 1 < W; k += 2) {
-        const int32_t lo = h[k] < h[k + 1] ? h[k] : h[k + 1];
-        const int32_t hi = h[k] < h[k + 1] ? h[k + 1] : h[k];
-        h[k] = lo; h[k + 1] = hi;
-      }
     }
     if (hash_min) {
       // KAS:190 index error: some set size m <= L has a negative rotation offset
       bool bad = false;
 #pragma unroll
       for (int m = 1; m <= W; ++m) bad = bad || (m <= Lp && idxm[m] < 0);
-      if (kasw::ballot(bad) != 0) { hash_fail = true; break; }
+      if (kasw::ballot(bad) != 0) return true;
     }
     bool pending = active && Lp > 0;
     // node index per list position, clamped so that unused positions address node 0
     int32_t hn[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) hn[k] = (pending && k < Lp) ? h[k] : 0;
-
-    // Which lower lanes share a node with me?  One 64-bit lane mask per node, or-ed in by every
-    // lane holding that node; a row may commit once none of those lower lanes is still pending.
     if (pending) {
 #pragma unroll
       for (int k = 0; k < W; ++k) if (k < Lp) kasw::lds_atomic_or_u64(&L.dep[hn[k]], mybit);
@@ -703,33 +887,8 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
       int32_t c[W][W];
 #pragma unroll
       for (int k = 0; k < W; ++k) load_cnt_row<W>(c[k], L.cnt + hn[k] * CS);
-      uint32_t alive = pending ? ((1u << Lp) - 1u) : 0u;   // sorted-set positions still in nodeSet
       int32_t pick[W], newc[W];
-#pragma unroll
-      for (int r = 0; r < W; ++r) {
-        // getLeastSeenNodeForReplicaId (KAS:263-278): the element of sorted rank i is visited at
-        // position (i + idx_m) % m; the first visited strictly smallest count wins, i.e. the
-        // minimum of (count, visit position)
-        const int32_t m = __builtin_popcount(alive);
-        const int32_t idx = sel<W + 1>(idxm, m);
-        int32_t keys[W];
-        int32_t best = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-          int32_t rr = __builtin_popcount(alive & ((1u << k) - 1u)) + idx;
-          rr -= rr >= m ? m : 0;
-          // arithmetic form of "alive bit k ? (count << 3 | rr) : INT_MAX" (no exec branches)
-          const int32_t dead = (int32_t)((((alive >> k) & 1u) - 1u) & 0x7fffffffu);
-          keys[k] = ((c[k][r] << 3) | rr) | dead;
-          best = keys[k] < best ? keys[k] : best;
-        }
-        int32_t pos = 0;
-#pragma unroll
-        for (int k = 1; k < W; ++k) pos = keys[k] == best ? k : pos;
-        pick[r] = sel<W>(hn, pos);
-        newc[r] = (best >> 3) + 1;
-        alive &= ~(1u << pos);                             // nodeSet.remove (KAS:232)
-      }
+      pick_row<W>(hn, c, Lp, pending, idxm, pick, newc);
       if (ready) {
 #pragma unroll
         for (int r = 0; r < W; ++r) {
@@ -754,28 +913,218 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
       }
     }
   }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One topic == one getRackAwareAssignment call.  Executed by the whole workgroup.
+// ---------------------------------------------------------------------------------------------
+template <int W, int NW>
+KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, uint32_t topic_k,
+                                 const LdsView& L, const NodeMap& nm, const int32_t* g_node_id,
+                                 const int32_t* g_node_rack, uint64_t* accmask, int32_t* orph,
+                                 bool cnt_live, int64_t (&st)[8]) {
+  constexpr int CS = cnt_stride<W>();
+  constexpr int NT = 64 * NW;
+  const int lane = kasw::lane();
+  const int tid = kasw::tid();
+  const int32_t wave = kasw::wave_id();
+  const uint64_t lt = kasw::lanemask_lt();
+  const int32_t N = nm.n;
+  TopicView T;
+  T.cur = a.cur + td.cur_off;
+  T.out = a.out + td.out_off;
+  T.orph = orph;
+  T.len_arr = td.cur_len_off >= 0 ? a.aux + td.cur_len_off : nullptr;
+  T.inp_arr = td.in_partitions_off >= 0 ? a.aux + td.in_partitions_off : nullptr;
+  T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
+  T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
+  T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
+  const int32_t P = T.P, hash = T.hash;
+
+  TopicOutcome res;
+  res.status = KAS_OK; res.fail_partition = -1;
+  res.moved_replicas = 0; res.moved_partitions = 0; res.digest = 0;
+
+  int64_t tmark = kasw::clock_ticks();
+  // ---- P0: capacity (KAS:45, 65-71) over |partitions| ---------------------------------------
+  int32_t n_in = P;
+  if (T.inp_arr) {                                          // every wave counts for itself
+    int32_t c = 0;
+    for (int32_t p = lane; p < P; p += 64) c += T.inp_arr[p] != 0 ? 1 : 0;
+    n_in = kasw::wave_sum(c);
+  }
+  T.cap = max_replicas_per_node(N, n_in, T.rf);
+  const int32_t cap = T.cap;
+
+  // ---- per-topic node state (KAS:46, 73-99): region A of the LDS carve-up -------------------
+  for (int32_t i = tid; i < N; i += NT) {
+    L.load[i] = 0;
+    L.rack[i] = (int16_t)g_node_rack[i];
+  }
+  if (nm.range != 0u) {
+    for (uint32_t i = (uint32_t)tid; i < nm.range; i += (uint32_t)NT) L.idmap[i] = (int16_t)-1;
+  } else {
+    for (int32_t i = tid; i < N; i += NT) L.ids[i] = g_node_id[i];
+  }
+  if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : 0;
+  if (tid < NW) L.dig[tid] = 0ull;
+  kasw::sync();
+  if (nm.range != 0u)
+    for (int32_t i = tid; i < N; i += NT) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
+
+  // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
+  // rack-diverse form when the histogram pass proves it applicable and its LDS table is free
+  // (it may alias the Context counters, which must then not carry state into this topic)
+  const bool try_fast = T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && (a.hist_separate || !cnt_live) &&
+                        cap >= 0 && cap < (1 << 28);
+  if (try_fast)
+    for (int32_t i = tid; i < N * W; i += NT) L.x[i] = 0;
+  kasw::sync();
+  { const int64_t now = kasw::clock_ticks(); st[0] += now - tmark; tmark = now; }
+  bool fast = false;
+  if (try_fast) {
+    const bool viol = fill_pass_a<W, NW>(L, T, nm, wave);
+    if (kasw::ballot(viol) != 0 && lane == 0) L.ctl[KAS_CTL_VIOL] = 1;
+    kasw::sync();
+    fast = L.ctl[KAS_CTL_VIOL] == 0;
+  }
+  int32_t moved_r = 0, moved_p = 0;
+  if (fast) {
+    fill_quota<W, NW>(L, T, tid);
+    kasw::sync();
+    if (NW > 1) {
+      fill_chunk_count<W, NW>(L, T, nm, wave);
+      kasw::sync();
+      fill_chunk_prefix<NW>(L, T, tid);
+      kasw::sync();
+    }
+    { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
+    const int32_t oc = fill_pass_b<W, NW>(L, T, nm, wave, moved_r, moved_p, st);
+    if (lane == 0) L.ctl[KAS_CTL_OC + wave] = oc;
+  } else if (wave == 0) {
+    fill_generic_sweeps<W>(L, T, nm, accmask, st);
+    { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
+  }
+  kasw::sync();
+
+  // ---- KAS:168: getNodeProcessingOrder(topic, all nodes); runs even with zero orphans -------
+  const int32_t idxN = java_abs_mod(hash, N);
+  if (idxN < 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }      // workgroup-uniform
+  if (wave == 0) {
+    const int32_t start = (N - idxN) % N;        // order[j] = sorted[(j + start) % N]
+    // non-full nodes in processing order (full nodes can never accept again)
+    int32_t live_count = 0;
+    for (int32_t base = 0; base < N; base += 64) {
+      const int32_t j = base + lane;
+      int32_t n = j + start; if (n >= N) n -= N;
+      const bool is_live = j < N && L.load[n] < cap;
+      const uint64_t m = kasw::ballot(is_live);
+      if (is_live) L.live[live_count + kasw::popc(m & lt)] = (int16_t)n;
+      live_count += kasw::popc(m);
+    }
+    kasw::lockstep();
+    // ---- P3 + P4: orphans (KAS:52, 133-160) and first fit (KAS:56, 162-186) -----------------
+    const int32_t fail_row = fast ? p4_lists<W, NW>(L, T, live_count, st)
+                                  : p3p4_generic<W>(L, T, nm, accmask, live_count, moved_r, moved_p, st);
+    if (lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
+  }
+  {
+    const int32_t mr = kasw::wave_sum(moved_r), mp = kasw::wave_sum(moved_p);
+    if (lane == 0 && (mr | mp) != 0) {
+      kasw::lds_atomic_add(&L.ctl[KAS_CTL_MOVED_R], mr);
+      kasw::lds_atomic_add(&L.ctl[KAS_CTL_MOVED_P], mp);
+    }
+  }
+  kasw::sync();   // out rows of P3/P4 are visible to every wave; region A is dead from here
+  { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
+  {
+    const int32_t fail_row = L.ctl[KAS_CTL_FAILROW];
+    if (fail_row >= 0) {                                       // KAS:183-184
+      res.status = KAS_FAIL_UNASSIGNABLE;
+      res.fail_partition = T.pid_arr ? T.pid_arr[fail_row] : fail_row;
+      return res;
+    }
+  }
+
+  // ---- P5: preference lists (KAS:62, 202-239) ------------------------------------------------
+  // region T: tickets handed out per node start at the node's counter sum, lane masks clear,
+  // broker ids for the final rows; the largest ticket decides whether tickets fit the packed row
+  {
+    int32_t maxt = 0;
+    const bool zero_cnt = fast && !a.hist_separate;          // the histogram lived in cnt's LDS
+    for (int32_t n = tid; n < N; n += NT) {
+      int32_t s = 0;
+      if (zero_cnt) {
+#pragma unroll
+        for (int r = 0; r < CS; ++r) L.cnt[n * CS + r] = 0;
+      } else if (cnt_live) {
+#pragma unroll
+        for (int r = 0; r < W; ++r) s += L.cnt[n * CS + r];
+      }
+      const int32_t ld = L.load[n];
+      maxt = s + ld > maxt ? s + ld : maxt;
+      maxt = (s < 0 || ld < 0) ? 0x7fffffff : maxt;
+      L.run[n] = s;
+    }
+    kasw::sync();                                            // load[] is read before dep/nid overwrite region A
+    for (int32_t n = tid; n < N; n += NT) {
+      L.dep[n] = 0ull;
+      L.nid[n] = g_node_id[n];
+    }
+    kasw::lds_atomic_max((uint32_t*)&L.ctl[KAS_CTL_MAXT], (uint32_t)maxt);
+    kasw::sync();
+  }
+  // rotation offsets idx_m = Math.abs(hash) % m for every set size m (KAS:190, via KAS:267)
+  int32_t idxm[W + 1];
+#pragma unroll
+  for (int m = 1; m <= W; ++m) idxm[m] = java_abs_mod(hash, m);
+  idxm[0] = 0;
+  const bool use_tickets = !(a.flags & KAS_FLAG_ROUND_ORDER) && hash != (int32_t)0x80000000 &&
+                           (uint32_t)L.ctl[KAS_CTL_MAXT] < (uint32_t)KAS_TICKET_LIMIT;
+  uint64_t digest = 0;
+  if (use_tickets) {
+    if (NW == 1) {
+      ticket_pass<W>(L, T);
+      order_rows<W>(L, T, idxm, lane, 64, topic_k, digest, st);
+    } else if (wave == NW - 1) {
+      ticket_pass<W>(L, T);
+    } else {
+      order_rows<W>(L, T, idxm, tid, 64 * (NW - 1), topic_k, digest, st);
+    }
+  } else if (wave == 0) {
+    if (order_rounds<W>(L, T, idxm, g_node_id, topic_k, digest, st) && lane == 0)
+      L.ctl[KAS_CTL_HASHFAIL] = 1;
+  }
+  {
+    const uint64_t dsum = kasw::wave_sum_u64(digest);
+    if (lane == 0) L.dig[wave] = dsum;
+  }
+  kasw::sync();
   { const int64_t now = kasw::clock_ticks(); st[3] += now - tmark; tmark = now; }
-  if (hash_fail) { res.status = KAS_FAIL_HASH_INDEX; return res; }
-  res.moved_replicas = kasw::wave_sum(moved_r);
-  res.moved_partitions = kasw::wave_sum(moved_p);
-  res.digest = digest;
+  if (L.ctl[KAS_CTL_HASHFAIL] != 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }
+  res.moved_replicas = L.ctl[KAS_CTL_MOVED_R];
+  res.moved_partitions = L.ctl[KAS_CTL_MOVED_P];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) res.digest += L.dig[w];
   return res;
 }
 
 // ---------------------------------------------------------------------------------------------
 // One scenario: the per-topic loop of KAG:173-184 against one Context (KTA:19-23).
 // ---------------------------------------------------------------------------------------------
-template <int W>
+template <int W, int NW>
 KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
-  const int lane = kasw::lane();
+  constexpr int NT = 64 * NW;
+  const int tid = kasw::tid();
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
-  const KasLds lay = kas_lds_layout(a.n_max, W, a.idmap_entries, a.need_bsearch, a.hist_separate);
+  const KasLds lay = kas_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch, a.hist_separate);
   LdsView L;
   L.cnt = (int32_t*)(lds_raw + lay.off_cnt);
-  L.dep = (uint64_t*)(lds_raw + lay.off_dep);
+  L.x = (int32_t*)(lds_raw + lay.off_x);
   L.load = (int32_t*)(lds_raw + lay.off_load);
-  L.hist = (int32_t*)(lds_raw + lay.off_hist);
+  L.qrs = (int32_t*)(lds_raw + lay.off_qrs);
   L.rack = (int16_t*)(lds_raw + lay.off_rack);
   L.live = (int16_t*)(lds_raw + lay.off_live);
   L.idmap = (int16_t*)(lds_raw + lay.off_idmap);
@@ -783,6 +1132,11 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
   L.ring_p = (int32_t*)(lds_raw + lay.off_ring);
   L.ring_meta = L.ring_p + KAS_RING_CAP;
   L.ring_rack = (int16_t*)(L.ring_meta + KAS_RING_CAP);
+  L.run = (int32_t*)(lds_raw + lay.off_run);
+  L.dep = (uint64_t*)(lds_raw + lay.off_dep);
+  L.nid = (int32_t*)(lds_raw + lay.off_nid);
+  L.ctl = (int32_t*)(lds_raw + lay.off_ctl);
+  L.dig = (uint64_t*)(L.ctl + KAS_CTL_INTS);
 
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int32_t* g_node_rack = a.node_rack + sd.node_off;
@@ -795,7 +1149,7 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
   // node table checks (strictly ascending, non-negative ids; racks in int16 range) and the
   // Context counters (KAS:360-369) into LDS
   bool bad = false;
-  for (int32_t i = lane; i < N; i += 64) {
+  for (int32_t i = tid; i < N; i += NT) {
     const int32_t id = g_node_id[i];
     const int32_t prev = i > 0 ? g_node_id[i - 1] : -1;
     const int32_t rk = g_node_rack[i];
@@ -804,7 +1158,11 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     for (int r = 0; r < cnt_stride<W>(); ++r)
       L.cnt[i * cnt_stride<W>() + r] = (has_ctx && r < W && r < ctxw) ? g_ctx[(int64_t)i * ctxw + r] : 0;
   }
-  const bool nodes_bad = kasw::ballot(bad) != 0;
+  if (tid == 0) L.ctl[KAS_CTL_VIOL] = 0;
+  kasw::sync();
+  if (kasw::ballot(bad) != 0 && kasw::lane() == 0) L.ctl[KAS_CTL_VIOL] = 1;
+  kasw::sync();
+  const bool nodes_bad = L.ctl[KAS_CTL_VIOL] != 0;
   NodeMap nm;
   nm.n = N; nm.min_id = 0; nm.range = 0u;
   if (N > 0 && !nodes_bad) {
@@ -817,6 +1175,7 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
 
   st[0] += kasw::clock_ticks() - t_begin;
   uint64_t* accmask = a.accmask + a.accmask_off[s];
+  int32_t* orph = a.orph + a.orph_off[s];
   int32_t scen_status = KAS_OK, fail_topic = -1, fail_part = -1;
   int32_t moved_r = 0, moved_p = 0;
   uint64_t digest = 0;
@@ -829,17 +1188,18 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = solve_topic<W>(a, td, (uint32_t)k, L, nm, g_node_id, g_node_rack, accmask,
-                            /*cnt_live=*/has_ctx || k > 0, st);
+    else o = solve_topic<W, NW>(a, td, (uint32_t)k, L, nm, g_node_id, g_node_rack, accmask, orph,
+                                /*cnt_live=*/has_ctx || k > 0, st);
+    kasw::sync();
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding
       int32_t* out = a.out + td.out_off;
       const int64_t cells = (int64_t)td.n_partitions * td.out_width;
-      for (int64_t i = lane; i < cells; i += 64) out[i] = -1;
+      for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
       o.moved_replicas = 0; o.moved_partitions = 0; o.digest = 0;
       if (scen_status == KAS_OK) { scen_status = o.status; fail_topic = k; fail_part = o.fail_partition; }
     }
-    if (lane == 0) {
+    if (tid == 0) {
       kas_topic_result tr;
       tr.status = o.status; tr.fail_partition = o.fail_partition;
       tr.moved_replicas = o.moved_replicas; tr.moved_partitions = o.moved_partitions;
@@ -850,17 +1210,16 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
     kasw::sync();
   }
   if (has_ctx) {
-    for (int32_t i = lane; i < N; i += 64)
+    for (int32_t i = tid; i < N; i += NT)
 #pragma unroll
       for (int r = 0; r < W; ++r)
         if (r < ctxw) g_ctx[(int64_t)i * ctxw + r] = L.cnt[i * cnt_stride<W>() + r];
   }
-  const uint64_t dsum = kasw::wave_sum_u64(digest);
-  if (lane == 0) {
+  if (tid == 0) {
     kas_scenario_result sr;
     sr.status = scen_status; sr.fail_topic = fail_topic; sr.fail_partition = fail_part;
     sr.moved_replicas = moved_r; sr.moved_partitions = moved_p; sr.reserved = 0;
-    sr.digest = dsum;
+    sr.digest = digest;
     a.scenario_results[s] = sr;
     if (a.stats) {
 #pragma unroll

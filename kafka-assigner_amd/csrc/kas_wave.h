@@ -1,11 +1,12 @@
-// kas_wave.h — wavefront primitives used by the solver body, gfx950 implementation.
+// kas_wave.h — wavefront / workgroup primitives used by the solver body, gfx950 implementation.
 //
-// One workgroup == one 64-lane wavefront == one scenario, so every cross-lane step is a
-// wave-level operation: 64-bit ballots, lane shuffles and LDS atomics.  kasw::sync() is the
-// only ordering primitive the body uses; with a single-wave workgroup s_barrier is nearly free
-// and __syncthreads() carries the workgroup-scope release/acquire that orders both LDS and
-// same-CU global accesses (the accept-mask scratch and the out rows are re-read by the wave
-// that wrote them).
+// One workgroup == one scenario == NW 64-lane wavefronts sharing the scenario's LDS state.
+// Cross-lane steps are wave-level operations (64-bit ballots, lane shuffles, LDS atomics);
+// kasw::sync() is the workgroup barrier between phases (it carries the workgroup-scope
+// release/acquire that orders LDS and same-CU global accesses: out rows, orphan lists and
+// accept-mask words written by one wave are re-read by another wave of the same workgroup,
+// which shares the CU's vector L1); publish()/observe() are the release/acquire pair of the
+// ticket-pass watermark.
 //
 // tests/emu/kas_wave.h provides the same names on top of CPU fibers so the identical body
 // source can be stepped on a machine without a GPU; the product only ever includes this file.
@@ -20,11 +21,36 @@ namespace kasw {
 
 KAS_DEV int lane() { return (int)(threadIdx.x & 63u); }
 
+KAS_DEV int tid() { return (int)threadIdx.x; }
+
+// wavefront index inside the workgroup (wave-uniform, kept in an SGPR)
+KAS_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 KAS_DEV uint64_t ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 
 KAS_DEV int shfl(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 KAS_DEV void sync() { __syncthreads(); }
+
+// Ordering point for a section that only ONE wave of the workgroup executes: this wave's
+// earlier LDS and global accesses complete before its later ones are issued (no s_barrier, the
+// other waves are not coming).
+KAS_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// back off inside a spin loop (the other waves of the CU get the issue slots)
+KAS_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+
+// watermark hand-off between waves of one workgroup: everything this wave stored (LDS and
+// global) before publish() is visible to a wave that observes the value
+KAS_DEV void publish(int32_t* flag, int32_t v) {
+  __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+KAS_DEV int32_t observe(const int32_t* flag) {
+  return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // Point where the body relies on the 64 lanes having executed the preceding LDS reads before
 // any lane executes the following LDS writes.  A wavefront issues each instruction for all
@@ -57,6 +83,10 @@ KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) {
 }
 
 KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
+KAS_DEV int lds_atomic_min(int* p, int v) { return atomicMin(p, v); }
+KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // 64-bit word written earlier by this wave (accept-mask scratch): force a vector load so the
 // value never comes from the scalar cache, which is not coherent with the wave's own stores.

@@ -12,7 +12,7 @@
 namespace kasw {
 
 Emu g_emu;
-static const size_t STACK_BYTES = 256 * 1024;
+static const size_t STACK_BYTES = 192 * 1024;
 static char* g_stacks = nullptr;
 
 struct Tramp { void (*fn)(void*); void* arg; };
@@ -20,16 +20,19 @@ static Tramp g_tramp;
 
 static void lane_entry() {
   g_tramp.fn(g_tramp.arg);
-  g_emu.done[g_emu.cur_lane] = true;
-  swapcontext(&g_emu.lane_ctx[g_emu.cur_lane], &g_emu.main_ctx);
+  g_emu.state[g_emu.cur] = S_DONE;
+  swapcontext(&g_emu.lane_ctx[g_emu.cur], &g_emu.main_ctx);
 }
 
-int run_wave(void (*fn)(void*), void* arg) {
+int run_block(void (*fn)(void*), void* arg, int n_waves) {
   Emu& e = g_emu;
-  if (!g_stacks) g_stacks = (char*)malloc(64 * STACK_BYTES);
+  const int n = 64 * n_waves;
+  if (n > KAS_EMU_MAX_LANES) return -1;
+  if (!g_stacks) g_stacks = (char*)malloc((size_t)KAS_EMU_MAX_LANES * STACK_BYTES);
   g_tramp.fn = fn; g_tramp.arg = arg;
-  for (int i = 0; i < 64; ++i) {
-    e.done[i] = false; e.kind[i] = K_NONE;
+  e.n_lanes = n;
+  for (int i = 0; i < n; ++i) {
+    e.state[i] = S_RUNNABLE; e.kind[i] = K_NONE;
     getcontext(&e.lane_ctx[i]);
     e.lane_ctx[i].uc_stack.ss_sp = g_stacks + (size_t)i * STACK_BYTES;
     e.lane_ctx[i].uc_stack.ss_size = STACK_BYTES;
@@ -37,26 +40,53 @@ int run_wave(void (*fn)(void*), void* arg) {
     makecontext(&e.lane_ctx[i], lane_entry, 0);
   }
   for (;;) {
-    int alive = 0;
-    for (int i = 0; i < 64; ++i) {
-      if (e.done[i]) continue;
-      e.cur_lane = i;
+    // 1. run every runnable fiber until it parks at a collective or finishes
+    int ran = 0, done = 0;
+    for (int i = 0; i < n; ++i) {
+      if (e.state[i] == S_DONE) { ++done; continue; }
+      if (e.state[i] != S_RUNNABLE) continue;
+      e.cur = i;
       swapcontext(&e.main_ctx, &e.lane_ctx[i]);
-      if (!e.done[i]) ++alive;
+      ++ran;
+      if (e.state[i] == S_DONE) ++done;
     }
-    if (alive == 0) return 0;
-    // all surviving lanes are parked: they must be at the same kind of collective, and no
-    // lane may have exited while others still wait
-    int k = -1;
-    for (int i = 0; i < 64; ++i) {
-      if (e.done[i]) { fprintf(stderr, "emu: lane %d exited while others wait at a collective\n", i); return -1; }
-      if (k < 0) k = e.kind[i];
-      else if (e.kind[i] != k) {
-        fprintf(stderr, "emu: wave divergence: lane %d at collective kind %d, lane 0.. at %d\n", i, e.kind[i], k);
-        return -1;
+    if (done == n) return 0;
+    // 2. release every wave whose 64 fibers all wait at the same wave collective; a workgroup
+    //    barrier releases when every fiber of the block waits at it
+    int released = 0, at_sync = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      int parked = 0, finished = 0, k = -1;
+      bool mixed = false;
+      for (int i = 64 * w; i < 64 * w + 64; ++i) {
+        if (e.state[i] == S_DONE) { ++finished; continue; }
+        if (e.state[i] == S_PARKED) {
+          ++parked;
+          if (k < 0) k = e.kind[i]; else if (e.kind[i] != k) mixed = true;
+        }
       }
+      if (finished == 64) continue;
+      if (parked + finished < 64) continue;                // cannot happen after step 1
+      if (finished > 0) { fprintf(stderr, "emu: wave %d: %d lanes exited while others wait at a collective\n", w, finished); return -1; }
+      if (mixed) { fprintf(stderr, "emu: wave %d: divergence, lanes wait at different collectives\n", w); return -1; }
+      if (k == K_SYNC) { at_sync += 64; continue; }
+      for (int i = 64 * w; i < 64 * w + 64; ++i) e.state[i] = S_RUNNABLE;
+      ++released;
+      e.collectives++;
     }
-    e.collectives++;
+    if (at_sync == n) {
+      for (int i = 0; i < n; ++i) e.state[i] = S_RUNNABLE;
+      ++released;
+    } else if (at_sync > 0 && at_sync == n - done && done > 0) {
+      fprintf(stderr, "emu: some waves exited while others wait at the workgroup barrier\n");
+      return -1;
+    }
+    if (released == 0 && ran == 0) { fprintf(stderr, "emu: deadlock (nothing runnable, nothing released)\n"); return -1; }
+    if (released == 0) {
+      // every live fiber is parked and no group is complete
+      bool any_runnable = false;
+      for (int i = 0; i < n; ++i) any_runnable = any_runnable || e.state[i] == S_RUNNABLE;
+      if (!any_runnable) { fprintf(stderr, "emu: deadlock at a collective\n"); return -1; }
+    }
   }
 }
 
@@ -66,46 +96,57 @@ namespace {
 
 struct RunArgs { const KasLaunch* a; int32_t s; unsigned char* lds; int W; };
 
-template <int W> void run_one(void* p) {
+template <int W, int NW> void run_one(void* p) {
   RunArgs* r = (RunArgs*)p;
-  kas::solve_scenario<W>(*r->a, r->s, r->lds);
+  kas::solve_scenario<W, NW>(*r->a, r->s, r->lds);
+}
+
+typedef void (*run_fn)(void*);
+template <int NW> run_fn run_for_w(int Wc) {
+  switch (Wc) {                            // the same width classes the product launcher uses
+    case 2: return run_one<2, NW>;
+    case 3: return run_one<3, NW>;
+    case 4: return run_one<4, NW>;
+    case 5: return run_one<5, NW>;
+    default: return run_one<8, NW>;
+  }
 }
 
 }  // namespace
 
+// flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario (0 = the planner's choice)
 extern "C" __attribute__((visibility("default")))
 int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen) {
   KasShape sh;
   std::string err;
-  int rc = kas_shape_batch(b, &sh, &err);
+  int rc = kas_shape_batch(b, &sh, &err, (int)((flags >> 8) & 0xfu));
   if (rc != KAS_E_OK) {
     if (errbuf && errlen > 0) { strncpy(errbuf, err.c_str(), (size_t)errlen - 1); errbuf[errlen - 1] = 0; }
     return rc;
   }
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
+  std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
   std::vector<unsigned char> lds((size_t)sh.lds.total + 64, 0xCD);
   KasLaunch a;
   a.scen = b->scenarios; a.topics = b->topics; a.node_id = b->node_id; a.node_rack = b->node_rack;
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data(); a.stats = nullptr;
+  a.orph = orph.data(); a.orph_off = sh.orph_off.data(); a.nw = sh.NW;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
-  a.need_bsearch = sh.need_bsearch; a.hist_separate = sh.hist_separate; a.flags = flags;
+  a.need_bsearch = sh.need_bsearch; a.hist_separate = sh.hist_separate; a.flags = flags & 0xffu;
+  run_fn fn = nullptr;
+  switch (sh.NW) {
+    case 1: fn = run_for_w<1>(sh.Wc); break;
+    case 2: fn = run_for_w<2>(sh.Wc); break;
+    case 8: fn = run_for_w<8>(sh.Wc); break;
+    default: fn = run_for_w<4>(sh.Wc); break;
+  }
   for (int32_t s = 0; s < b->n_scenarios; ++s) {
     memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
     RunArgs ra{&a, s, lds.data(), sh.W};
-    void (*fn)(void*) = nullptr;
-    switch (sh.Wc) {                       // the same width classes the product launcher uses
-      case 2: fn = run_one<2>; break;
-      case 3: fn = run_one<3>; break;
-      case 4: fn = run_one<4>; break;
-      case 5: fn = run_one<5>; break;
-      default: fn = run_one<8>; break;
-    }
-    if ((size_t)sh.lds.total + 64 > lds.size()) lds.resize((size_t)sh.lds.total + 64, 0xCD);
-    ra.lds = lds.data();
-    if (kasw::run_wave(fn, &ra) != 0) {
-      if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence in scenario %d", s);
+    if (kasw::run_block(fn, &ra, sh.NW) != 0) {
+      if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in scenario %d", s);
       return -100;
     }
   }

@@ -1,12 +1,16 @@
 // tests/emu/kas_wave.h — CPU stand-in for kafka-assigner_amd/csrc/kas_wave.h.  TEST INFRASTRUCTURE.
 //
 // Lets the unmodified solver body (csrc/kas_solver_body.h) be compiled with g++ and stepped on
-// a machine without a GPU: the 64 lanes of a wavefront are 64 ucontext fibers run round-robin
-// by a single thread.  Every collective (ballot, shfl, sync, lockstep, reductions) is a
-// rendezvous: a fiber parks there until all 64 have arrived, so lane i always observes what
-// lanes < i did before the rendezvous and nothing they do after it — the lockstep a real
-// wavefront provides.  The scheduler aborts when lanes arrive at different kinds of collective
-// (= wave-divergent control flow around a collective, which would hang or corrupt on hardware).
+// a machine without a GPU: the 64 * NW lanes of a workgroup are ucontext fibers run by a single
+// thread.  Every wave collective (ballot, shfl, lockstep, wave_sync, reductions) is a rendezvous
+// of the 64 fibers of that wave: a fiber parks there until all 64 have arrived, so lane i always
+// observes what lanes < i did before the rendezvous and nothing they do after it — the lockstep
+// a real wavefront provides.  kasw::sync() is a rendezvous of all fibers of the workgroup.
+// Waves are otherwise free-running relative to each other (round-robin), so cross-wave spin
+// loops (ticket waits, the watermark) make progress as long as they contain a wave collective.
+// The scheduler aborts when lanes of a wave arrive at different kinds of collective (= divergent
+// control flow around a collective, which would hang or corrupt on hardware) or when nothing can
+// run (deadlock).
 //
 // It checks the LOGIC of the kernel source against the oracle before GPU minutes are spent.
 // It is not a product path: nothing under kafka-assigner_amd/ includes or links it.
@@ -18,52 +22,64 @@
 #include <ucontext.h>
 
 #define KAS_DEV static inline
+#define KAS_EMU_MAX_LANES 512
 
 namespace kasw {
 
-enum Kind { K_NONE = 0, K_BALLOT, K_SHFL, K_SYNC, K_LOCKSTEP, K_SUM, K_SUM64 };
+enum Kind { K_NONE = 0, K_BALLOT, K_SHFL, K_SYNC, K_LOCKSTEP, K_SUM, K_SUM64, K_WAVESYNC };
+enum State { S_RUNNABLE = 0, S_PARKED, S_DONE };
 
 struct Emu {
   ucontext_t main_ctx;
-  ucontext_t lane_ctx[64];
-  bool done[64];
-  int kind[64];
-  int cur_lane;
-  uint64_t slot[64];
-  uint64_t result;       // combined value of the collective in flight
+  ucontext_t lane_ctx[KAS_EMU_MAX_LANES];
+  int state[KAS_EMU_MAX_LANES];
+  int kind[KAS_EMU_MAX_LANES];
+  int n_lanes;
+  int cur;               // fiber being run
+  uint64_t slot[KAS_EMU_MAX_LANES];
   long collectives;
 };
 
 extern Emu g_emu;
 
-KAS_DEV int lane() { return g_emu.cur_lane; }
+KAS_DEV int lane() { return g_emu.cur & 63; }
+KAS_DEV int tid() { return g_emu.cur; }
+KAS_DEV int wave_id() { return g_emu.cur >> 6; }
 
-// park this fiber at a collective of kind k; returns when all lanes have arrived
+// park this fiber at a collective of kind k; returns when its group has arrived
 KAS_DEV void rendezvous(int k) {
   Emu& e = g_emu;
-  e.kind[e.cur_lane] = k;
-  swapcontext(&e.lane_ctx[e.cur_lane], &e.main_ctx);
+  e.kind[e.cur] = k;
+  e.state[e.cur] = S_PARKED;
+  swapcontext(&e.lane_ctx[e.cur], &e.main_ctx);
 }
 
 KAS_DEV uint64_t ballot(bool p) {
-  g_emu.slot[lane()] = p ? 1 : 0;
+  const int base = g_emu.cur & ~63;
+  g_emu.slot[g_emu.cur] = p ? 1 : 0;
   rendezvous(K_BALLOT);
   uint64_t m = 0;
-  for (int i = 0; i < 64; ++i) m |= (g_emu.slot[i] & 1ull) << i;
+  for (int i = 0; i < 64; ++i) m |= (g_emu.slot[base + i] & 1ull) << i;
   rendezvous(K_BALLOT);   // everyone has read the slots before they are reused
   return m;
 }
 
 KAS_DEV int shfl(int v, int src_lane) {
-  g_emu.slot[lane()] = (uint64_t)(uint32_t)v;
+  const int base = g_emu.cur & ~63;
+  g_emu.slot[g_emu.cur] = (uint64_t)(uint32_t)v;
   rendezvous(K_SHFL);
-  int r = (int)(uint32_t)g_emu.slot[src_lane & 63];
+  int r = (int)(uint32_t)g_emu.slot[base + (src_lane & 63)];
   rendezvous(K_SHFL);
   return r;
 }
 
 KAS_DEV void sync() { rendezvous(K_SYNC); }
 KAS_DEV void lockstep() { rendezvous(K_LOCKSTEP); }
+KAS_DEV void wave_sync() { rendezvous(K_WAVESYNC); }
+KAS_DEV void spin_pause() {}
+
+KAS_DEV void publish(int32_t* flag, int32_t v) { *(volatile int32_t*)flag = v; }
+KAS_DEV int32_t observe(const int32_t* flag) { return *(const volatile int32_t*)flag; }
 
 KAS_DEV int32_t opaque(int32_t v) { return v; }
 
@@ -73,8 +89,9 @@ KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
-
+KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }
 KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+KAS_DEV int lds_atomic_min(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 
 KAS_DEV uint64_t load_shared_u64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
 KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
@@ -82,25 +99,27 @@ KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p 
 KAS_DEV int64_t clock_ticks() { return 0; }
 
 KAS_DEV int wave_sum(int v) {
-  g_emu.slot[lane()] = (uint64_t)(int64_t)v;
+  const int base = g_emu.cur & ~63;
+  g_emu.slot[g_emu.cur] = (uint64_t)(int64_t)v;
   rendezvous(K_SUM);
   int64_t s = 0;
-  for (int i = 0; i < 64; ++i) s += (int64_t)g_emu.slot[i];
+  for (int i = 0; i < 64; ++i) s += (int64_t)g_emu.slot[base + i];
   rendezvous(K_SUM);
   return (int)s;
 }
 
 KAS_DEV uint64_t wave_sum_u64(uint64_t v) {
-  g_emu.slot[lane()] = v;
+  const int base = g_emu.cur & ~63;
+  g_emu.slot[g_emu.cur] = v;
   rendezvous(K_SUM64);
   uint64_t s = 0;
-  for (int i = 0; i < 64; ++i) s += g_emu.slot[i];
+  for (int i = 0; i < 64; ++i) s += g_emu.slot[base + i];
   rendezvous(K_SUM64);
   return s;
 }
 
-// Run fn(arg) as 64 lock-stepped lanes.  Returns 0, or -1 on wave divergence.
-int run_wave(void (*fn)(void*), void* arg);
+// Run fn(arg) as n_waves * 64 fibers.  Returns 0, or -1 on divergence / deadlock.
+int run_block(void (*fn)(void*), void* arg, int n_waves);
 
 }  // namespace kasw
 #endif  // KAS_WAVE_H_

@@ -25,6 +25,8 @@ def test_emu_equals_oracle_small_odd_inputs(sc):
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=2 | (1 << 8)), "emu round order, 1 wave")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 8)), "emu 2 waves")
 
 
 def _batch(seed, S, P, N, R, RF, actions, rack_aware=True, cyclic=False, name_hash=3644):
@@ -65,6 +67,11 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
+    # every workgroup width, and the round form of the preference ordering
+    for nw in (1, 2, 8):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=nw << 8), f"emu {nw} waves")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round order")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=3 | (1 << 8)), "emu generic fill + round order, 1 wave")
     # the generator must produce solvable scenarios most of the time, else the test is vacuous
     assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 1
 

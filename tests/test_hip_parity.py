@@ -45,8 +45,13 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, native.solve_host(fb), "hip")
-    # the general multi-sweep sticky fill must agree with the rack-diverse single-scan form
+    # the general multi-sweep sticky fill must agree with the rack-diverse histogram/quota form,
+    # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip round order")
+    for nw in (1, 2, 4, 8):
+        assert_same_outputs(fb, want, native.solve_host_with_flags(fb, nw << 8), f"hip {nw} waves")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 3 | (1 << 8)), "hip generic+round, 1 wave")
 
 
 def test_hip_rack_awareness_disabled_cyclic_and_sparse_ids():
@@ -78,6 +83,9 @@ def test_config3_shape_full_size_scenarios():
     got = native.solve_host(fb)
     assert_same_outputs(fb, want, got, "C3")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
+    for nw in (1, 2, 8):
+        assert_same_outputs(fb, want, native.solve_host_with_flags(fb, nw << 8), f"C3 {nw} waves")
     assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 4
 
 
