@@ -50,12 +50,14 @@ def main() -> int:
     ap.add_argument("--check", type=int, default=8, help="scenarios list-compared against the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight: steps are issued round-robin on this many HIP streams, "
                          "each with its own plan scratch and output tables")
     ap.add_argument("--stats", default="", help="write the per-phase device counters (JSON) here")
     ap.add_argument("--waves", type=int, default=int(os.environ.get("KAS_BENCH_WAVES", "0")),
                     help="wavefronts per scenario workgroup (0 = the plan's choice)")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("KAS_BENCH_GROUPS", "0")),
+                    help="scenarios per wavefront of the ticket-form order kernel (0 = the plan's choice)")
     ap.add_argument("--plan-flags", type=int, default=0, help="KAS_PLAN_* switches (testing)")
     args = ap.parse_args()
 
@@ -97,8 +99,8 @@ def main() -> int:
     slots = []
     for _ in range(n_slots):
         plan_ = native.Plan(ctx, fb)
-        if args.waves or args.plan_flags:
-            plan_.set_flags((args.waves << 8) | args.plan_flags)
+        if args.waves or args.groups or args.plan_flags:
+            plan_.set_flags((args.waves << 8) | (args.groups << 12) | args.plan_flags)
         sl = {"plan": plan_,
               "out": torch.empty(fb.out_len, dtype=torch.int32, device=dev),
               "tr": torch.zeros(S * 16, dtype=torch.uint8, device=dev),
@@ -140,19 +142,23 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_us, kern_n = 0.0, 0
+    fill_us, order_us, kern_n = 0.0, 0.0, 0
     for sl in slots:
-        u, n = sl["plan"].kernel_time_us()
-        kern_us += u * n; kern_n += n
-    kern_us = kern_us / kern_n if kern_n else 0.0
+        f, o, n = sl["plan"].phase_times_us()
+        fill_us += f * n; order_us += o * n; kern_n += n
+    fill_us = fill_us / kern_n if kern_n else 0.0
+    order_us = order_us / kern_n if kern_n else 0.0
+    kern_us = fill_us + order_us
     if args.stats and rank == 0:
         st = plan.stats().astype(np.float64)
-        names = ["setup_us", "p2_hist_quota_us", "p2_keep_p3_p4_us", "p5_us", "p4_windows", "p4_steps",
-                 "p5_iterations_wave0", "p2_ranked_tiles_wave0"]
-        scale = [0.01, 0.01, 0.01, 0.01, 1, 1, 1, 1]
+        names = ["setup_us", "p2_hist_quota_us", "p2_keep_p3_p4_us", "tickets_us", "p4_windows", "p4_steps",
+                 "p5_rounds", "p2_ranked_tiles_wave0", "order_us", "solver_iterations", "solver_starved",
+                 "solver_blocked", "feeder_iterations", "feeder_idle"]
+        scale = [0.01, 0.01, 0.01, 0.01, 1, 1, 1, 1, 0.01, 1, 1, 1, 1, 1]
         summary = {n: {"mean": float(st[:, i].mean() * scale[i]), "max": float(st[:, i].max() * scale[i]),
                        "min": float(st[:, i].min() * scale[i])} for i, n in enumerate(names)}
-        summary["kernel_avg_us"] = kern_us
+        summary["fill_kernel_avg_us"] = fill_us
+        summary["order_kernel_avg_us"] = order_us
         json.dump(summary, open(args.stats, "w"), indent=1)
 
     # ---- results of this rank -------------------------------------------------------------------
@@ -233,7 +239,11 @@ def main() -> int:
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "kas_solve_kernel<3>", "kernel_avg_us": kern_us, "launches_timed": kern_n,
+                "kernel": "kas_fill_kernel<3,NW> + kas_order_ticket_kernel<3,G> (one solve = both, same stream)",
+                "kernel_avg_us": kern_us, "fill_kernel_avg_us": fill_us, "order_kernel_avg_us": order_us,
+                "launches_timed": kern_n,
+                "note": "durations are HIP-event times per launch while batches_in_flight solves share "
+                        "the GPU; achieved = algorithmic bytes of one solve / (fill + order duration)",
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
             "cpu_baseline": cpu,

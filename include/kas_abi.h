@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define KAS_ABI_VERSION 1
+#define KAS_ABI_VERSION 2
 
 /* Longest replica list the kernels keep in registers: max(cur_width, rf) <= KAS_MAX_WIDTH. */
 #define KAS_MAX_WIDTH 8
@@ -167,12 +167,12 @@ typedef struct kas_plan kas_plan;   /* validated batch shape: descriptors + node
 #endif
 KAS_ABI_FN uint64_t kas_digest_cell(uint32_t topic, uint32_t row, uint32_t slot,
                                        int32_t broker) {
-  uint64_t x = ((uint64_t)row << 32) | (uint32_t)broker;
-  x += 0x9E3779B97F4A7C15ull * (uint64_t)(slot + 1u);
-  x ^= 0xD6E8FEB86659FD93ull * (uint64_t)(topic + 1u);
-  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 27; x *= 0x94D049BB133111EBull;
-  x ^= x >> 31;
+  /* one 32x32->64 multiply-add per cell: the order kernel evaluates this inside its commit path */
+  const uint32_t tlo = (topic + 1u) * 0x9E3779B1u, thi = (topic + 1u) * 0x85EBCA77u;
+  const uint32_t b = (uint32_t)broker ^ tlo ^ 0x7F4A7C15u;
+  const uint32_t r = (((row << 4) | ((slot & 7u) << 1) | 1u)) ^ (thi & 0xFFFFFFFEu);   /* odd */
+  uint64_t x = (uint64_t)b * (uint64_t)r + (((uint64_t)r << 32) | (uint64_t)b);
+  x ^= x >> 29;
   return x;
 }
 
@@ -206,28 +206,37 @@ int kas_ctx_synchronize(kas_ctx* ctx);
 /* Convenience for host callers (JNI / ctypes / C++ mirror): H2D, solve, D2H, blocking. */
 int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables);
 
-/* Average device time in microseconds of the solver kernel over the launches recorded since
+/* Average device time in microseconds of one solve (both kernels) over the launches recorded since
  * the last call (HIP events on the launch stream); resets the accumulator. Returns <0 on
  * error, and *launches = 0 when nothing was recorded. */
 int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
 
+/* The same accumulator split by kernel: a solve is the fill kernel (P0-P4 + tickets) followed
+ * by the order kernel (P5) on one stream.  Either call resets the accumulator. */
+int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, int* launches);
+
 /* Per-scenario device counters of the plan's most recent solve (after it completed):
- * out[s*8 + 0..3] = time spent in setup / P2 histogram+quota / P2 keep-scan+P3+P4 / P5 preference
+ * out[s*16 + 0..3] = time spent in setup / P2 histogram+quota / P2 keep-scan+P3+P4 / P5 preference
  * order, in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
- * [6] P5 loop iterations of wave 0, [7] P2 tiles of wave 0 that needed quota ranking.  n = capacity of out in
- * int64 elements (>= 8 * n_scenarios).  Blocks until the plan's last launch has finished. */
+ * [6] P5 rounds (round form), [7] P2 tiles of wave 0 that needed quota ranking, [8] order kernel
+ * time (ticks), and for the ticket form [9] solver iterations, [10] of those with no row loaded in
+ * any lane, [11] with rows but none ready, [12] feeder iterations, [13] of those without work.  n = capacity of out in
+ * int64 elements (>= KAS_STATS_PER_SCENARIO * n_scenarios).  Blocks until the plan's last launch has finished. */
 /* Behaviour switches of a plan (default 0); every combination produces identical results, they
  * exist so that the alternative forms can be tested and timed on the same inputs.
  *   KAS_PLAN_GENERIC_FILL  always run the general multi-sweep sticky fill instead of the
  *                          rack-diverse histogram/quota form
  *   KAS_PLAN_ROUND_ORDER   always run the tile-round preference ordering instead of the ticket form
- *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup: 1, 2, 4 or 8 (0 = the plan's choice) */
+ *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup of the fill kernel: 1, 2, 4 or 8
+ *   KAS_PLAN_GROUPS(n)     scenarios per wavefront of the ticket-form order kernel: 1, 2 or 4
+ *                          (0 = the plan's choice for either) */
 #define KAS_PLAN_GENERIC_FILL 1u
 #define KAS_PLAN_ROUND_ORDER  2u
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
+#define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
 
-#define KAS_STATS_PER_SCENARIO 8
+#define KAS_STATS_PER_SCENARIO 16
 int kas_plan_stats(kas_plan* plan, int64_t* out, int64_t n);
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-KAS_ABI_VERSION = 1
+KAS_ABI_VERSION = 2
 KAS_MAX_WIDTH = 8
 
 KAS_E_OK = 0
@@ -140,12 +140,11 @@ _M64 = (1 << 64) - 1
 
 def digest_cell(topic: int, row: int, slot: int, broker: int) -> int:
     """Python twin of kas_digest_cell() in include/kas_abi.h."""
-    x = ((row & 0xFFFFFFFF) << 32) | (broker & 0xFFFFFFFF)
-    x = (x + 0x9E3779B97F4A7C15 * (slot + 1)) & _M64
-    x ^= (0xD6E8FEB86659FD93 * (topic + 1)) & _M64
-    x ^= x >> 30
-    x = (x * 0xBF58476D1CE4E5B9) & _M64
-    x ^= x >> 27
-    x = (x * 0x94D049BB133111EB) & _M64
-    x ^= x >> 31
+    m32 = 0xFFFFFFFF
+    tlo = ((topic + 1) * 0x9E3779B1) & m32
+    thi = ((topic + 1) * 0x85EBCA77) & m32
+    b = ((broker & m32) ^ tlo ^ 0x7F4A7C15) & m32
+    r = ((((row << 4) & m32) | ((slot & 7) << 1) | 1) ^ (thi & 0xFFFFFFFE)) & m32
+    x = (b * r + ((r << 32) | b)) & _M64
+    x ^= x >> 29
     return x

@@ -22,32 +22,67 @@
 #include "kas_solver_body.h"
 
 // ---------------------------------------------------------------------------------------------
-// kernel
+// kernels
 // ---------------------------------------------------------------------------------------------
 template <int W, int NW>
-__global__ __launch_bounds__(64 * NW) void kas_solve_kernel(KasLaunch a) {
+__global__ __launch_bounds__(64 * NW) void kas_fill_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
-    kas::solve_scenario<W, NW>(a, s, kas_lds);
+    kas::fill_scenario<W, NW>(a, s, kas_lds);
+}
+
+template <int W, int G>
+__global__ __launch_bounds__(128) void kas_order_ticket_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::order_tickets<W, G>(a, (int32_t)blockIdx.x * G, kas_lds);
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::order_scenario_rounds<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
 typedef void (*kas_kernel_fn)(KasLaunch);
 template <int NW>
-static kas_kernel_fn kas_kernel_for_w(int Wc) {
+static kas_kernel_fn kas_fill_for_w(int Wc) {
   switch (Wc) {
-    case 2: return kas_solve_kernel<2, NW>;
-    case 3: return kas_solve_kernel<3, NW>;
-    case 4: return kas_solve_kernel<4, NW>;
-    case 5: return kas_solve_kernel<5, NW>;
-    default: return kas_solve_kernel<8, NW>;
+    case 2: return kas_fill_kernel<2, NW>;
+    case 3: return kas_fill_kernel<3, NW>;
+    case 4: return kas_fill_kernel<4, NW>;
+    case 5: return kas_fill_kernel<5, NW>;
+    default: return kas_fill_kernel<8, NW>;
   }
 }
-static kas_kernel_fn kas_kernel_for(int Wc, int NW) {
+static kas_kernel_fn kas_fill_for(int Wc, int NW) {
   switch (NW) {
-    case 1: return kas_kernel_for_w<1>(Wc);
-    case 2: return kas_kernel_for_w<2>(Wc);
-    case 8: return kas_kernel_for_w<8>(Wc);
-    default: return kas_kernel_for_w<4>(Wc);
+    case 1: return kas_fill_for_w<1>(Wc);
+    case 2: return kas_fill_for_w<2>(Wc);
+    case 8: return kas_fill_for_w<8>(Wc);
+    default: return kas_fill_for_w<4>(Wc);
+  }
+}
+template <int G>
+static kas_kernel_fn kas_order_ticket_for_g(int Wc) {
+  switch (Wc) {
+    case 2: return kas_order_ticket_kernel<2, G>;
+    default: return kas_order_ticket_kernel<3, G>;
+  }
+}
+static kas_kernel_fn kas_order_ticket_for(int Wc, int G) {
+  switch (G) {
+    case 1: return kas_order_ticket_for_g<1>(Wc);
+    case 2: return kas_order_ticket_for_g<2>(Wc);
+    default: return kas_order_ticket_for_g<4>(Wc);
+  }
+}
+static kas_kernel_fn kas_order_round_for(int Wc) {
+  switch (Wc) {
+    case 2: return kas_order_round_kernel<2>;
+    case 3: return kas_order_round_kernel<3>;
+    case 4: return kas_order_round_kernel<4>;
+    case 5: return kas_order_round_kernel<5>;
+    default: return kas_order_round_kernel<8>;
   }
 }
 
@@ -79,7 +114,9 @@ struct kas_plan {
   kas_ctx* ctx;
   KasShape shape;
   int Wc;                       // instantiated width class
-  int NW;                       // wavefronts per scenario workgroup
+  int NW;                       // wavefronts per scenario workgroup of the fill kernel
+  int G;                        // scenarios per wavefront of the ticket-form order kernel
+  int tickets;                  // 1: ticket form of P5, 0: round form
   uint32_t flags;               // KAS_FLAG_*
   KasLds lds;
   int32_t n_scenarios, n_topics;
@@ -95,7 +132,7 @@ struct kas_plan {
   int64_t* d_stats;
   hipStream_t last_stream;
   // kernel timing: event pairs recorded around every launch on the launch stream
-  hipEvent_t ev_start[KAS_TIMER_SLOTS], ev_stop[KAS_TIMER_SLOTS];
+  hipEvent_t ev_start[KAS_TIMER_SLOTS], ev_mid[KAS_TIMER_SLOTS], ev_stop[KAS_TIMER_SLOTS];
   int timer_next, timer_count;
 };
 
@@ -185,6 +222,7 @@ void kas_plan_destroy(kas_plan* p) {
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
     if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
+    if (p->ev_mid[i]) (void)hipEventDestroy(p->ev_mid[i]);
   }
   delete p;
 }
@@ -197,21 +235,38 @@ static int upload(void** dst, const void* src, size_t bytes, hipStream_t st) {
   return KAS_E_OK;
 }
 
+// opt every kernel this plan may launch into its dynamic LDS size
+static int kas_plan_set_kernels(kas_plan* p) {
+  KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, p->lds.total));
+  if (p->Wc <= 3)
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kas_order_ticket_lds(p->shape.n_max, p->G)));
+  KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kas_order_round_lds(p->shape.n_max, p->Wc)));
+  return KAS_E_OK;
+}
+
 int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan) {
   if (!ctx || !batch || !out_plan) return set_error(KAS_E_INVALID_ARG, "NULL argument");
   *out_plan = nullptr;
   KasShape sh;
   std::string err;
-  int rc = kas_shape_batch(batch, &sh, &err, 0);
+  int rc = kas_shape_batch(batch, &sh, &err, 0, 0);
   if (rc != KAS_E_OK) return set_error(rc, err);
   KAS_HIP_TRY(hipSetDevice(ctx->device));
 
   kas_plan* p = new kas_plan();
   memset((void*)p->ev_start, 0, sizeof(p->ev_start));
   memset((void*)p->ev_stop, 0, sizeof(p->ev_stop));
+  memset((void*)p->ev_mid, 0, sizeof(p->ev_mid));
   p->ctx = ctx; p->shape = sh;
   p->Wc = sh.Wc;
   p->NW = sh.NW;
+  p->G = sh.G;
+  p->tickets = sh.tickets_ok;
   p->lds = sh.lds;
   p->flags = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
@@ -247,16 +302,16 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
     if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "stats buffer: " + std::string(hipGetErrorString(e))); }
   }
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
-    if (hipEventCreate(&p->ev_start[i]) != hipSuccess || hipEventCreate(&p->ev_stop[i]) != hipSuccess) {
+    if (hipEventCreate(&p->ev_start[i]) != hipSuccess || hipEventCreate(&p->ev_stop[i]) != hipSuccess ||
+        hipEventCreate(&p->ev_mid[i]) != hipSuccess) {
       kas_plan_destroy(p);
       return set_error(KAS_E_HIP, "hipEventCreate failed");
     }
   }
   {
-    hipError_t e = hipFuncSetAttribute((const void*)kas_kernel_for(p->Wc, p->NW),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, p->lds.total);
-    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
-    e = hipStreamSynchronize(st);   // descriptors are resident before the caller may free its copies
+    int rc2 = kas_plan_set_kernels(p);
+    if (rc2 != KAS_E_OK) { kas_plan_destroy(p); return rc2; }
+    hipError_t e = hipStreamSynchronize(st);   // descriptors are resident before the caller may free its copies
     if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_HIP, hipGetErrorString(e)); }
   }
 #undef KAS_PLAN_TRY
@@ -281,15 +336,24 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off; a.stats = p->d_stats;
-  a.orph = p->d_orph; a.orph_off = p->d_orph_off; a.nw = p->NW;
+  a.orph = p->d_orph; a.orph_off = p->d_orph_off;
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
-  a.hist_separate = p->shape.hist_separate; a.flags = p->flags;
+  a.flags = p->flags;
+  const bool tickets = p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
   const int slot = p->timer_next;
   KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
-  hipLaunchKernelGGL(kas_kernel_for(p->Wc, p->NW), dim3((unsigned)p->n_scenarios), dim3(64u * (unsigned)p->NW),
+  hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3((unsigned)p->n_scenarios), dim3(64u * (unsigned)p->NW),
                      (size_t)p->lds.total, st, a);
+  KAS_HIP_TRY(hipGetLastError());
+  KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
+  if (tickets)
+    hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G), dim3((unsigned)((p->n_scenarios + p->G - 1) / p->G)),
+                       dim3(128), (size_t)kas_order_ticket_lds(p->shape.n_max, p->G), st, a);
+  else
+    hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
+                       (size_t)kas_order_round_lds(p->shape.n_max, p->Wc), st, a);
   KAS_HIP_TRY(hipGetLastError());
   KAS_HIP_TRY(hipEventRecord(p->ev_stop[slot], st));
   p->timer_next = (slot + 1) % KAS_TIMER_SLOTS;
@@ -297,41 +361,64 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   return KAS_E_OK;
 }
 
-int kas_plan_kernel_time_us(kas_plan* p, double* avg_us, int* launches) {
-  if (!p || !avg_us || !launches) return set_error(KAS_E_INVALID_ARG, "NULL argument");
-  *avg_us = 0.0; *launches = 0;
+static int kas_plan_times(kas_plan* p, double* fill_us, double* order_us, int* launches) {
+  *fill_us = 0.0; *order_us = 0.0; *launches = 0;
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
-  double total_ms = 0.0;
+  double f_ms = 0.0, o_ms = 0.0;
   int n = 0;
   for (int i = 0; i < p->timer_count; ++i) {
     int slot = (p->timer_next - 1 - i + 2 * KAS_TIMER_SLOTS) % KAS_TIMER_SLOTS;
     KAS_HIP_TRY(hipEventSynchronize(p->ev_stop[slot]));
     float ms = 0.f;
-    KAS_HIP_TRY(hipEventElapsedTime(&ms, p->ev_start[slot], p->ev_stop[slot]));
-    total_ms += ms; ++n;
+    KAS_HIP_TRY(hipEventElapsedTime(&ms, p->ev_start[slot], p->ev_mid[slot]));
+    f_ms += ms;
+    KAS_HIP_TRY(hipEventElapsedTime(&ms, p->ev_mid[slot], p->ev_stop[slot]));
+    o_ms += ms;
+    ++n;
   }
   p->timer_count = 0;
   *launches = n;
-  *avg_us = n ? total_ms * 1000.0 / n : 0.0;
+  if (n) { *fill_us = f_ms * 1000.0 / n; *order_us = o_ms * 1000.0 / n; }
   return KAS_E_OK;
+}
+
+int kas_plan_kernel_time_us(kas_plan* p, double* avg_us, int* launches) {
+  if (!p || !avg_us || !launches) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  double f = 0.0, o = 0.0;
+  int rc = kas_plan_times(p, &f, &o, launches);
+  *avg_us = f + o;
+  return rc;
+}
+
+int kas_plan_phase_times_us(kas_plan* p, double* fill_us, double* order_us, int* launches) {
+  if (!p || !fill_us || !order_us || !launches) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  return kas_plan_times(p, fill_us, order_us, launches);
 }
 
 int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   if (!p) return set_error(KAS_E_INVALID_ARG, "plan == NULL");
-  const int nw = (int)((flags >> 8) & 0xfu);
+  const int nw = (int)((flags >> 8) & 0xfu), g = (int)((flags >> 12) & 0xfu);
+  if (nw != 0 && nw != 1 && nw != 2 && nw != 4 && nw != 8)
+    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_WAVES: waves per scenario must be 1, 2, 4 or 8");
+  if (g != 0 && g != 1 && g != 2 && g != 4)
+    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
+  const KasShape& sh = p->shape;
   if (nw != 0 && nw != p->NW) {
-    if (nw != 1 && nw != 2 && nw != 4 && nw != 8)
-      return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_WAVES: waves per scenario must be 1, 2, 4 or 8");
-    const KasShape& sh = p->shape;
-    KasLds l = kas_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch, sh.hist_separate);
+    KasLds l = kas_fill_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch);
     if (l.total > KAS_LDS_LIMIT)
       return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at that many waves");
-    KAS_HIP_TRY(hipSetDevice(p->ctx->device));
-    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_kernel_for(p->Wc, nw),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, l.total));
     p->lds = l;
     p->NW = nw;
   }
+  if (g != 0 && g != p->G) {
+    if (kas_order_ticket_lds(sh.n_max, g) > KAS_LDS_LIMIT ||
+        (int64_t)g * kas_order_ticket_group_bytes(sh.n_max, g) > 65536)
+      return set_error(KAS_E_UNSUPPORTED, "LDS of the order kernel exceeds 160 KiB at that many groups");
+    p->G = g;
+  }
+  KAS_HIP_TRY(hipSetDevice(p->ctx->device));
+  int rc = kas_plan_set_kernels(p);
+  if (rc != KAS_E_OK) return rc;
   p->flags = flags & 0xffu;
   return KAS_E_OK;
 }

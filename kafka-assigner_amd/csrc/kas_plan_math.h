@@ -1,7 +1,13 @@
-// kas_plan_math.h — host-side shape validation, LDS carve-up and launch arguments.
+// kas_plan_math.h — host-side shape validation, LDS carve-ups and launch arguments.
 //
 // Pure C++ (no HIP calls) so that the exact same planning code runs in the product library
-// (kas_abi.cpp) and in the CPU emulation harness under tests/emu/.
+// (kas_hip.hip) and in the CPU emulation harness under tests/emu/.
+//
+// A solve is two kernels on one stream:
+//   fill   (P0-P4 + tickets)  one workgroup of NW wavefronts per scenario; LDS = node state
+//   order  (P5)               ticket form: one lane group per scenario, G groups per wavefront,
+//                             LDS = packed 16-bit counters; round form: one wavefront per
+//                             scenario, LDS = int32 counters + lane masks
 #pragma once
 #include <stdint.h>
 #include <string>
@@ -30,23 +36,17 @@ struct KasLaunch {
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
   int32_t idmap_entries;        // entries of the direct broker-id -> node-index table
   int32_t need_bsearch;         // some scenario's id range exceeds idmap_entries
-  int32_t hist_separate;        // the sweep histogram has its own LDS (else it aliases cnt)
   uint32_t flags;               // KAS_FLAG_*
-  int32_t nw;                   // wavefronts per workgroup the kernel was launched with
 };
 
 #define KAS_FLAG_GENERIC_FILL 1u   // always use the general sticky fill (testing / comparison)
 #define KAS_FLAG_ROUND_ORDER  2u   // always use the tile-round preference ordering (testing / comparison)
 
-// Byte offsets into the workgroup's dynamic LDS (one workgroup of NW wavefronts per scenario).
-//   cnt     Context counters; the only state that persists across the topics of a scenario
-//   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]; aliases cnt unless a
-//           scenario carries Context state into a topic (hist_separate)
-//   region A (P2-P4): load, qrs, rack, live, idmap, ids, ring
-//   region T (P5, aliases region A): run, dep, nid
-//   ctl     control words + per-wave digest slots
+// Byte offsets into the dynamic LDS of the fill kernel.
+//   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
+//   load, qrs, rack, live, idmap, ids, ring: node state of P2-P4
+//   ctl     control words
 struct KasLds {
-  int32_t off_cnt;     // int32  [n_max * CS]   count[node][replica index] (KAS:244-302)
   int32_t off_x;       // int32  [max(W,NW)][n_max]
   int32_t off_load;    // int32  [n_max]        |Node.assignedPartitions|
   int32_t off_qrs;     // int32  [n_max]        saturating sweep r* << 28 | quota in that sweep
@@ -55,10 +55,7 @@ struct KasLds {
   int32_t off_idmap;   // int16  [idmap_entries] broker id - min_id -> node index
   int32_t off_ids;     // int32  [n_max]        sorted ids for binary search (only if needed)
   int32_t off_ring;    // orphan window: p[128] int32, meta[128] int32, rack[W][128] int16
-  int32_t off_run;     // int32  [n_max]        tickets handed out per node          (region T)
-  int32_t off_dep;     // uint64 [n_max]        lane-sharing masks per node          (region T)
-  int32_t off_nid;     // int32  [n_max]        broker id per node index             (region T)
-  int32_t off_ctl;     // int32  [KAS_CTL_INTS] + uint64 [NW] digest slots
+  int32_t off_ctl;     // int32  [KAS_CTL_INTS]
   int32_t total;
 };
 
@@ -69,39 +66,26 @@ struct KasLds {
 #define KAS_MAX_WAVES 8
 #define KAS_CTL_INTS 32
 // control words
-#define KAS_CTL_VIOL 0        // some row's replicas are not rack-diverse
+#define KAS_CTL_VIOL 0        // some row's replicas are not rack-diverse / node table invalid
 #define KAS_CTL_FAILROW 1     // first row P4 could not place (KAS:183-184), or -1
-#define KAS_CTL_WM 2          // tiles the ticket pass has published
 #define KAS_CTL_MOVED_R 3
 #define KAS_CTL_MOVED_P 4
-#define KAS_CTL_MAXT 5        // largest ticket any row can get (decides the packed format)
-#define KAS_CTL_HASHFAIL 6
 #define KAS_CTL_OC 8          // [NW] orphans found per chunk
+
+#define KAS_TICKET_LIMIT 65535  // tickets (= 16-bit counters of the order kernel) stay below this
 
 KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_t)15); }
 
-// Counter row stride in ints: 3-wide rows are padded to 4 so a row is one 16-byte LDS read.
+// int32 counter row stride of the round form: 3-wide rows are padded to one 16-byte LDS read
 KAS_ABI_FN int32_t kas_cnt_stride(int32_t W) { return W == 3 ? 4 : W; }
 
-KAS_ABI_FN KasLds kas_lds_layout(int32_t n_max, int32_t W, int32_t NW, int32_t idmap_entries,
-                                    int32_t need_bsearch, int32_t hist_separate) {
+KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int32_t idmap_entries,
+                                         int32_t need_bsearch) {
   KasLds L;
   int64_t n = n_max > 0 ? n_max : 1;
   int64_t o = 0;
   const int64_t xr = W > NW ? W : NW;
-  const int64_t cnt_bytes = 4 * n * kas_cnt_stride(W), x_bytes = 4 * n * xr;
-  L.off_cnt = (int32_t)o;
-  if (hist_separate) {
-    o = kas_align16(o + cnt_bytes);
-    L.off_x = (int32_t)o; o = kas_align16(o + x_bytes);
-  } else {
-    L.off_x = (int32_t)o; o = kas_align16(o + (cnt_bytes > x_bytes ? cnt_bytes : x_bytes));
-  }
-  const int64_t base = o;
-  L.off_run = (int32_t)base;
-  L.off_dep = kas_align16(base + 4 * n);
-  L.off_nid = kas_align16((int64_t)L.off_dep + 8 * n);
-  const int64_t endT = kas_align16((int64_t)L.off_nid + 4 * n);
+  L.off_x = (int32_t)o;     o = kas_align16(o + 4 * n * xr);
   L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n);
   L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
   L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
@@ -109,13 +93,29 @@ KAS_ABI_FN KasLds kas_lds_layout(int32_t n_max, int32_t W, int32_t NW, int32_t i
   L.off_idmap = (int32_t)o; o = kas_align16(o + 2 * (int64_t)(idmap_entries > 0 ? idmap_entries : 1));
   L.off_ids = (int32_t)o;   if (need_bsearch) o = kas_align16(o + 4 * n);
   L.off_ring = (int32_t)o;  o = kas_align16(o + KAS_RING_CAP * (4 + 4 + 2 * (int64_t)W));
-  o = o > endT ? o : endT;
-  L.off_ctl = (int32_t)o;   o = kas_align16(o + 4 * KAS_CTL_INTS + 8 * KAS_MAX_WAVES);
+  L.off_ctl = (int32_t)o;   o = kas_align16(o + 4 * KAS_CTL_INTS);
   L.total = (int32_t)o;
   return L;
 }
 
-// widths the kernel is instantiated for; a batch uses the smallest one >= its widest list
+// ticket form of order: per lane group (= scenario) uint64 counter rows [n_max + 1] (4 x uint16:
+// count[node][0..2] + commits; + the padding holder's row), int32 tickets handed out per node
+// [n_max], int32 broker id per node [n_max], one lane mask per node [n_max] (uint64 for 64-lane
+// groups, else uint32); a ring of 8 16-byte row slots per lane; one digest slot per group
+KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  return kas_align16(8 * (n + 1) + 8 * n + (G == 1 ? 8 : 4) * n);
+}
+KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G) {
+  return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G) + 8 * 64 * 16 + 8 * (int64_t)G);
+}
+// round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
+KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  return kas_align16(kas_align16(4 * n * kas_cnt_stride(W)) + 8 * n + 64);
+}
+
+// widths the kernels are instantiated for; a batch uses the smallest one >= its widest list
 KAS_ABI_FN int32_t kas_width_class(int32_t W) { return W <= 2 ? 2 : W <= 5 ? W : 8; }
 
 struct KasShape {
@@ -124,12 +124,13 @@ struct KasShape {
   int32_t n_max = 0;
   int32_t idmap_entries = 0;
   int32_t need_bsearch = 0;
-  int32_t hist_separate = 0;          // some scenario has several topics or a Context
+  int32_t tickets_ok = 1;             // the ticket form of P5 is applicable to every scenario
   std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
   int64_t accmask_words = 0;
   std::vector<int64_t> orph_off;      // per scenario, in int32 elements
   int64_t orph_ints = 0;
-  int32_t NW = 1;                     // wavefronts per scenario workgroup (1, 2, 4 or 8)
+  int32_t NW = 1;                     // wavefronts per scenario workgroup of the fill kernel
+  int32_t G = 1;                      // lane groups (= scenarios) per wavefront, ticket form
   int64_t algorithmic_bytes = 0;
   int64_t cur_need = 0, out_need = 0, aux_need = 0, ctx_need = 0;  // minimum pool lengths
   KasLds lds{};
@@ -137,10 +138,12 @@ struct KasShape {
 
 // Validate descriptors and derive everything a launch needs.  Returns KAS_E_* and fills err.
 static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::string* err,
-                                  int want_waves = 0) {
+                                  int want_waves = 0, int want_groups = 0) {
   auto fail = [&](int code, const std::string& m) { if (err) *err = m; return code; };
   if (want_waves != 0 && want_waves != 1 && want_waves != 2 && want_waves != 4 && want_waves != 8)
     return fail(KAS_E_INVALID_ARG, "waves per scenario must be 1, 2, 4 or 8");
+  if (want_groups != 0 && want_groups != 1 && want_groups != 2 && want_groups != 4)
+    return fail(KAS_E_INVALID_ARG, "scenarios per wavefront must be 1, 2 or 4");
   if (!b || b->n_scenarios < 0 || b->n_topics < 0) return fail(KAS_E_INVALID_ARG, "null/negative batch");
   if (b->n_scenarios > 0 && (!b->scenarios)) return fail(KAS_E_INVALID_ARG, "scenarios == NULL");
   if (b->n_topics > 0 && !b->topics) return fail(KAS_E_INVALID_ARG, "topics == NULL");
@@ -163,8 +166,10 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (range >= 1 && range <= KAS_IDMAP_CAP) { if (range > max_range_fit) max_range_fit = range; }
       else s.need_bsearch = 1;      // sparse ids (or unsorted: the kernel reports BAD_NODES)
     }
-    if (sd.ctx_off >= 0 || sd.topic_count > 1) s.hist_separate = 1;
+    // Context handed in (KAS:360-369): its counter sums are data, so ticket magnitudes cannot be
+    // bounded here -> round form
     if (sd.ctx_off >= 0) {
+      s.tickets_ok = 0;
       if (sd.ctx_width < 1 || sd.ctx_width > KAS_MAX_WIDTH)
         return fail(KAS_E_INVALID_ARG, "scenario " + std::to_string(i) + ": ctx_width outside [1,8]");
       int64_t e = sd.ctx_off + (int64_t)sd.n_nodes * sd.ctx_width;
@@ -173,7 +178,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     }
     if (sd.n_nodes > s.n_max) s.n_max = sd.n_nodes;
     s.algorithmic_bytes += 8ll * sd.n_nodes;
-    int64_t words = 0, rows = 0;
+    int64_t words = 0, rows = 0, ticket_bound = 0;
     for (int32_t k = 0; k < sd.topic_count; ++k) {
       const kas_topic_desc& td = b->topics[sd.topic_begin + k];
       std::string where = "scenario " + std::to_string(i) + " topic " + std::to_string(k) + ": ";
@@ -199,7 +204,16 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (w > words) words = w;
       if (((P + 63) / 64) * 64 > rows) rows = ((P + 63) / 64) * 64;
       s.algorithmic_bytes += 4ll * P * (td.cur_width + td.out_width);
+      // a node never holds more than cap rows of a topic (KAS:65-71, cap over <= P partitions), and
+      // a ticket on node n counts the rows that hold n so far in the scenario
+      if (td.rf >= 1 && td.rf <= sd.n_nodes && sd.n_nodes > 0) {
+        const int64_t prod = P * (int64_t)td.rf;
+        if (prod >= (1ll << 31)) s.tickets_ok = 0;
+        ticket_bound += (prod + sd.n_nodes - 1) / sd.n_nodes;
+      }
+      if (td.name_hash == (int32_t)0x80000000) s.tickets_ok = 0;   // KAS:190 index error: round form
     }
+    if (ticket_bound >= KAS_TICKET_LIMIT) s.tickets_ok = 0;
     s.accmask_off[(size_t)i] = s.accmask_words;
     s.accmask_words += words > 0 ? words : 1;
     s.orph_off[(size_t)i] = s.orph_ints;
@@ -207,24 +221,24 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   }
   s.idmap_entries = (int32_t)max_range_fit;
   s.Wc = kas_width_class(s.W);
-  // widest workgroup whose LDS carve-up fits: 4 wavefronts per scenario by default
+  if (s.Wc > 3) s.tickets_ok = 0;              // ring slots / packed counter rows hold lists up to 3
+  // widest fill workgroup whose LDS carve-up fits: 4 wavefronts per scenario by default
   int err_total = 0;
   for (int nw = want_waves > 0 ? want_waves : 4; nw >= 1; nw >>= 1) {
-    int hs = s.hist_separate;
-    KasLds l = kas_lds_layout(s.n_max, s.Wc, nw, s.idmap_entries, s.need_bsearch, hs);
-    if (l.total > KAS_LDS_LIMIT && hs) {
-      // no room for a separate histogram: alias it with the counters; topics that carry Context
-      // state then use the general sticky fill
-      hs = 0;
-      l = kas_lds_layout(s.n_max, s.Wc, nw, s.idmap_entries, s.need_bsearch, 0);
-    }
+    KasLds l = kas_fill_lds_layout(s.n_max, s.Wc, nw, s.idmap_entries, s.need_bsearch);
     err_total = l.total;
-    if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = nw; s.hist_separate = hs; err_total = 0; break; }
+    if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = nw; err_total = 0; break; }
   }
+  if (err_total == 0 && kas_order_round_lds(s.n_max, s.Wc) > KAS_LDS_LIMIT)
+    err_total = kas_order_round_lds(s.n_max, s.Wc);
   if (err_total)
     return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +
                 std::to_string(s.Wc) + " needs " + std::to_string(err_total) +
                 " B of LDS (limit 163840)");
+  // counter rows are addressed with 16-bit LDS byte offsets
+  s.G = want_groups > 0 ? want_groups : 1;
+  while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G) > 65536) s.G >>= 1;
+  if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G) > 65536) s.tickets_ok = 0;
   *sh = s;
   return KAS_E_OK;
 }

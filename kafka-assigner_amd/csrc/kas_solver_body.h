@@ -1,5 +1,5 @@
-// kas_solver_body.h — the per-scenario solver: one workgroup of NW 64-lane wavefronts per
-// scenario, all of the scenario's node state in that workgroup's LDS.
+// kas_solver_body.h — the per-scenario solver: device code of the fill kernel (one workgroup of
+// NW 64-lane wavefronts per scenario, the scenario's node state in LDS) and of the order kernels.
 //
 // Computes exactly what KafkaAssignmentStrategy.getRackAwareAssignment computes
 // (KafkaAssignmentStrategy.java:40-63, "KAS"), for every topic of a scenario in order, with the
@@ -27,24 +27,32 @@
 //  P4  first fit (KAS:162-186), wave 0: orphans in ascending row order, 64 per window, evaluated
 //      position-major over the compacted list of non-full nodes in processing order (a full
 //      node never becomes non-full; the reference spends >99% of its probes on them).
-//  P5  preference order (KAS:202-239).  Row p reads count[n][0..L) of its own nodes, picks, then
+//  P5  preference order (KAS:202-239), a kernel of its own (the order kernel): its only state
+//      is count[node][replica index], so it runs with a fraction of the fill kernel's LDS and
+//      many more scenarios per CU.  Row p reads count[n][0..L) of its own nodes, picks, then
 //      increments one counter per node, so it only has to wait for the EARLIER rows that hold
-//      one of its nodes.  Ticket form: a scan in row order hands every (row, node) its ticket =
-//      how many earlier rows hold that node (+ the node's counter sum at topic start), packed
-//      into the out row next to the node index.  Since every committed row adds exactly 1 to
-//      the counter row of each of its nodes, "sum of count[n][*] == ticket" says that all
-//      earlier rows on n have committed: lanes then work on rows independently (row = lane +
-//      k * lanes), spin on their tickets, pick and commit — no tile-wide rounds, any number of
-//      waves.  The last wave of the workgroup hands out tickets and publishes a watermark; the
-//      other waves follow it.  Round form (kept for ticket overflow and the KAS:190 index
-//      error): 64 ascending rows per tile, a lane commits once no lower lane sharing a node
-//      is pending.
+//      one of its nodes.  The chain of such waits is long (every orphan placed by first fit
+//      lands on the same few nodes, so there are at least as many dependent steps as orphans)
+//      and only ~10-20 rows are ever ready at once: P5 is latency-bound per scenario, and
+//      throughput comes from running many scenarios side by side.
+//      Ticket form: the fill kernel ends with a scan in row order that hands every (row, node)
+//      its ticket = how many earlier rows of the scenario hold that node, packed into the out
+//      row next to the node index.  Every committed row adds exactly 1 to the commit count of
+//      each of its nodes, so "commits on n == ticket" says that all earlier rows on n have
+//      committed: lanes then work on rows independently (row = lane + k * lanes), spin on their
+//      tickets, pick and commit with one LDS atomic add per node — no tile-wide rounds, and a
+//      wavefront can serve several scenarios at once (one lane group each).
+//      Round form (Context handed in, lists wider than 4, ticket overflow, the KAS:190 index
+//      error): one wavefront per scenario, 64 ascending rows per tile, a lane commits once no
+//      lower lane sharing a node is pending.
 //
 // Everything cross-lane goes through kas_wave.h; control flow around wave collectives is
 // wave-uniform and around kasw::sync() workgroup-uniform.  List positions live in registers
 // through fully unrolled loops (W is a template parameter).
 #pragma once
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "kas_abi.h"
 #include "kas_plan_math.h"
@@ -57,11 +65,10 @@ struct TopicOutcome {
   int32_t fail_partition;
   int32_t moved_replicas;
   int32_t moved_partitions;
-  uint64_t digest;
 };
 
+// LDS of the fill kernel (kas_fill_lds_layout)
 struct LdsView {
-  int32_t* cnt;
   int32_t* x;           // hist[W][N], then qc[NW][N]
   int32_t* load;
   int32_t* qrs;
@@ -72,11 +79,7 @@ struct LdsView {
   int32_t* ring_p;
   int32_t* ring_meta;
   int16_t* ring_rack;   // [W][KAS_RING_CAP]
-  int32_t* run;
-  uint64_t* dep;
-  int32_t* nid;
   int32_t* ctl;
-  uint64_t* dig;        // [NW]
 };
 
 struct NodeMap {
@@ -633,13 +636,14 @@ KAS_DEV int32_t p4_lists(const LdsView& L, const TopicView& T, int32_t live_coun
 // ---------------------------------------------------------------------------------------------
 // P5 helpers
 // ---------------------------------------------------------------------------------------------
-// The picks of one row (KAS:225-236).  hn[0..Lp) = the row's node indices ascending, c[k] = the
-// counter row of hn[k].  getLeastSeenNodeForReplicaId (KAS:263-278): the element of sorted rank i
-// is visited at position (i + idx_m) % m; the first visited strictly smallest count wins, i.e.
-// the minimum of (count, visit position).
+// The picks of one row (KAS:225-236).  Position k of the row's ascending node list has counter
+// row c[k].  getLeastSeenNodeForReplicaId (KAS:263-278): the element of sorted rank i is visited
+// at position (i + idx_m) % m; the first visited strictly smallest count wins, i.e. the minimum
+// of (count, visit position).  pos[r] = list position picked for replica index r; cnt_r[r] = its
+// counter value before the pick.
 template <int W>
-KAS_DEV void pick_row(const int32_t (&hn)[W], const int32_t (&c)[W][W], int32_t Lp, bool valid,
-                      const int32_t (&idxm)[W + 1], int32_t (&pick)[W], int32_t (&newc)[W]) {
+KAS_DEV void pick_row(const int32_t (&c)[W][W], int32_t Lp, bool valid, const int32_t (&idxm)[W + 1],
+                      int32_t (&pos)[W], int32_t (&cnt_r)[W]) {
   uint32_t alive = valid ? ((1u << Lp) - 1u) : 0u;       // sorted-set positions still in nodeSet
 #pragma unroll
   for (int r = 0; r < W; ++r) {
@@ -656,12 +660,12 @@ KAS_DEV void pick_row(const int32_t (&hn)[W], const int32_t (&c)[W][W], int32_t 
       keys[k] = ((c[k][r] << 3) | rr) | dead;
       best = keys[k] < best ? keys[k] : best;
     }
-    int32_t pos = 0;
+    int32_t ps = 0;
 #pragma unroll
-    for (int k = 1; k < W; ++k) pos = keys[k] == best ? k : pos;
-    pick[r] = sel<W>(hn, pos);
-    newc[r] = (best >> 3) + 1;
-    alive &= ~(1u << pos);                               // nodeSet.remove (KAS:232)
+    for (int k = 1; k < W; ++k) ps = keys[k] == best ? k : ps;
+    pos[r] = ps;
+    cnt_r[r] = best >> 3;
+    alive &= ~(1u << ps);                                // nodeSet.remove (KAS:232)
   }
 }
 
@@ -686,245 +690,15 @@ KAS_DEV void sort_holders(const int32_t (&cells)[W], int32_t (&h)[W], int32_t& L
   }
 }
 
-#define KAS_TICKET_SHIFT 15
-#define KAS_TICKET_LIMIT ((1 << 17) - 1)   // tickets must stay below this to fit next to a node index
-
-// Ticket pass (one wave, rows in ascending order): out row <- node index | ticket << 15 per
-// holder, ascending node index; publishes the number of finished tiles in ctl[WM].
-template <int W>
-KAS_DEV void ticket_pass(const LdsView& L, const TopicView& T) {
-  const int lane = kasw::lane();
-  const uint64_t lt = kasw::lanemask_lt();
-  const uint64_t mybit = 1ull << lane;
-  const int32_t P = T.P, ow = T.ow;
-  int32_t* out = T.out;
-  int32_t nx[W];
-#pragma unroll
-  for (int k = 0; k < W; ++k) nx[k] = (lane < P && k < ow) ? out[(int64_t)lane * ow + k] : -1;
-  for (int32_t tile = 0; tile < T.nt; ++tile) {
-    const int32_t p = (tile << 6) + lane;
-    const bool active = p < P;
-    int32_t h[W], Lp;
-    sort_holders<W>(nx, h, Lp);
-    {
-      const int32_t pn = p + 64;
-#pragma unroll
-      for (int k = 0; k < W; ++k) nx[k] = (pn < P && k < ow) ? out[(int64_t)pn * ow + k] : -1;
-    }
-    const bool holds = active && Lp > 0;
-    int32_t hn[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) hn[k] = (holds && k < Lp) ? h[k] : 0;
-    if (holds) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) if (k < Lp) kasw::lds_atomic_or_u64(&L.dep[hn[k]], mybit);
-    }
-    kasw::lockstep();
-    uint64_t m[W];
-    int32_t s[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-      const bool on = holds && k < Lp;
-      m[k] = on ? L.dep[hn[k]] : 0ull;
-      s[k] = on ? L.run[hn[k]] : 0;
-    }
-    kasw::lockstep();
-    if (holds) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        if (k < Lp && (m[k] & lt) == 0ull) {               // lowest lane holding this node
-          L.run[hn[k]] = s[k] + kasw::popc(m[k]);
-          L.dep[hn[k]] = 0ull;
-        }
-      }
-    }
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        if (k < ow) {
-          const int32_t ticket = s[k] + kasw::popc(m[k] & lt);
-          out[(int64_t)p * ow + k] = (holds && k < Lp) ? (hn[k] | (ticket << KAS_TICKET_SHIFT)) : -1;
-        }
-      }
-    }
-    kasw::wave_sync();                                     // rows + counters of this tile are out
-    if (lane == 0) kasw::publish(&L.ctl[KAS_CTL_WM], tile + 1);
-  }
-}
-
-// Ticket form of P5: this lane owns rows first, first + stride, ...; waits for each row's
-// tickets, picks (KAS:225-233) and commits (KAS:236, 254-261).
-template <int W>
-KAS_DEV void order_rows(const LdsView& L, const TopicView& T, const int32_t (&idxm)[W + 1],
-                        int32_t first, int32_t stride, uint32_t topic_k, uint64_t& digest,
-                        int64_t (&st)[8]) {
-  constexpr int CS = cnt_stride<W>();
-  const int32_t P = T.P, ow = T.ow;
-  int32_t* out = T.out;
-  bool cv = false, nv = false;
-  int32_t cp = 0, np = 0, nxp = first;
-  int32_t hn[W], tk[W], nc[W], Lp = 0;
-#pragma unroll
-  for (int k = 0; k < W; ++k) { hn[k] = 0; tk[k] = 0; nc[k] = -1; }
-  for (;;) {
-    kasw::lockstep();                                      // LDS / global are re-read below
-    const int32_t wm = kasw::observe(&L.ctl[KAS_CTL_WM]);
-    if (!cv && nv) {                                       // next row becomes the current one
-      Lp = 0;
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        const bool on = nc[k] >= 0;
-        hn[k] = on ? (nc[k] & ((1 << KAS_TICKET_SHIFT) - 1)) : 0;
-        tk[k] = on ? (int32_t)((uint32_t)nc[k] >> KAS_TICKET_SHIFT) : 0;
-        Lp += on ? 1 : 0;
-      }
-      cp = np;
-      cv = Lp > 0;
-      nv = false;
-    }
-    if (!nv && nxp < P && (nxp >> 6) < wm) {               // fetch the row after that
-#pragma unroll
-      for (int k = 0; k < W; ++k) nc[k] = k < ow ? out[(int64_t)nxp * ow + k] : -1;
-      np = nxp;
-      nv = true;
-      nxp += stride;
-    }
-    if (kasw::ballot(cv || nv || nxp < P) == 0) break;
-    if (kasw::ballot(cv) == 0) { kasw::spin_pause(); continue; }
-    st[6] += 1;
-    int32_t c[W][W];
-    bool ready = cv;
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-      load_cnt_row<W>(c[k], L.cnt + hn[k] * CS);
-      int32_t sum = 0;
-#pragma unroll
-      for (int r = 0; r < W; ++r) sum += c[k][r];
-      ready = ready && (k >= Lp || sum == tk[k]);         // every earlier row on hn[k] committed
-    }
-    if (kasw::ballot(ready) == 0) { kasw::spin_pause(); continue; }   // all waiting on other waves
-    int32_t pick[W], newc[W];
-    pick_row<W>(hn, c, Lp, cv, idxm, pick, newc);
-    if (ready) {
-#pragma unroll
-      for (int r = 0; r < W; ++r) {
-        if (r < Lp) {
-          L.cnt[pick[r] * CS + r] = newc[r];               // updateCountersFromList (KAS:254-261)
-          const int32_t id = L.nid[pick[r]];
-          out[(int64_t)cp * ow + r] = id;
-          digest += kas_digest_cell(topic_k, (uint32_t)cp, (uint32_t)r, id);
-        }
-      }
-      cv = false;
-    }
-  }
-}
-
-// Round form of P5 (one wave): 64 ascending rows per tile; once per tile every lane ors its
-// lane bit into a 64-bit LDS mask per node it holds and reads those masks back, so it knows
-// which LOWER lanes share a node with it; each round a lane none of whose lower sharers is
-// still pending commits.  Returns true on the KAS:190 index error.
-template <int W>
-KAS_DEV bool order_rounds(const LdsView& L, const TopicView& T, const int32_t (&idxm)[W + 1],
-                          const int32_t* g_node_id, uint32_t topic_k, uint64_t& digest,
-                          int64_t (&st)[8]) {
-  constexpr int CS = cnt_stride<W>();
-  const int lane = kasw::lane();
-  const uint64_t lt = kasw::lanemask_lt();
-  const int32_t P = T.P, ow = T.ow, nt = T.nt;
-  int32_t* out = T.out;
-  const bool hash_min = T.hash == (int32_t)0x80000000;
-  const uint64_t mybit = 1ull << lane;
-  int32_t nx[W];                                  // next tile's out row (software prefetch)
-#pragma unroll
-  for (int k = 0; k < W; ++k) nx[k] = (lane < P && k < ow) ? out[(int64_t)lane * ow + k] : -1;
-  for (int32_t tile = 0; tile < nt; ++tile) {
-    const int32_t p = (tile << 6) + lane;
-    const bool active = p < P;
-    int32_t h[W], Lp;
-    sort_holders<W>(nx, h, Lp);
-    {
-      const int32_t pn = p + 64;
-#pragma unroll
-      for (int k = 0; k < W; ++k) nx[k] = (pn < P && k < ow) ? out[(int64_t)pn * ow + k] : -1;
-    }
-    if (hash_min) {
-      // KAS:190 index error: some set size m <= L has a negative rotation offset
-      bool bad = false;
-#pragma unroll
-      for (int m = 1; m <= W; ++m) bad = bad || (m <= Lp && idxm[m] < 0);
-      if (kasw::ballot(bad) != 0) return true;
-    }
-    bool pending = active && Lp > 0;
-    // node index per list position, clamped so that unused positions address node 0
-    int32_t hn[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) hn[k] = (pending && k < Lp) ? h[k] : 0;
-    if (pending) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) if (k < Lp) kasw::lds_atomic_or_u64(&L.dep[hn[k]], mybit);
-    }
-    kasw::lockstep();
-    uint64_t share = 0;
-#pragma unroll
-    for (int k = 0; k < W; ++k) share |= (pending && k < Lp) ? L.dep[hn[k]] : 0ull;
-    kasw::lockstep();
-    if (pending) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) if (k < Lp) L.dep[hn[k]] = 0ull;
-    }
-    const uint64_t depmask = share & lt;
-
-    int32_t lst[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) lst[k] = -1;
-    for (;;) {
-      const uint64_t pend = kasw::ballot(pending);
-      if (pend == 0) break;
-      st[6] += 1;
-      const bool ready = pending && (depmask & pend) == 0;
-      // count[node][0..W) of my nodes (KAS:280-301); every lane computes, ready lanes commit
-      int32_t c[W][W];
-#pragma unroll
-      for (int k = 0; k < W; ++k) load_cnt_row<W>(c[k], L.cnt + hn[k] * CS);
-      int32_t pick[W], newc[W];
-      pick_row<W>(hn, c, Lp, pending, idxm, pick, newc);
-      if (ready) {
-#pragma unroll
-        for (int r = 0; r < W; ++r) {
-          if (r < Lp) {
-            lst[r] = pick[r];
-            L.cnt[pick[r] * CS + r] = newc[r];             // updateCountersFromList (KAS:254-261)
-          }
-        }
-        pending = false;
-      }
-      kasw::lockstep();
-    }
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        if (k < ow) {
-          const int32_t node = lst[k];
-          const int32_t id = node >= 0 ? g_node_id[node] : -1;
-          out[(int64_t)p * ow + k] = id;
-          if (node >= 0) digest += kas_digest_cell(topic_k, (uint32_t)p, (uint32_t)k, id);
-        }
-      }
-    }
-  }
-  return false;
-}
-
 // ---------------------------------------------------------------------------------------------
-// One topic == one getRackAwareAssignment call.  Executed by the whole workgroup.
+// fill kernel: one topic == P0-P4 of one getRackAwareAssignment call (+ tickets).  Executed by
+// the whole workgroup.  Leaves the out rows holding node indices (holders in acceptance order,
+// -1 padded); the order kernel turns them into the final preference lists.
 // ---------------------------------------------------------------------------------------------
 template <int W, int NW>
-KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, uint32_t topic_k,
-                                 const LdsView& L, const NodeMap& nm, const int32_t* g_node_id,
-                                 const int32_t* g_node_rack, uint64_t* accmask, int32_t* orph,
-                                 bool cnt_live, int64_t (&st)[8]) {
-  constexpr int CS = cnt_stride<W>();
+KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, const LdsView& L,
+                                const NodeMap& nm, const int32_t* g_node_id, const int32_t* g_node_rack,
+                                uint64_t* accmask, int32_t* orph, int64_t (&st)[8]) {
   constexpr int NT = 64 * NW;
   const int lane = kasw::lane();
   const int tid = kasw::tid();
@@ -944,7 +718,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
 
   TopicOutcome res;
   res.status = KAS_OK; res.fail_partition = -1;
-  res.moved_replicas = 0; res.moved_partitions = 0; res.digest = 0;
+  res.moved_replicas = 0; res.moved_partitions = 0;
 
   int64_t tmark = kasw::clock_ticks();
   // ---- P0: capacity (KAS:45, 65-71) over |partitions| ---------------------------------------
@@ -968,20 +742,17 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
     for (int32_t i = tid; i < N; i += NT) L.ids[i] = g_node_id[i];
   }
   if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : 0;
-  if (tid < NW) L.dig[tid] = 0ull;
-  kasw::sync();
-  if (nm.range != 0u)
-    for (int32_t i = tid; i < N; i += NT) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
-
-  // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
-  // rack-diverse form when the histogram pass proves it applicable and its LDS table is free
-  // (it may alias the Context counters, which must then not carry state into this topic)
-  const bool try_fast = T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && (a.hist_separate || !cnt_live) &&
-                        cap >= 0 && cap < (1 << 28);
+  // rack-diverse form of the sticky fill unless switched off or the quota word cannot hold cap
+  const bool try_fast = T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && cap >= 0 && cap < (1 << 28);
   if (try_fast)
     for (int32_t i = tid; i < N * W; i += NT) L.x[i] = 0;
   kasw::sync();
+  if (nm.range != 0u)
+    for (int32_t i = tid; i < N; i += NT) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
+  kasw::sync();
   { const int64_t now = kasw::clock_ticks(); st[0] += now - tmark; tmark = now; }
+
+  // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
   bool fast = false;
   if (try_fast) {
     const bool viol = fill_pass_a<W, NW>(L, T, nm, wave);
@@ -1036,7 +807,7 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
       kasw::lds_atomic_add(&L.ctl[KAS_CTL_MOVED_P], mp);
     }
   }
-  kasw::sync();   // out rows of P3/P4 are visible to every wave; region A is dead from here
+  kasw::sync();   // out rows of P3/P4 are visible to every wave; load/qrs are dead from here
   { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
   {
     const int32_t fail_row = L.ctl[KAS_CTL_FAILROW];
@@ -1046,82 +817,24 @@ KAS_DEV TopicOutcome solve_topic(const KasLaunch& a, const kas_topic_desc& td, u
       return res;
     }
   }
-
-  // ---- P5: preference lists (KAS:62, 202-239) ------------------------------------------------
-  // region T: tickets handed out per node start at the node's counter sum, lane masks clear,
-  // broker ids for the final rows; the largest ticket decides whether tickets fit the packed row
-  {
-    int32_t maxt = 0;
-    const bool zero_cnt = fast && !a.hist_separate;          // the histogram lived in cnt's LDS
-    for (int32_t n = tid; n < N; n += NT) {
-      int32_t s = 0;
-      if (zero_cnt) {
-#pragma unroll
-        for (int r = 0; r < CS; ++r) L.cnt[n * CS + r] = 0;
-      } else if (cnt_live) {
-#pragma unroll
-        for (int r = 0; r < W; ++r) s += L.cnt[n * CS + r];
-      }
-      const int32_t ld = L.load[n];
-      maxt = s + ld > maxt ? s + ld : maxt;
-      maxt = (s < 0 || ld < 0) ? 0x7fffffff : maxt;
-      L.run[n] = s;
-    }
-    kasw::sync();                                            // load[] is read before dep/nid overwrite region A
-    for (int32_t n = tid; n < N; n += NT) {
-      L.dep[n] = 0ull;
-      L.nid[n] = g_node_id[n];
-    }
-    kasw::lds_atomic_max((uint32_t*)&L.ctl[KAS_CTL_MAXT], (uint32_t)maxt);
-    kasw::sync();
-  }
-  // rotation offsets idx_m = Math.abs(hash) % m for every set size m (KAS:190, via KAS:267)
-  int32_t idxm[W + 1];
-#pragma unroll
-  for (int m = 1; m <= W; ++m) idxm[m] = java_abs_mod(hash, m);
-  idxm[0] = 0;
-  const bool use_tickets = !(a.flags & KAS_FLAG_ROUND_ORDER) && hash != (int32_t)0x80000000 &&
-                           (uint32_t)L.ctl[KAS_CTL_MAXT] < (uint32_t)KAS_TICKET_LIMIT;
-  uint64_t digest = 0;
-  if (use_tickets) {
-    if (NW == 1) {
-      ticket_pass<W>(L, T);
-      order_rows<W>(L, T, idxm, lane, 64, topic_k, digest, st);
-    } else if (wave == NW - 1) {
-      ticket_pass<W>(L, T);
-    } else {
-      order_rows<W>(L, T, idxm, tid, 64 * (NW - 1), topic_k, digest, st);
-    }
-  } else if (wave == 0) {
-    if (order_rounds<W>(L, T, idxm, g_node_id, topic_k, digest, st) && lane == 0)
-      L.ctl[KAS_CTL_HASHFAIL] = 1;
-  }
-  {
-    const uint64_t dsum = kasw::wave_sum_u64(digest);
-    if (lane == 0) L.dig[wave] = dsum;
-  }
-  kasw::sync();
-  { const int64_t now = kasw::clock_ticks(); st[3] += now - tmark; tmark = now; }
-  if (L.ctl[KAS_CTL_HASHFAIL] != 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }
   res.moved_replicas = L.ctl[KAS_CTL_MOVED_R];
   res.moved_partitions = L.ctl[KAS_CTL_MOVED_P];
-#pragma unroll
-  for (int w = 0; w < NW; ++w) res.digest += L.dig[w];
+
   return res;
 }
 
 // ---------------------------------------------------------------------------------------------
-// One scenario: the per-topic loop of KAG:173-184 against one Context (KTA:19-23).
+// fill kernel, one scenario: the per-topic loop of KAG:173-184 up to (not including) P5.
+// Writes the topic results and the scenario record (digest 0; the order kernel completes it).
 // ---------------------------------------------------------------------------------------------
 template <int W, int NW>
-KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   constexpr int NT = 64 * NW;
   const int tid = kasw::tid();
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
-  const KasLds lay = kas_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch, a.hist_separate);
+  const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch);
   LdsView L;
-  L.cnt = (int32_t*)(lds_raw + lay.off_cnt);
   L.x = (int32_t*)(lds_raw + lay.off_x);
   L.load = (int32_t*)(lds_raw + lay.off_load);
   L.qrs = (int32_t*)(lds_raw + lay.off_qrs);
@@ -1132,31 +845,20 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
   L.ring_p = (int32_t*)(lds_raw + lay.off_ring);
   L.ring_meta = L.ring_p + KAS_RING_CAP;
   L.ring_rack = (int16_t*)(L.ring_meta + KAS_RING_CAP);
-  L.run = (int32_t*)(lds_raw + lay.off_run);
-  L.dep = (uint64_t*)(lds_raw + lay.off_dep);
-  L.nid = (int32_t*)(lds_raw + lay.off_nid);
   L.ctl = (int32_t*)(lds_raw + lay.off_ctl);
-  L.dig = (uint64_t*)(L.ctl + KAS_CTL_INTS);
 
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int32_t* g_node_rack = a.node_rack + sd.node_off;
-  const bool has_ctx = sd.ctx_off >= 0 && sd.ctx_width > 0;
-  int32_t* g_ctx = has_ctx ? a.ctx + sd.ctx_off : nullptr;
-  const int32_t ctxw = sd.ctx_width;
 
   int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int64_t t_begin = kasw::clock_ticks();
-  // node table checks (strictly ascending, non-negative ids; racks in int16 range) and the
-  // Context counters (KAS:360-369) into LDS
+  // node table checks: strictly ascending, non-negative ids; racks in int16 range
   bool bad = false;
   for (int32_t i = tid; i < N; i += NT) {
     const int32_t id = g_node_id[i];
     const int32_t prev = i > 0 ? g_node_id[i - 1] : -1;
     const int32_t rk = g_node_rack[i];
     bad = bad || id <= prev || rk < 0 || rk > 32767;
-#pragma unroll
-    for (int r = 0; r < cnt_stride<W>(); ++r)
-      L.cnt[i * cnt_stride<W>() + r] = (has_ctx && r < W && r < ctxw) ? g_ctx[(int64_t)i * ctxw + r] : 0;
   }
   if (tid == 0) L.ctl[KAS_CTL_VIOL] = 0;
   kasw::sync();
@@ -1178,25 +880,23 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
   int32_t* orph = a.orph + a.orph_off[s];
   int32_t scen_status = KAS_OK, fail_topic = -1, fail_part = -1;
   int32_t moved_r = 0, moved_p = 0;
-  uint64_t digest = 0;
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
     const kas_topic_desc td = a.topics[ti];
     TopicOutcome o;
-    o.status = KAS_OK; o.fail_partition = -1; o.moved_replicas = 0; o.moved_partitions = 0; o.digest = 0;
+    o.status = KAS_OK; o.fail_partition = -1; o.moved_replicas = 0; o.moved_partitions = 0;
     if (scen_status != KAS_OK) o.status = KAS_SKIPPED;                 // KAG:173-184 aborted
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = solve_topic<W, NW>(a, td, (uint32_t)k, L, nm, g_node_id, g_node_rack, accmask, orph,
-                                /*cnt_live=*/has_ctx || k > 0, st);
+    else o = fill_topic<W, NW>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph, st);
     kasw::sync();
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding
       int32_t* out = a.out + td.out_off;
       const int64_t cells = (int64_t)td.n_partitions * td.out_width;
       for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
-      o.moved_replicas = 0; o.moved_partitions = 0; o.digest = 0;
+      o.moved_replicas = 0; o.moved_partitions = 0;
       if (scen_status == KAS_OK) { scen_status = o.status; fail_topic = k; fail_part = o.fail_partition; }
     }
     if (tid == 0) {
@@ -1206,24 +906,530 @@ KAS_DEV void solve_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_ra
       a.topic_results[ti] = tr;
     }
     moved_r += o.moved_replicas; moved_p += o.moved_partitions;
-    digest += o.digest;
     kasw::sync();
-  }
-  if (has_ctx) {
-    for (int32_t i = tid; i < N; i += NT)
-#pragma unroll
-      for (int r = 0; r < W; ++r)
-        if (r < ctxw) g_ctx[(int64_t)i * ctxw + r] = L.cnt[i * cnt_stride<W>() + r];
   }
   if (tid == 0) {
     kas_scenario_result sr;
     sr.status = scen_status; sr.fail_topic = fail_topic; sr.fail_partition = fail_part;
     sr.moved_replicas = moved_r; sr.moved_partitions = moved_p; sr.reserved = 0;
-    sr.digest = digest;
+    sr.digest = 0;
     a.scenario_results[s] = sr;
     if (a.stats) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a.stats[(int64_t)s * 8 + i] = st[i];
+      for (int i = 0; i < 8; ++i) a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + i] = st[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// order kernel, ticket form.  A workgroup is two wavefronts serving G scenarios (one lane group
+// of GL = 64 / G lanes each): wave 0 SOLVES, wave 1 FEEDS it.  Lane l of either wave owns the
+// rows li, li + GL, li + 2 GL, ... (li = l % GL) of every solved topic of its scenario, in order.
+//
+// The solver's loop is a chain of ~(number of orphans) dependent steps per scenario, so nothing
+// with memory latency may sit in it: it touches LDS only.  The feeder streams the fill kernel's
+// rows (node indices) from HBM one GL-row tile at a time, hands out tickets in row order
+// (ticket of (row, node) = how many earlier rows of the scenario hold that node: a per-node
+// running count + the rank among the tile's lanes holding it, from one lane mask per node),
+// stages each row into a ring of KAS_RING_SLOTS 16-byte slots per lane, and retires finished
+// rows: node index -> broker id, digest, the final out row.  Slot protocol (tag = first dword):
+//     FREE  --feeder-->  j (= the lane's j-th row is staged)  --solver-->  DONE | picks
+//     --feeder-->  FREE                                       END = the lane has no more rows
+//
+// count[n][r] lives in LDS as 4 x uint16 per node, the fourth field counting the rows that
+// committed on the node.  A row commits once "commits on n == its ticket" holds for each of its
+// nodes (every earlier row holding n has committed: KAS:225-236 runs rows in ascending order),
+// with one LDS atomic add per node.  Lanes never wait for each other except through tickets, so
+// the scenarios of one wavefront do not interact at all.
+// ---------------------------------------------------------------------------------------------
+#define KAS_RING_SLOTS 8
+#define KAS_TAG_FREE (-1)
+#define KAS_TAG_END  (-3)
+#define KAS_TAG_DONE ((int32_t)0x80000000)   // | w0 | w1 << 2 | Lp << 4
+#define KAS_TAG_IS_DONE(t) (((uint32_t)(t) & 0xffffff00u) == 0x80000000u)
+// staged tag: the lane's row counter j in bits 0..25; bits 26..28 = for each stored position w0
+// that the first pick may take, whether the HIGHER of the two remaining stored positions is
+// visited first by the second pick; bits 29..30 = list length Lp (1..3)
+#define KAS_TAG_JMASK 0x03ffffff
+#define KAS_DUMMY_COUNTS 0x0000ffffffffffffull   // counter row of the padding holder: never picked
+
+struct alignas(16) RingSlot { int32_t tag; int32_t c[3]; };
+
+// lane mask type of the ticket pass: one bit per lane of a group
+template <int G>
+struct OrderLds {
+  static constexpr int GL = 64 / G;
+  typedef typename std::conditional<(GL > 32), uint64_t, uint32_t>::type Mask;
+};
+
+// a group's tile sequence: GL-row tiles of every topic the fill kernel solved, in order
+struct TileIter {
+  int32_t k, tP, tow, t, idx2, idx3;     // topic, its rows / row width, next tile, rotation offsets
+  int64_t tout;
+  bool exhausted;
+};
+
+template <int GL>
+KAS_DEV bool tile_next(TileIter& it, const KasLaunch& a, const kas_scenario_desc& sd) {
+  if (it.exhausted) return false;
+  it.t += 1;
+  while ((int64_t)it.t * GL >= it.tP) {
+    it.k += 1;
+    if (it.k >= sd.topic_count) { it.exhausted = true; return false; }
+    const int32_t ti = sd.topic_begin + it.k;
+    if (a.topic_results[ti].status != KAS_OK) continue;
+    const kas_topic_desc td = a.topics[ti];
+    it.tP = td.n_partitions; it.tow = td.out_width; it.tout = td.out_off;
+    it.idx2 = java_abs_mod(td.name_hash, 2);                // rotation offsets (KAS:190)
+    it.idx3 = java_abs_mod(td.name_hash, 3);
+    it.t = 0;
+  }
+  return true;
+}
+
+// The feeder's half of the picks (KAS:263-278): put the row's holders (h[0..Lp) ascending node
+// index, tk = their tickets) into the order in which the FIRST pick visits them, so that the
+// solver's "first strictly smaller count wins" is a plain left-to-right argmin; and for each
+// possible first pick w0, say which of the two remaining stored positions the SECOND pick visits
+// first.  Returns the tag bits 26..30; stored[t] = ticket << 16 | LDS byte address of the row.
+KAS_DEV int32_t stage_row(const int32_t (&h)[3], const int32_t (&tk)[3], int32_t Lp, int32_t idx2,
+                          int32_t idx3, int32_t cnt_base, int32_t dummy_addr, int32_t (&stored)[3]) {
+  int32_t enc[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) enc[q] = q < Lp ? ((tk[q] << 16) | (cnt_base + h[q] * 8)) : dummy_addr;
+  // rank visited at position t of a set of m: (t + m - idx_m) % m
+  const int32_t m = Lp;
+  const int32_t idx = m == 3 ? idx3 : (m == 2 ? idx2 : 0);
+  int32_t rank_at[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    int32_t r = t + m - idx;
+    r -= r >= m ? m : 0;
+    rank_at[t] = t < m ? r : t;                             // padding stays behind the holders
+    stored[t] = rank_at[t] == 0 ? enc[0] : (rank_at[t] == 1 ? enc[1] : enc[2]);
+  }
+  int32_t bits = 0;
+  if (m == 3) {
+    // second pick: the two remaining holders in RANK order are visited (lower, higher) when
+    // idx2 == 0 and (higher, lower) when idx2 == 1
+#pragma unroll
+    for (int w0 = 0; w0 < 3; ++w0) {
+      const int pp = w0 == 0 ? 1 : 0, qq = w0 == 2 ? 1 : 2;            // remaining stored positions
+      const bool q_lower_rank = rank_at[qq] < rank_at[pp];
+      const bool q_first = idx2 == 0 ? q_lower_rank : !q_lower_rank;
+      bits |= q_first ? (1 << w0) : 0;
+    }
+  }
+  return (bits << 26) | (Lp << 29);
+}
+
+template <int W, int G>
+KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned char* lds_raw) {
+  static_assert(W <= 3, "ring slots and packed counter rows hold lists up to 3 wide");
+  typedef OrderLds<G> OL;
+  typedef typename OL::Mask Mask;
+  constexpr int GL = 64 / G;
+  constexpr int K = KAS_RING_SLOTS;
+  constexpr int UR = 2;                                     // rows retired per lane per feeder iteration
+  const int lane = kasw::lane();
+  const int32_t wave = kasw::wave_id();
+  const int32_t g = lane / GL, li = lane % GL;
+  const int32_t s = first_scenario + g;
+  const bool have_s = s < a.n_scenarios;
+  const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
+  const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G);    // LDS byte offset of this group's region
+  uint64_t* cnt = (uint64_t*)(lds_raw + cnt_base);          // [nmax + 1]: + the padding holder's row
+  int32_t* run = (int32_t*)(lds_raw + cnt_base + 8 * (nmax + 1));
+  int32_t* nid = run + nmax;                                // broker id per node index
+  Mask* dep = (Mask*)(nid + nmax);
+  const int32_t dummy_addr = cnt_base + nmax * 8;
+  RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G));
+  uint64_t* gdig = (uint64_t*)(ring + K * 64);
+
+  kas_scenario_desc sd;
+  sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
+  if (have_s) sd = a.scen[s];
+  const int32_t N = sd.n_nodes;
+  const int32_t* g_node_id = a.node_id + sd.node_off;
+  for (int32_t n = li + GL * wave; n < N; n += 2 * GL) {
+    cnt[n] = 0ull; run[n] = 0; dep[n] = (Mask)0; nid[n] = g_node_id[n];
+  }
+  if (wave == 0 && li == 0) { cnt[nmax] = KAS_DUMMY_COUNTS; gdig[g] = 0ull; }
+  for (int32_t k = wave; k < K; k += 2) ring[k * 64 + lane].tag = KAS_TAG_FREE;
+  kasw::sync();
+
+  if (wave == 0) {
+    // ------------------------------------------------------------------ solver: LDS only
+    // cur = the row being decided, nxt = the lane's following row, read ahead from the ring so
+    // that taking it costs no LDS round trip of its own
+    int32_t j = 0;                                           // rows this lane has committed
+    bool cv = false, nv = false, fin = false;
+    int32_t e0 = dummy_addr, e1 = dummy_addr, e2 = dummy_addr, meta = 0;
+    RingSlot nx;
+    nx.tag = KAS_TAG_FREE; nx.c[0] = 0; nx.c[1] = 0; nx.c[2] = 0;
+    int64_t n_iter = 0, n_blocked = 0;
+    const int64_t t_begin = kasw::clock_ticks();
+    for (;;) {
+      kasw::repoll();                                      // LDS is re-read below
+      n_iter += 1;
+      // one LDS round trip per iteration: the look-ahead slot and the three counter rows
+      const int32_t jn = j + (cv ? 1 : 0);
+      const RingSlot sl = ring[(jn & (K - 1)) * 64 + lane];
+      const uint64_t x0 = *(const uint64_t*)(lds_raw + (e0 & 0xffff));
+      const uint64_t x1 = *(const uint64_t*)(lds_raw + (e1 & 0xffff));
+      const uint64_t x2 = *(const uint64_t*)(lds_raw + (e2 & 0xffff));
+      if (!nv && !fin) {
+        if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == jn) { nx = sl; nv = true; }
+        else if (sl.tag == KAS_TAG_END && !cv) fin = true;
+      }
+      // commits on the node == my ticket: every earlier row holding it has committed
+      const bool ready = cv && (((uint32_t)(x0 >> 32) ^ (uint32_t)e0) >> 16) == 0u &&
+                         (((uint32_t)(x1 >> 32) ^ (uint32_t)e1) >> 16) == 0u &&
+                         (((uint32_t)(x2 >> 32) ^ (uint32_t)e2) >> 16) == 0u;
+      // first pick: count[.][0], holders in visit order, first strictly smaller wins
+      const uint32_t a0 = (uint32_t)x0 & 0xffffu, a1 = (uint32_t)x1 & 0xffffu, a2 = (uint32_t)x2 & 0xffffu;
+      const int32_t w0 = a1 < a0 ? (a2 < a1 ? 2 : 1) : (a2 < a0 ? 2 : 0);
+      // second pick: count[.][1] of the two remaining stored positions pp < qq
+      const uint32_t b0 = (uint32_t)x0 >> 16, b1 = (uint32_t)x1 >> 16, b2 = (uint32_t)x2 >> 16;
+      const uint32_t bp = w0 == 0 ? b1 : b0, bq = w0 == 2 ? b1 : b2;
+      const int32_t pp = w0 == 0 ? 1 : 0, qq = w0 == 2 ? 1 : 2;
+      const bool q_first = ((meta >> w0) & 1) != 0;
+      const bool take_q = q_first ? !(bp < bq) : (bq < bp);
+      const int32_t w1 = take_q ? qq : pp;
+      const int32_t w2 = 3 - w0 - w1;
+      if (ready) {
+        const int32_t Lp = (meta >> 3) & 3;
+        const int32_t ad0 = (w0 == 0 ? e0 : (w0 == 1 ? e1 : e2)) & 0xffff;
+        const int32_t ad1 = (w1 == 0 ? e0 : (w1 == 1 ? e1 : e2)) & 0xffff;
+        const int32_t ad2 = (w2 == 0 ? e0 : (w2 == 1 ? e1 : e2)) & 0xffff;
+        // updateCountersFromList (KAS:254-261): count[node][r] += 1, commits += 1
+        // (padding holders get + 0: their row must keep commits == 0)
+        kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad0), Lp > 0 ? 1ull + (1ull << 48) : 0ull);
+        kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad1), Lp > 1 ? (1ull << 16) + (1ull << 48) : 0ull);
+        kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad2), Lp > 2 ? (1ull << 32) + (1ull << 48) : 0ull);
+        ring[(j & (K - 1)) * 64 + lane].tag = KAS_TAG_DONE | w0 | (w1 << 2) | (Lp << 4);
+        j += 1;
+        cv = false;
+      }
+      if (!cv && nv) {                                     // the look-ahead row becomes current
+        e0 = nx.c[0]; e1 = nx.c[1]; e2 = nx.c[2];
+        meta = nx.tag >> 26;
+        cv = true; nv = false;
+      }
+      if (kasw::ballot(!fin) == 0) break;
+      if (kasw::ballot(ready) == 0) { n_blocked += 1; kasw::spin_pause(); }
+    }
+    if (a.stats && have_s && li == 0) {
+      int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = 0; st[11] = n_blocked;
+    }
+  } else {
+    // ------------------------------------------------------------------ feeder / retirer
+    const uint64_t gmask = (G == 1 ? ~0ull : ((1ull << GL) - 1ull)) << (g * GL);   // my group's lanes
+    const Mask mybit = (Mask)1 << li;
+    const Mask lt = mybit - (Mask)1;
+    TileIter itl, itr;
+    itl.k = -1; itl.tP = 0; itl.tow = 1; itl.t = -1; itl.idx2 = 0; itl.idx3 = 0; itl.tout = 0;
+    itl.exhausted = !have_s;
+    itr = itl;
+    int32_t jl = 0, jr = 0;                                 // tiles staged (group-uniform), rows retired
+    bool endl = false;
+    uint64_t digest = 0;
+    int64_t f_iter = 0, f_idle = 0;
+    for (;;) {
+      kasw::lockstep();
+      f_iter += 1;
+      // ---- next tile of my group, if every lane of the group has a free slot: issue its HBM read
+      const bool room = (kasw::ballot(jl - jr < K) & gmask) == gmask;
+      bool staging = false, have_row = false;
+      int32_t cells[3] = {-1, -1, -1};
+      if (!endl && room) {
+        staging = true;
+        if (tile_next<GL>(itl, a, sd)) {
+          const int32_t p = itl.t * GL + li;
+          have_row = p < itl.tP;
+          if (have_row) {
+            const int32_t* row = a.out + itl.tout + (int64_t)p * itl.tow;
+#pragma unroll
+            for (int q = 0; q < W; ++q) cells[q] = q < itl.tow ? row[q] : -1;
+          }
+        } else {
+          endl = true;
+        }
+      }
+      // ---- retire finished rows: stored position -> node index -> broker id, digest, out row
+      bool retired = false;
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        if (jr < jl) {
+          const RingSlot sl = ring[(jr & (K - 1)) * 64 + lane];
+          if (KAS_TAG_IS_DONE(sl.tag)) {
+            tile_next<GL>(itr, a, sd);
+            const int32_t p = itr.t * GL + li;
+            const int32_t w0 = sl.tag & 3, w1 = (sl.tag >> 2) & 3, Lp = (sl.tag >> 4) & 3;
+            const int32_t w[3] = {w0, w1, 3 - w0 - w1};
+            int32_t* row = a.out + itr.tout + (int64_t)p * itr.tow;
+#pragma unroll
+            for (int r = 0; r < W; ++r) {
+              if (r < Lp) {
+                const int32_t e = w[r] == 0 ? sl.c[0] : (w[r] == 1 ? sl.c[1] : sl.c[2]);
+                const int32_t node = ((e & 0xffff) - cnt_base) >> 3;
+                const int32_t id = nid[node];
+                row[r] = id;
+                digest += kas_digest_cell((uint32_t)itr.k, (uint32_t)p, (uint32_t)r, id);
+              }
+            }
+            ring[(jr & (K - 1)) * 64 + lane].tag = KAS_TAG_FREE;
+            jr += 1;
+            retired = true;
+          } else if (sl.tag == KAS_TAG_END) {
+            jr += 1;                                       // the end marker retires itself
+          }
+        }
+      }
+      // ---- tickets for the tile (wave-wide lockstep; lanes not staging carry no holders)
+      int32_t h[3], Lp = 0;
+      sort_holders<3>(cells, h, Lp);                        // Sets.newTreeSet (KAS:228)
+      const bool holds = staging && have_row && Lp > 0;
+      int32_t hn[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) hn[q] = (holds && q < Lp) ? h[q] : 0;
+      if (holds) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (q < Lp) {
+            if constexpr (sizeof(Mask) == 8) kasw::lds_atomic_or_u64((uint64_t*)&dep[hn[q]], (uint64_t)mybit);
+            else kasw::lds_atomic_or_u32((uint32_t*)&dep[hn[q]], (uint32_t)mybit);
+          }
+        }
+      }
+      kasw::lockstep();
+      Mask m[3];
+      int32_t base[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const bool on = holds && q < Lp;
+        m[q] = on ? dep[hn[q]] : (Mask)0;
+        base[q] = on ? run[hn[q]] : 0;
+      }
+      kasw::lockstep();
+      int32_t tk[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int32_t below = sizeof(Mask) == 8 ? kasw::popc((uint64_t)(m[q] & lt)) : __builtin_popcount((uint32_t)(m[q] & lt));
+        const int32_t all = sizeof(Mask) == 8 ? kasw::popc((uint64_t)m[q]) : __builtin_popcount((uint32_t)m[q]);
+        tk[q] = base[q] + below;
+        if (holds && q < Lp && (m[q] & lt) == (Mask)0) {   // lowest lane holding this node
+          run[hn[q]] = base[q] + all;
+          dep[hn[q]] = (Mask)0;
+        }
+      }
+      // ---- hand the staged row to the solver
+      if (staging) {
+        RingSlot o;
+        o.c[0] = dummy_addr; o.c[1] = dummy_addr; o.c[2] = dummy_addr;
+        if (endl) {
+          o.tag = KAS_TAG_END;
+        } else if (holds) {
+          o.tag = jl | stage_row(hn, tk, Lp, itl.idx2, itl.idx3, cnt_base, dummy_addr, o.c);
+        } else {
+          // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane:
+          // an empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
+          o.tag = jl;
+        }
+        ring[(jl & (K - 1)) * 64 + lane] = o;
+        jl += 1;
+      }
+      if (kasw::ballot(!(endl && jr == jl)) == 0) break;
+      if (kasw::ballot(staging || retired) == 0) { f_idle += 1; kasw::spin_pause(); }
+    }
+    if (a.stats && have_s && li == 0) {
+      int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      st[12] = f_iter; st[13] = f_idle;
+    }
+    kasw::lds_atomic_add_u64(&gdig[g], digest);
+    kasw::lockstep();
+    if (have_s && li == 0) a.scenario_results[s].digest = gdig[g];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// order kernel, round form (one wavefront per scenario; int32 counters, Context in/out).
+// 64 ascending rows per tile; once per tile every lane ors its lane bit into a 64-bit LDS mask
+// per node it holds and reads those masks back, so it knows which LOWER lanes share a node with
+// it; each round a lane none of whose lower sharers is still pending commits.  Lane order ==
+// row order, so the result is the sequential one.  Returns true on the KAS:190 index error.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td, int32_t* out,
+                          const int32_t* g_node_id, uint32_t topic_k, uint64_t& digest,
+                          int64_t& rounds) {
+  constexpr int CS = cnt_stride<W>();
+  const int lane = kasw::lane();
+  const uint64_t lt = kasw::lanemask_lt();
+  const int32_t P = td.n_partitions, ow = td.out_width, nt = (P + 63) >> 6;
+  const int32_t hash = td.name_hash;
+  const bool hash_min = hash == (int32_t)0x80000000;
+  const uint64_t mybit = 1ull << lane;
+  // rotation offsets idx_m = Math.abs(hash) % m for every set size m (KAS:190, via KAS:267)
+  int32_t idxm[W + 1];
+#pragma unroll
+  for (int m = 1; m <= W; ++m) idxm[m] = java_abs_mod(hash, m);
+  idxm[0] = 0;
+  int32_t nx[W];                                  // next tile's out row (software prefetch)
+#pragma unroll
+  for (int k = 0; k < W; ++k) nx[k] = (lane < P && k < ow) ? out[(int64_t)lane * ow + k] : -1;
+  for (int32_t tile = 0; tile < nt; ++tile) {
+    const int32_t p = (tile << 6) + lane;
+    const bool active = p < P;
+    int32_t h[W], Lp;
+    sort_holders<W>(nx, h, Lp);
+    {
+      const int32_t pn = p + 64;
+#pragma unroll
+      for (int k = 0; k < W; ++k) nx[k] = (pn < P && k < ow) ? out[(int64_t)pn * ow + k] : -1;
+    }
+    if (hash_min) {
+      // KAS:190 index error: some set size m <= L has a negative rotation offset
+      bool bad = false;
+#pragma unroll
+      for (int m = 1; m <= W; ++m) bad = bad || (m <= Lp && idxm[m] < 0);
+      if (kasw::ballot(bad) != 0) return true;
+    }
+    bool pending = active && Lp > 0;
+    // node index per list position, clamped so that unused positions address node 0
+    int32_t hn[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) hn[k] = (pending && k < Lp) ? h[k] : 0;
+    if (pending) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (k < Lp) kasw::lds_atomic_or_u64(&dep[hn[k]], mybit);
+    }
+    kasw::lockstep();
+    uint64_t share = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) share |= (pending && k < Lp) ? dep[hn[k]] : 0ull;
+    kasw::lockstep();
+    if (pending) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (k < Lp) dep[hn[k]] = 0ull;
+    }
+    const uint64_t depmask = share & lt;
+
+    int32_t lst[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) lst[k] = -1;
+    for (;;) {
+      const uint64_t pend = kasw::ballot(pending);
+      if (pend == 0) break;
+      rounds += 1;
+      const bool ready = pending && (depmask & pend) == 0;
+      // count[node][0..W) of my nodes (KAS:280-301); every lane computes, ready lanes commit
+      int32_t c[W][W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) load_cnt_row<W>(c[k], cnt + hn[k] * CS);
+      int32_t pos[W], cnt_r[W];
+      pick_row<W>(c, Lp, pending, idxm, pos, cnt_r);
+      if (ready) {
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+          if (r < Lp) {
+            const int32_t node = sel<W>(hn, pos[r]);
+            lst[r] = node;
+            cnt[node * CS + r] = cnt_r[r] + 1;             // updateCountersFromList (KAS:254-261)
+          }
+        }
+        pending = false;
+      }
+      kasw::lockstep();
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if (k < ow) {
+          const int32_t node = lst[k];
+          const int32_t id = node >= 0 ? g_node_id[node] : -1;
+          out[(int64_t)p * ow + k] = id;
+          if (node >= 0) digest += kas_digest_cell(topic_k, (uint32_t)p, (uint32_t)k, id);
+        }
+      }
+    }
+  }
+  return false;
+}
+
+template <int W>
+KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+  constexpr int CS = cnt_stride<W>();
+  const int lane = kasw::lane();
+  const kas_scenario_desc sd = a.scen[s];
+  const int32_t N = sd.n_nodes;
+  int32_t* cnt = (int32_t*)lds_raw;
+  uint64_t* dep = (uint64_t*)(lds_raw + kas_align16(4 * (int64_t)(a.n_max > 0 ? a.n_max : 1) * CS));
+  const int32_t* g_node_id = a.node_id + sd.node_off;
+  const bool has_ctx = sd.ctx_off >= 0 && sd.ctx_width > 0;
+  int32_t* g_ctx = has_ctx ? a.ctx + sd.ctx_off : nullptr;
+  const int32_t ctxw = sd.ctx_width;
+  const int64_t t_begin = kasw::clock_ticks();
+  // Context counters (KAS:360-369) into LDS
+  for (int32_t i = lane; i < N; i += 64) {
+#pragma unroll
+    for (int r = 0; r < CS; ++r)
+      cnt[i * CS + r] = (has_ctx && r < W && r < ctxw) ? g_ctx[(int64_t)i * ctxw + r] : 0;
+    dep[i] = 0ull;
+  }
+  kasw::lockstep();
+  kas_scenario_result sr = a.scenario_results[s];          // written by the fill kernel
+  uint64_t digest = 0;
+  int64_t rounds = 0;
+  bool failed_here = false;
+  for (int32_t k = 0; k < sd.topic_count; ++k) {
+    const int32_t ti = sd.topic_begin + k;
+    kas_topic_result tr = a.topic_results[ti];
+    const kas_topic_desc td = a.topics[ti];
+    int32_t* out = a.out + td.out_off;
+    if (failed_here && tr.status != KAS_SKIPPED) {
+      // an earlier topic failed in this kernel: the CLI run would have aborted (KAG:173-184)
+      if (tr.status == KAS_OK) {
+        sr.moved_replicas -= tr.moved_replicas; sr.moved_partitions -= tr.moved_partitions;
+        const int64_t cells = (int64_t)td.n_partitions * td.out_width;
+        for (int64_t i = lane; i < cells; i += 64) out[i] = -1;
+      }
+      tr.status = KAS_SKIPPED; tr.fail_partition = -1; tr.moved_replicas = 0; tr.moved_partitions = 0;
+      if (lane == 0) a.topic_results[ti] = tr;
+      continue;
+    }
+    if (tr.status != KAS_OK) continue;
+    uint64_t dg = 0;
+    const bool hash_fail = order_rounds<W>(cnt, dep, td, out, g_node_id, (uint32_t)k, dg, rounds);
+    if (hash_fail) {
+      kasw::wave_sync();
+      const int64_t cells = (int64_t)td.n_partitions * td.out_width;
+      for (int64_t i = lane; i < cells; i += 64) out[i] = -1;
+      sr.moved_replicas -= tr.moved_replicas; sr.moved_partitions -= tr.moved_partitions;
+      tr.status = KAS_FAIL_HASH_INDEX; tr.fail_partition = -1; tr.moved_replicas = 0; tr.moved_partitions = 0;
+      if (lane == 0) a.topic_results[ti] = tr;
+      sr.status = KAS_FAIL_HASH_INDEX; sr.fail_topic = k; sr.fail_partition = -1;
+      failed_here = true;
+      for (int32_t i = lane; i < N; i += 64) dep[i] = 0ull;
+      kasw::lockstep();
+    } else {
+      digest += dg;
+    }
+  }
+  if (has_ctx) {
+    for (int32_t i = lane; i < N; i += 64)
+#pragma unroll
+      for (int r = 0; r < W; ++r)
+        if (r < ctxw) g_ctx[(int64_t)i * ctxw + r] = cnt[i * CS + r];
+  }
+  const uint64_t dsum = kasw::wave_sum_u64(digest);
+  if (lane == 0) {
+    sr.digest = dsum;
+    a.scenario_results[s] = sr;
+    if (a.stats) {
+      a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 8] = kasw::clock_ticks() - t_begin;
+      a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 6] = rounds;
     }
   }
 }

@@ -61,6 +61,11 @@ KAS_DEV void lockstep() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Top of a spin loop that polls LDS written by ANOTHER wave of the workgroup: the compiler must
+// re-read LDS after this point, the hardware needs nothing (LDS has no cache in front of it and
+// serves the operations of a wave in issue order).
+KAS_DEV void repoll() { asm volatile("" ::: "memory"); }
+
 // Identity the optimiser cannot see through.  Used on the elements of small register tables
 // before a select chain: without it LLVM folds "select(i==j, a[j], ...)" back into a
 // dynamically indexed load and the table moves to scratch (= global memory).
@@ -77,6 +82,10 @@ KAS_DEV int first_lane(uint64_t m) { return __ffsll((unsigned long long)m) - 1; 
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { return atomicAdd(p, v); }
+
+KAS_DEV void lds_atomic_or_u32(uint32_t* p, uint32_t v) {
+  __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "kas_abi_version", "kas_strerror", "kas_status_string", "kas_last_error", "kas_device_count",
     "kas_ctx_create", "kas_ctx_destroy", "kas_ctx_synchronize", "kas_plan_create",
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
-    "kas_plan_kernel_time_us", "kas_plan_stats", "kas_plan_set_flags",
+    "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
 ]
 
 _LIB = None
@@ -71,6 +71,9 @@ def load():
     L.kas_solve_host.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
     L.kas_plan_kernel_time_us.restype = C.c_int
     L.kas_plan_kernel_time_us.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.kas_plan_phase_times_us.restype = C.c_int
+    L.kas_plan_phase_times_us.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_int)]
     L.kas_plan_set_flags.restype = C.c_int
     L.kas_plan_set_flags.argtypes = [C.c_void_p, C.c_uint32]
     L.kas_plan_stats.restype = C.c_int
@@ -138,11 +141,11 @@ class Plan:
         _check(self._lib.kas_plan_set_flags(self._h, flags))
 
     def stats(self) -> np.ndarray:
-        """Per-scenario device counters of the last solve: int64 [S, 8] =
+        """Per-scenario device counters of the last solve: int64 [S, 16] =
         (setup, P2, P3+P4, P5 time in 10 ns ticks; P4 windows, P4 node steps, P5 rounds,
         P2 overflow tiles)."""
         n = self._fb.n_scenarios
-        a = np.zeros((n, 8), dtype=np.int64)
+        a = np.zeros((n, 16), dtype=np.int64)
         _check(self._lib.kas_plan_stats(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size))
         return a
 
@@ -150,6 +153,12 @@ class Plan:
         avg = C.c_double(); n = C.c_int()
         _check(self._lib.kas_plan_kernel_time_us(self._h, C.byref(avg), C.byref(n)))
         return avg.value, n.value
+
+    def phase_times_us(self):
+        """(fill kernel avg us, order kernel avg us, launches) since the last call."""
+        f = C.c_double(); o = C.c_double(); n = C.c_int()
+        _check(self._lib.kas_plan_phase_times_us(self._h, C.byref(f), C.byref(o), C.byref(n)))
+        return f.value, o.value, n.value
 
     def close(self):
         if self._h:

@@ -94,60 +94,106 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
 
 namespace {
 
-struct RunArgs { const KasLaunch* a; int32_t s; unsigned char* lds; int W; };
+struct RunArgs { const KasLaunch* a; int32_t s; unsigned char* lds; };
 
-template <int W, int NW> void run_one(void* p) {
+template <int W, int NW> void run_fill(void* p) {
   RunArgs* r = (RunArgs*)p;
-  kas::solve_scenario<W, NW>(*r->a, r->s, r->lds);
+  kas::fill_scenario<W, NW>(*r->a, r->s, r->lds);
+}
+template <int W, int G> void run_order_tickets(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  if constexpr (W <= 3) kas::order_tickets<W, G>(*r->a, r->s, r->lds);
+}
+template <int W> void run_order_rounds(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  kas::order_scenario_rounds<W>(*r->a, r->s, r->lds);
 }
 
 typedef void (*run_fn)(void*);
-template <int NW> run_fn run_for_w(int Wc) {
+template <int NW> run_fn fill_for_w(int Wc) {
   switch (Wc) {                            // the same width classes the product launcher uses
-    case 2: return run_one<2, NW>;
-    case 3: return run_one<3, NW>;
-    case 4: return run_one<4, NW>;
-    case 5: return run_one<5, NW>;
-    default: return run_one<8, NW>;
+    case 2: return run_fill<2, NW>;
+    case 3: return run_fill<3, NW>;
+    case 4: return run_fill<4, NW>;
+    case 5: return run_fill<5, NW>;
+    default: return run_fill<8, NW>;
+  }
+}
+template <int G> run_fn tickets_for_g(int Wc) {
+  switch (Wc) {
+    case 2: return run_order_tickets<2, G>;
+    default: return run_order_tickets<3, G>;
+  }
+}
+run_fn rounds_for(int Wc) {
+  switch (Wc) {
+    case 2: return run_order_rounds<2>;
+    case 3: return run_order_rounds<3>;
+    case 4: return run_order_rounds<4>;
+    case 5: return run_order_rounds<5>;
+    default: return run_order_rounds<8>;
   }
 }
 
 }  // namespace
 
-// flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario (0 = the planner's choice)
+// flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
+// 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice)
 extern "C" __attribute__((visibility("default")))
 int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen) {
   KasShape sh;
   std::string err;
-  int rc = kas_shape_batch(b, &sh, &err, (int)((flags >> 8) & 0xfu));
+  int rc = kas_shape_batch(b, &sh, &err, (int)((flags >> 8) & 0xfu), (int)((flags >> 12) & 0xfu));
   if (rc != KAS_E_OK) {
     if (errbuf && errlen > 0) { strncpy(errbuf, err.c_str(), (size_t)errlen - 1); errbuf[errlen - 1] = 0; }
     return rc;
   }
+  const bool tickets = sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER);
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
-  std::vector<unsigned char> lds((size_t)sh.lds.total + 64, 0xCD);
+  size_t lds_bytes = (size_t)sh.lds.total;
+  if ((size_t)kas_order_round_lds(sh.n_max, sh.Wc) > lds_bytes) lds_bytes = (size_t)kas_order_round_lds(sh.n_max, sh.Wc);
+  if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G);
+  std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
   KasLaunch a;
   a.scen = b->scenarios; a.topics = b->topics; a.node_id = b->node_id; a.node_rack = b->node_rack;
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data(); a.stats = nullptr;
-  a.orph = orph.data(); a.orph_off = sh.orph_off.data(); a.nw = sh.NW;
+  a.orph = orph.data(); a.orph_off = sh.orph_off.data();
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
-  a.need_bsearch = sh.need_bsearch; a.hist_separate = sh.hist_separate; a.flags = flags & 0xffu;
-  run_fn fn = nullptr;
+  a.need_bsearch = sh.need_bsearch; a.flags = flags & 0xffu;
+  auto bad = [&](const char* what, int32_t s) {
+    if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
+    return -100;
+  };
+  // fill kernel: one workgroup of NW wavefronts per scenario
+  run_fn fill = nullptr;
   switch (sh.NW) {
-    case 1: fn = run_for_w<1>(sh.Wc); break;
-    case 2: fn = run_for_w<2>(sh.Wc); break;
-    case 8: fn = run_for_w<8>(sh.Wc); break;
-    default: fn = run_for_w<4>(sh.Wc); break;
+    case 1: fill = fill_for_w<1>(sh.Wc); break;
+    case 2: fill = fill_for_w<2>(sh.Wc); break;
+    case 8: fill = fill_for_w<8>(sh.Wc); break;
+    default: fill = fill_for_w<4>(sh.Wc); break;
   }
   for (int32_t s = 0; s < b->n_scenarios; ++s) {
     memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
-    RunArgs ra{&a, s, lds.data(), sh.W};
-    if (kasw::run_block(fn, &ra, sh.NW) != 0) {
-      if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in scenario %d", s);
-      return -100;
+    RunArgs ra{&a, s, lds.data()};
+    if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill", s);
+  }
+  // order kernel: one wavefront per G scenarios (ticket form) or per scenario (round form)
+  if (tickets) {
+    run_fn f = sh.G == 1 ? tickets_for_g<1>(sh.Wc) : sh.G == 2 ? tickets_for_g<2>(sh.Wc) : tickets_for_g<4>(sh.Wc);
+    for (int32_t s = 0; s < b->n_scenarios; s += sh.G) {
+      memset(lds.data(), 0xCD, lds.size());
+      RunArgs ra{&a, s, lds.data()};
+      if (kasw::run_block(f, &ra, 2) != 0) return bad("order (tickets)", s);
+    }
+  } else {
+    run_fn f = rounds_for(sh.Wc);
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(lds.data(), 0xCD, lds.size());
+      RunArgs ra{&a, s, lds.data()};
+      if (kasw::run_block(f, &ra, 1) != 0) return bad("order (rounds)", s);
     }
   }
   return KAS_E_OK;

@@ -77,6 +77,7 @@ KAS_DEV void sync() { rendezvous(K_SYNC); }
 KAS_DEV void lockstep() { rendezvous(K_LOCKSTEP); }
 KAS_DEV void wave_sync() { rendezvous(K_WAVESYNC); }
 KAS_DEV void spin_pause() {}
+KAS_DEV void repoll() { rendezvous(K_LOCKSTEP); }   // lets the other waves run
 
 KAS_DEV void publish(int32_t* flag, int32_t v) { *(volatile int32_t*)flag = v; }
 KAS_DEV int32_t observe(const int32_t* flag) { return *(const volatile int32_t*)flag; }
@@ -88,6 +89,7 @@ KAS_DEV int first_lane(uint64_t m) { return __builtin_ctzll(m); }
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+KAS_DEV void lds_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }
 KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }

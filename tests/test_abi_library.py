@@ -44,7 +44,7 @@ def test_library_contains_gfx950_code_object():
                           f"--input={so}"], capture_output=True, text=True)
     blob = open(so, "rb").read()
     assert b"gfx950" in blob, out.stdout + out.stderr
-    assert b"kas_solve_kernel" in blob
+    assert b"kas_fill_kernel" in blob and b"kas_order_ticket_kernel" in blob and b"kas_order_round_kernel" in blob
 
 
 def test_struct_layout_matches_c(tmp_path):

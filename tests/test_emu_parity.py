@@ -26,7 +26,7 @@ def test_emu_equals_oracle_small_odd_inputs(sc):
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
     assert_same_outputs(fb, want, emu_solve(fb, flags=2 | (1 << 8)), "emu round order, 1 wave")
-    assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 8)), "emu 2 waves")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 8) | (1 << 12)), "emu 2 waves, 1 scenario per wave")
 
 
 def _batch(seed, S, P, N, R, RF, actions, rack_aware=True, cyclic=False, name_hash=3644):
@@ -68,8 +68,8 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
     # every workgroup width, and the round form of the preference ordering
-    for nw in (1, 2, 8):
-        assert_same_outputs(fb, want, emu_solve(fb, flags=nw << 8), f"emu {nw} waves")
+    for nw, g in ((1, 1), (2, 2), (8, 4)):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=(nw << 8) | (g << 12)), f"emu {nw} waves, {g} scenarios per wave")
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round order")
     assert_same_outputs(fb, want, emu_solve(fb, flags=3 | (1 << 8)), "emu generic fill + round order, 1 wave")
     # the generator must produce solvable scenarios most of the time, else the test is vacuous
