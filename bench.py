@@ -63,7 +63,7 @@ def main() -> int:
 
     import torch
     import torch.distributed as dist
-    from kafka_assigner_amd import abi, generator as G, native
+    from kafka_assigner_amd import abi, generator as G, native, sharding
     from kafka_assigner_amd.flatten import node_set_batch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +109,7 @@ def main() -> int:
         sl["all"] = torch.zeros(world * S * 32, dtype=torch.uint8, device=dev) if world > 1 else sl["sr"]
         sl["stream"].wait_stream(torch.cuda.current_stream(dev))
         slots.append(sl)
-    plan, d_out, d_tr, d_sr, d_all = (slots[0][k] for k in ("plan", "out", "tr", "sr", "all"))
+    plan, d_out, d_tr, d_sr = (slots[0][k] for k in ("plan", "out", "tr", "sr"))
     step_no = [0]
 
     def step():
@@ -119,7 +119,7 @@ def main() -> int:
                                 sl["sr"].data_ptr(), stream=sl["stream"].cuda_stream)
         if world > 1:                                   # the single data-path collective
             with torch.cuda.stream(sl["stream"]):
-                dist.all_gather_into_tensor(sl["all"], sl["sr"])
+                sharding.gather_records(sl["sr"], world * S, out=sl["all"])
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -164,7 +164,7 @@ def main() -> int:
     # ---- results of this rank -------------------------------------------------------------------
     sr = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
     ok = int((sr["status"] == abi.KAS_OK).sum())
-    all_sr = d_all.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
+    all_sr = slots[0]["all"].cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
     if world > 1:
         assert (all_sr[first:first + S] == sr).all(), "all-gather returned a different record"
 

@@ -1388,6 +1388,7 @@ KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char*
     kas_topic_result tr = a.topic_results[ti];
     const kas_topic_desc td = a.topics[ti];
     int32_t* out = a.out + td.out_off;
+    kasw::lockstep();                                      // every lane has read tr before lane 0 rewrites it
     if (failed_here && tr.status != KAS_SKIPPED) {
       // an earlier topic failed in this kernel: the CLI run would have aborted (KAG:173-184)
       if (tr.status == KAS_OK) {
