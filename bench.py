@@ -242,8 +242,10 @@ def main() -> int:
                 "kernel": "kas_fill_kernel<3,NW> + kas_order_ticket_kernel<3,G> (one solve = both, same stream)",
                 "kernel_avg_us": kern_us, "fill_kernel_avg_us": fill_us, "order_kernel_avg_us": order_us,
                 "launches_timed": kern_n,
+                "achieved_wall": value * alg_bytes / (world * S) / 1e9,
                 "note": "durations are HIP-event times per launch while batches_in_flight solves share "
-                        "the GPU; achieved = algorithmic bytes of one solve / (fill + order duration)",
+                        "the GPU; achieved = algorithmic bytes of one solve / (fill + order duration); "
+                        "achieved_wall = algorithmic bytes per second at the measured whole-job rate",
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
             "cpu_baseline": cpu,

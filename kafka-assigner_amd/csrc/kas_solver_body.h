@@ -1086,16 +1086,22 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const bool ready = cv && (((uint32_t)(x0 >> 32) ^ (uint32_t)e0) >> 16) == 0u &&
                          (((uint32_t)(x1 >> 32) ^ (uint32_t)e1) >> 16) == 0u &&
                          (((uint32_t)(x2 >> 32) ^ (uint32_t)e2) >> 16) == 0u;
-      // first pick: count[.][0], holders in visit order, first strictly smaller wins
-      const uint32_t a0 = (uint32_t)x0 & 0xffffu, a1 = (uint32_t)x1 & 0xffffu, a2 = (uint32_t)x2 & 0xffffu;
-      const int32_t w0 = a1 < a0 ? (a2 < a1 ? 2 : 1) : (a2 < a0 ? 2 : 0);
-      // second pick: count[.][1] of the two remaining stored positions pp < qq
-      const uint32_t b0 = (uint32_t)x0 >> 16, b1 = (uint32_t)x1 >> 16, b2 = (uint32_t)x2 >> 16;
-      const uint32_t bp = w0 == 0 ? b1 : b0, bq = w0 == 2 ? b1 : b2;
-      const int32_t pp = w0 == 0 ? 1 : 0, qq = w0 == 2 ? 1 : 2;
-      const bool q_first = ((meta >> w0) & 1) != 0;
-      const bool take_q = q_first ? !(bp < bq) : (bq < bp);
-      const int32_t w1 = take_q ? qq : pp;
+      // first pick: count[.][0], holders in visit order, first strictly smaller wins == the
+      // minimum of (count, stored position)
+      const uint32_t k0 = (((uint32_t)x0 & 0xffffu) << 2), k1 = (((uint32_t)x1 & 0xffffu) << 2) | 1u,
+                     k2 = (((uint32_t)x2 & 0xffffu) << 2) | 2u;
+      const uint32_t kmin = k0 < k1 ? (k0 < k2 ? k0 : k2) : (k1 < k2 ? k1 : k2);
+      const int32_t w0 = (int32_t)(kmin & 3u);
+      // second pick: count[.][1] of the two remaining stored positions; the one visited first
+      // wins ties: minimum of (count, visited second, stored position), the taken one excluded
+      const uint32_t vis = (uint32_t)meta >> w0;            // bit 0: the higher remaining position is visited first
+      const uint32_t hi_first = vis & 1u;
+      const uint32_t lo_pos = w0 == 0 ? 1u : 0u, hi_pos = w0 == 2 ? 1u : 2u;
+      const uint32_t c1_0 = (uint32_t)x0 >> 16, c1_1 = (uint32_t)x1 >> 16, c1_2 = (uint32_t)x2 >> 16;
+      const uint32_t c_lo = w0 == 0 ? c1_1 : c1_0, c_hi = w0 == 2 ? c1_1 : c1_2;
+      const uint32_t key_lo = (c_lo << 3) | (hi_first << 2) | lo_pos;
+      const uint32_t key_hi = (c_hi << 3) | ((hi_first ^ 1u) << 2) | hi_pos;
+      const int32_t w1 = (int32_t)((key_lo < key_hi ? key_lo : key_hi) & 3u);
       const int32_t w2 = 3 - w0 - w1;
       if (ready) {
         const int32_t Lp = (meta >> 3) & 3;
@@ -1134,27 +1140,45 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     itr = itl;
     int32_t jl = 0, jr = 0;                                 // tiles staged (group-uniform), rows retired
     bool endl = false;
+    bool pf_valid = false, pf_have_row = false, pf_end = false;
+    int32_t pf_cells[3] = {-1, -1, -1}, pf_idx2 = 0, pf_idx3 = 0;
     uint64_t digest = 0;
     int64_t f_iter = 0, f_idle = 0;
     for (;;) {
       kasw::lockstep();
       f_iter += 1;
-      // ---- next tile of my group, if every lane of the group has a free slot: issue its HBM read
+      // ---- next tile of my group: its HBM read was issued an iteration ago (pf_*); it is staged
+      // now if every lane of the group has a free slot
       const bool room = (kasw::ballot(jl - jr < K) & gmask) == gmask;
-      bool staging = false, have_row = false;
+      bool staging = false, have_row = false, staging_end = false;
       int32_t cells[3] = {-1, -1, -1};
-      if (!endl && room) {
+      int32_t st_idx2 = 0, st_idx3 = 0;
+      if (!endl && room && pf_valid) {
         staging = true;
+        staging_end = pf_end;
+        have_row = pf_have_row;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) cells[q] = pf_cells[q];
+        st_idx2 = pf_idx2; st_idx3 = pf_idx3;
+        endl = pf_end;
+        pf_valid = false;
+      }
+      if (!pf_valid && !endl) {                             // read ahead: the tile after that
+        pf_valid = true;
+        pf_have_row = false;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pf_cells[q] = -1;
         if (tile_next<GL>(itl, a, sd)) {
           const int32_t p = itl.t * GL + li;
-          have_row = p < itl.tP;
-          if (have_row) {
+          pf_have_row = p < itl.tP;
+          pf_idx2 = itl.idx2; pf_idx3 = itl.idx3;
+          if (pf_have_row) {
             const int32_t* row = a.out + itl.tout + (int64_t)p * itl.tow;
 #pragma unroll
-            for (int q = 0; q < W; ++q) cells[q] = q < itl.tow ? row[q] : -1;
+            for (int q = 0; q < W; ++q) pf_cells[q] = q < itl.tow ? row[q] : -1;
           }
         } else {
-          endl = true;
+          pf_end = true;
         }
       }
       // ---- retire finished rows: stored position -> node index -> broker id, digest, out row
@@ -1228,10 +1252,10 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       if (staging) {
         RingSlot o;
         o.c[0] = dummy_addr; o.c[1] = dummy_addr; o.c[2] = dummy_addr;
-        if (endl) {
+        if (staging_end) {
           o.tag = KAS_TAG_END;
         } else if (holds) {
-          o.tag = jl | stage_row(hn, tk, Lp, itl.idx2, itl.idx3, cnt_base, dummy_addr, o.c);
+          o.tag = jl | stage_row(hn, tk, Lp, st_idx2, st_idx3, cnt_base, dummy_addr, o.c);
         } else {
           // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane:
           // an empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
