@@ -50,7 +50,7 @@ def main() -> int:
     ap.add_argument("--check", type=int, default=8, help="scenarios list-compared against the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=8,
                     help="batches in flight: steps are issued round-robin on this many HIP streams, "
                          "each with its own plan scratch and output tables")
     ap.add_argument("--stats", default="", help="write the per-phase device counters (JSON) here")

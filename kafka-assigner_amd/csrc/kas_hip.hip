@@ -24,8 +24,13 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// min waves per SIMD: 4 workgroups of 4 wavefronts per CU is what the LDS carve-up allows at
+// N = 1000, so the register budget is capped at 128 VGPRs to match (cold paths spill a little)
+#ifndef KAS_FILL_MIN_WAVES
+#define KAS_FILL_MIN_WAVES 4
+#endif
 template <int W, int NW>
-__global__ __launch_bounds__(64 * NW) void kas_fill_kernel(KasLaunch a) {
+__global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
     kas::fill_scenario<W, NW>(a, s, kas_lds);

@@ -233,6 +233,36 @@ KAS_DEV void load_row(const TopicView& T, int32_t p, int32_t (&ids)[W], int32_t&
   len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
 }
 
+// Stream the tiles tile0, tile0 + stride, ... (< t_end) of the cur table through `body(tile, ids,
+// len)` with KAS_TILES_AHEAD tiles of rows in flight per lane: the scans are HBM-latency-bound
+// (12 bytes per lane per tile), so several tiles are requested before the first is consumed.
+#define KAS_TILES_AHEAD 4
+template <int W, typename Body>
+KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
+  constexpr int D = KAS_TILES_AHEAD;
+  const int lane = kasw::lane();
+  int32_t nx[D][W], nlen[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_row<W>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
+  for (int32_t tile = tile0; tile < t_end; tile += stride * D) {
+    int32_t ids[D][W], len[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int r = 0; r < W; ++r) ids[d][r] = nx[d][r];
+      len[d] = nlen[d];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)                              // request the next batch
+      load_row<W>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int32_t t = tile + d * stride;
+      if (t < t_end) body(t, ids[d], len[d]);                // wave-uniform
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // P3 for one row per lane (KAS:133-160): holders of the row from its accepted replicas, orphan
 // count, movement bookkeeping and the out row (node indices for now).
@@ -424,18 +454,9 @@ KAS_DEV int32_t p3p4_generic(const LdsView& L, const TopicView& T, const NodeMap
 // A1: tiles wave, wave+NW, ... ; returns this lane's "not rack-diverse" verdict
 template <int W, int NW>
 KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
-  const int lane = kasw::lane();
   const int32_t N = T.N;
   bool viol = false;
-  int32_t nx[W], nlen;
-  load_row<W>(T, (wave << 6) + lane, nx, nlen);
-  for (int32_t tile = wave; tile < T.nt; tile += NW) {
-    const int32_t p = (tile << 6) + lane;
-    int32_t ids[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) ids[r] = nx[r];
-    const int32_t len = nlen;
-    load_row<W>(T, p + 64 * NW, nx, nlen);                  // prefetch this wave's next tile
+  for_tiles<W>(T, wave, NW, T.nt, [&](int32_t, const int32_t (&ids)[W], int32_t len) {
     int32_t idx[W], rk[W];
 #pragma unroll
     for (int r = 0; r < W; ++r) {
@@ -448,7 +469,7 @@ KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm
       for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[r] == rk[r2];
 #pragma unroll
     for (int r = 0; r < W; ++r) if (idx[r] >= 0) kasw::lds_atomic_add(&L.x[r * N + idx[r]], 1);
-  }
+  });
   return viol;
 }
 
@@ -478,25 +499,16 @@ KAS_DEV void fill_quota(const LdsView& L, const TopicView& T, int32_t tid) {
 // A2: wave w counts the sweep-r* candidates of chunk w per node
 template <int W, int NW>
 KAS_DEV void fill_chunk_count(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
-  const int lane = kasw::lane();
   const int32_t N = T.N;
   const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
   int32_t* qc = L.x + wave * N;
-  int32_t nx[W], nlen;
-  load_row<W>(T, (t0 << 6) + lane, nx, nlen);
-  for (int32_t tile = t0; tile < t1; ++tile) {
-    const int32_t p = (tile << 6) + lane;
-    int32_t ids[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) ids[r] = nx[r];
-    const int32_t len = nlen;
-    load_row<W>(T, p + 64, nx, nlen);
+  for_tiles<W>(T, t0, 1, t1, [&](int32_t, const int32_t (&ids)[W], int32_t len) {
 #pragma unroll
     for (int r = 0; r < W; ++r) {
       const int32_t i = r < len ? node_lookup(L, nm, ids[r]) : -1;
       if (i >= 0 && (int32_t)((uint32_t)L.qrs[i] >> 28) == r) kasw::lds_atomic_add(&qc[i], 1);
     }
-  }
+  });
 }
 
 // prefix over chunks: x[w][n] <- quota of node n still unused when chunk w starts
@@ -525,15 +537,8 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
   int32_t* qc = L.x + wave * N;
   int32_t* olist = T.orph + ((int64_t)t0 << 6);
   int32_t ocount = 0;
-  int32_t nx[W], nlen;
-  load_row<W>(T, (t0 << 6) + lane, nx, nlen);
-  for (int32_t tile = t0; tile < t1; ++tile) {
+  for_tiles<W>(T, t0, 1, t1, [&](int32_t tile, const int32_t (&ids)[W], int32_t len) {
     const int32_t p = (tile << 6) + lane;
-    int32_t ids[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) ids[r] = nx[r];
-    const int32_t len = nlen;
-    load_row<W>(T, p + 64, nx, nlen);
     int32_t idx[W], nn[W], before[W];
     uint32_t sure = 0, counting = 0;
 #pragma unroll
@@ -587,7 +592,7 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
     const uint64_t om = kasw::ballot(need > 0);
     if (need > 0) olist[ocount + kasw::popc(om & lt)] = p;
     ocount += kasw::popc(om);
-  }
+  });
   return ocount;
 }
 
@@ -942,7 +947,9 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 // with one LDS atomic add per node.  Lanes never wait for each other except through tickets, so
 // the scenarios of one wavefront do not interact at all.
 // ---------------------------------------------------------------------------------------------
-#define KAS_RING_SLOTS 8
+#ifndef KAS_RING_SLOTS
+#define KAS_RING_SLOTS 4
+#endif
 #define KAS_TAG_FREE (-1)
 #define KAS_TAG_END  (-3)
 #define KAS_TAG_DONE ((int32_t)0x80000000)   // | w0 | w1 << 2 | Lp << 4
@@ -954,13 +961,6 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 #define KAS_DUMMY_COUNTS 0x0000ffffffffffffull   // counter row of the padding holder: never picked
 
 struct alignas(16) RingSlot { int32_t tag; int32_t c[3]; };
-
-// lane mask type of the ticket pass: one bit per lane of a group
-template <int G>
-struct OrderLds {
-  static constexpr int GL = 64 / G;
-  typedef typename std::conditional<(GL > 32), uint64_t, uint32_t>::type Mask;
-};
 
 // a group's tile sequence: GL-row tiles of every topic the fill kernel solved, in order
 struct TileIter {
@@ -1026,9 +1026,8 @@ KAS_DEV int32_t stage_row(const int32_t (&h)[3], const int32_t (&tk)[3], int32_t
 template <int W, int G>
 KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned char* lds_raw) {
   static_assert(W <= 3, "ring slots and packed counter rows hold lists up to 3 wide");
-  typedef OrderLds<G> OL;
-  typedef typename OL::Mask Mask;
   constexpr int GL = 64 / G;
+  constexpr int HALVES = GL > 32 ? 2 : 1;                   // ticket pass: 32 rows per lane mask
   constexpr int K = KAS_RING_SLOTS;
   constexpr int UR = 2;                                     // rows retired per lane per feeder iteration
   const int lane = kasw::lane();
@@ -1039,9 +1038,9 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G);    // LDS byte offset of this group's region
   uint64_t* cnt = (uint64_t*)(lds_raw + cnt_base);          // [nmax + 1]: + the padding holder's row
-  int32_t* run = (int32_t*)(lds_raw + cnt_base + 8 * (nmax + 1));
-  int32_t* nid = run + nmax;                                // broker id per node index
-  Mask* dep = (Mask*)(nid + nmax);
+  int32_t* nid = (int32_t*)(lds_raw + cnt_base + 8 * (nmax + 1));   // broker id per node index
+  uint32_t* dep = (uint32_t*)(nid + nmax);                  // lane mask per node (ticket pass)
+  uint16_t* run = (uint16_t*)(dep + nmax);                  // tickets handed out per node so far
   const int32_t dummy_addr = cnt_base + nmax * 8;
   RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G));
   uint64_t* gdig = (uint64_t*)(ring + K * 64);
@@ -1052,7 +1051,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int32_t N = sd.n_nodes;
   const int32_t* g_node_id = a.node_id + sd.node_off;
   for (int32_t n = li + GL * wave; n < N; n += 2 * GL) {
-    cnt[n] = 0ull; run[n] = 0; dep[n] = (Mask)0; nid[n] = g_node_id[n];
+    cnt[n] = 0ull; run[n] = 0; dep[n] = 0u; nid[n] = g_node_id[n];
   }
   if (wave == 0 && li == 0) { cnt[nmax] = KAS_DUMMY_COUNTS; gdig[g] = 0ull; }
   for (int32_t k = wave; k < K; k += 2) ring[k * 64 + lane].tag = KAS_TAG_FREE;
@@ -1132,8 +1131,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   } else {
     // ------------------------------------------------------------------ feeder / retirer
     const uint64_t gmask = (G == 1 ? ~0ull : ((1ull << GL) - 1ull)) << (g * GL);   // my group's lanes
-    const Mask mybit = (Mask)1 << li;
-    const Mask lt = mybit - (Mask)1;
+    const uint32_t mybit = 1u << (li & 31);
+    const uint32_t lt = mybit - 1u;
     TileIter itl, itr;
     itl.k = -1; itl.tP = 0; itl.tow = 1; itl.t = -1; itl.idx2 = 0; itl.idx3 = 0; itl.tout = 0;
     itl.exhausted = !have_s;
@@ -1211,42 +1210,42 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           }
         }
       }
-      // ---- tickets for the tile (wave-wide lockstep; lanes not staging carry no holders)
+      // ---- tickets for the tile (wave-wide lockstep; lanes not staging carry no holders).  One
+      // 32-bit lane mask per node: a 64-lane group takes its tile as two ascending halves.
       int32_t h[3], Lp = 0;
       sort_holders<3>(cells, h, Lp);                        // Sets.newTreeSet (KAS:228)
       const bool holds = staging && have_row && Lp > 0;
-      int32_t hn[3];
+      int32_t hn[3], tk[3] = {0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 3; ++q) hn[q] = (holds && q < Lp) ? h[q] : 0;
-      if (holds) {
+#pragma unroll
+      for (int hf = 0; hf < HALVES; ++hf) {
+        const bool mine = holds && (HALVES == 1 || (li >> 5) == hf);
+        if (mine) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) if (q < Lp) kasw::lds_atomic_or_u32(&dep[hn[q]], mybit);
+        }
+        kasw::lockstep();
+        uint32_t m[3];
+        int32_t base[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          if (q < Lp) {
-            if constexpr (sizeof(Mask) == 8) kasw::lds_atomic_or_u64((uint64_t*)&dep[hn[q]], (uint64_t)mybit);
-            else kasw::lds_atomic_or_u32((uint32_t*)&dep[hn[q]], (uint32_t)mybit);
+          const bool on = mine && q < Lp;
+          m[q] = on ? dep[hn[q]] : 0u;
+          base[q] = on ? (int32_t)run[hn[q]] : 0;
+        }
+        kasw::lockstep();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (mine && q < Lp) {
+            tk[q] = base[q] + __builtin_popcount(m[q] & lt);
+            if ((m[q] & lt) == 0u) {                        // lowest lane holding this node
+              run[hn[q]] = (uint16_t)(base[q] + __builtin_popcount(m[q]));
+              dep[hn[q]] = 0u;
+            }
           }
         }
-      }
-      kasw::lockstep();
-      Mask m[3];
-      int32_t base[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const bool on = holds && q < Lp;
-        m[q] = on ? dep[hn[q]] : (Mask)0;
-        base[q] = on ? run[hn[q]] : 0;
-      }
-      kasw::lockstep();
-      int32_t tk[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int32_t below = sizeof(Mask) == 8 ? kasw::popc((uint64_t)(m[q] & lt)) : __builtin_popcount((uint32_t)(m[q] & lt));
-        const int32_t all = sizeof(Mask) == 8 ? kasw::popc((uint64_t)m[q]) : __builtin_popcount((uint32_t)m[q]);
-        tk[q] = base[q] + below;
-        if (holds && q < Lp && (m[q] & lt) == (Mask)0) {   // lowest lane holding this node
-          run[hn[q]] = base[q] + all;
-          dep[hn[q]] = (Mask)0;
-        }
+        if (hf + 1 < HALVES) kasw::lockstep();               // the second half sees the first's counts
       }
       // ---- hand the staged row to the solver
       if (staging) {

@@ -52,12 +52,13 @@ KAS_DEV int32_t observe(const int32_t* flag) {
   return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Point where the body relies on the 64 lanes having executed the preceding LDS reads before
-// any lane executes the following LDS writes.  A wavefront issues each instruction for all
-// lanes at once and its LDS operations complete in issue order, so on hardware this only has
-// to stop the compiler from reordering memory operations across it (no instruction emitted).
+// Point where the body relies on the 64 lanes having executed the preceding LDS accesses before
+// any lane executes the following ones (read-then-overwrite, atomic-then-read on the same words).
+// A wavefront issues each instruction for all lanes at once and the LDS serves a wave's
+// operations in issue order, so on hardware this only has to stop the COMPILER from reordering
+// or caching memory operations across it: no instruction, no s_waitcnt.
 KAS_DEV void lockstep() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 

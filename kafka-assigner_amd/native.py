@@ -40,9 +40,10 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get("KAS_HIP_LIB", LIB_PATH)     # tuning builds of the same library
+    if not os.path.exists(lib_path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m kafka_assigner_amd.build` "
+            f"{lib_path} is missing: build it with `python -m kafka_assigner_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     # PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 with the same SONAMEs as
     # /opt/rocm's; whichever is loaded first serves the whole process, and mixing them (ours
@@ -52,7 +53,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     L.kas_abi_version.restype = C.c_int
     L.kas_strerror.restype = C.c_char_p; L.kas_strerror.argtypes = [C.c_int]
     L.kas_status_string.restype = C.c_char_p; L.kas_status_string.argtypes = [C.c_int]
