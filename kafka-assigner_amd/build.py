@@ -43,5 +43,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+CLI = os.path.join(HOST, "kafka-assignment-generator")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """Compile the C++ host mirror's CLI (host/kas_cli.cpp) against csrc/libkas_hip.so."""
+    build(verbose=verbose)
+    deps = [os.path.join(HOST, f) for f in ("kas_cli.cpp", "kafka_assigner.hpp", "mini_json.hpp")]
+    deps += [LIB, os.path.join(ROOT, "include", "kas_abi.h")]
+    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(d) for d in deps):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
+           "-o", CLI, os.path.join(HOST, "kas_cli.cpp"), "-L" + CSRC, "-lkas_hip",
+           "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,--allow-shlib-undefined"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,123 @@
+"""C++ host mirror + CLI (kafka-assigner_amd/host): `--mode PRINT_REASSIGNMENT` over a cluster
+snapshot, the plumbing of BASELINE.json configs[0] (3 topics x 12 partitions, 6 brokers / 3
+racks, RF 3).  The snapshot-only modes and argument handling run anywhere; the solve itself needs
+the MI355X (-m gpu) and is compared with the known-answer vectors of SURVEY.md Appendix B as
+PARSED JSON (the reference's key order is JVM-dependent, quirk Q11)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from kafka_assigner_amd import build as kbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = json.load(open(os.path.join(ROOT, "tests", "golden", "survey_appendix_b.json")))
+C1 = G["config1"]
+
+
+@pytest.fixture(scope="module")
+def cli():
+    return kbuild.build_host()
+
+
+def _snapshot(tmp_path, brokers, racks, extra_brokers=()):
+    snap = {"brokers": [], "partitions": []}
+    for b in sorted(set(brokers) | set(extra_brokers)):
+        e = {"id": b, "host": f"kafka-{b}.example.com", "port": 9092}
+        if str(b) in racks or b in racks:
+            e["rack"] = racks.get(str(b), racks.get(b))
+        snap["brokers"].append(e)
+    for t, topic in enumerate(C1["topics"]):
+        for p, reps in sorted(C1["current"][t].items(), key=lambda kv: int(kv[0])):
+            snap["partitions"].append({"topic": topic, "partition": int(p), "replicas": reps})
+    path = tmp_path / "snapshot.json"
+    path.write_text(json.dumps(snap))
+    return str(path), snap
+
+
+def _run(cli, *args):
+    return subprocess.run([cli, *args], capture_output=True, text=True, timeout=120)
+
+
+def _sections(stdout):
+    """{'CURRENT ASSIGNMENT': json, 'NEW ASSIGNMENT': json, ...}"""
+    out, lines = {}, stdout.splitlines()
+    for i, line in enumerate(lines):
+        if line.endswith(":") and i + 1 < len(lines):
+            out[line[:-1]] = json.loads(lines[i + 1])
+    return out
+
+
+def test_usage_on_bad_arguments_returns_normally(cli, tmp_path):
+    # KAG:263-270: arg problems print the usage and RETURN (exit code 0), quirk Q12
+    r = _run(cli, "--mode", "PRINT_REASSIGNMENT")
+    assert r.returncode == 0 and "kafka-assignment-generator.sh [options...]" in r.stderr
+    path, _ = _snapshot(tmp_path, range(6), {})
+    r = _run(cli, "--snapshot", path, "--mode", "PRINT_REASSIGNMENT", "--integer_broker_ids", "1",
+             "--broker_hosts", "x")
+    assert r.returncode == 0 and r.stdout == "" and "options" in r.stderr
+
+
+def test_print_current_brokers_and_assignment_round_trip_the_snapshot(cli, tmp_path):
+    case = C1["cases"][0]
+    path, snap = _snapshot(tmp_path, case["brokers"], case["racks"])
+    r = _run(cli, "--snapshot", path, "--mode", "PRINT_CURRENT_BROKERS")
+    assert r.returncode == 0
+    assert _sections(r.stdout)["CURRENT BROKERS"] == snap["brokers"]         # KAG:113-129 shape
+    r = _run(cli, "--snapshot", path, "--mode", "PRINT_CURRENT_ASSIGNMENT", "--topics", "topic-1")
+    cur = _sections(r.stdout)["CURRENT ASSIGNMENT"]
+    assert cur["version"] == 1
+    assert cur["partitions"] == [p for p in snap["partitions"] if p["topic"] == "topic-1"]
+
+
+def test_unknown_hostnames_are_an_error_only_for_the_include_list(cli, tmp_path):
+    path, _ = _snapshot(tmp_path, range(6), {})
+    r = _run(cli, "--snapshot", path, "--mode", "PRINT_REASSIGNMENT", "--broker_hosts", "nope.example.com")
+    assert r.returncode == 1 and "Some hostnames could not be found! We found: []" in r.stderr   # KAG:199-201
+
+
+def _expected_new(case):
+    parts = []
+    for t, topic in enumerate(C1["topics"]):
+        for p, reps in sorted(case["expected"][t].items(), key=lambda kv: int(kv[0])):
+            parts.append({"topic": topic, "partition": int(p), "replicas": reps})
+    return {"version": 1, "partitions": parts}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in C1["cases"] if "fails" not in c], ids=lambda c: c["name"])
+def test_print_reassignment_matches_appendix_b(cli, tmp_path, case):
+    all_brokers = set(range(9))
+    path, snap = _snapshot(tmp_path, all_brokers, {str(b): "abc"[b % 3] for b in all_brokers})
+    args = ["--snapshot", path, "--mode", "PRINT_REASSIGNMENT",
+            "--integer_broker_ids", ",".join(str(b) for b in case["brokers"])]
+    if not case["racks"]:
+        args.append("--disable_rack_awareness")
+    r = _run(cli, *args)
+    assert r.returncode == 0, r.stderr
+    sec = _sections(r.stdout)
+    assert sec["CURRENT ASSIGNMENT"]["partitions"] == snap["partitions"]     # rollback aid, KAG:159-160
+    assert sec["NEW ASSIGNMENT"] == _expected_new(case)
+
+
+@pytest.mark.gpu
+def test_print_reassignment_decommission_by_hostname_aborts_like_the_reference(cli, tmp_path):
+    case = next(c for c in C1["cases"] if "fails" in c)
+    live = set(case["brokers"]) | {5}
+    path, _ = _snapshot(tmp_path, live, {str(b): "abc"[b % 3] for b in live})
+    r = _run(cli, "--snapshot", path, "--mode", "PRINT_REASSIGNMENT",
+             "--broker_hosts_to_remove", "kafka-5.example.com")
+    # uncaught IllegalStateException after the rollback block, before any NEW ASSIGNMENT
+    assert r.returncode == 1
+    assert "CURRENT ASSIGNMENT:" in r.stdout and "NEW ASSIGNMENT" not in r.stdout
+    assert "Partition %d could not be fully assigned!" % case["fails"]["partition"] in r.stderr
+
+
+def test_without_a_gpu_the_solve_fails_loudly(cli, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    path, _ = _snapshot(tmp_path, range(6), {})
+    r = _run(cli, "--snapshot", path, "--mode", "PRINT_REASSIGNMENT")
+    assert r.returncode == 2 and "no HIP device" in r.stderr                  # no CPU fallback
