@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(K
 }
 
 template <int W, int G>
-__global__ __launch_bounds__(128) void kas_order_ticket_kernel(KasLaunch a) {
+__global__ __launch_bounds__(192) void kas_order_ticket_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   kas::order_tickets<W, G>(a, (int32_t)blockIdx.x * G, kas_lds);
 }
@@ -355,7 +355,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
   if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G), dim3((unsigned)((p->n_scenarios + p->G - 1) / p->G)),
-                       dim3(128), (size_t)kas_order_ticket_lds(p->shape.n_max, p->G), st, a);
+                       dim3(192), (size_t)kas_order_ticket_lds(p->shape.n_max, p->G), st, a);
   else
     hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
                        (size_t)kas_order_round_lds(p->shape.n_max, p->Wc), st, a);

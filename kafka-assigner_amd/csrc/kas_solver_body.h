@@ -927,19 +927,21 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 }
 
 // ---------------------------------------------------------------------------------------------
-// order kernel, ticket form.  A workgroup is two wavefronts serving G scenarios (one lane group
-// of GL = 64 / G lanes each): wave 0 SOLVES, wave 1 FEEDS it.  Lane l of either wave owns the
-// rows li, li + GL, li + 2 GL, ... (li = l % GL) of every solved topic of its scenario, in order.
+// order kernel, ticket form.  A workgroup is three wavefronts serving G scenarios (one lane group
+// of GL = 64 / G lanes each): wave 0 SOLVES, wave 1 STAGES rows for it, wave 2 RETIRES what it
+// finished.  Lane l of every wave owns the rows li, li + GL, li + 2 GL, ... (li = l % GL) of every
+// solved topic of its scenario, in order.
 //
 // The solver's loop is a chain of ~(number of orphans) dependent steps per scenario, so nothing
-// with memory latency may sit in it: it touches LDS only.  The feeder streams the fill kernel's
+// with memory latency may sit in it: it touches LDS only.  The stager streams the fill kernel's
 // rows (node indices) from HBM one GL-row tile at a time, hands out tickets in row order
 // (ticket of (row, node) = how many earlier rows of the scenario hold that node: a per-node
 // running count + the rank among the tile's lanes holding it, from one lane mask per node),
-// stages each row into a ring of KAS_RING_SLOTS 16-byte slots per lane, and retires finished
-// rows: node index -> broker id, digest, the final out row.  Slot protocol (tag = first dword):
-//     FREE  --feeder-->  j (= the lane's j-th row is staged)  --solver-->  DONE | picks
-//     --feeder-->  FREE                                       END = the lane has no more rows
+// and stages each row into a ring of KAS_RING_SLOTS 16-byte slots per lane; the retirer turns
+// finished rows into the final out row (node index -> broker id) and the digest.  Slot protocol
+// (tag = first dword):
+//     FREE  --stager-->  j (= the lane's j-th row is staged)  --solver-->  DONE | picks
+//     --retirer-->  FREE                                      END = the lane has no more rows
 //
 // count[n][r] lives in LDS as 4 x uint16 per node, the fourth field counting the rows that
 // committed on the node.  A row commits once "commits on n == its ticket" holds for each of its
@@ -1029,7 +1031,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   constexpr int GL = 64 / G;
   constexpr int HALVES = GL > 32 ? 2 : 1;                   // ticket pass: 32 rows per lane mask
   constexpr int K = KAS_RING_SLOTS;
-  constexpr int UR = 2;                                     // rows retired per lane per feeder iteration
   const int lane = kasw::lane();
   const int32_t wave = kasw::wave_id();
   const int32_t g = lane / GL, li = lane % GL;
@@ -1050,11 +1051,11 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   if (have_s) sd = a.scen[s];
   const int32_t N = sd.n_nodes;
   const int32_t* g_node_id = a.node_id + sd.node_off;
-  for (int32_t n = li + GL * wave; n < N; n += 2 * GL) {
+  for (int32_t n = li + GL * wave; n < N; n += 3 * GL) {
     cnt[n] = 0ull; run[n] = 0; dep[n] = 0u; nid[n] = g_node_id[n];
   }
   if (wave == 0 && li == 0) { cnt[nmax] = KAS_DUMMY_COUNTS; gdig[g] = 0ull; }
-  for (int32_t k = wave; k < K; k += 2) ring[k * 64 + lane].tag = KAS_TAG_FREE;
+  for (int32_t k = wave; k < K; k += 3) ring[k * 64 + lane].tag = KAS_TAG_FREE;
   kasw::sync();
 
   if (wave == 0) {
@@ -1068,6 +1069,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     nx.tag = KAS_TAG_FREE; nx.c[0] = 0; nx.c[1] = 0; nx.c[2] = 0;
     int64_t n_iter = 0, n_blocked = 0;
     const int64_t t_begin = kasw::clock_ticks();
+    kasw::set_priority<3>();                               // the chain: first call on the SIMD's issue slots
     for (;;) {
       kasw::repoll();                                      // LDS is re-read below
       n_iter += 1;
@@ -1078,7 +1080,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const uint64_t x1 = *(const uint64_t*)(lds_raw + (e1 & 0xffff));
       const uint64_t x2 = *(const uint64_t*)(lds_raw + (e2 & 0xffff));
       if (!nv && !fin) {
-        if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == jn) { nx = sl; nv = true; }
+        if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
         else if (sl.tag == KAS_TAG_END && !cv) fin = true;
       }
       // commits on the node == my ticket: every earlier row holding it has committed
@@ -1128,27 +1130,26 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
       st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = 0; st[11] = n_blocked;
     }
-  } else {
-    // ------------------------------------------------------------------ feeder / retirer
+  } else if (wave == 1) {
+    // ------------------------------------------------------------------ stager: tickets + staging
     const uint64_t gmask = (G == 1 ? ~0ull : ((1ull << GL) - 1ull)) << (g * GL);   // my group's lanes
     const uint32_t mybit = 1u << (li & 31);
     const uint32_t lt = mybit - 1u;
-    TileIter itl, itr;
+    TileIter itl;
     itl.k = -1; itl.tP = 0; itl.tow = 1; itl.t = -1; itl.idx2 = 0; itl.idx3 = 0; itl.tout = 0;
     itl.exhausted = !have_s;
-    itr = itl;
-    int32_t jl = 0, jr = 0;                                 // tiles staged (group-uniform), rows retired
+    int32_t jl = 0;                                         // tiles staged (group-uniform)
     bool endl = false;
     bool pf_valid = false, pf_have_row = false, pf_end = false;
     int32_t pf_cells[3] = {-1, -1, -1}, pf_idx2 = 0, pf_idx3 = 0;
-    uint64_t digest = 0;
     int64_t f_iter = 0, f_idle = 0;
     for (;;) {
-      kasw::lockstep();
+      kasw::repoll();
       f_iter += 1;
       // ---- next tile of my group: its HBM read was issued an iteration ago (pf_*); it is staged
-      // now if every lane of the group has a free slot
-      const bool room = (kasw::ballot(jl - jr < K) & gmask) == gmask;
+      // now if the slot it goes to is free (retired) in every lane of the group
+      const bool slot_free = ring[(jl & (K - 1)) * 64 + lane].tag == KAS_TAG_FREE;
+      const bool room = (kasw::ballot(slot_free) & gmask) == gmask;
       bool staging = false, have_row = false, staging_end = false;
       int32_t cells[3] = {-1, -1, -1};
       int32_t st_idx2 = 0, st_idx3 = 0;
@@ -1178,36 +1179,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           }
         } else {
           pf_end = true;
-        }
-      }
-      // ---- retire finished rows: stored position -> node index -> broker id, digest, out row
-      bool retired = false;
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        if (jr < jl) {
-          const RingSlot sl = ring[(jr & (K - 1)) * 64 + lane];
-          if (KAS_TAG_IS_DONE(sl.tag)) {
-            tile_next<GL>(itr, a, sd);
-            const int32_t p = itr.t * GL + li;
-            const int32_t w0 = sl.tag & 3, w1 = (sl.tag >> 2) & 3, Lp = (sl.tag >> 4) & 3;
-            const int32_t w[3] = {w0, w1, 3 - w0 - w1};
-            int32_t* row = a.out + itr.tout + (int64_t)p * itr.tow;
-#pragma unroll
-            for (int r = 0; r < W; ++r) {
-              if (r < Lp) {
-                const int32_t e = w[r] == 0 ? sl.c[0] : (w[r] == 1 ? sl.c[1] : sl.c[2]);
-                const int32_t node = ((e & 0xffff) - cnt_base) >> 3;
-                const int32_t id = nid[node];
-                row[r] = id;
-                digest += kas_digest_cell((uint32_t)itr.k, (uint32_t)p, (uint32_t)r, id);
-              }
-            }
-            ring[(jr & (K - 1)) * 64 + lane].tag = KAS_TAG_FREE;
-            jr += 1;
-            retired = true;
-          } else if (sl.tag == KAS_TAG_END) {
-            jr += 1;                                       // the end marker retires itself
-          }
         }
       }
       // ---- tickets for the tile (wave-wide lockstep; lanes not staging carry no holders).  One
@@ -1254,21 +1225,65 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         if (staging_end) {
           o.tag = KAS_TAG_END;
         } else if (holds) {
-          o.tag = jl | stage_row(hn, tk, Lp, st_idx2, st_idx3, cnt_base, dummy_addr, o.c);
+          o.tag = (jl & KAS_TAG_JMASK) | stage_row(hn, tk, Lp, st_idx2, st_idx3, cnt_base, dummy_addr, o.c);
         } else {
           // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane:
           // an empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
-          o.tag = jl;
+          o.tag = jl & KAS_TAG_JMASK;
         }
         ring[(jl & (K - 1)) * 64 + lane] = o;
         jl += 1;
       }
-      if (kasw::ballot(!(endl && jr == jl)) == 0) break;
-      if (kasw::ballot(staging || retired) == 0) { f_idle += 1; kasw::spin_pause(); }
+      if (kasw::ballot(!endl) == 0) break;
+      if (kasw::ballot(staging) == 0) { f_idle += 1; kasw::nap<4>(); }
     }
     if (a.stats && have_s && li == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
       st[12] = f_iter; st[13] = f_idle;
+    }
+  } else {
+    // ------------------------------------------------------------------ retirer: finished rows ->
+    // broker ids, digest, the final out row; frees the slot for the stager
+    constexpr int UR = 2;                                   // rows per lane per iteration
+    TileIter itr;
+    itr.k = -1; itr.tP = 0; itr.tow = 1; itr.t = -1; itr.idx2 = 0; itr.idx3 = 0; itr.tout = 0;
+    itr.exhausted = !have_s;
+    int32_t jr = 0;
+    bool fin = false;
+    uint64_t digest = 0;
+    for (;;) {
+      kasw::repoll();
+      bool retired = false;
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        if (!fin) {
+          const RingSlot sl = ring[(jr & (K - 1)) * 64 + lane];
+          if (KAS_TAG_IS_DONE(sl.tag)) {
+            tile_next<GL>(itr, a, sd);
+            const int32_t p = itr.t * GL + li;
+            const int32_t w0 = sl.tag & 3, w1 = (sl.tag >> 2) & 3, Lp = (sl.tag >> 4) & 3;
+            const int32_t w[3] = {w0, w1, 3 - w0 - w1};
+            int32_t* row = a.out + itr.tout + (int64_t)p * itr.tow;
+#pragma unroll
+            for (int r = 0; r < W; ++r) {
+              if (r < Lp) {
+                const int32_t e = w[r] == 0 ? sl.c[0] : (w[r] == 1 ? sl.c[1] : sl.c[2]);
+                const int32_t node = ((e & 0xffff) - cnt_base) >> 3;
+                const int32_t id = nid[node];
+                row[r] = id;
+                digest += kas_digest_cell((uint32_t)itr.k, (uint32_t)p, (uint32_t)r, id);
+              }
+            }
+            ring[(jr & (K - 1)) * 64 + lane].tag = KAS_TAG_FREE;
+            jr += 1;
+            retired = true;
+          } else if (sl.tag == KAS_TAG_END) {
+            fin = true;
+          }
+        }
+      }
+      if (kasw::ballot(!fin) == 0) break;
+      if (kasw::ballot(retired) == 0) kasw::nap<8>();
     }
     kasw::lds_atomic_add_u64(&gdig[g], digest);
     kasw::lockstep();

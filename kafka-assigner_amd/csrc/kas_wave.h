@@ -40,8 +40,16 @@ KAS_DEV void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// back off inside a spin loop (the other waves of the CU get the issue slots)
+// back off inside a spin loop (the other waves of the CU get the issue slots): ~64 cycles, or
+// ~64 * N for a wave that is not on anybody's critical path
 KAS_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+template <int N>
+KAS_DEV void nap() { __builtin_amdgcn_s_sleep(N); }
+
+// issue priority of this wave among the waves of its SIMD (0..3): the one wave whose loop is a
+// dependency chain asks for the slots first
+template <int P>
+KAS_DEV void set_priority() { __builtin_amdgcn_s_setprio(P); }
 
 // watermark hand-off between waves of one workgroup: everything this wave stored (LDS and
 // global) before publish() is visible to a wave that observes the value

@@ -186,7 +186,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     for (int32_t s = 0; s < b->n_scenarios; s += sh.G) {
       memset(lds.data(), 0xCD, lds.size());
       RunArgs ra{&a, s, lds.data()};
-      if (kasw::run_block(f, &ra, 2) != 0) return bad("order (tickets)", s);
+      if (kasw::run_block(f, &ra, 3) != 0) return bad("order (tickets)", s);
     }
   } else {
     run_fn f = rounds_for(sh.Wc);

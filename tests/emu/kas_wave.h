@@ -77,6 +77,8 @@ KAS_DEV void sync() { rendezvous(K_SYNC); }
 KAS_DEV void lockstep() { rendezvous(K_LOCKSTEP); }
 KAS_DEV void wave_sync() { rendezvous(K_WAVESYNC); }
 KAS_DEV void spin_pause() {}
+template <int N> KAS_DEV void nap() {}
+template <int P> KAS_DEV void set_priority() {}
 KAS_DEV void repoll() { rendezvous(K_LOCKSTEP); }   // lets the other waves run
 
 KAS_DEV void publish(int32_t* flag, int32_t v) { *(volatile int32_t*)flag = v; }

@@ -89,7 +89,9 @@ def _expected_new(case):
 @pytest.mark.parametrize("case", [c for c in C1["cases"] if "fails" not in c], ids=lambda c: c["name"])
 def test_print_reassignment_matches_appendix_b(cli, tmp_path, case):
     all_brokers = set(range(9))
-    path, snap = _snapshot(tmp_path, all_brokers, {str(b): "abc"[b % 3] for b in all_brokers})
+    racks = {str(b): "abc"[b % 3] for b in range(6)}
+    racks.update({"6": "c", "7": "a", "8": "b"})             # extra brokers
+    path, snap = _snapshot(tmp_path, all_brokers, racks)
     args = ["--snapshot", path, "--mode", "PRINT_REASSIGNMENT",
             "--integer_broker_ids", ",".join(str(b) for b in case["brokers"])]
     if not case["racks"]:
