@@ -47,6 +47,8 @@ def main() -> int:
     ap.add_argument("--racks", type=int, default=20)
     ap.add_argument("--rf", type=int, default=3)
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--actions", default="", help="comma list overriding the per-scenario action mix "
+                    "(remove1,remove_k,add_k,mixed,replace1); default generator.BENCH_ACTIONS")
     ap.add_argument("--check", type=int, default=8, help="scenarios list-compared against the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget")
     ap.add_argument("--no-cpu", action="store_true")
@@ -84,9 +86,10 @@ def main() -> int:
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + 7919 * rank)
     d_cur = G.torch_random_assignment(gen, S, P, N, R, RF, dev)          # int32 [S, P, RF]
+    action_mix = tuple(a for a in args.actions.split(",") if a) or G.BENCH_ACTIONS
     actions, ids, racks = [], [], []
     for s in range(S):
-        act, bs = G.scenario_action(args.seed, first + s, N, R, actions=G.BENCH_ACTIONS)
+        act, bs = G.scenario_action(args.seed, first + s, N, R, actions=action_mix)
         actions.append(act); ids.append(bs.node_id); racks.append(bs.node_rack)
     fb = node_set_batch(ids, racks, P, RF, RF)
     ctx = native.DeviceContext(local_rank)
@@ -227,7 +230,7 @@ def main() -> int:
             "config": {
                 "workload": f"BASELINE.json configs[2]: batch of {S} independent scenarios per GPU, "
                             f"{P} partitions x {N} brokers x {R} racks, RF {RF}; per-scenario G(seed+s) "
-                            f"current assignment + action in {{remove1, remove<=5, add<=50, remove<=5+add<=50}}",
+                            f"current assignment + action in {{{', '.join(action_mix)}}} (remove <= 5, add <= 50)",
                 "scenarios_per_gpu": S, "partitions": P, "brokers": N, "racks": R, "rf": RF,
                 "ok_scenarios_rank0": ok, "failed_scenarios_rank0": S - ok,
                 "failed_note": "a failed scenario is the reference's own KAS:183-184 stranding, "
