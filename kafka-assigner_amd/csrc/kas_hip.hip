@@ -345,7 +345,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
-  a.flags = p->flags;
+  a.flags = p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL);
   const bool tickets = p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
   const int slot = p->timer_next;
   KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
@@ -409,7 +409,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
   const KasShape& sh = p->shape;
   if (nw != 0 && nw != p->NW) {
-    KasLds l = kas_fill_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch);
+    KasLds l = kas_fill_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch, sh.with_x);
     if (l.total > KAS_LDS_LIMIT)
       return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at that many waves");
     p->lds = l;

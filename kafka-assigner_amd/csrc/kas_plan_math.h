@@ -79,12 +79,13 @@ KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_
 // int32 counter row stride of the round form: 3-wide rows are padded to one 16-byte LDS read
 KAS_ABI_FN int32_t kas_cnt_stride(int32_t W) { return W == 3 ? 4 : W; }
 
+// with_x = 0: no histogram / quota table (only the general sticky fill is possible then)
 KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int32_t idmap_entries,
-                                         int32_t need_bsearch) {
+                                         int32_t need_bsearch, int32_t with_x) {
   KasLds L;
   int64_t n = n_max > 0 ? n_max : 1;
   int64_t o = 0;
-  const int64_t xr = W > NW ? W : NW;
+  const int64_t xr = with_x ? (W > NW ? W : NW) : 0;
   L.off_x = (int32_t)o;     o = kas_align16(o + 4 * n * xr);
   L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n);
   L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
@@ -129,6 +130,7 @@ struct KasShape {
   int32_t idmap_entries = 0;
   int32_t need_bsearch = 0;
   int32_t tickets_ok = 1;             // the ticket form of P5 is applicable to every scenario
+  int32_t with_x = 1;                 // LDS has room for the histogram / quota table of the fast fill
   std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
   int64_t accmask_words = 0;
   std::vector<int64_t> orph_off;      // per scenario, in int32 elements
@@ -229,9 +231,16 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // widest fill workgroup whose LDS carve-up fits: 4 wavefronts per scenario by default
   int err_total = 0;
   for (int nw = want_waves > 0 ? want_waves : 4; nw >= 1; nw >>= 1) {
-    KasLds l = kas_fill_lds_layout(s.n_max, s.Wc, nw, s.idmap_entries, s.need_bsearch);
+    KasLds l = kas_fill_lds_layout(s.n_max, s.Wc, nw, s.idmap_entries, s.need_bsearch, 1);
     err_total = l.total;
     if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = nw; err_total = 0; break; }
+  }
+  if (err_total) {
+    // many brokers x wide lists (BASELINE configs[4]: 5k brokers, RF 5): no room for the
+    // histogram, the general sticky fill needs none
+    KasLds l = kas_fill_lds_layout(s.n_max, s.Wc, 1, s.idmap_entries, s.need_bsearch, 0);
+    err_total = l.total;
+    if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = 1; s.with_x = 0; err_total = 0; }
   }
   if (err_total == 0 && kas_order_round_lds(s.n_max, s.Wc) > KAS_LDS_LIMIT)
     err_total = kas_order_round_lds(s.n_max, s.Wc);

@@ -838,7 +838,8 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
   const int tid = kasw::tid();
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
-  const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch);
+  const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch,
+                                         (a.flags & KAS_FLAG_GENERIC_FILL) ? 0 : 1);
   LdsView L;
   L.x = (int32_t*)(lds_raw + lay.off_x);
   L.load = (int32_t*)(lds_raw + lay.off_load);

@@ -162,7 +162,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data(); a.stats = nullptr;
   a.orph = orph.data(); a.orph_off = sh.orph_off.data();
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
-  a.need_bsearch = sh.need_bsearch; a.flags = flags & 0xffu;
+  a.need_bsearch = sh.need_bsearch; a.flags = (flags & 0xffu) | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL);
   auto bad = [&](const char* what, int32_t s) {
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;

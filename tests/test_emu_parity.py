@@ -93,3 +93,14 @@ def test_emu_sparse_broker_ids_use_binary_search():
     racks = (np.arange(20) % 5).astype(np.int32)[None, :]
     fb = uniform_batch(cur.astype(np.int32)[None], ids[:, :19], racks[:, :19], 3)
     assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu sparse")
+
+
+def test_emu_config5_broker_count_uses_general_fill_without_histogram_lds():
+    """BASELINE.json configs[4] shape: 5k brokers x 40 racks, RF 5, mixed remove + add.  The
+    histogram/quota table of the rack-diverse fill does not fit 160 KiB of LDS at this size, so
+    the plan falls back to the general sticky fill (and the round form of P5: lists are 5 wide)."""
+    P, N, R, RF = 3000, 5000, 40, 5
+    cur = G.random_assignment(7, P, N, R, RF)
+    bs = G.perturb_brokers(N, R, remove=list(range(0, N, 50)), add=200)
+    fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], RF)
+    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu C5 shape")

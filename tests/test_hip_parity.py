@@ -102,6 +102,18 @@ def test_config5_shape_rf5_rack_on_and_off_scaled():
         assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), f"C5 rack_aware={rack_aware}")
 
 
+def test_config5_full_broker_count_rf5():
+    """BASELINE.json configs[4] at its full broker count (5k brokers x 40 racks, RF 5, remove every
+    50th broker + add 200), 200k partitions: general sticky fill (no LDS for the histogram at this
+    size) + round form of P5, list-compared with the oracle, rack awareness on and off."""
+    P, N, R, RF = 200000, 5000, 40, 5
+    cur = G.random_assignment(7, P, N, R, RF)
+    for rack_aware in (True, False):
+        bs = G.perturb_brokers(N, R, remove=list(range(0, N, 50)), add=200, rack_aware=rack_aware)
+        fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], RF)
+        assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), f"C5 N=5100 rack_aware={rack_aware}")
+
+
 def test_device_resident_tables_and_what_if_shared_cur():
     """kas_solve_device with torch-owned HBM tables, and the what-if layout: many broker-set
     variants over ONE shared current assignment (SURVEY.md 8d, C4 'shared base cur')."""
