@@ -154,7 +154,7 @@ def main() -> int:
     kern_us = fill_us + order_us
     if args.stats and rank == 0:
         st = plan.stats().astype(np.float64)
-        names = ["setup_us", "p2_hist_quota_us", "p2_keep_p3_p4_us", "tickets_us", "p4_windows", "p4_steps",
+        names = ["setup_us", "p2_hist_quota_us", "p2_keep_p3_us", "p4_us", "p4_windows", "p4_steps",
                  "p5_rounds", "p2_ranked_tiles_wave0", "order_us", "solver_iterations", "solver_starved",
                  "solver_blocked", "feeder_iterations", "feeder_idle"]
         scale = [0.01, 0.01, 0.01, 0.01, 1, 1, 1, 1, 0.01, 1, 1, 1, 1, 1]

@@ -216,8 +216,7 @@ int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
 int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, int* launches);
 
 /* Per-scenario device counters of the plan's most recent solve (after it completed):
- * out[s*16 + 0..3] = time spent in setup / P2 histogram+quota / P2 keep-scan+P3+P4 / P5 preference
- * order, in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
+ * out[s*16 + 0..3] = time spent in setup / P2 histogram+quota / P2 keep-scan+P3 / P4 first fit, in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
  * [6] P5 rounds (round form), [7] P2 tiles of wave 0 that needed quota ranking, [8] order kernel
  * time (ticks), and for the ticket form [9] solver iterations, [10] of those with no row loaded in
  * any lane, [11] with rows but none ready, [12] feeder iterations, [13] of those without work.  n = capacity of out in

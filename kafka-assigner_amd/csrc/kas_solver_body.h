@@ -224,26 +224,40 @@ struct TopicView {
   int32_t P, cw, rf, ow, hash, nt, N, cap;
 };
 
-// current replica list of row p (ids beyond cur_width read as -1; validity comes from len)
+// current replica list of row p (ids beyond cur_width read as -1; validity comes from len).
+// FULL: every list of the topic is exactly W wide (cur_width == W, no cur_len array) — the whole
+// row is one W-dword load and needs no per-cell tests; rows past the end re-read the last row
+// with len = 0.
 template <int W>
+struct RowW { int32_t v[W]; };
+
+template <int W, bool FULL = false>
 KAS_DEV void load_row(const TopicView& T, int32_t p, int32_t (&ids)[W], int32_t& len) {
   const bool active = p < T.P;
+  if constexpr (FULL) {
+    const int32_t pc = active ? p : (T.P > 0 ? T.P - 1 : 0);
+    const RowW<W> q = *reinterpret_cast<const RowW<W>*>(T.cur + (int64_t)pc * W);
 #pragma unroll
-  for (int r = 0; r < W; ++r) ids[r] = (active && r < T.cw) ? T.cur[(int64_t)p * T.cw + r] : -1;
-  len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
+    for (int r = 0; r < W; ++r) ids[r] = q.v[r];
+    len = active ? W : 0;
+  } else {
+#pragma unroll
+    for (int r = 0; r < W; ++r) ids[r] = (active && r < T.cw) ? T.cur[(int64_t)p * T.cw + r] : -1;
+    len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
+  }
 }
 
 // Stream the tiles tile0, tile0 + stride, ... (< t_end) of the cur table through `body(tile, ids,
 // len)` with KAS_TILES_AHEAD tiles of rows in flight per lane: the scans are HBM-latency-bound
 // (12 bytes per lane per tile), so several tiles are requested before the first is consumed.
 #define KAS_TILES_AHEAD 4
-template <int W, typename Body>
-KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
+template <int W, bool FULL, typename Body>
+KAS_DEV void for_tiles_impl(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
   constexpr int D = KAS_TILES_AHEAD;
   const int lane = kasw::lane();
   int32_t nx[D][W], nlen[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) load_row<W>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
+  for (int d = 0; d < D; ++d) load_row<W, FULL>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
   for (int32_t tile = tile0; tile < t_end; tile += stride * D) {
     int32_t ids[D][W], len[D];
 #pragma unroll
@@ -254,13 +268,54 @@ KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_
     }
 #pragma unroll
     for (int d = 0; d < D; ++d)                              // request the next batch
-      load_row<W>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
+      load_row<W, FULL>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int32_t t = tile + d * stride;
       if (t < t_end) body(t, ids[d], len[d]);                // wave-uniform
     }
   }
+}
+
+// Same stream, but `body(ids[D][W], len[D])` gets KAS_TILES_AHEAD tiles at once (len = 0 for
+// rows / tiles past the end): for passes whose tiles do not depend on each other, so that the
+// LDS lookups of the four tiles overlap instead of forming four serial chains.
+template <int W, bool FULL, typename Body>
+KAS_DEV void for_tile_batches_impl(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
+  constexpr int D = KAS_TILES_AHEAD;
+  const int lane = kasw::lane();
+  int32_t nx[D][W], nlen[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_row<W, FULL>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
+  for (int32_t tile = tile0; tile < t_end; tile += stride * D) {
+    int32_t ids[D][W], len[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int r = 0; r < W; ++r) ids[d][r] = nx[d][r];
+      len[d] = (tile + d * stride < t_end) ? nlen[d] : 0;
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      load_row<W, FULL>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
+    body(ids, len);
+  }
+}
+
+// is every current list of the topic exactly W wide (and every out row too)?
+template <int W>
+KAS_DEV bool full_rows(const TopicView& T) { return T.cw == W && T.ow == W && T.len_arr == nullptr; }
+
+template <int W, typename Body>
+KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
+  if (full_rows<W>(T)) for_tiles_impl<W, true>(T, tile0, stride, t_end, body);
+  else for_tiles_impl<W, false>(T, tile0, stride, t_end, body);
+}
+
+template <int W, typename Body>
+KAS_DEV void for_tile_batches(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
+  if (full_rows<W>(T)) for_tile_batches_impl<W, true>(T, tile0, stride, t_end, body);
+  else for_tile_batches_impl<W, false>(T, tile0, stride, t_end, body);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,8 +346,15 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
     hc += acc ? 1 : 0;
   }
   if (active) {
+    if (T.ow == W) {                                        // wave-uniform: one W-dword store
+      RowW<W> q;
 #pragma unroll
-    for (int k = 0; k < W; ++k) if (k < T.ow) T.out[(int64_t)p * T.ow + k] = hold[k];
+      for (int k = 0; k < W; ++k) q.v[k] = hold[k];
+      *reinterpret_cast<RowW<W>*>(T.out + (int64_t)p * W) = q;
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (k < T.ow) T.out[(int64_t)p * T.ow + k] = hold[k];
+    }
   }
   const bool in_parts = active && (T.inp_arr ? T.inp_arr[p] != 0 : true);
   need = in_parts ? (T.rf - hc > 0 ? T.rf - hc : 0) : 0;   // KAS:151-157
@@ -454,21 +516,29 @@ KAS_DEV int32_t p3p4_generic(const LdsView& L, const TopicView& T, const NodeMap
 // A1: tiles wave, wave+NW, ... ; returns this lane's "not rack-diverse" verdict
 template <int W, int NW>
 KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
+  constexpr int D = KAS_TILES_AHEAD;
   const int32_t N = T.N;
   bool viol = false;
-  for_tiles<W>(T, wave, NW, T.nt, [&](int32_t, const int32_t (&ids)[W], int32_t len) {
-    int32_t idx[W], rk[W];
+  for_tile_batches<W>(T, wave, NW, T.nt, [&](const int32_t (&ids)[D][W], const int32_t (&len)[D]) {
+    int32_t idx[D][W], rk[D][W];
 #pragma unroll
-    for (int r = 0; r < W; ++r) {
-      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
-      rk[r] = idx[r] >= 0 ? (int32_t)L.rack[idx[r]] : -1 - r;   // invalid: never equal
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup(L, nm, ids[d][r]) : -1;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < W; ++r)
+        rk[d][r] = idx[d][r] >= 0 ? (int32_t)L.rack[idx[d][r]] : -1 - r;   // invalid: never equal
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int r = 1; r < W; ++r)
+#pragma unroll
+        for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[d][r] == rk[d][r2];
+#pragma unroll
+      for (int r = 0; r < W; ++r) if (idx[d][r] >= 0) kasw::lds_atomic_add(&L.x[r * N + idx[d][r]], 1);
     }
-#pragma unroll
-    for (int r = 1; r < W; ++r)
-#pragma unroll
-      for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[r] == rk[r2];
-#pragma unroll
-    for (int r = 0; r < W; ++r) if (idx[r] >= 0) kasw::lds_atomic_add(&L.x[r * N + idx[r]], 1);
   });
   return viol;
 }
@@ -499,15 +569,25 @@ KAS_DEV void fill_quota(const LdsView& L, const TopicView& T, int32_t tid) {
 // A2: wave w counts the sweep-r* candidates of chunk w per node
 template <int W, int NW>
 KAS_DEV void fill_chunk_count(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
+  constexpr int D = KAS_TILES_AHEAD;
   const int32_t N = T.N;
   const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
   int32_t* qc = L.x + wave * N;
-  for_tiles<W>(T, t0, 1, t1, [&](int32_t, const int32_t (&ids)[W], int32_t len) {
+  for_tile_batches<W>(T, t0, 1, t1, [&](const int32_t (&ids)[D][W], const int32_t (&len)[D]) {
+    int32_t idx[D][W], rs[D][W];
 #pragma unroll
-    for (int r = 0; r < W; ++r) {
-      const int32_t i = r < len ? node_lookup(L, nm, ids[r]) : -1;
-      if (i >= 0 && (int32_t)((uint32_t)L.qrs[i] >> 28) == r) kasw::lds_atomic_add(&qc[i], 1);
-    }
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup(L, nm, ids[d][r]) : -1;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < W; ++r)
+        rs[d][r] = idx[d][r] >= 0 ? (int32_t)((uint32_t)L.qrs[idx[d][r]] >> 28) : -1;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < W; ++r) if (rs[d][r] == r) kasw::lds_atomic_add(&qc[idx[d][r]], 1);
   });
 }
 
@@ -596,17 +676,18 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
   return ocount;
 }
 
-// P4 over the chunk lists, in chunk order == ascending row order.  One wave.
+// P4 over the chunk lists, in chunk order == ascending row order.  One wave.  The orphan row
+// indices are fetched two windows ahead and their out rows one window ahead (HBM latency would
+// otherwise sit between every two windows; a row is listed once, so nothing P4 writes is read
+// early).
 template <int W, int NW>
 KAS_DEV int32_t p4_lists(const LdsView& L, const TopicView& T, int32_t live_count, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   int32_t oc[NW], total = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) { oc[w] = L.ctl[KAS_CTL_OC + w]; total += oc[w]; }
-  int32_t head = 0;
-  for (int32_t g0 = 0; g0 < total; g0 += 64) {
-    const int32_t g = g0 + lane;
-    const bool mine = g < total;
+  // row index of the g-th orphan of the topic (chunk lists concatenated), or -1 past the end
+  auto orphan_row = [&](int32_t g) -> int32_t {
     int32_t w = 0, base = 0;
 #pragma unroll
     for (int k = 0; k < NW - 1; ++k) {
@@ -614,26 +695,36 @@ KAS_DEV int32_t p4_lists(const LdsView& L, const TopicView& T, int32_t live_coun
       base += next ? oc[k] : 0;
       w += next ? 1 : 0;
     }
-    int32_t p = 0, hc = 0, hr[W];
+    return g < total ? T.orph[((int64_t)chunk_begin<NW>(T.nt, w) << 6) + (g - base)] : -1;
+  };
+  auto row_cells = [&](int32_t p, int32_t (&c)[W]) {
 #pragma unroll
-    for (int k = 0; k < W; ++k) hr[k] = -1;
-    if (mine) {
-      p = T.orph[((int64_t)chunk_begin<NW>(T.nt, w) << 6) + (g - base)];
+    for (int k = 0; k < W; ++k) c[k] = (p >= 0 && k < T.ow) ? T.out[(int64_t)p * T.ow + k] : -1;
+  };
+  int32_t head = 0;
+  int32_t p_cur = orphan_row(lane), p_nxt = orphan_row(64 + lane);
+  int32_t c_cur[W], c_nxt[W];
+  row_cells(p_cur, c_cur);
+  for (int32_t g0 = 0; g0 < total; g0 += 64) {
+    row_cells(p_nxt, c_nxt);                                // next window's rows
+    const int32_t p_nn = orphan_row(g0 + 128 + lane);       // the window after that
+    if (p_cur >= 0) {
+      int32_t hc = 0;
+      L.ring_p[lane] = p_cur;
 #pragma unroll
-      for (int k = 0; k < W; ++k) {
-        const int32_t c = k < T.ow ? T.out[(int64_t)p * T.ow + k] : -1;   // holders are a prefix
-        hr[k] = c >= 0 ? (int32_t)L.rack[c] : -1;
-        hc += c >= 0 ? 1 : 0;
+      for (int k = 0; k < W; ++k) {                         // holders are a prefix of the row
+        L.ring_rack[k * KAS_RING_CAP + lane] = (int16_t)(c_cur[k] >= 0 ? (int32_t)L.rack[c_cur[k]] : -1);
+        hc += c_cur[k] >= 0 ? 1 : 0;
       }
-      L.ring_p[lane] = p;
       L.ring_meta[lane] = (T.rf - hc) | (hc << 8);
-#pragma unroll
-      for (int k = 0; k < W; ++k) L.ring_rack[k * KAS_RING_CAP + lane] = (int16_t)hr[k];
     }
     kasw::lockstep();
     const int32_t n_win = total - g0 < 64 ? total - g0 : 64;
     const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.out, T.ow, st);
     if (fl >= 0) return L.ring_p[fl];
+    p_cur = p_nxt; p_nxt = p_nn;
+#pragma unroll
+    for (int k = 0; k < W; ++k) c_cur[k] = c_nxt[k];
   }
   return -1;
 }
@@ -783,6 +874,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
   }
   kasw::sync();
+  { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
 
   // ---- KAS:168: getNodeProcessingOrder(topic, all nodes); runs even with zero orphans -------
   const int32_t idxN = java_abs_mod(hash, N);
@@ -813,7 +905,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     }
   }
   kasw::sync();   // out rows of P3/P4 are visible to every wave; load/qrs are dead from here
-  { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
+  { const int64_t now = kasw::clock_ticks(); st[3] += now - tmark; tmark = now; }
   {
     const int32_t fail_row = L.ctl[KAS_CTL_FAILROW];
     if (fail_row >= 0) {                                       // KAS:183-184
