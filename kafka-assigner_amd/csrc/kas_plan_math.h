@@ -100,8 +100,8 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
 }
 
 // ticket form of order: per lane group (= scenario) uint64 counter rows [n_max + 1] (4 x uint16:
-// count[node][0..2] + commits; + the padding holder's row), int32 broker id per node [n_max],
-// uint32 lane mask per node [n_max], uint16 tickets handed out per node [n_max]; a ring of
+// count[node][0..2] + commits; + the padding holder's row), uint32 lane mask per node [n_max],
+// uint16 tickets handed out per node [n_max]; a ring of
 // KAS_RING_SLOTS 16-byte row slots per lane; one digest slot per group
 #ifndef KAS_RING_SLOTS
 #define KAS_RING_SLOTS 4
@@ -109,7 +109,7 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
 KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G) {
   int64_t n = n_max > 0 ? n_max : 1;
   (void)G;
-  return kas_align16(8 * (n + 1) + 4 * n + 4 * n + 2 * n);
+  return kas_align16(8 * (n + 1) + 4 * n + 2 * n);
 }
 KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G) {
   return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G);

@@ -1132,8 +1132,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G);    // LDS byte offset of this group's region
   uint64_t* cnt = (uint64_t*)(lds_raw + cnt_base);          // [nmax + 1]: + the padding holder's row
-  int32_t* nid = (int32_t*)(lds_raw + cnt_base + 8 * (nmax + 1));   // broker id per node index
-  uint32_t* dep = (uint32_t*)(nid + nmax);                  // lane mask per node (ticket pass)
+  uint32_t* dep = (uint32_t*)(lds_raw + cnt_base + 8 * (nmax + 1));   // lane mask per node (ticket pass)
   uint16_t* run = (uint16_t*)(dep + nmax);                  // tickets handed out per node so far
   const int32_t dummy_addr = cnt_base + nmax * 8;
   RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G));
@@ -1145,7 +1144,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int32_t N = sd.n_nodes;
   const int32_t* g_node_id = a.node_id + sd.node_off;
   for (int32_t n = li + GL * wave; n < N; n += 3 * GL) {
-    cnt[n] = 0ull; run[n] = 0; dep[n] = 0u; nid[n] = g_node_id[n];
+    cnt[n] = 0ull; run[n] = 0; dep[n] = 0u;
   }
   if (wave == 0 && li == 0) { cnt[nmax] = KAS_DUMMY_COUNTS; gdig[g] = 0ull; }
   for (int32_t k = wave; k < K; k += 3) ring[k * 64 + lane].tag = KAS_TAG_FREE;
@@ -1362,7 +1361,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
               if (r < Lp) {
                 const int32_t e = w[r] == 0 ? sl.c[0] : (w[r] == 1 ? sl.c[1] : sl.c[2]);
                 const int32_t node = ((e & 0xffff) - cnt_base) >> 3;
-                const int32_t id = nid[node];
+                const int32_t id = g_node_id[node];       // 4 KB table per scenario: L2-resident
                 row[r] = id;
                 digest += kas_digest_cell((uint32_t)itr.k, (uint32_t)p, (uint32_t)r, id);
               }
