@@ -104,3 +104,29 @@ def test_emu_config5_broker_count_uses_general_fill_without_histogram_lds():
     bs = G.perturb_brokers(N, R, remove=list(range(0, N, 50)), add=200)
     fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], RF)
     assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu C5 shape")
+
+
+def _multi_topic_scenarios(seed, n_scen, n_topics, P, N, R, RF):
+    """Scenarios of several topics sharing one Context that is NOT handed in or out: the shape of one
+    PRINT_REASSIGNMENT run (KAG:172-184) — and the ticket form's cross-topic case (a topic's
+    tickets start where the previous topic's left off)."""
+    scs = []
+    for s in range(n_scen):
+        act, bs = G.scenario_action(seed, s, N, R, actions=G.BENCH_ACTIONS, max_add=max(2, N // 10))
+        racks = {int(b): "r%d" % int(r) for b, r in zip(bs.node_id, bs.node_rack)}
+        topics = []
+        for t in range(n_topics):
+            cur = G.random_assignment(seed + 31 * s + t, P + 17 * t, N, R, RF)
+            topics.append(Topic("topic-%d" % t, {p: cur[p].tolist() for p in range(cur.shape[0])}, RF))
+        scs.append(Scenario(brokers=[int(b) for b in bs.node_id], racks=racks, topics=topics))
+    return flatten(scs)
+
+
+def test_emu_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
+    fb = _multi_topic_scenarios(77, 3, 3, 700, 40, 8, 3)
+    assert (fb.scen["ctx_off"] < 0).all() and (fb.scen["topic_count"] == 3).all()
+    want = oracle_solve(fb)
+    assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 4      # and some that fail or are skipped
+    assert_same_outputs(fb, want, emu_solve(fb), "emu multi-topic tickets")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu multi-topic rounds")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 12) | (2 << 8)), "emu multi-topic, 2 scenarios per wave")

@@ -10,7 +10,7 @@ from kafka_assigner_amd import generator as G
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
-from test_emu_parity import _batch
+from test_emu_parity import _batch, _multi_topic_scenarios
 from test_oracle_vs_literal import scenarios
 
 pytestmark = pytest.mark.gpu
@@ -100,6 +100,17 @@ def test_config5_shape_rf5_rack_on_and_off_scaled():
         bs = G.perturb_brokers(N, R, remove=list(range(0, N, 50)), add=40, rack_aware=rack_aware)
         fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], RF)
         assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), f"C5 rack_aware={rack_aware}")
+
+
+def test_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
+    """Three topics per scenario sharing one Context that is neither handed in nor out (one
+    PRINT_REASSIGNMENT run, KAG:172-184): the ticket form carries the tickets across topics."""
+    fb = _multi_topic_scenarios(77, 6, 3, 5000, 120, 12, 3)
+    want = oracle_solve(fb)
+    assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 6
+    assert_same_outputs(fb, want, native.solve_host(fb), "hip multi-topic tickets")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip multi-topic rounds")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2 << 12), "hip multi-topic, 2 scenarios per wave")
 
 
 def test_config5_full_broker_count_rf5():
