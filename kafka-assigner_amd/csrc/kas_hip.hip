@@ -36,10 +36,10 @@ __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(K
     kas::fill_scenario<W, NW>(a, s, kas_lds);
 }
 
-template <int W, int G>
+template <int W, int G, bool PK>
 __global__ __launch_bounds__(192) void kas_order_ticket_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_tickets<W, G>(a, (int32_t)blockIdx.x * G, kas_lds);
+  kas::order_tickets<W, G, PK>(a, (int32_t)blockIdx.x * G, kas_lds);
 }
 
 template <int W>
@@ -67,18 +67,18 @@ static kas_kernel_fn kas_fill_for(int Wc, int NW) {
     default: return kas_fill_for_w<4>(Wc);
   }
 }
-template <int G>
+template <int G, bool PK>
 static kas_kernel_fn kas_order_ticket_for_g(int Wc) {
   switch (Wc) {
-    case 2: return kas_order_ticket_kernel<2, G>;
-    default: return kas_order_ticket_kernel<3, G>;
+    case 2: return kas_order_ticket_kernel<2, G, PK>;
+    default: return kas_order_ticket_kernel<3, G, PK>;
   }
 }
-static kas_kernel_fn kas_order_ticket_for(int Wc, int G) {
+static kas_kernel_fn kas_order_ticket_for(int Wc, int G, int packed) {
   switch (G) {
-    case 1: return kas_order_ticket_for_g<1>(Wc);
-    case 2: return kas_order_ticket_for_g<2>(Wc);
-    default: return kas_order_ticket_for_g<4>(Wc);
+    case 1: return packed ? kas_order_ticket_for_g<1, true>(Wc) : kas_order_ticket_for_g<1, false>(Wc);
+    case 2: return packed ? kas_order_ticket_for_g<2, true>(Wc) : kas_order_ticket_for_g<2, false>(Wc);
+    default: return packed ? kas_order_ticket_for_g<4, true>(Wc) : kas_order_ticket_for_g<4, false>(Wc);
   }
 }
 static kas_kernel_fn kas_order_round_for(int Wc) {
@@ -245,9 +245,10 @@ static int kas_plan_set_kernels(kas_plan* p) {
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, p->lds.total));
   if (p->Wc <= 3)
-    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kas_order_ticket_lds(p->shape.n_max, p->G)));
+    for (int pk = 0; pk < 2; ++pk)
+      KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kas_order_ticket_lds(p->shape.n_max, p->G, pk)));
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kas_order_round_lds(p->shape.n_max, p->Wc)));
@@ -353,9 +354,10 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
                      (size_t)p->lds.total, st, a);
   KAS_HIP_TRY(hipGetLastError());
   KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
+  const int packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
   if (tickets)
-    hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G), dim3((unsigned)((p->n_scenarios + p->G - 1) / p->G)),
-                       dim3(192), (size_t)kas_order_ticket_lds(p->shape.n_max, p->G), st, a);
+    hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3((unsigned)((p->n_scenarios + p->G - 1) / p->G)),
+                       dim3(192), (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, packed), st, a);
   else
     hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
                        (size_t)kas_order_round_lds(p->shape.n_max, p->Wc), st, a);
@@ -416,8 +418,8 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     p->NW = nw;
   }
   if (g != 0 && g != p->G) {
-    if (kas_order_ticket_lds(sh.n_max, g) > KAS_LDS_LIMIT ||
-        (int64_t)g * kas_order_ticket_group_bytes(sh.n_max, g) > 65536)
+    if (kas_order_ticket_lds(sh.n_max, g, 0) > KAS_LDS_LIMIT ||
+        (int64_t)g * kas_order_ticket_group_bytes(sh.n_max, g, 0) > 65536)
       return set_error(KAS_E_UNSUPPORTED, "LDS of the order kernel exceeds 160 KiB at that many groups");
     p->G = g;
   }

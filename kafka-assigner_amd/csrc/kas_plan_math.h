@@ -41,6 +41,7 @@ struct KasLaunch {
 
 #define KAS_FLAG_GENERIC_FILL 1u   // always use the general sticky fill (testing / comparison)
 #define KAS_FLAG_ROUND_ORDER  2u   // always use the tile-round preference ordering (testing / comparison)
+#define KAS_FLAG_WIDE_COUNTERS 4u  // ticket form: always 4 x uint16 counter rows (testing / comparison)
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
@@ -99,20 +100,22 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
   return L;
 }
 
-// ticket form of order: per lane group (= scenario) uint64 counter rows [n_max + 1] (4 x uint16:
-// count[node][0..2] + commits; + the padding holder's row), uint32 lane mask per node [n_max],
-// uint16 tickets handed out per node [n_max]; a ring of
-// KAS_RING_SLOTS 16-byte row slots per lane; one digest slot per group
+// ticket form of order: per lane group (= scenario) one counter row per node + the padding
+// holder's row (uint64 = 4 x uint16: count[node][0..2] + commits; or, packed, uint32 = three 10-bit
+// counts when no node ever holds 1023 rows of the scenario), uint32 lane mask per node [n_max],
+// uint16 tickets handed out per node [n_max]; a ring of KAS_RING_SLOTS 16-byte row slots per
+// lane; one digest slot per group
 #ifndef KAS_RING_SLOTS
 #define KAS_RING_SLOTS 4
 #endif
-KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G) {
+#define KAS_PACKED_TICKET_LIMIT 1023
+KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G, int32_t packed) {
   int64_t n = n_max > 0 ? n_max : 1;
   (void)G;
-  return kas_align16(8 * (n + 1) + 4 * n + 2 * n);
+  return kas_align16(kas_align16((packed ? 4 : 8) * (n + 1)) + 4 * n + 2 * n);
 }
-KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G) {
-  return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G);
+KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed) {
+  return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G, packed) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G);
 }
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {
@@ -131,6 +134,7 @@ struct KasShape {
   int32_t need_bsearch = 0;
   int32_t tickets_ok = 1;             // the ticket form of P5 is applicable to every scenario
   int32_t with_x = 1;                 // LDS has room for the histogram / quota table of the fast fill
+  int32_t packed_ok = 1;              // every scenario's ticket bound fits 10-bit counter fields
   std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
   int64_t accmask_words = 0;
   std::vector<int64_t> orph_off;      // per scenario, in int32 elements
@@ -220,6 +224,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (td.name_hash == (int32_t)0x80000000) s.tickets_ok = 0;   // KAS:190 index error: round form
     }
     if (ticket_bound >= KAS_TICKET_LIMIT) s.tickets_ok = 0;
+    if (ticket_bound >= KAS_PACKED_TICKET_LIMIT) s.packed_ok = 0;
     s.accmask_off[(size_t)i] = s.accmask_words;
     s.accmask_words += words > 0 ? words : 1;
     s.orph_off[(size_t)i] = s.orph_ints;
@@ -250,8 +255,8 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
                 " B of LDS (limit 163840)");
   // counter rows are addressed with 16-bit LDS byte offsets
   s.G = want_groups > 0 ? want_groups : 1;
-  while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G) > 65536) s.G >>= 1;
-  if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G) > 65536) s.tickets_ok = 0;
+  while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.G >>= 1;
+  if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.tickets_ok = 0;
   *sh = s;
   return KAS_E_OK;
 }

@@ -1088,10 +1088,11 @@ KAS_DEV bool tile_next(TileIter& it, const KasLaunch& a, const kas_scenario_desc
 // possible first pick w0, say which of the two remaining stored positions the SECOND pick visits
 // first.  Returns the tag bits 26..30; stored[t] = ticket << 16 | LDS byte address of the row.
 KAS_DEV int32_t stage_row(const int32_t (&h)[3], const int32_t (&tk)[3], int32_t Lp, int32_t idx2,
-                          int32_t idx3, int32_t cnt_base, int32_t dummy_addr, int32_t (&stored)[3]) {
+                          int32_t idx3, int32_t cnt_base, int32_t row_bytes, int32_t dummy_enc,
+                          int32_t (&stored)[3]) {
   int32_t enc[3];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) enc[q] = q < Lp ? ((tk[q] << 16) | (cnt_base + h[q] * 8)) : dummy_addr;
+  for (int q = 0; q < 3; ++q) enc[q] = q < Lp ? ((tk[q] << 16) | (cnt_base + h[q] * row_bytes)) : dummy_enc;
   // rank visited at position t of a set of m: (t + m - idx_m) % m
   const int32_t m = Lp;
   const int32_t idx = m == 3 ? idx3 : (m == 2 ? idx2 : 0);
@@ -1118,9 +1119,12 @@ KAS_DEV int32_t stage_row(const int32_t (&h)[3], const int32_t (&tk)[3], int32_t
   return (bits << 26) | (Lp << 29);
 }
 
-template <int W, int G>
+// PK: counter rows are one uint32 of three 10-bit counts (commits on the node = their sum) instead
+// of 4 x uint16 — half the LDS, for scenarios whose per-node row count stays below 1023.
+template <int W, int G, bool PK>
 KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned char* lds_raw) {
   static_assert(W <= 3, "ring slots and packed counter rows hold lists up to 3 wide");
+  constexpr int RB = PK ? 4 : 8;                            // bytes per counter row
   constexpr int GL = 64 / G;
   constexpr int HALVES = GL > 32 ? 2 : 1;                   // ticket pass: 32 rows per lane mask
   constexpr int K = KAS_RING_SLOTS;
@@ -1130,12 +1134,13 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int32_t s = first_scenario + g;
   const bool have_s = s < a.n_scenarios;
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
-  const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G);    // LDS byte offset of this group's region
-  uint64_t* cnt = (uint64_t*)(lds_raw + cnt_base);          // [nmax + 1]: + the padding holder's row
-  uint32_t* dep = (uint32_t*)(lds_raw + cnt_base + 8 * (nmax + 1));   // lane mask per node (ticket pass)
+  const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G, PK);   // LDS byte offset of this group's region
+  unsigned char* cnt = lds_raw + cnt_base;                  // [nmax + 1] rows: + the padding holder's row
+  uint32_t* dep = (uint32_t*)(lds_raw + cnt_base + kas_align16(RB * (int64_t)(nmax + 1)));   // lane mask per node (ticket pass)
   uint16_t* run = (uint16_t*)(dep + nmax);                  // tickets handed out per node so far
-  const int32_t dummy_addr = cnt_base + nmax * 8;
-  RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G));
+  // padding holder: counts that never win a pick, and a ticket that always matches its commits
+  const int32_t dummy_addr = PK ? ((3 * 0x3ff) << 16) | (cnt_base + nmax * RB) : (cnt_base + nmax * RB);
+  RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G, PK));
   uint64_t* gdig = (uint64_t*)(ring + K * 64);
 
   kas_scenario_desc sd;
@@ -1144,9 +1149,13 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int32_t N = sd.n_nodes;
   const int32_t* g_node_id = a.node_id + sd.node_off;
   for (int32_t n = li + GL * wave; n < N; n += 3 * GL) {
-    cnt[n] = 0ull; run[n] = 0; dep[n] = 0u;
+    if (PK) ((uint32_t*)cnt)[n] = 0u; else ((uint64_t*)cnt)[n] = 0ull;
+    run[n] = 0; dep[n] = 0u;
   }
-  if (wave == 0 && li == 0) { cnt[nmax] = KAS_DUMMY_COUNTS; gdig[g] = 0ull; }
+  if (wave == 0 && li == 0) {
+    if (PK) ((uint32_t*)cnt)[nmax] = 0x3fffffffu; else ((uint64_t*)cnt)[nmax] = KAS_DUMMY_COUNTS;
+    gdig[g] = 0ull;
+  }
   for (int32_t k = wave; k < K; k += 3) ring[k * 64 + lane].tag = KAS_TAG_FREE;
   kasw::sync();
 
@@ -1168,21 +1177,33 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       // one LDS round trip per iteration: the look-ahead slot and the three counter rows
       const int32_t jn = j + (cv ? 1 : 0);
       const RingSlot sl = ring[(jn & (K - 1)) * 64 + lane];
-      const uint64_t x0 = *(const uint64_t*)(lds_raw + (e0 & 0xffff));
-      const uint64_t x1 = *(const uint64_t*)(lds_raw + (e1 & 0xffff));
-      const uint64_t x2 = *(const uint64_t*)(lds_raw + (e2 & 0xffff));
+      uint32_t f0[3], f1[3], com[3];                        // count[.][0], count[.][1], commits per holder
+      const int32_t es[3] = {e0, e1, e2};
+      if constexpr (PK) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const uint32_t x = *(const uint32_t*)(lds_raw + (es[q] & 0xffff));
+          f0[q] = x & 0x3ffu; f1[q] = (x >> 10) & 0x3ffu;
+          com[q] = f0[q] + f1[q] + ((x >> 20) & 0x3ffu);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const uint64_t x = *(const uint64_t*)(lds_raw + (es[q] & 0xffff));
+          f0[q] = (uint32_t)x & 0xffffu; f1[q] = (uint32_t)x >> 16;
+          com[q] = (uint32_t)(x >> 48);
+        }
+      }
       if (!nv && !fin) {
         if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
         else if (sl.tag == KAS_TAG_END && !cv) fin = true;
       }
       // commits on the node == my ticket: every earlier row holding it has committed
-      const bool ready = cv && (((uint32_t)(x0 >> 32) ^ (uint32_t)e0) >> 16) == 0u &&
-                         (((uint32_t)(x1 >> 32) ^ (uint32_t)e1) >> 16) == 0u &&
-                         (((uint32_t)(x2 >> 32) ^ (uint32_t)e2) >> 16) == 0u;
+      const bool ready = cv && com[0] == ((uint32_t)e0 >> 16) && com[1] == ((uint32_t)e1 >> 16) &&
+                         com[2] == ((uint32_t)e2 >> 16);
       // first pick: count[.][0], holders in visit order, first strictly smaller wins == the
       // minimum of (count, stored position)
-      const uint32_t k0 = (((uint32_t)x0 & 0xffffu) << 2), k1 = (((uint32_t)x1 & 0xffffu) << 2) | 1u,
-                     k2 = (((uint32_t)x2 & 0xffffu) << 2) | 2u;
+      const uint32_t k0 = f0[0] << 2, k1 = (f0[1] << 2) | 1u, k2 = (f0[2] << 2) | 2u;
       const uint32_t kmin = k0 < k1 ? (k0 < k2 ? k0 : k2) : (k1 < k2 ? k1 : k2);
       const int32_t w0 = (int32_t)(kmin & 3u);
       // second pick: count[.][1] of the two remaining stored positions; the one visited first
@@ -1190,7 +1211,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const uint32_t vis = (uint32_t)meta >> w0;            // bit 0: the higher remaining position is visited first
       const uint32_t hi_first = vis & 1u;
       const uint32_t lo_pos = w0 == 0 ? 1u : 0u, hi_pos = w0 == 2 ? 1u : 2u;
-      const uint32_t c1_0 = (uint32_t)x0 >> 16, c1_1 = (uint32_t)x1 >> 16, c1_2 = (uint32_t)x2 >> 16;
+      const uint32_t c1_0 = f1[0], c1_1 = f1[1], c1_2 = f1[2];
       const uint32_t c_lo = w0 == 0 ? c1_1 : c1_0, c_hi = w0 == 2 ? c1_1 : c1_2;
       const uint32_t key_lo = (c_lo << 3) | (hi_first << 2) | lo_pos;
       const uint32_t key_hi = (c_hi << 3) | ((hi_first ^ 1u) << 2) | hi_pos;
@@ -1203,9 +1224,15 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         const int32_t ad2 = (w2 == 0 ? e0 : (w2 == 1 ? e1 : e2)) & 0xffff;
         // updateCountersFromList (KAS:254-261): count[node][r] += 1, commits += 1
         // (padding holders get + 0: their row must keep commits == 0)
-        kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad0), Lp > 0 ? 1ull + (1ull << 48) : 0ull);
-        kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad1), Lp > 1 ? (1ull << 16) + (1ull << 48) : 0ull);
-        kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad2), Lp > 2 ? (1ull << 32) + (1ull << 48) : 0ull);
+        if constexpr (PK) {
+          kasw::lds_atomic_add((int*)(lds_raw + ad0), Lp > 0 ? 1 : 0);
+          kasw::lds_atomic_add((int*)(lds_raw + ad1), Lp > 1 ? (1 << 10) : 0);
+          kasw::lds_atomic_add((int*)(lds_raw + ad2), Lp > 2 ? (1 << 20) : 0);
+        } else {
+          kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad0), Lp > 0 ? 1ull + (1ull << 48) : 0ull);
+          kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad1), Lp > 1 ? (1ull << 16) + (1ull << 48) : 0ull);
+          kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad2), Lp > 2 ? (1ull << 32) + (1ull << 48) : 0ull);
+        }
         ring[(j & (K - 1)) * 64 + lane].tag = KAS_TAG_DONE | w0 | (w1 << 2) | (Lp << 4);
         j += 1;
         cv = false;
@@ -1317,7 +1344,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         if (staging_end) {
           o.tag = KAS_TAG_END;
         } else if (holds) {
-          o.tag = (jl & KAS_TAG_JMASK) | stage_row(hn, tk, Lp, st_idx2, st_idx3, cnt_base, dummy_addr, o.c);
+          o.tag = (jl & KAS_TAG_JMASK) | stage_row(hn, tk, Lp, st_idx2, st_idx3, cnt_base, RB, dummy_addr, o.c);
         } else {
           // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane:
           // an empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
@@ -1360,7 +1387,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
             for (int r = 0; r < W; ++r) {
               if (r < Lp) {
                 const int32_t e = w[r] == 0 ? sl.c[0] : (w[r] == 1 ? sl.c[1] : sl.c[2]);
-                const int32_t node = ((e & 0xffff) - cnt_base) >> 3;
+                const int32_t node = ((e & 0xffff) - cnt_base) / RB;
                 const int32_t id = g_node_id[node];       // 4 KB table per scenario: L2-resident
                 row[r] = id;
                 digest += kas_digest_cell((uint32_t)itr.k, (uint32_t)p, (uint32_t)r, id);

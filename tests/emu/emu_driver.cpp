@@ -100,9 +100,9 @@ template <int W, int NW> void run_fill(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::fill_scenario<W, NW>(*r->a, r->s, r->lds);
 }
-template <int W, int G> void run_order_tickets(void* p) {
+template <int W, int G, bool PK> void run_order_tickets(void* p) {
   RunArgs* r = (RunArgs*)p;
-  if constexpr (W <= 3) kas::order_tickets<W, G>(*r->a, r->s, r->lds);
+  if constexpr (W <= 3) kas::order_tickets<W, G, PK>(*r->a, r->s, r->lds);
 }
 template <int W> void run_order_rounds(void* p) {
   RunArgs* r = (RunArgs*)p;
@@ -119,10 +119,10 @@ template <int NW> run_fn fill_for_w(int Wc) {
     default: return run_fill<8, NW>;
   }
 }
-template <int G> run_fn tickets_for_g(int Wc) {
+template <int G, bool PK> run_fn tickets_for_g(int Wc) {
   switch (Wc) {
-    case 2: return run_order_tickets<2, G>;
-    default: return run_order_tickets<3, G>;
+    case 2: return run_order_tickets<2, G, PK>;
+    default: return run_order_tickets<3, G, PK>;
   }
 }
 run_fn rounds_for(int Wc) {
@@ -153,7 +153,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
   size_t lds_bytes = (size_t)sh.lds.total;
   if ((size_t)kas_order_round_lds(sh.n_max, sh.Wc) > lds_bytes) lds_bytes = (size_t)kas_order_round_lds(sh.n_max, sh.Wc);
-  if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G);
+  if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
   std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
   KasLaunch a;
   a.scen = b->scenarios; a.topics = b->topics; a.node_id = b->node_id; a.node_rack = b->node_rack;
@@ -182,7 +182,10 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   }
   // order kernel: one wavefront per G scenarios (ticket form) or per scenario (round form)
   if (tickets) {
-    run_fn f = sh.G == 1 ? tickets_for_g<1>(sh.Wc) : sh.G == 2 ? tickets_for_g<2>(sh.Wc) : tickets_for_g<4>(sh.Wc);
+    const bool pk = sh.packed_ok && !(flags & KAS_FLAG_WIDE_COUNTERS);
+    run_fn f = sh.G == 1 ? (pk ? tickets_for_g<1, true>(sh.Wc) : tickets_for_g<1, false>(sh.Wc))
+             : sh.G == 2 ? (pk ? tickets_for_g<2, true>(sh.Wc) : tickets_for_g<2, false>(sh.Wc))
+                         : (pk ? tickets_for_g<4, true>(sh.Wc) : tickets_for_g<4, false>(sh.Wc));
     for (int32_t s = 0; s < b->n_scenarios; s += sh.G) {
       memset(lds.data(), 0xCD, lds.size());
       RunArgs ra{&a, s, lds.data()};

@@ -71,6 +71,7 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     for nw, g in ((1, 1), (2, 2), (8, 4)):
         assert_same_outputs(fb, want, emu_solve(fb, flags=(nw << 8) | (g << 12)), f"emu {nw} waves, {g} scenarios per wave")
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round order")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=4), "emu 4 x uint16 counter rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=3 | (1 << 8)), "emu generic fill + round order, 1 wave")
     # the generator must produce solvable scenarios most of the time, else the test is vacuous
     assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 1

@@ -49,6 +49,7 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip round order")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 4), "hip 4 x uint16 counter rows")
     for nw, g in ((1, 1), (2, 2), (4, 4), (8, 1)):
         assert_same_outputs(fb, want, native.solve_host_with_flags(fb, (nw << 8) | (g << 12)),
                             f"hip {nw} waves, {g} scenarios per wave")
@@ -85,6 +86,7 @@ def test_config3_shape_full_size_scenarios():
     assert_same_outputs(fb, want, got, "C3")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 4), "C3 4 x uint16 counter rows")
     for nw, g in ((1, 1), (2, 2), (8, 2)):     # 4 scenarios per wave do not fit 16-bit LDS offsets at N = 1000
         assert_same_outputs(fb, want, native.solve_host_with_flags(fb, (nw << 8) | (g << 12)),
                             f"C3 {nw} waves, {g} scenarios per wave")
