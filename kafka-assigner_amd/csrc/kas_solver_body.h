@@ -179,34 +179,50 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
   int32_t fail_lane = -1;
   int32_t j = head;
   st[4] += 1;
+  constexpr int U = 4;                                     // node positions fetched per LDS round trip
   for (;;) {
     uint64_t pend = kasw::ballot(need > 0);
     if (pend == 0) break;
-    st[5] += 1;
     if (j >= live_count) { fail_lane = kasw::first_lane(pend); break; }
-    const int32_t n = (int32_t)L.live[j];
-    const int32_t slots = cap - L.load[n];
-    if (slots > 0) {
-      const int32_t rk = (int32_t)L.rack[n];
-      bool want = need > 0;
+    // the next U non-full nodes in processing order: their table entries in one go (each node
+    // is listed once, and only this wave changes load[], so the values stay valid below)
+    int32_t n[U], slots[U], rk[U];
 #pragma unroll
-      for (int k = 0; k < W; ++k) want = want && !(k < hc && hr[k] == rk);
-      const uint64_t w = kasw::ballot(want);
-      if (w != 0) {
-        const int32_t rank = kasw::popc(w & kasw::lanemask_lt());
-        if (want && rank < slots) {                      // accept (KAS:178-181)
-          out[(int64_t)p * ow + hc] = n;
-          put<W>(hr, hc, rk);
-          hc += 1;
-          need -= 1;
+    for (int u = 0; u < U; ++u) n[u] = (int32_t)L.live[j + u < live_count ? j + u : j];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { slots[u] = cap - L.load[n[u]]; rk[u] = (int32_t)L.rack[n[u]]; }
+    int32_t taken[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      taken[u] = 0;
+      if (j + u < live_count && pend != 0) {               // wave-uniform
+        st[5] += 1;
+        if (slots[u] > 0) {
+          bool want = need > 0;
+#pragma unroll
+          for (int k = 0; k < W; ++k) want = want && !(k < hc && hr[k] == rk[u]);
+          const uint64_t w = kasw::ballot(want);
+          if (w != 0) {
+            const int32_t rank = kasw::popc(w & kasw::lanemask_lt());
+            if (want && rank < slots[u]) {                 // accept (KAS:178-181)
+              out[(int64_t)p * ow + hc] = n[u];
+              put<W>(hr, hc, rk[u]);
+              hc += 1;
+              need -= 1;
+            }
+            const int32_t takers = kasw::popc(w);
+            taken[u] = takers < slots[u] ? takers : slots[u];
+            pend = kasw::ballot(need > 0);
+          }
         }
-        const int32_t takers = kasw::popc(w);
-        kasw::lockstep();                                // every lane has read load[n]
-        if (lane == 0) L.load[n] += takers < slots ? takers : slots;
-        kasw::lockstep();
       }
     }
-    ++j;
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (taken[u] > 0) L.load[n[u]] += taken[u];
+    }
+    kasw::lockstep();
+    j += U;
   }
   // drop the leading nodes that are now full from future windows
   while (head < live_count && L.load[(int32_t)L.live[head]] >= cap) ++head;
@@ -246,6 +262,10 @@ KAS_DEV void load_row(const TopicView& T, int32_t p, int32_t (&ids)[W], int32_t&
     len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
   }
 }
+
+// every current list of the topic is exactly W wide, and every out row too
+template <int W>
+KAS_DEV bool full_rows_of(const TopicView& T) { return T.cw == W && T.ow == W && T.len_arr == nullptr; }
 
 // Stream the tiles tile0, tile0 + stride, ... (< t_end) of the cur table through `body(tile, ids,
 // len)` with KAS_TILES_AHEAD tiles of rows in flight per lane: the scans are HBM-latency-bound
@@ -302,9 +322,8 @@ KAS_DEV void for_tile_batches_impl(const TopicView& T, int32_t tile0, int32_t st
   }
 }
 
-// is every current list of the topic exactly W wide (and every out row too)?
 template <int W>
-KAS_DEV bool full_rows(const TopicView& T) { return T.cw == W && T.ow == W && T.len_arr == nullptr; }
+KAS_DEV bool full_rows(const TopicView& T) { return full_rows_of<W>(T); }
 
 template <int W, typename Body>
 KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
@@ -326,7 +345,7 @@ template <int W>
 KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t len,
                      const int32_t (&ids)[W], const int32_t (&idx)[W], uint32_t accbits,
                      int32_t& need, int32_t& hc, int32_t (&hrack)[W], int32_t& moved_r,
-                     int32_t& moved_p) {
+                     int32_t& moved_p, const int32_t* racks = nullptr) {
   const bool active = p < T.P;
   int32_t hold[W];
 #pragma unroll
@@ -336,7 +355,7 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
   for (int r = 0; r < W; ++r) {
     const bool acc = (accbits >> r) & 1u;
     const int32_t n = idx[r] >= 0 ? idx[r] : 0;
-    const int32_t rk = (int32_t)L.rack[n];
+    const int32_t rk = racks ? racks[r] : (int32_t)L.rack[n];   // the caller may have looked it up already
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       const bool here = acc && hc == k;
@@ -424,7 +443,7 @@ KAS_DEV int32_t drain_ring(const LdsView& L, const TopicView& T, int32_t min_fil
 // Executed by ONE wave (the other waves of the workgroup wait at the next barrier).
 // ---------------------------------------------------------------------------------------------
 template <int W>
-KAS_DEV void fill_generic_sweeps(const LdsView& L, const TopicView& T, const NodeMap& nm,
+KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, const NodeMap& nm,
                                  uint64_t* accmask, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   const uint64_t lt = kasw::lanemask_lt();
@@ -480,7 +499,7 @@ KAS_DEV void fill_generic_sweeps(const LdsView& L, const TopicView& T, const Nod
 
 // P3 + P4 over the accept-mask words of the general sticky fill (one wave)
 template <int W>
-KAS_DEV int32_t p3p4_generic(const LdsView& L, const TopicView& T, const NodeMap& nm,
+KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const NodeMap& nm,
                              const uint64_t* accmask, int32_t live_count, int32_t& moved_r,
                              int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();

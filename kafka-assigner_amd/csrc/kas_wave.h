@@ -16,6 +16,8 @@
 #include <stdint.h>
 
 #define KAS_DEV __device__ __forceinline__
+// rarely taken paths: a real call, so that their registers do not count against the hot loops
+#define KAS_DEV_COLD __device__ __noinline__
 
 namespace kasw {
 

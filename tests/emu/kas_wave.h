@@ -22,6 +22,7 @@
 #include <ucontext.h>
 
 #define KAS_DEV static inline
+#define KAS_DEV_COLD static
 #define KAS_EMU_MAX_LANES 512
 
 namespace kasw {
