@@ -26,6 +26,10 @@ import os
 import sys
 import time
 
+# The HIP runtime multiplexes streams onto 4 hardware queues by default; steps in flight on more
+# streams than that would serialise in pairs.  Must be set before the runtime is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -237,7 +241,7 @@ def main() -> int:
                                "reproduced bit-exactly (status + partition id)",
                 "parity_checked_scenarios": checked,
                 "collective": "all_gather of 32-byte result records per step" if world > 1 else "none (1 GPU)",
-                "batches_in_flight": n_slots,
+                "batches_in_flight": n_slots, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
