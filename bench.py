@@ -43,8 +43,8 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--scenarios", type=int, default=1000, help="scenarios per GPU per step")
     ap.add_argument("--partitions", type=int, default=100000)
     ap.add_argument("--brokers", type=int, default=1000)
