@@ -42,6 +42,10 @@ __global__ __launch_bounds__(192) void kas_order_ticket_kernel(KasLaunch a) {
   kas::order_tickets<W, G, PK>(a, (int32_t)blockIdx.x * G, kas_lds);
 }
 
+__global__ __launch_bounds__(256) void kas_order_permutation_kernel(KasLaunch a) {
+  kas::order_permutation(a, (int32_t)(blockIdx.x * blockDim.x + threadIdx.x), (int32_t)(gridDim.x * blockDim.x));
+}
+
 template <int W>
 __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
@@ -134,6 +138,7 @@ struct kas_plan {
   uint64_t* d_accmask;
   int64_t* d_orph_off;
   int32_t* d_orph;
+  int32_t* d_perm;
   int64_t* d_stats;
   hipStream_t last_stream;
   // kernel timing: event pairs recorded around every launch on the launch stream
@@ -223,7 +228,7 @@ void kas_plan_destroy(kas_plan* p) {
   (void)hipFree(p->d_scen); (void)hipFree(p->d_topics);
   (void)hipFree(p->d_node_id); (void)hipFree(p->d_node_rack);
   (void)hipFree(p->d_accmask_off); (void)hipFree(p->d_accmask); (void)hipFree(p->d_stats);
-  (void)hipFree(p->d_orph_off); (void)hipFree(p->d_orph);
+  (void)hipFree(p->d_orph_off); (void)hipFree(p->d_orph); (void)hipFree(p->d_perm);
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
     if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
@@ -278,7 +283,7 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
   p->d_accmask_off = nullptr; p->d_accmask = nullptr; p->d_stats = nullptr; p->last_stream = ctx->stream;
-  p->d_orph_off = nullptr; p->d_orph = nullptr;
+  p->d_orph_off = nullptr; p->d_orph = nullptr; p->d_perm = nullptr;
   p->timer_next = 0; p->timer_count = 0;
   if (p->lds.total > KAS_LDS_LIMIT) {
     delete p;
@@ -300,6 +305,10 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   {
     hipError_t e = hipMalloc((void**)&p->d_orph, sizeof(int32_t) * (size_t)(sh.orph_ints + 64));
     if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "orphan-list scratch: " + std::string(hipGetErrorString(e))); }
+  }
+  {
+    hipError_t e = hipMalloc((void**)&p->d_perm, sizeof(int32_t) * (size_t)(batch->n_scenarios + 1));
+    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "scenario-order scratch: " + std::string(hipGetErrorString(e))); }
   }
   {
     size_t sb = sizeof(int64_t) * KAS_STATS_PER_SCENARIO * (size_t)(batch->n_scenarios + 1);
@@ -343,6 +352,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off; a.stats = p->d_stats;
   a.orph = p->d_orph; a.orph_off = p->d_orph_off;
+  a.perm = nullptr;
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
@@ -355,6 +365,12 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   KAS_HIP_TRY(hipGetLastError());
   KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
   const int packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
+  if (tickets && p->G > 1 && p->n_scenarios > p->G && p->n_scenarios <= KAS_PAIRING_LIMIT) {
+    // scenarios that share a solver wavefront should have P5 chains of similar length
+    a.perm = p->d_perm;
+    hipLaunchKernelGGL(kas_order_permutation_kernel, dim3((unsigned)((p->n_scenarios + 255) / 256)), dim3(256), 0, st, a);
+    KAS_HIP_TRY(hipGetLastError());
+  }
   if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3((unsigned)((p->n_scenarios + p->G - 1) / p->G)),
                        dim3(192), (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, packed), st, a);

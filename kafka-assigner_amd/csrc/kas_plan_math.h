@@ -31,6 +31,7 @@ struct KasLaunch {
   const int64_t* accmask_off;   // [n_scenarios] offset of the region in 64-bit words
   int32_t* orph;                // scratch: orphan row lists, one region per scenario
   const int64_t* orph_off;      // [n_scenarios] offset of the region in int32 elements
+  int32_t* perm;                // scratch: order in which the order kernel takes the scenarios, or NULL
   int64_t* stats;               // [n_scenarios][KAS_STATS_PER_SCENARIO] device counters, or NULL
   int32_t n_scenarios;
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
@@ -73,6 +74,7 @@ struct KasLds {
 #define KAS_CTL_MOVED_P 4
 #define KAS_CTL_OC 8          // [NW] orphans found per chunk
 
+#define KAS_PAIRING_LIMIT 8192   // batches up to this many scenarios are ordered by chain length for P5
 #define KAS_TICKET_LIMIT 65535  // tickets (= 16-bit counters of the order kernel) stay below this
 
 KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_t)15); }

@@ -1039,6 +1039,26 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 }
 
 // ---------------------------------------------------------------------------------------------
+// Between fill and order: perm[] = scenario indices by descending number of orphans placed (the
+// length of a scenario's P5 dependency chain, known from the fill kernel's movement count).  The
+// order kernel takes scenarios in this order, so the G scenarios sharing a solver wavefront have
+// chains of similar length (the wavefront lasts as long as its longest chain) and the longest
+// ones start first.  Rank by counting: fine for the batch sizes it is used for.
+// ---------------------------------------------------------------------------------------------
+KAS_DEV void order_permutation(const KasLaunch& a, int32_t tid, int32_t n_threads) {
+  const int32_t S = a.n_scenarios;
+  for (int32_t i = tid; i < S; i += n_threads) {
+    const int32_t ki = a.scenario_results[i].moved_replicas;
+    int32_t rank = 0;
+    for (int32_t j = 0; j < S; ++j) {
+      const int32_t kj = a.scenario_results[j].moved_replicas;
+      rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+    }
+    a.perm[rank] = i;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // order kernel, ticket form.  A workgroup is three wavefronts serving G scenarios (one lane group
 // of GL = 64 / G lanes each): wave 0 SOLVES, wave 1 STAGES rows for it, wave 2 RETIRES what it
 // finished.  Lane l of every wave owns the rows li, li + GL, li + 2 GL, ... (li = l % GL) of every
@@ -1150,8 +1170,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int lane = kasw::lane();
   const int32_t wave = kasw::wave_id();
   const int32_t g = lane / GL, li = lane % GL;
-  const int32_t s = first_scenario + g;
-  const bool have_s = s < a.n_scenarios;
+  const bool have_s = first_scenario + g < a.n_scenarios;
+  const int32_t s = have_s ? (a.perm ? a.perm[first_scenario + g] : first_scenario + g) : a.n_scenarios;
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G, PK);   // LDS byte offset of this group's region
   unsigned char* cnt = lds_raw + cnt_base;                  // [nmax + 1] rows: + the padding holder's row

@@ -161,6 +161,8 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data(); a.stats = nullptr;
   a.orph = orph.data(); a.orph_off = sh.orph_off.data();
+  std::vector<int32_t> perm((size_t)b->n_scenarios + 1, -1);
+  a.perm = nullptr;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch; a.flags = (flags & 0xffu) | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL);
   auto bad = [&](const char* what, int32_t s) {
@@ -182,6 +184,11 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   }
   // order kernel: one wavefront per G scenarios (ticket form) or per scenario (round form)
   if (tickets) {
+    if (sh.G > 1 && b->n_scenarios > sh.G && b->n_scenarios <= KAS_PAIRING_LIMIT) {
+      a.perm = perm.data();                              // the permutation kernel, thread by thread
+      kasw::g_emu.cur = 0;
+      for (int32_t tid = 0; tid < 256; ++tid) kas::order_permutation(a, tid, 256);
+    }
     const bool pk = sh.packed_ok && !(flags & KAS_FLAG_WIDE_COUNTERS);
     run_fn f = sh.G == 1 ? (pk ? tickets_for_g<1, true>(sh.Wc) : tickets_for_g<1, false>(sh.Wc))
              : sh.G == 2 ? (pk ? tickets_for_g<2, true>(sh.Wc) : tickets_for_g<2, false>(sh.Wc))
