@@ -246,7 +246,7 @@ def main() -> int:
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "kas_fill_kernel<3,NW> + kas_order_ticket_kernel<3,G> (one solve = both, same stream)",
+                "kernel": "kas_fill_kernel<3,4> + kas_order_ticket_kernel<3,2,true> (one solve = both, same stream)",
                 "kernel_avg_us": kern_us, "fill_kernel_avg_us": fill_us, "order_kernel_avg_us": order_us,
                 "launches_timed": kern_n,
                 "achieved_wall": value * alg_bytes / (world * S) / 1e9,

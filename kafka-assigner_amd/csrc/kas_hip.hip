@@ -1,12 +1,15 @@
 // kas_hip.hip — gfx950 kernels + the C ABI of include/kas_abi.h (libkas_hip.so).
 //
-// One workgroup of NW wavefronts per scenario; the grid is the batch.  Scenarios share nothing,
-// so there is no inter-workgroup communication at all: each workgroup streams its own cur table
-// from HBM (coalesced 64-row tiles per wave), keeps broker load / rack / quota / Context counters
-// in LDS and writes its own out rows and one 32-byte result record.  Workgroup b lands on XCD
-// b % 8; in the what-if layout (many scenarios over one shared cur table) neighbouring scenarios
-// therefore spread the shared table over all eight L2s, and the 256 MiB Infinity Cache holds it
-// once.
+// A solve is three launches on one stream (device code in kas_solver_body.h):
+//   kas_fill_kernel<W, NW>              P0-P4: one workgroup of NW wavefronts per scenario
+//   kas_order_permutation_kernel        scenarios by descending P5 chain length
+//   kas_order_ticket_kernel<W, G, PK>   P5, ticket form: solver / stager / retirer wavefronts per
+//   (or kas_order_round_kernel<W>)      G scenarios — or the round form, one wavefront per scenario
+// Scenarios share nothing, so there is no inter-workgroup communication at all: each workgroup
+// streams its own tables from HBM (coalesced 64-row tiles per wave), keeps its node state in LDS
+// and writes its own out rows and one 32-byte result record.  Workgroup b lands on XCD b % 8; in
+// the what-if layout (many scenarios over one shared cur table) neighbouring scenarios therefore
+// spread the shared table over all eight L2s, and the 256 MiB Infinity Cache holds it once.
 #define KAS_ABI_FN __host__ __device__ static inline
 #include <hip/hip_runtime.h>
 

@@ -5,8 +5,8 @@
 // kasw::sync() is the workgroup barrier between phases (it carries the workgroup-scope
 // release/acquire that orders LDS and same-CU global accesses: out rows, orphan lists and
 // accept-mask words written by one wave are re-read by another wave of the same workgroup,
-// which shares the CU's vector L1); publish()/observe() are the release/acquire pair of the
-// ticket-pass watermark.
+// which shares the CU's vector L1).  The three waves of the order kernel talk through LDS slot
+// tags only and poll them with repoll().
 //
 // tests/emu/kas_wave.h provides the same names on top of CPU fibers so the identical body
 // source can be stepped on a machine without a GPU; the product only ever includes this file.
@@ -53,15 +53,6 @@ KAS_DEV void nap() { __builtin_amdgcn_s_sleep(N); }
 template <int P>
 KAS_DEV void set_priority() { __builtin_amdgcn_s_setprio(P); }
 
-// watermark hand-off between waves of one workgroup: everything this wave stored (LDS and
-// global) before publish() is visible to a wave that observes the value
-KAS_DEV void publish(int32_t* flag, int32_t v) {
-  __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-KAS_DEV int32_t observe(const int32_t* flag) {
-  return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // Point where the body relies on the 64 lanes having executed the preceding LDS accesses before
 // any lane executes the following ones (read-then-overwrite, atomic-then-read on the same words).
 // A wavefront issues each instruction for all lanes at once and the LDS serves a wave's
@@ -102,8 +93,6 @@ KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
-KAS_DEV int lds_atomic_min(int* p, int v) { return atomicMin(p, v); }
 KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

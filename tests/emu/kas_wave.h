@@ -82,9 +82,6 @@ template <int N> KAS_DEV void nap() {}
 template <int P> KAS_DEV void set_priority() {}
 KAS_DEV void repoll() { rendezvous(K_LOCKSTEP); }   // lets the other waves run
 
-KAS_DEV void publish(int32_t* flag, int32_t v) { *(volatile int32_t*)flag = v; }
-KAS_DEV int32_t observe(const int32_t* flag) { return *(const volatile int32_t*)flag; }
-
 KAS_DEV int32_t opaque(int32_t v) { return v; }
 
 KAS_DEV int popc(uint64_t m) { return __builtin_popcountll(m); }
@@ -95,8 +92,6 @@ KAS_DEV int lds_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 KAS_DEV void lds_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }
-KAS_DEV uint32_t lds_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
-KAS_DEV int lds_atomic_min(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 
 KAS_DEV uint64_t load_shared_u64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
 KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
