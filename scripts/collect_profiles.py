@@ -43,7 +43,7 @@ j = {"scenarios": 1000, "partitions": 100000,
      "read_correction_measured": corr}
 json.dump(j, open("profiles/pmc_traffic.json", "w"), indent=1)
 for src, dst in (("bench_default.log", f"{tag}_bench_default.log"), ("bench_f1.log", f"{tag}_bench_one_batch_in_flight.log"),
-                 ("bench_c2.log", f"{tag}_bench_config2_single_scenario.log"), ("pytest_gpu.log", f"{tag}_pytest_gpu.log"),
+                 ("bench_c2.log", f"{tag}_bench_config2_single_scenario.log"), ("bench_c4.log", f"{tag}_bench_config4_8000_scenarios_add_brokers.log"), ("pytest_gpu.log", f"{tag}_pytest_gpu.log"),
                  ("smoke.log", f"{tag}_smoke.log"), ("stats_default.json", f"{tag}_phase_stats_default.json"),
                  ("stats_f1.json", f"{tag}_phase_stats_one_batch_in_flight.json")):
     if os.path.exists("gpurun_out/" + src):
