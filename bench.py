@@ -232,7 +232,8 @@ def main() -> int:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE.json configs[2]: batch of {S} independent scenarios per GPU, "
+                "workload": f"{'BASELINE.json configs[2]' if (S, P, N, R, RF) == (1000, 100000, 1000, 20, 3) else 'custom shape'}: "
+                            f"batch of {S} independent scenarios per GPU, "
                             f"{P} partitions x {N} brokers x {R} racks, RF {RF}; per-scenario G(seed+s) "
                             f"current assignment + action in {{{', '.join(action_mix)}}} (remove <= 5, add <= 50)",
                 "scenarios_per_gpu": S, "partitions": P, "brokers": N, "racks": R, "rf": RF,

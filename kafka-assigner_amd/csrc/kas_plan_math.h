@@ -90,7 +90,10 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
   int64_t o = 0;
   const int64_t xr = with_x ? (W > NW ? W : NW) : 0;
   L.off_x = (int32_t)o;     o = kas_align16(o + 4 * n * xr);
-  L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n);
+  // lists wider than the workgroup has waves leave histogram rows NW..W-1 unused once the quota
+  // pass has consumed them: load[] (written by that pass, per node, after its reads) lives there
+  if (with_x && W > NW) L.off_load = L.off_x + (int32_t)(4 * n * NW);
+  else { L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n); }
   L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
   L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
   L.off_live = (int32_t)o;  o = kas_align16(o + 2 * n);

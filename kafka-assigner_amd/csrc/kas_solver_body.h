@@ -874,6 +874,11 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     if (kasw::ballot(viol) != 0 && lane == 0) L.ctl[KAS_CTL_VIOL] = 1;
     kasw::sync();
     fast = L.ctl[KAS_CTL_VIOL] == 0;
+    if (!fast) {
+      // the general fill starts from load == 0; for wide lists load[] shares LDS with a histogram row
+      for (int32_t i = tid; i < N; i += NT) L.load[i] = 0;
+      kasw::sync();
+    }
   }
   int32_t moved_r = 0, moved_p = 0;
   if (fast) {
@@ -953,7 +958,9 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
                                          (a.flags & KAS_FLAG_GENERIC_FILL) ? 0 : 1);
   LdsView L;
   L.x = (int32_t*)(lds_raw + lay.off_x);
-  L.load = (int32_t*)(lds_raw + lay.off_load);
+  // (wide lists: load[] takes the place of histogram row NW of THIS scenario's node count once the
+  // quota pass has consumed it, see kas_fill_lds_layout)
+  L.load = (W > NW && !(a.flags & KAS_FLAG_GENERIC_FILL)) ? L.x + NW * N : (int32_t*)(lds_raw + lay.off_load);
   L.qrs = (int32_t*)(lds_raw + lay.off_qrs);
   L.rack = (int16_t*)(lds_raw + lay.off_rack);
   L.live = (int16_t*)(lds_raw + lay.off_live);
