@@ -211,16 +211,10 @@ int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* 
  * error, and *launches = 0 when nothing was recorded. */
 int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
 
-/* The same accumulator split by kernel: a solve is the fill kernel (P0-P4 + tickets) followed
- * by the order kernel (P5) on one stream.  Either call resets the accumulator. */
+/* The same accumulator split by kernel: a solve is the fill kernel (P0-P4) followed by the order
+ * kernel (P5) on one stream.  Either call resets the accumulator. */
 int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, int* launches);
 
-/* Per-scenario device counters of the plan's most recent solve (after it completed):
- * out[s*16 + 0..3] = time spent in setup / P2 histogram+quota / P2 keep-scan+P3 / P4 first fit, in 10 ns ticks of the constant 100 MHz device clock; [4] P4 windows, [5] P4 node steps,
- * [6] P5 rounds (round form), [7] P2 tiles of wave 0 that needed quota ranking, [8] order kernel
- * time (ticks), and for the ticket form [9] solver iterations, [10] of those with no row loaded in
- * any lane, [11] with rows but none ready, [12] feeder iterations, [13] of those without work.  n = capacity of out in
- * int64 elements (>= KAS_STATS_PER_SCENARIO * n_scenarios).  Blocks until the plan's last launch has finished. */
 /* Behaviour switches of a plan (default 0); every combination produces identical results, they
  * exist so that the alternative forms can be tested and timed on the same inputs.
  *   KAS_PLAN_GENERIC_FILL  always run the general multi-sweep sticky fill instead of the
@@ -238,6 +232,15 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
 
+/* Per-scenario device counters of the plan's most recent solve (after it completed), 16 int64
+ * per scenario; times in 10 ns ticks of the constant 100 MHz device clock:
+ *   [0] setup  [1] P2 histogram + quota  [2] P2 keep-scan + P3  [3] P4 first fit
+ *   [4] P4 windows  [5] P4 node steps  [6] P5 rounds (round form)
+ *   [7] P2 tiles of wave 0 that needed quota ranking  [8] order kernel time
+ *   ticket form: [9] solver iterations  [11] of those with rows but none ready
+ *                [12] stager iterations  [13] of those without work
+ * n = capacity of out in int64 elements (>= KAS_STATS_PER_SCENARIO * n_scenarios).  Blocks until the
+ * plan's last launch has finished. */
 #define KAS_STATS_PER_SCENARIO 16
 int kas_plan_stats(kas_plan* plan, int64_t* out, int64_t n);
 

@@ -1128,7 +1128,7 @@ KAS_DEV bool tile_next(TileIter& it, const KasLaunch& a, const kas_scenario_desc
   return true;
 }
 
-// The feeder's half of the picks (KAS:263-278): put the row's holders (h[0..Lp) ascending node
+// The stager's half of the picks (KAS:263-278): put the row's holders (h[0..Lp) ascending node
 // index, tk = their tickets) into the order in which the FIRST pick visits them, so that the
 // solver's "first strictly smaller count wins" is a plain left-to-right argmin; and for each
 // possible first pick w0, say which of the two remaining stored positions the SECOND pick visits

@@ -16,7 +16,7 @@ try:
     r=d["roofline"]
     print("$4", "value", round(d["value"]), "ms/step", round(d["ms_per_step"],2), "fill_us", round(r["fill_kernel_avg_us"]), "order_us", round(r["order_kernel_avg_us"]))
     st=json.load(open("gpurun_out/stats_$4.json"))
-    print({k:(round(v["mean"],1),round(v["max"],1)) for k,v in st.items() if isinstance(v,dict) and k in ("order_us","solver_iterations","solver_blocked","feeder_iterations","p2_hist_quota_us","p2_keep_p3_p4_us")})
+    print({k:(round(v["mean"],1),round(v["max"],1)) for k,v in st.items() if isinstance(v,dict) and k in ("order_us","solver_iterations","solver_blocked","stager_iterations","p2_hist_quota_us","p2_keep_p3_p4_us")})
 except Exception as e:
     print("$4 FAILED", e); print(open("gpurun_out/bench_$4.log").read()[-1500:])
 PY
