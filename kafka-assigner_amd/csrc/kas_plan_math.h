@@ -46,14 +46,14 @@ struct KasLaunch {
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
-//   load, qrs, rack, live, idmap, ids, ring: node state of P2-P4
+//   load, qrs, rack, idmap, ids, ring: node state of P2-P4; live (P4) overlays qrs (P2)
 //   ctl     control words
 struct KasLds {
   int32_t off_x;       // int32  [max(W,NW)][n_max]
   int32_t off_load;    // int32  [n_max]        |Node.assignedPartitions|
   int32_t off_qrs;     // int32  [n_max]        saturating sweep r* << 28 | quota in that sweep
   int32_t off_rack;    // int16  [n_max]        dense rack index per node
-  int32_t off_live;    // int16  [n_max]        non-full nodes in processing order
+  int32_t off_live;    // int16  [n_max]        non-full nodes in processing order (== off_qrs)
   int32_t off_idmap;   // int16  [idmap_entries] broker id - min_id -> node index
   int32_t off_ids;     // int32  [n_max]        sorted ids for binary search (only if needed)
   int32_t off_ring;    // orphan window: p[128] int32, meta[128] int32, rack[W][128] int16
@@ -96,7 +96,7 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
   else { L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n); }
   L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
   L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
-  L.off_live = (int32_t)o;  o = kas_align16(o + 2 * n);
+  L.off_live = L.off_qrs;                      // P4's list of non-full nodes: qrs is dead after pass B
   L.off_idmap = (int32_t)o; o = kas_align16(o + 2 * (int64_t)(idmap_entries > 0 ? idmap_entries : 1));
   L.off_ids = (int32_t)o;   if (need_bsearch) o = kas_align16(o + 4 * n);
   L.off_ring = (int32_t)o;  o = kas_align16(o + KAS_RING_CAP * (4 + 4 + 2 * (int64_t)W));
