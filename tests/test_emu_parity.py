@@ -29,6 +29,19 @@ def test_emu_equals_oracle_small_odd_inputs(sc):
     assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 8) | (1 << 12)), "emu 2 waves, 1 scenario per wave")
 
 
+@settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(scenarios())
+def test_emu_equals_oracle_small_odd_inputs_without_context_io(sc):
+    """Same odd inputs, but no Context handed in or out: lists up to 3 wide then take the ticket form
+    of P5 (ragged lists, duplicate brokers, partitions != keys(cur), empty topics, failures)."""
+    brokers, racks, topics = sc
+    fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=False,
+                           topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
+    want = oracle_solve(fb)
+    assert_same_outputs(fb, want, emu_solve(fb), "emu (no ctx)")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=4 | (1 << 12)), "emu (no ctx), wide counters, 1 scenario per wave")
+
+
 def _batch(seed, S, P, N, R, RF, actions, rack_aware=True, cyclic=False, name_hash=3644):
     curs, ids, racks = [], [], []
     nmax = 0

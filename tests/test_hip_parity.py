@@ -34,6 +34,17 @@ def test_hip_equals_oracle_small_odd_inputs(sc):
     assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip")
 
 
+@seed(20260922)
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(scenarios())
+def test_hip_equals_oracle_small_odd_inputs_without_context_io(sc):
+    """No Context in or out: lists up to 3 wide take the ticket form of P5."""
+    brokers, racks, topics = sc
+    fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=False,
+                           topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip (no ctx)")
+
+
 @pytest.mark.parametrize("P,N,R,RF,actions", [
     (1000, 40, 8, 3, G.ACTIONS),
     (3000, 100, 10, 3, ("remove1",)),
