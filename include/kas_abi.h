@@ -238,6 +238,7 @@ int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
  *   [4] P4 windows  [5] P4 node steps  [6] P5 rounds (round form)
  *   [7] P2 tiles of wave 0 that needed quota ranking  [8] order kernel time
  *   ticket form: [9] solver iterations  [11] of those with rows but none ready
+ *                [10] re-pick rounds spent inside runs  [14] rows decided inside runs
  *                [12] stager iterations  [13] of those without work
  * n = capacity of out in int64 elements (>= KAS_STATS_PER_SCENARIO * n_scenarios).  Blocks until the
  * plan's last launch has finished. */

@@ -117,10 +117,10 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
 KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G, int32_t packed) {
   int64_t n = n_max > 0 ? n_max : 1;
   (void)G;
-  return kas_align16(kas_align16((packed ? 4 : 8) * (n + 1)) + 4 * n + 2 * n);
+  return kas_align16(kas_align16((packed ? 4 : 8) * (n + 1)) + 4 * (n + 1) + 2 * (n + 1));
 }
 KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed) {
-  return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G, packed) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G);
+  return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G, packed) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G + 256);
 }
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {

@@ -1103,66 +1103,100 @@ KAS_DEV void order_permutation(const KasLaunch& a, int32_t tid, int32_t n_thread
 
 struct alignas(16) RingSlot { int32_t tag; int32_t c[3]; };
 
-// a group's tile sequence: GL-row tiles of every topic the fill kernel solved, in order
+// a lane's tile sequence: GL-row tiles of every topic the fill kernel solved, in order
 struct TileIter {
-  int32_t k, tP, tow, t, idx2, idx3;     // topic, its rows / row width, next tile, rotation offsets
+  int32_t k, tP, tow, row0;              // topic, its rows / row width, first row of the current tile
+  int32_t rot;                           // the topic's rotation tables, see ticket_rotation()
   int64_t tout;
   bool exhausted;
 };
 
-template <int GL>
-KAS_DEV bool tile_next(TileIter& it, const KasLaunch& a, const kas_scenario_desc& sd) {
-  if (it.exhausted) return false;
-  it.t += 1;
-  while ((int64_t)it.t * GL >= it.tP) {
+// How a staged row is laid out for a topic (KAS:190, 263-278).  The holders of a row, ascending,
+// are visited by a pick over m of them starting at offset idx_m = abs(hash) % m.  Returned word:
+//   bits 0..5   for m = 3: which ascending holder goes to stored position 0, 1, 2 (2 bits each) so
+//               that stored order == the FIRST pick's visit order
+//   bits 6..11  the same for m = 2 (the third stored position keeps the padding holder)
+//   bits 12..14 for m = 3 and each stored position w0 the first pick may take: whether the HIGHER
+//               of the two remaining stored positions is visited first by the second pick
+KAS_DEV int32_t ticket_rotation(int32_t name_hash) {
+  const int32_t idx2 = java_abs_mod(name_hash, 2), idx3 = java_abs_mod(name_hash, 3);
+  int32_t rank3[3], word = 0;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    int32_t r = t + 3 - idx3;                               // rank visited at position t: (t + m - idx_m) % m
+    r -= r >= 3 ? 3 : 0;
+    rank3[t] = r;
+    word |= r << (2 * t);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int32_t r = t + 2 - idx2;
+    r -= r >= 2 ? 2 : 0;
+    word |= r << (6 + 2 * t);
+  }
+  word |= 2 << 10;
+#pragma unroll
+  for (int w0 = 0; w0 < 3; ++w0) {
+    // second pick: the two remaining holders in RANK order are visited (lower, higher) when
+    // idx2 == 0 and (higher, lower) when idx2 == 1
+    const int pp = w0 == 0 ? 1 : 0, qq = w0 == 2 ? 1 : 2;  // remaining stored positions
+    const bool q_lower_rank = rank3[qq] < rank3[pp];
+    const bool q_first = idx2 == 0 ? q_lower_rank : !q_lower_rank;
+    word |= q_first ? (1 << (12 + w0)) : 0;
+  }
+  return word;
+}
+#define KAS_ROT_IDENT (0 | (1 << 2) | (2 << 4))
+
+// next topic the fill kernel solved (rarely taken: kept out of the tile loops; by value so that
+// the iterator stays in registers)
+KAS_DEV_COLD TileIter tile_next_topic(TileIter it, const KasLaunch& a, const kas_scenario_desc& sd) {
+  for (;;) {
     it.k += 1;
-    if (it.k >= sd.topic_count) { it.exhausted = true; return false; }
+    if (it.k >= sd.topic_count) { it.exhausted = true; return it; }
     const int32_t ti = sd.topic_begin + it.k;
     if (a.topic_results[ti].status != KAS_OK) continue;
     const kas_topic_desc td = a.topics[ti];
+    if (td.n_partitions <= 0) continue;
     it.tP = td.n_partitions; it.tow = td.out_width; it.tout = td.out_off;
-    it.idx2 = java_abs_mod(td.name_hash, 2);                // rotation offsets (KAS:190)
-    it.idx3 = java_abs_mod(td.name_hash, 3);
-    it.t = 0;
+    it.rot = ticket_rotation(td.name_hash);
+    it.row0 = 0;
+    return it;
   }
-  return true;
 }
 
-// The stager's half of the picks (KAS:263-278): put the row's holders (h[0..Lp) ascending node
-// index, tk = their tickets) into the order in which the FIRST pick visits them, so that the
-// solver's "first strictly smaller count wins" is a plain left-to-right argmin; and for each
-// possible first pick w0, say which of the two remaining stored positions the SECOND pick visits
-// first.  Returns the tag bits 26..30; stored[t] = ticket << 16 | LDS byte address of the row.
-KAS_DEV int32_t stage_row(const int32_t (&h)[3], const int32_t (&tk)[3], int32_t Lp, int32_t idx2,
-                          int32_t idx3, int32_t cnt_base, int32_t row_bytes, int32_t dummy_enc,
-                          int32_t (&stored)[3]) {
-  int32_t enc[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) enc[q] = q < Lp ? ((tk[q] << 16) | (cnt_base + h[q] * row_bytes)) : dummy_enc;
-  // rank visited at position t of a set of m: (t + m - idx_m) % m
-  const int32_t m = Lp;
-  const int32_t idx = m == 3 ? idx3 : (m == 2 ? idx2 : 0);
-  int32_t rank_at[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    int32_t r = t + m - idx;
-    r -= r >= m ? m : 0;
-    rank_at[t] = t < m ? r : t;                             // padding stays behind the holders
-    stored[t] = rank_at[t] == 0 ? enc[0] : (rank_at[t] == 1 ? enc[1] : enc[2]);
-  }
-  int32_t bits = 0;
-  if (m == 3) {
-    // second pick: the two remaining holders in RANK order are visited (lower, higher) when
-    // idx2 == 0 and (higher, lower) when idx2 == 1
-#pragma unroll
-    for (int w0 = 0; w0 < 3; ++w0) {
-      const int pp = w0 == 0 ? 1 : 0, qq = w0 == 2 ? 1 : 2;            // remaining stored positions
-      const bool q_lower_rank = rank_at[qq] < rank_at[pp];
-      const bool q_first = idx2 == 0 ? q_lower_rank : !q_lower_rank;
-      bits |= q_first ? (1 << w0) : 0;
-    }
-  }
-  return (bits << 26) | (Lp << 29);
+template <int GL>
+KAS_DEV bool tile_next(TileIter& it, const KasLaunch& a, const kas_scenario_desc& sd) {
+  if (it.exhausted) return false;
+  it.row0 += GL;
+  if (it.row0 < it.tP) return true;
+  it = tile_next_topic(it, a, sd);
+  return !it.exhausted;
+}
+
+KAS_DEV TileIter tile_iter_begin(bool have_scenario) {
+  TileIter it;
+  it.k = -1; it.tP = 0; it.tow = 1; it.row0 = 0; it.rot = KAS_ROT_IDENT; it.tout = 0;
+  it.exhausted = !have_scenario;
+  return it;
+}
+
+// The solver's two picks over a staged row (stored positions 0..2 = the first pick's visit order).
+// First pick: count[.][0], first strictly smaller wins == the minimum of (count, stored position).
+// Second pick: count[.][1] of the two remaining stored positions; the one visited first wins ties:
+// minimum of (count, visited second, stored position), the taken one excluded.  The third is what
+// is left.
+KAS_DEV void ticket_picks(const uint32_t (&f0)[3], const uint32_t (&f1)[3], int32_t meta, int32_t& w0, int32_t& w1) {
+  const uint32_t k0 = f0[0] << 2, k1 = (f0[1] << 2) | 1u, k2 = (f0[2] << 2) | 2u;
+  const uint32_t kmin = k0 < k1 ? (k0 < k2 ? k0 : k2) : (k1 < k2 ? k1 : k2);
+  w0 = (int32_t)(kmin & 3u);
+  const uint32_t vis = (uint32_t)meta >> w0;                // bit 0: the higher remaining position is visited first
+  const uint32_t hi_first = vis & 1u;
+  const uint32_t lo_pos = w0 == 0 ? 1u : 0u, hi_pos = w0 == 2 ? 1u : 2u;
+  const uint32_t c_lo = w0 == 0 ? f1[1] : f1[0], c_hi = w0 == 2 ? f1[1] : f1[2];
+  const uint32_t key_lo = (c_lo << 3) | (hi_first << 2) | lo_pos;
+  const uint32_t key_hi = (c_hi << 3) | ((hi_first ^ 1u) << 2) | hi_pos;
+  w1 = (int32_t)((key_lo < key_hi ? key_lo : key_hi) & 3u);
 }
 
 // PK: counter rows are one uint32 of three 10-bit counts (commits on the node = their sum) instead
@@ -1183,11 +1217,12 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G, PK);   // LDS byte offset of this group's region
   unsigned char* cnt = lds_raw + cnt_base;                  // [nmax + 1] rows: + the padding holder's row
   uint32_t* dep = (uint32_t*)(lds_raw + cnt_base + kas_align16(RB * (int64_t)(nmax + 1)));   // lane mask per node (ticket pass)
-  uint16_t* run = (uint16_t*)(dep + nmax);                  // tickets handed out per node so far
+  uint16_t* run = (uint16_t*)(dep + nmax + 1);              // tickets handed out per node so far (both: + the padding node)
   // padding holder: counts that never win a pick, and a ticket that always matches its commits
   const int32_t dummy_addr = PK ? ((3 * 0x3ff) << 16) | (cnt_base + nmax * RB) : (cnt_base + nmax * RB);
   RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G, PK));
   uint64_t* gdig = (uint64_t*)(ring + K * 64);
+  uint32_t* rank_owner = (uint32_t*)(gdig + G);             // [64] run scratch of the solver: rank -> lane
 
   kas_scenario_desc sd;
   sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
@@ -1202,6 +1237,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     if (PK) ((uint32_t*)cnt)[nmax] = 0x3fffffffu; else ((uint64_t*)cnt)[nmax] = KAS_DUMMY_COUNTS;
     gdig[g] = 0ull;
   }
+  if (wave == 0) rank_owner[lane] = 0u;
   for (int32_t k = wave; k < K; k += 3) ring[k * 64 + lane].tag = KAS_TAG_FREE;
   kasw::sync();
 
@@ -1214,7 +1250,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     int32_t e0 = dummy_addr, e1 = dummy_addr, e2 = dummy_addr, meta = 0;
     RingSlot nx;
     nx.tag = KAS_TAG_FREE; nx.c[0] = 0; nx.c[1] = 0; nx.c[2] = 0;
-    int64_t n_iter = 0, n_blocked = 0;
+    int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0, n_cur = 0;
     const int64_t t_begin = kasw::clock_ticks();
     kasw::set_priority<3>();                               // the chain: first call on the SIMD's issue slots
     for (;;) {
@@ -1244,24 +1280,97 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
         else if (sl.tag == KAS_TAG_END && !cv) fin = true;
       }
-      // commits on the node == my ticket: every earlier row holding it has committed
-      const bool ready = cv && com[0] == ((uint32_t)e0 >> 16) && com[1] == ((uint32_t)e1 >> 16) &&
-                         com[2] == ((uint32_t)e2 >> 16);
-      // first pick: count[.][0], holders in visit order, first strictly smaller wins == the
-      // minimum of (count, stored position)
-      const uint32_t k0 = f0[0] << 2, k1 = (f0[1] << 2) | 1u, k2 = (f0[2] << 2) | 2u;
-      const uint32_t kmin = k0 < k1 ? (k0 < k2 ? k0 : k2) : (k1 < k2 ? k1 : k2);
-      const int32_t w0 = (int32_t)(kmin & 3u);
-      // second pick: count[.][1] of the two remaining stored positions; the one visited first
-      // wins ties: minimum of (count, visited second, stored position), the taken one excluded
-      const uint32_t vis = (uint32_t)meta >> w0;            // bit 0: the higher remaining position is visited first
-      const uint32_t hi_first = vis & 1u;
-      const uint32_t lo_pos = w0 == 0 ? 1u : 0u, hi_pos = w0 == 2 ? 1u : 2u;
-      const uint32_t c1_0 = f1[0], c1_1 = f1[1], c1_2 = f1[2];
-      const uint32_t c_lo = w0 == 0 ? c1_1 : c1_0, c_hi = w0 == 2 ? c1_1 : c1_2;
-      const uint32_t key_lo = (c_lo << 3) | (hi_first << 2) | lo_pos;
-      const uint32_t key_hi = (c_hi << 3) | ((hi_first ^ 1u) << 2) | hi_pos;
-      const int32_t w1 = (int32_t)((key_lo < key_hi ? key_lo : key_hi) & 3u);
+      // rows still ahead of mine on each holder: ticket - commits on the node; 0 everywhere ==
+      // every earlier row holding any of my nodes has committed
+      const uint32_t d0 = ((uint32_t)e0 >> 16) - com[0], d1 = ((uint32_t)e1 >> 16) - com[1],
+                     d2 = ((uint32_t)e2 >> 16) - com[2];
+      const uint32_t d_any = d0 | d1 | d2, d_sum = d0 + d1 + d2;
+      bool ready = cv && d_any == 0u;
+      if (a.stats) n_cur += kasw::popc((kasw::ballot(cv) >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)));
+      // ---- runs.  First fit hands consecutive orphans to one node until it is full, so the rows
+      // in hand often queue on ONE node X (tickets t, t+1, ...) while their other holders are
+      // free.  Such a queue is decided in this iteration: its rows differ from "ready" only in
+      // the counts of X they will see — X's counts now plus what the rows before them in the
+      // queue add.  X wins a row's first pick iff count[X][0] is below a threshold fixed by the
+      // row's other holders, else its second pick iff count[X][1] is below another; with the
+      // queue laid out by rank (lane r of the group = the row r places behind X's commits) the
+      // counts are prefix sums of those wins, and re-evaluating them until nothing changes gives
+      // the sequential answer (row r is right after round r at the latest; usually 2 rounds).
+      {
+        // a row waiting on exactly one node with two rows ahead of it nominates that node
+        const uint64_t nb = kasw::ballot(cv && d_any == 2u && d_sum == 2u);
+        if (nb != 0ull) {
+          constexpr uint64_t GLM = GL == 64 ? ~0ull : ((1ull << GL) - 1ull);
+          const int32_t gsh = g * GL;
+          const int32_t a0 = e0 & 0xffff, a1 = e1 & 0xffff, a2 = e2 & 0xffff;
+          const int32_t my_ax = d0 != 0u ? a0 : (d1 != 0u ? a1 : a2);
+          int32_t ax = -1;                                    // my group's nominated node (its counter row)
+#pragma unroll
+          for (int gg = 0; gg < G; ++gg) {
+            const uint64_t m = (nb >> (gg * GL)) & GLM;
+            const int32_t v = kasw::read_lane(my_ax, m != 0ull ? gg * GL + kasw::first_lane(m) : 0);
+            ax = (g == gg && m != 0ull) ? v : ax;
+          }
+          const int32_t hx = a0 == ax ? 0 : (a1 == ax ? 1 : (a2 == ax ? 2 : -1));
+          const uint32_t kx = hx == 0 ? d0 : (hx == 1 ? d1 : d2);             // my rank in X's queue
+          // candidates: rows in hand that hold X and wait for nothing else
+          const bool cand = cv && hx >= 0 && d_sum == kx && kx < (uint32_t)GL;
+          n_runs += 1;
+          const uint32_t seq = (uint32_t)(n_runs & 0xffffff);          // never 0: stale and initial entries differ
+          if (cand) rank_owner[gsh + (int32_t)kx] = (seq << 8) | (uint32_t)lane;
+          kasw::lockstep();
+          const uint32_t ow = rank_owner[lane];                // rank view: lane li of a group = rank li
+          kasw::lockstep();
+          const bool have = (ow >> 8) == seq;
+          const uint64_t hb = (kasw::ballot(have) >> gsh) & GLM;
+          const int32_t qlen = (~hb & GLM) != 0ull ? kasw::first_lane(~hb & GLM) : GL;   // ranks 0..qlen-1 are all in hand
+          const bool member = cand && (int32_t)kx < qlen;
+          if (kasw::ballot(member && kx > 0u) != 0ull) {
+            // thresholds of the owner's row (relative to X's counts now)
+            const uint32_t k0 = f0[0] << 2, k1 = (f0[1] << 2) | 1u, k2 = (f0[2] << 2) | 2u;
+            const uint32_t mo = hx == 0 ? (k1 < k2 ? k1 : k2) : (hx == 1 ? (k0 < k2 ? k0 : k2) : (k0 < k1 ? k0 : k1));
+            const uint32_t bx0 = hx == 0 ? f0[0] : (hx == 1 ? f0[1] : f0[2]);
+            const uint32_t bx1 = hx == 0 ? f1[0] : (hx == 1 ? f1[1] : f1[2]);
+            // first pick: (c << 2 | hx) < mo  <=>  c < ceil((mo - hx) / 4)
+            const int32_t t0 = (int32_t)((mo - (uint32_t)hx + 3u) >> 2) - (int32_t)bx0;
+            // X loses the first pick to stored position o0; the second pick is between X and o1
+            const int32_t o0 = (int32_t)(mo & 3u), o1 = 3 - hx - o0;
+            const uint32_t hi_first = ((uint32_t)meta >> o0) & 1u;
+            const uint32_t vx = hx > o1 ? hi_first ^ 1u : hi_first;          // "visited second" bit of X / of o1
+            const uint32_t co1 = o1 == 0 ? f1[0] : (o1 == 1 ? f1[1] : f1[2]);
+            const uint32_t ko = (co1 << 3) | ((vx ^ 1u) << 2) | (uint32_t)o1;
+            const uint32_t lowx = (vx << 2) | (uint32_t)hx;
+            // (c << 3 | lowx) < ko  <=>  c < ceil((ko - lowx) / 8)
+            const int32_t t1 = (int32_t)((ko - lowx + 7u) >> 3) - (int32_t)bx1;
+            const int32_t t0c = t0 < 0 ? 0 : (t0 > 127 ? 127 : t0), t1c = t1 < 0 ? 0 : (t1 > 127 ? 127 : t1);
+            const int32_t th = kasw::shfl(t0c | (t1c << 8), have ? (int32_t)(ow & 0xffu) : lane);   // owner -> rank view
+            const int32_t T0 = th & 0xff, T1 = (th >> 8) & 0xff;
+            const bool act = li < qlen;
+            const uint64_t ltm = (1ull << li) - 1ull;
+            int32_t pre0 = 0, pre1 = 0;
+            for (;;) {
+              n_relax += 1;
+              const bool win0 = act && pre0 < T0;
+              const bool win1 = act && !win0 && pre1 < T1;
+              const int32_t np0 = kasw::popc((kasw::ballot(win0) >> gsh) & ltm);
+              const int32_t np1 = kasw::popc((kasw::ballot(win1) >> gsh) & ltm);
+              const bool moved = act && (np0 != pre0 || np1 != pre1);
+              pre0 = np0; pre1 = np1;
+              if (kasw::ballot(moved) == 0ull) break;
+            }
+            const int32_t back = kasw::shfl(pre0 | (pre1 << 8), member ? gsh + (int32_t)kx : lane);   // rank view -> owner
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              f0[q] = (member && hx == q) ? bx0 + (uint32_t)(back & 0xff) : f0[q];
+              f1[q] = (member && hx == q) ? bx1 + (uint32_t)((back >> 8) & 0xff) : f1[q];
+            }
+            n_run_rows += (member && kx > 0u) ? 1 : 0;
+            ready = ready || member;
+          }
+        }
+      }
+      int32_t w0, w1;
+      ticket_picks(f0, f1, meta, w0, w1);
       const int32_t w2 = 3 - w0 - w1;
       if (ready) {
         const int32_t Lp = (meta >> 3) & 3;
@@ -1291,22 +1400,35 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       if (kasw::ballot(!fin) == 0) break;
       if (kasw::ballot(ready) == 0) { n_blocked += 1; kasw::spin_pause(); }
     }
+    int32_t run_rows = 0;                                  // rows of my scenario decided inside runs
+    if (a.stats) {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) {
+        const int32_t v = kasw::wave_sum(g == gg ? (int32_t)n_run_rows : 0);
+        run_rows = g == gg ? v : run_rows;
+      }
+    }
     if (a.stats && have_s && li == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
-      st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = 0; st[11] = n_blocked;
+      st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
+      st[14] = run_rows; st[6] = n_runs; st[15] = n_cur;
     }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ stager: tickets + staging
+    // Every lane runs the same LDS instructions each iteration: a lane without a row, or a list
+    // position without a holder, works on the padding node nmax (its mask / count words are
+    // scratch), so nothing below branches on the data.
     const uint64_t gmask = (G == 1 ? ~0ull : ((1ull << GL) - 1ull)) << (g * GL);   // my group's lanes
     const uint32_t mybit = 1u << (li & 31);
     const uint32_t lt = mybit - 1u;
-    TileIter itl;
-    itl.k = -1; itl.tP = 0; itl.tow = 1; itl.t = -1; itl.idx2 = 0; itl.idx3 = 0; itl.tout = 0;
-    itl.exhausted = !have_s;
+    const uint32_t pad = (uint32_t)nmax;
+    const int32_t dummy_tk = PK ? 3 * 0x3ff : 0;
+    TileIter itl = tile_iter_begin(have_s);
     int32_t jl = 0;                                         // tiles staged (group-uniform)
     bool endl = false;
-    bool pf_valid = false, pf_have_row = false, pf_end = false;
-    int32_t pf_cells[3] = {-1, -1, -1}, pf_idx2 = 0, pf_idx3 = 0;
+    bool pf_valid = false, pf_end = false;
+    uint32_t pf_c0 = ~0u, pf_c1 = ~0u, pf_c2 = ~0u;         // the read-ahead tile's row (node indices, ~0 = none)
+    int32_t pf_rot = KAS_ROT_IDENT;
     int64_t f_iter = 0, f_idle = 0;
     for (;;) {
       kasw::repoll();
@@ -1315,87 +1437,86 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       // now if the slot it goes to is free (retired) in every lane of the group
       const bool slot_free = ring[(jl & (K - 1)) * 64 + lane].tag == KAS_TAG_FREE;
       const bool room = (kasw::ballot(slot_free) & gmask) == gmask;
-      bool staging = false, have_row = false, staging_end = false;
-      int32_t cells[3] = {-1, -1, -1};
-      int32_t st_idx2 = 0, st_idx3 = 0;
-      if (!endl && room && pf_valid) {
-        staging = true;
-        staging_end = pf_end;
-        have_row = pf_have_row;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) cells[q] = pf_cells[q];
-        st_idx2 = pf_idx2; st_idx3 = pf_idx3;
-        endl = pf_end;
-        pf_valid = false;
-      }
+      const bool staging = !endl && room && pf_valid;
+      const bool staging_end = staging && pf_end;
+      const uint32_t c0 = staging ? pf_c0 : ~0u, c1 = staging ? pf_c1 : ~0u, c2 = staging ? pf_c2 : ~0u;
+      const int32_t rot = pf_rot;
+      endl = endl || staging_end;
+      pf_valid = pf_valid && !staging;
       if (!pf_valid && !endl) {                             // read ahead: the tile after that
         pf_valid = true;
-        pf_have_row = false;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) pf_cells[q] = -1;
+        pf_c0 = ~0u; pf_c1 = ~0u; pf_c2 = ~0u;
         if (tile_next<GL>(itl, a, sd)) {
-          const int32_t p = itl.t * GL + li;
-          pf_have_row = p < itl.tP;
-          pf_idx2 = itl.idx2; pf_idx3 = itl.idx3;
-          if (pf_have_row) {
+          const int32_t p = itl.row0 + li;
+          pf_rot = itl.rot;
+          if (p < itl.tP) {
             const int32_t* row = a.out + itl.tout + (int64_t)p * itl.tow;
-#pragma unroll
-            for (int q = 0; q < W; ++q) pf_cells[q] = q < itl.tow ? row[q] : -1;
+            if (W == 3 && itl.tow == 3) {
+              const RowW<3> r = *(const RowW<3>*)row;
+              pf_c0 = (uint32_t)r.v[0]; pf_c1 = (uint32_t)r.v[1]; pf_c2 = (uint32_t)r.v[2];
+            } else {
+              pf_c0 = (uint32_t)row[0];
+              if (W > 1 && itl.tow > 1) pf_c1 = (uint32_t)row[1];
+              if (W > 2 && itl.tow > 2) pf_c2 = (uint32_t)row[2];
+            }
           }
         } else {
           pf_end = true;
         }
       }
-      // ---- tickets for the tile (wave-wide lockstep; lanes not staging carry no holders).  One
-      // 32-bit lane mask per node: a 64-lane group takes its tile as two ascending halves.
-      int32_t h[3], Lp = 0;
-      sort_holders<3>(cells, h, Lp);                        // Sets.newTreeSet (KAS:228)
-      const bool holds = staging && have_row && Lp > 0;
-      int32_t hn[3], tk[3] = {0, 0, 0};
-#pragma unroll
-      for (int q = 0; q < 3; ++q) hn[q] = (holds && q < Lp) ? h[q] : 0;
+      // ---- holders ascending (Sets.newTreeSet, KAS:228); empty cells (-1) sort last
+      const uint32_t ab_lo = c0 < c1 ? c0 : c1, ab_hi = c0 < c1 ? c1 : c0;
+      const uint32_t s0 = ab_lo < c2 ? ab_lo : c2;
+      const uint32_t s2 = ab_hi < c2 ? c2 : ab_hi;
+      const uint32_t mid_hi = ab_hi < c2 ? ab_hi : c2;
+      const uint32_t s1 = ab_lo < mid_hi ? mid_hi : ab_lo;
+      const int32_t Lp = (s0 < pad ? 1 : 0) + (s1 < pad ? 1 : 0) + (s2 < pad ? 1 : 0);
+      uint32_t hn[3] = {s0 < pad ? s0 : pad, s1 < pad ? s1 : pad, s2 < pad ? s2 : pad};
+      // ---- tickets for the tile (wave-wide lockstep).  One 32-bit lane mask per node: a 64-lane
+      // group takes its tile as two ascending halves.
+      uint32_t tk[3] = {0u, 0u, 0u};
 #pragma unroll
       for (int hf = 0; hf < HALVES; ++hf) {
-        const bool mine = holds && (HALVES == 1 || (li >> 5) == hf);
-        if (mine) {
+        const bool mine = HALVES == 1 || (li >> 5) == hf;
+        uint32_t nn[3];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) if (q < Lp) kasw::lds_atomic_or_u32(&dep[hn[q]], mybit);
-        }
+        for (int q = 0; q < 3; ++q) nn[q] = mine ? hn[q] : pad;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) kasw::lds_atomic_or_u32(&dep[nn[q]], mybit);
         kasw::lockstep();
-        uint32_t m[3];
-        int32_t base[3];
+        uint32_t m[3], base[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const bool on = mine && q < Lp;
-          m[q] = on ? dep[hn[q]] : 0u;
-          base[q] = on ? (int32_t)run[hn[q]] : 0;
-        }
+        for (int q = 0; q < 3; ++q) { m[q] = dep[nn[q]]; base[q] = (uint32_t)run[nn[q]]; }
         kasw::lockstep();
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          if (mine && q < Lp) {
-            tk[q] = base[q] + __builtin_popcount(m[q] & lt);
-            if ((m[q] & lt) == 0u) {                        // lowest lane holding this node
-              run[hn[q]] = (uint16_t)(base[q] + __builtin_popcount(m[q]));
-              dep[hn[q]] = 0u;
-            }
-          }
+          const uint32_t t = base[q] + (uint32_t)__builtin_popcount(m[q] & lt);
+          tk[q] = mine ? t : tk[q];
+          // the lowest lane holding the node moves its running count on and clears the mask
+          const uint32_t wn = (m[q] & lt) == 0u ? nn[q] : pad;
+          run[wn] = (uint16_t)(base[q] + (uint32_t)__builtin_popcount(m[q]));
+          dep[wn] = 0u;
         }
         if (hf + 1 < HALVES) kasw::lockstep();               // the second half sees the first's counts
       }
-      // ---- hand the staged row to the solver
+      // ---- hand the staged row to the solver: stored[t] = ticket << 16 | LDS byte address of the
+      // holder's counter row, holders in the first pick's visit order (padding behind them)
       if (staging) {
+        int32_t enc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          enc[q] = (int32_t)(((q < Lp ? tk[q] : (uint32_t)dummy_tk) << 16) | (uint32_t)(cnt_base + (int32_t)hn[q] * RB));
+        const int32_t lut = Lp == 3 ? (rot & 0x3f) : (Lp == 2 ? ((rot >> 6) & 0x3f) : KAS_ROT_IDENT);
         RingSlot o;
-        o.c[0] = dummy_addr; o.c[1] = dummy_addr; o.c[2] = dummy_addr;
-        if (staging_end) {
-          o.tag = KAS_TAG_END;
-        } else if (holds) {
-          o.tag = (jl & KAS_TAG_JMASK) | stage_row(hn, tk, Lp, st_idx2, st_idx3, cnt_base, RB, dummy_addr, o.c);
-        } else {
-          // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane:
-          // an empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
-          o.tag = jl & KAS_TAG_JMASK;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int32_t r = (lut >> (2 * t)) & 3;
+          o.c[t] = r == 0 ? enc[0] : (r == 1 ? enc[1] : enc[2]);
         }
+        // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane: an
+        // empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
+        const int32_t bits = Lp == 3 ? ((rot >> 12) & 7) : 0;
+        o.tag = staging_end ? KAS_TAG_END : ((jl & KAS_TAG_JMASK) | (bits << 26) | (Lp << 29));
         ring[(jl & (K - 1)) * 64 + lane] = o;
         jl += 1;
       }
@@ -1408,48 +1529,90 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     }
   } else {
     // ------------------------------------------------------------------ retirer: finished rows ->
-    // broker ids, digest, the final out row; frees the slot for the stager
-    constexpr int UR = 2;                                   // rows per lane per iteration
-    TileIter itr;
-    itr.k = -1; itr.tP = 0; itr.tow = 1; itr.t = -1; itr.idx2 = 0; itr.idx3 = 0; itr.tout = 0;
-    itr.exhausted = !have_s;
+    // broker ids, digest, the final out row.  A finished slot is copied to registers and freed for
+    // the stager at once; the node index -> broker id reads (L2) of two batches of UR rows per
+    // lane are in flight alternately, so their latency is not in the slot's way.
+    constexpr int UR = 2;                                   // rows per lane per batch
+    constexpr int RSH = PK ? 2 : 3;                         // log2(bytes per counter row)
+    struct Retired { bool on; int32_t id[3], Lp, p, k; int32_t* row; };
+    TileIter itr = tile_iter_begin(have_s);
     int32_t jr = 0;
     bool fin = false;
     uint64_t digest = 0;
-    for (;;) {
-      kasw::repoll();
-      bool retired = false;
+    auto finish = [&](Retired& r) {
+      if (r.on) {
 #pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        if (!fin) {
-          const RingSlot sl = ring[(jr & (K - 1)) * 64 + lane];
-          if (KAS_TAG_IS_DONE(sl.tag)) {
-            tile_next<GL>(itr, a, sd);
-            const int32_t p = itr.t * GL + li;
-            const int32_t w0 = sl.tag & 3, w1 = (sl.tag >> 2) & 3, Lp = (sl.tag >> 4) & 3;
-            const int32_t w[3] = {w0, w1, 3 - w0 - w1};
-            int32_t* row = a.out + itr.tout + (int64_t)p * itr.tow;
-#pragma unroll
-            for (int r = 0; r < W; ++r) {
-              if (r < Lp) {
-                const int32_t e = w[r] == 0 ? sl.c[0] : (w[r] == 1 ? sl.c[1] : sl.c[2]);
-                const int32_t node = ((e & 0xffff) - cnt_base) / RB;
-                const int32_t id = g_node_id[node];       // 4 KB table per scenario: L2-resident
-                row[r] = id;
-                digest += kas_digest_cell((uint32_t)itr.k, (uint32_t)p, (uint32_t)r, id);
-              }
-            }
-            ring[(jr & (K - 1)) * 64 + lane].tag = KAS_TAG_FREE;
-            jr += 1;
-            retired = true;
-          } else if (sl.tag == KAS_TAG_END) {
-            fin = true;
+        for (int q = 0; q < W; ++q) {
+          if (q < r.Lp) {
+            r.row[q] = r.id[q];
+            digest += kas_digest_cell((uint32_t)r.k, (uint32_t)r.p, (uint32_t)q, r.id[q]);
           }
         }
       }
-      if (kasw::ballot(!fin) == 0) break;
-      if (kasw::ballot(retired) == 0) kasw::nap<8>();
+      r.on = false;
+    };
+    auto gather = [&](Retired& r) -> bool {
+      if (fin) return false;
+      const RingSlot sl = ring[(jr & (K - 1)) * 64 + lane];
+      if (KAS_TAG_IS_DONE(sl.tag)) {
+        ring[(jr & (K - 1)) * 64 + lane].tag = KAS_TAG_FREE;
+        jr += 1;
+        tile_next<GL>(itr, a, sd);
+        const int32_t w0 = sl.tag & 3, w1 = (sl.tag >> 2) & 3;
+        const int32_t w[3] = {w0, w1, 3 - w0 - w1};
+        r.on = true; r.Lp = (sl.tag >> 4) & 3; r.p = itr.row0 + li; r.k = itr.k;
+        r.row = a.out + itr.tout + (int64_t)r.p * itr.tow;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+          const int32_t e = w[q] == 0 ? sl.c[0] : (w[q] == 1 ? sl.c[1] : sl.c[2]);
+          const int32_t node = q < r.Lp ? ((e & 0xffff) - cnt_base) >> RSH : 0;
+          r.id[q] = g_node_id[node];                      // 4 KB table per scenario: L2-resident
+        }
+        return true;
+      }
+      if (sl.tag == KAS_TAG_END) fin = true;
+      return false;
+    };
+    Retired ra[UR], rb[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      ra[u].on = false; rb[u].on = false;
+      ra[u].Lp = 0; rb[u].Lp = 0; ra[u].p = 0; rb[u].p = 0; ra[u].k = 0; rb[u].k = 0;
+      ra[u].row = nullptr; rb[u].row = nullptr;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { ra[u].id[q] = 0; rb[u].id[q] = 0; }
     }
+#ifdef KAS_RUN_DEBUG
+    int64_t r_iter = 0, r_idle = 0, r_rows = 0;
+#endif
+    for (;;) {
+      bool retired = false;
+      kasw::repoll();
+#pragma unroll
+      for (int u = 0; u < UR; ++u) finish(ra[u]);
+#pragma unroll
+      for (int u = 0; u < UR; ++u) retired = gather(ra[u]) || retired;
+      kasw::repoll();
+#pragma unroll
+      for (int u = 0; u < UR; ++u) finish(rb[u]);
+#pragma unroll
+      for (int u = 0; u < UR; ++u) retired = gather(rb[u]) || retired;
+#ifdef KAS_RUN_DEBUG
+      r_iter += 1;
+      r_rows += (ra[0].on ? 1 : 0) + (ra[1].on ? 1 : 0) + (rb[0].on ? 1 : 0) + (rb[1].on ? 1 : 0);
+      if (kasw::ballot(retired) == 0) r_idle += 1;
+#endif
+      if (kasw::ballot(!fin) == 0) break;
+      if (kasw::ballot(retired) == 0) kasw::nap<4>();
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) { finish(ra[u]); finish(rb[u]); }
+#ifdef KAS_RUN_DEBUG
+    if (a.stats && have_s && li == 0) {
+      int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      st[0] = r_iter; st[1] = r_idle; st[2] = r_rows;
+    }
+#endif
     kasw::lds_atomic_add_u64(&gdig[g], digest);
     kasw::lockstep();
     if (have_s && li == 0) a.scenario_results[s].digest = gdig[g];

@@ -32,6 +32,11 @@ KAS_DEV uint64_t ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 
 KAS_DEV int shfl(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
+// value of v in one lane, the same lane for the whole wavefront (v_readlane: no LDS crossbar trip)
+KAS_DEV int read_lane(int v, int uniform_lane) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(uniform_lane));
+}
+
 KAS_DEV void sync() { __syncthreads(); }
 
 // Ordering point for a section that only ONE wave of the workgroup executes: this wave's

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "emu/kas_wave.h"     // defines KAS_WAVE_H_ first, so the body's own #include "kas_wave.h" is a no-op
@@ -159,7 +160,9 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.scen = b->scenarios; a.topics = b->topics; a.node_id = b->node_id; a.node_rack = b->node_rack;
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
-  a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data(); a.stats = nullptr;
+  a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data();
+  std::vector<int64_t> stats((size_t)KAS_STATS_PER_SCENARIO * (size_t)(b->n_scenarios + 1), 0);
+  a.stats = getenv("KAS_EMU_STATS") ? stats.data() : nullptr;
   a.orph = orph.data(); a.orph_off = sh.orph_off.data();
   std::vector<int32_t> perm((size_t)b->n_scenarios + 1, -1);
   a.perm = nullptr;
@@ -197,6 +200,13 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
       memset(lds.data(), 0xCD, lds.size());
       RunArgs ra{&a, s, lds.data()};
       if (kasw::run_block(f, &ra, 3) != 0) return bad("order (tickets)", s);
+    }
+    if (a.stats) {
+      for (int32_t s = 0; s < b->n_scenarios; ++s) {
+        const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+        fprintf(stderr, "emu stats s=%d solver_iter=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld\n", s,
+                (long long)st[9], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12]);
+      }
     }
   } else {
     run_fn f = rounds_for(sh.Wc);
