@@ -260,8 +260,9 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
                 " B of LDS (limit 163840)");
   // counter rows are addressed with 16-bit LDS byte offsets
   // two scenarios per solver wavefront by default: a scenario rarely has more than ~20 rows ready
-  // at once, so 32 lanes serve it as well as 64 and the wave's instructions are shared
-  s.G = want_groups > 0 ? want_groups : 2;
+  // at once, so 32 lanes serve it nearly as well as 64 and the wave's instructions are shared
+  // (a lone scenario has nobody to share with and takes the whole wavefront)
+  s.G = want_groups > 0 ? want_groups : (b->n_scenarios == 1 ? 1 : 2);
   while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.G >>= 1;
   if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.tickets_ok = 0;
   *sh = s;

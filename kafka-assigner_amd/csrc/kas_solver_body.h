@@ -1091,6 +1091,10 @@ KAS_DEV void order_permutation(const KasLaunch& a, int32_t tid, int32_t n_thread
 #ifndef KAS_RING_SLOTS
 #define KAS_RING_SLOTS 4
 #endif
+// rows a run must decide beyond the ones that were ready anyway for its path to pay
+#ifndef KAS_RUN_MIN_GAIN
+#define KAS_RUN_MIN_GAIN 3
+#endif
 #define KAS_TAG_FREE (-1)
 #define KAS_TAG_END  (-3)
 #define KAS_TAG_DONE ((int32_t)0x80000000)   // | w0 | w1 << 2 | Lp << 4
@@ -1251,6 +1255,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     RingSlot nx;
     nx.tag = KAS_TAG_FREE; nx.c[0] = 0; nx.c[1] = 0; nx.c[2] = 0;
     int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0, n_cur = 0;
+    int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
     const int64_t t_begin = kasw::clock_ticks();
     kasw::set_priority<3>();                               // the chain: first call on the SIMD's issue slots
     for (;;) {
@@ -1298,7 +1303,11 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       // the sequential answer (row r is right after round r at the latest; usually 2 rounds).
       {
         // a row waiting on exactly one node with two rows ahead of it nominates that node
-        const uint64_t nb = kasw::ballot(cv && d_any == 2u && d_sum == 2u);
+        // (queues that turn out too short to pay for this path — dense small clusters — make it
+        // back off: the next attempts are skipped, twice as many each time, up to 16)
+        uint64_t nb = 0ull;
+        if (run_skip > 0) run_skip -= 1;
+        else nb = kasw::ballot(cv && d_any == 2u && d_sum == 2u);
         if (nb != 0ull) {
           constexpr uint64_t GLM = GL == 64 ? ~0ull : ((1ull << GL) - 1ull);
           const int32_t gsh = g * GL;
@@ -1325,7 +1334,12 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           const uint64_t hb = (kasw::ballot(have) >> gsh) & GLM;
           const int32_t qlen = (~hb & GLM) != 0ull ? kasw::first_lane(~hb & GLM) : GL;   // ranks 0..qlen-1 are all in hand
           const bool member = cand && (int32_t)kx < qlen;
-          if (kasw::ballot(member && kx > 0u) != 0ull) {
+          const int32_t gain = kasw::popc(kasw::ballot(member && kx > 0u));   // rows beyond the ones ready anyway
+          if (gain < KAS_RUN_MIN_GAIN) {
+            run_backoff = run_backoff == 0 ? 1 : (run_backoff < 16 ? 2 * run_backoff : 16);
+            run_skip = run_backoff;
+          } else {
+            if (gain > KAS_RUN_MIN_GAIN) run_backoff = 0;
             // thresholds of the owner's row (relative to X's counts now)
             const uint32_t k0 = f0[0] << 2, k1 = (f0[1] << 2) | 1u, k2 = (f0[2] << 2) | 2u;
             const uint32_t mo = hx == 0 ? (k1 < k2 ? k1 : k2) : (hx == 1 ? (k0 < k2 ? k0 : k2) : (k0 < k1 ? k0 : k1));
@@ -1582,9 +1596,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
       for (int q = 0; q < 3; ++q) { ra[u].id[q] = 0; rb[u].id[q] = 0; }
     }
-#ifdef KAS_RUN_DEBUG
-    int64_t r_iter = 0, r_idle = 0, r_rows = 0;
-#endif
     for (;;) {
       bool retired = false;
       kasw::repoll();
@@ -1597,22 +1608,11 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       for (int u = 0; u < UR; ++u) finish(rb[u]);
 #pragma unroll
       for (int u = 0; u < UR; ++u) retired = gather(rb[u]) || retired;
-#ifdef KAS_RUN_DEBUG
-      r_iter += 1;
-      r_rows += (ra[0].on ? 1 : 0) + (ra[1].on ? 1 : 0) + (rb[0].on ? 1 : 0) + (rb[1].on ? 1 : 0);
-      if (kasw::ballot(retired) == 0) r_idle += 1;
-#endif
       if (kasw::ballot(!fin) == 0) break;
       if (kasw::ballot(retired) == 0) kasw::nap<4>();
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) { finish(ra[u]); finish(rb[u]); }
-#ifdef KAS_RUN_DEBUG
-    if (a.stats && have_s && li == 0) {
-      int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
-      st[0] = r_iter; st[1] = r_idle; st[2] = r_rows;
-    }
-#endif
     kasw::lds_atomic_add_u64(&gdig[g], digest);
     kasw::lockstep();
     if (have_s && li == 0) a.scenario_results[s].digest = gdig[g];
