@@ -46,7 +46,11 @@ __global__ __launch_bounds__(192) void kas_order_ticket_kernel(KasLaunch a) {
 }
 
 __global__ __launch_bounds__(256) void kas_order_permutation_kernel(KasLaunch a) {
-  kas::order_permutation(a, (int32_t)(blockIdx.x * blockDim.x + threadIdx.x), (int32_t)(gridDim.x * blockDim.x));
+  __shared__ int32_t keys[KAS_PAIRING_LIMIT];               // every workgroup ranks against all scenarios
+  for (int32_t j = (int32_t)threadIdx.x; j < a.n_scenarios; j += (int32_t)blockDim.x)
+    keys[j] = a.scenario_results[j].moved_replicas;
+  __syncthreads();
+  kas::order_permutation(a, keys, (int32_t)(blockIdx.x * blockDim.x + threadIdx.x), (int32_t)(gridDim.x * blockDim.x));
 }
 
 template <int W>

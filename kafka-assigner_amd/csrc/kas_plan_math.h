@@ -70,6 +70,10 @@ struct KasLds {
 // control words
 #define KAS_CTL_VIOL 0        // some row's replicas are not rack-diverse / node table invalid
 #define KAS_CTL_FAILROW 1     // first row P4 could not place (KAS:183-184), or -1
+#define KAS_CTL_FAILWIN 2     // P4 window that row was in (INT32_MAX: none)
+#define KAS_CTL_LIVE 6        // P4: length of the live list
+#define KAS_CTL_HEAD 5        // P4: live-list positions before this one are full
+#define KAS_CTL_PROG 16       // P4: uint64 [NW] per wave (window << 32 | live-list positions done)
 #define KAS_CTL_MOVED_R 3
 #define KAS_CTL_MOVED_P 4
 #define KAS_CTL_OC 8          // [NW] orphans found per chunk
@@ -260,9 +264,9 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
                 " B of LDS (limit 163840)");
   // counter rows are addressed with 16-bit LDS byte offsets
   // two scenarios per solver wavefront by default: a scenario rarely has more than ~20 rows ready
-  // at once, so 32 lanes serve it nearly as well as 64 and the wave's instructions are shared
-  // (a lone scenario has nobody to share with and takes the whole wavefront)
-  s.G = want_groups > 0 ? want_groups : (b->n_scenarios == 1 ? 1 : 2);
+  // at once, so 32 lanes serve it as well as 64 and the wave's instructions are shared (even a
+  // lone scenario is no faster on 64 lanes: its stager then tickets each tile in two halves)
+  s.G = want_groups > 0 ? want_groups : 2;
   while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.G >>= 1;
   if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.tickets_ok = 0;
   *sh = s;

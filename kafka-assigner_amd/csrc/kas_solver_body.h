@@ -695,13 +695,25 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
   return ocount;
 }
 
-// P4 over the chunk lists, in chunk order == ascending row order.  One wave.  The orphan row
-// indices are fetched two windows ahead and their out rows one window ahead (HBM latency would
-// otherwise sit between every two windows; a row is listed once, so nothing P4 writes is read
-// early).
+
+// ---------------------------------------------------------------------------------------------
+// P4 of the rack-diverse fill (KAS:162-186) on ALL wavefronts of the workgroup.  The orphan rows
+// were listed per chunk by pass B; windows of 64 orphans (lane = orphan, ascending row order,
+// position-major first fit as in p4_window) go to the waves round-robin.  Window w + 1 may look
+// at live-list positions [j, j + U) as soon as window w is done with them (cell (orphan, node
+// position) of the reference's double loop depends only on earlier orphans at that position and
+// on earlier positions of that orphan), so consecutive windows run one step apart.
+// prog[wave] = window << 32 | positions done (monotone; a finished window counts as the start of
+// the next one).  The earliest window that cannot place an orphan decides the failure
+// (KAS:183-184): everything before it completed exactly as in the sequential order; later
+// windows stop when they see it.  LDS words other waves write are read through a ballot or a
+// broadcast, so a wave always acts on one answer.
+// ---------------------------------------------------------------------------------------------
 template <int W, int NW>
-KAS_DEV int32_t p4_lists(const LdsView& L, const TopicView& T, int32_t live_count, int64_t (&st)[8]) {
+KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t live_count, int32_t wave,
+                               int64_t (&st)[8], int32_t& fail_win, int32_t& fail_row) {
   const int lane = kasw::lane();
+  uint64_t* prog = (uint64_t*)&L.ctl[KAS_CTL_PROG];
   int32_t oc[NW], total = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) { oc[w] = L.ctl[KAS_CTL_OC + w]; total += oc[w]; }
@@ -720,32 +732,110 @@ KAS_DEV int32_t p4_lists(const LdsView& L, const TopicView& T, int32_t live_coun
 #pragma unroll
     for (int k = 0; k < W; ++k) c[k] = (p >= 0 && k < T.ow) ? T.out[(int64_t)p * T.ow + k] : -1;
   };
-  int32_t head = 0;
-  int32_t p_cur = orphan_row(lane), p_nxt = orphan_row(64 + lane);
-  int32_t c_cur[W], c_nxt[W];
-  row_cells(p_cur, c_cur);
-  for (int32_t g0 = 0; g0 < total; g0 += 64) {
-    row_cells(p_nxt, c_nxt);                                // next window's rows
-    const int32_t p_nn = orphan_row(g0 + 128 + lane);       // the window after that
-    if (p_cur >= 0) {
-      int32_t hc = 0;
-      L.ring_p[lane] = p_cur;
-#pragma unroll
-      for (int k = 0; k < W; ++k) {                         // holders are a prefix of the row
-        L.ring_rack[k * KAS_RING_CAP + lane] = (int16_t)(c_cur[k] >= 0 ? (int32_t)L.rack[c_cur[k]] : -1);
-        hc += c_cur[k] >= 0 ? 1 : 0;
-      }
-      L.ring_meta[lane] = (T.rf - hc) | (hc << 8);
-    }
-    kasw::lockstep();
-    const int32_t n_win = total - g0 < 64 ? total - g0 : 64;
-    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.out, T.ow, st);
-    if (fl >= 0) return L.ring_p[fl];
-    p_cur = p_nxt; p_nxt = p_nn;
+  const int32_t n_win = (total + 63) >> 6;
+  const int32_t prev = wave == 0 ? NW - 1 : wave - 1;       // the wave that has window w - 1
+  const int32_t cap = T.cap, ow = T.ow;
+  constexpr int U = 4;                                     // node positions fetched per LDS round trip
+  int32_t p_nxt = orphan_row(64 * wave + lane);
+  int32_t c_nxt[W];
+  row_cells(p_nxt, c_nxt);
+  for (int32_t w = wave; w < n_win; w += NW) {
+    const int32_t p = p_nxt;
+    int32_t c_cur[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) c_cur[k] = c_nxt[k];
+    p_nxt = orphan_row(64 * (w + NW) + lane);              // my next window's rows: read ahead
+    row_cells(p_nxt, c_nxt);
+    kasw::repoll();
+    if (kasw::ballot(L.ctl[KAS_CTL_FAILWIN] < w) != 0) break;   // an earlier window failed: so has the topic
+    int32_t hc = 0, hr[W];                                  // holders are a prefix of the row
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      hr[k] = (p >= 0 && c_cur[k] >= 0) ? (int32_t)L.rack[c_cur[k]] : -1;
+      hc += (p >= 0 && c_cur[k] >= 0) ? 1 : 0;
+    }
+    int32_t need = p >= 0 ? T.rf - hc : 0;
+    int32_t j = kasw::shfl(L.ctl[KAS_CTL_HEAD], 0);
+    if (lane == 0) prog[wave] = ((uint64_t)(uint32_t)w << 32) | (uint32_t)j;
+    st[4] += 1;
+    bool stop = false;
+    for (;;) {
+      uint64_t pend = kasw::ballot(need > 0);
+      if (pend == 0) break;
+      if (j >= live_count) {                                // KAS:183-184: this orphan cannot be placed
+        if (lane == 0) kasw::lds_atomic_min(&L.ctl[KAS_CTL_FAILWIN], w);
+        stop = true;
+        break;
+      }
+      if (w > 0) {                                          // until window w - 1 is done with [j, j + U)
+        const int32_t upto = j + U < live_count ? j + U : live_count;
+        const uint64_t want = ((uint64_t)(uint32_t)(w - 1) << 32) + (uint32_t)upto;
+        bool abandoned = false;
+        for (;;) {
+          kasw::repoll();
+          if (kasw::ballot(prog[prev] >= want) != 0) break;
+          if (kasw::ballot(L.ctl[KAS_CTL_FAILWIN] < w) != 0) { abandoned = true; break; }
+          kasw::spin_pause();
+        }
+        if (abandoned) { stop = true; break; }
+      }
+      int32_t n[U], slots[U], rk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) n[u] = (int32_t)L.live[j + u < live_count ? j + u : j];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { slots[u] = cap - L.load[n[u]]; rk[u] = (int32_t)L.rack[n[u]]; }
+      int32_t taken[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        taken[u] = 0;
+        if (j + u < live_count && pend != 0) {             // wave-uniform
+          st[5] += 1;
+          if (slots[u] > 0) {
+            bool want = need > 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) want = want && !(k < hc && hr[k] == rk[u]);
+            const uint64_t wm = kasw::ballot(want);
+            if (wm != 0) {
+              const int32_t rank = kasw::popc(wm & kasw::lanemask_lt());
+              if (want && rank < slots[u]) {               // accept (KAS:178-181)
+                T.out[(int64_t)p * ow + hc] = n[u];
+                put<W>(hr, hc, rk[u]);
+                hc += 1;
+                need -= 1;
+              }
+              const int32_t takers = kasw::popc(wm);
+              taken[u] = takers < slots[u] ? takers : slots[u];
+              pend = kasw::ballot(need > 0);
+            }
+          }
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (taken[u] > 0) L.load[n[u]] += taken[u];
+      }
+      kasw::lockstep();
+      j += U;
+      if (lane == 0) prog[wave] = ((uint64_t)(uint32_t)w << 32) | (uint32_t)(j < live_count ? j : live_count);
+    }
+    if (stop) {
+      // failed or abandoned: whoever waits on this window must not hang
+      if (j >= live_count) {
+        const uint64_t left = kasw::ballot(need > 0);
+        fail_win = w;
+        fail_row = kasw::shfl(p, left != 0 ? kasw::first_lane(left) : 0);
+      }
+      if (lane == 0) prog[wave] = (uint64_t)(uint32_t)(w + 1) << 32;
+      break;
+    }
+    // done: full nodes at the front of the live list need not be looked at again
+    if (lane == 0) {
+      int32_t head = L.ctl[KAS_CTL_HEAD];
+      while (head < live_count && L.load[(int32_t)L.live[head]] >= cap) ++head;
+      kasw::lds_atomic_max(&L.ctl[KAS_CTL_HEAD], head);
+      prog[wave] = (uint64_t)(uint32_t)(w + 1) << 32;
+    }
   }
-  return -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -856,7 +946,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   } else {
     for (int32_t i = tid; i < N; i += NT) L.ids[i] = g_node_id[i];
   }
-  if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : 0;
+  if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : (tid == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
   // rack-diverse form of the sticky fill unless switched off or the quota word cannot hold cap
   const bool try_fast = T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && cap >= 0 && cap < (1 << 28);
   if (try_fast)
@@ -916,10 +1006,19 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
       live_count += kasw::popc(m);
     }
     kasw::lockstep();
+    if (lane == 0) L.ctl[KAS_CTL_LIVE] = live_count;
     // ---- P3 + P4: orphans (KAS:52, 133-160) and first fit (KAS:56, 162-186) -----------------
-    const int32_t fail_row = fast ? p4_lists<W, NW>(L, T, live_count, st)
-                                  : p3p4_generic<W>(L, T, nm, accmask, live_count, moved_r, moved_p, st);
-    if (lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
+    if (!fast) {
+      const int32_t fail_row = p3p4_generic<W>(L, T, nm, accmask, live_count, moved_r, moved_p, st);
+      if (lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
+    }
+  }
+  if (fast) {                                                // workgroup-uniform: every wave takes windows
+    kasw::sync();
+    int32_t fail_win = -1, fail_row = -1;
+    p4_lists_parallel<W, NW>(L, T, L.ctl[KAS_CTL_LIVE], wave, st, fail_win, fail_row);
+    kasw::sync();                                            // KAS_CTL_FAILWIN is final: its wave reports the row
+    if (fail_win >= 0 && fail_win == L.ctl[KAS_CTL_FAILWIN] && lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
   }
   {
     const int32_t mr = kasw::wave_sum(moved_r), mp = kasw::wave_sum(moved_p);
@@ -1052,13 +1151,14 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 // chains of similar length (the wavefront lasts as long as its longest chain) and the longest
 // ones start first.  Rank by counting: fine for the batch sizes it is used for.
 // ---------------------------------------------------------------------------------------------
-KAS_DEV void order_permutation(const KasLaunch& a, int32_t tid, int32_t n_threads) {
+// keys[j] = moved_replicas of scenario j, staged by the caller (LDS in the kernel).
+KAS_DEV void order_permutation(const KasLaunch& a, const int32_t* keys, int32_t tid, int32_t n_threads) {
   const int32_t S = a.n_scenarios;
   for (int32_t i = tid; i < S; i += n_threads) {
-    const int32_t ki = a.scenario_results[i].moved_replicas;
+    const int32_t ki = keys[i];
     int32_t rank = 0;
     for (int32_t j = 0; j < S; ++j) {
-      const int32_t kj = a.scenario_results[j].moved_replicas;
+      const int32_t kj = keys[j];
       rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
     }
     a.perm[rank] = i;

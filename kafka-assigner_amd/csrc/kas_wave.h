@@ -89,6 +89,8 @@ KAS_DEV int first_lane(uint64_t m) { return __ffsll((unsigned long long)m) - 1; 
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { return atomicAdd(p, v); }
+KAS_DEV void lds_atomic_min(int* p, int v) { atomicMin(p, v); }
+KAS_DEV void lds_atomic_max(int* p, int v) { atomicMax(p, v); }
 
 KAS_DEV void lds_atomic_or_u32(uint32_t* p, uint32_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -190,7 +190,9 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if (sh.G > 1 && b->n_scenarios > sh.G && b->n_scenarios <= KAS_PAIRING_LIMIT) {
       a.perm = perm.data();                              // the permutation kernel, thread by thread
       kasw::g_emu.cur = 0;
-      for (int32_t tid = 0; tid < 256; ++tid) kas::order_permutation(a, tid, 256);
+      std::vector<int32_t> keys((size_t)b->n_scenarios);
+      for (int32_t j = 0; j < b->n_scenarios; ++j) keys[(size_t)j] = a.scenario_results[j].moved_replicas;
+      for (int32_t tid = 0; tid < 256; ++tid) kas::order_permutation(a, keys.data(), tid, 256);
     }
     const bool pk = sh.packed_ok && !(flags & KAS_FLAG_WIDE_COUNTERS);
     run_fn f = sh.G == 1 ? (pk ? tickets_for_g<1, true>(sh.Wc) : tickets_for_g<1, false>(sh.Wc))

@@ -91,6 +91,8 @@ KAS_DEV int first_lane(uint64_t m) { return __builtin_ctzll(m); }
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+KAS_DEV void lds_atomic_min(int* p, int v) { if (v < *p) *p = v; }
+KAS_DEV void lds_atomic_max(int* p, int v) { if (v > *p) *p = v; }
 KAS_DEV void lds_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }

@@ -74,6 +74,7 @@ def _batch(seed, S, P, N, R, RF, actions, rack_aware=True, cyclic=False, name_ha
     (2048, 64, 8, 2, ("add_k",)),           # N power of two, RF 2
     (777, 40, 10, 5, G.ACTIONS),            # RF 5, ragged last tile
     (640, 24, 8, 4, ("replace1", "remove1")),
+    (8000, 80, 8, 3, ("replace1", "add_k")),  # many P4 windows in flight on all waves; zero-slack strandings
 ])
 def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)

@@ -51,6 +51,7 @@ def test_hip_equals_oracle_small_odd_inputs_without_context_io(sc):
     (2048, 64, 8, 2, ("add_k",)),
     (777, 40, 10, 5, G.ACTIONS),
     (640, 24, 8, 4, ("replace1", "remove1")),
+    (8000, 80, 8, 3, ("replace1", "add_k")),  # many P4 windows in flight on all waves; zero-slack strandings
 ])
 def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
