@@ -159,8 +159,8 @@ def main() -> int:
     if args.stats and rank == 0:
         st = plan.stats().astype(np.float64)
         names = ["setup_us", "p2_hist_quota_us", "p2_keep_p3_us", "p4_us", "p4_windows", "p4_steps",
-                 "p5_rounds", "p2_ranked_tiles_wave0", "order_us", "solver_iterations", "solver_run_rounds",
-                 "solver_blocked", "stager_iterations", "stager_idle", "solver_run_rows", "solver_rows_in_hand"]
+                 "p5_rounds_or_queue_steps", "p2_ranked_tiles_wave0", "order_us", "solver_iterations", "solver_queue_rounds",
+                 "solver_blocked", "stager_iterations", "stager_idle", "solver_queue_rows", "solver_rows_in_hand"]
         scale = [0.01, 0.01, 0.01, 0.01, 1, 1, 1, 1, 0.01, 1, 1, 1, 1, 1, 1, 1]
         summary = {n: {"mean": float(st[:, i].mean() * scale[i]), "max": float(st[:, i].max() * scale[i]),
                        "min": float(st[:, i].min() * scale[i])} for i, n in enumerate(names)}

@@ -237,9 +237,11 @@ int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
  *   [0] setup  [1] P2 histogram + quota  [2] P2 keep-scan + P3  [3] P4 first fit
  *   [4] P4 windows  [5] P4 node steps  [6] P5 rounds (round form)
  *   [7] P2 tiles of wave 0 that needed quota ranking  [8] order kernel time
- *   ticket form: [9] solver iterations  [11] of those with rows but none ready
- *                [10] re-pick rounds spent inside runs  [14] rows decided inside runs
+ *   ticket form: [9] solver steps  [11] of those with rows in hand but none ready
+ *                [6] steps that took the queue path  [10] wins / prefix-sum rounds spent there
+ *                [14] rows decided inside queues  [15] sum over steps of rows in hand
  *                [12] stager iterations  [13] of those without work
+ *   ([4], [5] count wave 0's share of the P4 windows / node positions)
  * n = capacity of out in int64 elements (>= KAS_STATS_PER_SCENARIO * n_scenarios).  Blocks until the
  * plan's last launch has finished. */
 #define KAS_STATS_PER_SCENARIO 16

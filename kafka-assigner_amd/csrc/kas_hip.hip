@@ -46,7 +46,8 @@ __global__ __launch_bounds__(192) void kas_order_ticket_kernel(KasLaunch a) {
 }
 
 __global__ __launch_bounds__(256) void kas_order_permutation_kernel(KasLaunch a) {
-  __shared__ int32_t keys[KAS_PAIRING_LIMIT];               // every workgroup ranks against all scenarios
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  int32_t* keys = (int32_t*)kas_lds;                        // [n_scenarios]: every workgroup ranks against all
   for (int32_t j = (int32_t)threadIdx.x; j < a.n_scenarios; j += (int32_t)blockDim.x)
     keys[j] = a.scenario_results[j].moved_replicas;
   __syncthreads();
@@ -375,7 +376,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   if (tickets && p->G > 1 && p->n_scenarios > p->G && p->n_scenarios <= KAS_PAIRING_LIMIT) {
     // scenarios that share a solver wavefront should have P5 chains of similar length
     a.perm = p->d_perm;
-    hipLaunchKernelGGL(kas_order_permutation_kernel, dim3((unsigned)((p->n_scenarios + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kas_order_permutation_kernel, dim3((unsigned)((p->n_scenarios + 255) / 256)), dim3(256),
+                       sizeof(int32_t) * (size_t)p->n_scenarios, st, a);
     KAS_HIP_TRY(hipGetLastError());
   }
   if (tickets)

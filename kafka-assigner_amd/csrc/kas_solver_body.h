@@ -1171,8 +1171,8 @@ KAS_DEV void order_permutation(const KasLaunch& a, const int32_t* keys, int32_t 
 // finished.  Lane l of every wave owns the rows li, li + GL, li + 2 GL, ... (li = l % GL) of every
 // solved topic of its scenario, in order.
 //
-// The solver's loop is a chain of ~(number of orphans) dependent steps per scenario, so nothing
-// with memory latency may sit in it: it touches LDS only.  The stager streams the fill kernel's
+// The solver's loop is a chain of dependent steps (rows waiting for earlier rows on a shared
+// node), so nothing with memory latency may sit in it: it touches LDS only.  The stager streams the fill kernel's
 // rows (node indices) from HBM one GL-row tile at a time, hands out tickets in row order
 // (ticket of (row, node) = how many earlier rows of the scenario hold that node: a per-node
 // running count + the rank among the tile's lanes holding it, from one lane mask per node),
