@@ -175,6 +175,10 @@ def test_device_resident_tables_and_what_if_shared_cur():
     assert plan.algorithmic_bytes == fb.algorithmic_bytes()
     stats = plan.stats()
     assert stats.shape == (S, 16) and (stats[:, 1] > 0).all() and (stats[:, 9] > 0).all()
+    # the ticket form decided rows inside queues (rows waiting in line on one node commit together):
+    # the parity above covers that path, not only the one-row-per-step path
+    ok = sr["status"] == abi.KAS_OK
+    assert ok.any() and (stats[ok, 14] > 0).any() and (stats[ok, 6] > 0).any()
     plan.close()
 
 
