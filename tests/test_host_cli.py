@@ -123,3 +123,52 @@ def test_without_a_gpu_the_solve_fails_loudly(cli, tmp_path):
     path, _ = _snapshot(tmp_path, range(6), {})
     r = _run(cli, "--snapshot", path, "--mode", "PRINT_REASSIGNMENT")
     assert r.returncode == 2 and "no HIP device" in r.stderr                  # no CPU fallback
+
+
+def test_export_scenarios_writes_cli_snapshots(tmp_path):
+    """tools/export_scenarios.py (input side of the JVM harness) writes snapshots the
+    CLI reads back unchanged."""
+    out = tmp_path / "scen"
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "export_scenarios.py"), "--out", str(out),
+                        "--scenarios", "2", "--partitions", "300", "--brokers", "20", "--racks", "5"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    snap = json.load(open(out / "scen_0000.json"))
+    assert len(snap["partitions"]) == 300 and set(snap["solve_brokers"]) <= {b["id"] for b in snap["brokers"]}
+    cli_path = kbuild.build_host()
+    r = _run(cli_path, "--snapshot", str(out / "scen_0000.json"), "--mode", "PRINT_CURRENT_ASSIGNMENT")
+    assert r.returncode == 0
+    assert _sections(r.stdout)["CURRENT ASSIGNMENT"]["partitions"] == snap["partitions"]
+
+
+@pytest.mark.gpu
+def test_exported_scenarios_through_the_cli_equal_the_oracle(cli, tmp_path):
+    """The path a JVM site would diff against JavaGolden: exported snapshot -> CLI -> NEW ASSIGNMENT,
+    here against the oracle on the same inputs (list-equal, or the same failing partition)."""
+    import numpy as np
+    from kafka_assigner_amd.flatten import Scenario, Topic, flatten
+    from oracle_lib import oracle_solve
+    from kafka_assigner_amd import abi
+    out = tmp_path / "scen"
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "export_scenarios.py"), "--out", str(out),
+                        "--scenarios", "4", "--partitions", "2000", "--brokers", "40", "--racks", "8"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for s in range(4):
+        path = str(out / f"scen_{s:04d}.json")
+        snap = json.load(open(path))
+        cur = {p["partition"]: p["replicas"] for p in snap["partitions"]}
+        racks = {b["id"]: b["rack"] for b in snap["brokers"]}
+        fb = flatten([Scenario(brokers=snap["solve_brokers"], racks=racks, want_context=False,
+                               topics=[Topic("t0", cur, 3, None)])])
+        want = oracle_solve(fb)
+        r = _run(cli, "--snapshot", path, "--mode", "PRINT_REASSIGNMENT",
+                 "--integer_broker_ids", ",".join(str(b) for b in snap["solve_brokers"]))
+        if want.scenario_results["status"][0] == abi.KAS_OK:
+            assert r.returncode == 0, r.stderr
+            new = _sections(r.stdout)["NEW ASSIGNMENT"]["partitions"]
+            got = np.array([p["replicas"] for p in new], dtype=np.int32)
+            np.testing.assert_array_equal(got.reshape(-1), want.out[:fb.out_len])
+        else:
+            assert r.returncode == 1
+            assert "Partition %d could not be fully assigned!" % want.scenario_results["fail_partition"][0] in r.stderr
