@@ -1192,6 +1192,10 @@ KAS_DEV void order_permutation(const KasLaunch& a, const int32_t* keys, int32_t 
 #define KAS_RING_SLOTS 4
 #endif
 // rows a run must decide beyond the ones that were ready anyway for its path to pay
+// s_sleep argument of a stager / retirer iteration that found nothing to do (~64 cycles each)
+#ifndef KAS_IDLE_NAP
+#define KAS_IDLE_NAP 4
+#endif
 #ifndef KAS_RUN_MIN_GAIN
 #define KAS_RUN_MIN_GAIN 3
 #endif
@@ -1635,7 +1639,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;
-      if (kasw::ballot(staging) == 0) { f_idle += 1; kasw::nap<4>(); }
+      if (kasw::ballot(staging) == 0) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
     }
     if (a.stats && have_s && li == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
@@ -1709,7 +1713,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
       for (int u = 0; u < UR; ++u) retired = gather(rb[u]) || retired;
       if (kasw::ballot(!fin) == 0) break;
-      if (kasw::ballot(retired) == 0) kasw::nap<4>();
+      if (kasw::ballot(retired) == 0) kasw::nap<KAS_IDLE_NAP>();
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) { finish(ra[u]); finish(rb[u]); }
