@@ -138,6 +138,9 @@ run_fn rounds_for(int Wc) {
 
 }  // namespace
 
+// rows the ticket-form solver decided inside queues during the last kas_emu_solve_batch (summed
+// over scenarios): lets a CPU test assert that the queue path ran, not only the one-row path
+static long g_last_queue_rows = 0;
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
 // 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice)
 extern "C" __attribute__((visibility("default")))
@@ -162,7 +165,8 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
   a.accmask = accmask.data(); a.accmask_off = sh.accmask_off.data();
   std::vector<int64_t> stats((size_t)KAS_STATS_PER_SCENARIO * (size_t)(b->n_scenarios + 1), 0);
-  a.stats = getenv("KAS_EMU_STATS") ? stats.data() : nullptr;
+  a.stats = stats.data();
+  g_last_queue_rows = 0;
   a.orph = orph.data(); a.orph_off = sh.orph_off.data();
   std::vector<int32_t> perm((size_t)b->n_scenarios + 1, -1);
   a.perm = nullptr;
@@ -203,7 +207,8 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
       RunArgs ra{&a, s, lds.data()};
       if (kasw::run_block(f, &ra, 3) != 0) return bad("order (tickets)", s);
     }
-    if (a.stats) {
+    for (int32_t s = 0; s < b->n_scenarios; ++s) g_last_queue_rows += (long)a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 14];
+    if (getenv("KAS_EMU_STATS")) {
       for (int32_t s = 0; s < b->n_scenarios; ++s) {
         const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
         fprintf(stderr, "emu stats s=%d solver_iter=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld\n", s,
@@ -223,3 +228,6 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
 
 extern "C" __attribute__((visibility("default")))
 long kas_emu_collectives(void) { return kasw::g_emu.collectives; }
+
+extern "C" __attribute__((visibility("default")))
+long kas_emu_last_queue_rows(void) { return g_last_queue_rows; }

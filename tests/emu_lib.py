@@ -35,8 +35,14 @@ def lib():
         L.kas_emu_solve_batch.restype = C.c_int
         L.kas_emu_solve_batch.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
                                           C.c_uint, C.c_char_p, C.c_int]
+        L.kas_emu_last_queue_rows.restype = C.c_long
         _LIB = L
     return _LIB
+
+
+def last_queue_rows() -> int:
+    """Rows the ticket-form solver decided inside queues during the last emu_solve."""
+    return int(lib().kas_emu_last_queue_rows())
 
 
 def emu_solve(fb: FlatBatch, flags: int = 0) -> HostOutputs:

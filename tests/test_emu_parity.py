@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import emu_solve
+from emu_lib import emu_solve, last_queue_rows
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_oracle_vs_literal import scenarios
@@ -145,3 +145,16 @@ def test_emu_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
     assert_same_outputs(fb, want, emu_solve(fb), "emu multi-topic tickets")
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu multi-topic rounds")
     assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 12) | (2 << 8)), "emu multi-topic, 2 scenarios per wave")
+
+
+def test_emu_queue_path_runs_and_agrees():
+    """Added brokers fill up from consecutive orphans, so rows wait in line on one node: the ticket
+    form decides such queues in one step (thresholds + prefix sums in rank space).  Assert that
+    path really ran here (the emulator counts the rows decided inside queues) and agrees with the
+    oracle, for both group widths and both counter layouts."""
+    fb = _batch(4321, 4, 6000, 100, 10, 3, ("add_k", "mixed"))
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).any()
+    for flags in (0, 1 << 12, 4 | (4 << 12)):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu flags {flags:#x}")
+        assert last_queue_rows() > 100, "the queue path did not run"
