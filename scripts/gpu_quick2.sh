@@ -5,5 +5,4 @@ export TMPDIR=/tmp
 run() {  # lib inflight
   KAS_HIP_LIB=$PWD/kafka-assigner_amd/csrc/$1 timeout 300 python bench.py --no-cpu --check 2 --steps 32 --warmup 8 --in-flight $2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1 f$2', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['fill_kernel_avg_us']), round(d['roofline']['order_kernel_avg_us']))"
 }
-for l in libkas_hip.so libkas_hip_nap1.so libkas_hip_nap2.so libkas_hip_nap8.so libkas_hip.so; do run $l 8; done
-for l in libkas_hip.so libkas_hip_nap1.so libkas_hip_nap8.so; do run $l 1; done
+for l in libkas_hip.so libkas_hip_lb6.so libkas_hip.so libkas_hip_lb6.so; do run $l 8; done
