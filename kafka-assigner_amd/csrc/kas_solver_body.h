@@ -1192,6 +1192,10 @@ KAS_DEV void order_permutation(const KasLaunch& a, const int32_t* keys, int32_t 
 #define KAS_RING_SLOTS 4
 #endif
 // rows a run must decide beyond the ones that were ready anyway for its path to pay
+// a row waiting on exactly one node with this many rows ahead of it nominates the node
+#ifndef KAS_RUN_NOMINATE
+#define KAS_RUN_NOMINATE 2
+#endif
 // s_sleep argument of a stager / retirer iteration that found nothing to do (~64 cycles each)
 #ifndef KAS_IDLE_NAP
 #define KAS_IDLE_NAP 4
@@ -1411,7 +1415,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         // back off: the next attempts are skipped, twice as many each time, up to 16)
         uint64_t nb = 0ull;
         if (run_skip > 0) run_skip -= 1;
-        else nb = kasw::ballot(cv && d_any == 2u && d_sum == 2u);
+        else nb = kasw::ballot(cv && d_any == (uint32_t)KAS_RUN_NOMINATE && d_sum == (uint32_t)KAS_RUN_NOMINATE);
         if (nb != 0ull) {
           constexpr uint64_t GLM = GL == 64 ? ~0ull : ((1ull << GL) - 1ull);
           const int32_t gsh = g * GL;
