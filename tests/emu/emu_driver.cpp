@@ -25,8 +25,26 @@ static void lane_entry() {
   swapcontext(&g_emu.lane_ctx[g_emu.cur], &g_emu.main_ctx);
 }
 
+// KAS_EMU_CHAOS=<seed>: waves no longer advance in step.  Each round a wave whose lanes have all
+// arrived at a collective is released only with probability 1/2 (never none of them), and now and
+// then one wave is held back for a long stretch — relative wave speeds on hardware are arbitrary,
+// and the protocols between waves (ring tags, P4 progress words) must not depend on them.
+static uint64_t g_chaos = 0;
+static uint32_t chaos_next() {
+  g_chaos ^= g_chaos << 13; g_chaos ^= g_chaos >> 7; g_chaos ^= g_chaos << 17;
+  return (uint32_t)(g_chaos >> 32);
+}
+
 int run_block(void (*fn)(void*), void* arg, int n_waves) {
   Emu& e = g_emu;
+  static int chaos_init = 0;
+  if (!chaos_init) {
+    chaos_init = 1;
+    const char* c = getenv("KAS_EMU_CHAOS");
+    if (c && *c) g_chaos = 0x9E3779B97F4A7C15ull * (uint64_t)(strtoull(c, nullptr, 10) + 1);
+  }
+  int held_wave = -1;
+  long held_rounds = 0, rounds = 0;
   const int n = 64 * n_waves;
   if (n > KAS_EMU_MAX_LANES) return -1;
   if (!g_stacks) g_stacks = (char*)malloc((size_t)KAS_EMU_MAX_LANES * STACK_BYTES);
@@ -54,7 +72,8 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
     if (done == n) return 0;
     // 2. release every wave whose 64 fibers all wait at the same wave collective; a workgroup
     //    barrier releases when every fiber of the block waits at it
-    int released = 0, at_sync = 0;
+    int released = 0, at_sync = 0, n_ready = 0;
+    int ready_waves[KAS_EMU_MAX_LANES / 64];
     for (int w = 0; w < n_waves; ++w) {
       int parked = 0, finished = 0, k = -1;
       bool mixed = false;
@@ -70,10 +89,31 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
       if (finished > 0) { fprintf(stderr, "emu: wave %d: %d lanes exited while others wait at a collective\n", w, finished); return -1; }
       if (mixed) { fprintf(stderr, "emu: wave %d: divergence, lanes wait at different collectives\n", w); return -1; }
       if (k == K_SYNC) { at_sync += 64; continue; }
-      for (int i = 64 * w; i < 64 * w + 64; ++i) e.state[i] = S_RUNNABLE;
-      ++released;
-      e.collectives++;
+      ready_waves[n_ready++] = w;
     }
+    if (n_ready > 0) {
+      int first_released = -1;
+      if (g_chaos != 0 && n_waves > 1) {
+        if (held_rounds > 0) --held_rounds; else held_wave = -1;
+        if (held_wave < 0 && (chaos_next() & 1023u) == 0) { held_wave = (int)(chaos_next() % (uint32_t)n_waves); held_rounds = 50 + (long)(chaos_next() % 2000u); }
+      }
+      for (int r = 0; r < n_ready; ++r) {
+        const int w = ready_waves[r];
+        bool go = true;
+        if (g_chaos != 0 && n_waves > 1) go = w != held_wave && (chaos_next() & 1u) != 0;
+        if (!go) continue;
+        for (int i = 64 * w; i < 64 * w + 64; ++i) e.state[i] = S_RUNNABLE;
+        ++released; e.collectives++;
+        if (first_released < 0) first_released = w;
+      }
+      if (released == 0) {                                 // never stall everybody
+        int w = ready_waves[chaos_next() % (uint32_t)n_ready];
+        if (w == held_wave && n_ready > 1) w = ready_waves[(w == ready_waves[0]) ? 1 : 0];
+        for (int i = 64 * w; i < 64 * w + 64; ++i) e.state[i] = S_RUNNABLE;
+        ++released; e.collectives++;
+      }
+    }
+    if (++rounds > 400000000L) { fprintf(stderr, "emu: no end in sight after %ld rounds (livelock?)\n", rounds); return -1; }
     if (at_sync == n) {
       for (int i = 0; i < n; ++i) e.state[i] = S_RUNNABLE;
       ++released;

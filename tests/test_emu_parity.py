@@ -158,3 +158,31 @@ def test_emu_queue_path_runs_and_agrees():
     for flags in (0, 1 << 12, 4 | (4 << 12)):
         assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu flags {flags:#x}")
         assert last_queue_rows() > 100, "the queue path did not run"
+
+
+def test_emu_protocols_survive_arbitrary_wave_speeds():
+    """The waves of a workgroup talk through LDS words only (ring tags of the order kernel, P4
+    progress words of the fill kernel).  KAS_EMU_CHAOS makes the emulator release waves at random
+    and hold one back for long stretches; the results must not change.  (Own processes: the seed
+    is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, '.')\n"
+        "from test_emu_parity import _batch\n"
+        "from emu_lib import emu_solve\n"
+        "from oracle_lib import oracle_solve\n"
+        "from parity_util import assert_same_outputs\n"
+        "from kafka_assigner_amd import generator as G\n"
+        "for acts, P, N in ((G.ACTIONS, 3000, 60), (('replace1', 'add_k'), 5000, 80)):\n"
+        "    fb = _batch(99, 4, P, N, 8, 3, acts)\n"
+        "    want = oracle_solve(fb)\n"
+        "    for flags in (0, 1 << 12, (8 << 8) | (4 << 12)):\n"
+        "        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), 'chaos')\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for seed in ("1", "7"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                           env=dict(os.environ, KAS_EMU_CHAOS=seed), timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
