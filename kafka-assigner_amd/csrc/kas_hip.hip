@@ -27,11 +27,11 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// min waves per SIMD: the LDS carve-up allows 4 workgroups of 4 wavefronts per CU at N = 1000,
-// but the fill kernel shares the CUs with order workgroups of other batches in flight: at 96 VGPRs
-// (5 waves per SIMD) three fill workgroups leave room for two of those, at 128 (4 per SIMD) fill
-// workgroups fill the register files on their own.  Measured: +3.8 % whole-job throughput at 8
-// batches in flight, fill alone 12 % slower (cold paths and the P4 prologue spill a little more).
+// min waves per SIMD: at N = 1000 the LDS carve-up (31 KB) allows 5 workgroups of 4 wavefronts per
+// CU; at 128 VGPRs (4 waves per SIMD) four of them fill the register files, at 96 the fifth fits
+// and order workgroups of other batches in flight share the CU more easily.  Measured: +3.8 %
+// whole-job throughput at 8 batches in flight, fill alone 12 % slower (cold paths and the P4
+// prologue spill a little more).
 #ifndef KAS_FILL_MIN_WAVES
 #define KAS_FILL_MIN_WAVES 5
 #endif
