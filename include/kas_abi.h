@@ -34,6 +34,12 @@
  *                                                               ids in preference order, -1 padded
  *   IllegalStateException (KAS:183-184, KTA:65-69)              kas_topic_result.status/.fail_partition
  *
+ * The boundary is generateAssignment-level: the replication-factor preconditions of
+ * KafkaTopicAssigner.java:65-69 are applied by the solver (KAS_FAIL_RF_NOT_POSITIVE /
+ * KAS_FAIL_RF_GT_BROKERS), i.e. rf outside [1, N] never reaches the KAS:40-63 phases, exactly
+ * as no call through KTA:70-71 can carry such an rf.  (getRackAwareAssignment itself has no such
+ * checks; callers that bypass KafkaTopicAssigner see the KTA status for those two ranges.)
+ *
  * A *scenario* is one cluster snapshot: one broker set + rack map and an ordered list of
  * topics that share one Context (what one `--mode PRINT_REASSIGNMENT` run of
  * KafkaAssignmentGenerator.java:131-187 solves).  A *batch* is many independent scenarios;
@@ -53,7 +59,7 @@
 extern "C" {
 #endif
 
-#define KAS_ABI_VERSION 2
+#define KAS_ABI_VERSION 3
 
 /* Longest replica list the kernels keep in registers: max(cur_width, rf) <= KAS_MAX_WIDTH. */
 #define KAS_MAX_WIDTH 8
@@ -192,12 +198,27 @@ void kas_ctx_destroy(kas_ctx* ctx);
 int  kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan);
 void kas_plan_destroy(kas_plan* plan);
 
+/* What a solve of this plan launches, for measurement records: the instantiated kernels with
+ * their template arguments (list width class W, wavefronts per scenario workgroup NW, scenarios
+ * per solver wavefront G, packed counters), the form of each phase and the launch geometry, as
+ * one line of text, e.g.
+ *   "kas_fill_kernel<3,4>[quota] grid=1000x256 lds=32016 + kas_order_permutation_kernel +
+ *    kas_order_ticket_kernel<3,2,true> grid=500x192 lds=25744"
+ * Reflects the current kas_plan_set_flags state.  Returns the length written (excluding the
+ * terminating NUL; truncated to n-1), or a negative KAS_E_* code. */
+int kas_plan_describe(const kas_plan* plan, char* buf, int n);
+
 /* Bytes of HBM the path must move per solve of this plan:
  * sum over topics 4*P*(cur_width + out_width) + sum over scenarios 8*N (+ ctx in/out). */
 int64_t kas_plan_algorithmic_bytes(const kas_plan* plan);
 
 /* Solve with every bulk table already resident in HBM.  `hip_stream` is a hipStream_t
- * (NULL = the context's own stream).  Asynchronous: returns after enqueueing. */
+ * (NULL = the context's own stream).  Asynchronous: returns after enqueueing.
+ * A plan owns the scratch of ONE solve (orphan lists, accept masks, scenario order, device
+ * counters): it supports one solve in flight.  Solves of the same plan are therefore ordered —
+ * a solve enqueued on a different stream than the plan's previous one first waits (on the device,
+ * hipStreamWaitEvent) for that previous solve to finish.  Callers that want several batches in
+ * flight create one plan per batch in flight (what bench.py does). */
 int kas_solve_device(kas_plan* plan, const kas_tables* device_tables, void* hip_stream);
 
 /* Block until everything enqueued on the context's own stream has finished. */

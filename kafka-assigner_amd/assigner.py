@@ -48,7 +48,7 @@ def resolve_replication_factor(topic, current_assignment: Dict[int, Sequence[int
     return replication_factor
 
 
-def raise_for_status(topic, status: int, fail_partition: int) -> None:
+def raise_for_status(topic, status: int, fail_partition: int, replication_factor=None) -> None:
     """Turn a kas_topic_result status back into the exception the reference throws."""
     if status == abi.KAS_OK:
         return
@@ -58,9 +58,11 @@ def raise_for_status(topic, status: int, fail_partition: int) -> None:
     if status == abi.KAS_FAIL_RF_NOT_POSITIVE:
         raise IllegalStateException(
             "Topic " + str(topic) + " does not have a positive replication factor!")
-    if status == abi.KAS_FAIL_RF_GT_BROKERS:
+    if status == abi.KAS_FAIL_RF_GT_BROKERS:                               # KTA:67-69
         raise IllegalStateException(
-            "Topic " + str(topic) + " has a higher replication factor than available brokers!")
+            "Topic " + str(topic) + " has a higher replication factor (" +
+            str(replication_factor if replication_factor is not None else "?") +
+            ") than available brokers!")
     if status == abi.KAS_FAIL_HASH_INDEX:                                  # KAS:190-192
         raise ArrayIndexOutOfBoundsException("negative node processing index")
     raise RuntimeError("solver status " + abi.STATUS_NAMES.get(status, str(status)))
@@ -84,7 +86,7 @@ def _solve_one(solve_host, topic, current_assignment, node_rack_assignment, node
     fb = flatten([sc])
     ho = solve_host(fb)
     tr = ho.topic_results[0]
-    raise_for_status(topic, int(tr["status"]), int(tr["fail_partition"]))
+    raise_for_status(topic, int(tr["status"]), int(tr["fail_partition"]), replication_factor)
     if context is not None:
         # counters of brokers outside `nodes` are untouched by this call (they are not in the
         # flat table), exactly as the reference only touches nodes it iterates
@@ -98,7 +100,15 @@ def _solve_one(solve_host, topic, current_assignment, node_rack_assignment, node
 
 
 class KafkaAssignmentStrategy:
-    """Static entry point mirroring KAS:40-63, solved on the GPU through the C ABI."""
+    """Static entry point mirroring KAS:40-63, solved on the GPU through the C ABI.
+
+    The C ABI is a generateAssignment-level boundary (include/kas_abi.h): the solver applies
+    KafkaTopicAssigner's two replication-factor preconditions (KTA:65-69) itself.  The reference's
+    getRackAwareAssignment has no such checks — called directly with rf > |nodes| it throws
+    "Partition p could not be fully assigned!" from KAS:183-184 and with rf <= 0 it returns the
+    sticky-filled map — so a DIRECT caller of this mirror gets KafkaTopicAssigner's message for
+    those two argument ranges instead.  Every in-range call (what KTA:70-71 can pass) is
+    identical."""
 
     @staticmethod
     def get_rack_aware_assignment(topic_name, current_assignment: Dict[int, Sequence[int]],

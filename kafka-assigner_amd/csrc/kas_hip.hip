@@ -152,6 +152,7 @@ struct kas_plan {
   int32_t* d_perm;
   int64_t* d_stats;
   hipStream_t last_stream;
+  int last_slot;                // timer slot of the most recent solve (-1: none yet)
   // kernel timing: event pairs recorded around every launch on the launch stream
   hipEvent_t ev_start[KAS_TIMER_SLOTS], ev_mid[KAS_TIMER_SLOTS], ev_stop[KAS_TIMER_SLOTS];
   int timer_next, timer_count;
@@ -294,6 +295,7 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
   p->d_accmask_off = nullptr; p->d_accmask = nullptr; p->d_stats = nullptr; p->last_stream = ctx->stream;
+  p->last_slot = -1;
   p->d_orph_off = nullptr; p->d_orph = nullptr; p->d_perm = nullptr;
   p->timer_next = 0; p->timer_count = 0;
   if (p->lds.total > KAS_LDS_LIMIT) {
@@ -345,6 +347,47 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   return KAS_E_OK;
 }
 
+// the launch decisions of kas_solve_device, in one place
+struct KasLaunchPlan {
+  bool tickets, pairing;
+  int packed;
+  unsigned fill_grid, fill_block, order_grid, order_block;
+  size_t fill_lds, order_lds;
+};
+static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
+  KasLaunchPlan lp;
+  lp.tickets = p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
+  lp.packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
+  lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G && p->n_scenarios <= KAS_PAIRING_LIMIT;
+  lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
+  lp.fill_lds = (size_t)p->lds.total;
+  if (lp.tickets) {
+    lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
+    lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed);
+  } else {
+    lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
+    lp.order_lds = (size_t)kas_order_round_lds(p->shape.n_max, p->Wc);
+  }
+  return lp;
+}
+
+int kas_plan_describe(const kas_plan* p, char* buf, int n) {
+  if (!p || !buf || n <= 0) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  const KasLaunchPlan lp = kas_launch_plan(p);
+  const bool generic = (p->flags & KAS_FLAG_GENERIC_FILL) || !p->shape.with_x;
+  char order[192];
+  if (lp.tickets)
+    snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu",
+             lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
+             lp.order_grid, lp.order_block, lp.order_lds);
+  else
+    snprintf(order, sizeof(order), "kas_order_round_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
+             lp.order_block, lp.order_lds);
+  const int len = snprintf(buf, (size_t)n, "kas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu + %s", p->Wc, p->NW,
+                           generic ? "sweeps" : "quota", lp.fill_grid, lp.fill_block, lp.fill_lds, order);
+  return len < n ? len : n - 1;
+}
+
 int64_t kas_plan_algorithmic_bytes(const kas_plan* plan) {
   return plan ? plan->shape.algorithmic_bytes : -1;
 }
@@ -364,19 +407,22 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off; a.stats = p->d_stats;
   a.orph = p->d_orph; a.orph_off = p->d_orph_off;
   a.perm = nullptr;
+  // the plan's scratch serves one solve at a time: order this solve behind the previous one
+  if (p->last_slot >= 0 && p->last_stream != st)
+    KAS_HIP_TRY(hipStreamWaitEvent(st, p->ev_stop[p->last_slot], 0));
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
   a.flags = p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL);
-  const bool tickets = p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
+  const KasLaunchPlan lp = kas_launch_plan(p);
+  const bool tickets = lp.tickets;
   const int slot = p->timer_next;
   KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
-  hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3((unsigned)p->n_scenarios), dim3(64u * (unsigned)p->NW),
-                     (size_t)p->lds.total, st, a);
+  hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
   KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
-  const int packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
-  if (tickets && p->G > 1 && p->n_scenarios > p->G && p->n_scenarios <= KAS_PAIRING_LIMIT) {
+  const int packed = lp.packed;
+  if (lp.pairing) {
     // scenarios that share a solver wavefront should have P5 chains of similar length
     a.perm = p->d_perm;
     hipLaunchKernelGGL(kas_order_permutation_kernel, dim3((unsigned)((p->n_scenarios + 255) / 256)), dim3(256),
@@ -384,13 +430,13 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
     KAS_HIP_TRY(hipGetLastError());
   }
   if (tickets)
-    hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3((unsigned)((p->n_scenarios + p->G - 1) / p->G)),
-                       dim3(192), (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, packed), st, a);
+    hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
+                       lp.order_lds, st, a);
   else
-    hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
-                       (size_t)kas_order_round_lds(p->shape.n_max, p->Wc), st, a);
+    hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
   KAS_HIP_TRY(hipEventRecord(p->ev_stop[slot], st));
+  p->last_slot = slot;
   p->timer_next = (slot + 1) % KAS_TIMER_SLOTS;
   if (p->timer_count < KAS_TIMER_SLOTS) p->timer_count += 1;
   return KAS_E_OK;

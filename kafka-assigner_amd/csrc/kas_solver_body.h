@@ -948,7 +948,9 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   }
   if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : (tid == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
   // rack-diverse form of the sticky fill unless switched off or the quota word cannot hold cap
-  const bool try_fast = T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && cap >= 0 && cap < (1 << 28);
+  // (a topic without rows takes the general form: the row stream of the fast form re-reads the last
+  // row for lanes past the end and there is no row to read)
+  const bool try_fast = P > 0 && T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && cap >= 0 && cap < (1 << 28);
   if (try_fast)
     for (int32_t i = tid; i < N * W; i += NT) L.x[i] = 0;
   kasw::sync();

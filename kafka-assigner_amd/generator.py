@@ -75,6 +75,8 @@ def scenario_action(seed: int, s: int, N: int, R: int, actions: Sequence[str] = 
         return act, perturb_brokers(N, R, add=int(rng.integers(1, max_add + 1)))
     if act == "replace1":
         return act, perturb_brokers(N, R, remove=[int(rng.integers(N))], add=1)
+    if act == "add50":                      # BASELINE.json configs[3]: brokers 1000-1049, rack id mod R
+        return act, perturb_brokers(N, R, add=50)
     if act == "mixed":
         k = int(rng.integers(1, max_remove + 1))
         return act, perturb_brokers(N, R, remove=rng.choice(N, size=k, replace=False).tolist(),

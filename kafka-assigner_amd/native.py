@@ -23,6 +23,7 @@ SYMBOLS = [
     "kas_ctx_create", "kas_ctx_destroy", "kas_ctx_synchronize", "kas_plan_create",
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
     "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
+    "kas_plan_describe",
 ]
 
 _LIB = None
@@ -77,6 +78,8 @@ def load():
                                           C.POINTER(C.c_int)]
     L.kas_plan_set_flags.restype = C.c_int
     L.kas_plan_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+    L.kas_plan_describe.restype = C.c_int
+    L.kas_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.kas_plan_stats.restype = C.c_int
     L.kas_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64]
     if L.kas_abi_version() != abi.KAS_ABI_VERSION:
@@ -140,6 +143,14 @@ class Plan:
 
     def set_flags(self, flags: int):
         _check(self._lib.kas_plan_set_flags(self._h, flags))
+
+    def describe(self) -> str:
+        """The kernels a solve of this plan launches (template arguments, grids, LDS)."""
+        buf = C.create_string_buffer(512)
+        n = self._lib.kas_plan_describe(self._h, buf, 512)
+        if n < 0:
+            _check(n)
+        return buf.value.decode()
 
     def stats(self) -> np.ndarray:
         """Per-scenario device counters of the last solve: int64 [S, 16] =

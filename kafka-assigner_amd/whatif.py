@@ -47,7 +47,10 @@ class VariantResult:
 
     def raise_for_status(self):
         """The exception the reference's CLI run would have died with (KAS:183-184 ...)."""
-        raise_for_status(self.fail_topic, self.status, self.fail_partition)
+        rf = None
+        if self.fail_topic is not None and self._plan is not None:
+            rf = self._plan.rfs[self._plan.topic_names.index(self.fail_topic)]
+        raise_for_status(self.fail_topic, self.status, self.fail_partition, rf)
 
     def assignment(self, topic: str) -> Dict[int, List[int]]:
         """partition -> new replica list of `topic` under this variant."""

@@ -1,0 +1,137 @@
+/*
+ * kas_batch_loop.h — batch driver shared by the two CPU solvers under oracle/ (the structure-
+ * faithful oracle, kas_oracle.c, and the flat-array baseline, kas_cpu_fast.c).
+ * TEST / BENCH INFRASTRUCTURE, NOT PRODUCT: nothing under kafka-assigner_amd/ includes this.
+ *
+ * Semantics of kas_solve_host (include/kas_abi.h): scenarios are independent; inside a scenario
+ * the topics run in order against one Context (KafkaTopicAssigner.java:19-23 keeps one Context
+ * per assigner instance) and the first failure skips the rest — the CLI run aborts at the first
+ * exception (KafkaAssignmentGenerator.java:173-184).
+ *
+ * The threaded entry splits the SCENARIOS over n_threads pthreads inside one C call (a shared
+ * atomic cursor; every scenario is solved by exactly one thread with its own scratch), which is
+ * what "scenario-parallel on all host cores" in BASELINE.md section 3 asks for.
+ */
+#ifndef KAS_BATCH_LOOP_H
+#define KAS_BATCH_LOOP_H
+
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <unistd.h>
+
+#include "kas_abi.h"
+
+typedef int (*kas_topic_fn)(int32_t name_hash, int32_t P, const int32_t* part_id,
+                            const int32_t* cur, int32_t cur_width, const int32_t* cur_len,
+                            const int32_t* in_partitions, int32_t N, const int32_t* node_id,
+                            const int32_t* node_rack, int32_t rf, int32_t* counter, int32_t cw,
+                            int32_t* out, int32_t out_width, kas_topic_result* res, int64_t* probes);
+
+static void kas_loop_fill_minus_one(int32_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = -1;
+}
+
+/* one scenario: the per-topic loop of KAG:173-184 over one Context (KAS:360-369) */
+static void kas_loop_scenario(const kas_batch_desc* b, const kas_tables* t, int32_t s, kas_topic_fn solve) {
+  const kas_scenario_desc* sd = &b->scenarios[s];
+  kas_scenario_result* sr = &t->scenario_results[s];
+  sr->status = KAS_OK; sr->fail_topic = -1; sr->fail_partition = -1;
+  sr->moved_replicas = 0; sr->moved_partitions = 0; sr->reserved = 0; sr->digest = 0;
+  const int32_t N = sd->n_nodes;
+  const int32_t* node_id = b->node_id + sd->node_off;
+  const int32_t* node_rack = b->node_rack + sd->node_off;
+
+  const int32_t cw = KAS_MAX_WIDTH;
+  int32_t* counter = (int32_t*)calloc((size_t)(N > 0 ? N : 1) * cw, sizeof(int32_t));
+  if (sd->ctx_off >= 0 && sd->ctx_width > 0)
+    for (int32_t n = 0; n < N; ++n)
+      for (int32_t r = 0; r < sd->ctx_width && r < cw; ++r)
+        counter[(int64_t)n * cw + r] = t->ctx[sd->ctx_off + (int64_t)n * sd->ctx_width + r];
+
+  int failed = 0;
+  for (int32_t k = 0; k < sd->topic_count; ++k) {
+    const int32_t ti = sd->topic_begin + k;
+    const kas_topic_desc* td = &b->topics[ti];
+    kas_topic_result* tr = &t->topic_results[ti];
+    int32_t* out = t->out + td->out_off;
+    if (failed) {
+      tr->status = KAS_SKIPPED; tr->fail_partition = -1;
+      tr->moved_replicas = 0; tr->moved_partitions = 0;
+      kas_loop_fill_minus_one(out, (int64_t)td->n_partitions * td->out_width);
+      continue;
+    }
+    solve(td->name_hash, td->n_partitions,
+          td->part_id_off >= 0 ? t->aux + td->part_id_off : NULL,
+          t->cur + td->cur_off, td->cur_width,
+          td->cur_len_off >= 0 ? t->aux + td->cur_len_off : NULL,
+          td->in_partitions_off >= 0 ? t->aux + td->in_partitions_off : NULL,
+          N, node_id, node_rack, td->rf, counter, cw, out, td->out_width, tr, NULL);
+    if (tr->status != KAS_OK) {
+      failed = 1;
+      sr->status = tr->status; sr->fail_topic = k; sr->fail_partition = tr->fail_partition;
+      continue;
+    }
+    sr->moved_replicas += tr->moved_replicas;
+    sr->moved_partitions += tr->moved_partitions;
+    for (int32_t p = 0; p < td->n_partitions; ++p)
+      for (int32_t r = 0; r < td->out_width; ++r) {
+        const int32_t v = out[(int64_t)p * td->out_width + r];
+        if (v != -1) sr->digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, v);
+      }
+  }
+  if (sd->ctx_off >= 0 && sd->ctx_width > 0)
+    for (int32_t n = 0; n < N; ++n)
+      for (int32_t r = 0; r < sd->ctx_width && r < cw; ++r)
+        t->ctx[sd->ctx_off + (int64_t)n * sd->ctx_width + r] = counter[(int64_t)n * cw + r];
+  free(counter);
+}
+
+typedef struct {
+  const kas_batch_desc* b;
+  const kas_tables* t;
+  kas_topic_fn solve;
+  int32_t next;          /* shared cursor, advanced with __atomic_fetch_add */
+} kas_loop_shared;
+
+static void* kas_loop_worker(void* arg) {
+  kas_loop_shared* sh = (kas_loop_shared*)arg;
+  for (;;) {
+    const int32_t s = __atomic_fetch_add(&sh->next, 1, __ATOMIC_RELAXED);
+    if (s >= sh->b->n_scenarios) break;
+    kas_loop_scenario(sh->b, sh->t, s, sh->solve);
+  }
+  return NULL;
+}
+
+/* hardware threads of this host (what std::thread::hardware_concurrency() reports) */
+static int kas_loop_host_threads(void) {
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  return n > 0 ? (int)n : 1;
+}
+
+/* n_threads <= 0: every hardware thread.  Returns the number of threads used, or < 0. */
+static int kas_loop_batch(const kas_batch_desc* b, const kas_tables* t, kas_topic_fn solve, int n_threads) {
+  if (!b || !t || b->n_scenarios < 0 || b->n_topics < 0) return KAS_E_INVALID_ARG;
+  if (n_threads <= 0) n_threads = kas_loop_host_threads();
+  if (n_threads > b->n_scenarios) n_threads = b->n_scenarios > 0 ? b->n_scenarios : 1;
+  if (n_threads == 1) {
+    for (int32_t s = 0; s < b->n_scenarios; ++s) kas_loop_scenario(b, t, s, solve);
+    return 1;
+  }
+  kas_loop_shared sh;
+  sh.b = b; sh.t = t; sh.solve = solve; sh.next = 0;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  if (!th) return KAS_E_NOMEM;
+  int started = 0;
+  for (int i = 0; i < n_threads; ++i) {
+    if (pthread_create(&th[i], NULL, kas_loop_worker, &sh) != 0) break;
+    ++started;
+  }
+  if (started == 0) kas_loop_worker(&sh);          /* no thread could be created: run inline */
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  free(th);
+  return started > 0 ? started : 1;
+}
+
+#endif /* KAS_BATCH_LOOP_H */

@@ -28,6 +28,7 @@
 #include <limits.h>
 
 #include "kas_abi.h"
+#include "kas_batch_loop.h"
 
 #if defined(__GNUC__)
 #define KAS_ORACLE_API __attribute__((visibility("default")))
@@ -295,70 +296,26 @@ int kas_oracle_solve_topic(int32_t name_hash, int32_t P, const int32_t* part_id,
 }
 
 /*
- * Whole batch with the semantics of kas_solve_host (include/kas_abi.h): scenarios are
- * independent; inside a scenario topics run in order against one Context and the first
- * failure skips the rest (the CLI run aborts, KAG:173-184).  `tables` holds HOST pointers.
- * Returns 0, or a negative KAS_E_* code for malformed descriptors.
+ * Whole batch with the semantics of kas_solve_host (include/kas_abi.h); the per-scenario topic
+ * loop (one Context per scenario, first failure skips the rest: KAG:173-184) is in
+ * kas_batch_loop.h.  `tables` holds HOST pointers.  Returns 0, or a negative KAS_E_* code for
+ * malformed descriptors.
  */
 KAS_ORACLE_API
 int kas_oracle_solve_batch(const kas_batch_desc* b, const kas_tables* t) {
-  if (!b || !t || b->n_scenarios < 0 || b->n_topics < 0) return KAS_E_INVALID_ARG;
-  for (int32_t s = 0; s < b->n_scenarios; ++s) {
-    const kas_scenario_desc* sd = &b->scenarios[s];
-    kas_scenario_result* sr = &t->scenario_results[s];
-    sr->status = KAS_OK; sr->fail_topic = -1; sr->fail_partition = -1;
-    sr->moved_replicas = 0; sr->moved_partitions = 0; sr->reserved = 0; sr->digest = 0;
-    int32_t N = sd->n_nodes;
-    const int32_t* node_id = b->node_id + sd->node_off;
-    const int32_t* node_rack = b->node_rack + sd->node_off;
-
-    int32_t cw = KAS_MAX_WIDTH;
-    int32_t* counter = (int32_t*)calloc((size_t)(N > 0 ? N : 1) * cw, sizeof(int32_t));
-    if (sd->ctx_off >= 0 && sd->ctx_width > 0)
-      for (int32_t n = 0; n < N; ++n)
-        for (int32_t r = 0; r < sd->ctx_width && r < cw; ++r)
-          counter[(int64_t)n * cw + r] = t->ctx[sd->ctx_off + (int64_t)n * sd->ctx_width + r];
-
-    int failed = 0;
-    for (int32_t k = 0; k < sd->topic_count; ++k) {
-      int32_t ti = sd->topic_begin + k;
-      const kas_topic_desc* td = &b->topics[ti];
-      kas_topic_result* tr = &t->topic_results[ti];
-      int32_t* out = t->out + td->out_off;
-      if (failed) {
-        tr->status = KAS_SKIPPED; tr->fail_partition = -1;
-        tr->moved_replicas = 0; tr->moved_partitions = 0;
-        fill_minus_one(out, (int64_t)td->n_partitions * td->out_width);
-        continue;
-      }
-      kas_oracle_solve_topic(
-          td->name_hash, td->n_partitions,
-          td->part_id_off >= 0 ? t->aux + td->part_id_off : NULL,
-          t->cur + td->cur_off, td->cur_width,
-          td->cur_len_off >= 0 ? t->aux + td->cur_len_off : NULL,
-          td->in_partitions_off >= 0 ? t->aux + td->in_partitions_off : NULL,
-          N, node_id, node_rack, td->rf, counter, cw, out, td->out_width, tr, NULL);
-      if (tr->status != KAS_OK) {
-        failed = 1;
-        sr->status = tr->status; sr->fail_topic = k; sr->fail_partition = tr->fail_partition;
-        continue;
-      }
-      sr->moved_replicas += tr->moved_replicas;
-      sr->moved_partitions += tr->moved_partitions;
-      for (int32_t p = 0; p < td->n_partitions; ++p)
-        for (int32_t r = 0; r < td->out_width; ++r) {
-          int32_t v = out[(int64_t)p * td->out_width + r];
-          if (v != -1) sr->digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, v);
-        }
-    }
-    if (sd->ctx_off >= 0 && sd->ctx_width > 0)
-      for (int32_t n = 0; n < N; ++n)
-        for (int32_t r = 0; r < sd->ctx_width && r < cw; ++r)
-          t->ctx[sd->ctx_off + (int64_t)n * sd->ctx_width + r] = counter[(int64_t)n * cw + r];
-    free(counter);
-  }
-  return KAS_E_OK;
+  const int rc = kas_loop_batch(b, t, kas_oracle_solve_topic, 1);
+  return rc < 0 ? rc : KAS_E_OK;
 }
+
+/* The same batch, scenario-parallel on n_threads host threads inside this one call (<= 0: every
+ * hardware thread).  Returns the number of threads used, or a negative KAS_E_* code. */
+KAS_ORACLE_API
+int kas_oracle_solve_batch_mt(const kas_batch_desc* b, const kas_tables* t, int n_threads) {
+  return kas_loop_batch(b, t, kas_oracle_solve_topic, n_threads);
+}
+
+KAS_ORACLE_API
+int kas_oracle_host_threads(void) { return kas_loop_host_threads(); }
 
 KAS_ORACLE_API
 int kas_oracle_abi_version(void) { return KAS_ABI_VERSION; }

@@ -13,17 +13,25 @@ from kafka_assigner_amd.flatten import FlatBatch, HostOutputs, batch_desc, host_
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 _LIB = None
+_FAST = None
+
+
+def _build(name: str, src_name: str, force: bool = False) -> str:
+    so = os.path.join(ORACLE_DIR, name)
+    deps = [os.path.join(ORACLE_DIR, src_name), os.path.join(ORACLE_DIR, "kas_batch_loop.h"),
+            os.path.join(ROOT, "include", "kas_abi.h")]
+    stale = not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "-B", name])
+    return so
 
 
 def build_oracle(force: bool = False) -> str:
-    so = os.path.join(ORACLE_DIR, "libkas_oracle.so")
-    src = os.path.join(ORACLE_DIR, "kas_oracle.c")
-    hdr = os.path.join(ROOT, "include", "kas_abi.h")
-    stale = (not os.path.exists(so)
-             or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
-    if force or stale:
-        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "-B", "libkas_oracle.so"])
-    return so
+    return _build("libkas_oracle.so", "kas_oracle.c", force)
+
+
+def build_cpu_fast(force: bool = False) -> str:
+    return _build("libkas_cpu_fast.so", "kas_cpu_fast.c", force)
 
 
 def lib():
@@ -32,17 +40,60 @@ def lib():
         L = C.CDLL(build_oracle())
         L.kas_oracle_solve_batch.restype = C.c_int
         L.kas_oracle_solve_batch.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
+        L.kas_oracle_solve_batch_mt.restype = C.c_int
+        L.kas_oracle_solve_batch_mt.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables), C.c_int]
+        L.kas_oracle_host_threads.restype = C.c_int
         L.kas_oracle_abi_version.restype = C.c_int
         assert L.kas_oracle_abi_version() == abi.KAS_ABI_VERSION
         _LIB = L
     return _LIB
 
 
-def oracle_solve(fb: FlatBatch) -> HostOutputs:
-    """Solve a flattened batch with the CPU oracle; same semantics as kas_solve_host."""
+def fast_lib():
+    """oracle/kas_cpu_fast.c: the flat-array CPU baseline (B2); same results as the oracle."""
+    global _FAST
+    if _FAST is None:
+        L = C.CDLL(build_cpu_fast())
+        L.kas_cpu_fast_solve_batch.restype = C.c_int
+        L.kas_cpu_fast_solve_batch.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
+        L.kas_cpu_fast_solve_batch_mt.restype = C.c_int
+        L.kas_cpu_fast_solve_batch_mt.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables), C.c_int]
+        L.kas_cpu_fast_host_threads.restype = C.c_int
+        L.kas_cpu_fast_abi_version.restype = C.c_int
+        assert L.kas_cpu_fast_abi_version() == abi.KAS_ABI_VERSION
+        _FAST = L
+    return _FAST
+
+
+def host_threads() -> int:
+    """Hardware threads of this host (== std::thread::hardware_concurrency())."""
+    return int(lib().kas_oracle_host_threads())
+
+
+def _solve(fn_st, fn_mt, fb: FlatBatch, threads: int, what: str) -> HostOutputs:
     bd = batch_desc(fb)
     t, ho = host_tables(fb)
-    rc = lib().kas_oracle_solve_batch(C.byref(bd), C.byref(t))
-    if rc != 0:
-        raise RuntimeError(f"kas_oracle_solve_batch returned {rc}")
+    if threads == 1:
+        rc = fn_st(C.byref(bd), C.byref(t))
+        if rc != 0:
+            raise RuntimeError(f"{what} returned {rc}")
+        ho.threads_used = 1
+    else:
+        rc = fn_mt(C.byref(bd), C.byref(t), int(threads))
+        if rc < 0:
+            raise RuntimeError(f"{what} (threaded) returned {rc}")
+        ho.threads_used = rc
     return ho
+
+
+def oracle_solve(fb: FlatBatch, threads: int = 1) -> HostOutputs:
+    """Solve a flattened batch with the CPU oracle; same semantics as kas_solve_host.
+    threads != 1: scenario-parallel inside the one C call (0 = every hardware thread)."""
+    L = lib()
+    return _solve(L.kas_oracle_solve_batch, L.kas_oracle_solve_batch_mt, fb, threads, "kas_oracle_solve_batch")
+
+
+def cpu_fast_solve(fb: FlatBatch, threads: int = 1) -> HostOutputs:
+    """The same batch by the flat-array CPU baseline (oracle/kas_cpu_fast.c)."""
+    L = fast_lib()
+    return _solve(L.kas_cpu_fast_solve_batch, L.kas_cpu_fast_solve_batch_mt, fb, threads, "kas_cpu_fast_solve_batch")

@@ -186,3 +186,16 @@ def test_emu_protocols_survive_arbitrary_wave_speeds():
         r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
                            env=dict(os.environ, KAS_EMU_CHAOS=seed), timeout=900)
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_emu_topic_without_rows_next_to_full_width_topics():
+    """A topic with zero partitions whose widths match the kernel's width class: the fast fill's
+    full-row loads re-read the last row for lanes past the end, and there is no row."""
+    cur = G.random_assignment(3, 300, 12, 4, 3)
+    sc = Scenario(brokers=list(range(12)), racks={b: "r%d" % (b % 4) for b in range(12)},
+                  topics=[Topic("a", {p: cur[p].tolist() for p in range(300)}, 3), Topic("empty", {}, 3)])
+    fb = flatten([sc])
+    fb.topics["cur_width"][1] = 3; fb.topics["out_width"][1] = 3
+    want = oracle_solve(fb)
+    assert want.topic_results["status"][1] == abi.KAS_OK
+    assert_same_outputs(fb, want, emu_solve(fb), "emu empty topic last")

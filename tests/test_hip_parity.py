@@ -116,6 +116,78 @@ def test_config5_shape_rf5_rack_on_and_off_scaled():
         assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), f"C5 rack_aware={rack_aware}")
 
 
+def test_config4_exact_action_add_brokers_1000_to_1049_full_size():
+    """BASELINE.json configs[3]'s exact action at full size: 100k partitions x 1k brokers x 20
+    racks, RF 3, add brokers 1000-1049 (rack id mod 20) -> N = 1050, cap 286; 64 scenarios with
+    their own G(seed+s) tables — one GPU's slice of the 64k — every list compared."""
+    fb = _batch(4004, 64, 100000, 1000, 20, 3, ("add50",))
+    assert (fb.scen["n_nodes"] == 1050).all()
+    want = oracle_solve(fb, threads=0)
+    assert (want.scenario_results["status"] == abi.KAS_OK).all()
+    assert (want.scenario_results["moved_replicas"] > 10000).all()      # 14k-16k orphans each (SURVEY App. C)
+    assert_same_outputs(fb, want, native.solve_host(fb), "C4 add 50")
+
+
+def test_config5_full_size_1m_partitions_5k_brokers_rf5_rack_on_and_off():
+    """BASELINE.json configs[4] at its stated size: 1M partitions x 5k brokers x 40 racks, RF 5,
+    remove every 50th broker + add 5000-5199, rack map as generated and empty
+    (--disable_rack_awareness): N = 5100, cap 981, ~219k moved replicas.  Every list compared."""
+    P, N, R, RF = 1000000, 5000, 40, 5
+    cur = G.random_assignment(7, P, N, R, RF)
+    for rack_aware in (True, False):
+        bs = G.perturb_brokers(N, R, remove=list(range(0, N, 50)), add=200, rack_aware=rack_aware)
+        assert bs.node_id.shape[0] == 5100
+        fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], RF)
+        want = oracle_solve(fb)
+        assert want.scenario_results["status"][0] == abi.KAS_OK
+        assert want.scenario_results["moved_replicas"][0] > 200000
+        assert_same_outputs(fb, want, native.solve_host(fb), f"C5 full size rack_aware={rack_aware}")
+
+
+def test_one_plan_orders_its_solves_across_streams():
+    """A plan owns the scratch of one solve (include/kas_abi.h): solves of one plan enqueued on
+    different streams must not overlap.  Alternate two streams without any host synchronisation in
+    between and compare every result."""
+    import torch
+    fb = _batch(515, 24, 20000, 200, 10, 3, G.ACTIONS)
+    want = oracle_solve(fb, threads=0)
+    ctx = native.default_context()
+    plan = native.Plan(ctx, fb)
+    assert "kas_fill_kernel<3,4>[quota]" in plan.describe() and "kas_order_ticket_kernel<3,2,true>" in plan.describe()
+    dev = torch.device("cuda", ctx.device)
+    d_cur = torch.from_numpy(fb.cur).to(dev)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = []
+    for i in range(6):
+        d_out = torch.full((fb.out_len,), -7, dtype=torch.int32, device=dev)
+        d_tr = torch.zeros(fb.n_topics * 16, dtype=torch.uint8, device=dev)
+        d_sr = torch.zeros(fb.n_scenarios * 32, dtype=torch.uint8, device=dev)
+        streams[i % 2].wait_stream(torch.cuda.current_stream(dev))
+        plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
+                          stream=streams[i % 2].cuda_stream)
+        outs.append((d_out, d_sr))
+    torch.cuda.synchronize(dev)
+    for d_out, d_sr in outs:
+        np.testing.assert_array_equal(d_out.cpu().numpy(), want.out[:fb.out_len])
+        sr = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
+        np.testing.assert_array_equal(sr["digest"], want.scenario_results["digest"])
+    plan.set_flags(2)
+    assert "kas_order_round_kernel<3>" in plan.describe()
+    plan.close()
+
+
+def test_topic_without_rows_next_to_full_width_topics():
+    """A topic with zero partitions whose widths match the kernel's width class (the fast fill's
+    full-row loads must not touch a table that has no rows), at the very end of the cur pool."""
+    cur = G.random_assignment(3, 300, 12, 4, 3)
+    sc = Scenario(brokers=list(range(12)), racks={b: "r%d" % (b % 4) for b in range(12)},
+                  topics=[Topic("a", {p: cur[p].tolist() for p in range(300)}, 3),
+                          Topic("empty", {}, 3)])
+    fb = flatten([sc])
+    fb.topics["cur_width"][1] = 3; fb.topics["out_width"][1] = 3        # same width class, no rows
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "empty topic last")
+
+
 def test_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
     """Three topics per scenario sharing one Context that is neither handed in nor out (one
     PRINT_REASSIGNMENT run, KAG:172-184): the ticket form carries the tickets across topics."""
