@@ -64,6 +64,19 @@ __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
 }
 
 typedef void (*kas_kernel_fn)(KasLaunch);
+#ifdef KAS_MINIMAL_INSTANCES
+// tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
+// lists 3 wide, 4 fill waves, 2 scenarios per solver wavefront — so that a variant compiles in
+// seconds.  Other shapes are refused by kas_plan_create in such a build.
+static bool kas_minimal_ok(int Wc, int NW, int G) { return Wc == 3 && NW == 4 && (G == 2 || G == 1); }
+static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<3, 4>; }
+static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
+  if (G == 1) return packed ? kas_order_ticket_kernel<3, 1, true> : kas_order_ticket_kernel<3, 1, false>;
+  return packed ? kas_order_ticket_kernel<3, 2, true> : kas_order_ticket_kernel<3, 2, false>;
+}
+static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
+#else
+static bool kas_minimal_ok(int, int, int) { return true; }
 template <int NW>
 static kas_kernel_fn kas_fill_for_w(int Wc) {
   switch (Wc) {
@@ -105,6 +118,7 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
     default: return kas_order_round_kernel<8>;
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -302,6 +316,10 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
     delete p;
     return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at the instantiated width");
   }
+  if (!kas_minimal_ok(p->Wc, p->NW, p->G)) {
+    delete p;
+    return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only lists 3 wide, 4 fill waves");
+  }
   hipStream_t st = ctx->stream;
 #define KAS_PLAN_TRY(call)                                  \
   do { int rc_ = (call); if (rc_ != KAS_E_OK) { kas_plan_destroy(p); return rc_; } } while (0)
@@ -483,6 +501,8 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_WAVES: waves per scenario must be 1, 2, 4 or 8");
   if (g != 0 && g != 1 && g != 2 && g != 4)
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
+  if (!kas_minimal_ok(p->Wc, nw ? nw : p->NW, g ? g : p->G))
+    return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only 4 fill waves, 1 or 2 groups");
   const KasShape& sh = p->shape;
   if (nw != 0 && nw != p->NW) {
     KasLds l = kas_fill_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch, sh.with_x);

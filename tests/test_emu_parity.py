@@ -191,7 +191,7 @@ def test_emu_protocols_survive_arbitrary_wave_speeds():
 def test_emu_topic_without_rows_next_to_full_width_topics():
     """A topic with zero partitions whose widths match the kernel's width class: the fast fill's
     full-row loads re-read the last row for lanes past the end, and there is no row."""
-    cur = G.random_assignment(3, 300, 12, 4, 3)
+    cur = G.cyclic_assignment(300, 12, 3)                # balanced and rack-diverse: topic a succeeds
     sc = Scenario(brokers=list(range(12)), racks={b: "r%d" % (b % 4) for b in range(12)},
                   topics=[Topic("a", {p: cur[p].tolist() for p in range(300)}, 3), Topic("empty", {}, 3)])
     fb = flatten([sc])

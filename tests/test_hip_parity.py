@@ -179,7 +179,7 @@ def test_one_plan_orders_its_solves_across_streams():
 def test_topic_without_rows_next_to_full_width_topics():
     """A topic with zero partitions whose widths match the kernel's width class (the fast fill's
     full-row loads must not touch a table that has no rows), at the very end of the cur pool."""
-    cur = G.random_assignment(3, 300, 12, 4, 3)
+    cur = G.cyclic_assignment(300, 12, 3)                # balanced and rack-diverse: topic a succeeds
     sc = Scenario(brokers=list(range(12)), racks={b: "r%d" % (b % 4) for b in range(12)},
                   topics=[Topic("a", {p: cur[p].tolist() for p in range(300)}, 3),
                           Topic("empty", {}, 3)])
