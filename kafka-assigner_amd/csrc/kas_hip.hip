@@ -63,6 +63,13 @@ __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
   kas::order_scenario_rounds<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
+// lists 4 and 5 wide: one scenario per workgroup (solver / stager / retirer wavefronts)
+template <int W>
+__global__ __launch_bounds__(192) void kas_order_wide_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::order_tickets_wide<W>(a, (int32_t)blockIdx.x, kas_lds);
+}
+
 typedef void (*kas_kernel_fn)(KasLaunch);
 #ifdef KAS_MINIMAL_INSTANCES
 // tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
@@ -75,6 +82,7 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
   return packed ? kas_order_ticket_kernel<3, 2, true> : kas_order_ticket_kernel<3, 2, false>;
 }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
+static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
 #else
 static bool kas_minimal_ok(int, int, int) { return true; }
 template <int NW>
@@ -117,6 +125,9 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
     case 5: return kas_order_round_kernel<5>;
     default: return kas_order_round_kernel<8>;
   }
+}
+static kas_kernel_fn kas_order_wide_for(int Wc) {
+  return Wc == 4 ? kas_order_wide_kernel<4> : kas_order_wide_kernel<5>;
 }
 #endif
 
@@ -283,6 +294,10 @@ static int kas_plan_set_kernels(kas_plan* p) {
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kas_order_round_lds(p->shape.n_max, p->Wc)));
+  if (p->shape.wide_ok && kas_order_wide_for(p->Wc))
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_wide_for(p->Wc),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kas_order_wide_lds(p->shape.n_max)));
   return KAS_E_OK;
 }
 
@@ -367,7 +382,7 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
 
 // the launch decisions of kas_solve_device, in one place
 struct KasLaunchPlan {
-  bool tickets, pairing;
+  bool tickets, pairing, wide;
   int packed;
   unsigned fill_grid, fill_block, order_grid, order_block;
   size_t fill_lds, order_lds;
@@ -377,11 +392,15 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   lp.tickets = p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
   lp.packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
   lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G && p->n_scenarios <= KAS_PAIRING_LIMIT;
+  lp.wide = !lp.tickets && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
   lp.fill_lds = (size_t)p->lds.total;
   if (lp.tickets) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
     lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed);
+  } else if (lp.wide) {
+    lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 192u;
+    lp.order_lds = (size_t)kas_order_wide_lds(p->shape.n_max);
   } else {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
     lp.order_lds = (size_t)kas_order_round_lds(p->shape.n_max, p->Wc);
@@ -398,6 +417,9 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
              lp.order_grid, lp.order_block, lp.order_lds);
+  else if (lp.wide)
+    snprintf(order, sizeof(order), "kas_order_wide_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
+             lp.order_block, lp.order_lds);
   else
     snprintf(order, sizeof(order), "kas_order_round_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
              lp.order_block, lp.order_lds);
@@ -450,6 +472,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
                        lp.order_lds, st, a);
+  else if (lp.wide)
+    hipLaunchKernelGGL(kas_order_wide_for(p->Wc), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else
     hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());

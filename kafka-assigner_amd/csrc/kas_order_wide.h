@@ -1,0 +1,443 @@
+// kas_order_wide.h — P5 (computePreferenceLists, KAS:202-239), ticket form for replica lists 4 and 5
+// wide (BASELINE.json configs[4]: 1M partitions x 5k brokers, RF 5).  Included by kas_solver_body.h.
+//
+// Same plan as order_tickets<W <= 3>: a workgroup is three wavefronts — wave 0 SOLVES, wave 1 STAGES
+// rows for it (mid rows from HBM, tickets, ring slots), wave 2 RETIRES finished rows (node index ->
+// broker id, digest, final out row) — talking only through the tags of a ring of K slots per lane.
+// One scenario per workgroup, lane l owns rows l, l + 64, ... (a 1M-row scenario is served by one
+// workgroup; wide lists mean more state per row, not more rows in flight).
+//
+// What differs from the 3-wide kernel:
+//   * count[n][0..5) live in one uint64 per node as five 10-bit fields (bits 0, 10, 20, 32, 42);
+//     commits on n = their sum.  Applicable while no node can hold 1023 rows of the scenario
+//     (the plan checks the bound; configs[4] has cap 981).
+//   * holders are stored ascending (Sets.newTreeSet, KAS:228) and the picks are the general
+//     "minimum of (count, visit position) over the nodes still in the set" of pick_row<W>
+//     (KAS:263-278), five times; the rotation offsets idx_m = abs(hash) % m travel in the slot.
+//   * queues.  First fit hands consecutive orphans to one node X (at configs[4] each added broker
+//     takes ~981 of them: the P5 dependency chain is ~180k rows long against 15.6k tiles), so rows
+//     in hand that wait on X alone are decided together, as in the 3-wide kernel, generalised:
+//     with X's other holders free, X takes the row's pick r* = the first r with
+//     count[X][r] + (rows ahead in the queue that took r) < T_r, where the thresholds T_0..T_{L-2}
+//     follow from the other holders' counts alone (if X loses pick r, the winner among the others
+//     is fixed, leaves the set, and pick r + 1 is again X against the rest), T_{L-1} = always.
+//     Laid out by rank the counts are prefix sums of the wins; wins -> prefix sums are re-evaluated
+//     until nothing changes (rank r is right after round r at the latest).  Several nodes are
+//     usually being filled at once (rack constraints interleave them): up to KAS_WIDE_QUEUE_PASSES
+//     nodes are served per solver step.
+#pragma once
+
+namespace kas {
+
+#ifndef KAS_WIDE_QUEUE_PASSES
+#define KAS_WIDE_QUEUE_PASSES 2
+#endif
+#define KAS_WIDE_FIELD_MASK 0x3ffu
+#define KAS_WIDE_DUMMY_TICKET (5 * 0x3ff)
+
+struct alignas(16) WideSlot { int32_t tag; int32_t e[5]; int32_t rot; int32_t spare; };
+// tag: KAS_TAG_FREE / KAS_TAG_END as in the 3-wide kernel
+//      staged:  row counter j of the lane (bits 0..25) | list length Lp << 26 (0..5)
+//      done:    0x80000000 | pos[0] | pos[1] << 3 | ... | pos[4] << 12 | Lp << 15
+#define KAS_WTAG_DONE ((int32_t)0x80000000)
+#define KAS_WTAG_IS_DONE(t) (((uint32_t)(t) & 0xfffc0000u) == 0x80000000u)
+
+// slot.rot = TileIter::rotw: idx_m = Math.abs(hash) % m (KAS:190) for set sizes m = 1..5, 3 bits each
+// at bit 3 m (computed per topic by tile_next_topic)
+
+KAS_DEV uint64_t wide_field_unit(int r) {                   // + 1 on count field r
+  return r == 0 ? 1ull : r == 1 ? (1ull << 10) : r == 2 ? (1ull << 20) : r == 3 ? (1ull << 32) : (1ull << 42);
+}
+
+template <int W>
+KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned char* lds_raw) {
+  static_assert(W == 4 || W == 5, "the narrow kernel serves lists up to 3 wide, the round form beyond 5");
+  constexpr int K = KAS_RING_SLOTS;
+  constexpr int T = W - 1;                                  // replica indices whose counts decide a pick
+  const int lane = kasw::lane();
+  const int32_t wave = kasw::wave_id();
+  const bool have_s = s_index < a.n_scenarios;
+  const int32_t s = have_s ? s_index : a.n_scenarios;
+  const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
+  uint64_t* cnt = (uint64_t*)lds_raw;                       // [nmax + 1]: + the padding holder's row
+  uint64_t* dep = (uint64_t*)(lds_raw + kas_align16(8 * (int64_t)(nmax + 1)));                  // lane mask per node
+  uint16_t* run = (uint16_t*)((unsigned char*)dep + kas_align16(8 * (int64_t)(nmax + 1)));       // tickets handed out
+  WideSlot* ring = (WideSlot*)((unsigned char*)run + kas_align16(2 * (int64_t)(nmax + 1)));
+  uint64_t* gdig = (uint64_t*)(ring + K * 64);
+  uint32_t* rank_owner = (uint32_t*)(gdig + 2);             // [64] queue scratch of the solver: rank -> lane
+  // padding holder: a ticket that always matches its commits; never picked (pick_row looks at Lp cells)
+  const int32_t dummy_e = (KAS_WIDE_DUMMY_TICKET << 16) | (nmax * 8);
+
+  kas_scenario_desc sd;
+  sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
+  if (have_s) sd = a.scen[s];
+  const int32_t* g_node_id = a.node_id + sd.node_off;
+  for (int32_t n = lane + 64 * wave; n <= nmax; n += 192) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; }
+  for (int32_t k = wave; k < K; k += 3) ring[k * 64 + lane].tag = KAS_TAG_FREE;
+  if (wave == 0) rank_owner[lane] = 0u;
+  kasw::sync();
+  if (wave == 0 && lane == 0) {
+    cnt[nmax] = ((uint64_t)0xfffffu << 32) | 0x3fffffffull;  // five fields of 0x3ff: commits == the dummy ticket
+    gdig[0] = 0ull;
+  }
+  kasw::sync();
+
+  if (wave == 0) {
+    // ------------------------------------------------------------------ solver: LDS only
+    int32_t j = 0;                                           // rows this lane has committed
+    bool cv = false, nv = false, fin = false;
+    int32_t e[W], Lp = 0, rot = 0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) e[q] = dummy_e;
+    WideSlot nx;
+    nx.tag = KAS_TAG_FREE; nx.rot = 0; nx.spare = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) nx.e[q] = dummy_e;
+    int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0;
+    int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
+    const int64_t t_begin = kasw::clock_ticks();
+    kasw::set_priority<3>();
+    for (;;) {
+      kasw::repoll();
+      n_iter += 1;
+      // one LDS round trip: the look-ahead slot and the counter rows of the row in hand
+      const int32_t jn = j + (cv ? 1 : 0);
+      const WideSlot sl = ring[(jn & (K - 1)) * 64 + lane];
+      int32_t c[W][W];                                      // c[k][r] = count[holder k][replica index r]
+      uint32_t d[W];                                        // rows still ahead of mine on holder k
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        const uint64_t x = *(const uint64_t*)(lds_raw + (e[q] & 0xffff));
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        const uint32_t f[5] = {lo & KAS_WIDE_FIELD_MASK, (lo >> 10) & KAS_WIDE_FIELD_MASK, (lo >> 20) & KAS_WIDE_FIELD_MASK,
+                               hi & KAS_WIDE_FIELD_MASK, (hi >> 10) & KAS_WIDE_FIELD_MASK};
+#pragma unroll
+        for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];
+        d[q] = ((uint32_t)e[q] >> 16) - (f[0] + f[1] + f[2] + f[3] + f[4]);
+      }
+      if (!nv && !fin) {
+        if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
+        else if (sl.tag == KAS_TAG_END && !cv) fin = true;
+      }
+      uint32_t d_any = 0u, d_sum = 0u;
+      int32_t nz = 0;                                       // holders I wait on
+#pragma unroll
+      for (int q = 0; q < W; ++q) { d_any |= d[q]; d_sum += d[q]; nz += d[q] != 0u ? 1 : 0; }
+      bool ready = cv && d_any == 0u;
+      bool ready_q = false;                                 // decided inside a queue in this step
+      int32_t idxm[W + 1];
+      idxm[0] = 0;
+#pragma unroll
+      for (int m = 1; m <= W; ++m) idxm[m] = (rot >> (3 * m)) & 7;
+      // ---- queues: rows in hand that hold one node X and wait for nothing but X
+      {
+        uint64_t nb = 0ull;
+        if (run_skip > 0) run_skip -= 1;
+        else nb = kasw::ballot(cv && nz == 1 && d_sum == (uint32_t)KAS_RUN_NOMINATE);   // third in line on X, free otherwise
+        int32_t my_ax = 0;
+#pragma unroll
+        for (int q = 0; q < W; ++q) my_ax = d[q] != 0u ? (e[q] & 0xffff) : my_ax;       // (a nominating row waits on one node)
+#pragma unroll 1
+        for (int pass = 0; pass < KAS_WIDE_QUEUE_PASSES && nb != 0ull; ++pass) {
+          const int32_t ax = kasw::read_lane(my_ax, kasw::first_lane(nb));              // X's counter row
+          int32_t hx = -1;                                  // where X sits in my (ascending) list
+#pragma unroll
+          for (int q = 0; q < W; ++q) hx = (e[q] & 0xffff) == ax ? q : hx;
+          const int32_t hq = hx >= 0 ? hx : 0;
+          int32_t dcol[W];
+#pragma unroll
+          for (int q = 0; q < W; ++q) dcol[q] = (int32_t)d[q];
+          const uint32_t kx = (uint32_t)sel<W>(dcol, hq);    // my rank in X's queue
+          // candidates: rows in hand that hold X and wait for nothing else (rank 0 = the ready one)
+          const bool cand = cv && !ready_q && hx >= 0 && d_sum == kx && kx < 64u;
+          n_runs += 1;
+          const uint32_t seq = (uint32_t)(n_runs & 0xffffff);             // never 0: stale and initial entries differ
+          if (cand) rank_owner[(int32_t)kx] = (seq << 8) | (uint32_t)lane;
+          kasw::lockstep();
+          const uint32_t ow = rank_owner[lane];             // rank view: lane = rank
+          kasw::lockstep();
+          const bool have = (ow >> 8) == seq;
+          const uint64_t hb = kasw::ballot(have);
+          const int32_t qlen = ~hb != 0ull ? kasw::first_lane(~hb) : 64;   // ranks 0..qlen-1 are all in hand
+          const bool member = cand && (int32_t)kx < qlen;
+          const int32_t gain = kasw::popc(kasw::ballot(member && kx > 0u));
+          if (gain < KAS_RUN_MIN_GAIN) {
+            run_backoff = run_backoff == 0 ? 1 : (run_backoff < 16 ? 2 * run_backoff : 16);
+            run_skip = run_backoff;
+          } else {
+            if (gain > KAS_RUN_MIN_GAIN) run_backoff = 0;
+            // thresholds of my row against X (relative to X's counts now): X takes pick r iff
+            // count[X][r] + (wins of the rows ahead of me at r) < T_r, the other holders being free
+            int32_t cX[W];
+#pragma unroll
+            for (int r = 0; r < W; ++r) {
+              int32_t col[W];
+#pragma unroll
+              for (int q = 0; q < W; ++q) col[q] = c[q][r];
+              cX[r] = sel<W>(col, hq);
+            }
+            const uint32_t xbit = 1u << hq, xlow = xbit - 1u;
+            uint32_t alive_o = ((1u << Lp) - 1u) & ~xbit;
+            int32_t tpack = 0;
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+              const uint32_t setmask = alive_o | xbit;
+              const int32_t m = __builtin_popcount(setmask);
+              const int32_t idx = sel<W + 1>(idxm, m);
+              int32_t keys[W], best = 0x7fffffff;
+#pragma unroll
+              for (int k = 0; k < W; ++k) {
+                int32_t rr = __builtin_popcount(setmask & ((1u << k) - 1u)) + idx;
+                rr -= rr >= m ? m : 0;
+                const int32_t dead = (int32_t)((((alive_o >> k) & 1u) - 1u) & 0x7fffffffu);
+                keys[k] = ((c[k][r] << 3) | rr) | dead;
+                best = keys[k] < best ? keys[k] : best;
+              }
+              int32_t bestk = 0;
+#pragma unroll
+              for (int k = 1; k < W; ++k) bestk = keys[k] == best ? k : bestk;
+              int32_t rrX = __builtin_popcount(setmask & xlow) + idx;
+              rrX -= rrX >= m ? m : 0;
+              // (c << 3 | rrX) < best  <=>  c < ceil((best - rrX) / 8); nobody else left: always
+              int32_t t = alive_o != 0u ? ((best - rrX + 7) >> 3) - cX[r] : 127;
+              t = t < 0 ? 0 : (t > 127 ? 127 : t);
+              tpack |= t << (8 * r);
+              alive_o = alive_o != 0u ? (alive_o & ~(1u << bestk)) : 0u;   // the winner among the others leaves
+            }
+            const int32_t th = kasw::shfl(tpack, have ? (int32_t)(ow & 0xffu) : lane);   // owner -> rank view
+            const bool act = lane < qlen;
+            const uint64_t ltm = (1ull << lane) - 1ull;
+            int32_t pre[T];
+#pragma unroll
+            for (int r = 0; r < T; ++r) pre[r] = 0;
+            for (;;) {
+              n_relax += 1;
+              bool won = false, moved = false;
+              int32_t np[T];
+#pragma unroll
+              for (int r = 0; r < T; ++r) {
+                const bool win = act && !won && pre[r] < ((th >> (8 * r)) & 0xff);
+                won = won || win;
+                np[r] = kasw::popc(kasw::ballot(win) & ltm);
+              }
+#pragma unroll
+              for (int r = 0; r < T; ++r) { moved = moved || (act && np[r] != pre[r]); pre[r] = np[r]; }
+              if (kasw::ballot(moved) == 0ull) break;
+            }
+            int32_t ppack = 0;
+#pragma unroll
+            for (int r = 0; r < T; ++r) ppack |= pre[r] << (8 * r);
+            const int32_t back = kasw::shfl(ppack, member ? (int32_t)kx : lane);   // rank view -> owner
+#pragma unroll
+            for (int q = 0; q < W; ++q)
+#pragma unroll
+              for (int r = 0; r < T; ++r)
+                c[q][r] += (member && hx == q) ? ((back >> (8 * r)) & 0xff) : 0;
+            n_run_rows += (member && kx > 0u) ? 1 : 0;
+            ready_q = ready_q || member;
+          }
+          nb &= ~kasw::ballot(my_ax == ax);                 // next: a nominated row of another node
+        }
+      }
+      ready = ready || ready_q;
+      int32_t pos[W], cnt_r[W];
+      pick_row<W>(c, Lp, cv, idxm, pos, cnt_r);
+      if (ready) {
+        // updateCountersFromList (KAS:254-261): count[node][r] += 1 (positions behind the list: + 0)
+        int32_t tag = KAS_WTAG_DONE | (Lp << 15);
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+          const int32_t ad = sel<W>(e, pos[r]) & 0xffff;
+          kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad), r < Lp ? wide_field_unit(r) : 0ull);
+          tag |= (r < Lp ? pos[r] : 0) << (3 * r);
+        }
+        ring[(j & (K - 1)) * 64 + lane].tag = tag;
+        j += 1;
+        cv = false;
+      }
+      if (!cv && nv) {                                     // the look-ahead row becomes current
+#pragma unroll
+        for (int q = 0; q < W; ++q) e[q] = nx.e[q];
+        Lp = (nx.tag >> 26) & 7;
+        rot = nx.rot;
+        cv = true; nv = false;
+      }
+      if (kasw::ballot(!fin) == 0) break;
+      if (kasw::ballot(ready) == 0) { n_blocked += 1; kasw::spin_pause(); }
+    }
+    if (a.stats && have_s) {
+      const int32_t run_rows = kasw::wave_sum((int32_t)n_run_rows);
+      if (lane == 0) {
+        int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+        st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
+        st[14] = run_rows; st[6] = n_runs;
+      }
+    }
+  } else if (wave == 1) {
+    // ------------------------------------------------------------------ stager: tickets + staging
+    const uint64_t mybit = 1ull << lane;
+    const uint64_t lt = mybit - 1ull;
+    const uint32_t pad = (uint32_t)nmax;
+    TileIter itl = tile_iter_begin(have_s);
+    int32_t jl = 0;
+    bool endl = false, pf_valid = false, pf_end = false;
+    uint32_t pf_c[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) pf_c[q] = ~0u;
+    int32_t pf_rot = 0;
+    int64_t f_iter = 0, f_idle = 0;
+    for (;;) {
+      kasw::repoll();
+      f_iter += 1;
+      const bool slot_free = ring[(jl & (K - 1)) * 64 + lane].tag == KAS_TAG_FREE;
+      const bool room = kasw::ballot(slot_free) == ~0ull;
+      const bool staging = !endl && room && pf_valid;
+      const bool staging_end = staging && pf_end;
+      uint32_t cs[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) cs[q] = staging ? pf_c[q] : ~0u;
+      const int32_t rotw = pf_rot;
+      endl = endl || staging_end;
+      pf_valid = pf_valid && !staging;
+      if (!pf_valid && !endl) {                             // read ahead: the tile after that
+        pf_valid = true;
+#pragma unroll
+        for (int q = 0; q < W; ++q) pf_c[q] = ~0u;
+        if (tile_next<64>(itl, a, sd)) {
+          const int32_t p = itl.row0 + lane;
+          pf_rot = itl.rotw;
+          int32_t cells[W];
+          load_mid_row<W>((const uint16_t*)a.out + itl.tmid, mid_width(itl.tow), itl.tow, p < itl.tP ? p : 0,
+                          p < itl.tP, cells);
+#pragma unroll
+          for (int q = 0; q < W; ++q) pf_c[q] = (uint32_t)cells[q];   // -1 = none: sorts last
+        } else {
+          pf_end = true;
+        }
+      }
+      // ---- holders ascending (Sets.newTreeSet, KAS:228); empty cells sort last
+#pragma unroll
+      for (int pass = 0; pass < W; ++pass) {
+#pragma unroll
+        for (int k = (pass & 1); k + 1 < W; k += 2) {
+          const uint32_t lo = cs[k] < cs[k + 1] ? cs[k] : cs[k + 1];
+          const uint32_t hi = cs[k] < cs[k + 1] ? cs[k + 1] : cs[k];
+          cs[k] = lo; cs[k + 1] = hi;
+        }
+      }
+      int32_t Lp = 0;
+      uint32_t hn[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) { Lp += cs[q] < pad ? 1 : 0; hn[q] = cs[q] < pad ? cs[q] : pad; }
+      // ---- tickets for the tile (wave-wide lockstep): one 64-bit lane mask per node
+#pragma unroll
+      for (int q = 0; q < W; ++q) kasw::lds_atomic_or_u64(&dep[hn[q]], mybit);
+      kasw::lockstep();
+      uint64_t m[W];
+      uint32_t base[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) { m[q] = dep[hn[q]]; base[q] = (uint32_t)run[hn[q]]; }
+      kasw::lockstep();
+      uint32_t tk[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        tk[q] = base[q] + (uint32_t)kasw::popc(m[q] & lt);
+        // the lowest lane holding the node moves its running count on and clears the mask
+        const uint32_t wn = (m[q] & lt) == 0ull ? hn[q] : pad;
+        run[wn] = (uint16_t)(base[q] + (uint32_t)kasw::popc(m[q]));
+        dep[wn] = 0ull;
+      }
+      kasw::lockstep();                                     // the next tile's masks start from zero
+      if (staging) {
+        WideSlot o;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+          o.e[q] = q < W ? (int32_t)(((q < Lp ? tk[q < W ? q : 0] : (uint32_t)KAS_WIDE_DUMMY_TICKET) << 16) |
+                                     (hn[q < W ? q : 0] * 8u))
+                         : dummy_e;
+        o.rot = rotw; o.spare = 0;
+        o.tag = staging_end ? KAS_TAG_END : ((jl & KAS_TAG_JMASK) | (Lp << 26));
+        ring[(jl & (K - 1)) * 64 + lane] = o;
+        jl += 1;
+      }
+      if (kasw::ballot(!endl) == 0) break;
+      if (kasw::ballot(staging) == 0) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
+    }
+    if (a.stats && have_s && lane == 0) {
+      int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      st[12] = f_iter; st[13] = f_idle;
+    }
+  } else {
+    // ------------------------------------------------------------------ retirer: finished rows ->
+    // broker ids, digest, the final out row (two batches of rows per lane alternate so that the id
+    // reads of one are in flight while the other is written)
+    struct Retired { bool on; int32_t id[W], Lp, p, k, ow; int32_t* row; };
+    TileIter itr = tile_iter_begin(have_s);
+    int32_t jr = 0;
+    bool fin = false;
+    uint64_t digest = 0;
+    auto finish = [&](Retired& r) {
+      if (r.on) {
+#pragma unroll
+        for (int q = 0; q < W; ++q)
+          if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.k, (uint32_t)r.p, (uint32_t)q, r.id[q]);
+        if (r.ow == W) {
+          RowW<W> o;
+#pragma unroll
+          for (int q = 0; q < W; ++q) o.v[q] = q < r.Lp ? r.id[q] : -1;
+          *reinterpret_cast<RowW<W>*>(r.row) = o;
+        } else {
+#pragma unroll
+          for (int q = 0; q < W; ++q) if (q < r.ow) r.row[q] = q < r.Lp ? r.id[q] : -1;
+        }
+      }
+      r.on = false;
+    };
+    auto gather = [&](Retired& r) -> bool {
+      if (fin) return false;
+      const WideSlot sl = ring[(jr & (K - 1)) * 64 + lane];
+      if (KAS_WTAG_IS_DONE(sl.tag)) {
+        ring[(jr & (K - 1)) * 64 + lane].tag = KAS_TAG_FREE;
+        jr += 1;
+        tile_next<64>(itr, a, sd);
+        int32_t es[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) es[q] = sl.e[q];
+        r.on = true; r.Lp = (sl.tag >> 15) & 7; r.p = itr.row0 + lane; r.k = itr.k;
+        r.ow = r.p < itr.tP ? itr.tow : 0;                  // a lane past the last row of the tile writes nothing
+        r.row = a.out + itr.tout + (int64_t)r.p * itr.tow;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+          const int32_t en = sel<W>(es, (sl.tag >> (3 * q)) & 7);
+          const int32_t node = q < r.Lp ? (en & 0xffff) >> 3 : 0;
+          r.id[q] = g_node_id[node];                        // node table of the scenario: L2-resident
+        }
+        return true;
+      }
+      if (sl.tag == KAS_TAG_END) fin = true;
+      return false;
+    };
+    Retired ra, rb;
+    ra.on = false; rb.on = false; ra.Lp = 0; rb.Lp = 0; ra.p = 0; rb.p = 0; ra.k = 0; rb.k = 0; ra.ow = 0; rb.ow = 0;
+    ra.row = nullptr; rb.row = nullptr;
+#pragma unroll
+    for (int q = 0; q < W; ++q) { ra.id[q] = 0; rb.id[q] = 0; }
+    for (;;) {
+      bool retired = false;
+      kasw::repoll();
+      finish(ra);
+      retired = gather(ra) || retired;
+      kasw::repoll();
+      finish(rb);
+      retired = gather(rb) || retired;
+      if (kasw::ballot(!fin) == 0) break;
+      if (kasw::ballot(retired) == 0) kasw::nap<KAS_IDLE_NAP>();
+    }
+    finish(ra); finish(rb);
+    kasw::lds_atomic_add_u64(&gdig[0], digest);
+    kasw::lockstep();
+    if (have_s && lane == 0) a.scenario_results[s].digest = gdig[0];
+  }
+}
+
+}  // namespace kas

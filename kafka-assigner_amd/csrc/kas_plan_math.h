@@ -126,6 +126,14 @@ KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G, int32_
 KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed) {
   return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G, packed) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G + 256);
 }
+// ticket form for lists 4 and 5 wide (kas_order_wide.h), one scenario per workgroup: uint64 counter
+// row per node + the padding holder's (five 10-bit counts), uint64 lane mask per node, uint16
+// tickets handed out per node, a ring of KAS_RING_SLOTS 32-byte row slots per lane, digest + queue scratch
+KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  return kas_align16(2 * (int64_t)kas_align16(8 * (n + 1)) + kas_align16(2 * (n + 1)) +
+                     KAS_RING_SLOTS * 64 * 32 + 16 + 256);
+}
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {
   int64_t n = n_max > 0 ? n_max : 1;
@@ -144,6 +152,7 @@ struct KasShape {
   int32_t tickets_ok = 1;             // the ticket form of P5 is applicable to every scenario
   int32_t with_x = 1;                 // LDS has room for the histogram / quota table of the fast fill
   int32_t packed_ok = 1;              // every scenario's ticket bound fits 10-bit counter fields
+  int32_t wide_ok = 0;                // lists 4 or 5 wide and the wide ticket form is applicable
   std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
   int64_t accmask_words = 0;
   std::vector<int64_t> orph_off;      // per scenario, in int32 elements
@@ -241,6 +250,10 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   }
   s.idmap_entries = (int32_t)max_range_fit;
   s.Wc = kas_width_class(s.W);
+  // lists 4 and 5 wide: the wide ticket form (kas_order_wide.h) under the same conditions plus 10-bit
+  // count fields and 16-bit LDS offsets of its 8-byte counter rows; beyond 5: round form
+  s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.packed_ok && 8 * ((int64_t)s.n_max + 1) <= 65536 &&
+              kas_order_wide_lds(s.n_max) <= KAS_LDS_LIMIT;
   if (s.Wc > 3) s.tickets_ok = 0;              // ring slots / packed counter rows hold lists up to 3
   // widest fill workgroup whose LDS carve-up fits: 4 wavefronts per scenario by default
   int err_total = 0;

@@ -67,6 +67,9 @@ struct TopicOutcome {
   int32_t moved_partitions;
 };
 
+template <int D>
+struct RowWords { uint32_t v[D]; };
+
 // LDS of the fill kernel (kas_fill_lds_layout)
 struct LdsView {
   int32_t* x;           // hist[W][N], then qc[NW][N]
@@ -164,7 +167,7 @@ KAS_DEV int32_t chunk_begin(int32_t nt, int32_t w) { return (int32_t)(((int64_t)
 // ---------------------------------------------------------------------------------------------
 template <int W>
 KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t live_count,
-                          int32_t& head, int32_t* out, int32_t ow, int64_t (&st)[8]) {
+                          int32_t& head, uint16_t* mid, int32_t mw, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   const bool mine = lane < count;
   const int32_t p = mine ? L.ring_p[lane] : 0;
@@ -205,7 +208,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
           if (w != 0) {
             const int32_t rank = kasw::popc(w & kasw::lanemask_lt());
             if (want && rank < slots[u]) {                 // accept (KAS:178-181)
-              out[(int64_t)p * ow + hc] = n[u];
+              mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
               put<W>(hr, hc, rk[u]);
               hc += 1;
               need -= 1;
@@ -229,10 +232,45 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
   return fail_lane;
 }
 
+// Intermediate ("mid") rows.  Between the fill kernel and the order kernel a row is the node indices
+// of its holders in acceptance order as uint16 (KAS_MID_NONE = no holder; N <= 32767 is a plan
+// limit), mid_width(ow) of them per row, stored at the END of the topic's out region: half the
+// bytes of an int32 row for the fill to write and the order kernel to read.  The order kernel turns
+// rows into final out rows (broker ids, int32) in ascending row order from the START of the same
+// region: final row p ends at 4 ow (p + 1) bytes, mid row q starts at 4 ow P - 2 mw (P - q), and
+// 2 mw <= 4 ow, so a final row never reaches a mid row that is still to be read (q > p).
+#define KAS_MID_NONE 0xffffu
+KAS_DEV int32_t mid_width(int32_t ow) { return (ow + 1) & ~1; }
+template <int W>
+constexpr int mid_width_of() { return (W + 1) & ~1; }
+KAS_DEV uint16_t* mid_base(int32_t* out, int32_t P, int32_t ow) {
+  return (uint16_t*)(out + (int64_t)P * ow) - (int64_t)P * mid_width(ow);
+}
+KAS_DEV int32_t mid_to_index(uint32_t v) { return v == KAS_MID_NONE ? -1 : (int32_t)v; }
+
+// one mid row -> node indices (-1 = none); FULLW: the row is mid_width_of<W>() wide (ow == W)
+template <int W>
+KAS_DEV void load_mid_row(const uint16_t* mid, int32_t mw, int32_t ow, int64_t p, bool active, int32_t (&c)[W]) {
+  constexpr int MW = mid_width_of<W>();
+  if (mw == MW && ow == W) {                                // wave-uniform: the row as MW / 2 dwords
+    RowWords<MW / 2> q;
+#pragma unroll
+    for (int k = 0; k < MW / 2; ++k) q.v[k] = 0xffffffffu;
+    if (active) q = *reinterpret_cast<const RowWords<MW / 2>*>(mid + p * MW);
+#pragma unroll
+    for (int k = 0; k < W; ++k) c[k] = mid_to_index((q.v[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) c[k] = (active && k < ow) ? mid_to_index(mid[p * mw + k]) : -1;
+  }
+}
+
 // Everything a phase needs to know about the topic being solved.
 struct TopicView {
   const int32_t* cur;
   int32_t* out;
+  uint16_t* mid;        // mid rows of the topic (inside its out region)
+  int32_t mw;           // uint16 per mid row
   int32_t* orph;        // orphan row lists of this scenario (HBM scratch)
   const int32_t* len_arr;
   const int32_t* inp_arr;
@@ -365,14 +403,20 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
     hc += acc ? 1 : 0;
   }
   if (active) {
-    if (T.ow == W) {                                        // wave-uniform: one W-dword store
-      RowW<W> q;
+    constexpr int MW = mid_width_of<W>();
+    if (T.ow == W) {                                        // wave-uniform: the mid row as MW / 2 dwords
+      RowWords<MW / 2> q;
 #pragma unroll
-      for (int k = 0; k < W; ++k) q.v[k] = hold[k];
-      *reinterpret_cast<RowW<W>*>(T.out + (int64_t)p * W) = q;
+      for (int k = 0; k < MW / 2; ++k) {
+        const uint32_t lo = (uint32_t)hold[2 * k] & 0xffffu;
+        const uint32_t hi = 2 * k + 1 < W ? ((uint32_t)hold[2 * k + 1] & 0xffffu) : KAS_MID_NONE;
+        q.v[k] = lo | (hi << 16);
+      }
+      *reinterpret_cast<RowWords<MW / 2>*>(T.mid + (int64_t)p * MW) = q;
     } else {
 #pragma unroll
-      for (int k = 0; k < W; ++k) if (k < T.ow) T.out[(int64_t)p * T.ow + k] = hold[k];
+      for (int k = 0; k < MW; ++k)
+        if (k < T.mw) T.mid[(int64_t)p * T.mw + k] = (uint16_t)(k < W ? hold[k] : -1);
     }
   }
   const bool in_parts = active && (T.inp_arr ? T.inp_arr[p] != 0 : true);
@@ -415,7 +459,7 @@ KAS_DEV int32_t drain_ring(const LdsView& L, const TopicView& T, int32_t min_fil
   const int lane = kasw::lane();
   while (ring_count >= min_fill && ring_count > 0) {
     const int32_t n_win = ring_count < 64 ? ring_count : 64;
-    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.out, T.ow, st);
+    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.mid, T.mw, st);
     if (fl >= 0) return L.ring_p[fl];
     const int32_t rest = ring_count - n_win;           // shift the ring down by one window
     int32_t tp = 0, tm = 0; int32_t tr[W];
@@ -729,12 +773,11 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     return g < total ? T.orph[((int64_t)chunk_begin<NW>(T.nt, w) << 6) + (g - base)] : -1;
   };
   auto row_cells = [&](int32_t p, int32_t (&c)[W]) {
-#pragma unroll
-    for (int k = 0; k < W; ++k) c[k] = (p >= 0 && k < T.ow) ? T.out[(int64_t)p * T.ow + k] : -1;
+    load_mid_row<W>(T.mid, T.mw, T.ow, p >= 0 ? p : 0, p >= 0, c);
   };
   const int32_t n_win = (total + 63) >> 6;
   const int32_t prev = wave == 0 ? NW - 1 : wave - 1;       // the wave that has window w - 1
-  const int32_t cap = T.cap, ow = T.ow;
+  const int32_t cap = T.cap, mw = T.mw;
   constexpr int U = 4;                                     // node positions fetched per LDS round trip
   int32_t p_nxt = orphan_row(64 * wave + lane);
   int32_t c_nxt[W];
@@ -798,7 +841,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
             if (wm != 0) {
               const int32_t rank = kasw::popc(wm & kasw::lanemask_lt());
               if (want && rank < slots[u]) {               // accept (KAS:178-181)
-                T.out[(int64_t)p * ow + hc] = n[u];
+                T.mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
                 put<W>(hr, hc, rk[u]);
                 hc += 1;
                 need -= 1;
@@ -919,6 +962,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
   T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
   T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
+  T.mw = mid_width(T.ow); T.mid = mid_base(T.out, T.P, T.ow);
   const int32_t P = T.P, hash = T.hash;
 
   TopicOutcome res;
@@ -1221,7 +1265,9 @@ struct alignas(16) RingSlot { int32_t tag; int32_t c[3]; };
 struct TileIter {
   int32_t k, tP, tow, row0;              // topic, its rows / row width, first row of the current tile
   int32_t rot;                           // the topic's rotation tables, see ticket_rotation()
+  int32_t rotw;                          // idx_m for m = 1..5, see wide_rotation() (lists 4 and 5 wide)
   int64_t tout;
+  int64_t tmid;                          // first mid row of the topic: uint16 offset from a.out
   bool exhausted;
 };
 
@@ -1273,7 +1319,11 @@ KAS_DEV_COLD TileIter tile_next_topic(TileIter it, const KasLaunch& a, const kas
     const kas_topic_desc td = a.topics[ti];
     if (td.n_partitions <= 0) continue;
     it.tP = td.n_partitions; it.tow = td.out_width; it.tout = td.out_off;
+    it.tmid = 2 * (td.out_off + (int64_t)it.tP * it.tow) - (int64_t)it.tP * mid_width(it.tow);
     it.rot = ticket_rotation(td.name_hash);
+    it.rotw = 0;
+#pragma unroll
+    for (int m = 1; m <= 5; ++m) it.rotw |= (java_abs_mod(td.name_hash, m) & 7) << (3 * m);
     it.row0 = 0;
     return it;
   }
@@ -1290,7 +1340,7 @@ KAS_DEV bool tile_next(TileIter& it, const KasLaunch& a, const kas_scenario_desc
 
 KAS_DEV TileIter tile_iter_begin(bool have_scenario) {
   TileIter it;
-  it.k = -1; it.tP = 0; it.tow = 1; it.row0 = 0; it.rot = KAS_ROT_IDENT; it.tout = 0;
+  it.k = -1; it.tP = 0; it.tow = 1; it.row0 = 0; it.rot = KAS_ROT_IDENT; it.rotw = 0; it.tout = 0; it.tmid = 0;
   it.exhausted = !have_scenario;
   return it;
 }
@@ -1574,10 +1624,14 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           const int32_t p = itl.row0 + li;
           pf_rot = itl.rot;
           if (p < itl.tP) {
-            const int32_t* row = a.out + itl.tout + (int64_t)p * itl.tow;
+            // the fill kernel's mid row: uint16 node indices, 0xffff = none (sorts last, like ~0)
+            const uint16_t* row = (const uint16_t*)a.out + itl.tmid + (int64_t)p * mid_width(itl.tow);
             if (W == 3 && itl.tow == 3) {
-              const RowW<3> r = *(const RowW<3>*)row;
-              pf_c0 = (uint32_t)r.v[0]; pf_c1 = (uint32_t)r.v[1]; pf_c2 = (uint32_t)r.v[2];
+              const RowWords<2> r = *(const RowWords<2>*)row;
+              pf_c0 = r.v[0] & 0xffffu; pf_c1 = r.v[0] >> 16; pf_c2 = r.v[1] & 0xffffu;
+            } else if (W == 2 && itl.tow == 2) {
+              const uint32_t r = *(const uint32_t*)row;
+              pf_c0 = r & 0xffffu; pf_c1 = r >> 16;
             } else {
               pf_c0 = (uint32_t)row[0];
               if (W > 1 && itl.tow > 1) pf_c1 = (uint32_t)row[1];
@@ -1658,19 +1712,25 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     // lane are in flight alternately, so their latency is not in the slot's way.
     constexpr int UR = 2;                                   // rows per lane per batch
     constexpr int RSH = PK ? 2 : 3;                         // log2(bytes per counter row)
-    struct Retired { bool on; int32_t id[3], Lp, p, k; int32_t* row; };
+    struct Retired { bool on; int32_t id[3], Lp, p, k, ow; int32_t* row; };
     TileIter itr = tile_iter_begin(have_s);
     int32_t jr = 0;
     bool fin = false;
     uint64_t digest = 0;
     auto finish = [&](Retired& r) {
       if (r.on) {
+        // the whole final row, -1 behind the list (the mid row it came from lives elsewhere)
 #pragma unroll
-        for (int q = 0; q < W; ++q) {
-          if (q < r.Lp) {
-            r.row[q] = r.id[q];
-            digest += kas_digest_cell((uint32_t)r.k, (uint32_t)r.p, (uint32_t)q, r.id[q]);
-          }
+        for (int q = 0; q < W; ++q)
+          if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.k, (uint32_t)r.p, (uint32_t)q, r.id[q]);
+        if (r.ow == W) {
+          RowW<W> o;
+#pragma unroll
+          for (int q = 0; q < W; ++q) o.v[q] = q < r.Lp ? r.id[q] : -1;
+          *reinterpret_cast<RowW<W>*>(r.row) = o;
+        } else {
+#pragma unroll
+          for (int q = 0; q < W; ++q) if (q < r.ow) r.row[q] = q < r.Lp ? r.id[q] : -1;
         }
       }
       r.on = false;
@@ -1685,6 +1745,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         const int32_t w0 = sl.tag & 3, w1 = (sl.tag >> 2) & 3;
         const int32_t w[3] = {w0, w1, 3 - w0 - w1};
         r.on = true; r.Lp = (sl.tag >> 4) & 3; r.p = itr.row0 + li; r.k = itr.k;
+        r.ow = r.p < itr.tP ? itr.tow : 0;                // a lane past the last row of the tile writes nothing
         r.row = a.out + itr.tout + (int64_t)r.p * itr.tow;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
@@ -1701,7 +1762,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       ra[u].on = false; rb[u].on = false;
-      ra[u].Lp = 0; rb[u].Lp = 0; ra[u].p = 0; rb[u].p = 0; ra[u].k = 0; rb[u].k = 0;
+      ra[u].Lp = 0; rb[u].Lp = 0; ra[u].p = 0; rb[u].p = 0; ra[u].k = 0; rb[u].k = 0; ra[u].ow = 0; rb[u].ow = 0;
       ra[u].row = nullptr; rb[u].row = nullptr;
 #pragma unroll
       for (int q = 0; q < 3; ++q) { ra[u].id[q] = 0; rb[u].id[q] = 0; }
@@ -1752,9 +1813,12 @@ KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td,
 #pragma unroll
   for (int m = 1; m <= W; ++m) idxm[m] = java_abs_mod(hash, m);
   idxm[0] = 0;
-  int32_t nx[W];                                  // next tile's out row (software prefetch)
-#pragma unroll
-  for (int k = 0; k < W; ++k) nx[k] = (lane < P && k < ow) ? out[(int64_t)lane * ow + k] : -1;
+  // rows come in as mid rows at the end of the topic's out region and leave as final rows from its
+  // start: the tile after the current one is read before the current tile's final rows are written
+  const uint16_t* mid = mid_base(out, P, ow);
+  const int32_t mw = mid_width(ow);
+  int32_t nx[W];                                  // next tile's mid row (software prefetch)
+  load_mid_row<W>(mid, mw, ow, lane < P ? lane : 0, lane < P, nx);
   for (int32_t tile = 0; tile < nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
     const bool active = p < P;
@@ -1762,8 +1826,7 @@ KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td,
     sort_holders<W>(nx, h, Lp);
     {
       const int32_t pn = p + 64;
-#pragma unroll
-      for (int k = 0; k < W; ++k) nx[k] = (pn < P && k < ow) ? out[(int64_t)pn * ow + k] : -1;
+      load_mid_row<W>(mid, mw, ow, pn < P ? pn : 0, pn < P, nx);
     }
     if (hash_min) {
       // KAS:190 index error: some set size m <= L has a negative rotation offset
@@ -1912,3 +1975,5 @@ KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char*
 }
 
 }  // namespace kas
+
+#include "kas_order_wide.h"

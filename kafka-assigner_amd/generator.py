@@ -77,6 +77,8 @@ def scenario_action(seed: int, s: int, N: int, R: int, actions: Sequence[str] = 
         return act, perturb_brokers(N, R, remove=[int(rng.integers(N))], add=1)
     if act == "add50":                      # BASELINE.json configs[3]: brokers 1000-1049, rack id mod R
         return act, perturb_brokers(N, R, add=50)
+    if act in ("c5", "c5_norack"):          # BASELINE.json configs[4]: remove every 50th broker, add N/25 new ones
+        return act, perturb_brokers(N, R, remove=list(range(0, N, 50)), add=N // 25, rack_aware=act == "c5")
     if act == "mixed":
         k = int(rng.integers(1, max_remove + 1))
         return act, perturb_brokers(N, R, remove=rng.choice(N, size=k, replace=False).tolist(),

@@ -1,51 +1,50 @@
 #!/usr/bin/env python
-"""Copy the summaries of scripts/gpu_final.sh from gpurun_out/ into profiles/ (tracked) and derive
-profiles/pmc_traffic.json (HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes)."""
+"""Copy rocprofv3 summaries of a GPU trip from gpurun_out/<dir>/ into profiles/ (tracked) and derive
+profiles/pmc_traffic.json (HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes).
+usage: collect_profiles.py DIR TAG   (DIR holds prof_fetch/, prof_write/ and optionally prof_trace*/)"""
 import collections
 import csv
+import glob
 import json
 import os
-import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+d, tag = sys.argv[1], sys.argv[2]
 os.makedirs("profiles", exist_ok=True)
-rows = list(csv.DictReader(open("gpurun_out/prof_trace/trace_kernel_stats.csv")))
-with open(f"profiles/{tag}_kernel_trace_stats.csv", "w") as f:
-    w = csv.writer(f)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in rows:
-        w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
-                    r["MinNs"], r["MaxNs"], r["StdDev"]])
+for tr in glob.glob(os.path.join(d, "prof_trace*", "*_kernel_stats.csv")):
+    name = os.path.basename(os.path.dirname(tr)).replace("prof_trace", "kernel_trace_stats")
+    rows = list(csv.DictReader(open(tr)))
+    with open(f"profiles/{tag}_{name}.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
 res = {}
 with open(f"profiles/{tag}_pmc_hbm_traffic.csv", "w") as out:
     out.write("pass,kernel,dispatches,counter,avg_value_kb_per_dispatch\n")
     for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f"gpurun_out/prof_{name}/{name}_counter_collection.csv")):
-            if r["Counter_Name"] == ctr and "kas_" in r["Kernel_Name"]:
-                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        for f in glob.glob(os.path.join(d, f"prof_{name}", "*counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == ctr and "kas_" in r["Kernel_Name"]:
+                    agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out.write(f'{name},"{k}",{len(v)},{ctr},{sum(v) / len(v):.1f}\n')
-            res[(ctr, "fill" if "fill" in k else "order")] = sum(v) / len(v)
+            if "permutation" not in k:
+                res[(ctr, "fill" if "fill" in k else "order")] = sum(v) / len(v)
 KB = 1024
 ff, fo = res[("FETCH_SIZE", "fill")] * KB, res[("FETCH_SIZE", "order")] * KB
 wf, wo = res[("WRITE_SIZE", "fill")] * KB, res[("WRITE_SIZE", "order")] * KB
-known = 1000 * 100000 * 12          # the order kernel reads every 12-byte out row exactly once
+known = 1000 * 100000 * 8           # the order kernel reads every 8-byte mid row exactly once
 corr = known / fo
 j = {"scenarios": 1000, "partitions": 100000,
      "hbm_bytes_per_launch": 2 * (ff + fo) + wf + wo,
      "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, profiles/{tag}_pmc_hbm_traffic.csv), "
                "kB -> bytes; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE tallies 128-B requests at 64 B) - "
-               "calibrated on the order kernel, which reads each 12-byte out row exactly once: known/measured = %.3f" % corr,
+               "check: the order kernel reads each 8-byte mid row exactly once, known/measured = %.3f" % corr,
      "fetch_kb": {"fill": res[("FETCH_SIZE", "fill")], "order": res[("FETCH_SIZE", "order")]},
      "write_kb": {"fill": res[("WRITE_SIZE", "fill")], "order": res[("WRITE_SIZE", "order")]},
      "read_correction_measured": corr}
 json.dump(j, open("profiles/pmc_traffic.json", "w"), indent=1)
-for src, dst in (("bench_default.log", f"{tag}_bench_default.log"), ("bench_f1.log", f"{tag}_bench_one_batch_in_flight.log"),
-                 ("bench_c2.log", f"{tag}_bench_config2_single_scenario.log"), ("bench_c4.log", f"{tag}_bench_config4_8000_scenarios_add_brokers.log"), ("pytest_gpu.log", f"{tag}_pytest_gpu.log"),
-                 ("smoke.log", f"{tag}_smoke.log"), ("stats_default.json", f"{tag}_phase_stats_default.json"),
-                 ("stats_f1.json", f"{tag}_phase_stats_one_batch_in_flight.json")):
-    if os.path.exists("gpurun_out/" + src):
-        shutil.copy("gpurun_out/" + src, "profiles/" + dst)
 print(json.dumps(j, indent=1))

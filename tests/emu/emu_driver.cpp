@@ -145,6 +145,10 @@ template <int W, int G, bool PK> void run_order_tickets(void* p) {
   RunArgs* r = (RunArgs*)p;
   if constexpr (W <= 3) kas::order_tickets<W, G, PK>(*r->a, r->s, r->lds);
 }
+template <int W> void run_order_wide(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
+}
 template <int W> void run_order_rounds(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_scenario_rounds<W>(*r->a, r->s, r->lds);
@@ -193,11 +197,13 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     return rc;
   }
   const bool tickets = sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER);
+  const bool wide = sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER);
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
   size_t lds_bytes = (size_t)sh.lds.total;
   if ((size_t)kas_order_round_lds(sh.n_max, sh.Wc) > lds_bytes) lds_bytes = (size_t)kas_order_round_lds(sh.n_max, sh.Wc);
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
+  if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
   std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
   KasLaunch a;
   a.scen = b->scenarios; a.topics = b->topics; a.node_id = b->node_id; a.node_rack = b->node_rack;
@@ -253,6 +259,21 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
         const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
         fprintf(stderr, "emu stats s=%d solver_iter=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld\n", s,
                 (long long)st[9], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12]);
+      }
+    }
+  } else if (wide) {
+    run_fn f = sh.Wc == 4 ? run_order_wide<4> : run_order_wide<5>;
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(lds.data(), 0xCD, lds.size());
+      RunArgs ra{&a, s, lds.data()};
+      if (kasw::run_block(f, &ra, 3) != 0) return bad("order (wide tickets)", s);
+    }
+    for (int32_t s = 0; s < b->n_scenarios; ++s) g_last_queue_rows += (long)a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 14];
+    if (getenv("KAS_EMU_STATS")) {
+      for (int32_t s = 0; s < b->n_scenarios; ++s) {
+        const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+        fprintf(stderr, "emu stats (wide) s=%d solver_iter=%lld queue_passes=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld\n", s,
+                (long long)st[9], (long long)st[6], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12]);
       }
     }
   } else {

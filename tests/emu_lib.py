@@ -17,7 +17,8 @@ _LIB = None
 def build_emu() -> str:
     so = os.path.join(EMU_DIR, "libkas_emu.so")
     deps = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "kas_wave.h"),
-            os.path.join(CSRC, "kas_solver_body.h"), os.path.join(CSRC, "kas_plan_math.h"),
+            os.path.join(CSRC, "kas_solver_body.h"), os.path.join(CSRC, "kas_order_wide.h"),
+            os.path.join(CSRC, "kas_plan_math.h"),
             os.path.join(ROOT, "include", "kas_abi.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call([

@@ -199,3 +199,41 @@ def test_emu_topic_without_rows_next_to_full_width_topics():
     want = oracle_solve(fb)
     assert want.topic_results["status"][1] == abi.KAS_OK
     assert_same_outputs(fb, want, emu_solve(fb), "emu empty topic last")
+
+
+@pytest.mark.parametrize("P,N,R,RF,actions,rack_aware", [
+    (20000, 200, 20, 5, ("add_k",), False),   # one broker at a time fills up: long single-node queues
+    (20000, 200, 20, 4, ("mixed",), True),    # rack constraints interleave several nodes being filled
+    (3000, 120, 12, 5, G.ACTIONS, True),
+    (777, 40, 10, 4, G.ACTIONS, True),
+])
+def test_emu_wide_lists_take_the_wide_ticket_form(P, N, R, RF, actions, rack_aware):
+    """Lists 4 and 5 wide without Context in/out: kas_order_wide.h (tickets, five 10-bit counts per
+    node, the generalised queue step) against the oracle and against the round form."""
+    fb = _batch(100, 3, P, N, R, RF, actions, rack_aware=rack_aware)
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).any()
+    assert_same_outputs(fb, want, emu_solve(fb), "emu wide tickets")
+    if P >= 20000:
+        assert last_queue_rows() > 0, "the queue path of the wide kernel did not run"
+    assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round form")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=1 | (2 << 8)), "emu wide tickets after the general fill, 2 waves")
+
+
+def test_emu_wide_lists_multi_topic_and_mixed_widths():
+    """Topics of different widths in one scenario (3-, 5- and 4-wide lists: the batch runs at width
+    class 5), tickets carried across topics."""
+    scs = []
+    for s in range(3):
+        act, bs = G.scenario_action(5, s, 60, 12, actions=("add_k",), max_add=6)
+        racks = {int(b): "r%d" % int(r) for b, r in zip(bs.node_id, bs.node_rack)}
+        topics = []
+        for t, rf in enumerate((3, 5, 4)):
+            cur = G.random_assignment(9 + 7 * s + t, 900 + 31 * t, 60, 12, rf)
+            topics.append(Topic("topic-%d" % t, {p: cur[p].tolist() for p in range(cur.shape[0])}, rf))
+        scs.append(Scenario(brokers=[int(b) for b in bs.node_id], racks=racks, topics=topics))
+    fb = flatten(scs)
+    want = oracle_solve(fb)
+    assert (want.topic_results["status"][3:6] == abi.KAS_OK).all()      # one scenario runs all three widths
+    assert_same_outputs(fb, want, emu_solve(fb), "emu wide multi-topic")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu wide multi-topic, round form")
