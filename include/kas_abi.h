@@ -258,6 +258,7 @@ int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
  *   [0] setup  [1] P2 histogram + quota  [2] P2 keep-scan + P3  [3] P4 first fit
  *   [4] P4 windows  [5] P4 node steps  [6] P5 rounds (round form)
  *   [7] P2 tiles of wave 0 that needed quota ranking  [8] order kernel time
+ *   ([4], [5], [7] are zero unless the library was built with -DKAS_FILL_COUNTERS)
  *   ticket form: [9] solver steps  [11] of those with rows in hand but none ready
  *                [6] steps that took the queue path  [10] wins / prefix-sum rounds spent there
  *                [14] rows decided inside queues  [15] sum over steps of rows in hand

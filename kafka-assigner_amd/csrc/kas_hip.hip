@@ -27,13 +27,13 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// min waves per SIMD: at N = 1000 the LDS carve-up (31 KB) allows 5 workgroups of 4 wavefronts per
-// CU; at 128 VGPRs (4 waves per SIMD) four of them fill the register files, at 96 the fifth fits
-// and order workgroups of other batches in flight share the CU more easily.  Measured: +3.8 %
-// whole-job throughput at 8 batches in flight, fill alone 12 % slower (cold paths and the P4
-// prologue spill a little more).
+// min waves per SIMD of the fill kernel.  Its row scans keep four tiles of rows in flight per lane
+// and spill heavily below 128 VGPRs: measured in round 2 (mid rows, lookup mode hoisted, event
+// counters compiled out) one batch alone takes 1.30 ms at 128 VGPRs (4 waves per SIMD, 4 workgroups
+// per CU) against 1.61 ms at 96 (5, the LDS limit), and with 8 batches in flight the whole-job rate
+// is the same within noise (297-299k scenarios/s), so the faster single launch wins.
 #ifndef KAS_FILL_MIN_WAVES
-#define KAS_FILL_MIN_WAVES 5
+#define KAS_FILL_MIN_WAVES 4
 #endif
 template <int W, int NW>
 __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(KasLaunch a) {
@@ -71,7 +71,14 @@ __global__ __launch_bounds__(192) void kas_order_wide_kernel(KasLaunch a) {
 }
 
 typedef void (*kas_kernel_fn)(KasLaunch);
-#ifdef KAS_MINIMAL_INSTANCES
+#if defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES == 5
+// tuning build for BASELINE.json configs[4] (lists 5 wide, 4 fill waves): seconds to compile
+static bool kas_minimal_ok(int Wc, int NW, int) { return Wc == 5 && NW == 4; }
+static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<5, 4>; }
+static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
+static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
+static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
+#elif defined(KAS_MINIMAL_INSTANCES)
 // tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
 // lists 3 wide, 4 fill waves, 2 scenarios per solver wavefront — so that a variant compiles in
 // seconds.  Other shapes are refused by kas_plan_create in such a build.
@@ -286,7 +293,7 @@ static int upload(void** dst, const void* src, size_t bytes, hipStream_t st) {
 static int kas_plan_set_kernels(kas_plan* p) {
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, p->lds.total));
-  if (p->Wc <= 3)
+  if (p->Wc <= 3 && kas_order_ticket_for(p->Wc, p->G, 0))
     for (int pk = 0; pk < 2; ++pk)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,

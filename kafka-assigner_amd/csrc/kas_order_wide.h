@@ -32,6 +32,21 @@ namespace kas {
 #ifndef KAS_WIDE_QUEUE_PASSES
 #define KAS_WIDE_QUEUE_PASSES 2
 #endif
+// a row waiting on exactly one node with this many rows ahead of it nominates that node
+#ifndef KAS_WIDE_NOMINATE
+#define KAS_WIDE_NOMINATE 2
+#endif
+// rows a queue must decide beyond the one that was ready anyway for the pass to count as paying;
+// below that the next nominations are skipped (1, 2, 4 ... up to KAS_WIDE_BACKOFF_MAX steps)
+#ifndef KAS_WIDE_MIN_GAIN
+#define KAS_WIDE_MIN_GAIN 3
+#endif
+#ifndef KAS_WIDE_BACKOFF_MAX
+#define KAS_WIDE_BACKOFF_MAX 16
+#endif
+#ifndef KAS_WIDE_RING_SLOTS
+#define KAS_WIDE_RING_SLOTS KAS_RING_SLOTS
+#endif
 #define KAS_WIDE_FIELD_MASK 0x3ffu
 #define KAS_WIDE_DUMMY_TICKET (5 * 0x3ff)
 
@@ -42,17 +57,45 @@ struct alignas(16) WideSlot { int32_t tag; int32_t e[5]; int32_t rot; int32_t sp
 #define KAS_WTAG_DONE ((int32_t)0x80000000)
 #define KAS_WTAG_IS_DONE(t) (((uint32_t)(t) & 0xfffc0000u) == 0x80000000u)
 
-// slot.rot = TileIter::rotw: idx_m = Math.abs(hash) % m (KAS:190) for set sizes m = 1..5, 3 bits each
+// slot.rot = TileIter::rot of a wide iterator: idx_m = Math.abs(hash) % m (KAS:190) for set sizes m = 1..5, 3 bits each
 // at bit 3 m (computed per topic by tile_next_topic)
 
 KAS_DEV uint64_t wide_field_unit(int r) {                   // + 1 on count field r
   return r == 0 ? 1ull : r == 1 ? (1ull << 10) : r == 2 ? (1ull << 20) : r == 3 ? (1ull << 32) : (1ull << 42);
 }
 
+// The picks of one row (KAS:225-236) as pick_row<W>, with the rotation offsets taken straight from
+// the packed word (idx_m at bit 3 m) and the ranks of the set members carried along instead of
+// recounted.  c[k][r] = count[holder k][r], holders ascending; pos[r] = list position picked for r.
+template <int W>
+KAS_DEV void pick_row_packed(const int32_t (&c)[W][W], int32_t Lp, bool valid, int32_t rot, int32_t (&pos)[W]) {
+  uint32_t alive = valid ? ((1u << Lp) - 1u) : 0u;
+  int32_t m = valid ? Lp : 0;
+#pragma unroll
+  for (int r = 0; r < W; ++r) {
+    const int32_t idx = (rot >> (3 * m)) & 7;
+    int32_t keys[W], best = 0x7fffffff, rank = idx;         // rank of the next set member + idx
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const int32_t in = (int32_t)((alive >> k) & 1u);
+      const int32_t rr = rank >= m ? rank - m : rank;
+      keys[k] = in ? ((c[k][r] << 3) | rr) : 0x7fffffff;
+      best = keys[k] < best ? keys[k] : best;
+      rank += in;
+    }
+    int32_t ps = 0;
+#pragma unroll
+    for (int k = 1; k < W; ++k) ps = keys[k] == best ? k : ps;
+    pos[r] = ps;
+    alive &= ~(1u << ps);                                   // nodeSet.remove (KAS:232)
+    m -= m > 0 ? 1 : 0;
+  }
+}
+
 template <int W>
 KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned char* lds_raw) {
   static_assert(W == 4 || W == 5, "the narrow kernel serves lists up to 3 wide, the round form beyond 5");
-  constexpr int K = KAS_RING_SLOTS;
+  constexpr int K = KAS_WIDE_RING_SLOTS;
   constexpr int T = W - 1;                                  // replica indices whose counts decide a pick
   const int lane = kasw::lane();
   const int32_t wave = kasw::wave_id();
@@ -125,15 +168,11 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       for (int q = 0; q < W; ++q) { d_any |= d[q]; d_sum += d[q]; nz += d[q] != 0u ? 1 : 0; }
       bool ready = cv && d_any == 0u;
       bool ready_q = false;                                 // decided inside a queue in this step
-      int32_t idxm[W + 1];
-      idxm[0] = 0;
-#pragma unroll
-      for (int m = 1; m <= W; ++m) idxm[m] = (rot >> (3 * m)) & 7;
       // ---- queues: rows in hand that hold one node X and wait for nothing but X
       {
         uint64_t nb = 0ull;
         if (run_skip > 0) run_skip -= 1;
-        else nb = kasw::ballot(cv && nz == 1 && d_sum == (uint32_t)KAS_RUN_NOMINATE);   // third in line on X, free otherwise
+        else nb = kasw::ballot(cv && nz == 1 && d_sum == (uint32_t)KAS_WIDE_NOMINATE);   // third in line on X, free otherwise
         int32_t my_ax = 0;
 #pragma unroll
         for (int q = 0; q < W; ++q) my_ax = d[q] != 0u ? (e[q] & 0xffff) : my_ax;       // (a nominating row waits on one node)
@@ -161,11 +200,11 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           const int32_t qlen = ~hb != 0ull ? kasw::first_lane(~hb) : 64;   // ranks 0..qlen-1 are all in hand
           const bool member = cand && (int32_t)kx < qlen;
           const int32_t gain = kasw::popc(kasw::ballot(member && kx > 0u));
-          if (gain < KAS_RUN_MIN_GAIN) {
-            run_backoff = run_backoff == 0 ? 1 : (run_backoff < 16 ? 2 * run_backoff : 16);
-            run_skip = run_backoff;
+          if (gain < KAS_WIDE_MIN_GAIN) {
+            run_backoff = run_backoff == 0 ? 1 : (run_backoff < KAS_WIDE_BACKOFF_MAX ? 2 * run_backoff : KAS_WIDE_BACKOFF_MAX);
+            run_skip = KAS_WIDE_BACKOFF_MAX > 0 ? run_backoff : 0;
           } else {
-            if (gain > KAS_RUN_MIN_GAIN) run_backoff = 0;
+            if (gain > KAS_WIDE_MIN_GAIN) run_backoff = 0;
             // thresholds of my row against X (relative to X's counts now): X takes pick r iff
             // count[X][r] + (wins of the rows ahead of me at r) < T_r, the other holders being free
             int32_t cX[W];
@@ -176,28 +215,28 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
               for (int q = 0; q < W; ++q) col[q] = c[q][r];
               cX[r] = sel<W>(col, hq);
             }
-            const uint32_t xbit = 1u << hq, xlow = xbit - 1u;
+            const uint32_t xbit = 1u << hq;
             uint32_t alive_o = ((1u << Lp) - 1u) & ~xbit;
             int32_t tpack = 0;
 #pragma unroll
             for (int r = 0; r < T; ++r) {
               const uint32_t setmask = alive_o | xbit;
               const int32_t m = __builtin_popcount(setmask);
-              const int32_t idx = sel<W + 1>(idxm, m);
-              int32_t keys[W], best = 0x7fffffff;
+              const int32_t idx = (rot >> (3 * m)) & 7;
+              int32_t keys[W], best = 0x7fffffff, rank = idx, rrX = 0;
 #pragma unroll
               for (int k = 0; k < W; ++k) {
-                int32_t rr = __builtin_popcount(setmask & ((1u << k) - 1u)) + idx;
-                rr -= rr >= m ? m : 0;
-                const int32_t dead = (int32_t)((((alive_o >> k) & 1u) - 1u) & 0x7fffffffu);
-                keys[k] = ((c[k][r] << 3) | rr) | dead;
+                const int32_t in = (int32_t)((setmask >> k) & 1u);
+                const int32_t rr = rank >= m ? rank - m : rank;
+                const bool other = ((alive_o >> k) & 1u) != 0u;
+                keys[k] = other ? ((c[k][r] << 3) | rr) : 0x7fffffff;
                 best = keys[k] < best ? keys[k] : best;
+                rrX = hq == k ? rr : rrX;
+                rank += in;
               }
               int32_t bestk = 0;
 #pragma unroll
               for (int k = 1; k < W; ++k) bestk = keys[k] == best ? k : bestk;
-              int32_t rrX = __builtin_popcount(setmask & xlow) + idx;
-              rrX -= rrX >= m ? m : 0;
               // (c << 3 | rrX) < best  <=>  c < ceil((best - rrX) / 8); nobody else left: always
               int32_t t = alive_o != 0u ? ((best - rrX + 7) >> 3) - cX[r] : 127;
               t = t < 0 ? 0 : (t > 127 ? 127 : t);
@@ -240,8 +279,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         }
       }
       ready = ready || ready_q;
-      int32_t pos[W], cnt_r[W];
-      pick_row<W>(c, Lp, cv, idxm, pos, cnt_r);
+      int32_t pos[W];
+      pick_row_packed<W>(c, Lp, cv, rot, pos);
       if (ready) {
         // updateCountersFromList (KAS:254-261): count[node][r] += 1 (positions behind the list: + 0)
         int32_t tag = KAS_WTAG_DONE | (Lp << 15);
@@ -281,10 +320,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     TileIter itl = tile_iter_begin(have_s);
     int32_t jl = 0;
     bool endl = false, pf_valid = false, pf_end = false;
-    uint32_t pf_c[W];
+    MidRaw<W> pf_raw;                                       // the read-ahead tile's mid row as loaded
 #pragma unroll
-    for (int q = 0; q < W; ++q) pf_c[q] = ~0u;
-    int32_t pf_rot = 0;
+    for (int q = 0; q < W; ++q) pf_raw.w[q] = ~0u;
+    int32_t pf_rot = 0, pf_ow = 0;
     int64_t f_iter = 0, f_idle = 0;
     for (;;) {
       kasw::repoll();
@@ -294,23 +333,24 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       const bool staging = !endl && room && pf_valid;
       const bool staging_end = staging && pf_end;
       uint32_t cs[W];
+      {
+        int32_t cells[W];
+        mid_unpack<W>(pf_raw, pf_ow, cells);                // -1 = none: sorts last
 #pragma unroll
-      for (int q = 0; q < W; ++q) cs[q] = staging ? pf_c[q] : ~0u;
+        for (int q = 0; q < W; ++q) cs[q] = staging ? (uint32_t)cells[q] : ~0u;
+      }
       const int32_t rotw = pf_rot;
       endl = endl || staging_end;
       pf_valid = pf_valid && !staging;
       if (!pf_valid && !endl) {                             // read ahead: the tile after that
         pf_valid = true;
 #pragma unroll
-        for (int q = 0; q < W; ++q) pf_c[q] = ~0u;
-        if (tile_next<64>(itl, a, sd)) {
+        for (int q = 0; q < W; ++q) pf_raw.w[q] = ~0u;
+        pf_ow = 0;
+        if (tile_next<64, true>(itl, a, sd)) {
           const int32_t p = itl.row0 + lane;
-          pf_rot = itl.rotw;
-          int32_t cells[W];
-          load_mid_row<W>((const uint16_t*)a.out + itl.tmid, mid_width(itl.tow), itl.tow, p < itl.tP ? p : 0,
-                          p < itl.tP, cells);
-#pragma unroll
-          for (int q = 0; q < W; ++q) pf_c[q] = (uint32_t)cells[q];   // -1 = none: sorts last
+          pf_rot = itl.rot; pf_ow = itl.tow;
+          pf_raw = mid_load_raw<W>((const uint16_t*)a.out + tile_mid_offset(itl), itl.tow, p < itl.tP ? p : 0, p < itl.tP);
         } else {
           pf_end = true;
         }
@@ -379,16 +419,15 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     auto finish = [&](Retired& r) {
       if (r.on) {
 #pragma unroll
-        for (int q = 0; q < W; ++q)
-          if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.k, (uint32_t)r.p, (uint32_t)q, r.id[q]);
-        if (r.ow == W) {
-          RowW<W> o;
+        for (int q = 0; q < W; ++q) {
+          if (q < r.Lp) {
+            r.row[q] = r.id[q];
+            digest += kas_digest_cell((uint32_t)r.k, (uint32_t)r.p, (uint32_t)q, r.id[q]);
+          }
+        }
+        if (r.Lp < r.ow) {                                  // -1 behind a list shorter than the row (rare)
 #pragma unroll
-          for (int q = 0; q < W; ++q) o.v[q] = q < r.Lp ? r.id[q] : -1;
-          *reinterpret_cast<RowW<W>*>(r.row) = o;
-        } else {
-#pragma unroll
-          for (int q = 0; q < W; ++q) if (q < r.ow) r.row[q] = q < r.Lp ? r.id[q] : -1;
+          for (int q = 0; q < W; ++q) if (q >= r.Lp && q < r.ow) r.row[q] = -1;
         }
       }
       r.on = false;
@@ -399,7 +438,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       if (KAS_WTAG_IS_DONE(sl.tag)) {
         ring[(jr & (K - 1)) * 64 + lane].tag = KAS_TAG_FREE;
         jr += 1;
-        tile_next<64>(itr, a, sd);
+        tile_next<64, true>(itr, a, sd);
         int32_t es[W];
 #pragma unroll
         for (int q = 0; q < W; ++q) es[q] = sl.e[q];

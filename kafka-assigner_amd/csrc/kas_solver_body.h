@@ -58,6 +58,16 @@
 #include "kas_plan_math.h"
 #include "kas_wave.h"
 
+// Event counters of the fill kernel (P4 windows / node steps, ranked tiles; kas_plan_stats() [4],
+// [5], [7]).  They are per-lane 64-bit values that live across the whole kernel: in the product
+// build they are compiled out (zero) — the row scans are short of registers and ran 20-35 %
+// slower with them (round 2, profiles/) — and a -DKAS_FILL_COUNTERS build brings them back.
+#ifdef KAS_FILL_COUNTERS
+#define KAS_COUNT(x) do { (x) += 1; } while (0)
+#else
+#define KAS_COUNT(x) do { } while (0)
+#endif
+
 namespace kas {
 
 struct TopicOutcome {
@@ -92,6 +102,26 @@ struct NodeMap {
 };
 
 // nodeMap.get(nodeId) (KAS:119): node index of a broker id, or -1.
+// The three row scans of the rack-diverse fill are instantiated per lookup mode (DIRECT: the
+// broker-id range fits the LDS table, the usual case; else binary search over the sorted ids) and
+// the mode is chosen once per topic: the search loop, unrolled per list position and tile in
+// flight, would otherwise sit in the hot loops' register budget.
+template <bool DIRECT>
+KAS_DEV int32_t node_lookup_as(const LdsView& L, const NodeMap& m, int32_t id) {
+  if (DIRECT) {
+    uint32_t d = (uint32_t)id - (uint32_t)m.min_id;
+    return d < m.range ? (int32_t)L.idmap[d] : -1;
+  }
+  int32_t lo = 0, hi = m.n - 1, res = -1;
+  while (lo <= hi) {
+    int32_t mid = (lo + hi) >> 1;
+    int32_t v = L.ids[mid];
+    if (v == id) { res = mid; break; }
+    if (v < id) lo = mid + 1; else hi = mid - 1;
+  }
+  return res;
+}
+
 KAS_DEV int32_t node_lookup(const LdsView& L, const NodeMap& m, int32_t id) {
   if (m.range != 0u) {
     uint32_t d = (uint32_t)id - (uint32_t)m.min_id;
@@ -181,7 +211,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
 
   int32_t fail_lane = -1;
   int32_t j = head;
-  st[4] += 1;
+  KAS_COUNT(st[4]);
   constexpr int U = 4;                                     // node positions fetched per LDS round trip
   for (;;) {
     uint64_t pend = kasw::ballot(need > 0);
@@ -199,7 +229,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
     for (int u = 0; u < U; ++u) {
       taken[u] = 0;
       if (j + u < live_count && pend != 0) {               // wave-uniform
-        st[5] += 1;
+        KAS_COUNT(st[5]);
         if (slots[u] > 0) {
           bool want = need > 0;
 #pragma unroll
@@ -248,29 +278,45 @@ KAS_DEV uint16_t* mid_base(int32_t* out, int32_t P, int32_t ow) {
 }
 KAS_DEV int32_t mid_to_index(uint32_t v) { return v == KAS_MID_NONE ? -1 : (int32_t)v; }
 
-// one mid row -> node indices (-1 = none); FULLW: the row is mid_width_of<W>() wide (ow == W)
+// One mid row, as loaded: nothing is computed from the loaded values here, so a row read ahead of its
+// use (every consumer prefetches) does not make the wave wait for the load where it is issued.
+// Rows of the template width (ow == W) come as mid_width_of<W>() / 2 dwords, others cell by cell.
 template <int W>
-KAS_DEV void load_mid_row(const uint16_t* mid, int32_t mw, int32_t ow, int64_t p, bool active, int32_t (&c)[W]) {
+struct MidRaw { uint32_t w[W]; };
+template <int W>
+KAS_DEV MidRaw<W> mid_load_raw(const uint16_t* mid, int32_t ow, int64_t p, bool active) {
   constexpr int MW = mid_width_of<W>();
-  if (mw == MW && ow == W) {                                // wave-uniform: the row as MW / 2 dwords
-    RowWords<MW / 2> q;
+  MidRaw<W> raw;
 #pragma unroll
-    for (int k = 0; k < MW / 2; ++k) q.v[k] = 0xffffffffu;
-    if (active) q = *reinterpret_cast<const RowWords<MW / 2>*>(mid + p * MW);
+  for (int k = 0; k < W; ++k) raw.w[k] = 0xffffffffu;
+  if (ow == W) {                                            // the row as MW / 2 dwords
+    if (active) {
+      const RowWords<MW / 2> q = *reinterpret_cast<const RowWords<MW / 2>*>(mid + p * MW);
 #pragma unroll
-    for (int k = 0; k < W; ++k) c[k] = mid_to_index((q.v[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+      for (int k = 0; k < MW / 2; ++k) raw.w[k] = q.v[k];
+    }
   } else {
+    const int32_t mw = mid_width(ow);
 #pragma unroll
-    for (int k = 0; k < W; ++k) c[k] = (active && k < ow) ? mid_to_index(mid[p * mw + k]) : -1;
+    for (int k = 0; k < W; ++k) if (active && k < ow) raw.w[k] = (uint32_t)mid[p * mw + k];
+  }
+  return raw;
+}
+// ... and unpacked where it is used: node indices, -1 = none
+template <int W>
+KAS_DEV void mid_unpack(const MidRaw<W>& raw, int32_t ow, int32_t (&c)[W]) {
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const uint32_t packed = (raw.w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+    const uint32_t v = ow == W ? packed : (raw.w[k] & 0xffffu);
+    c[k] = mid_to_index(v);
   }
 }
 
 // Everything a phase needs to know about the topic being solved.
 struct TopicView {
   const int32_t* cur;
-  int32_t* out;
-  uint16_t* mid;        // mid rows of the topic (inside its out region)
-  int32_t mw;           // uint16 per mid row
+  uint16_t* mid;        // mid rows of the topic (at the end of its out region); mid_width(ow) uint16 each
   int32_t* orph;        // orphan row lists of this scenario (HBM scratch)
   const int32_t* len_arr;
   const int32_t* inp_arr;
@@ -308,7 +354,9 @@ KAS_DEV bool full_rows_of(const TopicView& T) { return T.cw == W && T.ow == W &&
 // Stream the tiles tile0, tile0 + stride, ... (< t_end) of the cur table through `body(tile, ids,
 // len)` with KAS_TILES_AHEAD tiles of rows in flight per lane: the scans are HBM-latency-bound
 // (12 bytes per lane per tile), so several tiles are requested before the first is consumed.
+#ifndef KAS_TILES_AHEAD
 #define KAS_TILES_AHEAD 4
+#endif
 template <int W, bool FULL, typename Body>
 KAS_DEV void for_tiles_impl(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
   constexpr int D = KAS_TILES_AHEAD;
@@ -416,7 +464,7 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
     } else {
 #pragma unroll
       for (int k = 0; k < MW; ++k)
-        if (k < T.mw) T.mid[(int64_t)p * T.mw + k] = (uint16_t)(k < W ? hold[k] : -1);
+        if (k < mid_width(T.ow)) T.mid[(int64_t)p * mid_width(T.ow) + k] = (uint16_t)(k < W ? hold[k] : -1);
     }
   }
   const bool in_parts = active && (T.inp_arr ? T.inp_arr[p] != 0 : true);
@@ -459,7 +507,7 @@ KAS_DEV int32_t drain_ring(const LdsView& L, const TopicView& T, int32_t min_fil
   const int lane = kasw::lane();
   while (ring_count >= min_fill && ring_count > 0) {
     const int32_t n_win = ring_count < 64 ? ring_count : 64;
-    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.mid, T.mw, st);
+    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.mid, mid_width(T.ow), st);
     if (fl >= 0) return L.ring_p[fl];
     const int32_t rest = ring_count - n_win;           // shift the ring down by one window
     int32_t tp = 0, tm = 0; int32_t tr[W];
@@ -519,7 +567,7 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
       bool accepted = took;
       uint64_t todo = kasw::ballot(took && L.load[n] > cap);
       if (todo != 0) {
-        st[7] += 1;
+        KAS_COUNT(st[7]);
         // some node overflowed inside this tile: keep its first (cap - load_before) lanes
         while (todo != 0) {
           const int leader = kasw::first_lane(todo);
@@ -577,7 +625,7 @@ KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const No
 // P2, rack-diverse form: passes A1, Q, A2, prefix, B (see the header comment).
 // ---------------------------------------------------------------------------------------------
 // A1: tiles wave, wave+NW, ... ; returns this lane's "not rack-diverse" verdict
-template <int W, int NW>
+template <int W, int NW, bool DIRECT>
 KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
   constexpr int D = KAS_TILES_AHEAD;
   const int32_t N = T.N;
@@ -587,7 +635,7 @@ KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup(L, nm, ids[d][r]) : -1;
+      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup_as<DIRECT>(L, nm, ids[d][r]) : -1;
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -630,7 +678,7 @@ KAS_DEV void fill_quota(const LdsView& L, const TopicView& T, int32_t tid) {
 }
 
 // A2: wave w counts the sweep-r* candidates of chunk w per node
-template <int W, int NW>
+template <int W, int NW, bool DIRECT>
 KAS_DEV void fill_chunk_count(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
   constexpr int D = KAS_TILES_AHEAD;
   const int32_t N = T.N;
@@ -641,7 +689,7 @@ KAS_DEV void fill_chunk_count(const LdsView& L, const TopicView& T, const NodeMa
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup(L, nm, ids[d][r]) : -1;
+      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup_as<DIRECT>(L, nm, ids[d][r]) : -1;
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -670,7 +718,7 @@ KAS_DEV void fill_chunk_prefix(const LdsView& L, const TopicView& T, int32_t tid
 }
 
 // B + P3 over chunk `wave`; orphans go to the chunk's list; returns the number of orphans
-template <int W, int NW>
+template <int W, int NW, bool DIRECT>
 KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave,
                             int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();
@@ -686,7 +734,7 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
     uint32_t sure = 0, counting = 0;
 #pragma unroll
     for (int r = 0; r < W; ++r) {
-      idx[r] = r < len ? node_lookup(L, nm, ids[r]) : -1;
+      idx[r] = r < len ? node_lookup_as<DIRECT>(L, nm, ids[r]) : -1;
       nn[r] = idx[r] >= 0 ? idx[r] : 0;
       const int32_t rs = (int32_t)((uint32_t)L.qrs[nn[r]] >> 28);
       sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
@@ -709,7 +757,7 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
       }
       uint64_t todo = kasw::ballot(contested != 0u);
       if (todo != 0) {
-        st[7] += 1;
+        KAS_COUNT(st[7]);
         // the quota of some node runs out inside this tile: rank its lanes (row order)
         while (todo != 0) {
           const int leader = kasw::first_lane(todo);
@@ -772,23 +820,21 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     }
     return g < total ? T.orph[((int64_t)chunk_begin<NW>(T.nt, w) << 6) + (g - base)] : -1;
   };
-  auto row_cells = [&](int32_t p, int32_t (&c)[W]) {
-    load_mid_row<W>(T.mid, T.mw, T.ow, p >= 0 ? p : 0, p >= 0, c);
+  auto row_cells = [&](int32_t p) -> MidRaw<W> {
+    return mid_load_raw<W>(T.mid, T.ow, p >= 0 ? p : 0, p >= 0);
   };
   const int32_t n_win = (total + 63) >> 6;
   const int32_t prev = wave == 0 ? NW - 1 : wave - 1;       // the wave that has window w - 1
-  const int32_t cap = T.cap, mw = T.mw;
+  const int32_t cap = T.cap, mw = mid_width(T.ow);
   constexpr int U = 4;                                     // node positions fetched per LDS round trip
   int32_t p_nxt = orphan_row(64 * wave + lane);
-  int32_t c_nxt[W];
-  row_cells(p_nxt, c_nxt);
+  MidRaw<W> c_nxt = row_cells(p_nxt);
   for (int32_t w = wave; w < n_win; w += NW) {
     const int32_t p = p_nxt;
     int32_t c_cur[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) c_cur[k] = c_nxt[k];
+    mid_unpack<W>(c_nxt, T.ow, c_cur);
     p_nxt = orphan_row(64 * (w + NW) + lane);              // my next window's rows: read ahead
-    row_cells(p_nxt, c_nxt);
+    c_nxt = row_cells(p_nxt);
     kasw::repoll();
     if (kasw::ballot(L.ctl[KAS_CTL_FAILWIN] < w) != 0) break;   // an earlier window failed: so has the topic
     int32_t hc = 0, hr[W];                                  // holders are a prefix of the row
@@ -800,7 +846,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     int32_t need = p >= 0 ? T.rf - hc : 0;
     int32_t j = kasw::shfl(L.ctl[KAS_CTL_HEAD], 0);
     if (lane == 0) prog[wave] = ((uint64_t)(uint32_t)w << 32) | (uint32_t)j;
-    st[4] += 1;
+    KAS_COUNT(st[4]);
     bool stop = false;
     for (;;) {
       uint64_t pend = kasw::ballot(need > 0);
@@ -832,7 +878,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
       for (int u = 0; u < U; ++u) {
         taken[u] = 0;
         if (j + u < live_count && pend != 0) {             // wave-uniform
-          st[5] += 1;
+          KAS_COUNT(st[5]);
           if (slots[u] > 0) {
             bool want = need > 0;
 #pragma unroll
@@ -955,14 +1001,13 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   const int32_t N = nm.n;
   TopicView T;
   T.cur = a.cur + td.cur_off;
-  T.out = a.out + td.out_off;
   T.orph = orph;
   T.len_arr = td.cur_len_off >= 0 ? a.aux + td.cur_len_off : nullptr;
   T.inp_arr = td.in_partitions_off >= 0 ? a.aux + td.in_partitions_off : nullptr;
   T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
   T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
   T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
-  T.mw = mid_width(T.ow); T.mid = mid_base(T.out, T.P, T.ow);
+  T.mid = mid_base(a.out + td.out_off, T.P, T.ow);
   const int32_t P = T.P, hash = T.hash;
 
   TopicOutcome res;
@@ -1006,7 +1051,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
   bool fast = false;
   if (try_fast) {
-    const bool viol = fill_pass_a<W, NW>(L, T, nm, wave);
+    const bool viol = nm.range != 0u ? fill_pass_a<W, NW, true>(L, T, nm, wave) : fill_pass_a<W, NW, false>(L, T, nm, wave);
     if (kasw::ballot(viol) != 0 && lane == 0) L.ctl[KAS_CTL_VIOL] = 1;
     kasw::sync();
     fast = L.ctl[KAS_CTL_VIOL] == 0;
@@ -1021,13 +1066,15 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     fill_quota<W, NW>(L, T, tid);
     kasw::sync();
     if (NW > 1) {
-      fill_chunk_count<W, NW>(L, T, nm, wave);
+      if (nm.range != 0u) fill_chunk_count<W, NW, true>(L, T, nm, wave);
+      else fill_chunk_count<W, NW, false>(L, T, nm, wave);
       kasw::sync();
       fill_chunk_prefix<NW>(L, T, tid);
       kasw::sync();
     }
     { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
-    const int32_t oc = fill_pass_b<W, NW>(L, T, nm, wave, moved_r, moved_p, st);
+    const int32_t oc = nm.range != 0u ? fill_pass_b<W, NW, true>(L, T, nm, wave, moved_r, moved_p, st)
+                                      : fill_pass_b<W, NW, false>(L, T, nm, wave, moved_r, moved_p, st);
     if (lane == 0) L.ctl[KAS_CTL_OC + wave] = oc;
   } else if (wave == 0) {
     fill_generic_sweeps<W>(L, T, nm, accmask, st);
@@ -1237,6 +1284,9 @@ KAS_DEV void order_permutation(const KasLaunch& a, const int32_t* keys, int32_t 
 #ifndef KAS_RING_SLOTS
 #define KAS_RING_SLOTS 4
 #endif
+#ifndef KAS_RETIRE_PAD_STYLE
+#define KAS_RETIRE_PAD_STYLE 0
+#endif
 // rows a run must decide beyond the ones that were ready anyway for its path to pay
 // a row waiting on exactly one node with this many rows ahead of it nominates the node
 #ifndef KAS_RUN_NOMINATE
@@ -1264,10 +1314,10 @@ struct alignas(16) RingSlot { int32_t tag; int32_t c[3]; };
 // a lane's tile sequence: GL-row tiles of every topic the fill kernel solved, in order
 struct TileIter {
   int32_t k, tP, tow, row0;              // topic, its rows / row width, first row of the current tile
-  int32_t rot;                           // the topic's rotation tables, see ticket_rotation()
-  int32_t rotw;                          // idx_m for m = 1..5, see wide_rotation() (lists 4 and 5 wide)
+  int32_t rot;                           // the topic's rotation word: ticket_rotation() (lists <= 3 wide)
+                                         // or idx_m at bit 3 m for m = 1..5 (wide lists)
   int64_t tout;
-  int64_t tmid;                          // first mid row of the topic: uint16 offset from a.out
+  int64_t tmid;                          // first mid row of the topic: uint16 offset from the out pool
   bool exhausted;
 };
 
@@ -1310,6 +1360,7 @@ KAS_DEV int32_t ticket_rotation(int32_t name_hash) {
 
 // next topic the fill kernel solved (rarely taken: kept out of the tile loops; by value so that
 // the iterator stays in registers)
+template <bool WIDE>
 KAS_DEV_COLD TileIter tile_next_topic(TileIter it, const KasLaunch& a, const kas_scenario_desc& sd) {
   for (;;) {
     it.k += 1;
@@ -1320,27 +1371,33 @@ KAS_DEV_COLD TileIter tile_next_topic(TileIter it, const KasLaunch& a, const kas
     if (td.n_partitions <= 0) continue;
     it.tP = td.n_partitions; it.tow = td.out_width; it.tout = td.out_off;
     it.tmid = 2 * (td.out_off + (int64_t)it.tP * it.tow) - (int64_t)it.tP * mid_width(it.tow);
-    it.rot = ticket_rotation(td.name_hash);
-    it.rotw = 0;
+    if (WIDE) {
+      it.rot = 0;
 #pragma unroll
-    for (int m = 1; m <= 5; ++m) it.rotw |= (java_abs_mod(td.name_hash, m) & 7) << (3 * m);
+      for (int m = 1; m <= 5; ++m) it.rot |= (java_abs_mod(td.name_hash, m) & 7) << (3 * m);
+    } else {
+      it.rot = ticket_rotation(td.name_hash);
+    }
     it.row0 = 0;
     return it;
   }
 }
 
-template <int GL>
+template <int GL, bool WIDE = false>
 KAS_DEV bool tile_next(TileIter& it, const KasLaunch& a, const kas_scenario_desc& sd) {
   if (it.exhausted) return false;
   it.row0 += GL;
   if (it.row0 < it.tP) return true;
-  it = tile_next_topic(it, a, sd);
+  it = tile_next_topic<WIDE>(it, a, sd);
   return !it.exhausted;
 }
 
+// first mid row of the iterator's topic, as a uint16 offset from the out pool
+KAS_DEV int64_t tile_mid_offset(const TileIter& it) { return it.tmid; }
+
 KAS_DEV TileIter tile_iter_begin(bool have_scenario) {
   TileIter it;
-  it.k = -1; it.tP = 0; it.tow = 1; it.row0 = 0; it.rot = KAS_ROT_IDENT; it.rotw = 0; it.tout = 0; it.tmid = 0;
+  it.k = -1; it.tP = 0; it.tow = 1; it.row0 = 0; it.rot = KAS_ROT_IDENT; it.tout = 0; it.tmid = 0;
   it.exhausted = !have_scenario;
   return it;
 }
@@ -1601,7 +1658,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     int32_t jl = 0;                                         // tiles staged (group-uniform)
     bool endl = false;
     bool pf_valid = false, pf_end = false;
-    uint32_t pf_c0 = ~0u, pf_c1 = ~0u, pf_c2 = ~0u;         // the read-ahead tile's row (node indices, ~0 = none)
+    uint32_t pf_w0 = ~0u, pf_w1 = ~0u;                      // the read-ahead tile's mid row as two dwords of uint16
+                                                            // cells, AS LOADED (unpacked when it is staged)
     int32_t pf_rot = KAS_ROT_IDENT;
     int64_t f_iter = 0, f_idle = 0;
     for (;;) {
@@ -1613,29 +1671,31 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const bool room = (kasw::ballot(slot_free) & gmask) == gmask;
       const bool staging = !endl && room && pf_valid;
       const bool staging_end = staging && pf_end;
-      const uint32_t c0 = staging ? pf_c0 : ~0u, c1 = staging ? pf_c1 : ~0u, c2 = staging ? pf_c2 : ~0u;
+      // unpack: uint16 node indices, 0xffff = none (sorts last, like ~0)
+      const uint32_t c0 = staging ? (pf_w0 & 0xffffu) : ~0u, c1 = staging ? (pf_w0 >> 16) : ~0u,
+                     c2 = staging ? (pf_w1 & 0xffffu) : ~0u;
       const int32_t rot = pf_rot;
       endl = endl || staging_end;
       pf_valid = pf_valid && !staging;
       if (!pf_valid && !endl) {                             // read ahead: the tile after that
         pf_valid = true;
-        pf_c0 = ~0u; pf_c1 = ~0u; pf_c2 = ~0u;
+        pf_w0 = ~0u; pf_w1 = ~0u;
         if (tile_next<GL>(itl, a, sd)) {
           const int32_t p = itl.row0 + li;
           pf_rot = itl.rot;
           if (p < itl.tP) {
-            // the fill kernel's mid row: uint16 node indices, 0xffff = none (sorts last, like ~0)
-            const uint16_t* row = (const uint16_t*)a.out + itl.tmid + (int64_t)p * mid_width(itl.tow);
+            // the fill kernel's mid row; nothing is computed from it before it is staged
+            const uint16_t* row = (const uint16_t*)a.out + tile_mid_offset(itl) + (int64_t)p * mid_width(itl.tow);
             if (W == 3 && itl.tow == 3) {
               const RowWords<2> r = *(const RowWords<2>*)row;
-              pf_c0 = r.v[0] & 0xffffu; pf_c1 = r.v[0] >> 16; pf_c2 = r.v[1] & 0xffffu;
+              pf_w0 = r.v[0]; pf_w1 = r.v[1];
             } else if (W == 2 && itl.tow == 2) {
-              const uint32_t r = *(const uint32_t*)row;
-              pf_c0 = r & 0xffffu; pf_c1 = r >> 16;
-            } else {
-              pf_c0 = (uint32_t)row[0];
-              if (W > 1 && itl.tow > 1) pf_c1 = (uint32_t)row[1];
-              if (W > 2 && itl.tow > 2) pf_c2 = (uint32_t)row[2];
+              pf_w0 = *(const uint32_t*)row;
+            } else {                                        // narrower rows of a wider batch: cell by cell (rare)
+              uint32_t v0 = (uint32_t)row[0], v1 = 0xffffu, v2 = 0xffffu;
+              if (W > 1 && itl.tow > 1) v1 = (uint32_t)row[1];
+              if (W > 2 && itl.tow > 2) v2 = (uint32_t)row[2];
+              pf_w0 = v0 | (v1 << 16); pf_w1 = v2 | 0xffff0000u;
             }
           }
         } else {
@@ -1712,26 +1772,33 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     // lane are in flight alternately, so their latency is not in the slot's way.
     constexpr int UR = 2;                                   // rows per lane per batch
     constexpr int RSH = PK ? 2 : 3;                         // log2(bytes per counter row)
-    struct Retired { bool on; int32_t id[3], Lp, p, k, ow; int32_t* row; };
+    struct Retired { bool on; int32_t id[3], Lp, p, kw; int32_t* row; };   // kw = topic | row width << 27
     TileIter itr = tile_iter_begin(have_s);
     int32_t jr = 0;
     bool fin = false;
     uint64_t digest = 0;
     auto finish = [&](Retired& r) {
       if (r.on) {
-        // the whole final row, -1 behind the list (the mid row it came from lives elsewhere)
+#if KAS_RETIRE_PAD_STYLE == 1
 #pragma unroll
         for (int q = 0; q < W; ++q)
-          if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.k, (uint32_t)r.p, (uint32_t)q, r.id[q]);
-        if (r.ow == W) {
-          RowW<W> o;
+          if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.kw & 0x7ffffffu, (uint32_t)r.p, (uint32_t)q, r.id[q]);
 #pragma unroll
-          for (int q = 0; q < W; ++q) o.v[q] = q < r.Lp ? r.id[q] : -1;
-          *reinterpret_cast<RowW<W>*>(r.row) = o;
-        } else {
+        for (int q = 0; q < W; ++q) if (q < (r.kw >> 27)) r.row[q] = q < r.Lp ? r.id[q] : -1;
+#else
 #pragma unroll
-          for (int q = 0; q < W; ++q) if (q < r.ow) r.row[q] = q < r.Lp ? r.id[q] : -1;
+        for (int q = 0; q < W; ++q) {
+          if (q < r.Lp) {
+            r.row[q] = r.id[q];
+            digest += kas_digest_cell((uint32_t)r.kw & 0x7ffffffu, (uint32_t)r.p, (uint32_t)q, r.id[q]);
+          }
         }
+        // -1 behind a list shorter than the row (rare: the mid row this came from lives elsewhere)
+        if (r.Lp < (r.kw >> 27)) {
+#pragma unroll
+          for (int q = 0; q < W; ++q) if (q >= r.Lp && q < (r.kw >> 27)) r.row[q] = -1;
+        }
+#endif
       }
       r.on = false;
     };
@@ -1744,8 +1811,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         tile_next<GL>(itr, a, sd);
         const int32_t w0 = sl.tag & 3, w1 = (sl.tag >> 2) & 3;
         const int32_t w[3] = {w0, w1, 3 - w0 - w1};
-        r.on = true; r.Lp = (sl.tag >> 4) & 3; r.p = itr.row0 + li; r.k = itr.k;
-        r.ow = r.p < itr.tP ? itr.tow : 0;                // a lane past the last row of the tile writes nothing
+        r.on = true; r.Lp = (sl.tag >> 4) & 3; r.p = itr.row0 + li;
+        r.kw = itr.k | ((r.p < itr.tP ? itr.tow : 0) << 27);   // a lane past the last row of the tile writes nothing
         r.row = a.out + itr.tout + (int64_t)r.p * itr.tow;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
@@ -1762,7 +1829,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       ra[u].on = false; rb[u].on = false;
-      ra[u].Lp = 0; rb[u].Lp = 0; ra[u].p = 0; rb[u].p = 0; ra[u].k = 0; rb[u].k = 0; ra[u].ow = 0; rb[u].ow = 0;
+      ra[u].Lp = 0; rb[u].Lp = 0; ra[u].p = 0; rb[u].p = 0; ra[u].kw = 0; rb[u].kw = 0;
       ra[u].row = nullptr; rb[u].row = nullptr;
 #pragma unroll
       for (int q = 0; q < 3; ++q) { ra[u].id[q] = 0; rb[u].id[q] = 0; }
@@ -1816,17 +1883,16 @@ KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td,
   // rows come in as mid rows at the end of the topic's out region and leave as final rows from its
   // start: the tile after the current one is read before the current tile's final rows are written
   const uint16_t* mid = mid_base(out, P, ow);
-  const int32_t mw = mid_width(ow);
-  int32_t nx[W];                                  // next tile's mid row (software prefetch)
-  load_mid_row<W>(mid, mw, ow, lane < P ? lane : 0, lane < P, nx);
+  MidRaw<W> nxr = mid_load_raw<W>(mid, ow, lane < P ? lane : 0, lane < P);   // next tile's mid row (software prefetch)
   for (int32_t tile = 0; tile < nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
     const bool active = p < P;
-    int32_t h[W], Lp;
+    int32_t nx[W], h[W], Lp;
+    mid_unpack<W>(nxr, ow, nx);
     sort_holders<W>(nx, h, Lp);
     {
       const int32_t pn = p + 64;
-      load_mid_row<W>(mid, mw, ow, pn < P ? pn : 0, pn < P, nx);
+      nxr = mid_load_raw<W>(mid, ow, pn < P ? pn : 0, pn < P);
     }
     if (hash_min) {
       // KAS:190 index error: some set size m <= L has a negative rotation offset
