@@ -88,6 +88,11 @@ extern "C" {
                                        Kafka broker ids are non-negative), or node_rack[]
                                        outside [0, 32767]                                    */
 
+#define KAS_FAIL_WATCHDOG        8  /* debug builds of the library only (-DKAS_SPIN_BOUND=n): a
+                                       wavefront polled n times without progress; the scenario's
+                                       rows are unspecified.  The product build has no bound and
+                                       never reports this                                     */
+
 /* One topic of one scenario.  Offsets are in int32 elements into the named pool. */
 typedef struct kas_topic_desc {
   int32_t name_hash;        /* Java String.hashCode() of the topic name (KAS:190)           */
@@ -224,8 +229,17 @@ int kas_solve_device(kas_plan* plan, const kas_tables* device_tables, void* hip_
 /* Block until everything enqueued on the context's own stream has finished. */
 int kas_ctx_synchronize(kas_ctx* ctx);
 
-/* Convenience for host callers (JNI / ctypes / C++ mirror): H2D, solve, D2H, blocking. */
+/* Convenience for host callers (JNI / ctypes / C++ mirror): H2D, solve, D2H, blocking.
+ * The context keeps what repeated calls can share: its device buffers only ever grow, and the
+ * plans of the most recent batch shapes (descriptors + node tables equal byte for byte) are reused,
+ * so a caller that solves the same cluster shape again — the CLI's per-topic loop
+ * (KafkaAssignmentGenerator.java:172-184), a JVM calling once per topic — pays no hipMalloc /
+ * hipFree and no descriptor upload after the first call.  Calls on one context are serialised. */
 int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables);
+
+/* Counters of the host path since kas_ctx_create: calls, calls that found their plan in the
+ * context's cache, device allocations made (any pointer may be NULL). */
+int kas_ctx_host_stats(kas_ctx* ctx, int64_t* calls, int64_t* plan_hits, int64_t* device_allocs);
 
 /* Average device time in microseconds of one solve (both kernels) over the launches recorded since
  * the last call (HIP events on the launch stream); resets the accumulator. Returns <0 on
@@ -258,7 +272,7 @@ int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
  *   [0] setup  [1] P2 histogram + quota  [2] P2 keep-scan + P3  [3] P4 first fit
  *   [4] P4 windows  [5] P4 node steps  [6] P5 rounds (round form)
  *   [7] P2 tiles of wave 0 that needed quota ranking  [8] order kernel time
- *   ([4], [5], [7] are zero unless the library was built with -DKAS_FILL_COUNTERS)
+ *   ([4], [5], [7], [15] are zero unless the library was built with -DKAS_FILL_COUNTERS)
  *   ticket form: [9] solver steps  [11] of those with rows in hand but none ready
  *                [6] steps that took the queue path  [10] wins / prefix-sum rounds spent there
  *                [14] rows decided inside queues  [15] sum over steps of rows in hand

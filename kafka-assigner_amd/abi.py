@@ -24,6 +24,7 @@ KAS_FAIL_HASH_INDEX = 4
 KAS_FAIL_RF_MISMATCH = 5
 KAS_SKIPPED = 6
 KAS_FAIL_BAD_NODES = 7
+KAS_FAIL_WATCHDOG = 8
 
 STATUS_NAMES = {
     KAS_OK: "OK",
@@ -34,6 +35,7 @@ STATUS_NAMES = {
     KAS_FAIL_RF_MISMATCH: "FAIL_RF_MISMATCH",
     KAS_SKIPPED: "SKIPPED",
     KAS_FAIL_BAD_NODES: "FAIL_BAD_NODES",
+    KAS_FAIL_WATCHDOG: "FAIL_WATCHDOG",
 }
 
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -78,7 +79,7 @@ static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<5, 4>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
-#elif defined(KAS_MINIMAL_INSTANCES)
+#elif defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES != 0
 // tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
 // lists 3 wide, 4 fill waves, 2 scenarios per solver wavefront — so that a variant compiles in
 // seconds.  Other shapes are refused by kas_plan_create in such a build.
@@ -155,9 +156,26 @@ static int set_error(int code, const std::string& msg) {
       return set_error(KAS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
   } while (0)
 
+// Host-path cache of a context (kas_solve_host): device buffers that only ever grow, and the plan
+// of the most recent batch shapes — a caller that solves the same cluster shape again (the CLI's
+// per-topic loop, a JVM calling once per topic, a what-if planner) pays neither hipMalloc /
+// hipFree nor the descriptor upload again.
+struct KasHostBuf { void* p = nullptr; size_t cap = 0; };
+struct KasCachedPlan {
+  kas_plan* plan = nullptr;
+  uint64_t key = 0;
+  std::vector<unsigned char> desc;      // the bytes the key was computed from (compared on a hit)
+  uint64_t last_use = 0;
+};
+#define KAS_HOST_PLAN_CACHE 4
 struct kas_ctx {
   int device;
   hipStream_t stream;
+  std::mutex host_mu;                   // kas_solve_host calls on one context are serialised
+  KasHostBuf h_cur, h_out, h_aux, h_ctx, h_tr, h_sr;
+  KasCachedPlan plans[KAS_HOST_PLAN_CACHE];
+  uint64_t use_clock = 0;
+  uint64_t host_calls = 0, host_plan_hits = 0, host_allocs = 0;
 };
 
 #define KAS_TIMER_SLOTS 64
@@ -216,6 +234,7 @@ const char* kas_status_string(int status) {
     case KAS_FAIL_RF_MISMATCH: return "partition with unexpected replication factor (KTA:58-60)";
     case KAS_SKIPPED: return "skipped: an earlier topic of the scenario failed";
     case KAS_FAIL_BAD_NODES: return "node table not strictly ascending / non-negative, or rack out of range";
+    case KAS_FAIL_WATCHDOG: return "debug build: a wavefront polled past KAS_SPIN_BOUND without progress";
     default: return "unknown status";
   }
 }
@@ -254,6 +273,9 @@ void kas_ctx_destroy(kas_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (KasCachedPlan& c : ctx->plans) if (c.plan) kas_plan_destroy(c.plan);
+  for (KasHostBuf* b : {&ctx->h_cur, &ctx->h_out, &ctx->h_aux, &ctx->h_ctx, &ctx->h_tr, &ctx->h_sr})
+    if (b->p) (void)hipFree(b->p);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -565,53 +587,112 @@ int kas_plan_stats(kas_plan* p, int64_t* out, int64_t n) {
   return KAS_E_OK;
 }
 
+// grow-only device buffer of the host path
+static int kas_host_buf(kas_ctx* ctx, KasHostBuf* b, size_t bytes) {
+  if (bytes <= b->cap) return KAS_E_OK;
+  if (b->p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+  const size_t want = bytes + bytes / 4 + 256;              // headroom: the next batch is rarely the same size
+  hipError_t e = hipMalloc(&b->p, want);
+  if (e != hipSuccess) { b->p = nullptr; return set_error(KAS_E_NOMEM, std::string("host-path buffer: ") + hipGetErrorString(e)); }
+  b->cap = want;
+  ctx->host_allocs += 1;
+  return KAS_E_OK;
+}
+
+static uint64_t kas_fnv64(uint64_t h, const void* data, size_t n) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
+// The plan of this batch from the context's cache (same descriptors and node tables, byte for
+// byte), or a new one that replaces the least recently used entry.
+static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_plan) {
+  *out_plan = nullptr;
+  if (b->n_scenarios < 0 || b->n_topics < 0 || b->node_pool_len < 0 ||
+      (b->n_scenarios > 0 && !b->scenarios) || (b->n_topics > 0 && !b->topics) ||
+      (b->node_pool_len > 0 && (!b->node_id || !b->node_rack)))
+    return set_error(KAS_E_INVALID_ARG, "null/negative batch");
+  const size_t sb = sizeof(kas_scenario_desc) * (size_t)b->n_scenarios, tb = sizeof(kas_topic_desc) * (size_t)b->n_topics,
+               nb = sizeof(int32_t) * (size_t)b->node_pool_len;
+  std::vector<unsigned char> desc(16 + sb + tb + 2 * nb);
+  int64_t hdr[2] = {((int64_t)b->n_scenarios << 32) | (uint32_t)b->n_topics, b->node_pool_len};
+  memcpy(desc.data(), hdr, 16);
+  if (sb) memcpy(desc.data() + 16, b->scenarios, sb);
+  if (tb) memcpy(desc.data() + 16 + sb, b->topics, tb);
+  if (nb) { memcpy(desc.data() + 16 + sb + tb, b->node_id, nb); memcpy(desc.data() + 16 + sb + tb + nb, b->node_rack, nb); }
+  const uint64_t key = kas_fnv64(0xcbf29ce484222325ull, desc.data(), desc.size());
+  ctx->use_clock += 1;
+  KasCachedPlan* victim = &ctx->plans[0];
+  for (KasCachedPlan& c : ctx->plans) {
+    if (c.plan && c.key == key && c.desc == desc) {
+      c.last_use = ctx->use_clock;
+      ctx->host_plan_hits += 1;
+      *out_plan = c.plan;
+      return KAS_E_OK;
+    }
+    if (!c.plan) { if (victim->plan) victim = &c; }
+    else if (victim->plan && c.last_use < victim->last_use) victim = &c;
+  }
+  kas_plan* plan = nullptr;
+  int rc = kas_plan_create(ctx, b, &plan);
+  if (rc != KAS_E_OK) return rc;
+  if (victim->plan) kas_plan_destroy(victim->plan);
+  victim->plan = plan; victim->key = key; victim->desc.swap(desc); victim->last_use = ctx->use_clock;
+  *out_plan = plan;
+  return KAS_E_OK;
+}
+
 int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h) {
   if (!ctx || !batch || !h) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  KAS_HIP_TRY(hipSetDevice(ctx->device));
+  ctx->host_calls += 1;
   kas_plan* plan = nullptr;
-  int rc = kas_plan_create(ctx, batch, &plan);
+  int rc = kas_host_plan(ctx, batch, &plan);
   if (rc != KAS_E_OK) return rc;
   const KasShape& sh = plan->shape;
   if (h->cur_len < sh.cur_need || h->out_len < sh.out_need || h->aux_len < sh.aux_need ||
-      h->ctx_len < sh.ctx_need) {
-    kas_plan_destroy(plan);
+      h->ctx_len < sh.ctx_need)
     return set_error(KAS_E_INVALID_ARG, "a descriptor offset reaches beyond the pool length given in kas_tables");
-  }
+  if ((sh.cur_need && !h->cur) || (sh.out_need && !h->out) || (sh.aux_need && !h->aux) || (sh.ctx_need && !h->ctx) ||
+      (batch->n_topics && !h->topic_results) || (batch->n_scenarios && !h->scenario_results))
+    return set_error(KAS_E_INVALID_ARG, "a table the descriptors refer to is NULL");
   hipStream_t st = ctx->stream;
-  int32_t *d_cur = nullptr, *d_out = nullptr, *d_aux = nullptr, *d_ctx = nullptr;
-  kas_topic_result* d_tr = nullptr; kas_scenario_result* d_sr = nullptr;
+  // (+ 8 ints: the fill kernel's full-row loads re-read the last row for lanes past the end)
+  if ((rc = kas_host_buf(ctx, &ctx->h_cur, sizeof(int32_t) * (size_t)(sh.cur_need + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_out, sizeof(int32_t) * (size_t)(sh.out_need + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_aux, sizeof(int32_t) * (size_t)(sh.aux_need + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_ctx, sizeof(int32_t) * (size_t)(sh.ctx_need + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_tr, sizeof(kas_topic_result) * (size_t)(batch->n_topics + 1))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_sr, sizeof(kas_scenario_result) * (size_t)(batch->n_scenarios + 1))) != KAS_E_OK) return rc;
+  int32_t *d_cur = (int32_t*)ctx->h_cur.p, *d_out = (int32_t*)ctx->h_out.p, *d_aux = (int32_t*)ctx->h_aux.p,
+          *d_ctx = (int32_t*)ctx->h_ctx.p;
+  kas_topic_result* d_tr = (kas_topic_result*)ctx->h_tr.p;
+  kas_scenario_result* d_sr = (kas_scenario_result*)ctx->h_sr.p;
+  if (sh.cur_need) KAS_HIP_TRY(hipMemcpyAsync(d_cur, h->cur, sizeof(int32_t) * (size_t)sh.cur_need, hipMemcpyHostToDevice, st));
+  if (sh.aux_need) KAS_HIP_TRY(hipMemcpyAsync(d_aux, h->aux, sizeof(int32_t) * (size_t)sh.aux_need, hipMemcpyHostToDevice, st));
+  if (sh.ctx_need) KAS_HIP_TRY(hipMemcpyAsync(d_ctx, h->ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyHostToDevice, st));
   kas_tables d;
   memset(&d, 0, sizeof(d));
-  hipError_t e = hipSuccess;
-  auto H = [&](hipError_t x) { if (e == hipSuccess && x != hipSuccess) e = x; return x == hipSuccess; };
-  H(hipMalloc((void**)&d_cur, sizeof(int32_t) * (size_t)(sh.cur_need + 4)));
-  H(hipMalloc((void**)&d_out, sizeof(int32_t) * (size_t)(sh.out_need + 4)));
-  H(hipMalloc((void**)&d_aux, sizeof(int32_t) * (size_t)(sh.aux_need + 4)));
-  H(hipMalloc((void**)&d_ctx, sizeof(int32_t) * (size_t)(sh.ctx_need + 4)));
-  H(hipMalloc((void**)&d_tr, sizeof(kas_topic_result) * (size_t)(batch->n_topics + 1)));
-  H(hipMalloc((void**)&d_sr, sizeof(kas_scenario_result) * (size_t)(batch->n_scenarios + 1)));
-  if (e == hipSuccess) {
-    if (sh.cur_need) H(hipMemcpyAsync(d_cur, h->cur, sizeof(int32_t) * (size_t)sh.cur_need, hipMemcpyHostToDevice, st));
-    if (sh.aux_need) H(hipMemcpyAsync(d_aux, h->aux, sizeof(int32_t) * (size_t)sh.aux_need, hipMemcpyHostToDevice, st));
-    if (sh.ctx_need) H(hipMemcpyAsync(d_ctx, h->ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyHostToDevice, st));
-  }
-  rc = KAS_E_OK;
-  if (e == hipSuccess) {
-    d.cur = d_cur; d.out = d_out; d.aux = d_aux; d.ctx = d_ctx;
-    d.topic_results = d_tr; d.scenario_results = d_sr;
-    rc = kas_solve_device(plan, &d, st);
-  }
-  if (rc == KAS_E_OK && e == hipSuccess) {
-    if (sh.out_need) H(hipMemcpyAsync(h->out, d_out, sizeof(int32_t) * (size_t)sh.out_need, hipMemcpyDeviceToHost, st));
-    if (sh.ctx_need) H(hipMemcpyAsync(h->ctx, d_ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyDeviceToHost, st));
-    if (batch->n_topics) H(hipMemcpyAsync(h->topic_results, d_tr, sizeof(kas_topic_result) * (size_t)batch->n_topics, hipMemcpyDeviceToHost, st));
-    if (batch->n_scenarios) H(hipMemcpyAsync(h->scenario_results, d_sr, sizeof(kas_scenario_result) * (size_t)batch->n_scenarios, hipMemcpyDeviceToHost, st));
-    H(hipStreamSynchronize(st));
-  }
-  (void)hipFree(d_cur); (void)hipFree(d_out); (void)hipFree(d_aux); (void)hipFree(d_ctx);
-  (void)hipFree(d_tr); (void)hipFree(d_sr);
-  kas_plan_destroy(plan);
+  d.cur = d_cur; d.out = d_out; d.aux = d_aux; d.ctx = d_ctx;
+  d.topic_results = d_tr; d.scenario_results = d_sr;
+  rc = kas_solve_device(plan, &d, st);
   if (rc != KAS_E_OK) return rc;
-  if (e != hipSuccess) return set_error(KAS_E_HIP, hipGetErrorString(e));
+  if (sh.out_need) KAS_HIP_TRY(hipMemcpyAsync(h->out, d_out, sizeof(int32_t) * (size_t)sh.out_need, hipMemcpyDeviceToHost, st));
+  if (sh.ctx_need) KAS_HIP_TRY(hipMemcpyAsync(h->ctx, d_ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyDeviceToHost, st));
+  if (batch->n_topics) KAS_HIP_TRY(hipMemcpyAsync(h->topic_results, d_tr, sizeof(kas_topic_result) * (size_t)batch->n_topics, hipMemcpyDeviceToHost, st));
+  if (batch->n_scenarios) KAS_HIP_TRY(hipMemcpyAsync(h->scenario_results, d_sr, sizeof(kas_scenario_result) * (size_t)batch->n_scenarios, hipMemcpyDeviceToHost, st));
+  KAS_HIP_TRY(hipStreamSynchronize(st));
+  return KAS_E_OK;
+}
+
+int kas_ctx_host_stats(kas_ctx* ctx, int64_t* calls, int64_t* plan_hits, int64_t* device_allocs) {
+  if (!ctx) return set_error(KAS_E_INVALID_ARG, "ctx == NULL");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  if (calls) *calls = (int64_t)ctx->host_calls;
+  if (plan_hits) *plan_hits = (int64_t)ctx->host_plan_hits;
+  if (device_allocs) *device_allocs = (int64_t)ctx->host_allocs;
   return KAS_E_OK;
 }
 

@@ -38,11 +38,14 @@ namespace kas {
 #endif
 // rows a queue must decide beyond the one that was ready anyway for the pass to count as paying;
 // below that the next nominations are skipped (1, 2, 4 ... up to KAS_WIDE_BACKOFF_MAX steps)
+// (measured at configs[4], round 2: gain >= 1 without back-off 83 ms, the 3-wide kernel's
+// gain >= 3 with back-off up to 16 steps 93 ms; nominating rank-1 rows as well 188 ms — the passes
+// are then spent on two-row queues while the long ones wait)
 #ifndef KAS_WIDE_MIN_GAIN
-#define KAS_WIDE_MIN_GAIN 3
+#define KAS_WIDE_MIN_GAIN 1
 #endif
 #ifndef KAS_WIDE_BACKOFF_MAX
-#define KAS_WIDE_BACKOFF_MAX 16
+#define KAS_WIDE_BACKOFF_MAX 0
 #endif
 #ifndef KAS_WIDE_RING_SLOTS
 #define KAS_WIDE_RING_SLOTS KAS_RING_SLOTS
@@ -108,6 +111,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   WideSlot* ring = (WideSlot*)((unsigned char*)run + kas_align16(2 * (int64_t)(nmax + 1)));
   uint64_t* gdig = (uint64_t*)(ring + K * 64);
   uint32_t* rank_owner = (uint32_t*)(gdig + 2);             // [64] queue scratch of the solver: rank -> lane
+  uint32_t* wd = rank_owner + 64;                           // watchdog word (debug builds, see watchdog_poll)
   // padding holder: a ticket that always matches its commits; never picked (pick_row looks at Lp cells)
   const int32_t dummy_e = (KAS_WIDE_DUMMY_TICKET << 16) | (nmax * 8);
 
@@ -122,8 +126,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   if (wave == 0 && lane == 0) {
     cnt[nmax] = ((uint64_t)0xfffffu << 32) | 0x3fffffffull;  // five fields of 0x3ff: commits == the dummy ticket
     gdig[0] = 0ull;
+    *wd = 0u;
   }
   kasw::sync();
+  int32_t wd_idle = 0;
 
   if (wave == 0) {
     // ------------------------------------------------------------------ solver: LDS only
@@ -302,7 +308,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         cv = true; nv = false;
       }
       if (kasw::ballot(!fin) == 0) break;
-      if (kasw::ballot(ready) == 0) { n_blocked += 1; kasw::spin_pause(); }
+      const bool progress = kasw::ballot(ready) != 0;
+      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (!progress) { n_blocked += 1; kasw::spin_pause(); }
     }
     if (a.stats && have_s) {
       const int32_t run_rows = kasw::wave_sum((int32_t)n_run_rows);
@@ -330,7 +338,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       f_iter += 1;
       const bool slot_free = ring[(jl & (K - 1)) * 64 + lane].tag == KAS_TAG_FREE;
       const bool room = kasw::ballot(slot_free) == ~0ull;
-      const bool staging = !endl && room && pf_valid;
+      const bool stalled = KAS_TEST_STALL_AFTER > 0 && jl >= KAS_TEST_STALL_AFTER;   // debug-build test hook
+      const bool staging = !endl && room && pf_valid && !stalled;
       const bool staging_end = staging && pf_end;
       uint32_t cs[W];
       {
@@ -401,7 +410,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;
-      if (kasw::ballot(staging) == 0) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
+      const bool progress = kasw::ballot(staging) != 0;
+      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (!progress) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
     }
     if (a.stats && have_s && lane == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
@@ -470,12 +481,18 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       finish(rb);
       retired = gather(rb) || retired;
       if (kasw::ballot(!fin) == 0) break;
-      if (kasw::ballot(retired) == 0) kasw::nap<KAS_IDLE_NAP>();
+      const bool progress = kasw::ballot(retired) != 0;
+      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (!progress) kasw::nap<KAS_IDLE_NAP>();
     }
     finish(ra); finish(rb);
     kasw::lds_atomic_add_u64(&gdig[0], digest);
     kasw::lockstep();
     if (have_s && lane == 0) a.scenario_results[s].digest = gdig[0];
+    if (KAS_SPIN_BOUND > 0 && have_s && lane == 0 && *(volatile uint32_t*)wd != 0u) {
+      a.scenario_results[s].status = KAS_FAIL_WATCHDOG;
+      a.scenario_results[s].fail_topic = -1; a.scenario_results[s].fail_partition = -1;
+    }
   }
 }
 

@@ -77,6 +77,7 @@ struct KasLds {
 #define KAS_CTL_MOVED_R 3
 #define KAS_CTL_MOVED_P 4
 #define KAS_CTL_OC 8          // [NW] orphans found per chunk
+#define KAS_CTL_WATCHDOG 7    // debug builds (KAS_SPIN_BOUND): a P4 wait ran past its bound
 
 #define KAS_PAIRING_LIMIT 8192   // batches up to this many scenarios are ordered by chain length for P5
 #define KAS_TICKET_LIMIT 65535  // tickets (= 16-bit counters of the order kernel) stay below this
@@ -124,7 +125,7 @@ KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G, int32_
   return kas_align16(kas_align16((packed ? 4 : 8) * (n + 1)) + 4 * (n + 1) + 2 * (n + 1));
 }
 KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed) {
-  return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G, packed) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G + 256);
+  return kas_align16((int64_t)G * kas_order_ticket_group_bytes(n_max, G, packed) + KAS_RING_SLOTS * 64 * 16 + 8 * (int64_t)G + 256 + 16);
 }
 // ticket form for lists 4 and 5 wide (kas_order_wide.h), one scenario per workgroup: uint64 counter
 // row per node + the padding holder's (five 10-bit counts), uint64 lane mask per node, uint16
@@ -135,7 +136,7 @@ KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed
 KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
   return kas_align16(2 * (int64_t)kas_align16(8 * (n + 1)) + kas_align16(2 * (n + 1)) +
-                     KAS_WIDE_RING_SLOTS * 64 * 32 + 16 + 256);
+                     KAS_WIDE_RING_SLOTS * 64 * 32 + 16 + 256 + 16);
 }
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {

@@ -59,16 +59,47 @@
 #include "kas_wave.h"
 
 // Event counters of the fill kernel (P4 windows / node steps, ranked tiles; kas_plan_stats() [4],
-// [5], [7]).  They are per-lane 64-bit values that live across the whole kernel: in the product
-// build they are compiled out (zero) — the row scans are short of registers and ran 20-35 %
-// slower with them (round 2, profiles/) — and a -DKAS_FILL_COUNTERS build brings them back.
+// [5], [7]) and the solver's "rows in hand" tally ([15]).  They are per-lane 64-bit values that live
+// across a whole kernel: in the product build they are compiled out (zero) — the row scans are
+// short of registers and ran 20-35 % slower with them (round 2, profiles/) — and a
+// -DKAS_FILL_COUNTERS build brings them back.
 #ifdef KAS_FILL_COUNTERS
 #define KAS_COUNT(x) do { (x) += 1; } while (0)
+#define KAS_COUNTERS_ON 1
 #else
 #define KAS_COUNT(x) do { } while (0)
+#define KAS_COUNTERS_ON 0
+#endif
+
+// Hang containment.  The order kernels' three wavefronts and the P4 windows of the fill kernel wait
+// for each other by polling LDS words; a protocol error there would spin forever and take the GPU
+// with it.  A debug build (-DKAS_SPIN_BOUND=n, scripts/build_variant.sh) bounds every such loop: a
+// wavefront that polls n times without making progress raises the workgroup's watchdog word, every
+// polling loop of the workgroup leaves when it sees the word, and the scenario is reported as
+// KAS_FAIL_WATCHDOG instead of hanging.  The product build (KAS_SPIN_BOUND 0) has none of this.
+#ifndef KAS_SPIN_BOUND
+#define KAS_SPIN_BOUND 0
+#endif
+// test hook of the debug build: the staging wavefront stops handing out rows after this many tiles
+#ifndef KAS_TEST_STALL_AFTER
+#define KAS_TEST_STALL_AFTER 0
 #endif
 
 namespace kas {
+
+// one poll of a bounded loop: `progress` (wave-uniform) = this iteration did something; returns
+// true when the loop must be left (watchdog raised by this or another wavefront)
+KAS_DEV bool watchdog_poll(uint32_t* wd, bool progress, int32_t& idle) {
+#if KAS_SPIN_BOUND > 0
+  idle = progress ? 0 : idle + 1;
+  if (idle > KAS_SPIN_BOUND && kasw::lane() == 0) *(volatile uint32_t*)wd = 1u;
+  kasw::repoll();
+  return kasw::ballot(*(volatile uint32_t*)wd != 0u) != 0ull;
+#else
+  (void)wd; (void)progress; (void)idle;
+  return false;
+#endif
+}
 
 struct TopicOutcome {
   int32_t status;
@@ -860,10 +891,16 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
         const int32_t upto = j + U < live_count ? j + U : live_count;
         const uint64_t want = ((uint64_t)(uint32_t)(w - 1) << 32) + (uint32_t)upto;
         bool abandoned = false;
+        int32_t idle = 0;
         for (;;) {
           kasw::repoll();
           if (kasw::ballot(prog[prev] >= want) != 0) break;
           if (kasw::ballot(L.ctl[KAS_CTL_FAILWIN] < w) != 0) { abandoned = true; break; }
+          if (watchdog_poll((uint32_t*)&L.ctl[KAS_CTL_WATCHDOG], false, idle)) {
+            if (lane == 0) kasw::lds_atomic_min(&L.ctl[KAS_CTL_FAILWIN], -1);   // every later window stops
+            abandoned = true;
+            break;
+          }
           kasw::spin_pause();
         }
         if (abandoned) { stop = true; break; }
@@ -1112,6 +1149,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     p4_lists_parallel<W, NW>(L, T, L.ctl[KAS_CTL_LIVE], wave, st, fail_win, fail_row);
     kasw::sync();                                            // KAS_CTL_FAILWIN is final: its wave reports the row
     if (fail_win >= 0 && fail_win == L.ctl[KAS_CTL_FAILWIN] && lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
+    if (KAS_SPIN_BOUND > 0 && L.ctl[KAS_CTL_WATCHDOG] != 0) { res.status = KAS_FAIL_WATCHDOG; return res; }   // workgroup-uniform
   }
   {
     const int32_t mr = kasw::wave_sum(moved_r), mp = kasw::wave_sum(moved_p);
@@ -1444,6 +1482,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G, PK));
   uint64_t* gdig = (uint64_t*)(ring + K * 64);
   uint32_t* rank_owner = (uint32_t*)(gdig + G);             // [64] run scratch of the solver: rank -> lane
+  uint32_t* wd = rank_owner + 64;                           // watchdog word (debug builds, see watchdog_poll)
 
   kas_scenario_desc sd;
   sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
@@ -1459,8 +1498,10 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     gdig[g] = 0ull;
   }
   if (wave == 0) rank_owner[lane] = 0u;
+  if (wave == 0 && lane == 0) *wd = 0u;
   for (int32_t k = wave; k < K; k += 3) ring[k * 64 + lane].tag = KAS_TAG_FREE;
   kasw::sync();
+  int32_t wd_idle = 0;
 
   if (wave == 0) {
     // ------------------------------------------------------------------ solver: LDS only
@@ -1508,7 +1549,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
                      d2 = ((uint32_t)e2 >> 16) - com[2];
       const uint32_t d_any = d0 | d1 | d2, d_sum = d0 + d1 + d2;
       bool ready = cv && d_any == 0u;
-      if (a.stats) n_cur += kasw::popc((kasw::ballot(cv) >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)));
+      if (KAS_COUNTERS_ON && a.stats) n_cur += kasw::popc((kasw::ballot(cv) >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)));
       // ---- runs.  First fit hands consecutive orphans to one node until it is full, so the rows
       // in hand often queue on ONE node X (tickets t, t+1, ...) while their other holders are
       // free.  Such a queue is decided in this iteration: its rows differ from "ready" only in
@@ -1629,7 +1670,9 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         cv = true; nv = false;
       }
       if (kasw::ballot(!fin) == 0) break;
-      if (kasw::ballot(ready) == 0) { n_blocked += 1; kasw::spin_pause(); }
+      const bool progress = kasw::ballot(ready) != 0;
+      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (!progress) { n_blocked += 1; kasw::spin_pause(); }
     }
     int32_t run_rows = 0;                                  // rows of my scenario decided inside runs
     if (a.stats) {
@@ -1669,7 +1712,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       // now if the slot it goes to is free (retired) in every lane of the group
       const bool slot_free = ring[(jl & (K - 1)) * 64 + lane].tag == KAS_TAG_FREE;
       const bool room = (kasw::ballot(slot_free) & gmask) == gmask;
-      const bool staging = !endl && room && pf_valid;
+      const bool stalled = KAS_TEST_STALL_AFTER > 0 && jl >= KAS_TEST_STALL_AFTER;   // debug-build test hook
+      const bool staging = !endl && room && pf_valid && !stalled;
       const bool staging_end = staging && pf_end;
       // unpack: uint16 node indices, 0xffff = none (sorts last, like ~0)
       const uint32_t c0 = staging ? (pf_w0 & 0xffffu) : ~0u, c1 = staging ? (pf_w0 >> 16) : ~0u,
@@ -1759,7 +1803,9 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;
-      if (kasw::ballot(staging) == 0) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
+      const bool progress = kasw::ballot(staging) != 0;
+      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (!progress) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
     }
     if (a.stats && have_s && li == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
@@ -1847,13 +1893,19 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
       for (int u = 0; u < UR; ++u) retired = gather(rb[u]) || retired;
       if (kasw::ballot(!fin) == 0) break;
-      if (kasw::ballot(retired) == 0) kasw::nap<KAS_IDLE_NAP>();
+      const bool progress = kasw::ballot(retired) != 0;
+      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (!progress) kasw::nap<KAS_IDLE_NAP>();
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) { finish(ra[u]); finish(rb[u]); }
     kasw::lds_atomic_add_u64(&gdig[g], digest);
     kasw::lockstep();
     if (have_s && li == 0) a.scenario_results[s].digest = gdig[g];
+    if (KAS_SPIN_BOUND > 0 && have_s && li == 0 && *(volatile uint32_t*)wd != 0u) {
+      a.scenario_results[s].status = KAS_FAIL_WATCHDOG;
+      a.scenario_results[s].fail_topic = -1; a.scenario_results[s].fail_partition = -1;
+    }
   }
 }
 

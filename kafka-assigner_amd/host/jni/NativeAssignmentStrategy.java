@@ -1,6 +1,7 @@
 // Java side of the JNI boundary (see INTEGRATION.md).  Not compiled in this repository's image
 // (there is no JDK); a maintainer of the reference adds this file next to
-// KafkaAssignmentStrategy.java and routes getRackAwareAssignment (KAS:40-63) through solve().
+// KafkaAssignmentStrategy.java and routes getRackAwareAssignment (KAS:40-63) through solve(), or
+// a whole PRINT_REASSIGNMENT run / a set of what-if broker sets through solveScenarios().
 package siftscience.kafka.tools;
 
 import java.nio.ByteBuffer;
@@ -16,77 +17,221 @@ import java.util.TreeSet;
 final class NativeAssignmentStrategy {
     static { System.loadLibrary("kas_jni"); }
 
+    static final int LAYOUT = 2;         // KAS_JNI_LAYOUT of kas_jni.cpp
     static final int WIDTH = 8;          // KAS_MAX_WIDTH
-    static final int HEADER_INTS = 8;    // {nameHash, P, curWidth, rf, outWidth, N, hasCtx, reserved}
+    static final int HEADER_INTS = 8;    // {LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen}
 
-    /** Layout of `in` (int32, native order): header[8], nodeId[N], nodeRack[N], partId[P],
-     *  curLen[P], inPartitions[P], cur[P*curWidth], ctx[N*8].
-     *  Layout of `out`: {status, failPartition, movedReplicas, movedPartitions}, out[P*outWidth],
-     *  ctx[N*8]. */
+    /** One batch: S scenarios, each a broker set + rack map and an ordered run of topics that share
+     *  one Context.  Layout of `in` (int32 / int64 fields, native order): header[8], S scenario
+     *  descriptors (32 bytes: nNodes, topicBegin, topicCount, ctxWidth, long nodeOff, long ctxOff),
+     *  T topic descriptors (64 bytes: nameHash, nPartitions, curWidth, rf, outWidth, reserved,
+     *  long curOff, outOff, curLenOff, inPartitionsOff, partIdOff), nodeId[], nodeRack[], cur[],
+     *  aux[], ctx[].  Layout of `out`: T topic results (status, failPartition, movedReplicas,
+     *  movedPartitions), S scenario results (32 bytes), out[], ctx[]. */
     static native int solveBatch(ByteBuffer in, ByteBuffer out);
 
+    /** One topic of a scenario, in the reference's own argument types (KAS:40-43). */
+    static final class TopicRequest {
+        final String topic;
+        final Map<Integer, List<Integer>> currentAssignment;
+        final Set<Integer> partitions;       // null = keys(currentAssignment), as KTA:50-54 passes
+        final int replicationFactor;
+        TopicRequest(String topic, Map<Integer, List<Integer>> cur, Set<Integer> partitions, int rf) {
+            this.topic = topic; this.currentAssignment = cur; this.partitions = partitions;
+            this.replicationFactor = rf;
+        }
+    }
+
+    /** One scenario: what one PRINT_REASSIGNMENT run solves (KAG:172-184). */
+    static final class ScenarioRequest {
+        final Set<Integer> nodes;
+        final Map<Integer, String> racks;
+        final List<TopicRequest> topics = new ArrayList<TopicRequest>();
+        /** Context counters in/out (KAS:360-369); null = start empty, do not report back. */
+        Map<Integer, Map<Integer, Integer>> counters;
+        ScenarioRequest(Set<Integer> nodes, Map<Integer, String> racks) { this.nodes = nodes; this.racks = racks; }
+    }
+
+    /** Outcome of one topic: the new assignment, or the exception the reference would have thrown. */
+    static final class TopicOutcome {
+        int status, failPartition, movedReplicas, movedPartitions;
+        Map<Integer, List<Integer>> assignment;
+        RuntimeException failure() {
+            if (status == 0) return null;
+            if (status == 1)       // KAS:183-184
+                return new IllegalStateException("Partition " + failPartition + " could not be fully assigned!");
+            if (status == 4) return new ArrayIndexOutOfBoundsException();   // KAS:190 with hashCode() == MIN_VALUE
+            if (status == 6) return new IllegalStateException("skipped: an earlier topic of the run failed");
+            return new IllegalStateException("solver status " + status);
+        }
+    }
+
+    /** Drop-in body for getRackAwareAssignment: one scenario, one topic. */
     static Map<Integer, List<Integer>> solve(String topic, Map<Integer, List<Integer>> cur,
             Map<Integer, String> racks, Set<Integer> nodes, Set<Integer> partitions, int rf,
             Map<Integer, Map<Integer, Integer>> counters) {
-        TreeSet<Integer> nodeSet = new TreeSet<Integer>(nodes);
-        TreeMap<Integer, List<Integer>> rows = new TreeMap<Integer, List<Integer>>(cur);
-        int n = nodeSet.size(), p = rows.size(), cw = 0;
-        for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
-        int ow = Math.max(Math.max(cw, rf), 1);
-        if (ow > WIDTH) throw new IllegalStateException("replica lists longer than " + WIDTH);
-        ByteBuffer in = ByteBuffer.allocateDirect(4 * (HEADER_INTS + 2 * n + 3 * p + p * cw + n * WIDTH))
-                .order(ByteOrder.nativeOrder());
-        in.putInt(topic.hashCode()).putInt(p).putInt(cw).putInt(rf).putInt(ow).putInt(n)
-          .putInt(counters != null ? 1 : 0).putInt(0);
-        for (int id : nodeSet) in.putInt(id);
-        Map<String, Integer> rackIndex = new HashMap<String, Integer>();
-        for (int id : nodeSet) {                       // KAS:82-86: missing rack = own id string
-            String r = racks.containsKey(id) ? racks.get(id) : Integer.toString(id);
-            Integer k = rackIndex.get(r);
-            if (k == null) { k = rackIndex.size(); rackIndex.put(r, k); }
-            in.putInt(k);
-        }
-        for (int part : rows.keySet()) in.putInt(part);
-        for (List<Integer> l : rows.values()) in.putInt(l.size());
-        for (int part : rows.keySet()) in.putInt(partitions.contains(part) ? 1 : 0);
-        for (List<Integer> l : rows.values())
-            for (int k = 0; k < cw; ++k) in.putInt(k < l.size() ? l.get(k) : -1);
-        for (int id : nodeSet)
-            for (int k = 0; k < WIDTH; ++k) {
-                Map<Integer, Integer> c = counters != null ? counters.get(id) : null;
-                Integer v = c != null ? c.get(k) : null;
-                in.putInt(v != null ? v : 0);
+        ScenarioRequest sc = new ScenarioRequest(nodes, racks);
+        sc.counters = counters;
+        sc.topics.add(new TopicRequest(topic, cur, partitions, rf));
+        List<ScenarioRequest> batch = new ArrayList<ScenarioRequest>();
+        batch.add(sc);
+        TopicOutcome o = solveScenarios(batch).get(0).get(0);
+        RuntimeException e = o.failure();
+        if (e != null) throw e;
+        return o.assignment;
+    }
+
+    /** The batch path: every scenario is independent, the topics of a scenario run in order
+     *  against its Context and the first failure skips the rest (the CLI run aborts there). */
+    static List<List<TopicOutcome>> solveScenarios(List<ScenarioRequest> batch) {
+        final int S = batch.size();
+        int T = 0;
+        long nodePool = 0, curLen = 0, auxLen = 0, ctxLen = 0, outLen = 0;
+        // rows of a topic: keys(cur) UNION partitions, ascending (a member of `partitions` without a
+        // current list is an all-orphan row, KAS:150-157)
+        List<List<TreeMap<Integer, List<Integer>>>> rowsOf = new ArrayList<List<TreeMap<Integer, List<Integer>>>>();
+        for (ScenarioRequest sc : batch) {
+            List<TreeMap<Integer, List<Integer>>> perTopic = new ArrayList<TreeMap<Integer, List<Integer>>>();
+            for (TopicRequest t : sc.topics) {
+                TreeMap<Integer, List<Integer>> rows = new TreeMap<Integer, List<Integer>>(t.currentAssignment);
+                if (t.partitions != null)
+                    for (int part : t.partitions)
+                        if (!rows.containsKey(part)) rows.put(part, new ArrayList<Integer>());
+                int cw = 0;
+                for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
+                int ow = Math.max(Math.max(cw, Math.min(t.replicationFactor, sc.nodes.size())), 1);
+                if (ow > WIDTH) throw new IllegalStateException("replica lists longer than " + WIDTH);
+                perTopic.add(rows);
+                curLen += (long) rows.size() * cw; auxLen += 3L * rows.size(); outLen += (long) rows.size() * ow;
+                ++T;
             }
-        ByteBuffer out = ByteBuffer.allocateDirect(4 * (4 + p * ow + n * WIDTH)).order(ByteOrder.nativeOrder());
+            rowsOf.add(perTopic);
+            nodePool += sc.nodes.size();
+            if (sc.counters != null) ctxLen += (long) sc.nodes.size() * WIDTH;
+        }
+        long inInts = HEADER_INTS + 8L * S + 16L * T + 2 * nodePool + curLen + auxLen + ctxLen;
+        long outInts = 4L * T + 8L * S + outLen + ctxLen;
+        ByteBuffer in = ByteBuffer.allocateDirect((int) (4 * inInts)).order(ByteOrder.nativeOrder());
+        ByteBuffer out = ByteBuffer.allocateDirect((int) (4 * outInts)).order(ByteOrder.nativeOrder());
+        in.putInt(LAYOUT).putInt(S).putInt(T).putInt((int) nodePool).putInt((int) curLen).putInt((int) auxLen)
+          .putInt((int) ctxLen).putInt((int) outLen);
+        // ---- descriptors
+        long nodeOff = 0, ctxOff = 0;
+        int topicBegin = 0;
+        for (ScenarioRequest sc : batch) {
+            in.putInt(sc.nodes.size()).putInt(topicBegin).putInt(sc.topics.size())
+              .putInt(sc.counters != null ? WIDTH : 0).putLong(nodeOff).putLong(sc.counters != null ? ctxOff : -1L);
+            nodeOff += sc.nodes.size(); topicBegin += sc.topics.size();
+            if (sc.counters != null) ctxOff += (long) sc.nodes.size() * WIDTH;
+        }
+        long curOff = 0, outOff = 0, auxOff = 0;
+        for (int s = 0; s < S; ++s) {
+            ScenarioRequest sc = batch.get(s);
+            for (int k = 0; k < sc.topics.size(); ++k) {
+                TopicRequest t = sc.topics.get(k);
+                TreeMap<Integer, List<Integer>> rows = rowsOf.get(s).get(k);
+                int p = rows.size(), cw = 0;
+                for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
+                int ow = Math.max(Math.max(cw, Math.min(t.replicationFactor, sc.nodes.size())), 1);
+                in.putInt(t.topic.hashCode()).putInt(p).putInt(cw).putInt(t.replicationFactor).putInt(ow).putInt(0)
+                  .putLong(curOff).putLong(outOff)
+                  .putLong(auxOff + p)         // curLen[P]
+                  .putLong(auxOff + 2L * p)    // inPartitions[P]
+                  .putLong(auxOff);            // partId[P]
+                curOff += (long) p * cw; outOff += (long) p * ow; auxOff += 3L * p;
+            }
+        }
+        // ---- node pools: ids ascending; rack = dense index of the rack string, a broker without a
+        // rack is its own rack named by its id (KAS:82-86, string equality as in KAS:90-94)
+        List<TreeSet<Integer>> nodeSets = new ArrayList<TreeSet<Integer>>();
+        for (ScenarioRequest sc : batch) {
+            TreeSet<Integer> ns = new TreeSet<Integer>(sc.nodes);
+            nodeSets.add(ns);
+            for (int id : ns) in.putInt(id);
+        }
+        for (int s = 0; s < S; ++s) {
+            Map<String, Integer> rackIndex = new HashMap<String, Integer>();
+            for (int id : nodeSets.get(s)) {
+                Map<Integer, String> racks = batch.get(s).racks;
+                String r = racks != null && racks.containsKey(id) ? racks.get(id) : Integer.toString(id);
+                Integer k = rackIndex.get(r);
+                if (k == null) { k = rackIndex.size(); rackIndex.put(r, k); }
+                in.putInt(k);
+            }
+        }
+        // ---- cur pool, then aux pool (per topic: partId[P], curLen[P], inPartitions[P])
+        for (int s = 0; s < S; ++s)
+            for (TreeMap<Integer, List<Integer>> rows : rowsOf.get(s)) {
+                int cw = 0;
+                for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
+                for (List<Integer> l : rows.values())
+                    for (int k = 0; k < cw; ++k) in.putInt(k < l.size() ? l.get(k) : -1);
+            }
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < batch.get(s).topics.size(); ++k) {
+                TopicRequest t = batch.get(s).topics.get(k);
+                TreeMap<Integer, List<Integer>> rows = rowsOf.get(s).get(k);
+                for (int part : rows.keySet()) in.putInt(part);
+                for (List<Integer> l : rows.values()) in.putInt(l.size());
+                for (int part : rows.keySet()) in.putInt(t.partitions == null || t.partitions.contains(part) ? 1 : 0);
+            }
+        // ---- Context counters in
+        for (int s = 0; s < S; ++s) {
+            Map<Integer, Map<Integer, Integer>> counters = batch.get(s).counters;
+            if (counters == null) continue;
+            for (int id : nodeSets.get(s))
+                for (int k = 0; k < WIDTH; ++k) {
+                    Map<Integer, Integer> c = counters.get(id);
+                    Integer v = c != null ? c.get(k) : null;
+                    in.putInt(v != null ? v : 0);
+                }
+        }
         int rc = solveBatch(in, out);
         if (rc != 0) throw new IllegalStateException("native solver error " + rc);
-        int status = out.getInt(0), failPartition = out.getInt(4);
-        if (status == 1)
-            throw new IllegalStateException("Partition " + failPartition + " could not be fully assigned!");
-        if (status == 4) throw new ArrayIndexOutOfBoundsException();
-        if (status != 0) throw new IllegalStateException("solver status " + status);
-        Map<Integer, List<Integer>> result = new TreeMap<Integer, List<Integer>>();
-        int row = 0;
-        for (int part : rows.keySet()) {
-            List<Integer> l = new ArrayList<Integer>();
-            for (int k = 0; k < ow; ++k) {
-                int b = out.getInt(4 * (4 + row * ow + k));
-                if (b >= 0) l.add(b);
-            }
-            if (!l.isEmpty()) result.put(part, l);
-            ++row;
-        }
-        if (counters != null) {
-            int i = 0;
-            for (int id : nodeSet) {
-                Map<Integer, Integer> c = new HashMap<Integer, Integer>();
-                for (int k = 0; k < WIDTH; ++k) {
-                    int v = out.getInt(4 * (4 + p * ow + i * WIDTH + k));
-                    if (v != 0) c.put(k, v);
+        // ---- results
+        List<List<TopicOutcome>> result = new ArrayList<List<TopicOutcome>>();
+        int ti = 0;
+        long rowBase = 4L * T + 8L * S;      // int index of out[] inside `out`
+        long ctxBase = rowBase + outLen;
+        for (int s = 0; s < S; ++s) {
+            ScenarioRequest sc = batch.get(s);
+            List<TopicOutcome> outcomes = new ArrayList<TopicOutcome>();
+            for (int k = 0; k < sc.topics.size(); ++k, ++ti) {
+                TreeMap<Integer, List<Integer>> rows = rowsOf.get(s).get(k);
+                int cw = 0;
+                for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
+                int ow = Math.max(Math.max(cw, Math.min(sc.topics.get(k).replicationFactor, sc.nodes.size())), 1);
+                TopicOutcome o = new TopicOutcome();
+                o.status = out.getInt(4 * (4 * ti)); o.failPartition = out.getInt(4 * (4 * ti + 1));
+                o.movedReplicas = out.getInt(4 * (4 * ti + 2)); o.movedPartitions = out.getInt(4 * (4 * ti + 3));
+                if (o.status == 0) {
+                    o.assignment = new TreeMap<Integer, List<Integer>>();
+                    long row = 0;
+                    for (int part : rows.keySet()) {
+                        List<Integer> l = new ArrayList<Integer>();
+                        for (int c = 0; c < ow; ++c) {
+                            int b = out.getInt((int) (4 * (rowBase + row * ow + c)));
+                            if (b >= 0) l.add(b);
+                        }
+                        if (!l.isEmpty()) o.assignment.put(part, l);   // a row nobody holds is not a key (KAS:205-214)
+                        ++row;
+                    }
                 }
-                counters.put(id, c);
-                ++i;
+                rowBase += (long) rows.size() * ow;
+                outcomes.add(o);
             }
+            if (sc.counters != null) {
+                for (int id : nodeSets.get(s)) {
+                    Map<Integer, Integer> c = new HashMap<Integer, Integer>();
+                    for (int k = 0; k < WIDTH; ++k) {
+                        int v = out.getInt((int) (4 * (ctxBase + k)));
+                        if (v != 0) c.put(k, v);
+                    }
+                    sc.counters.put(id, c);
+                    ctxBase += WIDTH;
+                }
+            }
+            result.add(outcomes);
         }
         return result;
     }

@@ -1,9 +1,21 @@
 // kas_jni.cpp — thin JNI shim over the C ABI of include/kas_abi.h.
 //
 // Replaces the body of KafkaAssignmentStrategy.getRackAwareAssignment
-// (KafkaAssignmentStrategy.java:40-63) as called from KafkaTopicAssigner.java:70-71.
+// (KafkaAssignmentStrategy.java:40-63) as called from KafkaTopicAssigner.java:70-71 — and, because
+// the payload is a whole batch (S scenarios x their topics, the kas_batch_desc shape), also gives
+// Java callers the batch path: one call per PRINT_REASSIGNMENT run (all topics of
+// KafkaAssignmentGenerator.java:172-184 against one Context) or per set of what-if broker sets.
 // Compiled only where a JDK provides <jni.h>; this repository's image has none, so the
-// translation unit is empty there and build() reports it as skipped.
+// translation unit is empty there, build() reports it as skipped, and tests/test_jni_shim.py
+// compiles it against tests/jni_stub/jni.h.
+//
+// Payload (int32 units, native byte order; written by NativeAssignmentStrategy.java):
+//   in :  header[8] = {KAS_JNI_LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen}
+//         scenario descriptors  S x 8 ints   (kas_scenario_desc, 32 bytes each)
+//         topic descriptors     T x 16 ints  (kas_topic_desc, 64 bytes each)
+//         nodeId[nodePoolLen] nodeRack[nodePoolLen] cur[curLen] aux[auxLen] ctx[ctxLen]
+//   out:  topicResults T x 4 ints, scenarioResults S x 8 ints, out[outLen], ctx[ctxLen]
+// Offsets inside the descriptors index these pools exactly as in kas_abi.h.
 #if defined(__has_include)
 #if __has_include(<jni.h>)
 #define KAS_HAVE_JNI 1
@@ -16,68 +28,79 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "kas_abi.h"
 
+#define KAS_JNI_LAYOUT 2
+
 namespace {
-std::mutex g_mu;          // one kas_ctx (= one HIP stream) for the JVM; callers are serialised
+std::mutex g_mu;          // guards the lazily created context; kas_solve_host serialises its own callers
 kas_ctx* g_ctx = nullptr;
 constexpr int kHeaderInts = 8;
-constexpr int kCtxWidth = KAS_MAX_WIDTH;
 }  // namespace
 
 extern "C" JNIEXPORT jint JNICALL
 Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jclass, jobject jin, jobject jout) {
-  int32_t* in = static_cast<int32_t*>(env->GetDirectBufferAddress(jin));
+  const int32_t* in = static_cast<const int32_t*>(env->GetDirectBufferAddress(jin));
   int32_t* out = static_cast<int32_t*>(env->GetDirectBufferAddress(jout));
   if (!in || !out) return KAS_E_INVALID_ARG;
   const int64_t in_ints = env->GetDirectBufferCapacity(jin) / 4, out_ints = env->GetDirectBufferCapacity(jout) / 4;
-  const int32_t hash = in[0], P = in[1], cw = in[2], rf = in[3], ow = in[4], N = in[5], has_ctx = in[6];
-  if (P < 0 || N < 0 || cw < 0 || ow < 1 || ow > KAS_MAX_WIDTH || cw > ow) return KAS_E_INVALID_ARG;
-  const int64_t need_in = kHeaderInts + 2ll * N + 3ll * P + (int64_t)P * cw + (int64_t)N * kCtxWidth;
-  const int64_t need_out = 4 + (int64_t)P * ow + (int64_t)N * kCtxWidth;
+  if (in_ints < kHeaderInts || in[0] != KAS_JNI_LAYOUT) return KAS_E_INVALID_ARG;
+  const int64_t S = in[1], T = in[2], npool = in[3], cur_len = in[4], aux_len = in[5], ctx_len = in[6], out_len = in[7];
+  if (S < 0 || T < 0 || npool < 0 || cur_len < 0 || aux_len < 0 || ctx_len < 0 || out_len < 0) return KAS_E_INVALID_ARG;
+  const int64_t need_in = kHeaderInts + 8 * S + 16 * T + 2 * npool + cur_len + aux_len + ctx_len;
+  const int64_t need_out = 4 * T + 8 * S + out_len + ctx_len;
   if (in_ints < need_in || out_ints < need_out) return KAS_E_INVALID_ARG;
 
-  const int32_t* node_id = in + kHeaderInts;
-  const int32_t* node_rack = node_id + N;
-  const int32_t* aux = node_rack + N;                 // partId[P], curLen[P], inPartitions[P]
-  const int32_t* cur = aux + 3ll * P;
-  const int32_t* ctx_in = cur + (int64_t)P * cw;
-  int32_t* out_rows = out + 4;
-  int32_t* ctx_out = out_rows + (int64_t)P * ow;
-  memcpy(ctx_out, ctx_in, sizeof(int32_t) * (size_t)N * kCtxWidth);
+  // descriptors are copied out of the buffer: no alignment assumption on the ByteBuffer
+  static_assert(sizeof(kas_scenario_desc) == 32 && sizeof(kas_topic_desc) == 64, "payload layout");
+  std::vector<kas_scenario_desc> scen((size_t)S);
+  std::vector<kas_topic_desc> topics((size_t)T);
+  const int32_t* p = in + kHeaderInts;
+  if (S) memcpy(scen.data(), p, sizeof(kas_scenario_desc) * (size_t)S);
+  p += 8 * S;
+  if (T) memcpy(topics.data(), p, sizeof(kas_topic_desc) * (size_t)T);
+  p += 16 * T;
+  const int32_t* node_id = p; p += npool;
+  const int32_t* node_rack = p; p += npool;
+  const int32_t* cur = p; p += cur_len;
+  const int32_t* aux = p; p += aux_len;
+  const int32_t* ctx_in = p;
 
-  kas_topic_desc td;
-  memset(&td, 0, sizeof(td));
-  td.name_hash = hash; td.n_partitions = P; td.cur_width = cw; td.rf = rf; td.out_width = ow;
-  td.cur_off = 0; td.out_off = 0;
-  td.part_id_off = 0; td.cur_len_off = P; td.in_partitions_off = 2ll * P;
-  kas_scenario_desc sd;
-  memset(&sd, 0, sizeof(sd));
-  sd.n_nodes = N; sd.topic_begin = 0; sd.topic_count = 1;
-  sd.ctx_width = has_ctx ? kCtxWidth : 0; sd.node_off = 0; sd.ctx_off = has_ctx ? 0 : -1;
+  static_assert(sizeof(kas_topic_result) == 16 && sizeof(kas_scenario_result) == 32, "payload layout");
+  std::vector<kas_topic_result> tr((size_t)T);
+  std::vector<kas_scenario_result> sr((size_t)S);
+  int32_t* out_tr = out;
+  int32_t* out_sr = out_tr + 4 * T;
+  int32_t* out_rows = out_sr + 8 * S;
+  int32_t* ctx_out = out_rows + out_len;
+  if (ctx_len) memcpy(ctx_out, ctx_in, sizeof(int32_t) * (size_t)ctx_len);     // Context counters are in/out
+
   kas_batch_desc bd;
   memset(&bd, 0, sizeof(bd));
-  bd.n_scenarios = 1; bd.n_topics = 1; bd.scenarios = &sd; bd.topics = &td;
-  bd.node_id = node_id; bd.node_rack = node_rack; bd.node_pool_len = N;
-
-  kas_topic_result tr;
-  kas_scenario_result sr;
+  bd.n_scenarios = (int32_t)S; bd.n_topics = (int32_t)T;
+  bd.scenarios = scen.data(); bd.topics = topics.data();
+  bd.node_id = node_id; bd.node_rack = node_rack; bd.node_pool_len = npool;
   kas_tables t;
   memset(&t, 0, sizeof(t));
-  t.cur = cur; t.out = out_rows; t.aux = aux; t.ctx = ctx_out;
-  t.topic_results = &tr; t.scenario_results = &sr;
-  t.cur_len = (int64_t)P * cw; t.out_len = (int64_t)P * ow; t.aux_len = 3ll * P;
-  t.ctx_len = has_ctx ? (int64_t)N * kCtxWidth : 0;
+  t.cur = cur; t.out = out_rows; t.aux = aux_len ? aux : nullptr; t.ctx = ctx_len ? ctx_out : nullptr;
+  t.topic_results = tr.data(); t.scenario_results = sr.data();
+  t.cur_len = cur_len; t.out_len = out_len; t.aux_len = aux_len; t.ctx_len = ctx_len;
 
-  std::lock_guard<std::mutex> lock(g_mu);
-  if (!g_ctx) {
-    int rc = kas_ctx_create(0, &g_ctx);
-    if (rc != KAS_E_OK) return rc;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_ctx) {
+      int rc = kas_ctx_create(0, &g_ctx);
+      if (rc != KAS_E_OK) return rc;
+    }
   }
+  // the context keeps its device buffers and the plans of recent batch shapes: a JVM that calls
+  // once per topic or per what-if round pays no allocation after the first call
   int rc = kas_solve_host(g_ctx, &bd, &t);
   if (rc != KAS_E_OK) return rc;
-  out[0] = tr.status; out[1] = tr.fail_partition; out[2] = tr.moved_replicas; out[3] = tr.moved_partitions;
+  if (T) memcpy(out_tr, tr.data(), sizeof(kas_topic_result) * (size_t)T);
+  if (S) memcpy(out_sr, sr.data(), sizeof(kas_scenario_result) * (size_t)S);
   return KAS_E_OK;
 }
 #endif  // KAS_HAVE_JNI

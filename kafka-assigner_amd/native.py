@@ -23,7 +23,7 @@ SYMBOLS = [
     "kas_ctx_create", "kas_ctx_destroy", "kas_ctx_synchronize", "kas_plan_create",
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
     "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
-    "kas_plan_describe",
+    "kas_plan_describe", "kas_ctx_host_stats",
 ]
 
 _LIB = None
@@ -78,6 +78,8 @@ def load():
                                           C.POINTER(C.c_int)]
     L.kas_plan_set_flags.restype = C.c_int
     L.kas_plan_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+    L.kas_ctx_host_stats.restype = C.c_int
+    L.kas_ctx_host_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.kas_plan_describe.restype = C.c_int
     L.kas_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.kas_plan_stats.restype = C.c_int
@@ -105,6 +107,12 @@ class DeviceContext:
 
     def synchronize(self):
         _check(self._lib.kas_ctx_synchronize(self._h))
+
+    def host_stats(self):
+        """(kas_solve_host calls, calls served by a cached plan, device allocations made)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self._lib.kas_ctx_host_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def close(self):
         if self._h:

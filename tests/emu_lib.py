@@ -29,6 +29,38 @@ def build_emu() -> str:
     return so
 
 
+def build_emu_variant(name: str, flags) -> str:
+    """The emulator compiled with extra -D flags (debug-build macros of the kernel source)."""
+    so = os.path.join(EMU_DIR, f"libkas_emu_{name}.so")
+    deps = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "kas_wave.h"),
+            os.path.join(CSRC, "kas_solver_body.h"), os.path.join(CSRC, "kas_order_wide.h"),
+            os.path.join(CSRC, "kas_plan_math.h"), os.path.join(ROOT, "include", "kas_abi.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call([
+            "g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-parameter", "-Wno-unknown-pragmas",
+            *flags, "-I" + os.path.join(ROOT, "tests"), "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+            "-o", so, deps[0]])
+    return so
+
+
+def variant_solver(name: str, flags):
+    """emu_solve bound to an emulator variant (own shared object, loaded side by side)."""
+    L = C.CDLL(build_emu_variant(name, flags))
+    L.kas_emu_solve_batch.restype = C.c_int
+    L.kas_emu_solve_batch.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
+                                      C.c_uint, C.c_char_p, C.c_int]
+
+    def solve(fb: FlatBatch, flags: int = 0) -> HostOutputs:
+        bd = batch_desc(fb)
+        t, ho = host_tables(fb)
+        err = C.create_string_buffer(512)
+        rc = L.kas_emu_solve_batch(C.byref(bd), C.byref(t), flags, err, 512)
+        if rc != 0:
+            raise RuntimeError(f"kas_emu_solve_batch rc={rc}: {err.value.decode()}")
+        return ho
+    return solve
+
+
 def lib():
     global _LIB
     if _LIB is None:

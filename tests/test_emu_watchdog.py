@@ -1,0 +1,38 @@
+"""Hang containment (debug builds, -DKAS_SPIN_BOUND=n): every loop in which the wavefronts of a
+workgroup wait for each other is bounded; a wavefront that polls n times without progress raises
+the workgroup's watchdog word, all polling loops leave, and the scenario reports
+KAS_FAIL_WATCHDOG instead of hanging the GPU.  Checked on the CPU emulator of the kernel source:
+(1) with the bound on and nothing wrong, results are the oracle's (no false alarm);
+(2) with the staging wavefront made to stop handing out rows (test hook), the kernel RETURNS and
+    says so — for the 3-wide and the wide ticket kernels."""
+import numpy as np
+
+from kafka_assigner_amd import abi
+from kafka_assigner_amd import generator as G
+from emu_lib import variant_solver
+from oracle_lib import oracle_solve
+from parity_util import assert_same_outputs
+from test_emu_parity import _batch
+
+
+def test_bounded_build_without_a_fault_equals_the_oracle():
+    solve = variant_solver("bounded", ["-DKAS_SPIN_BOUND=200000"])
+    for P, N, R, RF, acts in ((3000, 60, 6, 3, G.ACTIONS), (8000, 80, 8, 3, ("replace1", "add_k")),
+                              (3000, 120, 12, 5, G.ACTIONS)):
+        fb = _batch(77, 4, P, N, R, RF, acts)
+        want = oracle_solve(fb)
+        assert_same_outputs(fb, want, solve(fb), "bounded build")
+        assert not (want.scenario_results["status"] == abi.KAS_FAIL_WATCHDOG).any()
+
+
+def test_a_stalled_staging_wavefront_is_reported_not_hung():
+    solve = variant_solver("stalled", ["-DKAS_SPIN_BOUND=3000", "-DKAS_TEST_STALL_AFTER=2"])
+    for RF in (3, 5):                                   # order_tickets<3, ...> and order_tickets_wide<5>
+        fb = _batch(78, 4, 3000, 120, 12, RF, ("add_k", "remove1"))
+        want = oracle_solve(fb)
+        got = solve(fb)                                  # returns: that is the point
+        ok = want.scenario_results["status"] == abi.KAS_OK
+        assert ok.any()
+        np.testing.assert_array_equal(got.scenario_results["status"][ok], abi.KAS_FAIL_WATCHDOG)
+        # scenarios that had already failed in the fill kernel never reach the order kernel's rows
+        np.testing.assert_array_equal(got.scenario_results["status"][~ok], want.scenario_results["status"][~ok])

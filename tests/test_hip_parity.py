@@ -176,6 +176,29 @@ def test_one_plan_orders_its_solves_across_streams():
     plan.close()
 
 
+def test_host_path_reuses_buffers_and_plans_across_calls():
+    """kas_solve_host on one context: the device buffers only grow and the plan of a batch shape
+    is reused (include/kas_abi.h) — what the CLI's per-topic loop and a JVM calling once per topic
+    rely on.  Results stay the oracle's on every call, including after a bigger and a smaller batch."""
+    ctx = native.DeviceContext(0)
+    fb = _batch(91, 5, 4000, 80, 8, 3, G.ACTIONS)
+    want = oracle_solve(fb)
+    for _ in range(3):
+        assert_same_outputs(fb, want, native.solve_host(fb, ctx), "host path, same batch")
+    calls, hits, allocs = ctx.host_stats()
+    assert (calls, hits) == (3, 2) and allocs > 0
+    big = _batch(92, 9, 9000, 120, 12, 3, G.ACTIONS)
+    assert_same_outputs(big, oracle_solve(big), native.solve_host(big, ctx), "host path, bigger batch")
+    calls2, hits2, allocs2 = ctx.host_stats()
+    assert hits2 == 2 and allocs2 > allocs                   # new shape: new plan, buffers grown
+    assert_same_outputs(fb, want, native.solve_host(fb, ctx), "host path, first batch again")
+    fb5 = _batch(93, 3, 2000, 60, 12, 5, G.ACTIONS)          # other width class, smaller
+    assert_same_outputs(fb5, oracle_solve(fb5), native.solve_host(fb5, ctx), "host path, RF 5")
+    calls3, hits3, allocs3 = ctx.host_stats()
+    assert calls3 == 6 and hits3 == 3 and allocs3 == allocs2  # cached plan hit; nothing had to grow
+    ctx.close()
+
+
 def test_topic_without_rows_next_to_full_width_topics():
     """A topic with zero partitions whose widths match the kernel's width class (the fast fill's
     full-row loads must not touch a table that has no rows), at the very end of the cur pool."""

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from kafka_assigner_amd import build as kbuild
+from kafka_assigner_amd import abi, build as kbuild
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, java_string_hashcode, unflatten_topic
 from oracle_lib import oracle_solve
 
@@ -38,52 +38,93 @@ def shim():
     return fn
 
 
-def _java_layout(topic, cur, racks, nodes, partitions, rf, counters):
-    """What NativeAssignmentStrategy.solve() puts into the input ByteBuffer."""
-    node_ids = sorted(nodes)
-    rows = sorted(cur)
-    n, p = len(node_ids), len(rows)
-    cw = max([len(v) for v in cur.values()] + [0])
-    ow = max(cw, rf, 1)
-    rack_index, node_rack = {}, []
-    for b in node_ids:
-        r = racks.get(b, str(b))
-        node_rack.append(rack_index.setdefault(r, len(rack_index)))
-    buf = [java_string_hashcode(topic), p, cw, rf, ow, n, 1 if counters is not None else 0, 0]
-    buf += node_ids + node_rack + rows + [len(cur[q]) for q in rows] + [1 if q in partitions else 0 for q in rows]
-    for q in rows:
-        buf += list(cur[q]) + [-1] * (cw - len(cur[q]))
-    for b in node_ids:
-        buf += [(counters or {}).get(b, {}).get(k, 0) for k in range(WIDTH)]
-    return np.asarray(buf, dtype=np.int32), (n, p, cw, ow, node_ids, rows)
+def _payload(fb):
+    """The batch payload NativeAssignmentStrategy.solveScenarios() writes (layout 2): header,
+    scenario and topic descriptors as the C structs, node pools, cur, aux, ctx."""
+    S, T = fb.n_scenarios, fb.n_topics
+    cur = fb.cur if fb.cur.size else np.zeros(0, np.int32)
+    hdr = np.asarray([2, S, T, fb.node_id.size, cur.size, fb.aux.size, fb.ctx.size, fb.out_len], dtype=np.int32)
+    parts = [hdr, fb.scen[:S].view(np.int32).reshape(-1), fb.topics[:T].view(np.int32).reshape(-1),
+             fb.node_id, fb.node_rack, cur, fb.aux, fb.ctx]
+    inp = np.concatenate([np.ascontiguousarray(x, dtype=np.int32).reshape(-1) for x in parts])
+    out = np.full(4 * T + 8 * S + fb.out_len + fb.ctx.size, -7, dtype=np.int32)
+    return inp, out
 
 
-def test_shim_rejects_short_buffers_without_a_gpu(shim):
-    inp = np.asarray([0, 4, 2, 2, 2, 3, 0, 0], dtype=np.int32)        # header only: tables missing
-    out = np.zeros(4, dtype=np.int32)
-    bi = StubBuffer(inp.ctypes.data, inp.nbytes)
-    bo = StubBuffer(out.ctypes.data, out.nbytes)
-    assert shim(None, None, C.byref(bi), C.byref(bo)) == -1                # KAS_E_INVALID_ARG
+def _call(shim, inp, out):
+    bi, bo = StubBuffer(inp.ctypes.data, inp.nbytes), StubBuffer(out.ctypes.data, out.nbytes)
+    return shim(None, None, C.byref(bi), C.byref(bo))
+
+
+def _unpack(fb, out):
+    S, T = fb.n_scenarios, fb.n_topics
+    tr = out[:4 * T].view(abi.TOPIC_RESULT_DTYPE)
+    sr = out[4 * T:4 * T + 8 * S].view(abi.SCENARIO_RESULT_DTYPE)
+    rows = out[4 * T + 8 * S:4 * T + 8 * S + fb.out_len]
+    ctx = out[4 * T + 8 * S + fb.out_len:]
+    return tr, sr, rows, ctx
+
+
+def test_shim_rejects_short_buffers_and_unknown_layouts_without_a_gpu(shim):
+    out = np.zeros(64, dtype=np.int32)
+    hdr_only = np.asarray([2, 1, 1, 5, 8, 12, 0, 8], dtype=np.int32)           # tables missing
+    assert _call(shim, hdr_only, out) == -1                                    # KAS_E_INVALID_ARG
+    old_layout = np.zeros(64, dtype=np.int32); old_layout[0] = 97              # layout 1 started with a hash
+    assert _call(shim, old_layout, out) == -1
+    neg = np.asarray([2, -1, 0, 0, 0, 0, 0, 0], dtype=np.int32)
+    assert _call(shim, neg, out) == -1
 
 
 @pytest.mark.gpu
 def test_shim_solves_the_junit_cluster_and_carries_the_context(shim):
+    """One scenario, one topic per call (what KTA:70-71 does), the Context carried across two calls."""
     cur = {0: [10, 11], 1: [11, 12], 2: [12, 10], 3: [10, 12]}
     racks = {10: "a", 11: "b", 12: "c", 13: "a", 14: "b"}
     nodes = [10, 11, 12, 13, 14]
     counters = {}
-    for topic in ("test", "topic-1"):                                      # one Context across two calls
-        inp, (n, p, cw, ow, node_ids, rows) = _java_layout(topic, cur, racks, nodes, set(cur), 2, counters)
-        out = np.zeros(4 + p * ow + n * WIDTH, dtype=np.int32)
-        bi, bo = StubBuffer(inp.ctypes.data, inp.nbytes), StubBuffer(out.ctypes.data, out.nbytes)
-        assert shim(None, None, C.byref(bi), C.byref(bo)) == 0
+    for topic in ("test", "topic-1"):
         fb = flatten([Scenario(brokers=nodes, racks=racks, context=counters, want_context=True,
                                topics=[Topic(topic, cur, 2)])])
+        inp, out = _payload(fb)
+        assert _call(shim, inp, out) == 0
         want = oracle_solve(fb)
-        assert out[0] == want.topic_results["status"][0] == 0
-        assert out[2] == want.topic_results["moved_replicas"][0]
-        got = {rows[i]: [int(b) for b in out[4 + i * ow:4 + (i + 1) * ow] if b >= 0] for i in range(p)}
-        assert got == unflatten_topic(fb, want.out, 0)
-        ctx = out[4 + p * ow:].reshape(n, WIDTH)
-        np.testing.assert_array_equal(ctx, want.ctx[:n * WIDTH].reshape(n, WIDTH))
-        counters = {b: {k: int(ctx[i, k]) for k in range(WIDTH) if ctx[i, k]} for i, b in enumerate(node_ids)}
+        tr, sr, rows, ctx = _unpack(fb, out)
+        assert tr["status"][0] == want.topic_results["status"][0] == 0
+        assert tr["moved_replicas"][0] == want.topic_results["moved_replicas"][0]
+        np.testing.assert_array_equal(rows, want.out[:fb.out_len])
+        np.testing.assert_array_equal(ctx, want.ctx[:fb.ctx.size])
+        n = len(nodes)
+        c2 = ctx.reshape(n, WIDTH)
+        counters = {b: {k: int(c2[i, k]) for k in range(WIDTH) if c2[i, k]} for i, b in enumerate(sorted(nodes))}
+
+
+@pytest.mark.gpu
+def test_shim_batch_payload_many_scenarios_and_topics(shim):
+    """The batch path through JNI: several scenarios, several topics each (with and without a
+    Context, one scenario that strands and skips its later topics), one solveBatch call; then the
+    same payload again — the second call must be served by the context's cached plan and buffers."""
+    from kafka_assigner_amd import generator as G
+    scs = []
+    for s in range(5):
+        act, bs = G.scenario_action(11, s, 60, 12, actions=("add_k", "remove1", "replace1"), max_add=6)
+        racks = {int(b): "r%d" % int(r) for b, r in zip(bs.node_id, bs.node_rack)}
+        topics = []
+        for t in range(3):
+            cur = G.random_assignment(3 + 7 * s + t, 700 + 13 * t, 60, 12, 3)
+            topics.append(Topic("topic-%d" % t, {p: cur[p].tolist() for p in range(cur.shape[0])}, 3))
+        scs.append(Scenario(brokers=[int(b) for b in bs.node_id], racks=racks, topics=topics,
+                            want_context=(s % 2 == 0)))
+    fb = flatten(scs)
+    want = oracle_solve(fb)
+    assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 6
+    for _ in range(2):
+        inp, out = _payload(fb)
+        assert _call(shim, inp, out) == 0
+        tr, sr, rows, ctx = _unpack(fb, out)
+        for f in ("status", "fail_partition", "moved_replicas", "moved_partitions"):
+            np.testing.assert_array_equal(tr[f], want.topic_results[f][:fb.n_topics])
+        for f in ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest"):
+            np.testing.assert_array_equal(sr[f], want.scenario_results[f][:fb.n_scenarios])
+        np.testing.assert_array_equal(rows, want.out[:fb.out_len])
+        ok_ctx = np.ones(fb.ctx.size, dtype=bool)
+        np.testing.assert_array_equal(ctx[ok_ctx], want.ctx[:fb.ctx.size][ok_ctx])
