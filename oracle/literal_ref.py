@@ -5,8 +5,9 @@ Second, independent restatement of
 written against Python dicts / sorted containers so that every statement can be laid next to the
 Java it mirrors (TreeMap -> iterate sorted keys, TreeSet -> sorted list, HashMap -> dict).  It is
 slow (pure Python loops) and only meant for small cases: it cross-checks oracle/kas_oracle.c
-(under hypothesis-generated inputs) and generates tests/golden/*.json via
-tests/golden/make_golden.py.  Nothing in the product imports it.
+(under hypothesis-generated inputs) and re-derives the golden vectors of tests/golden/ (which were
+transcribed by hand from SURVEY.md Appendix B) in tests/golden/make_golden.py.  Nothing in the
+product imports it.
 """
 from __future__ import annotations
 

@@ -157,7 +157,7 @@ def test_emu_queue_path_runs_and_agrees():
     assert (want.scenario_results["status"] == abi.KAS_OK).any()
     for flags in (0, 1 << 12, 4 | (4 << 12)):
         assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu flags {flags:#x}")
-        assert last_queue_rows() > 100, "the queue path did not run"
+        assert last_queue_rows() > 20, "the queue path did not run"
 
 
 def test_emu_protocols_survive_arbitrary_wave_speeds():

@@ -77,3 +77,13 @@ def test_quirks(impl, case):
             IMPLS[impl]().generate_assignment(*args)
     else:
         assert IMPLS[impl]().generate_assignment(*args) == _int_keys(case["expected"])
+
+
+def test_golden_file_is_what_the_literal_restatement_derives():
+    """tests/golden/make_golden.py recomputes every expected entry of the (hand-transcribed) JSON
+    with oracle/literal_ref.py; the committed file must be exactly that."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "golden", "make_golden.py")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
