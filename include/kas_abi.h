@@ -257,12 +257,15 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_ROUND_ORDER   always run the tile-round preference ordering instead of the ticket form
  *   KAS_PLAN_WIDE_COUNTERS ticket form with 4 x uint16 counter rows even where three 10-bit counts
  *                          in one uint32 would do
+ *   KAS_PLAN_TWO_PASS_HIST rack-diverse fill with one histogram for the whole topic and a separate
+ *                          chunk-count pass over cur, instead of per-chunk histograms
  *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup of the fill kernel: 1, 2, 4 or 8
  *   KAS_PLAN_GROUPS(n)     scenarios per wavefront of the ticket-form order kernel: 1, 2 or 4
  *                          (0 = the plan's choice for either) */
 #define KAS_PLAN_GENERIC_FILL 1u
 #define KAS_PLAN_ROUND_ORDER  2u
 #define KAS_PLAN_WIDE_COUNTERS 4u
+#define KAS_PLAN_TWO_PASS_HIST 8u
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
 #define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);

@@ -187,8 +187,9 @@ struct kas_plan {
   int NW;                       // wavefronts per scenario workgroup of the fill kernel
   int G;                        // scenarios per wavefront of the ticket-form order kernel
   int tickets;                  // 1: ticket form of P5, 0: round form
+  int fused;                    // 1: per-chunk histograms in the fill (KasShape::fused_ok), see kas_plan_fused()
   uint32_t flags;               // KAS_FLAG_*
-  KasLds lds;
+  KasLds lds, lds_fused;
   int32_t n_scenarios, n_topics;
   // device copies owned by the plan
   kas_scenario_desc* d_scen;
@@ -313,8 +314,8 @@ static int upload(void** dst, const void* src, size_t bytes, hipStream_t st) {
 
 // opt every kernel this plan may launch into its dynamic LDS size
 static int kas_plan_set_kernels(kas_plan* p) {
-  KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, p->lds.total));
+  KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  p->fused && p->lds_fused.total > p->lds.total ? p->lds_fused.total : p->lds.total));
   if (p->Wc <= 3 && kas_order_ticket_for(p->Wc, p->G, 0))
     for (int pk = 0; pk < 2; ++pk)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
@@ -348,7 +349,8 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   p->NW = sh.NW;
   p->G = sh.G;
   p->tickets = sh.tickets_ok;
-  p->lds = sh.lds;
+  p->fused = sh.fused_ok;
+  p->lds = sh.lds; p->lds_fused = sh.lds_fused;
   p->flags = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
@@ -409,6 +411,11 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   return KAS_E_OK;
 }
 
+// per-chunk histograms: what the shape allows unless switched off (or the general fill is forced)
+static bool kas_plan_fused(const kas_plan* p) {
+  return p->fused && !(p->flags & (KAS_FLAG_TWO_PASS_HIST | KAS_FLAG_GENERIC_FILL));
+}
+
 // the launch decisions of kas_solve_device, in one place
 struct KasLaunchPlan {
   bool tickets, pairing, wide;
@@ -423,7 +430,7 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G && p->n_scenarios <= KAS_PAIRING_LIMIT;
   lp.wide = !lp.tickets && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
-  lp.fill_lds = (size_t)p->lds.total;
+  lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total);
   if (lp.tickets) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
     lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed);
@@ -453,7 +460,8 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
     snprintf(order, sizeof(order), "kas_order_round_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
              lp.order_block, lp.order_lds);
   const int len = snprintf(buf, (size_t)n, "kas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu + %s", p->Wc, p->NW,
-                           generic ? "sweeps" : "quota", lp.fill_grid, lp.fill_block, lp.fill_lds, order);
+                           generic ? "sweeps" : (kas_plan_fused(p) ? "quota, chunk histograms" : "quota"), lp.fill_grid,
+                           lp.fill_block, lp.fill_lds, order);
   return len < n ? len : n - 1;
 }
 
@@ -482,7 +490,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
-  a.flags = p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL);
+  a.flags = (p->flags & ~KAS_FLAG_FUSED_HIST) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
+            (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
   const int slot = p->timer_next;
@@ -563,6 +572,10 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
       return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at that many waves");
     p->lds = l;
     p->NW = nw;
+    KasShape tmp = sh;                                       // per-chunk histograms at the new workgroup width?
+    tmp.NW = nw; tmp.lds = l;
+    kas_choose_fused(&tmp);
+    p->fused = tmp.fused_ok; p->lds_fused = tmp.lds_fused;
   }
   if (g != 0 && g != p->G) {
     if (kas_order_ticket_lds(sh.n_max, g, 0) > KAS_LDS_LIMIT ||
@@ -573,7 +586,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  p->flags = flags & 0xffu;
+  p->flags = flags & 0xffu & ~KAS_FLAG_FUSED_HIST;
   return KAS_E_OK;
 }
 

@@ -43,6 +43,8 @@ struct KasLaunch {
 #define KAS_FLAG_GENERIC_FILL 1u   // always use the general sticky fill (testing / comparison)
 #define KAS_FLAG_ROUND_ORDER  2u   // always use the tile-round preference ordering (testing / comparison)
 #define KAS_FLAG_WIDE_COUNTERS 4u  // ticket form: always 4 x uint16 counter rows (testing / comparison)
+#define KAS_FLAG_TWO_PASS_HIST 8u  // rack-diverse fill: keep the separate chunk-count pass (testing / comparison)
+#define KAS_FLAG_FUSED_HIST   16u  // set by the launcher: per-chunk histograms, no chunk-count pass (KasShape::fused_ok)
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
@@ -87,17 +89,27 @@ KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_
 // int32 counter row stride of the round form: 3-wide rows are padded to one 16-byte LDS read
 KAS_ABI_FN int32_t kas_cnt_stride(int32_t W) { return W == 3 ? 4 : W; }
 
+// dwords per node of the fused histogram layout: NW x W uint16 per-chunk counts, later NW int32 quotas
+KAS_ABI_FN int32_t kas_fused_block_words(int32_t W, int32_t NW) {
+  const int32_t h = (NW * W + 1) / 2;
+  return h > NW ? h : NW;
+}
+
 // with_x = 0: no histogram / quota table (only the general sticky fill is possible then)
+//          1: hist[W][n] int32, then qc[NW][n] int32 over the same words (two passes over cur + a
+//             chunk-count pass)
+//          2: fused — node-major blocks of kas_fused_block_words() dwords: uint16 hist[n][NW][W]
+//             counted per chunk in the first pass, then int32 qc[n][NW] (no chunk-count pass)
 KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int32_t idmap_entries,
                                          int32_t need_bsearch, int32_t with_x) {
   KasLds L;
   int64_t n = n_max > 0 ? n_max : 1;
   int64_t o = 0;
-  const int64_t xr = with_x ? (W > NW ? W : NW) : 0;
+  const int64_t xr = with_x == 2 ? kas_fused_block_words(W, NW) : (with_x ? (W > NW ? W : NW) : 0);
   L.off_x = (int32_t)o;     o = kas_align16(o + 4 * n * xr);
   // lists wider than the workgroup has waves leave histogram rows NW..W-1 unused once the quota
   // pass has consumed them: load[] (written by that pass, per node, after its reads) lives there
-  if (with_x && W > NW) L.off_load = L.off_x + (int32_t)(4 * n * NW);
+  if (with_x == 1 && W > NW) L.off_load = L.off_x + (int32_t)(4 * n * NW);
   else { L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n); }
   L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
   L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
@@ -157,6 +169,9 @@ struct KasShape {
   int32_t with_x = 1;                 // LDS has room for the histogram / quota table of the fast fill
   int32_t packed_ok = 1;              // every scenario's ticket bound fits 10-bit counter fields
   int32_t wide_ok = 0;                // lists 4 or 5 wide and the wide ticket form is applicable
+  int32_t fused_ok = 0;               // rack-diverse fill with per-chunk histograms (no chunk-count pass)
+  KasLds lds_fused{};                 // its LDS carve-up (valid when fused_ok)
+  int32_t max_partitions = 0;         // largest topic of the batch
   std::vector<int64_t> accmask_off;   // per scenario, in 64-bit words
   int64_t accmask_words = 0;
   std::vector<int64_t> orph_off;      // per scenario, in int32 elements
@@ -167,6 +182,22 @@ struct KasShape {
   int64_t cur_need = 0, out_need = 0, aux_need = 0, ctx_need = 0;  // minimum pool lengths
   KasLds lds{};
 };
+
+// Fused histogram layout of the rack-diverse fill (kas_fill_lds_layout with_x = 2): lists up to 3 wide
+// (the instantiated variants), more than one chunk, a chunk's rows countable in uint16, and the larger
+// table must not cost a resident workgroup (4 per CU is what the kernel's 128 VGPRs allow anyway).
+static inline void kas_choose_fused(KasShape* s) {
+  s->fused_ok = 0;
+  if (!s->with_x || s->Wc > 3 || s->NW < 2) return;
+  const int64_t tiles = ((int64_t)s->max_partitions + 63) / 64;
+  if ((tiles / s->NW + 2) * 64 > 65535) return;
+  const KasLds f = kas_fill_lds_layout(s->n_max, s->Wc, s->NW, s->idmap_entries, s->need_bsearch, 2);
+  if (f.total > KAS_LDS_LIMIT) return;
+  const int per_cu_fused = KAS_LDS_LIMIT / f.total, per_cu_now = KAS_LDS_LIMIT / s->lds.total;
+  if (per_cu_fused < (per_cu_now < 4 ? per_cu_now : 4)) return;
+  s->fused_ok = 1;
+  s->lds_fused = f;
+}
 
 // Validate descriptors and derive everything a launch needs.  Returns KAS_E_* and fills err.
 static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::string* err,
@@ -223,6 +254,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
         return fail(KAS_E_UNSUPPORTED, where + "rf exceeds out_width");
       if (td.cur_off < 0 || td.out_off < 0) return fail(KAS_E_INVALID_ARG, where + "negative pool offset");
       if (td.out_width > s.W) s.W = td.out_width;
+      if (td.n_partitions > s.max_partitions) s.max_partitions = td.n_partitions;
       int64_t P = td.n_partitions;
       int64_t ce = td.cur_off + P * td.cur_width, oe = td.out_off + P * td.out_width;
       if (ce > s.cur_need) s.cur_need = ce;
@@ -273,6 +305,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     err_total = l.total;
     if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = 1; s.with_x = 0; err_total = 0; }
   }
+  kas_choose_fused(&s);
   if (err_total == 0 && kas_order_round_lds(s.n_max, s.Wc) > KAS_LDS_LIMIT)
     err_total = kas_order_round_lds(s.n_max, s.Wc);
   if (err_total)

@@ -685,6 +685,91 @@ KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm
   return viol;
 }
 
+template <int W, int NW>
+constexpr int fused_block_words() { return ((NW * W + 1) / 2) > NW ? ((NW * W + 1) / 2) : NW; }   // == kas_fused_block_words
+
+// A1, fused form: wave w scans chunk w (the rows pass B will walk) and counts per chunk: x is node-major,
+// kas_fused_block_words() dwords per node holding uint16 hist[n][w][r] (a chunk has < 65536 rows: the
+// plan checks), so that the quota pass below also knows every chunk's share and no second counting
+// pass over cur is needed.  Returns this lane's "not rack-diverse" verdict.
+template <int W, int NW, bool DIRECT>
+KAS_DEV bool fill_pass_a_fused(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
+  constexpr int D = KAS_TILES_AHEAD;
+  constexpr int BW = fused_block_words<W, NW>();
+  const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
+  bool viol = false;
+  for_tile_batches<W>(T, t0, 1, t1, [&](const int32_t (&ids)[D][W], const int32_t (&len)[D]) {
+    int32_t idx[D][W], rk[D][W];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup_as<DIRECT>(L, nm, ids[d][r]) : -1;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < W; ++r)
+        rk[d][r] = idx[d][r] >= 0 ? (int32_t)L.rack[idx[d][r]] : -1 - r;   // invalid: never equal
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int r = 1; r < W; ++r)
+#pragma unroll
+        for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[d][r] == rk[d][r2];
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        const int32_t cell = wave * W + r;                   // uint16 cell of the node's block
+        if (idx[d][r] >= 0) kasw::lds_atomic_add(&L.x[idx[d][r] * BW + (cell >> 1)], 1 << (16 * (cell & 1)));
+      }
+    }
+  });
+  return viol;
+}
+
+// Q + chunk prefix, fused form: per node the sweep totals over all chunks -> r*, quota, load as in
+// fill_quota; then, from the per-chunk counts of sweep r*, the quota left when chunk w starts, written
+// over the first NW dwords of the node's own block (all its counts were read first).
+template <int W, int NW>
+KAS_DEV void fill_quota_fused(const LdsView& L, const TopicView& T, int32_t tid) {
+  const int32_t N = T.N;
+  constexpr int BW = fused_block_words<W, NW>();
+  for (int32_t n = tid; n < N; n += 64 * NW) {
+    uint32_t words[BW];
+#pragma unroll
+    for (int k = 0; k < BW; ++k) words[k] = (uint32_t)L.x[n * BW + k];
+    int32_t h[NW][W], tot[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) tot[r] = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        const int cell = w * W + r;
+        h[w][r] = (int32_t)((words[cell >> 1] >> (16 * (cell & 1))) & 0xffffu);
+        tot[r] += h[w][r];
+      }
+    int32_t cum = 0, rs = W, q = 0;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      const int32_t c = tot[r];
+      const bool sat = rs == W && c > T.cap - cum;          // cum + c > cap, overflow-safe
+      q = sat ? T.cap - cum : q;
+      cum = rs == W ? (sat ? T.cap : cum + c) : cum;
+      rs = sat ? r : rs;
+    }
+    L.load[n] = cum;
+    L.qrs[n] = (int32_t)(((uint32_t)rs << 28) | (uint32_t)q);
+    int32_t rem = q;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      int32_t c = 0;
+#pragma unroll
+      for (int r = 0; r < W; ++r) c = rs == r ? h[w][r] : c;
+      L.x[n * BW + w] = rem;
+      rem -= c;
+    }
+  }
+}
+
 // Q: load[n] <- replicas the node keeps, qrs[n] <- r* << 28 | quota in sweep r*; the chunk rows
 // of x (which alias the histogram rows of the same node) are cleared, or set to the quota when
 // there is only one chunk.
@@ -749,14 +834,16 @@ KAS_DEV void fill_chunk_prefix(const LdsView& L, const TopicView& T, int32_t tid
 }
 
 // B + P3 over chunk `wave`; orphans go to the chunk's list; returns the number of orphans
-template <int W, int NW, bool DIRECT>
+// (FUSED: the quota words are x[n * BW + wave] of the node-major layout, else x[wave * N + n])
+template <int W, int NW, bool DIRECT, bool FUSED = false>
 KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave,
                             int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   const uint64_t lt = kasw::lanemask_lt();
   const int32_t N = T.N;
   const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
-  int32_t* qc = L.x + wave * N;
+  constexpr int QS = FUSED ? fused_block_words<W, NW>() : 1;     // stride of a node's quota word
+  int32_t* qc = FUSED ? L.x + wave : L.x + wave * N;
   int32_t* olist = T.orph + ((int64_t)t0 << 6);
   int32_t ocount = 0;
   for_tiles<W>(T, t0, 1, t1, [&](int32_t tile, const int32_t (&ids)[W], int32_t len) {
@@ -770,18 +857,18 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
       const int32_t rs = (int32_t)((uint32_t)L.qrs[nn[r]] >> 28);
       sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
       counting |= (idx[r] >= 0 && r == rs) ? (1u << r) : 0u;
-      before[r] = qc[nn[r]];                                // quota left before this tile
+      before[r] = qc[nn[r] * QS];                           // quota left before this tile
     }
     uint32_t accbits = sure;
     if (kasw::ballot(counting != 0u) != 0) {
       kasw::lockstep();                                     // every lane saw the pre-tile quota
 #pragma unroll
-      for (int r = 0; r < W; ++r) if ((counting >> r) & 1u) kasw::lds_atomic_add(&qc[nn[r]], -1);
+      for (int r = 0; r < W; ++r) if ((counting >> r) & 1u) kasw::lds_atomic_add(&qc[nn[r] * QS], -1);
       kasw::lockstep();
       uint32_t contested = 0;
 #pragma unroll
       for (int r = 0; r < W; ++r) {
-        const int32_t after = qc[nn[r]];
+        const int32_t after = qc[nn[r] * QS];
         const bool cnt = (counting >> r) & 1u;
         accbits |= (cnt && after >= 0) ? (1u << r) : 0u;
         contested |= (cnt && before[r] > 0 && after < 0) ? (1u << r) : 0u;
@@ -1077,8 +1164,10 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   // (a topic without rows takes the general form: the row stream of the fast form re-reads the last
   // row for lanes past the end and there is no row to read)
   const bool try_fast = P > 0 && T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && cap >= 0 && cap < (1 << 28);
+  // per-chunk histograms (no chunk-count pass) when the launcher says the layout fits (lists <= 3 wide)
+  const bool fused = W <= 3 && NW > 1 && (a.flags & KAS_FLAG_FUSED_HIST) != 0u;
   if (try_fast)
-    for (int32_t i = tid; i < N * W; i += NT) L.x[i] = 0;
+    for (int32_t i = tid; i < N * (fused ? fused_block_words<W, NW>() : W); i += NT) L.x[i] = 0;
   kasw::sync();
   if (nm.range != 0u)
     for (int32_t i = tid; i < N; i += NT) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
@@ -1088,7 +1177,13 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
   bool fast = false;
   if (try_fast) {
-    const bool viol = nm.range != 0u ? fill_pass_a<W, NW, true>(L, T, nm, wave) : fill_pass_a<W, NW, false>(L, T, nm, wave);
+    bool viol;
+    if constexpr (W <= 3 && NW > 1) {
+      if (fused) viol = nm.range != 0u ? fill_pass_a_fused<W, NW, true>(L, T, nm, wave) : fill_pass_a_fused<W, NW, false>(L, T, nm, wave);
+      else viol = nm.range != 0u ? fill_pass_a<W, NW, true>(L, T, nm, wave) : fill_pass_a<W, NW, false>(L, T, nm, wave);
+    } else {
+      viol = nm.range != 0u ? fill_pass_a<W, NW, true>(L, T, nm, wave) : fill_pass_a<W, NW, false>(L, T, nm, wave);
+    }
     if (kasw::ballot(viol) != 0 && lane == 0) L.ctl[KAS_CTL_VIOL] = 1;
     kasw::sync();
     fast = L.ctl[KAS_CTL_VIOL] == 0;
@@ -1100,18 +1195,32 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   }
   int32_t moved_r = 0, moved_p = 0;
   if (fast) {
-    fill_quota<W, NW>(L, T, tid);
-    kasw::sync();
-    if (NW > 1) {
-      if (nm.range != 0u) fill_chunk_count<W, NW, true>(L, T, nm, wave);
-      else fill_chunk_count<W, NW, false>(L, T, nm, wave);
-      kasw::sync();
-      fill_chunk_prefix<NW>(L, T, tid);
-      kasw::sync();
+    int32_t oc = 0;
+    bool done = false;
+    if constexpr (W <= 3 && NW > 1) {
+      if (fused) {                                          // workgroup-uniform
+        fill_quota_fused<W, NW>(L, T, tid);
+        kasw::sync();
+        { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
+        oc = nm.range != 0u ? fill_pass_b<W, NW, true, true>(L, T, nm, wave, moved_r, moved_p, st)
+                            : fill_pass_b<W, NW, false, true>(L, T, nm, wave, moved_r, moved_p, st);
+        done = true;
+      }
     }
-    { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
-    const int32_t oc = nm.range != 0u ? fill_pass_b<W, NW, true>(L, T, nm, wave, moved_r, moved_p, st)
-                                      : fill_pass_b<W, NW, false>(L, T, nm, wave, moved_r, moved_p, st);
+    if (!done) {
+      fill_quota<W, NW>(L, T, tid);
+      kasw::sync();
+      if (NW > 1) {
+        if (nm.range != 0u) fill_chunk_count<W, NW, true>(L, T, nm, wave);
+        else fill_chunk_count<W, NW, false>(L, T, nm, wave);
+        kasw::sync();
+        fill_chunk_prefix<NW>(L, T, tid);
+        kasw::sync();
+      }
+      { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
+      oc = nm.range != 0u ? fill_pass_b<W, NW, true>(L, T, nm, wave, moved_r, moved_p, st)
+                          : fill_pass_b<W, NW, false>(L, T, nm, wave, moved_r, moved_p, st);
+    }
     if (lane == 0) L.ctl[KAS_CTL_OC + wave] = oc;
   } else if (wave == 0) {
     fill_generic_sweeps<W>(L, T, nm, accmask, st);
@@ -1185,12 +1294,12 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
   const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch,
-                                         (a.flags & KAS_FLAG_GENERIC_FILL) ? 0 : 1);
+                                         (a.flags & KAS_FLAG_GENERIC_FILL) ? 0 : ((a.flags & KAS_FLAG_FUSED_HIST) ? 2 : 1));
   LdsView L;
   L.x = (int32_t*)(lds_raw + lay.off_x);
   // (wide lists: load[] takes the place of histogram row NW of THIS scenario's node count once the
   // quota pass has consumed it, see kas_fill_lds_layout)
-  L.load = (W > NW && !(a.flags & KAS_FLAG_GENERIC_FILL)) ? L.x + NW * N : (int32_t*)(lds_raw + lay.off_load);
+  L.load = (W > NW && !(a.flags & (KAS_FLAG_GENERIC_FILL | KAS_FLAG_FUSED_HIST))) ? L.x + NW * N : (int32_t*)(lds_raw + lay.off_load);
   L.qrs = (int32_t*)(lds_raw + lay.off_qrs);
   L.rack = (int16_t*)(lds_raw + lay.off_rack);
   L.live = (int16_t*)(lds_raw + lay.off_live);

@@ -185,6 +185,7 @@ run_fn rounds_for(int Wc) {
 // rows the ticket-form solver decided inside queues during the last kas_emu_solve_batch (summed
 // over scenarios): lets a CPU test assert that the queue path ran, not only the one-row path
 static long g_last_queue_rows = 0;
+static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
 // 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice)
 extern "C" __attribute__((visibility("default")))
@@ -200,7 +201,8 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   const bool wide = sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER);
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
-  size_t lds_bytes = (size_t)sh.lds.total;
+  const bool fused = sh.fused_ok && !(flags & KAS_FLAG_TWO_PASS_HIST) && !(flags & KAS_FLAG_GENERIC_FILL);
+  size_t lds_bytes = (size_t)(fused ? sh.lds_fused.total : sh.lds.total);
   if ((size_t)kas_order_round_lds(sh.n_max, sh.Wc) > lds_bytes) lds_bytes = (size_t)kas_order_round_lds(sh.n_max, sh.Wc);
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
   if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
@@ -213,11 +215,13 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   std::vector<int64_t> stats((size_t)KAS_STATS_PER_SCENARIO * (size_t)(b->n_scenarios + 1), 0);
   a.stats = stats.data();
   g_last_queue_rows = 0;
+  g_last_fused = fused ? 1 : 0;
   a.orph = orph.data(); a.orph_off = sh.orph_off.data();
   std::vector<int32_t> perm((size_t)b->n_scenarios + 1, -1);
   a.perm = nullptr;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
-  a.need_bsearch = sh.need_bsearch; a.flags = (flags & 0xffu) | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL);
+  a.need_bsearch = sh.need_bsearch;
+  a.flags = (flags & 0xffu & ~KAS_FLAG_FUSED_HIST) | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u);
   auto bad = [&](const char* what, int32_t s) {
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;
@@ -292,3 +296,6 @@ long kas_emu_collectives(void) { return kasw::g_emu.collectives; }
 
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_queue_rows(void) { return g_last_queue_rows; }
+
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_fused(void) { return g_last_fused; }

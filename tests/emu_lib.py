@@ -73,6 +73,13 @@ def lib():
     return _LIB
 
 
+def last_fused() -> bool:
+    """The last emu_solve ran the rack-diverse fill with per-chunk histograms (no chunk-count pass)."""
+    L = lib()
+    L.kas_emu_last_fused.restype = C.c_int
+    return bool(L.kas_emu_last_fused())
+
+
 def last_queue_rows() -> int:
     """Rows the ticket-form solver decided inside queues during the last emu_solve."""
     return int(lib().kas_emu_last_queue_rows())

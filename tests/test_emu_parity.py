@@ -237,3 +237,28 @@ def test_emu_wide_lists_multi_topic_and_mixed_widths():
     assert (want.topic_results["status"][3:6] == abi.KAS_OK).all()      # one scenario runs all three widths
     assert_same_outputs(fb, want, emu_solve(fb), "emu wide multi-topic")
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu wide multi-topic, round form")
+
+
+def test_emu_fill_with_per_chunk_histograms_and_with_the_chunk_count_pass():
+    """The rack-diverse fill counts its sweep histograms per chunk in the first pass over cur when the
+    LDS allows (lists <= 3 wide): no second counting pass.  Both forms against the oracle, at every
+    workgroup width that has chunks, with quota edges inside tiles (small clusters) and sparse ids."""
+    from emu_lib import last_fused
+    for P, N, R, RF, acts in ((9000, 90, 9, 3, G.ACTIONS), (5000, 40, 8, 2, ("add_k", "remove1")),
+                              (4000, 33, 11, 3, ("mixed", "replace1"))):
+        fb = _batch(555, 4, P, N, R, RF, acts)
+        want = oracle_solve(fb)
+        assert (want.scenario_results["status"] == abi.KAS_OK).any()
+        for nw in (0, 2, 8):
+            assert_same_outputs(fb, want, emu_solve(fb, flags=nw << 8), f"emu per-chunk histograms, waves {nw}")
+            assert last_fused()
+            assert_same_outputs(fb, want, emu_solve(fb, flags=8 | (nw << 8)), f"emu chunk-count pass, waves {nw}")
+            assert not last_fused()
+        assert_same_outputs(fb, want, emu_solve(fb, flags=1 << 8), "emu one wave: nothing to fuse")
+        assert not last_fused()
+    cur = G.random_assignment(5, 2500, 20, 5, 3).astype(np.int64) * 100003 + 7            # sparse ids: binary search
+    ids = (np.arange(20, dtype=np.int64) * 100003 + 7).astype(np.int32)[None, :]
+    racks = (np.arange(20) % 5).astype(np.int32)[None, :]
+    fb = uniform_batch(cur.astype(np.int32)[None], ids[:, :19], racks[:, :19], 3)
+    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu per-chunk histograms, sparse ids")
+    assert last_fused()
