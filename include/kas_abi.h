@@ -259,7 +259,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *                          in one uint32 would do
  *   KAS_PLAN_TWO_PASS_HIST rack-diverse fill with one histogram for the whole topic and a separate
  *                          chunk-count pass over cur, instead of per-chunk histograms
- *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup of the fill kernel: 1, 2, 4 or 8
+ *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup of the fill kernel: 1, 2 or 4
  *   KAS_PLAN_GROUPS(n)     scenarios per wavefront of the ticket-form order kernel: 1, 2 or 4
  *                          (0 = the plan's choice for either) */
 #define KAS_PLAN_GENERIC_FILL 1u

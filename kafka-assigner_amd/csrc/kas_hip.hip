@@ -104,10 +104,9 @@ static kas_kernel_fn kas_fill_for_w(int Wc) {
   }
 }
 static kas_kernel_fn kas_fill_for(int Wc, int NW) {
-  switch (NW) {
-    case 1: return kas_fill_for_w<1>(Wc);
-    case 2: return kas_fill_for_w<2>(Wc);
-    case 8: return kas_fill_for_w<8>(Wc);
+  switch (NW) {                            // (8 wavefronts per scenario: only on the CPU emulator — each
+    case 1: return kas_fill_for_w<1>(Wc);   // instantiated width costs a minute of build time and 8 was
+    case 2: return kas_fill_for_w<2>(Wc);   // never the faster choice on the GPU)
     default: return kas_fill_for_w<4>(Wc);
   }
 }
@@ -559,8 +558,8 @@ int kas_plan_phase_times_us(kas_plan* p, double* fill_us, double* order_us, int*
 int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   if (!p) return set_error(KAS_E_INVALID_ARG, "plan == NULL");
   const int nw = (int)((flags >> 8) & 0xfu), g = (int)((flags >> 12) & 0xfu);
-  if (nw != 0 && nw != 1 && nw != 2 && nw != 4 && nw != 8)
-    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_WAVES: waves per scenario must be 1, 2, 4 or 8");
+  if (nw != 0 && nw != 1 && nw != 2 && nw != 4)
+    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_WAVES: waves per scenario must be 1, 2 or 4");
   if (g != 0 && g != 1 && g != 2 && g != 4)
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
   if (!kas_minimal_ok(p->Wc, nw ? nw : p->NW, g ? g : p->G))

@@ -1,0 +1,36 @@
+#!/bin/bash
+# round 2 evidence run with the production library: parity tests, smoke, the bench line, the small
+# BASELINE configs, kernel traces and PMC traffic passes.  Summaries are copied into profiles/ by
+# scripts/collect_profiles.py.
+set -x
+O=gpurun_out/${1:-r2k}
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
+tail -9 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log; tail -2 $O/smoke.log
+timeout 900 python bench.py --stats $O/stats_default.json > $O/bench_default.log 2>&1; echo "exit $?" >> $O/bench_default.log
+tail -2 $O/bench_default.log | cut -c1-300
+timeout 300 python bench.py --no-cpu --check 0 --no-extras --steps 10 --in-flight 1 --stats $O/stats_one_batch_in_flight.json > $O/bench_one_batch_in_flight.log 2>&1
+# BASELINE configs[1]: single scenario, 10k partitions x 100 brokers x 10 racks, RF 3 (latency)
+timeout 300 python bench.py --no-cpu --no-extras --check 1 --scenarios 1 --partitions 10000 --brokers 100 --racks 10 --actions remove1 --in-flight 1 --steps 50 --warmup 5 > $O/bench_config2_single_scenario.log 2>&1
+tail -1 $O/bench_config2_single_scenario.log | cut -c1-200
+# BASELINE configs[3] per-GPU share: 8000 scenarios in one batch (64k / 8 GPUs), add brokers 1000-1049
+timeout 900 python bench.py --no-cpu --no-extras --check 64 --scenarios 8000 --actions add50 --in-flight 2 --steps 4 --warmup 1 > $O/bench_config4_8000_scenarios_add50.log 2>&1
+tail -1 $O/bench_config4_8000_scenarios_add50.log | cut -c1-200
+# BASELINE configs[4]: 1M x 5k x RF 5, rack map on / off, one scenario and one GPU's 8
+for act in c5 c5_norack; do
+  timeout 600 python bench.py --no-cpu --no-extras --check 1 --scenarios 1 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions $act --in-flight 1 --steps 6 --warmup 1 --stats $O/stats_config5_$act.json > $O/bench_config5_$act.log 2>&1
+  echo "$act $(grep -o '"in_flight_launch": {[^}]*' $O/bench_config5_$act.log | cut -c1-110)"
+done
+timeout 600 python bench.py --no-cpu --no-extras --check 2 --scenarios 8 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 5 --warmup 1 > $O/bench_config5_x8.log 2>&1
+tail -1 $O/bench_config5_x8.log | cut -c1-200
+timeout 300 python scripts/host_path_rate.py 200 > $O/host_path_rate.log 2>&1; tail -1 $O/host_path_rate.log
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_trace_one_batch_in_flight -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --check 0 --no-extras --in-flight 1 --steps 20 > $GRAFT_REPO_ROOT/$O/prof_trace_f1.log 2>&1; echo "trace exit $?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_trace_default -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --check 0 --no-extras > $GRAFT_REPO_ROOT/$O/prof_trace_default.log 2>&1; echo "trace exit $?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_fetch -o fetch -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --check 0 --no-extras --steps 2 --warmup 1 --in-flight 1 > $GRAFT_REPO_ROOT/$O/prof_fetch.log 2>&1; echo "fetch exit $?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_write -o write -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --check 0 --no-extras --steps 2 --warmup 1 --in-flight 1 > $GRAFT_REPO_ROOT/$O/prof_write.log 2>&1; echo "write exit $?"
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_sq1 -o sq -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --check 0 --no-extras --steps 3 --warmup 1 --in-flight 1 > $GRAFT_REPO_ROOT/$O/prof_sq1.log 2>&1; echo "sq1 exit $?"
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_sq2 -o sq -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --check 0 --no-extras --steps 3 --warmup 1 --in-flight 1 > $GRAFT_REPO_ROOT/$O/prof_sq2.log 2>&1; echo "sq2 exit $?"
+cd $GRAFT_REPO_ROOT

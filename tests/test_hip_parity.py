@@ -62,7 +62,8 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip round order")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 4), "hip 4 x uint16 counter rows")
-    for nw, g in ((1, 1), (2, 2), (4, 4), (8, 1)):
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 8), "hip chunk-count pass instead of per-chunk histograms")
+    for nw, g in ((1, 1), (2, 2), (4, 4), (2, 1)):
         assert_same_outputs(fb, want, native.solve_host_with_flags(fb, (nw << 8) | (g << 12)),
                             f"hip {nw} waves, {g} scenarios per wave")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 3 | (1 << 8)), "hip generic+round, 1 wave")
@@ -99,7 +100,8 @@ def test_config3_shape_full_size_scenarios():
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 4), "C3 4 x uint16 counter rows")
-    for nw, g in ((1, 1), (2, 2), (8, 2)):     # 4 scenarios per wave do not fit 16-bit LDS offsets at N = 1000
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 8), "C3 chunk-count pass instead of per-chunk histograms")
+    for nw, g in ((1, 1), (2, 2), (4, 1)):     # 4 scenarios per wave do not fit 16-bit LDS offsets at N = 1000
         assert_same_outputs(fb, want, native.solve_host_with_flags(fb, (nw << 8) | (g << 12)),
                             f"C3 {nw} waves, {g} scenarios per wave")
     assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 4
