@@ -155,7 +155,7 @@ def test_one_plan_orders_its_solves_across_streams():
     want = oracle_solve(fb, threads=0)
     ctx = native.default_context()
     plan = native.Plan(ctx, fb)
-    assert "kas_fill_kernel<3,4>[quota]" in plan.describe() and "kas_order_ticket_kernel<3,2,true>" in plan.describe()
+    assert "kas_fill_kernel<3,4>[quota, chunk histograms]" in plan.describe() and "kas_order_ticket_kernel<3,2,true>" in plan.describe()
     dev = torch.device("cuda", ctx.device)
     d_cur = torch.from_numpy(fb.cur).to(dev)
     streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
