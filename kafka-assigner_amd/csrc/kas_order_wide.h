@@ -364,6 +364,13 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           pf_end = true;
         }
       }
+      if (kasw::ballot(staging) == 0) {                     // nothing to stage: skip the ticket work, poll again
+        if (kasw::ballot(!endl) == 0) break;
+        if (watchdog_poll(wd, false, wd_idle)) break;
+        f_idle += 1;
+        kasw::nap<KAS_IDLE_NAP>();
+        continue;
+      }
       // ---- holders ascending (Sets.newTreeSet, KAS:228); empty cells sort last
 #pragma unroll
       for (int pass = 0; pass < W; ++pass) {
@@ -410,9 +417,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;
-      const bool progress = kasw::ballot(staging) != 0;
-      if (watchdog_poll(wd, progress, wd_idle)) break;
-      if (!progress) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
+      if (watchdog_poll(wd, true, wd_idle)) break;
     }
     if (a.stats && have_s && lane == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;

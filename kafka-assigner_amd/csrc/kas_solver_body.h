@@ -1855,6 +1855,16 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           pf_end = true;
         }
       }
+      // nothing to stage for either group (ring full or rows still on their way): skip the ticket work
+      // of this iteration — a third of the iterations, and their instructions are issue slots taken
+      // from the solvers sharing the CU — and poll again after a nap
+      if (kasw::ballot(staging) == 0) {
+        if (kasw::ballot(!endl) == 0) break;
+        if (watchdog_poll(wd, false, wd_idle)) break;
+        f_idle += 1;
+        kasw::nap<KAS_IDLE_NAP>();
+        continue;
+      }
       // ---- holders ascending (Sets.newTreeSet, KAS:228); empty cells (-1) sort last
       const uint32_t ab_lo = c0 < c1 ? c0 : c1, ab_hi = c0 < c1 ? c1 : c0;
       const uint32_t s0 = ab_lo < c2 ? ab_lo : c2;
@@ -1912,9 +1922,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;
-      const bool progress = kasw::ballot(staging) != 0;
-      if (watchdog_poll(wd, progress, wd_idle)) break;
-      if (!progress) { f_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
+      if (watchdog_poll(wd, true, wd_idle)) break;
     }
     if (a.stats && have_s && li == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
