@@ -17,18 +17,17 @@ from test_emu_parity import _batch
 
 def test_bounded_build_without_a_fault_equals_the_oracle():
     solve = variant_solver("bounded", ["-DKAS_SPIN_BOUND=200000"])
-    for P, N, R, RF, acts in ((3000, 60, 6, 3, G.ACTIONS), (8000, 80, 8, 3, ("replace1", "add_k")),
-                              (3000, 120, 12, 5, G.ACTIONS)):
-        fb = _batch(77, 4, P, N, R, RF, acts)
+    for P, N, R, RF, acts in ((3000, 60, 6, 3, G.ACTIONS), (2000, 80, 12, 5, G.ACTIONS)):
+        fb = _batch(77, 3, P, N, R, RF, acts)
         want = oracle_solve(fb)
         assert_same_outputs(fb, want, solve(fb), "bounded build")
         assert not (want.scenario_results["status"] == abi.KAS_FAIL_WATCHDOG).any()
 
 
 def test_a_stalled_staging_wavefront_is_reported_not_hung():
-    solve = variant_solver("stalled", ["-DKAS_SPIN_BOUND=3000", "-DKAS_TEST_STALL_AFTER=2"])
+    solve = variant_solver("stalled", ["-DKAS_SPIN_BOUND=1500", "-DKAS_TEST_STALL_AFTER=2"])
     for RF in (3, 5):                                   # order_tickets<3, ...> and order_tickets_wide<5>
-        fb = _batch(78, 4, 3000, 120, 12, RF, ("add_k", "remove1"))
+        fb = _batch(78, 3, 1500, 120, 12, RF, ("add_k", "remove1"))
         want = oracle_solve(fb)
         got = solve(fb)                                  # returns: that is the point
         ok = want.scenario_results["status"] == abi.KAS_OK
