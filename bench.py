@@ -421,8 +421,9 @@ def run_rank(args) -> int:
 
     # ---- the literal SURVEY 8(d) C3 action mix (with 'replace 1'), same cur tables ---------------
     literal = None
-    if (not args.stub and not args.no_extras and not args.actions and
-            (S, args.partitions, args.brokers, args.racks, args.rf) == C3_SHAPE):
+    # (the condition must not depend on the rank: every rank takes part in the timed collectives)
+    if (not args.stub and not args.no_extras and not args.actions and args.scaling == "weak" and
+            (args.scenarios, args.partitions, args.brokers, args.racks, args.rf) == C3_SHAPE):
         run.set_actions(G.ACTIONS)
         n_lit = max(run.n_slots, min(args.steps, 24))
         el2 = timed(n_lit, run.n_slots)

@@ -49,13 +49,9 @@ __global__ __launch_bounds__(192) void kas_order_ticket_kernel(KasLaunch a) {
   kas::order_tickets<W, G, PK>(a, (int32_t)blockIdx.x * G, kas_lds);
 }
 
-__global__ __launch_bounds__(256) void kas_order_permutation_kernel(KasLaunch a) {
+__global__ __launch_bounds__(64 * KAS_PERM_WAVES) void kas_order_permutation_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  int32_t* keys = (int32_t*)kas_lds;                        // [n_scenarios]: every workgroup ranks against all
-  for (int32_t j = (int32_t)threadIdx.x; j < a.n_scenarios; j += (int32_t)blockDim.x)
-    keys[j] = a.scenario_results[j].moved_replicas;
-  __syncthreads();
-  kas::order_permutation(a, keys, (int32_t)(blockIdx.x * blockDim.x + threadIdx.x), (int32_t)(gridDim.x * blockDim.x));
+  kas::order_permutation(a, kas_lds);
 }
 
 template <int W>
@@ -426,7 +422,7 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   KasLaunchPlan lp;
   lp.tickets = p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
   lp.packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
-  lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G && p->n_scenarios <= KAS_PAIRING_LIMIT;
+  lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G;
   lp.wide = !lp.tickets && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
   lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total);
@@ -502,8 +498,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   if (lp.pairing) {
     // scenarios that share a solver wavefront should have P5 chains of similar length
     a.perm = p->d_perm;
-    hipLaunchKernelGGL(kas_order_permutation_kernel, dim3((unsigned)((p->n_scenarios + 255) / 256)), dim3(256),
-                       sizeof(int32_t) * (size_t)p->n_scenarios, st, a);
+    hipLaunchKernelGGL(kas_order_permutation_kernel, dim3(1), dim3(64 * KAS_PERM_WAVES),
+                       sizeof(int32_t) * (size_t)(KAS_PERM_BINS + 8), st, a);
     KAS_HIP_TRY(hipGetLastError());
   }
   if (tickets)

@@ -81,7 +81,6 @@ struct KasLds {
 #define KAS_CTL_OC 8          // [NW] orphans found per chunk
 #define KAS_CTL_WATCHDOG 7    // debug builds (KAS_SPIN_BOUND): a P4 wait ran past its bound
 
-#define KAS_PAIRING_LIMIT 8192   // batches up to this many scenarios are ordered by chain length for P5
 #define KAS_TICKET_LIMIT 65535  // tickets (= 16-bit counters of the order kernel) stay below this
 
 KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_t)15); }

@@ -1389,19 +1389,58 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 // length of a scenario's P5 dependency chain, known from the fill kernel's movement count).  The
 // order kernel takes scenarios in this order, so the G scenarios sharing a solver wavefront have
 // chains of similar length (the wavefront lasts as long as its longest chain) and the longest
-// ones start first.  Rank by counting: fine for the batch sizes it is used for.
+// ones start first.  One workgroup of KAS_PERM_WAVES wavefronts, any batch size: a counting sort
+// over KAS_PERM_BINS key classes (key >> shift, largest class first; inside a class the order is
+// whatever the atomics make it — scenarios of one class are as good as equal for pairing, and no
+// result depends on the permutation).  LDS: int32 bins[KAS_PERM_BINS + 1] + one word.
 // ---------------------------------------------------------------------------------------------
-// keys[j] = moved_replicas of scenario j, staged by the caller (LDS in the kernel).
-KAS_DEV void order_permutation(const KasLaunch& a, const int32_t* keys, int32_t tid, int32_t n_threads) {
+#define KAS_PERM_WAVES 4
+#define KAS_PERM_BINS 4096
+KAS_DEV void order_permutation(const KasLaunch& a, unsigned char* lds_raw) {
+  constexpr int NT = 64 * KAS_PERM_WAVES;
   const int32_t S = a.n_scenarios;
-  for (int32_t i = tid; i < S; i += n_threads) {
-    const int32_t ki = keys[i];
-    int32_t rank = 0;
-    for (int32_t j = 0; j < S; ++j) {
-      const int32_t kj = keys[j];
-      rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
-    }
-    a.perm[rank] = i;
+  const int tid = kasw::tid();
+  int32_t* bins = (int32_t*)lds_raw;
+  int32_t* kmax = bins + KAS_PERM_BINS + 1;
+  for (int32_t i = tid; i <= KAS_PERM_BINS; i += NT) bins[i] = 0;
+  if (tid == 0) *kmax = 0;
+  kasw::sync();
+  int32_t m = 0;
+  for (int32_t i = tid; i < S; i += NT) {
+    const int32_t k = a.scenario_results[i].moved_replicas;
+    m = k > m ? k : m;
+  }
+  kasw::lds_atomic_max(kmax, m);
+  kasw::sync();
+  int32_t shift = 0;
+  while (((*kmax) >> shift) >= KAS_PERM_BINS) ++shift;      // workgroup-uniform
+  for (int32_t i = tid; i < S; i += NT) {
+    const int32_t k = a.scenario_results[i].moved_replicas;
+    const int32_t cls = KAS_PERM_BINS - 1 - ((k > 0 ? k : 0) >> shift);   // largest keys first
+    kasw::lds_atomic_add(&bins[cls + 1], 1);
+  }
+  kasw::sync();
+  // inclusive prefix over the classes (bins[c + 1] = scenarios in classes <= c): each thread scans
+  // its own run of classes, one thread adds up the run totals, every thread adds its run's offset
+  constexpr int RUN = KAS_PERM_BINS / NT;
+  int32_t run_sum = 0;
+  for (int32_t c = 0; c < RUN; ++c) { run_sum += bins[1 + tid * RUN + c]; bins[1 + tid * RUN + c] = run_sum; }
+  kasw::sync();
+  if (tid == 0) {
+    int32_t acc = 0;
+    for (int32_t t = 0; t < NT; ++t) { const int32_t v = bins[1 + t * RUN + RUN - 1]; bins[1 + t * RUN + RUN - 1] = acc + v; acc += v; }
+  }
+  kasw::sync();
+  // (the last class of every run now holds the global inclusive count; the others still lack the
+  // offset of the runs before theirs)
+  const int32_t before = tid > 0 ? bins[1 + tid * RUN - 1] : 0;
+  for (int32_t c = 0; c + 1 < RUN; ++c) bins[1 + tid * RUN + c] += before;
+  kasw::sync();
+  // bins[c] = first position of class c (bins[0] = 0); hand out positions
+  for (int32_t i = tid; i < S; i += NT) {
+    const int32_t k = a.scenario_results[i].moved_replicas;
+    const int32_t cls = KAS_PERM_BINS - 1 - ((k > 0 ? k : 0) >> shift);
+    a.perm[kasw::lds_atomic_add(&bins[cls], 1)] = i;
   }
 }
 

@@ -145,6 +145,10 @@ template <int W, int G, bool PK> void run_order_tickets(void* p) {
   RunArgs* r = (RunArgs*)p;
   if constexpr (W <= 3) kas::order_tickets<W, G, PK>(*r->a, r->s, r->lds);
 }
+void run_permutation(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  kas::order_permutation(*r->a, r->lds);
+}
 template <int W> void run_order_wide(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
@@ -206,6 +210,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   if ((size_t)kas_order_round_lds(sh.n_max, sh.Wc) > lds_bytes) lds_bytes = (size_t)kas_order_round_lds(sh.n_max, sh.Wc);
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
   if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
+  if (lds_bytes < sizeof(int32_t) * (KAS_PERM_BINS + 8)) lds_bytes = sizeof(int32_t) * (KAS_PERM_BINS + 8);
   std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
   KasLaunch a;
   a.scen = b->scenarios; a.topics = b->topics; a.node_id = b->node_id; a.node_rack = b->node_rack;
@@ -241,12 +246,23 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   }
   // order kernel: one wavefront per G scenarios (ticket form) or per scenario (round form)
   if (tickets) {
-    if (sh.G > 1 && b->n_scenarios > sh.G && b->n_scenarios <= KAS_PAIRING_LIMIT) {
-      a.perm = perm.data();                              // the permutation kernel, thread by thread
-      kasw::g_emu.cur = 0;
-      std::vector<int32_t> keys((size_t)b->n_scenarios);
-      for (int32_t j = 0; j < b->n_scenarios; ++j) keys[(size_t)j] = a.scenario_results[j].moved_replicas;
-      for (int32_t tid = 0; tid < 256; ++tid) kas::order_permutation(a, keys.data(), tid, 256);
+    if (sh.G > 1 && b->n_scenarios > sh.G) {
+      a.perm = perm.data();                              // the permutation kernel: one workgroup
+      memset(lds.data(), 0xCD, lds.size());
+      RunArgs ra{&a, 0, lds.data()};
+      if (kasw::run_block(run_permutation, &ra, KAS_PERM_WAVES) != 0) return bad("permutation", 0);
+      std::vector<char> seen((size_t)b->n_scenarios, 0);  // it must be a permutation, whatever the order
+      for (int32_t j = 0; j < b->n_scenarios; ++j) {
+        const int32_t v = perm[(size_t)j];
+        if (v < 0 || v >= b->n_scenarios || seen[(size_t)v]) return bad("permutation (not a permutation)", j);
+        seen[(size_t)v] = 1;
+      }
+      int32_t kmax = 0, shift = 0;                       // ... and largest key classes first
+      for (int32_t j = 0; j < b->n_scenarios; ++j) kmax = a.scenario_results[j].moved_replicas > kmax ? a.scenario_results[j].moved_replicas : kmax;
+      while ((kmax >> shift) >= KAS_PERM_BINS) ++shift;
+      for (int32_t j = 0; j + 1 < b->n_scenarios; ++j)
+        if ((a.scenario_results[perm[(size_t)j]].moved_replicas >> shift) < (a.scenario_results[perm[(size_t)j + 1]].moved_replicas >> shift))
+          return bad("permutation (not descending by key class)", j);
     }
     const bool pk = sh.packed_ok && !(flags & KAS_FLAG_WIDE_COUNTERS);
     run_fn f = sh.G == 1 ? (pk ? tickets_for_g<1, true>(sh.Wc) : tickets_for_g<1, false>(sh.Wc))
