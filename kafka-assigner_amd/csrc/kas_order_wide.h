@@ -133,15 +133,21 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 
   if (wave == 0) {
     // ------------------------------------------------------------------ solver: LDS only
-    int32_t j = 0;                                           // rows this lane has committed
-    bool cv = false, nv = false, fin = false;
+    // (KAS_CLAIM_ROWS: lanes claim the next unclaimed row of the scenario, as in the 3-wide kernel)
     int32_t e[W], Lp = 0, rot = 0;
 #pragma unroll
     for (int q = 0; q < W; ++q) e[q] = dummy_e;
+#if KAS_CLAIM_ROWS
+    int32_t gnext = 0, my_slot = lane;                       // next unclaimed virtual row; slot of the row in hand
+    bool cv = false, gfin = false;
+#else
+    int32_t j = 0;                                           // rows this lane has committed
+    bool cv = false, nv = false, fin = false;
     WideSlot nx;
     nx.tag = KAS_TAG_FREE; nx.rot = 0; nx.spare = 0;
 #pragma unroll
     for (int q = 0; q < 5; ++q) nx.e[q] = dummy_e;
+#endif
     int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
     const int64_t t_begin = kasw::clock_ticks();
@@ -150,8 +156,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       kasw::repoll();
       n_iter += 1;
       // one LDS round trip: the look-ahead slot and the counter rows of the row in hand
+#if !KAS_CLAIM_ROWS
       const int32_t jn = j + (cv ? 1 : 0);
       const WideSlot sl = ring[(jn & (K - 1)) * 64 + lane];
+#endif
       int32_t c[W][W];                                      // c[k][r] = count[holder k][replica index r]
       uint32_t d[W];                                        // rows still ahead of mine on holder k
 #pragma unroll
@@ -164,10 +172,12 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];
         d[q] = ((uint32_t)e[q] >> 16) - (f[0] + f[1] + f[2] + f[3] + f[4]);
       }
+#if !KAS_CLAIM_ROWS
       if (!nv && !fin) {
         if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
         else if (sl.tag == KAS_TAG_END && !cv) fin = true;
       }
+#endif
       uint32_t d_any = 0u, d_sum = 0u;
       int32_t nz = 0;                                       // holders I wait on
 #pragma unroll
@@ -296,10 +306,37 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad), r < Lp ? wide_field_unit(r) : 0ull);
           tag |= (r < Lp ? pos[r] : 0) << (3 * r);
         }
+#if KAS_CLAIM_ROWS
+        ring[my_slot].tag = tag;
+#else
         ring[(j & (K - 1)) * 64 + lane].tag = tag;
         j += 1;
+#endif
         cv = false;
       }
+#if KAS_CLAIM_ROWS
+      {
+        const bool need = !cv && !gfin;
+        const uint64_t nbm = kasw::ballot(need);
+        const int32_t v = gnext + kasw::popc(nbm & ((1ull << lane) - 1ull));
+        const int32_t tile = v >> 6, slot = (tile & (K - 1)) * 64 + (v & 63);
+        const WideSlot sl = ring[need ? slot : my_slot];
+        const bool taken = need && sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (tile & KAS_TAG_JMASK);
+        const bool saw_end = need && sl.tag == KAS_TAG_END;
+        if (taken) {
+#pragma unroll
+          for (int q = 0; q < W; ++q) e[q] = sl.e[q];
+          Lp = (sl.tag >> 26) & 7;
+          rot = sl.rot;
+          my_slot = slot;
+          cv = true;
+        }
+        gnext += kasw::popc(kasw::ballot(taken));
+        const uint64_t endb = kasw::ballot(saw_end);         // (a collective: not behind a short-circuit)
+        gfin = gfin || endb != 0ull;
+      }
+      const bool fin = gfin && !cv;
+#else
       if (!cv && nv) {                                     // the look-ahead row becomes current
 #pragma unroll
         for (int q = 0; q < W; ++q) e[q] = nx.e[q];
@@ -307,6 +344,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         rot = nx.rot;
         cv = true; nv = false;
       }
+#endif
       if (kasw::ballot(!fin) == 0) break;
       const bool progress = kasw::ballot(ready) != 0;
       if (watchdog_poll(wd, progress, wd_idle)) break;

@@ -1473,6 +1473,10 @@ KAS_DEV void order_permutation(const KasLaunch& a, unsigned char* lds_raw) {
 #ifndef KAS_RETIRE_PAD_STYLE
 #define KAS_RETIRE_PAD_STYLE 0
 #endif
+// solver lanes claim rows dynamically (1) or own a column of the ring (0: round 1's form)
+#ifndef KAS_CLAIM_ROWS
+#define KAS_CLAIM_ROWS 1
+#endif
 // rows a run must decide beyond the ones that were ready anyway for its path to pay
 // a row waiting on exactly one node with this many rows ahead of it nominates the node
 #ifndef KAS_RUN_NOMINATE
@@ -1655,11 +1659,23 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     // ------------------------------------------------------------------ solver: LDS only
     // cur = the row being decided, nxt = the lane's following row, read ahead from the ring so
     // that taking it costs no LDS round trip of its own
+#if KAS_CLAIM_ROWS
+    // Rows are not tied to lanes: a lane without a row CLAIMS the next unclaimed row of its scenario
+    // (rows in tile order: virtual row v = tile * GL + column lives in ring slot (tile % K, column)),
+    // so the GL lanes of a group always hold the oldest rows that are still undecided — a lane
+    // stuck behind a ticket no longer keeps the rows of "its" column from being worked on
+    // (rows in hand 21 -> ~30 of 32).  Any lane may decide any row: the tickets order them.
+    int32_t gnext = 0;                                       // next unclaimed virtual row (group-uniform)
+    int32_t my_slot = lane;                                  // ring slot of the row in hand
+    bool cv = false, gfin = false;
+    int32_t e0 = dummy_addr, e1 = dummy_addr, e2 = dummy_addr, meta = 0;
+#else
     int32_t j = 0;                                           // rows this lane has committed
     bool cv = false, nv = false, fin = false;
     int32_t e0 = dummy_addr, e1 = dummy_addr, e2 = dummy_addr, meta = 0;
     RingSlot nx;
     nx.tag = KAS_TAG_FREE; nx.c[0] = 0; nx.c[1] = 0; nx.c[2] = 0;
+#endif
     int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0, n_cur = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
     const int64_t t_begin = kasw::clock_ticks();
@@ -1667,9 +1683,12 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     for (;;) {
       kasw::repoll();                                      // LDS is re-read below
       n_iter += 1;
-      // one LDS round trip per iteration: the look-ahead slot and the three counter rows
+      // one LDS round trip per iteration: the three counter rows (+ the look-ahead slot / the slot
+      // of the row claimed at the end of the previous iteration)
+#if !KAS_CLAIM_ROWS
       const int32_t jn = j + (cv ? 1 : 0);
       const RingSlot sl = ring[(jn & (K - 1)) * 64 + lane];
+#endif
       uint32_t f0[3], f1[3], com[3];                        // count[.][0], count[.][1], commits per holder
       const int32_t es[3] = {e0, e1, e2};
       if constexpr (PK) {
@@ -1687,10 +1706,12 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           com[q] = (uint32_t)(x >> 48);
         }
       }
+#if !KAS_CLAIM_ROWS
       if (!nv && !fin) {
         if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
         else if (sl.tag == KAS_TAG_END && !cv) fin = true;
       }
+#endif
       // rows still ahead of mine on each holder: ticket - commits on the node; 0 everywhere ==
       // every earlier row holding any of my nodes has committed
       const uint32_t d0 = ((uint32_t)e0 >> 16) - com[0], d1 = ((uint32_t)e1 >> 16) - com[1],
@@ -1808,15 +1829,45 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad1), Lp > 1 ? (1ull << 16) + (1ull << 48) : 0ull);
           kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad2), Lp > 2 ? (1ull << 32) + (1ull << 48) : 0ull);
         }
+#if KAS_CLAIM_ROWS
+        ring[my_slot].tag = KAS_TAG_DONE | w0 | (w1 << 2) | (Lp << 4);
+#else
         ring[(j & (K - 1)) * 64 + lane].tag = KAS_TAG_DONE | w0 | (w1 << 2) | (Lp << 4);
         j += 1;
+#endif
         cv = false;
       }
+#if KAS_CLAIM_ROWS
+      {
+        // lanes without a row claim the next rows of their group in order; a claimed row is taken if
+        // its tile has been staged (tiles are staged whole, so the rows taken are a prefix of the
+        // rows claimed and gnext moves on by their number); the END tile ends the group
+        constexpr uint64_t GLM = GL == 64 ? ~0ull : ((1ull << GL) - 1ull);
+        const bool need = !cv && !gfin;
+        const uint64_t nbg = (kasw::ballot(need) >> (g * GL)) & GLM;
+        const int32_t v = gnext + kasw::popc(nbg & ((1ull << li) - 1ull));
+        const int32_t tile = v / GL, slot = (tile & (K - 1)) * 64 + g * GL + (v % GL);
+        const RingSlot sl = ring[need ? slot : my_slot];
+        const bool taken = need && sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (tile & KAS_TAG_JMASK);
+        const bool saw_end = need && sl.tag == KAS_TAG_END;
+        if (taken) {
+          e0 = sl.c[0]; e1 = sl.c[1]; e2 = sl.c[2];
+          meta = sl.tag >> 26;
+          my_slot = slot;
+          cv = true;
+        }
+        gnext += kasw::popc((kasw::ballot(taken) >> (g * GL)) & GLM);
+        const uint64_t endb = kasw::ballot(saw_end);         // (a collective: not behind a short-circuit)
+        gfin = gfin || ((endb >> (g * GL)) & GLM) != 0ull;
+      }
+      const bool fin = gfin && !cv;
+#else
       if (!cv && nv) {                                     // the look-ahead row becomes current
         e0 = nx.c[0]; e1 = nx.c[1]; e2 = nx.c[2];
         meta = nx.tag >> 26;
         cv = true; nv = false;
       }
+#endif
       if (kasw::ballot(!fin) == 0) break;
       const bool progress = kasw::ballot(ready) != 0;
       if (watchdog_poll(wd, progress, wd_idle)) break;

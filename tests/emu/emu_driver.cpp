@@ -87,7 +87,12 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
       if (finished == 64) continue;
       if (parked + finished < 64) continue;                // cannot happen after step 1
       if (finished > 0) { fprintf(stderr, "emu: wave %d: %d lanes exited while others wait at a collective\n", w, finished); return -1; }
-      if (mixed) { fprintf(stderr, "emu: wave %d: divergence, lanes wait at different collectives\n", w); return -1; }
+      if (mixed) {
+        fprintf(stderr, "emu: wave %d: divergence, lanes wait at different collectives:", w);
+        for (int i = 64 * w; i < 64 * w + 64; ++i) fprintf(stderr, " %d", e.kind[i]);
+        fprintf(stderr, "\n");
+        return -1;
+      }
       if (k == K_SYNC) { at_sync += 64; continue; }
       ready_waves[n_ready++] = w;
     }
