@@ -1489,6 +1489,10 @@ KAS_DEV void order_permutation(const KasLaunch& a, unsigned char* lds_raw) {
 #ifndef KAS_RUN_MIN_GAIN
 #define KAS_RUN_MIN_GAIN 3
 #endif
+// a queue pass that gained less than that makes the next 1, 2, 4 ... KAS_RUN_BACKOFF_MAX nominations be skipped
+#ifndef KAS_RUN_BACKOFF_MAX
+#define KAS_RUN_BACKOFF_MAX 16
+#endif
 #define KAS_TAG_FREE (-1)
 #define KAS_TAG_END  (-3)
 #define KAS_TAG_DONE ((int32_t)0x80000000)   // | w0 | w1 << 2 | Lp << 4
@@ -1763,8 +1767,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           const bool member = cand && (int32_t)kx < qlen;
           const int32_t gain = kasw::popc(kasw::ballot(member && kx > 0u));   // rows beyond the ones ready anyway
           if (gain < KAS_RUN_MIN_GAIN) {
-            run_backoff = run_backoff == 0 ? 1 : (run_backoff < 16 ? 2 * run_backoff : 16);
-            run_skip = run_backoff;
+            run_backoff = run_backoff == 0 ? 1 : (run_backoff < KAS_RUN_BACKOFF_MAX ? 2 * run_backoff : KAS_RUN_BACKOFF_MAX);
+            run_skip = KAS_RUN_BACKOFF_MAX > 0 ? run_backoff : 0;
           } else {
             if (gain > KAS_RUN_MIN_GAIN) run_backoff = 0;
             // thresholds of the owner's row (relative to X's counts now)

@@ -11,6 +11,9 @@ tail -9 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log; tail -2 $O/smoke.log
 timeout 900 python bench.py --stats $O/stats_default.json > $O/bench_default.log 2>&1; echo "exit $?" >> $O/bench_default.log
 tail -2 $O/bench_default.log | cut -c1-300
+# the driver's own command line
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmdline.log 2>&1; echo "exit $?" >> $O/bench_driver_cmdline.log
+tail -2 $O/bench_driver_cmdline.log | cut -c1-200
 timeout 300 python bench.py --no-cpu --check 0 --no-extras --steps 10 --in-flight 1 --stats $O/stats_one_batch_in_flight.json > $O/bench_one_batch_in_flight.log 2>&1
 # BASELINE configs[1]: single scenario, 10k partitions x 100 brokers x 10 racks, RF 3 (latency)
 timeout 300 python bench.py --no-cpu --no-extras --check 1 --scenarios 1 --partitions 10000 --brokers 100 --racks 10 --actions remove1 --in-flight 1 --steps 50 --warmup 5 > $O/bench_config2_single_scenario.log 2>&1
@@ -25,6 +28,7 @@ for act in c5 c5_norack; do
 done
 timeout 600 python bench.py --no-cpu --no-extras --check 2 --scenarios 8 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 5 --warmup 1 > $O/bench_config5_x8.log 2>&1
 tail -1 $O/bench_config5_x8.log | cut -c1-200
+timeout 200 python scripts/stress_gpu.py 45 > $O/stress.log 2>&1; echo "stress exit $?" >> $O/stress.log; tail -2 $O/stress.log
 timeout 300 python scripts/host_path_rate.py 200 > $O/host_path_rate.log 2>&1; tail -1 $O/host_path_rate.log
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_trace_one_batch_in_flight -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --check 0 --no-extras --in-flight 1 --steps 20 > $GRAFT_REPO_ROOT/$O/prof_trace_f1.log 2>&1; echo "trace exit $?"
