@@ -44,6 +44,8 @@ import time
 # The HIP runtime multiplexes streams onto 4 hardware queues by default; steps in flight on more
 # streams than that would serialise in pairs.  Must be set before the runtime is loaded.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):

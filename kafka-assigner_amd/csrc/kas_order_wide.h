@@ -50,6 +50,12 @@ namespace kas {
 #ifndef KAS_WIDE_RING_SLOTS
 #define KAS_WIDE_RING_SLOTS KAS_RING_SLOTS
 #endif
+// A queue usually breaks at a row that also waits for a row of its own tile; that row is free one
+// step later.  Skipping the queue pass of that step lets the next pass take the whole rest of the
+// queue instead of two passes taking half each.
+#ifndef KAS_WIDE_SKIP_AFTER_PASS
+#define KAS_WIDE_SKIP_AFTER_PASS 0
+#endif
 #define KAS_WIDE_FIELD_MASK 0x3ffu
 #define KAS_WIDE_DUMMY_TICKET (5 * 0x3ff)
 
@@ -221,6 +227,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
             run_skip = KAS_WIDE_BACKOFF_MAX > 0 ? run_backoff : 0;
           } else {
             if (gain > KAS_WIDE_MIN_GAIN) run_backoff = 0;
+            run_skip = KAS_WIDE_SKIP_AFTER_PASS;            // steps without a queue pass after one that paid
             // thresholds of my row against X (relative to X's counts now): X takes pick r iff
             // count[X][r] + (wins of the rows ahead of me at r) < T_r, the other holders being free
             int32_t cX[W];
