@@ -11,38 +11,41 @@
 //  P2  sticky fill (KAS:101-131), rack-diverse form.  When every row's valid replicas sit on
 //      pairwise different racks the rack test of canAccept can never fail during the fill, so a
 //      node keeps its first `cap` candidates in (replica index, row) order independently of
-//      every other node:
-//        A1  all waves, tiles interleaved: hist[r][n] = candidates of sweep r on node n (LDS
-//            atomics) and the proof of rack diversity
-//        Q   per node: the one sweep r* in which it saturates and its quota q there
-//        A2  row range cut into NW chunks, wave w counts chunk w's sweep-r* candidates per node;
-//            a prefix over chunks turns that into the quota left when chunk w starts
+//      every other node.  The row range is cut into NW chunks, one per wavefront:
+//        A   wave w scans chunk w: per-chunk histogram hist[n][w][r] = candidates of sweep r on
+//            node n (uint16 cells, LDS atomics) and the proof of rack diversity
+//        Q   per node: the one sweep r* in which it saturates, its quota q there, and — a prefix
+//            over the node's own per-chunk counts — the quota left when chunk w starts
+//            (lists wider than 3, or tables that do not fit: one histogram for the whole topic,
+//            then a separate pass A2 in which wave w counts chunk w's sweep-r* candidates)
 //        B   wave w walks chunk w in row order: replica (p, r) on n is kept iff r < r*(n), or
 //            r == r*(n) and its rank among n's sweep-r* candidates is below the quota (ranked
 //            by ballot only in the one tile where the quota runs out).  P3 (KAS:133-160) runs
-//            in the same scan: holders -> out row (node indices), movement counts, and the
-//            orphan rows appended to the chunk's list in HBM scratch (ascending).
+//            in the same scan: holders -> mid row (uint16 node indices at the end of the topic's
+//            out region), movement counts, and the orphan rows appended to the chunk's list in
+//            HBM scratch (ascending).
 //      General form (rows that are not rack-diverse, or no LDS for the histogram): one sweep per
 //      replica index over 64-row tiles by wave 0, accept masks as ballot words in HBM scratch.
-//  P4  first fit (KAS:162-186), wave 0: orphans in ascending row order, 64 per window, evaluated
+//  P4  first fit (KAS:162-186): orphans in ascending row order, 64 per window, evaluated
 //      position-major over the compacted list of non-full nodes in processing order (a full
-//      node never becomes non-full; the reference spends >99% of its probes on them).
+//      node never becomes non-full; the reference spends >99% of its probes on them); the windows
+//      go round-robin to all wavefronts, one step apart.
 //  P5  preference order (KAS:202-239), a kernel of its own (the order kernel): its only state
 //      is count[node][replica index], so it runs with a fraction of the fill kernel's LDS and
 //      many more scenarios per CU.  Row p reads count[n][0..L) of its own nodes, picks, then
 //      increments one counter per node, so it only has to wait for the EARLIER rows that hold
 //      one of its nodes.  The chain of such waits is long (every orphan placed by first fit
-//      lands on the same few nodes, so there are at least as many dependent steps as orphans)
-//      and only ~10-20 rows are ever ready at once: P5 is latency-bound per scenario, and
-//      throughput comes from running many scenarios side by side.
-//      Ticket form: the fill kernel ends with a scan in row order that hands every (row, node)
-//      its ticket = how many earlier rows of the scenario hold that node, packed into the out
-//      row next to the node index.  Every committed row adds exactly 1 to the commit count of
-//      each of its nodes, so "commits on n == ticket" says that all earlier rows on n have
-//      committed: lanes then work on rows independently (row = lane + k * lanes), spin on their
-//      tickets, pick and commit with one LDS atomic add per node — no tile-wide rounds, and a
-//      wavefront can serve several scenarios at once (one lane group each).
-//      Round form (Context handed in, lists wider than 4, ticket overflow, the KAS:190 index
+//      lands on the same few nodes) and only ~10-20 rows are ever ready at once: P5 is
+//      latency-bound per scenario, and throughput comes from running many scenarios side by side.
+//      Ticket form (order_tickets, lists <= 3 wide; kas_order_wide.h, lists 4 and 5 wide): a
+//      staging wavefront streams the mid rows and hands every (row, node) its ticket = how many
+//      earlier rows of the scenario hold that node.  Every committed row adds exactly 1 to the
+//      commit count of each of its nodes, so "commits on n == ticket" says that all earlier rows
+//      on n have committed: the solving wavefront's lanes claim rows in order, wait on their
+//      tickets, pick and commit with one LDS atomic add per node — no tile-wide rounds, rows that
+//      queue on one node are decided together, and a wavefront can serve several scenarios at
+//      once (one lane group each); a retiring wavefront writes the final rows.
+//      Round form (Context handed in, lists wider than 5, ticket overflow, the KAS:190 index
 //      error): one wavefront per scenario, 64 ascending rows per tile, a lane commits once no
 //      lower lane sharing a node is pending.
 //
