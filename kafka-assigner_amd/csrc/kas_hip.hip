@@ -316,9 +316,10 @@ static int kas_plan_set_kernels(kas_plan* p) {
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kas_order_ticket_lds(p->shape.n_max, p->G, pk)));
-  KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kas_order_round_lds(p->shape.n_max, p->Wc)));
+  if (p->shape.round_fits)
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kas_order_round_lds(p->shape.n_max, p->Wc)));
   if (p->shape.wide_ok && kas_order_wide_for(p->Wc))
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_wide_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -558,6 +559,8 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_WAVES: waves per scenario must be 1, 2 or 4");
   if (g != 0 && g != 1 && g != 2 && g != 4)
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
+  if ((flags & KAS_FLAG_ROUND_ORDER) && !p->shape.round_fits)
+    return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_ROUND_ORDER: the round form's LDS exceeds 160 KiB at this broker count x width");
   if (!kas_minimal_ok(p->Wc, nw ? nw : p->NW, g ? g : p->G))
     return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only 4 fill waves, 1 or 2 groups");
   const KasShape& sh = p->shape;

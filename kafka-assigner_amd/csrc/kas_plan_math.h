@@ -168,6 +168,7 @@ struct KasShape {
   int32_t with_x = 1;                 // LDS has room for the histogram / quota table of the fast fill
   int32_t packed_ok = 1;              // every scenario's ticket bound fits 10-bit counter fields
   int32_t wide_ok = 0;                // lists 4 or 5 wide and the wide ticket form is applicable
+  int32_t round_fits = 1;             // the round form's LDS (int32 counters + 64-bit masks) fits 160 KiB
   int32_t fused_ok = 0;               // rack-diverse fill with per-chunk histograms (no chunk-count pass)
   KasLds lds_fused{};                 // its LDS carve-up (valid when fused_ok)
   int32_t max_partitions = 0;         // largest topic of the batch
@@ -305,7 +306,10 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = 1; s.with_x = 0; err_total = 0; }
   }
   kas_choose_fused(&s);
-  if (err_total == 0 && kas_order_round_lds(s.n_max, s.Wc) > KAS_LDS_LIMIT)
+  // the round form of P5 is the universal fallback; a batch that one of the ticket forms serves does
+  // not need it to fit (KAS_PLAN_ROUND_ORDER is refused for such a plan, see round_fits)
+  s.round_fits = kas_order_round_lds(s.n_max, s.Wc) <= KAS_LDS_LIMIT;
+  if (err_total == 0 && !s.round_fits && !(s.tickets_ok || s.wide_ok))
     err_total = kas_order_round_lds(s.n_max, s.Wc);
   if (err_total)
     return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +

@@ -212,7 +212,11 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
   const bool fused = sh.fused_ok && !(flags & KAS_FLAG_TWO_PASS_HIST) && !(flags & KAS_FLAG_GENERIC_FILL);
   size_t lds_bytes = (size_t)(fused ? sh.lds_fused.total : sh.lds.total);
-  if ((size_t)kas_order_round_lds(sh.n_max, sh.Wc) > lds_bytes) lds_bytes = (size_t)kas_order_round_lds(sh.n_max, sh.Wc);
+  if (sh.round_fits && (size_t)kas_order_round_lds(sh.n_max, sh.Wc) > lds_bytes) lds_bytes = (size_t)kas_order_round_lds(sh.n_max, sh.Wc);
+  if ((flags & KAS_FLAG_ROUND_ORDER) && !sh.round_fits) {
+    if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "round form does not fit LDS");
+    return KAS_E_UNSUPPORTED;
+  }
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
   if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
   if (lds_bytes < sizeof(int32_t) * (KAS_PERM_BINS + 8)) lds_bytes = sizeof(int32_t) * (KAS_PERM_BINS + 8);
