@@ -8,8 +8,8 @@
 // workgroup; wide lists mean more state per row, not more rows in flight).
 //
 // What differs from the 3-wide kernel:
-//   * count[n][0..5) live in one uint64 per node as five 10-bit fields (bits 0, 10, 20, 32, 42);
-//     commits on n = their sum.  Applicable while no node can hold 1023 rows of the scenario
+//   * count[n][0..5) live in one uint64 per node as five 10-bit fields (bits 0, 10, 20, 32, 42)
+//     plus the commits on n (their sum) at bit 52.  Applicable while no node can hold 1023 rows of the scenario
 //     (the plan checks the bound; configs[4] has cap 981).
 //   * holders are stored ascending (Sets.newTreeSet, KAS:228) and the picks are the general
 //     "minimum of (count, visit position) over the nodes still in the set" of pick_row<W>
@@ -57,7 +57,7 @@ namespace kas {
 #define KAS_WIDE_SKIP_AFTER_PASS 0
 #endif
 #define KAS_WIDE_FIELD_MASK 0x3ffu
-#define KAS_WIDE_DUMMY_TICKET (5 * 0x3ff)
+#define KAS_WIDE_DUMMY_TICKET 0xfff                      // the padding holder's ticket == its row's commits field
 
 struct alignas(16) WideSlot { int32_t tag; int32_t e[5]; int32_t rot; int32_t spare; };
 // tag: KAS_TAG_FREE / KAS_TAG_END as in the 3-wide kernel
@@ -69,8 +69,12 @@ struct alignas(16) WideSlot { int32_t tag; int32_t e[5]; int32_t rot; int32_t sp
 // slot.rot = TileIter::rot of a wide iterator: idx_m = Math.abs(hash) % m (KAS:190) for set sizes m = 1..5, 3 bits each
 // at bit 3 m (computed per topic by tile_next_topic)
 
-KAS_DEV uint64_t wide_field_unit(int r) {                   // + 1 on count field r
-  return r == 0 ? 1ull : r == 1 ? (1ull << 10) : r == 2 ? (1ull << 20) : r == 3 ? (1ull << 32) : (1ull << 42);
+// counter row of a node: five 10-bit counts at bits 0, 10, 20, 32, 42 (.. 51) and the number of rows
+// that committed on the node (= their sum, kept separately so that readiness is one shift) in the
+// 12 bits from bit 52 (a node holds fewer than 1023 rows of the scenario: the plan checks)
+KAS_DEV uint64_t wide_field_unit(int r) {                   // + 1 on count field r and on the commits
+  return (1ull << 52) +
+         (r == 0 ? 1ull : r == 1 ? (1ull << 10) : r == 2 ? (1ull << 20) : r == 3 ? (1ull << 32) : (1ull << 42));
 }
 
 // The picks of one row (KAS:225-236) as pick_row<W>, with the rotation offsets taken straight from
@@ -82,6 +86,13 @@ KAS_DEV void pick_row_packed(const int32_t (&c)[W][W], int32_t Lp, bool valid, i
   int32_t m = valid ? Lp : 0;
 #pragma unroll
   for (int r = 0; r < W; ++r) {
+    if (r == W - 1) {                                       // at most one node is left: nothing to compare
+      int32_t ps = W - 1;
+#pragma unroll
+      for (int k = W - 2; k >= 0; --k) ps = ((alive >> k) & 1u) ? k : ps;
+      pos[r] = ps;
+      break;
+    }
     const int32_t idx = (rot >> (3 * m)) & 7;
     int32_t keys[W], best = 0x7fffffff, rank = idx;         // rank of the next set member + idx
 #pragma unroll
@@ -130,7 +141,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   if (wave == 0) rank_owner[lane] = 0u;
   kasw::sync();
   if (wave == 0 && lane == 0) {
-    cnt[nmax] = ((uint64_t)0xfffffu << 32) | 0x3fffffffull;  // five fields of 0x3ff: commits == the dummy ticket
+    // the padding holder's row: counts that never matter, commits == the dummy ticket
+    cnt[nmax] = ((uint64_t)KAS_WIDE_DUMMY_TICKET << 52) | ((uint64_t)0xfffffu << 32) | 0x3fffffffull;
     gdig[0] = 0ull;
     *wd = 0u;
   }
@@ -175,8 +187,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         const uint32_t f[5] = {lo & KAS_WIDE_FIELD_MASK, (lo >> 10) & KAS_WIDE_FIELD_MASK, (lo >> 20) & KAS_WIDE_FIELD_MASK,
                                hi & KAS_WIDE_FIELD_MASK, (hi >> 10) & KAS_WIDE_FIELD_MASK};
 #pragma unroll
-        for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];
-        d[q] = ((uint32_t)e[q] >> 16) - (f[0] + f[1] + f[2] + f[3] + f[4]);
+        for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];   // (the last index is never compared: dead code)
+        d[q] = ((uint32_t)e[q] >> 16) - (hi >> 20);           // ticket - commits on the node
       }
 #if !KAS_CLAIM_ROWS
       if (!nv && !fin) {

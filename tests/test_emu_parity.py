@@ -262,3 +262,15 @@ def test_emu_fill_with_per_chunk_histograms_and_with_the_chunk_count_pass():
     fb = uniform_batch(cur.astype(np.int32)[None], ids[:, :19], racks[:, :19], 3)
     assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu per-chunk histograms, sparse ids")
     assert last_fused()
+
+
+@pytest.mark.timeout(900)      # a field overlap shows as rows that never become ready
+def test_emu_wide_lists_counts_near_the_field_limit():
+    """Five-wide lists on few brokers: ~1000 rows per broker, so the 10-bit count fields of the wide
+    ticket form — including the last one, next to the commits field — run up to their limit."""
+    fb = _batch(31, 1, 3800, 20, 10, 5, ("add_k",), rack_aware=False)
+    want = oracle_solve(fb)
+    assert want.scenario_results["status"][0] == abi.KAS_OK
+    out = want.out[:3800 * 5].reshape(3800, 5)
+    assert np.bincount(out[:, 4]).max() > 255 and np.bincount(out.reshape(-1)).max() > 800
+    assert_same_outputs(fb, want, emu_solve(fb), "emu wide, counts near the field limit")
