@@ -43,8 +43,17 @@ __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(K
     kas::fill_scenario<W, NW>(a, s, kas_lds);
 }
 
+// min waves per SIMD of the ticket-form order kernel (0 = whatever the allocation comes to: 92 VGPRs, 5)
+#ifndef KAS_ORDER_MIN_WAVES
+#define KAS_ORDER_MIN_WAVES 0
+#endif
+#if KAS_ORDER_MIN_WAVES > 0
+#define KAS_ORDER_BOUNDS __launch_bounds__(192, KAS_ORDER_MIN_WAVES)
+#else
+#define KAS_ORDER_BOUNDS __launch_bounds__(192)
+#endif
 template <int W, int G, bool PK>
-__global__ __launch_bounds__(192) void kas_order_ticket_kernel(KasLaunch a) {
+__global__ KAS_ORDER_BOUNDS void kas_order_ticket_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   kas::order_tickets<W, G, PK>(a, (int32_t)blockIdx.x * G, kas_lds);
 }
@@ -60,9 +69,9 @@ __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
   kas::order_scenario_rounds<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
-// lists 4 and 5 wide: one scenario per workgroup (solver / stager / retirer wavefronts)
+// lists 4 and 5 wide: one scenario per workgroup (two solver wavefronts, stager, retirer)
 template <int W>
-__global__ __launch_bounds__(192) void kas_order_wide_kernel(KasLaunch a) {
+__global__ __launch_bounds__(KAS_ORDER_WIDE_BLOCK) void kas_order_wide_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   kas::order_tickets_wide<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
@@ -431,7 +440,7 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
     lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed);
   } else if (lp.wide) {
-    lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 192u;
+    lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = (unsigned)KAS_ORDER_WIDE_BLOCK;
     lp.order_lds = (size_t)kas_order_wide_lds(p->shape.n_max);
   } else {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;

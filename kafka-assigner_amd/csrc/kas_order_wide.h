@@ -1,11 +1,21 @@
 // kas_order_wide.h — P5 (computePreferenceLists, KAS:202-239), ticket form for replica lists 4 and 5
 // wide (BASELINE.json configs[4]: 1M partitions x 5k brokers, RF 5).  Included by kas_solver_body.h.
 //
-// Same plan as order_tickets<W <= 3>: a workgroup is three wavefronts — wave 0 SOLVES, wave 1 STAGES
-// rows for it (mid rows from HBM, tickets, ring slots), wave 2 RETIRES finished rows (node index ->
-// broker id, digest, final out row) — talking only through the tags of a ring of K slots per lane.
-// One scenario per workgroup, lane l owns rows l, l + 64, ... (a 1M-row scenario is served by one
-// workgroup; wide lists mean more state per row, not more rows in flight).
+// Same plan as order_tickets<W <= 3> — wave 1 STAGES rows (mid rows from HBM, tickets, ring slots),
+// wave 2 RETIRES finished rows (node index -> broker id, digest, final out row), talking only through
+// the tags of a ring of K tiles of 64 slots — but with TWO solver wavefronts, one per SIMD that the
+// other two leave free: a single wavefront issues one instruction of its dependent chain every ~5
+// cycles (1.1 us per 64-row step at configs[4], 2.1 us with a queue pass), so the solver, not the
+// dependency chain, was what a 1M-row scenario waited for.  The staging wave sorts every row into one
+// of two classes and appends its slot to that class's claim list:
+//   class 1 (wave 0): rows holding a node that >= KAS_WIDE_CHAIN_DENSITY rows of the same 64-row
+//     tile hold — the brokers that first fit is filling with consecutive orphans.  All of this
+//     wave's 64 rows in hand sit on those chains, so a queue pass decides many of them at once.
+//   class 0 (wave 3): everything else — rows whose nodes are ~N/W rows apart, almost always ready.
+// Tickets make any split exact: a row commits when every earlier row on each of its nodes has
+// (ticket == commits of the node), whichever wave holds them.  No deadlock: each solver claims its
+// class in row order, so the oldest undecided row of the scenario is always in some lane's hand,
+// and its tickets are all due.  One scenario per workgroup.
 //
 // What differs from the 3-wide kernel:
 //   * count[n][0..5) live in one uint64 per node as five 10-bit fields (bits 0, 10, 20, 32, 42)
@@ -48,8 +58,13 @@ namespace kas {
 #define KAS_WIDE_BACKOFF_MAX 0
 #endif
 #ifndef KAS_WIDE_RING_SLOTS
-#define KAS_WIDE_RING_SLOTS KAS_RING_SLOTS
+#define KAS_WIDE_RING_SLOTS 8
 #endif
+// rows of one staged tile on the same node from which the node counts as "being filled" (class 1)
+#ifndef KAS_WIDE_CHAIN_DENSITY
+#define KAS_WIDE_CHAIN_DENSITY 3
+#endif
+#define KAS_WIDE_SOLVER_WAVE(w) ((w) == 0 || (w) == 3)
 // A queue usually breaks at a row that also waits for a row of its own tile; that row is free one
 // step later.  Skipping the queue pass of that step lets the next pass take the whole rest of the
 // queue instead of two passes taking half each.
@@ -126,9 +141,11 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   uint64_t* dep = (uint64_t*)(lds_raw + kas_align16(8 * (int64_t)(nmax + 1)));                  // lane mask per node
   uint16_t* run = (uint16_t*)((unsigned char*)dep + kas_align16(8 * (int64_t)(nmax + 1)));       // tickets handed out
   WideSlot* ring = (WideSlot*)((unsigned char*)run + kas_align16(2 * (int64_t)(nmax + 1)));
-  uint64_t* gdig = (uint64_t*)(ring + K * 64);
-  uint32_t* rank_owner = (uint32_t*)(gdig + 2);             // [64] queue scratch of the solver: rank -> lane
-  uint32_t* wd = rank_owner + 64;                           // watchdog word (debug builds, see watchdog_poll)
+  uint16_t* clist = (uint16_t*)(ring + K * 64);             // [2][K * 64] claim lists: ring slot of the class's next rows
+  uint64_t* gdig = (uint64_t*)(clist + 2 * K * 64);
+  uint32_t* lstate = (uint32_t*)(gdig + 1);                 // [2] rows appended to each list | 1 << 31 once staging has ended
+  uint32_t* rank_owner_all = (uint32_t*)(gdig + 2);         // [2][64] queue scratch of the solvers: rank -> lane
+  uint32_t* wd = rank_owner_all + 128;                      // watchdog word (debug builds, see watchdog_poll)
   // padding holder: a ticket that always matches its commits; never picked (pick_row looks at Lp cells)
   const int32_t dummy_e = (KAS_WIDE_DUMMY_TICKET << 16) | (nmax * 8);
 
@@ -136,9 +153,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
   if (have_s) sd = a.scen[s];
   const int32_t* g_node_id = a.node_id + sd.node_off;
-  for (int32_t n = lane + 64 * wave; n <= nmax; n += 192) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; }
-  for (int32_t k = wave; k < K; k += 3) ring[k * 64 + lane].tag = KAS_TAG_FREE;
-  if (wave == 0) rank_owner[lane] = 0u;
+  for (int32_t n = lane + 64 * wave; n <= nmax; n += 256) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; }
+  for (int32_t k = wave; k < K; k += 4) ring[k * 64 + lane].tag = KAS_TAG_FREE;
+  if (wave < 2) rank_owner_all[wave * 64 + lane] = 0u;
+  if (wave == 2 && lane < 2) lstate[lane] = 0u;
   kasw::sync();
   if (wave == 0 && lane == 0) {
     // the padding holder's row: counts that never matter, commits == the dummy ticket
@@ -149,23 +167,17 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   kasw::sync();
   int32_t wd_idle = 0;
 
-  if (wave == 0) {
-    // ------------------------------------------------------------------ solver: LDS only
-    // (KAS_CLAIM_ROWS: lanes claim the next unclaimed row of the scenario, as in the 3-wide kernel)
+  if (KAS_WIDE_SOLVER_WAVE(wave)) {
+    // ------------------------------------------------------------------ solvers: LDS only
+    // a lane without a row claims the next entry of its class's list (rows in row order)
+    const int32_t cls = wave == 0 ? 1 : 0;
+    uint32_t* rank_owner = rank_owner_all + cls * 64;
+    const uint16_t* my_list = clist + cls * (K * 64);
     int32_t e[W], Lp = 0, rot = 0;
 #pragma unroll
     for (int q = 0; q < W; ++q) e[q] = dummy_e;
-#if KAS_CLAIM_ROWS
-    int32_t gnext = 0, my_slot = lane;                       // next unclaimed virtual row; slot of the row in hand
+    int32_t cn = 0, my_slot = lane;                          // list entries claimed; slot of the row in hand
     bool cv = false, gfin = false;
-#else
-    int32_t j = 0;                                           // rows this lane has committed
-    bool cv = false, nv = false, fin = false;
-    WideSlot nx;
-    nx.tag = KAS_TAG_FREE; nx.rot = 0; nx.spare = 0;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) nx.e[q] = dummy_e;
-#endif
     int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
     const int64_t t_begin = kasw::clock_ticks();
@@ -173,11 +185,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     for (;;) {
       kasw::repoll();
       n_iter += 1;
-      // one LDS round trip: the look-ahead slot and the counter rows of the row in hand
-#if !KAS_CLAIM_ROWS
-      const int32_t jn = j + (cv ? 1 : 0);
-      const WideSlot sl = ring[(jn & (K - 1)) * 64 + lane];
-#endif
+      // the counter rows of the row in hand
       int32_t c[W][W];                                      // c[k][r] = count[holder k][replica index r]
       uint32_t d[W];                                        // rows still ahead of mine on holder k
 #pragma unroll
@@ -190,12 +198,6 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];   // (the last index is never compared: dead code)
         d[q] = ((uint32_t)e[q] >> 16) - (hi >> 20);           // ticket - commits on the node
       }
-#if !KAS_CLAIM_ROWS
-      if (!nv && !fin) {
-        if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
-        else if (sl.tag == KAS_TAG_END && !cv) fin = true;
-      }
-#endif
       uint32_t d_any = 0u, d_sum = 0u;
       int32_t nz = 0;                                       // holders I wait on
 #pragma unroll
@@ -325,24 +327,20 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad), r < Lp ? wide_field_unit(r) : 0ull);
           tag |= (r < Lp ? pos[r] : 0) << (3 * r);
         }
-#if KAS_CLAIM_ROWS
         ring[my_slot].tag = tag;
-#else
-        ring[(j & (K - 1)) * 64 + lane].tag = tag;
-        j += 1;
-#endif
         cv = false;
       }
-#if KAS_CLAIM_ROWS
       {
         const bool need = !cv && !gfin;
         const uint64_t nbm = kasw::ballot(need);
-        const int32_t v = gnext + kasw::popc(nbm & ((1ull << lane) - 1ull));
-        const int32_t tile = v >> 6, slot = (tile & (K - 1)) * 64 + (v & 63);
-        const WideSlot sl = ring[need ? slot : my_slot];
-        const bool taken = need && sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (tile & KAS_TAG_JMASK);
-        const bool saw_end = need && sl.tag == KAS_TAG_END;
-        if (taken) {
+        const uint32_t st = *(volatile uint32_t*)&lstate[cls];
+        kasw::repoll();                                      // list and slots are read after the count that covers them
+        const int32_t staged = (int32_t)(st & 0x7fffffffu);
+        const int32_t k = kasw::popc(nbm & ((1ull << lane) - 1ull));
+        const bool take = need && cn + k < staged;
+        const int32_t slot = take ? (int32_t)my_list[(cn + k) & (K * 64 - 1)] : my_slot;
+        const WideSlot sl = ring[slot];
+        if (take) {
 #pragma unroll
           for (int q = 0; q < W; ++q) e[q] = sl.e[q];
           Lp = (sl.tag >> 26) & 7;
@@ -350,20 +348,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           my_slot = slot;
           cv = true;
         }
-        gnext += kasw::popc(kasw::ballot(taken));
-        const uint64_t endb = kasw::ballot(saw_end);         // (a collective: not behind a short-circuit)
-        gfin = gfin || endb != 0ull;
+        cn += kasw::popc(kasw::ballot(take));
+        gfin = (st >> 31) != 0u && cn == staged;             // the list is complete and claimed
       }
       const bool fin = gfin && !cv;
-#else
-      if (!cv && nv) {                                     // the look-ahead row becomes current
-#pragma unroll
-        for (int q = 0; q < W; ++q) e[q] = nx.e[q];
-        Lp = (nx.tag >> 26) & 7;
-        rot = nx.rot;
-        cv = true; nv = false;
-      }
-#endif
       if (kasw::ballot(!fin) == 0) break;
       const bool progress = kasw::ballot(ready) != 0;
       if (watchdog_poll(wd, progress, wd_idle)) break;
@@ -373,8 +361,12 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       const int32_t run_rows = kasw::wave_sum((int32_t)n_run_rows);
       if (lane == 0) {
         int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
-        st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
-        st[14] = run_rows; st[6] = n_runs;
+        if (cls == 1) {
+          st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
+          st[14] = run_rows; st[6] = n_runs;
+        } else {
+          st[15] = n_iter;                                   // steps of the class-0 solver
+        }
       }
     }
   } else if (wave == 1) {
@@ -389,6 +381,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
     for (int q = 0; q < W; ++q) pf_raw.w[q] = ~0u;
     int32_t pf_rot = 0, pf_ow = 0;
+    int32_t listed[2] = {0, 0};                             // rows appended to the two claim lists (wave-uniform)
     int64_t f_iter = 0, f_idle = 0;
     for (;;) {
       kasw::repoll();
@@ -452,8 +445,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       for (int q = 0; q < W; ++q) { m[q] = dep[hn[q]]; base[q] = (uint32_t)run[hn[q]]; }
       kasw::lockstep();
       uint32_t tk[W];
+      bool dense = false;                                   // a node of mine that many rows of this tile hold
 #pragma unroll
       for (int q = 0; q < W; ++q) {
+        dense = dense || (q < Lp && kasw::popc(m[q]) >= KAS_WIDE_CHAIN_DENSITY);
         tk[q] = base[q] + (uint32_t)kasw::popc(m[q] & lt);
         // the lowest lane holding the node moves its running count on and clears the mask
         const uint32_t wn = (m[q] & lt) == 0ull ? hn[q] : pad;
@@ -471,7 +466,22 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         o.rot = rotw; o.spare = 0;
         o.tag = staging_end ? KAS_TAG_END : ((jl & KAS_TAG_JMASK) | (Lp << 26));
         ring[(jl & (K - 1)) * 64 + lane] = o;
-        jl += 1;
+      }
+      {
+        // claim lists: the slot of every staged row goes to the end of its class's list, then the
+        // list's length is published (this wave's LDS writes land in issue order: slot, entry, length)
+        const bool row = staging && !staging_end;
+        const uint64_t b1 = kasw::ballot(row && dense), b0 = kasw::ballot(row && !dense);
+        kasw::lockstep();
+        if (row) {
+          const int32_t at = dense ? listed[1] + kasw::popc(b1 & lt) : listed[0] + kasw::popc(b0 & lt);
+          clist[(dense ? K * 64 : 0) + (at & (K * 64 - 1))] = (uint16_t)((jl & (K - 1)) * 64 + lane);
+        }
+        listed[0] += kasw::popc(b0); listed[1] += kasw::popc(b1);
+        kasw::lockstep();
+        const uint32_t endbit = kasw::ballot(staging_end) != 0ull ? 0x80000000u : 0u;
+        if (lane < 2) *(volatile uint32_t*)&lstate[lane] = (uint32_t)(lane == 0 ? listed[0] : listed[1]) | endbit;
+        if (staging) jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;
       if (watchdog_poll(wd, true, wd_idle)) break;
