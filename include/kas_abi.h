@@ -280,6 +280,8 @@ int kas_plan_set_flags(kas_plan* plan, uint32_t flags);
  *                [6] steps that took the queue path  [10] wins / prefix-sum rounds spent there
  *                [14] rows decided inside queues  [15] sum over steps of rows in hand
  *                [12] stager iterations  [13] of those without work
+ *   wide ticket form (lists 4, 5 wide): [9]..[11], [6], [14] are the class-1 solver's, [15] = steps of
+ *                the first class-0 solver
  *   ([4], [5] count wave 0's share of the P4 windows / node positions)
  * n = capacity of out in int64 elements (>= KAS_STATS_PER_SCENARIO * n_scenarios).  Blocks until the
  * plan's last launch has finished. */

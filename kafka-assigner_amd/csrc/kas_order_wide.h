@@ -64,7 +64,14 @@ namespace kas {
 #ifndef KAS_WIDE_CHAIN_DENSITY
 #define KAS_WIDE_CHAIN_DENSITY 3
 #endif
-#define KAS_WIDE_SOLVER_WAVE(w) ((w) == 0 || (w) == 3)
+// wavefronts of the workgroup: 0 stages, 1 solves class 1, 2 retires, 3 .. 3 + KAS_WIDE_BULK_SOLVERS - 1
+// solve class 0 (solver b takes the list entries b, b + NB, ...: in row order each, no claim races).
+// A workgroup's waves go round the four SIMDs, so wave 4 shares its SIMD with the staging wave, not
+// with the class-1 solver.
+#define KAS_WIDE_WAVES (3 + KAS_WIDE_BULK_SOLVERS)
+#define KAS_WIDE_STAGER 0
+#define KAS_WIDE_CHAIN_SOLVER 1
+#define KAS_WIDE_RETIRER 2
 // A queue usually breaks at a row that also waits for a row of its own tile; that row is free one
 // step later.  Skipping the queue pass of that step lets the next pass take the whole rest of the
 // queue instead of two passes taking half each.
@@ -144,8 +151,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   uint16_t* clist = (uint16_t*)(ring + K * 64);             // [2][K * 64] claim lists: ring slot of the class's next rows
   uint64_t* gdig = (uint64_t*)(clist + 2 * K * 64);
   uint32_t* lstate = (uint32_t*)(gdig + 1);                 // [2] rows appended to each list | 1 << 31 once staging has ended
-  uint32_t* rank_owner_all = (uint32_t*)(gdig + 2);         // [2][64] queue scratch of the solvers: rank -> lane
-  uint32_t* wd = rank_owner_all + 128;                      // watchdog word (debug builds, see watchdog_poll)
+  uint32_t* rank_owner_all = (uint32_t*)(gdig + 2);         // [1 + NB][64] queue scratch of the solvers: rank -> lane
+  uint32_t* wd = rank_owner_all + 64 * (1 + KAS_WIDE_BULK_SOLVERS);                      // watchdog word (debug builds, see watchdog_poll)
   // padding holder: a ticket that always matches its commits; never picked (pick_row looks at Lp cells)
   const int32_t dummy_e = (KAS_WIDE_DUMMY_TICKET << 16) | (nmax * 8);
 
@@ -153,9 +160,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
   if (have_s) sd = a.scen[s];
   const int32_t* g_node_id = a.node_id + sd.node_off;
-  for (int32_t n = lane + 64 * wave; n <= nmax; n += 256) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; }
-  for (int32_t k = wave; k < K; k += 4) ring[k * 64 + lane].tag = KAS_TAG_FREE;
-  if (wave < 2) rank_owner_all[wave * 64 + lane] = 0u;
+  constexpr int NB = KAS_WIDE_BULK_SOLVERS;
+  for (int32_t n = lane + 64 * wave; n <= nmax; n += 64 * KAS_WIDE_WAVES) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; }
+  for (int32_t k = wave; k < K; k += KAS_WIDE_WAVES) ring[k * 64 + lane].tag = KAS_TAG_FREE;
+  for (int32_t k = wave; k < 1 + NB; k += KAS_WIDE_WAVES) rank_owner_all[k * 64 + lane] = 0u;
   if (wave == 2 && lane < 2) lstate[lane] = 0u;
   kasw::sync();
   if (wave == 0 && lane == 0) {
@@ -167,11 +175,12 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   kasw::sync();
   int32_t wd_idle = 0;
 
-  if (KAS_WIDE_SOLVER_WAVE(wave)) {
+  if (wave == KAS_WIDE_CHAIN_SOLVER || wave >= 3) {
     // ------------------------------------------------------------------ solvers: LDS only
-    // a lane without a row claims the next entry of its class's list (rows in row order)
-    const int32_t cls = wave == 0 ? 1 : 0;
-    uint32_t* rank_owner = rank_owner_all + cls * 64;
+    // a lane without a row claims the next entry of its share of its class's list (rows in row order)
+    const int32_t cls = wave == KAS_WIDE_CHAIN_SOLVER ? 1 : 0;
+    const int32_t stride = cls ? 1 : NB, first = cls ? 0 : wave - 3;    // my entries: first, first + stride, ...
+    uint32_t* rank_owner = rank_owner_all + (cls ? 0 : 1 + first) * 64;
     const uint16_t* my_list = clist + cls * (K * 64);
     int32_t e[W], Lp = 0, rot = 0;
 #pragma unroll
@@ -180,6 +189,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     bool cv = false, gfin = false;
     int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
+#ifdef KAS_WIDE_DIAG
+    int64_t dg_hold = 0, dg_cand = 0, dg_qlen = 0, dg_inhand = 0;
+#endif
     const int64_t t_begin = kasw::clock_ticks();
     kasw::set_priority<3>();
     for (;;) {
@@ -235,6 +247,12 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           const uint64_t hb = kasw::ballot(have);
           const int32_t qlen = ~hb != 0ull ? kasw::first_lane(~hb) : 64;   // ranks 0..qlen-1 are all in hand
           const bool member = cand && (int32_t)kx < qlen;
+#ifdef KAS_WIDE_DIAG
+          dg_hold += kasw::popc(kasw::ballot(cv && hx >= 0));
+          dg_cand += kasw::popc(kasw::ballot(cand));
+          dg_qlen += qlen;
+          dg_inhand += kasw::popc(kasw::ballot(cv));
+#endif
           const int32_t gain = kasw::popc(kasw::ballot(member && kx > 0u));
           if (gain < KAS_WIDE_MIN_GAIN) {
             run_backoff = run_backoff == 0 ? 1 : (run_backoff < KAS_WIDE_BACKOFF_MAX ? 2 * run_backoff : KAS_WIDE_BACKOFF_MAX);
@@ -316,9 +334,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         }
       }
       ready = ready || ready_q;
-      int32_t pos[W];
-      pick_row_packed<W>(c, Lp, cv, rot, pos);
-      if (ready) {
+      if (ready) {                                          // (a step in which nothing is ready skips all of it)
+        int32_t pos[W];
+        pick_row_packed<W>(c, Lp, cv, rot, pos);
         // updateCountersFromList (KAS:254-261): count[node][r] += 1 (positions behind the list: + 0)
         int32_t tag = KAS_WTAG_DONE | (Lp << 15);
 #pragma unroll
@@ -337,8 +355,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         kasw::repoll();                                      // list and slots are read after the count that covers them
         const int32_t staged = (int32_t)(st & 0x7fffffffu);
         const int32_t k = kasw::popc(nbm & ((1ull << lane) - 1ull));
-        const bool take = need && cn + k < staged;
-        const int32_t slot = take ? (int32_t)my_list[(cn + k) & (K * 64 - 1)] : my_slot;
+        const int32_t at = (cn + k) * stride + first;
+        const bool take = need && at < staged;
+        const int32_t slot = take ? (int32_t)my_list[at & (K * 64 - 1)] : my_slot;
         const WideSlot sl = ring[slot];
         if (take) {
 #pragma unroll
@@ -349,7 +368,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           cv = true;
         }
         cn += kasw::popc(kasw::ballot(take));
-        gfin = (st >> 31) != 0u && cn == staged;             // the list is complete and claimed
+        gfin = (st >> 31) != 0u && cn * stride + first >= staged;   // the list is complete and my share claimed
       }
       const bool fin = gfin && !cv;
       if (kasw::ballot(!fin) == 0) break;
@@ -364,12 +383,15 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         if (cls == 1) {
           st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
           st[14] = run_rows; st[6] = n_runs;
-        } else {
-          st[15] = n_iter;                                   // steps of the class-0 solver
+#ifdef KAS_WIDE_DIAG
+          st[4] = dg_hold; st[5] = dg_cand; st[7] = dg_qlen; st[3] = dg_inhand;
+#endif
+        } else if (first == 0) {
+          st[15] = n_iter;                                   // steps of the first class-0 solver
         }
       }
     }
-  } else if (wave == 1) {
+  } else if (wave == KAS_WIDE_STAGER) {
     // ------------------------------------------------------------------ stager: tickets + staging
     const uint64_t mybit = 1ull << lane;
     const uint64_t lt = mybit - 1ull;

@@ -144,14 +144,18 @@ KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed
 #ifndef KAS_WIDE_RING_SLOTS
 #define KAS_WIDE_RING_SLOTS 8
 #endif
+// solver wavefronts for the rows that do not sit on a broker being filled (kas_order_wide.h)
+#ifndef KAS_WIDE_BULK_SOLVERS
+#define KAS_WIDE_BULK_SOLVERS 2
+#endif
 // counter rows + lane masks + running tickets per node, the ring, the two claim lists, digest and list
-// lengths, the two solvers' queue scratch, the watchdog word
+// lengths, the solvers' queue scratch, the watchdog word
 KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
   return kas_align16(2 * (int64_t)kas_align16(8 * (n + 1)) + kas_align16(2 * (n + 1)) +
-                     KAS_WIDE_RING_SLOTS * 64 * 32 + 2 * KAS_WIDE_RING_SLOTS * 64 * 2 + 16 + 512 + 16);
+                     KAS_WIDE_RING_SLOTS * 64 * 32 + 2 * KAS_WIDE_RING_SLOTS * 64 * 2 + 16 + 256 * (1 + KAS_WIDE_BULK_SOLVERS) + 16);
 }
-#define KAS_ORDER_WIDE_BLOCK 256      // two solver wavefronts, the staging and the retiring one
+#define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {
   int64_t n = n_max > 0 ? n_max : 1;
