@@ -76,6 +76,13 @@ __global__ __launch_bounds__(KAS_ORDER_WIDE_BLOCK) void kas_order_wide_kernel(Ka
   kas::order_tickets_wide<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
+// tuning builds only: extra dynamic LDS per workgroup, to measure how much residency is worth
+#ifndef KAS_TUNE_ORDER_LDS_PAD
+#define KAS_TUNE_ORDER_LDS_PAD 0
+#endif
+#ifndef KAS_TUNE_FILL_LDS_PAD
+#define KAS_TUNE_FILL_LDS_PAD 0
+#endif
 typedef void (*kas_kernel_fn)(KasLaunch);
 #if defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES == 5
 // tuning build for BASELINE.json configs[4] (lists 5 wide, 4 fill waves): seconds to compile
@@ -319,12 +326,12 @@ static int upload(void** dst, const void* src, size_t bytes, hipStream_t st) {
 // opt every kernel this plan may launch into its dynamic LDS size
 static int kas_plan_set_kernels(kas_plan* p) {
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  p->fused && p->lds_fused.total > p->lds.total ? p->lds_fused.total : p->lds.total));
+                                  (p->fused && p->lds_fused.total > p->lds.total ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD));
   if (p->Wc <= 3 && kas_order_ticket_for(p->Wc, p->G, 0))
     for (int pk = 0; pk < 2; ++pk)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kas_order_ticket_lds(p->shape.n_max, p->G, pk)));
+                                      kas_order_ticket_lds(p->shape.n_max, p->G, pk) + KAS_TUNE_ORDER_LDS_PAD));
   if (p->shape.round_fits)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -435,10 +442,10 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G;
   lp.wide = !lp.tickets && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
-  lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total);
+  lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD;
   if (lp.tickets) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
-    lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed);
+    lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed) + KAS_TUNE_ORDER_LDS_PAD;
   } else if (lp.wide) {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = (unsigned)KAS_ORDER_WIDE_BLOCK;
     lp.order_lds = (size_t)kas_order_wide_lds(p->shape.n_max);
