@@ -202,8 +202,8 @@ def test_emu_topic_without_rows_next_to_full_width_topics():
 
 
 @pytest.mark.parametrize("P,N,R,RF,actions,rack_aware", [
-    (9000, 120, 12, 5, ("add_k",), False),    # one broker at a time fills up: long single-node queues
-    (9000, 120, 12, 4, ("mixed",), True),     # rack constraints interleave several nodes being filled
+    (6000, 120, 12, 5, ("add_k",), False),    # one broker at a time fills up: long single-node queues
+    (6000, 120, 12, 4, ("mixed",), True),     # rack constraints interleave several nodes being filled
     (3000, 120, 12, 5, G.ACTIONS, True),
     (777, 40, 10, 4, G.ACTIONS, True),
 ])
@@ -214,7 +214,7 @@ def test_emu_wide_lists_take_the_wide_ticket_form(P, N, R, RF, actions, rack_awa
     want = oracle_solve(fb)
     assert (want.scenario_results["status"] == abi.KAS_OK).any()
     assert_same_outputs(fb, want, emu_solve(fb), "emu wide tickets")
-    if P >= 9000:
+    if P >= 6000:
         assert last_queue_rows() > 0, "the queue path of the wide kernel did not run"
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1 | (2 << 8)), "emu wide tickets after the general fill, 2 waves")
