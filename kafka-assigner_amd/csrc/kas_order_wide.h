@@ -62,7 +62,7 @@ namespace kas {
 #endif
 // rows of one staged tile on the same node from which the node counts as "being filled" (class 1)
 #ifndef KAS_WIDE_CHAIN_DENSITY
-#define KAS_WIDE_CHAIN_DENSITY 3
+#define KAS_WIDE_CHAIN_DENSITY 2
 #endif
 // wavefronts of the workgroup: 0 stages, 1 solves class 1, 2 retires, 3 .. 3 + KAS_WIDE_BULK_SOLVERS - 1
 // solve class 0 (solver b takes the list entries b, b + NB, ...: in row order each, no claim races).
@@ -77,6 +77,22 @@ namespace kas {
 // queue instead of two passes taking half each.
 #ifndef KAS_WIDE_SKIP_AFTER_PASS
 #define KAS_WIDE_SKIP_AFTER_PASS 0
+#endif
+// Joint solve (KAS_WIDE_JOINT 1, the default): every row in hand whose pending holders are all among
+// KAS_WIDE_HOT nominated nodes — and whose predecessors on those nodes are in hand and decidable too — is
+// decided in one step, rows that sit in TWO queues included (0: the single-node threshold queues above).
+#ifndef KAS_WIDE_JOINT
+#define KAS_WIDE_JOINT 1
+#endif
+// naming the nodes of the joint solve: 0 = by rows that are third in line on one node and wait for nothing
+// else; k > 0 = every row with two or more rows ahead of it names its deepest queue, and the most named
+// nodes among the first KAS_WIDE_HOT + k names are taken
+#ifndef KAS_WIDE_VOTE
+#define KAS_WIDE_VOTE 1
+#endif
+// side dependencies of the joint solve (0: rows that wait on a node that is not named are left out)
+#ifndef KAS_WIDE_SIDE
+#define KAS_WIDE_SIDE 1
 #endif
 #define KAS_WIDE_FIELD_MASK 0x3ffu
 #define KAS_WIDE_DUMMY_TICKET 0xfff                      // the padding holder's ticket == its row's commits field
@@ -151,8 +167,11 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   uint16_t* clist = (uint16_t*)(ring + K * 64);             // [2][K * 64] claim lists: ring slot of the class's next rows
   uint64_t* gdig = (uint64_t*)(clist + 2 * K * 64);
   uint32_t* lstate = (uint32_t*)(gdig + 1);                 // [2] rows appended to each list | 1 << 31 once staging has ended
-  uint32_t* rank_owner_all = (uint32_t*)(gdig + 2);         // [1 + NB][64] queue scratch of the solvers: rank -> lane
-  uint32_t* wd = rank_owner_all + 64 * (1 + KAS_WIDE_BULK_SOLVERS);                      // watchdog word (debug builds, see watchdog_poll)
+  uint32_t* rank_owner_all = (uint32_t*)(gdig + 2);         // [1 + NB][KAS_WIDE_HOT][64] queue scratch of the solvers: rank -> lane
+  uint32_t* wd = rank_owner_all + 64 * KAS_WIDE_HOT * (1 + KAS_WIDE_BULK_SOLVERS);       // watchdog word (debug builds, see watchdog_poll)
+  // front[n] = the class-1 solver's row in hand that is next to commit on node n: step stamp << 11 | the
+  // node's position in that row's list << 8 | lane (joint solve, side dependencies)
+  uint32_t* front = wd + 4;                                 // [nmax + 1]
   // padding holder: a ticket that always matches its commits; never picked (pick_row looks at Lp cells)
   const int32_t dummy_e = (KAS_WIDE_DUMMY_TICKET << 16) | (nmax * 8);
 
@@ -161,9 +180,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   if (have_s) sd = a.scen[s];
   const int32_t* g_node_id = a.node_id + sd.node_off;
   constexpr int NB = KAS_WIDE_BULK_SOLVERS;
-  for (int32_t n = lane + 64 * wave; n <= nmax; n += 64 * KAS_WIDE_WAVES) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; }
+  for (int32_t n = lane + 64 * wave; n <= nmax; n += 64 * KAS_WIDE_WAVES) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; front[n] = 0u; }
   for (int32_t k = wave; k < K; k += KAS_WIDE_WAVES) ring[k * 64 + lane].tag = KAS_TAG_FREE;
-  for (int32_t k = wave; k < 1 + NB; k += KAS_WIDE_WAVES) rank_owner_all[k * 64 + lane] = 0u;
+  for (int32_t k = wave; k < KAS_WIDE_HOT * (1 + NB); k += KAS_WIDE_WAVES) rank_owner_all[k * 64 + lane] = 0u;
   if (wave == 2 && lane < 2) lstate[lane] = 0u;
   kasw::sync();
   if (wave == 0 && lane == 0) {
@@ -180,7 +199,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     // a lane without a row claims the next entry of its share of its class's list (rows in row order)
     const int32_t cls = wave == KAS_WIDE_CHAIN_SOLVER ? 1 : 0;
     const int32_t stride = cls ? 1 : NB, first = cls ? 0 : wave - 3;    // my entries: first, first + stride, ...
-    uint32_t* rank_owner = rank_owner_all + (cls ? 0 : 1 + first) * 64;
+    uint32_t* rank_owner = rank_owner_all + (cls ? 0 : 1 + first) * (64 * KAS_WIDE_HOT);
     const uint16_t* my_list = clist + cls * (K * 64);
     int32_t e[W], Lp = 0, rot = 0;
 #pragma unroll
@@ -189,8 +208,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     bool cv = false, gfin = false;
     int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
+    uint32_t fstep = 0u;                                     // stamp of the front[] entries of the current step (never 0)
 #ifdef KAS_WIDE_DIAG
-    int64_t dg_hold = 0, dg_cand = 0, dg_qlen = 0, dg_inhand = 0;
+    int64_t dg_hold = 0, dg_cand = 0, dg_qlen = 0, dg_inhand = 0, dg_c1 = 0, dg_c2 = 0, dg_c4 = 0, dg_steps = 0, dg_a = 0, dg_b = 0, dg_b3 = 0;
 #endif
     const int64_t t_begin = kasw::clock_ticks();
     kasw::set_priority<3>();
@@ -200,6 +220,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       // the counter rows of the row in hand
       int32_t c[W][W];                                      // c[k][r] = count[holder k][replica index r]
       uint32_t d[W];                                        // rows still ahead of mine on holder k
+#if KAS_WIDE_JOINT
+      uint32_t xlo[W], xhi[W];                              // the counter rows as loaded (joint solve: packed adds)
+#endif
 #pragma unroll
       for (int q = 0; q < W; ++q) {
         const uint64_t x = *(const uint64_t*)(lds_raw + (e[q] & 0xffff));
@@ -209,6 +232,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
         for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];   // (the last index is never compared: dead code)
         d[q] = ((uint32_t)e[q] >> 16) - (hi >> 20);           // ticket - commits on the node
+#if KAS_WIDE_JOINT
+        xlo[q] = lo; xhi[q] = hi;
+#endif
       }
       uint32_t d_any = 0u, d_sum = 0u;
       int32_t nz = 0;                                       // holders I wait on
@@ -216,6 +242,259 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       for (int q = 0; q < W; ++q) { d_any |= d[q]; d_sum += d[q]; nz += d[q] != 0u ? 1 : 0; }
       bool ready = cv && d_any == 0u;
       bool ready_q = false;                                 // decided inside a queue in this step
+#if KAS_WIDE_JOINT
+      // ---- joint solve.  Up to KAS_WIDE_HOT nodes are named by rows that wait on one node only (the
+      // brokers first fit is filling).  A row in hand is ELIGIBLE when it waits on named nodes only and,
+      // on each of them, every row ahead of it (ranks 0 .. its own - 1, rank = ticket - commits) is in
+      // this wave's hand and eligible too; the eligible set is then closed under "earlier uncommitted row
+      // on one of my nodes", so deciding it in row order is all the sequential algorithm would do next
+      // on these nodes.  The counts row i sees on a named node are the node's counts now plus the
+      // wins of the eligible rows ahead of it there: picks -> per-position prefix sums over each node's
+      // rank layout -> picks are re-evaluated until nothing changes (the earliest row is right after
+      // round 1, a row of dependency depth k after round k), and the whole set commits in this step —
+      // rows that sit in two queues included.
+      bool have_pos = false;                                // wave-uniform: pos[] is final for every row that commits
+      int32_t pos[W];
+#pragma unroll
+      for (int r = 0; r < W; ++r) pos[r] = 0;
+      {
+        uint64_t nb = 0ull;
+        if (run_skip > 0) run_skip -= 1;
+#if KAS_WIDE_VOTE
+        else nb = kasw::ballot(cv && d_any > 1u);           // a row with two or more rows ahead of it on some node
+#else
+        else nb = kasw::ballot(cv && nz == 1 && d_sum == (uint32_t)KAS_WIDE_NOMINATE);   // third in line on X, free otherwise
+#endif
+        if (nb != 0ull) {
+          constexpr int KH = KAS_WIDE_HOT;
+          int32_t my_ax = 0;
+#if KAS_WIDE_VOTE
+          {                                                 // a row names the node on which most rows are ahead of it
+            uint32_t dm = 0u;
+#pragma unroll
+            for (int q = 0; q < W; ++q) { my_ax = d[q] > dm ? (e[q] & 0xffff) : my_ax; dm = d[q] > dm ? d[q] : dm; }
+          }
+#else
+#pragma unroll
+          for (int q = 0; q < W; ++q) my_ax = d[q] != 0u ? (e[q] & 0xffff) : my_ax;       // (a nominating row waits on one node)
+#endif
+          int32_t dcol[W];
+#pragma unroll
+          for (int q = 0; q < W; ++q) dcol[q] = (int32_t)d[q];
+          int32_t hq[KH];                                   // where named node h sits in my (ascending) list, or -1
+          uint32_t kx[KH], d_hot = 0u;                      // my rank in its queue
+          {
+            uint64_t rest = nb;
+#if KAS_WIDE_VOTE
+            // the KH most named nodes among the first KH + KAS_WIDE_VOTE candidates (names of the lowest lanes)
+            constexpr int KC = KH + KAS_WIDE_VOTE;
+            int32_t cand_ax[KC], cand_n[KC];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+              cand_ax[k] = -1 - k; cand_n[k] = 0;
+              if (rest != 0ull) {
+                cand_ax[k] = kasw::read_lane(my_ax, kasw::first_lane(rest));
+                const uint64_t sup = kasw::ballot(my_ax == cand_ax[k]) & nb;
+                cand_n[k] = kasw::popc(sup);
+                rest &= ~sup;
+              }
+            }
+#endif
+#pragma unroll
+            for (int h = 0; h < KH; ++h) {
+              int32_t ax = -1;                              // (no holder entry has this address)
+#if KAS_WIDE_VOTE
+              {
+                int32_t best = 0;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { ax = cand_n[k] > best ? cand_ax[k] : ax; best = cand_n[k] > best ? cand_n[k] : best; }
+#pragma unroll
+                for (int k = 0; k < KC; ++k) cand_n[k] = cand_ax[k] == ax ? 0 : cand_n[k];
+              }
+#else
+              if (rest != 0ull) ax = kasw::read_lane(my_ax, kasw::first_lane(rest));
+              rest &= ~kasw::ballot(my_ax == ax);
+#endif
+              hq[h] = -1;
+#pragma unroll
+              for (int q = 0; q < W; ++q) hq[h] = (e[q] & 0xffff) == ax ? q : hq[h];
+              kx[h] = hq[h] >= 0 ? (uint32_t)sel<W>(dcol, hq[h]) : 0u;
+              d_hot += kx[h];
+            }
+          }
+          // Side dependency (class-1 solver): besides named nodes a row may wait on ONE other node with
+          // exactly one row ahead of it there, if that row is in this wave's hand too (two rows of the
+          // hand that share an old broker: at configs[4] one row in five of a full hand).  The row ahead
+          // is next to commit on that node, so it sees the node's counts as they are and the row behind
+          // sees them plus its one increment.
+          bool side = false;
+          int32_t qs = 0, pl = lane, pk = 0;                // my list position of that node; lane and list position of the row ahead
+          if (KAS_WIDE_SIDE && cls != 0) {                  // wave-uniform
+            fstep = (fstep + 1u) & 0x1fffffu;
+            if (fstep == 0u) {                              // the stamp wrapped: forget every old entry
+              for (int32_t n = lane; n <= nmax; n += 64) front[n] = 0u;
+              fstep = 1u;
+              kasw::lockstep();
+            }
+#pragma unroll
+            for (int q = 0; q < W; ++q)
+              if (cv && q < Lp && d[q] == 0u) front[(e[q] & 0xffff) >> 3] = (fstep << 11) | ((uint32_t)q << 8) | (uint32_t)lane;
+            kasw::lockstep();
+            const bool one = cv && d_sum == d_hot + 1u;     // one row ahead on one node that is not named
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+              bool named = false;
+#pragma unroll
+              for (int h = 0; h < KH; ++h) named = named || hq[h] == q;
+              qs = (one && d[q] == 1u && !named) ? q : qs;
+            }
+            const uint32_t f = one ? front[(sel<W>(e, qs) & 0xffff) >> 3] : 0u;
+            side = one && (f >> 11) == fstep;
+            pl = side ? (int32_t)(f & 0xffu) : lane;
+            pk = (int32_t)((f >> 8) & 7u);
+            kasw::lockstep();
+          }
+          bool elig = cv && (d_sum == d_hot || side);       // waits on named nodes (and its side dependency) only
+#ifdef KAS_WIDE_DIAG
+          const bool elig_first = elig;
+          {
+            const bool one_d = cv && d_sum == d_hot + 1u;
+            dg_c1 += kasw::popc(kasw::ballot(cv && d_sum > d_hot + 1u));          // more than one row ahead on nodes that are not named
+            int32_t nzo = 0; uint32_t dmx = 0u;
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+              bool named = false;
+#pragma unroll
+              for (int h = 0; h < KH; ++h) named = named || hq[h] == q;
+              nzo += (!named && d[q] != 0u) ? 1 : 0;
+              dmx = (!named && d[q] > dmx) ? d[q] : dmx;
+            }
+            dg_a += kasw::popc(kasw::ballot(cv && nzo == 2 && dmx == 1u));        // two nodes, one row ahead on each
+            dg_b += kasw::popc(kasw::ballot(cv && nzo == 1 && dmx == 2u));        // one node, two rows ahead
+            dg_b3 += kasw::popc(kasw::ballot(cv && nzo == 1 && dmx > 2u));        // one node, more rows ahead
+            dg_c2 += kasw::popc(kasw::ballot(one_d && !side));                    // one row ahead, not in my hand
+          }
+#endif
+#pragma unroll
+          for (int h = 0; h < KH; ++h) elig = elig && kx[h] < 64u;
+          uint32_t ow[KH];
+          bool have[KH];
+          int32_t qlen[KH];
+          for (;;) {                                        // closure: drop rows behind a gap in one of their queues
+            n_runs += 1;
+            const uint32_t seq = (uint32_t)(n_runs & 0xffffff);             // never 0: stale and initial entries differ
+#pragma unroll
+            for (int h = 0; h < KH; ++h)
+              if (elig && hq[h] >= 0) rank_owner[h * 64 + (int32_t)kx[h]] = (seq << 8) | (uint32_t)lane;
+            kasw::lockstep();
+#pragma unroll
+            for (int h = 0; h < KH; ++h) ow[h] = rank_owner[h * 64 + lane];   // rank view: lane = rank
+            kasw::lockstep();
+            bool ok = elig;
+#pragma unroll
+            for (int h = 0; h < KH; ++h) {
+              have[h] = (ow[h] >> 8) == seq;
+              const uint64_t hb = kasw::ballot(have[h]);
+              qlen[h] = ~hb != 0ull ? kasw::first_lane(~hb) : 64;           // ranks 0..qlen-1 are all eligible rows in hand
+              ok = ok && (hq[h] < 0 || (int32_t)kx[h] < qlen[h]);
+            }
+            if (KAS_WIDE_SIDE && cls != 0) {                // the row ahead on my side node must be decided here too
+              const int32_t ahead = kasw::shfl(elig ? 1 : 0, pl);
+              ok = ok && (ahead != 0 || !side);
+            }
+            if (kasw::ballot(elig && !ok) == 0ull) break;
+            elig = ok;
+          }
+          const bool extra = elig && d_any != 0u;           // decided here, not ready by itself
+          const int32_t gain = kasw::popc(kasw::ballot(extra));
+#ifdef KAS_WIDE_DIAG
+          dg_inhand += kasw::popc(kasw::ballot(cv));
+          dg_hold += kasw::popc(kasw::ballot(cv && (hq[0] >= 0 || hq[KH - 1] >= 0)));
+          dg_cand += kasw::popc(kasw::ballot(cv && d_sum == d_hot));
+          dg_qlen += kasw::popc(kasw::ballot(elig));
+          dg_c4 += kasw::popc(kasw::ballot(elig_first && !elig));                 // behind a gap in a queue
+          dg_steps += 1;
+#endif
+          if (gain < KAS_WIDE_MIN_GAIN) {
+            run_backoff = run_backoff == 0 ? 1 : (run_backoff < KAS_WIDE_BACKOFF_MAX ? 2 * run_backoff : KAS_WIDE_BACKOFF_MAX);
+            run_skip = KAS_WIDE_BACKOFF_MAX > 0 ? run_backoff : 0;
+          } else {
+            if (gain > KAS_WIDE_MIN_GAIN) run_backoff = 0;
+            run_skip = KAS_WIDE_SKIP_AFTER_PASS;
+            // wins ahead of me on named node h, per replica index, packed like the low word of a counter
+            // row: index 0 at bit 0, 1 at bit 10, 2 at bit 20 (6 bits each: < 64 rows in a queue), 3 at
+            // bit 26.  A virtual count never leaves its 10-bit field: count + rows ahead of me on the node
+            // <= rows the node holds at the end < 1023.
+            uint32_t pp[KH];
+            bool on[KH], mq[KH][W];
+            int32_t sh3[KH], src_in[KH], src_out[KH];
+#pragma unroll
+            for (int h = 0; h < KH; ++h) {
+              pp[h] = 0u;
+              on[h] = elig && hq[h] >= 0;
+              sh3[h] = 3 * (hq[h] >= 0 ? hq[h] : 0);
+              src_in[h] = have[h] ? (int32_t)(ow[h] & 0xffu) : lane;       // owner -> rank view
+              src_out[h] = on[h] ? (int32_t)kx[h] : lane;                   // rank view -> owner
+#pragma unroll
+              for (int q = 0; q < W; ++q) mq[h][q] = hq[h] == q;
+            }
+            bool sq[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) sq[q] = side && qs == q;
+            int32_t rs = 7;                                 // the replica index my side node takes in the row ahead
+            for (;;) {
+              n_relax += 1;
+              const uint32_t s_lo = rs < 3 ? (1u << (10 * rs)) : 0u;   // (7 = no side dependency)
+              const uint32_t s_hi = rs == 3 ? 1u : 0u;
+              int32_t c2[W][W];
+#pragma unroll
+              for (int q = 0; q < W; ++q) {
+                uint32_t lo2 = xlo[q] + (sq[q] ? s_lo : 0u), hi2 = xhi[q] + (sq[q] ? s_hi : 0u);
+#pragma unroll
+                for (int h = 0; h < KH; ++h) {
+                  lo2 += mq[h][q] ? (pp[h] & 0x03ffffffu) : 0u;
+                  hi2 += mq[h][q] ? (pp[h] >> 26) : 0u;
+                }
+                c2[q][0] = (int32_t)(lo2 & KAS_WIDE_FIELD_MASK);
+                c2[q][1] = (int32_t)((lo2 >> 10) & KAS_WIDE_FIELD_MASK);
+                c2[q][2] = (int32_t)((lo2 >> 20) & KAS_WIDE_FIELD_MASK);
+                c2[q][3] = (int32_t)(hi2 & KAS_WIDE_FIELD_MASK);
+                if (W > 4) c2[q][W - 1] = 0;                // (the last index is never compared)
+              }
+              pick_row_packed<W>(c2, Lp, elig, rot, pos);
+              int32_t inv = 0;                              // replica index of each list position, 3 bits each
+#pragma unroll
+              for (int r = 0; r < W; ++r) inv |= (r < Lp ? r : 0) << (3 * pos[r]);   // (every holder gets one pick)
+              bool moved = false;
+              if (KAS_WIDE_SIDE && cls != 0) {              // wave-uniform
+                const int32_t got = kasw::shfl(inv, pl);
+                const int32_t nrs = side ? ((got >> (3 * pk)) & 7) : 7;
+                moved = nrs != rs;
+                rs = nrs;
+              }
+#pragma unroll
+              for (int h = 0; h < KH; ++h) {
+                const int32_t rh = on[h] ? ((inv >> sh3[h]) & 7) : 7;     // the replica index node h takes in my row
+                const int32_t v = kasw::shfl(rh, src_in[h]);
+                const int32_t v2 = lane < qlen[h] ? v : 7;
+                uint32_t pack = (uint32_t)kasw::count_below(kasw::ballot(v2 == 0));
+                pack |= (uint32_t)kasw::count_below(kasw::ballot(v2 == 1)) << 10;
+                pack |= (uint32_t)kasw::count_below(kasw::ballot(v2 == 2)) << 20;
+                pack |= (uint32_t)kasw::count_below(kasw::ballot(v2 == 3)) << 26;
+                const uint32_t back = (uint32_t)kasw::shfl((int32_t)pack, src_out[h]);
+                const uint32_t npp = on[h] ? back : 0u;
+                moved = moved || npp != pp[h];
+                pp[h] = npp;
+              }
+              if (kasw::ballot(moved) == 0ull) break;
+            }
+            n_run_rows += extra ? 1 : 0;
+            ready_q = elig;
+            have_pos = true;
+          }
+        }
+      }
+#else
       // ---- queues: rows in hand that hold one node X and wait for nothing but X
       {
         uint64_t nb = 0ull;
@@ -300,7 +579,6 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
             }
             const int32_t th = kasw::shfl(tpack, have ? (int32_t)(ow & 0xffu) : lane);   // owner -> rank view
             const bool act = lane < qlen;
-            const uint64_t ltm = (1ull << lane) - 1ull;
             int32_t pre[T];
 #pragma unroll
             for (int r = 0; r < T; ++r) pre[r] = 0;
@@ -312,7 +590,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
               for (int r = 0; r < T; ++r) {
                 const bool win = act && !won && pre[r] < ((th >> (8 * r)) & 0xff);
                 won = won || win;
-                np[r] = kasw::popc(kasw::ballot(win) & ltm);
+                np[r] = kasw::count_below(kasw::ballot(win));
               }
 #pragma unroll
               for (int r = 0; r < T; ++r) { moved = moved || (act && np[r] != pre[r]); pre[r] = np[r]; }
@@ -333,10 +611,15 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           nb &= ~kasw::ballot(my_ax == ax);                 // next: a nominated row of another node
         }
       }
+#endif
       ready = ready || ready_q;
       if (ready) {                                          // (a step in which nothing is ready skips all of it)
+#if KAS_WIDE_JOINT
+        if (!have_pos) pick_row_packed<W>(c, Lp, cv, rot, pos);          // (wave-uniform test)
+#else
         int32_t pos[W];
         pick_row_packed<W>(c, Lp, cv, rot, pos);
+#endif
         // updateCountersFromList (KAS:254-261): count[node][r] += 1 (positions behind the list: + 0)
         int32_t tag = KAS_WTAG_DONE | (Lp << 15);
 #pragma unroll
@@ -354,7 +637,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         const uint32_t st = *(volatile uint32_t*)&lstate[cls];
         kasw::repoll();                                      // list and slots are read after the count that covers them
         const int32_t staged = (int32_t)(st & 0x7fffffffu);
-        const int32_t k = kasw::popc(nbm & ((1ull << lane) - 1ull));
+        const int32_t k = kasw::count_below(nbm);
         const int32_t at = (cn + k) * stride + first;
         const bool take = need && at < staged;
         const int32_t slot = take ? (int32_t)my_list[at & (K * 64 - 1)] : my_slot;
@@ -385,6 +668,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           st[14] = run_rows; st[6] = n_runs;
 #ifdef KAS_WIDE_DIAG
           st[4] = dg_hold; st[5] = dg_cand; st[7] = dg_qlen; st[3] = dg_inhand;
+          st[0] = dg_c1; st[1] = dg_c2; st[2] = dg_c4; st[13] = dg_steps; st[12] = dg_a; st[11] = dg_b; st[15] = dg_b3;
 #endif
         } else if (first == 0) {
           st[15] = n_iter;                                   // steps of the first class-0 solver
@@ -471,7 +755,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
       for (int q = 0; q < W; ++q) {
         dense = dense || (q < Lp && kasw::popc(m[q]) >= KAS_WIDE_CHAIN_DENSITY);
-        tk[q] = base[q] + (uint32_t)kasw::popc(m[q] & lt);
+        tk[q] = base[q] + (uint32_t)kasw::count_below(m[q]);
         // the lowest lane holding the node moves its running count on and clears the mask
         const uint32_t wn = (m[q] & lt) == 0ull ? hn[q] : pad;
         run[wn] = (uint16_t)(base[q] + (uint32_t)kasw::popc(m[q]));
@@ -496,7 +780,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         const uint64_t b1 = kasw::ballot(row && dense), b0 = kasw::ballot(row && !dense);
         kasw::lockstep();
         if (row) {
-          const int32_t at = dense ? listed[1] + kasw::popc(b1 & lt) : listed[0] + kasw::popc(b0 & lt);
+          const int32_t at = dense ? listed[1] + kasw::count_below(b1) : listed[0] + kasw::count_below(b0);
           clist[(dense ? K * 64 : 0) + (at & (K * 64 - 1))] = (uint16_t)((jl & (K - 1)) * 64 + lane);
         }
         listed[0] += kasw::popc(b0); listed[1] += kasw::popc(b1);

@@ -148,12 +148,17 @@ KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed
 #ifndef KAS_WIDE_BULK_SOLVERS
 #define KAS_WIDE_BULK_SOLVERS 2
 #endif
+// nodes whose queues one solver step of the wide kernel decides together (rank -> lane scratch per node)
+#ifndef KAS_WIDE_HOT
+#define KAS_WIDE_HOT 2
+#endif
 // counter rows + lane masks + running tickets per node, the ring, the two claim lists, digest and list
 // lengths, the solvers' queue scratch, the watchdog word
 KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
   return kas_align16(2 * (int64_t)kas_align16(8 * (n + 1)) + kas_align16(2 * (n + 1)) +
-                     KAS_WIDE_RING_SLOTS * 64 * 32 + 2 * KAS_WIDE_RING_SLOTS * 64 * 2 + 16 + 256 * (1 + KAS_WIDE_BULK_SOLVERS) + 16);
+                     KAS_WIDE_RING_SLOTS * 64 * 32 + 2 * KAS_WIDE_RING_SLOTS * 64 * 2 + 16 + 256 * KAS_WIDE_HOT * (1 + KAS_WIDE_BULK_SOLVERS) + 16 +
+                     kas_align16(4 * (n + 1)));   // + front[] of the class-1 solver
 }
 #define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]

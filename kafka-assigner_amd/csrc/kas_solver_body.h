@@ -270,7 +270,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
           for (int k = 0; k < W; ++k) want = want && !(k < hc && hr[k] == rk[u]);
           const uint64_t w = kasw::ballot(want);
           if (w != 0) {
-            const int32_t rank = kasw::popc(w & kasw::lanemask_lt());
+            const int32_t rank = kasw::count_below(w);
             if (want && rank < slots[u]) {                 // accept (KAS:178-181)
               mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
               put<W>(hr, hc, rk[u]);
@@ -523,7 +523,7 @@ KAS_DEV void ring_push(const LdsView& L, int32_t p, int32_t need, int32_t hc,
   const bool orphan = need > 0;
   const uint64_t om = kasw::ballot(orphan);
   if (orphan) {
-    const int32_t slot = ring_count + kasw::popc(om & kasw::lanemask_lt());
+    const int32_t slot = ring_count + kasw::count_below(om);
     L.ring_p[slot] = p;
     L.ring_meta[slot] = need | (hc << 8);
 #pragma unroll
@@ -609,7 +609,7 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
           const bool same_l = took && n == t;
           const uint64_t same = kasw::ballot(same_l);
           const int32_t before = L.load[t] - kasw::popc(same);
-          if (same_l) accepted = before + kasw::popc(same & lt) < cap;
+          if (same_l) accepted = before + kasw::count_below(same) < cap;
           kasw::lockstep();                                 // all lanes read load[t]
           if (lane == leader) L.load[t] = cap;
           todo &= ~same;
@@ -890,7 +890,7 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
 #pragma unroll
           for (int r = 0; r < W; ++r) hit |= (((counting >> r) & 1u) && nn[r] == t) ? (1u << r) : 0u;
           const uint64_t same = kasw::ballot(hit != 0u);
-          const int32_t rank = kasw::popc(same & lt);
+          const int32_t rank = kasw::count_below(same);
 #pragma unroll
           for (int r = 0; r < W; ++r)
             accbits |= (((hit >> r) & 1u) && rank < before[r]) ? (1u << r) : 0u;
@@ -902,7 +902,7 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
     int32_t need, hc, hrack[W];
     p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p);
     const uint64_t om = kasw::ballot(need > 0);
-    if (need > 0) olist[ocount + kasw::popc(om & lt)] = p;
+    if (need > 0) olist[ocount + kasw::count_below(om)] = p;
     ocount += kasw::popc(om);
   });
   return ocount;
@@ -1012,7 +1012,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
             for (int k = 0; k < W; ++k) want = want && !(k < hc && hr[k] == rk[u]);
             const uint64_t wm = kasw::ballot(want);
             if (wm != 0) {
-              const int32_t rank = kasw::popc(wm & kasw::lanemask_lt());
+              const int32_t rank = kasw::count_below(wm);
               if (want && rank < slots[u]) {               // accept (KAS:178-181)
                 T.mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
                 put<W>(hr, hc, rk[u]);
@@ -1244,7 +1244,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
       int32_t n = j + start; if (n >= N) n -= N;
       const bool is_live = j < N && L.load[n] < cap;
       const uint64_t m = kasw::ballot(is_live);
-      if (is_live) L.live[live_count + kasw::popc(m & lt)] = (int16_t)n;
+      if (is_live) L.live[live_count + kasw::count_below(m)] = (int16_t)n;
       live_count += kasw::popc(m);
     }
     kasw::lockstep();

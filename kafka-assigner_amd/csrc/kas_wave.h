@@ -28,7 +28,9 @@ KAS_DEV int tid() { return (int)threadIdx.x; }
 // wavefront index inside the workgroup (wave-uniform, kept in an SGPR)
 KAS_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-KAS_DEV uint64_t ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
+// (the builtin takes the predicate itself: __ballot(int) made the compiler materialise 0 / 1 in a VGPR
+// and compare it again wherever the predicate was an AND of lane masks)
+KAS_DEV uint64_t ballot(bool p) { return (uint64_t)__builtin_amdgcn_ballot_w64(p); }
 
 KAS_DEV int shfl(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
@@ -87,6 +89,12 @@ KAS_DEV int popc(uint64_t m) { return __popcll((unsigned long long)m); }
 KAS_DEV int first_lane(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
+
+// popc(m & lanemask_lt()): bits of m below this lane (v_mbcnt_lo / v_mbcnt_hi: two instructions, m may
+// differ per lane)
+KAS_DEV int count_below(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 KAS_DEV int lds_atomic_add(int* p, int v) { return atomicAdd(p, v); }
 KAS_DEV void lds_atomic_min(int* p, int v) { atomicMin(p, v); }

@@ -35,6 +35,8 @@ static uint32_t chaos_next() {
   return (uint32_t)(g_chaos >> 32);
 }
 
+long g_last_block_rounds = 0;   // scheduling rounds of the last run_block (KAS_EMU_STATS)
+
 int run_block(void (*fn)(void*), void* arg, int n_waves) {
   Emu& e = g_emu;
   static int chaos_init = 0;
@@ -42,6 +44,24 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
     chaos_init = 1;
     const char* c = getenv("KAS_EMU_CHAOS");
     if (c && *c) g_chaos = 0x9E3779B97F4A7C15ull * (uint64_t)(strtoull(c, nullptr, 10) + 1);
+  }
+  // KAS_EMU_WAVE_DIV="w:k[,w:k...]": wave w is released only every k-th scheduling round — a crude way
+  // of making one wavefront the slow one (on hardware the class-1 solver of the wide order kernel is the
+  // bottleneck and always has a full hand; with every wave at the same speed it is starved instead)
+  static int wave_div[KAS_EMU_MAX_LANES / 64];
+  static int div_init = 0;
+  if (!div_init) {
+    div_init = 1;
+    for (int w = 0; w < KAS_EMU_MAX_LANES / 64; ++w) wave_div[w] = 1;
+    const char* c = getenv("KAS_EMU_WAVE_DIV");
+    while (c && *c) {
+      char* end = nullptr;
+      const long w = strtol(c, &end, 10);
+      if (!end || *end != ':') break;
+      const long k = strtol(end + 1, &end, 10);
+      if (w >= 0 && w < KAS_EMU_MAX_LANES / 64 && k >= 1) wave_div[w] = (int)k;
+      c = (*end == ',') ? end + 1 : nullptr;
+    }
   }
   int held_wave = -1;
   long held_rounds = 0, rounds = 0;
@@ -69,7 +89,7 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
       ++ran;
       if (e.state[i] == S_DONE) ++done;
     }
-    if (done == n) return 0;
+    if (done == n) { g_last_block_rounds = rounds; return 0; }
     // 2. release every wave whose 64 fibers all wait at the same wave collective; a workgroup
     //    barrier releases when every fiber of the block waits at it
     int released = 0, at_sync = 0, n_ready = 0;
@@ -106,6 +126,7 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
         const int w = ready_waves[r];
         bool go = true;
         if (g_chaos != 0 && n_waves > 1) go = w != held_wave && (chaos_next() & 1u) != 0;
+        if (wave_div[w] > 1 && n_waves > 1 && (rounds % wave_div[w]) != 0) go = false;
         if (!go) continue;
         for (int i = 64 * w; i < 64 * w + 64; ++i) e.state[i] = S_RUNNABLE;
         ++released; e.collectives++;
@@ -301,8 +322,11 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if (getenv("KAS_EMU_STATS")) {
       for (int32_t s = 0; s < b->n_scenarios; ++s) {
         const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
-        fprintf(stderr, "emu stats (wide) s=%d solver_iter=%lld bulk_solver_iter=%lld queue_passes=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld\n", s,
-                (long long)st[9], (long long)st[15], (long long)st[6], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12]);
+        fprintf(stderr, "emu stats (wide) s=%d solver_iter=%lld bulk_solver_iter=%lld queue_passes=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld stager_idle=%lld sched_rounds(last block)=%ld\n", s,
+                (long long)st[9], (long long)st[15], (long long)st[6], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12],
+                (long long)st[13], kasw::g_last_block_rounds);
+        fprintf(stderr, "emu diag (wide, -DKAS_WIDE_DIAG) joint_steps=%lld in_hand=%lld hold_hot=%lld wait_hot_only=%lld eligible=%lld | not eligible: many_ahead_elsewhere=%lld one_ahead_not_in_hand=%lld behind_gap=%lld (two_nodes_one_each=%lld one_node_two_ahead=%lld one_node_more=%lld)\n",
+                (long long)st[13], (long long)st[3], (long long)st[4], (long long)st[5], (long long)st[7], (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[12], (long long)st[11], (long long)st[15]);
       }
     }
   } else {

@@ -89,6 +89,7 @@ KAS_DEV int32_t opaque(int32_t v) { return v; }
 KAS_DEV int popc(uint64_t m) { return __builtin_popcountll(m); }
 KAS_DEV int first_lane(uint64_t m) { return __builtin_ctzll(m); }
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
+KAS_DEV int count_below(uint64_t m) { return __builtin_popcountll(m & lanemask_lt()); }
 
 KAS_DEV int lds_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 KAS_DEV void lds_atomic_min(int* p, int v) { if (v < *p) *p = v; }
