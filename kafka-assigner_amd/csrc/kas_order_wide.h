@@ -206,11 +206,11 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     for (int q = 0; q < W; ++q) e[q] = dummy_e;
     int32_t cn = 0, my_slot = lane;                          // list entries claimed; slot of the row in hand
     bool cv = false, gfin = false;
-    int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0;
+    int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0, n_closure = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
     uint32_t fstep = 0u;                                     // stamp of the front[] entries of the current step (never 0)
 #ifdef KAS_WIDE_DIAG
-    int64_t dg_hold = 0, dg_cand = 0, dg_qlen = 0, dg_inhand = 0, dg_c1 = 0, dg_c2 = 0, dg_c4 = 0, dg_steps = 0, dg_a = 0, dg_b = 0, dg_b3 = 0;
+    int64_t dg_hold = 0, dg_cand = 0, dg_qlen = 0, dg_inhand = 0, dg_c1 = 0, dg_c2 = 0, dg_c4 = 0, dg_steps = 0, dg_tclos = 0, dg_tjac = 0;
 #endif
     const int64_t t_begin = kasw::clock_ticks();
     kasw::set_priority<3>();
@@ -267,6 +267,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #endif
         if (nb != 0ull) {
           constexpr int KH = KAS_WIDE_HOT;
+#ifdef KAS_WIDE_DIAG
+          const int64_t dg_t0 = kasw::clock_ticks();
+#endif
           int32_t my_ax = 0;
 #if KAS_WIDE_VOTE
           {                                                 // a row names the node on which most rows are ahead of it
@@ -327,9 +330,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           // hand that share an old broker: at configs[4] one row in five of a full hand).  The row ahead
           // is next to commit on that node, so it sees the node's counts as they are and the row behind
           // sees them plus its one increment.
-          bool side = false;
+          bool side = false, one = false;
           int32_t qs = 0, pl = lane, pk = 0;                // my list position of that node; lane and list position of the row ahead
-          if (KAS_WIDE_SIDE && cls != 0) {                  // wave-uniform
+          const bool use_side = KAS_WIDE_SIDE && cls != 0;  // wave-uniform
+          if (use_side) {
             fstep = (fstep + 1u) & 0x1fffffu;
             if (fstep == 0u) {                              // the stamp wrapped: forget every old entry
               for (int32_t n = lane; n <= nmax; n += 64) front[n] = 0u;
@@ -339,8 +343,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
             for (int q = 0; q < W; ++q)
               if (cv && q < Lp && d[q] == 0u) front[(e[q] & 0xffff) >> 3] = (fstep << 11) | ((uint32_t)q << 8) | (uint32_t)lane;
-            kasw::lockstep();
-            const bool one = cv && d_sum == d_hot + 1u;     // one row ahead on one node that is not named
+            one = cv && d_sum == d_hot + 1u;                // one row ahead on one node that is not named
 #pragma unroll
             for (int q = 0; q < W; ++q) {
               bool named = false;
@@ -348,59 +351,57 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
               for (int h = 0; h < KH; ++h) named = named || hq[h] == q;
               qs = (one && d[q] == 1u && !named) ? q : qs;
             }
+          }
+          // every row that may be eligible enters the rank layout of its named nodes (one LDS round trip
+          // together with the front[] words); rows drop out of the set below, the layout stays
+          bool elig = cv && (d_sum == d_hot || one);
+#pragma unroll
+          for (int h = 0; h < KH; ++h) elig = elig && kx[h] < 64u;
+          n_runs += 1;
+          const uint32_t seq = (uint32_t)(n_runs & 0xffffff);               // never 0: stale and initial entries differ
+#pragma unroll
+          for (int h = 0; h < KH; ++h)
+            if (elig && hq[h] >= 0) rank_owner[h * 64 + (int32_t)kx[h]] = (seq << 8) | (uint32_t)lane;
+          kasw::lockstep();
+          uint32_t ow[KH];
+          bool have[KH];
+          int32_t qlen[KH], own[KH];
+#pragma unroll
+          for (int h = 0; h < KH; ++h) ow[h] = rank_owner[h * 64 + lane];   // rank view: lane = rank
+          if (use_side) {
             const uint32_t f = one ? front[(sel<W>(e, qs) & 0xffff) >> 3] : 0u;
             side = one && (f >> 11) == fstep;
             pl = side ? (int32_t)(f & 0xffu) : lane;
             pk = (int32_t)((f >> 8) & 7u);
-            kasw::lockstep();
+            elig = elig && (side || !one);                  // waits on named nodes (and its side dependency) only
           }
-          bool elig = cv && (d_sum == d_hot || side);       // waits on named nodes (and its side dependency) only
+          kasw::lockstep();
+#pragma unroll
+          for (int h = 0; h < KH; ++h) {
+            have[h] = (ow[h] >> 8) == seq;
+            own[h] = have[h] ? (int32_t)(ow[h] & 0xffu) : lane;
+          }
 #ifdef KAS_WIDE_DIAG
           const bool elig_first = elig;
           {
             const bool one_d = cv && d_sum == d_hot + 1u;
             dg_c1 += kasw::popc(kasw::ballot(cv && d_sum > d_hot + 1u));          // more than one row ahead on nodes that are not named
-            int32_t nzo = 0; uint32_t dmx = 0u;
-#pragma unroll
-            for (int q = 0; q < W; ++q) {
-              bool named = false;
-#pragma unroll
-              for (int h = 0; h < KH; ++h) named = named || hq[h] == q;
-              nzo += (!named && d[q] != 0u) ? 1 : 0;
-              dmx = (!named && d[q] > dmx) ? d[q] : dmx;
-            }
-            dg_a += kasw::popc(kasw::ballot(cv && nzo == 2 && dmx == 1u));        // two nodes, one row ahead on each
-            dg_b += kasw::popc(kasw::ballot(cv && nzo == 1 && dmx == 2u));        // one node, two rows ahead
-            dg_b3 += kasw::popc(kasw::ballot(cv && nzo == 1 && dmx > 2u));        // one node, more rows ahead
             dg_c2 += kasw::popc(kasw::ballot(one_d && !side));                    // one row ahead, not in my hand
           }
 #endif
-#pragma unroll
-          for (int h = 0; h < KH; ++h) elig = elig && kx[h] < 64u;
-          uint32_t ow[KH];
-          bool have[KH];
-          int32_t qlen[KH];
           for (;;) {                                        // closure: drop rows behind a gap in one of their queues
-            n_runs += 1;
-            const uint32_t seq = (uint32_t)(n_runs & 0xffffff);             // never 0: stale and initial entries differ
+            n_closure += 1;
+            const int32_t mine = elig ? 1 : 0;
+            int32_t ev[KH], ahead = 1;
 #pragma unroll
-            for (int h = 0; h < KH; ++h)
-              if (elig && hq[h] >= 0) rank_owner[h * 64 + (int32_t)kx[h]] = (seq << 8) | (uint32_t)lane;
-            kasw::lockstep();
-#pragma unroll
-            for (int h = 0; h < KH; ++h) ow[h] = rank_owner[h * 64 + lane];   // rank view: lane = rank
-            kasw::lockstep();
-            bool ok = elig;
+            for (int h = 0; h < KH; ++h) ev[h] = kasw::shfl(mine, own[h]);   // is the row of rank `lane` still in the set
+            if (use_side) ahead = kasw::shfl(mine, pl);     // ... and the row ahead on my side node
+            bool ok = elig && (ahead != 0 || !side);
 #pragma unroll
             for (int h = 0; h < KH; ++h) {
-              have[h] = (ow[h] >> 8) == seq;
-              const uint64_t hb = kasw::ballot(have[h]);
+              const uint64_t hb = kasw::ballot(have[h] && ev[h] != 0);
               qlen[h] = ~hb != 0ull ? kasw::first_lane(~hb) : 64;           // ranks 0..qlen-1 are all eligible rows in hand
               ok = ok && (hq[h] < 0 || (int32_t)kx[h] < qlen[h]);
-            }
-            if (KAS_WIDE_SIDE && cls != 0) {                // the row ahead on my side node must be decided here too
-              const int32_t ahead = kasw::shfl(elig ? 1 : 0, pl);
-              ok = ok && (ahead != 0 || !side);
             }
             if (kasw::ballot(elig && !ok) == 0ull) break;
             elig = ok;
@@ -421,6 +422,10 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           } else {
             if (gain > KAS_WIDE_MIN_GAIN) run_backoff = 0;
             run_skip = KAS_WIDE_SKIP_AFTER_PASS;
+#ifdef KAS_WIDE_DIAG
+            const int64_t dg_t1 = kasw::clock_ticks();
+            dg_tclos += dg_t1 - dg_t0;
+#endif
             // wins ahead of me on named node h, per replica index, packed like the low word of a counter
             // row: index 0 at bit 0, 1 at bit 10, 2 at bit 20 (6 bits each: < 64 rows in a queue), 3 at
             // bit 26.  A virtual count never leaves its 10-bit field: count + rows ahead of me on the node
@@ -433,7 +438,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
               pp[h] = 0u;
               on[h] = elig && hq[h] >= 0;
               sh3[h] = 3 * (hq[h] >= 0 ? hq[h] : 0);
-              src_in[h] = have[h] ? (int32_t)(ow[h] & 0xffu) : lane;       // owner -> rank view
+              src_in[h] = own[h];                                          // owner -> rank view
               src_out[h] = on[h] ? (int32_t)kx[h] : lane;                   // rank view -> owner
 #pragma unroll
               for (int q = 0; q < W; ++q) mq[h][q] = hq[h] == q;
@@ -488,6 +493,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
               }
               if (kasw::ballot(moved) == 0ull) break;
             }
+#ifdef KAS_WIDE_DIAG
+            dg_tjac += kasw::clock_ticks() - dg_t1;
+#endif
             n_run_rows += extra ? 1 : 0;
             ready_q = elig;
             have_pos = true;
@@ -665,10 +673,13 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
         if (cls == 1) {
           st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
-          st[14] = run_rows; st[6] = n_runs;
+          st[14] = run_rows; st[6] = KAS_WIDE_JOINT ? n_closure : n_runs;
 #ifdef KAS_WIDE_DIAG
           st[4] = dg_hold; st[5] = dg_cand; st[7] = dg_qlen; st[3] = dg_inhand;
-          st[0] = dg_c1; st[1] = dg_c2; st[2] = dg_c4; st[13] = dg_steps; st[12] = dg_a; st[11] = dg_b; st[15] = dg_b3;
+          st[0] = dg_c1; st[1] = dg_c2; st[2] = dg_c4; st[13] = dg_steps;
+#ifdef KAS_WIDE_DIAG_TIMES
+          st[0] = dg_tclos; st[1] = dg_tjac;                 // ticks before / inside the relaxation loop of the joint solve
+#endif
 #endif
         } else if (first == 0) {
           st[15] = n_iter;                                   // steps of the first class-0 solver

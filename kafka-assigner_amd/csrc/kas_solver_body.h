@@ -917,7 +917,9 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
 // position) of the reference's double loop depends only on earlier orphans at that position and
 // on earlier positions of that orphan), so consecutive windows run one step apart.
 // prog[wave] = window << 32 | positions done (monotone; a finished window counts as the start of
-// the next one).  The earliest window that cannot place an orphan decides the failure
+// the next one).  A window waits for EVERY earlier window that may still be running (the latest
+// window of each other wave; earlier windows of its own wave are finished), not only for its
+// predecessor: that one can finish early while an older window still walks the list.  The earliest window that cannot place an orphan decides the failure
 // (KAS:183-184): everything before it completed exactly as in the sequential order; later
 // windows stop when they see it.  LDS words other waves write are read through a ballot or a
 // broadcast, so a wave always acts on one answer.
@@ -945,7 +947,15 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     return mid_load_raw<W>(T.mid, T.ow, p >= 0 ? p : 0, p >= 0);
   };
   const int32_t n_win = (total + 63) >> 6;
-  const int32_t prev = wave == 0 ? NW - 1 : wave - 1;       // the wave that has window w - 1
+  // Window w may touch live-list positions [j, j + U) once EVERY earlier window is done with them.
+  // Waiting for window w - 1 alone is not enough: it may finish early (its orphans all placed on the
+  // first nodes) while window w - 2 still walks the list with an orphan whose racks were taken, and
+  // window w would then overtake that orphan and take a slot that is not its turn (round 2: one
+  // scenario solve in ~70,000 of the bench mix ended with a broker one over its cap).  Windows
+  // w - NW and earlier ran on this wave and are finished; lane d (1 <= d < NW) watches the wave that
+  // has window w - d.
+  const int32_t dw = (lane >= 1 && lane < NW) ? lane : 1;
+  const int32_t xw = (wave + NW - dw) % NW;
   const int32_t cap = T.cap, mw = mid_width(T.ow);
   constexpr int U = 4;                                     // node positions fetched per LDS round trip
   int32_t p_nxt = orphan_row(64 * wave + lane);
@@ -977,14 +987,15 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
         stop = true;
         break;
       }
-      if (w > 0) {                                          // until window w - 1 is done with [j, j + U)
+      if (w > 0 && NW > 1) {                                // until every earlier window is done with [j, j + U)
         const int32_t upto = j + U < live_count ? j + U : live_count;
-        const uint64_t want = ((uint64_t)(uint32_t)(w - 1) << 32) + (uint32_t)upto;
+        const bool watch = lane >= 1 && lane < NW && w - dw >= 0;
+        const uint64_t want = ((uint64_t)(uint32_t)(w - dw) << 32) + (uint32_t)upto;
         bool abandoned = false;
         int32_t idle = 0;
         for (;;) {
           kasw::repoll();
-          if (kasw::ballot(prog[prev] >= want) != 0) break;
+          if (kasw::ballot(watch && prog[xw] < want) == 0) break;
           if (kasw::ballot(L.ctl[KAS_CTL_FAILWIN] < w) != 0) { abandoned = true; break; }
           if (watchdog_poll((uint32_t*)&L.ctl[KAS_CTL_WATCHDOG], false, idle)) {
             if (lane == 0) kasw::lds_atomic_min(&L.ctl[KAS_CTL_FAILWIN], -1);   // every later window stops

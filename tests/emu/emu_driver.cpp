@@ -325,8 +325,8 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
         fprintf(stderr, "emu stats (wide) s=%d solver_iter=%lld bulk_solver_iter=%lld queue_passes=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld stager_idle=%lld sched_rounds(last block)=%ld\n", s,
                 (long long)st[9], (long long)st[15], (long long)st[6], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12],
                 (long long)st[13], kasw::g_last_block_rounds);
-        fprintf(stderr, "emu diag (wide, -DKAS_WIDE_DIAG) joint_steps=%lld in_hand=%lld hold_hot=%lld wait_hot_only=%lld eligible=%lld | not eligible: many_ahead_elsewhere=%lld one_ahead_not_in_hand=%lld behind_gap=%lld (two_nodes_one_each=%lld one_node_two_ahead=%lld one_node_more=%lld)\n",
-                (long long)st[13], (long long)st[3], (long long)st[4], (long long)st[5], (long long)st[7], (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[12], (long long)st[11], (long long)st[15]);
+        fprintf(stderr, "emu diag (wide, -DKAS_WIDE_DIAG) joint_steps=%lld in_hand=%lld hold_hot=%lld wait_hot_only=%lld eligible=%lld | not eligible: many_ahead_elsewhere=%lld one_ahead_not_in_hand=%lld behind_gap=%lld\n",
+                (long long)st[13], (long long)st[3], (long long)st[4], (long long)st[5], (long long)st[7], (long long)st[0], (long long)st[1], (long long)st[2]);
       }
     }
   } else {

@@ -180,6 +180,9 @@ def test_emu_protocols_survive_arbitrary_wave_speeds():
         "    want = oracle_solve(fb)\n"
         "    for flags in (0, 1 << 12, (8 << 8) | (4 << 12)):\n"
         "        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), 'chaos')\n"
+        "for rf, acts in ((5, ('add_k', 'mixed')), (4, G.ACTIONS)):\n"      # the wide ticket form: joint solve, claim lists
+        "    fb = _batch(77, 2, 2500, 120, 12, rf, acts)\n"
+        "    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), 'chaos, wide lists')\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for seed in ("1", "7"):

@@ -300,3 +300,21 @@ def test_idempotent_on_own_output():
     assert loads.max() <= -(-P * RF // bs.node_id.shape[0])                       # <= cap
     racks = new % R
     assert (np.sort(racks, axis=1)[:, 1:] != np.sort(racks, axis=1)[:, :-1]).all()  # distinct racks
+
+
+@pytest.mark.gpu
+def test_solves_in_flight_leave_identical_records():
+    """bench.py's regime: twelve batches of 1000 full-size scenarios in flight on twelve streams, all
+    solving the same inputs.  Every solve must leave the records (status, movement, digest of every
+    emitted cell) of a reference solve that ran alone and is checked against the oracle.  (Round 2:
+    with four fill wavefronts a P4 window could overtake an older window's orphan when the window in
+    between finished early; one scenario solve in ~70,000 then put a broker one over its cap, which
+    only this regime's timing brought out: scripts/stress_inflight.py.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_inflight.py"), "100"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "0 scenario records differ" in r.stdout
