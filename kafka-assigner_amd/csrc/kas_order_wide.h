@@ -171,7 +171,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   uint32_t* wd = rank_owner_all + 64 * KAS_WIDE_HOT * (1 + KAS_WIDE_BULK_SOLVERS);       // watchdog word (debug builds, see watchdog_poll)
   // front[n] = the class-1 solver's row in hand that is next to commit on node n: step stamp << 11 | the
   // node's position in that row's list << 8 | lane (joint solve, side dependencies)
-  uint32_t* front = wd + 4;                                 // [nmax + 1]
+  uint32_t* front = wd + 4;                                 // [nmax + 1], if the LDS has room for it
+  const bool has_front = kas_order_wide_has_front(a.n_max) != 0;
   // padding holder: a ticket that always matches its commits; never picked (pick_row looks at Lp cells)
   const int32_t dummy_e = (KAS_WIDE_DUMMY_TICKET << 16) | (nmax * 8);
 
@@ -180,7 +181,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   if (have_s) sd = a.scen[s];
   const int32_t* g_node_id = a.node_id + sd.node_off;
   constexpr int NB = KAS_WIDE_BULK_SOLVERS;
-  for (int32_t n = lane + 64 * wave; n <= nmax; n += 64 * KAS_WIDE_WAVES) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; front[n] = 0u; }
+  for (int32_t n = lane + 64 * wave; n <= nmax; n += 64 * KAS_WIDE_WAVES) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; if (has_front) front[n] = 0u; }
   for (int32_t k = wave; k < K; k += KAS_WIDE_WAVES) ring[k * 64 + lane].tag = KAS_TAG_FREE;
   for (int32_t k = wave; k < KAS_WIDE_HOT * (1 + NB); k += KAS_WIDE_WAVES) rank_owner_all[k * 64 + lane] = 0u;
   if (wave == 2 && lane < 2) lstate[lane] = 0u;
@@ -332,7 +333,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           // sees them plus its one increment.
           bool side = false, one = false;
           int32_t qs = 0, pl = lane, pk = 0;                // my list position of that node; lane and list position of the row ahead
-          const bool use_side = KAS_WIDE_SIDE && cls != 0;  // wave-uniform
+          const bool use_side = KAS_WIDE_SIDE && cls != 0 && has_front;   // wave-uniform
           if (use_side) {
             fstep = (fstep + 1u) & 0x1fffffu;
             if (fstep == 0u) {                              // the stamp wrapped: forget every old entry
@@ -471,7 +472,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
               for (int r = 0; r < W; ++r) inv |= (r < Lp ? r : 0) << (3 * pos[r]);   // (every holder gets one pick)
               bool moved = false;
-              if (KAS_WIDE_SIDE && cls != 0) {              // wave-uniform
+              if (KAS_WIDE_SIDE && cls != 0 && has_front) { // wave-uniform
                 const int32_t got = kasw::shfl(inv, pl);
                 const int32_t nrs = side ? ((got >> (3 * pk)) & 7) : 7;
                 moved = nrs != rs;

@@ -154,11 +154,20 @@ KAS_ABI_FN int32_t kas_order_ticket_lds(int32_t n_max, int32_t G, int32_t packed
 #endif
 // counter rows + lane masks + running tickets per node, the ring, the two claim lists, digest and list
 // lengths, the solvers' queue scratch, the watchdog word
-KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
+KAS_ABI_FN int32_t kas_order_wide_lds_core(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
   return kas_align16(2 * (int64_t)kas_align16(8 * (n + 1)) + kas_align16(2 * (n + 1)) +
-                     KAS_WIDE_RING_SLOTS * 64 * 32 + 2 * KAS_WIDE_RING_SLOTS * 64 * 2 + 16 + 256 * KAS_WIDE_HOT * (1 + KAS_WIDE_BULK_SOLVERS) + 16 +
-                     kas_align16(4 * (n + 1)));   // + front[] of the class-1 solver
+                     KAS_WIDE_RING_SLOTS * 64 * 32 + 2 * KAS_WIDE_RING_SLOTS * 64 * 2 + 16 + 256 * KAS_WIDE_HOT * (1 + KAS_WIDE_BULK_SOLVERS) + 16);
+}
+// front[] of the class-1 solver (joint solve, side dependencies): one word per node, kept only while
+// the whole carve-up stays inside the LDS — beyond ~5,900 brokers the kernel runs without it
+KAS_ABI_FN int32_t kas_order_wide_has_front(int32_t n_max) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  return (int64_t)kas_order_wide_lds_core(n_max) + kas_align16(4 * (n + 1)) <= KAS_LDS_LIMIT ? 1 : 0;
+}
+KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  return kas_order_wide_lds_core(n_max) + (kas_order_wide_has_front(n_max) ? kas_align16(4 * (n + 1)) : 0);
 }
 #define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]

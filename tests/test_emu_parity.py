@@ -267,6 +267,17 @@ def test_emu_fill_with_per_chunk_histograms_and_with_the_chunk_count_pass():
     assert last_fused()
 
 
+def test_emu_wide_lists_more_brokers_than_the_side_table_has_room_for():
+    """Beyond ~6,500 brokers the wide ticket form's LDS has no room for the joint solve's front[] words
+    (one per node): the kernel then runs without side dependencies — same results."""
+    from kas_plan_math_py import wide_has_front
+    fb = _batch(41, 1, 7000, 6560, 40, 5, ("add_k",))
+    assert not wide_has_front(int(fb.scen["n_nodes"].max()))
+    want = oracle_solve(fb)
+    assert want.scenario_results["status"][0] == abi.KAS_OK
+    assert_same_outputs(fb, want, emu_solve(fb), "emu wide tickets, no front[] table")
+
+
 @pytest.mark.timeout(900)      # a field overlap shows as rows that never become ready
 def test_emu_wide_lists_counts_near_the_field_limit():
     """Five-wide lists on few brokers: ~1000 rows per broker, so the 10-bit count fields of the wide
