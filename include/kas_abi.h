@@ -259,6 +259,9 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *                          in one uint32 would do
  *   KAS_PLAN_TWO_PASS_HIST rack-diverse fill with one histogram for the whole topic and a separate
  *                          chunk-count pass over cur, instead of per-chunk histograms
+ *   KAS_PLAN_SPREAD_FILL   take the spread fill (the row scans of large single-topic scenarios over many
+ *                          one-wavefront workgroups; chosen by itself for batches of <= 64 scenarios
+ *                          of >= 131,072 partitions) for any single-topic batch, with few chunks
  *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup of the fill kernel: 1, 2 or 4
  *   KAS_PLAN_GROUPS(n)     scenarios per wavefront of the ticket-form order kernel: 1, 2 or 4
  *                          (0 = the plan's choice for either) */
@@ -266,6 +269,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_ROUND_ORDER  2u
 #define KAS_PLAN_WIDE_COUNTERS 4u
 #define KAS_PLAN_TWO_PASS_HIST 8u
+#define KAS_PLAN_SPREAD_FILL  32u
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
 #define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);

@@ -76,6 +76,33 @@ __global__ __launch_bounds__(KAS_ORDER_WIDE_BLOCK) void kas_order_wide_kernel(Ka
   kas::order_tickets_wide<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
+// spread fill (kas_solver_body.h, "Spread fill"): (scenario, chunk) one-wavefront workgroups for the two
+// row scans, a thread per (scenario, node) for the quota, one workgroup per scenario for P4
+template <int W>
+__global__ __launch_bounds__(64) void kas_spread_a_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::spread_pass_a<W>(a, (int32_t)blockIdx.y, (int32_t)blockIdx.x, kas_lds);
+}
+template <int W>
+__global__ __launch_bounds__(256) void kas_spread_q_kernel(KasLaunch a) {
+  kas::spread_quota<W>(a, (int32_t)blockIdx.y, (int32_t)(blockIdx.x * 256u + threadIdx.x));
+}
+template <int W>
+__global__ __launch_bounds__(64) void kas_spread_b_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::spread_pass_b<W>(a, (int32_t)blockIdx.y, (int32_t)blockIdx.x, kas_lds);
+}
+template <int W>
+__global__ __launch_bounds__(256) void kas_spread_p4_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::spread_p4<W, 4>(a, (int32_t)blockIdx.x, kas_lds);
+}
+struct KasSpreadKernels { void (*a)(KasLaunch); void (*q)(KasLaunch); void (*b)(KasLaunch); void (*p4)(KasLaunch); };
+template <int W>
+static KasSpreadKernels kas_spread_kernels_w() {
+  return KasSpreadKernels{kas_spread_a_kernel<W>, kas_spread_q_kernel<W>, kas_spread_b_kernel<W>, kas_spread_p4_kernel<W>};
+}
+
 // tuning builds only: extra dynamic LDS per workgroup, to measure how much residency is worth
 #ifndef KAS_TUNE_ORDER_LDS_PAD
 #define KAS_TUNE_ORDER_LDS_PAD 0
@@ -91,6 +118,7 @@ static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<5, 4>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
+static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_kernels_w<5>() : KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #elif defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES != 0
 // tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
 // lists 3 wide, 4 fill waves, 2 scenarios per solver wavefront — so that a variant compiles in
@@ -103,6 +131,7 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
 }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
 static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
+static KasSpreadKernels kas_spread_for(int) { return KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #else
 static bool kas_minimal_ok(int, int, int) { return true; }
 template <int NW>
@@ -147,6 +176,14 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
 }
 static kas_kernel_fn kas_order_wide_for(int Wc) {
   return Wc == 4 ? kas_order_wide_kernel<4> : kas_order_wide_kernel<5>;
+}
+static KasSpreadKernels kas_spread_for(int Wc) {
+  switch (Wc) {
+    case 3: return kas_spread_kernels_w<3>();
+    case 4: return kas_spread_kernels_w<4>();
+    case 5: return kas_spread_kernels_w<5>();
+    default: return KasSpreadKernels{nullptr, nullptr, nullptr, nullptr};
+  }
 }
 #endif
 
@@ -213,6 +250,10 @@ struct kas_plan {
   int32_t* d_orph;
   int32_t* d_perm;
   int64_t* d_stats;
+  // spread fill scratch (allocated on first use, for sp_alloc_chunks chunks per scenario)
+  int single_topic;             // every scenario has exactly one topic
+  int32_t sp_alloc_chunks;
+  int32_t* d_sp_hist; int32_t* d_sp_quota; int32_t* d_sp_node; int32_t* d_sp_flag; int32_t* d_sp_oc;
   hipStream_t last_stream;
   int last_slot;                // timer slot of the most recent solve (-1: none yet)
   // kernel timing: event pairs recorded around every launch on the launch stream
@@ -307,6 +348,8 @@ void kas_plan_destroy(kas_plan* p) {
   (void)hipFree(p->d_node_id); (void)hipFree(p->d_node_rack);
   (void)hipFree(p->d_accmask_off); (void)hipFree(p->d_accmask); (void)hipFree(p->d_stats);
   (void)hipFree(p->d_orph_off); (void)hipFree(p->d_orph); (void)hipFree(p->d_perm);
+  (void)hipFree(p->d_sp_hist); (void)hipFree(p->d_sp_quota); (void)hipFree(p->d_sp_node);
+  (void)hipFree(p->d_sp_flag); (void)hipFree(p->d_sp_oc);
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
     if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
@@ -340,6 +383,16 @@ static int kas_plan_set_kernels(kas_plan* p) {
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_wide_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_order_wide_lds(p->shape.n_max)));
+  const KasSpreadKernels sk = kas_spread_for(p->Wc);
+  if (sk.a && p->shape.with_x) {
+    const int l1 = kas_fill_lds_layout(p->shape.n_max, p->Wc, 1, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
+    const int l4 = kas_fill_lds_layout(p->shape.n_max, p->Wc, 4, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
+    if (l1 <= KAS_LDS_LIMIT && l4 <= KAS_LDS_LIMIT) {
+      KAS_HIP_TRY(hipFuncSetAttribute((const void*)sk.a, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
+      KAS_HIP_TRY(hipFuncSetAttribute((const void*)sk.b, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
+      KAS_HIP_TRY(hipFuncSetAttribute((const void*)sk.p4, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+    }
+  }
   return KAS_E_OK;
 }
 
@@ -369,6 +422,9 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   p->d_accmask_off = nullptr; p->d_accmask = nullptr; p->d_stats = nullptr; p->last_stream = ctx->stream;
   p->last_slot = -1;
   p->d_orph_off = nullptr; p->d_orph = nullptr; p->d_perm = nullptr;
+  p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
+  p->sp_alloc_chunks = 0;
+  p->d_sp_hist = nullptr; p->d_sp_quota = nullptr; p->d_sp_node = nullptr; p->d_sp_flag = nullptr; p->d_sp_oc = nullptr;
   p->timer_next = 0; p->timer_count = 0;
   if (p->lds.total > KAS_LDS_LIMIT) {
     delete p;
@@ -428,6 +484,13 @@ static bool kas_plan_fused(const kas_plan* p) {
   return p->fused && !(p->flags & (KAS_FLAG_TWO_PASS_HIST | KAS_FLAG_GENERIC_FILL));
 }
 
+// chunks per scenario of the spread fill for this plan's next solve, or 0 (one-workgroup fill kernel)
+static int32_t kas_plan_spread_chunks(const kas_plan* p) {
+  if (p->NW != 4 || !kas_spread_for(p->Wc).a || (p->flags & KAS_FLAG_GENERIC_FILL)) return 0;
+  if (kas_fill_lds_layout(p->shape.n_max, p->Wc, 4, p->shape.idmap_entries, p->shape.need_bsearch, 1).total > KAS_LDS_LIMIT) return 0;
+  return kas_spread_chunks(p->shape, p->n_scenarios, p->single_topic != 0, (p->flags & KAS_FLAG_SPREAD_FILL) != 0);
+}
+
 // the launch decisions of kas_solve_device, in one place
 struct KasLaunchPlan {
   bool tickets, pairing, wide;
@@ -471,9 +534,15 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   else
     snprintf(order, sizeof(order), "kas_order_round_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
              lp.order_block, lp.order_lds);
-  const int len = snprintf(buf, (size_t)n, "kas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu + %s", p->Wc, p->NW,
+  const int32_t chunks = kas_plan_spread_chunks(p);
+  char spread[128];
+  spread[0] = 0;
+  if (chunks > 0)
+    snprintf(spread, sizeof(spread), "kas_spread_{a,q,b,p4}_kernel<%d> %d chunks x %d scenarios (rows not rack-diverse: ", p->Wc,
+             chunks, p->n_scenarios);
+  const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s + %s", spread, p->Wc, p->NW,
                            generic ? "sweeps" : (kas_plan_fused(p) ? "quota, chunk histograms" : "quota"), lp.fill_grid,
-                           lp.fill_block, lp.fill_lds, order);
+                           lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", order);
   return len < n ? len : n - 1;
 }
 
@@ -507,9 +576,42 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
   const int slot = p->timer_next;
+  a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
+  const int32_t chunks = kas_plan_spread_chunks(p);
+  if (chunks > 0 && chunks != p->sp_alloc_chunks) {               // scratch of the spread fill, on first use
+    (void)hipFree(p->d_sp_hist); (void)hipFree(p->d_sp_quota); (void)hipFree(p->d_sp_node);
+    (void)hipFree(p->d_sp_flag); (void)hipFree(p->d_sp_oc);
+    p->d_sp_hist = nullptr; p->d_sp_quota = nullptr; p->d_sp_node = nullptr; p->d_sp_flag = nullptr; p->d_sp_oc = nullptr;
+    p->sp_alloc_chunks = 0;
+    const size_t S = (size_t)p->n_scenarios, NM = (size_t)(p->shape.n_max > 0 ? p->shape.n_max : 1), C = (size_t)chunks;
+    if (hipMalloc((void**)&p->d_sp_hist, 4 * S * C * (size_t)p->Wc * NM) != hipSuccess ||
+        hipMalloc((void**)&p->d_sp_quota, 4 * S * C * NM) != hipSuccess ||
+        hipMalloc((void**)&p->d_sp_node, 4 * S * 2 * NM) != hipSuccess ||
+        hipMalloc((void**)&p->d_sp_flag, 4 * (S + 1)) != hipSuccess ||
+        hipMalloc((void**)&p->d_sp_oc, 4 * S * (C + 2)) != hipSuccess)
+      return set_error(KAS_E_NOMEM, "spread-fill scratch");
+    p->sp_alloc_chunks = chunks;
+  }
   KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
+  if (chunks > 0) {
+    const KasSpreadKernels sk = kas_spread_for(p->Wc);
+    a.sp_hist = p->d_sp_hist; a.sp_quota = p->d_sp_quota; a.sp_node = p->d_sp_node; a.sp_flag = p->d_sp_flag;
+    a.sp_oc = p->d_sp_oc; a.sp_chunks = chunks;
+    KAS_HIP_TRY(hipMemsetAsync(p->d_sp_flag, 0, 4 * ((size_t)p->n_scenarios + 1), st));
+    KAS_HIP_TRY(hipMemsetAsync(p->d_sp_oc, 0, 4 * (size_t)p->n_scenarios * ((size_t)chunks + 2), st));
+    const size_t l1 = (size_t)kas_fill_lds_layout(p->shape.n_max, p->Wc, 1, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
+    const size_t l4 = (size_t)kas_fill_lds_layout(p->shape.n_max, p->Wc, 4, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
+    const dim3 gc((unsigned)chunks, (unsigned)p->n_scenarios);
+    hipLaunchKernelGGL(sk.a, gc, dim3(64), l1, st, a);
+    hipLaunchKernelGGL(sk.q, dim3((unsigned)((p->shape.n_max + 255) / 256), (unsigned)p->n_scenarios), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(sk.b, gc, dim3(64), l1, st, a);
+    hipLaunchKernelGGL(sk.p4, dim3((unsigned)p->n_scenarios), dim3(256), l4, st, a);
+    KAS_HIP_TRY(hipGetLastError());
+    a.flags |= KAS_FLAG_ONLY_FLAGGED;                              // what is left: scenarios handed back (not rack-diverse, ...)
+  }
   hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
+  a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
   KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
   const int packed = lp.packed;
   if (lp.pairing) {
@@ -600,7 +702,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  p->flags = flags & 0xffu & ~KAS_FLAG_FUSED_HIST;
+  p->flags = flags & 0xffu & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED);
   return KAS_E_OK;
 }
 

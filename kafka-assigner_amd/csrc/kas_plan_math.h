@@ -33,6 +33,13 @@ struct KasLaunch {
   const int64_t* orph_off;      // [n_scenarios] offset of the region in int32 elements
   int32_t* perm;                // scratch: order in which the order kernel takes the scenarios, or NULL
   int64_t* stats;               // [n_scenarios][KAS_STATS_PER_SCENARIO] device counters, or NULL
+  // spread fill (large single-topic scenarios: passes A and B over many one-wavefront workgroups)
+  int32_t* sp_hist;             // [S][chunks][W][n_max] sweep histograms of the chunks (pass A)
+  int32_t* sp_quota;            // [S][chunks][n_max]    quota of sweep r* left when the chunk starts
+  int32_t* sp_node;             // [S][2][n_max]         load after the sticky fill, r* << 28 | quota
+  int32_t* sp_flag;             // [S]                   != 0: the scenario takes the one-workgroup kernel instead
+  int32_t* sp_oc;               // [S][chunks + 2]       orphans per chunk, then moved replicas / partitions
+  int32_t sp_chunks;            // chunks per scenario (0: no spread fill in this launch)
   int32_t n_scenarios;
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
   int32_t idmap_entries;        // entries of the direct broker-id -> node-index table
@@ -45,6 +52,8 @@ struct KasLaunch {
 #define KAS_FLAG_WIDE_COUNTERS 4u  // ticket form: always 4 x uint16 counter rows (testing / comparison)
 #define KAS_FLAG_TWO_PASS_HIST 8u  // rack-diverse fill: keep the separate chunk-count pass (testing / comparison)
 #define KAS_FLAG_FUSED_HIST   16u  // set by the launcher: per-chunk histograms, no chunk-count pass (KasShape::fused_ok)
+#define KAS_FLAG_SPREAD_FILL  32u  // spread fill also for small scenarios, with few chunks (testing / comparison)
+#define KAS_FLAG_ONLY_FLAGGED 64u  // set by the launcher: the fill kernel takes only the scenarios the spread fill handed back
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
@@ -218,6 +227,28 @@ static inline void kas_choose_fused(KasShape* s) {
   if (per_cu_fused < (per_cu_now < 4 ? per_cu_now : 4)) return;
   s->fused_ok = 1;
   s->lds_fused = f;
+}
+
+// Spread fill: chunks per scenario, or 0 when the batch takes the one-workgroup fill kernel.  For
+// batches of few, large, single-topic scenarios (BASELINE.json configs[4]: 1M rows — one workgroup
+// streams them in 10 ms, 256 one-wavefront workgroups in a fraction of that); `force` (KAS_FLAG_SPREAD_FILL)
+// takes any single-topic batch, with few chunks, so that small cases exercise the same kernels.
+static inline bool kas_batch_single_topic(const kas_batch_desc* b) {
+  if (b->n_scenarios <= 0 || b->n_topics != b->n_scenarios) return false;
+  for (int32_t i = 0; i < b->n_scenarios; ++i) if (b->scenarios[i].topic_count != 1) return false;
+  return true;
+}
+static inline int32_t kas_spread_chunks(const KasShape& s, int32_t n_scenarios, bool single_topic, bool force) {
+  if (!s.with_x || n_scenarios <= 0 || !single_topic) return 0;
+  // the layout of a one-wavefront workgroup (histogram rows, node tables) must fit as well
+  if (kas_fill_lds_layout(s.n_max, s.Wc, 1, s.idmap_entries, s.need_bsearch, 1).total > KAS_LDS_LIMIT) return 0;
+  const int64_t tiles = ((int64_t)s.max_partitions + 63) / 64;
+  if (force) return (int32_t)(tiles >= 6 ? 6 : (tiles > 0 ? tiles : 1));
+  if (n_scenarios > 64 || tiles < 2048) return 0;
+  int64_t ch = 512 / n_scenarios;
+  if (ch > 256) ch = 256;
+  while (ch > 1 && tiles / ch < 16) ch >>= 1;
+  return (int32_t)(ch >= 4 ? ch : 0);
 }
 
 // Validate descriptors and derive everything a launch needs.  Returns KAS_E_* and fills err.

@@ -572,7 +572,6 @@ template <int W>
 KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, const NodeMap& nm,
                                  uint64_t* accmask, int64_t (&st)[8]) {
   const int lane = kasw::lane();
-  const uint64_t lt = kasw::lanemask_lt();
   const int32_t cap = T.cap, nt = T.nt;
   for (int32_t r = 0; r < T.cw; ++r) {
     for (int32_t tile = 0; tile < nt; ++tile) {
@@ -659,12 +658,13 @@ KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const No
 // P2, rack-diverse form: passes A1, Q, A2, prefix, B (see the header comment).
 // ---------------------------------------------------------------------------------------------
 // A1: tiles wave, wave+NW, ... ; returns this lane's "not rack-diverse" verdict
-template <int W, int NW, bool DIRECT>
-KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
+template <int W, bool DIRECT>
+KAS_DEV bool fill_pass_a_range(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t tile0,
+                               int32_t stride, int32_t t_end) {
   constexpr int D = KAS_TILES_AHEAD;
   const int32_t N = T.N;
   bool viol = false;
-  for_tile_batches<W>(T, wave, NW, T.nt, [&](const int32_t (&ids)[D][W], const int32_t (&len)[D]) {
+  for_tile_batches<W>(T, tile0, stride, t_end, [&](const int32_t (&ids)[D][W], const int32_t (&len)[D]) {
     int32_t idx[D][W], rk[D][W];
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -686,6 +686,10 @@ KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm
     }
   });
   return viol;
+}
+template <int W, int NW, bool DIRECT>
+KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
+  return fill_pass_a_range<W, DIRECT>(L, T, nm, wave, NW, T.nt);
 }
 
 template <int W, int NW>
@@ -838,15 +842,10 @@ KAS_DEV void fill_chunk_prefix(const LdsView& L, const TopicView& T, int32_t tid
 
 // B + P3 over chunk `wave`; orphans go to the chunk's list; returns the number of orphans
 // (FUSED: the quota words are x[n * BW + wave] of the node-major layout, else x[wave * N + n])
-template <int W, int NW, bool DIRECT, bool FUSED = false>
-KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave,
-                            int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
+template <int W, bool DIRECT, int QS>
+KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t t0, int32_t t1,
+                                  int32_t* qc, int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();
-  const uint64_t lt = kasw::lanemask_lt();
-  const int32_t N = T.N;
-  const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
-  constexpr int QS = FUSED ? fused_block_words<W, NW>() : 1;     // stride of a node's quota word
-  int32_t* qc = FUSED ? L.x + wave : L.x + wave * N;
   int32_t* olist = T.orph + ((int64_t)t0 << 6);
   int32_t ocount = 0;
   for_tiles<W>(T, t0, 1, t1, [&](int32_t tile, const int32_t (&ids)[W], int32_t len) {
@@ -906,6 +905,14 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
     ocount += kasw::popc(om);
   });
   return ocount;
+}
+template <int W, int NW, bool DIRECT, bool FUSED = false>
+KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave,
+                            int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
+  const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
+  constexpr int QS = FUSED ? fused_block_words<W, NW>() : 1;     // stride of a node's quota word
+  int32_t* qc = FUSED ? L.x + wave : L.x + wave * T.N;
+  return fill_pass_b_range<W, DIRECT, QS>(L, T, nm, t0, t1, qc, moved_r, moved_p, st);
 }
 
 
@@ -1305,6 +1312,7 @@ template <int W, int NW>
 KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   constexpr int NT = 64 * NW;
   const int tid = kasw::tid();
+  if ((a.flags & KAS_FLAG_ONLY_FLAGGED) && a.sp_flag[s] == 0) return;   // the spread fill did this one
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
   const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch,
@@ -1394,6 +1402,287 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
     if (a.stats) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + i] = st[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Spread fill.  One workgroup streams a 1M-row scenario in ~10 ms (four wavefronts, each waiting on
+// its own HBM round trips); the two row scans of the rack-diverse fill only meet at the quota, so for
+// batches of few large single-topic scenarios they run over `sp_chunks` one-wavefront workgroups per
+// scenario, one contiguous chunk of tiles each, as kernels of their own:
+//   A   (scenario, chunk): sweep histogram of the chunk -> sp_hist; not rack-diverse / anything the
+//       path does not cover -> sp_flag (the one-workgroup kernel then takes that scenario)
+//   Q   (scenario, node): totals -> r*, quota, load (fill_quota's arithmetic) -> sp_node; the quota
+//       left when chunk c starts -> sp_quota (prefix over the chunks' sweep-r* counts)
+//   B   (scenario, chunk): pass B + P3 of the chunk (mid rows, orphan list at the chunk's place in
+//       the scenario's list region, movement counts)
+//   P4  (scenario): the chunk lists moved together, then first fit and the result records exactly as
+//       in fill_topic (p4_lists_parallel on four wavefronts)
+// Same row scans, same quota arithmetic, same P4: only where they run differs.
+// ---------------------------------------------------------------------------------------------
+struct SpreadTopic {
+  TopicView T;
+  NodeMap nm;
+  kas_topic_desc td;
+  int32_t ti;
+  bool ok;              // the spread path covers this scenario
+};
+
+// what every phase derives first (uniform over the workgroup); LDS tables are not touched
+template <int W>
+KAS_DEV SpreadTopic spread_topic(const KasLaunch& a, int32_t s) {
+  SpreadTopic S;
+  const kas_scenario_desc sd = a.scen[s];
+  const int32_t N = sd.n_nodes;
+  S.ok = sd.topic_count == 1 && N > 0 && sd.ctx_off < 0;
+  S.ti = sd.topic_begin;
+  S.td = a.topics[S.ok ? sd.topic_begin : 0];
+  const kas_topic_desc& td = S.td;
+  TopicView& T = S.T;
+  T.cur = a.cur + td.cur_off;
+  T.orph = a.orph + a.orph_off[s];
+  T.len_arr = nullptr; T.inp_arr = nullptr;
+  T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
+  T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
+  T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
+  T.mid = mid_base(a.out + td.out_off, T.P, T.ow);
+  T.cap = S.ok ? max_replicas_per_node(N, T.P, T.rf) : 0;
+  // rows exactly W wide without length / membership arrays (what the full-row stream reads), the
+  // reference's pre-checks passed, a quota word that holds cap, a valid rotation (KAS:190)
+  S.ok = S.ok && td.cur_width == W && td.out_width == W && td.cur_len_off < 0 && td.in_partitions_off < 0 &&
+         td.rf > 0 && td.rf <= N && T.P > 0 && T.cap >= 0 && T.cap < (1 << 28) && java_abs_mod(td.name_hash, N) >= 0 &&
+         !(a.flags & KAS_FLAG_GENERIC_FILL);
+  S.nm.n = N; S.nm.min_id = 0; S.nm.range = 0u;
+  if (N > 0) {
+    const int64_t lo = a.node_id[sd.node_off], hi = a.node_id[sd.node_off + N - 1];
+    const int64_t range = hi - lo + 1;
+    S.nm.min_id = (int32_t)lo;
+    if (range >= 1 && range <= (int64_t)a.idmap_entries) S.nm.range = (uint32_t)range;
+  }
+  S.ok = S.ok && S.nm.range != 0u;            // (sparse ids: the one-workgroup kernel's binary search)
+  return S;
+}
+
+KAS_DEV LdsView spread_lds(const KasLaunch& a, unsigned char* lds_raw, int W, int NW) {
+  const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch, 1);
+  LdsView L;
+  L.x = (int32_t*)(lds_raw + lay.off_x);
+  L.load = (int32_t*)(lds_raw + lay.off_load);
+  L.qrs = (int32_t*)(lds_raw + lay.off_qrs);
+  L.rack = (int16_t*)(lds_raw + lay.off_rack);
+  L.live = (int16_t*)(lds_raw + lay.off_live);
+  L.idmap = (int16_t*)(lds_raw + lay.off_idmap);
+  L.ids = (int32_t*)(lds_raw + lay.off_ids);
+  L.ring_p = (int32_t*)(lds_raw + lay.off_ring);
+  L.ring_meta = L.ring_p + KAS_RING_CAP;
+  L.ring_rack = (int16_t*)(L.ring_meta + KAS_RING_CAP);
+  L.ctl = (int32_t*)(lds_raw + lay.off_ctl);
+  return L;
+}
+
+// rack[] and the broker id -> node index table of a scenario (every thread of the workgroup; two barriers)
+KAS_DEV void spread_node_tables(const KasLaunch& a, int32_t s, const LdsView& L, const NodeMap& nm, int32_t nt_threads) {
+  const int tid = kasw::tid();
+  const kas_scenario_desc sd = a.scen[s];
+  const int32_t* g_node_id = a.node_id + sd.node_off;
+  const int32_t* g_node_rack = a.node_rack + sd.node_off;
+  for (int32_t i = tid; i < nm.n; i += nt_threads) L.rack[i] = (int16_t)g_node_rack[i];
+  for (uint32_t i = (uint32_t)tid; i < nm.range; i += (uint32_t)nt_threads) L.idmap[i] = (int16_t)-1;
+  kasw::sync();
+  for (int32_t i = tid; i < nm.n; i += nt_threads) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
+  kasw::sync();
+}
+
+// node table checks of fill_scenario (strictly ascending non-negative ids, racks in int16 range)
+KAS_DEV bool spread_nodes_bad(const KasLaunch& a, int32_t s) {
+  const kas_scenario_desc sd = a.scen[s];
+  bool bad = false;
+  for (int32_t i = kasw::lane(); i < sd.n_nodes; i += 64) {
+    const int32_t id = a.node_id[sd.node_off + i];
+    const int32_t prev = i > 0 ? a.node_id[sd.node_off + i - 1] : -1;
+    const int32_t rk = a.node_rack[sd.node_off + i];
+    bad = bad || id <= prev || rk < 0 || rk > 32767;
+  }
+  return kasw::ballot(bad) != 0ull;
+}
+
+// phase A: one wavefront, chunk c of scenario s
+template <int W>
+KAS_DEV void spread_pass_a(const KasLaunch& a, int32_t s, int32_t c, unsigned char* lds_raw) {
+  const int lane = kasw::lane();
+  const int32_t CH = a.sp_chunks;
+  SpreadTopic S = spread_topic<W>(a, s);
+  if (S.ok && spread_nodes_bad(a, s)) S.ok = false;               // (before the id table is built from it)
+  if (!S.ok) {
+    if (lane == 0) a.sp_flag[s] = 1;
+    return;
+  }
+  const LdsView L = spread_lds(a, lds_raw, W, 1);
+  const TopicView& T = S.T;
+  const int32_t N = T.N;
+  spread_node_tables(a, s, L, S.nm, 64);
+  for (int32_t i = lane; i < N * W; i += 64) L.x[i] = 0;
+  kasw::sync();
+  const int32_t t0 = (int32_t)(((int64_t)T.nt * c) / CH), t1 = (int32_t)(((int64_t)T.nt * (c + 1)) / CH);
+  const bool viol = fill_pass_a_range<W, true>(L, T, S.nm, t0, 1, t1);
+  if (kasw::ballot(viol) != 0ull && lane == 0) a.sp_flag[s] = 1;   // not rack-diverse: the general fill's case
+  kasw::sync();
+  int32_t* g = a.sp_hist + ((int64_t)s * CH + c) * W * a.n_max;
+  for (int32_t r = 0; r < W; ++r)
+    for (int32_t n = lane; n < N; n += 64) g[(int64_t)r * a.n_max + n] = L.x[r * N + n];
+}
+
+// phase Q: node n of scenario s (no LDS; any launch shape)
+template <int W>
+KAS_DEV void spread_quota(const KasLaunch& a, int32_t s, int32_t n) {
+  if (a.sp_flag[s] != 0) return;
+  const kas_scenario_desc sd = a.scen[s];
+  if (n >= sd.n_nodes) return;
+  const kas_topic_desc td = a.topics[sd.topic_begin];
+  const int32_t cap = max_replicas_per_node(sd.n_nodes, td.n_partitions, td.rf);
+  const int32_t CH = a.sp_chunks;
+  const int32_t* g = a.sp_hist + (int64_t)s * CH * W * a.n_max;
+  int32_t tot[W];
+#pragma unroll
+  for (int r = 0; r < W; ++r) tot[r] = 0;
+  for (int32_t c = 0; c < CH; ++c)
+#pragma unroll
+    for (int r = 0; r < W; ++r) tot[r] += g[((int64_t)c * W + r) * a.n_max + n];
+  int32_t cum = 0, rs = W, q = 0;                               // as fill_quota
+#pragma unroll
+  for (int r = 0; r < W; ++r) {
+    const int32_t cnt = tot[r];
+    const bool sat = rs == W && cnt > cap - cum;
+    q = sat ? cap - cum : q;
+    cum = rs == W ? (sat ? cap : cum + cnt) : cum;
+    rs = sat ? r : rs;
+  }
+  a.sp_node[((int64_t)s * 2 + 0) * a.n_max + n] = cum;
+  a.sp_node[((int64_t)s * 2 + 1) * a.n_max + n] = (int32_t)(((uint32_t)rs << 28) | (uint32_t)q);
+  int32_t rem = q;
+  for (int32_t c = 0; c < CH; ++c) {
+    a.sp_quota[((int64_t)s * CH + c) * a.n_max + n] = rem;
+    rem -= rs < W ? g[((int64_t)c * W + rs) * a.n_max + n] : 0;
+  }
+}
+
+// phase B: one wavefront, chunk c of scenario s
+template <int W>
+KAS_DEV void spread_pass_b(const KasLaunch& a, int32_t s, int32_t c, unsigned char* lds_raw) {
+  const int lane = kasw::lane();
+  if (a.sp_flag[s] != 0) return;                                 // (written by an earlier kernel: uniform)
+  const int32_t CH = a.sp_chunks;
+  SpreadTopic S = spread_topic<W>(a, s);
+  const LdsView L = spread_lds(a, lds_raw, W, 1);
+  const TopicView& T = S.T;
+  const int32_t N = T.N;
+  spread_node_tables(a, s, L, S.nm, 64);
+  for (int32_t n = lane; n < N; n += 64) {
+    L.qrs[n] = a.sp_node[((int64_t)s * 2 + 1) * a.n_max + n];
+    L.x[n] = a.sp_quota[((int64_t)s * CH + c) * a.n_max + n];
+  }
+  kasw::sync();
+  const int32_t t0 = (int32_t)(((int64_t)T.nt * c) / CH), t1 = (int32_t)(((int64_t)T.nt * (c + 1)) / CH);
+  int32_t moved_r = 0, moved_p = 0;
+  int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int32_t oc = fill_pass_b_range<W, true, 1>(L, T, S.nm, t0, t1, L.x, moved_r, moved_p, st);
+  const int32_t mr = kasw::wave_sum(moved_r), mp = kasw::wave_sum(moved_p);
+  if (lane == 0) {
+    int32_t* g = a.sp_oc + (int64_t)s * (CH + 2);
+    g[c] = oc;
+    if (mr != 0) kasw::global_atomic_add(&g[CH], mr);
+    if (mp != 0) kasw::global_atomic_add(&g[CH + 1], mp);
+  }
+}
+
+// phase P4: NW wavefronts, scenario s
+template <int W, int NW>
+KAS_DEV void spread_p4(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+  constexpr int NT = 64 * NW;
+  const int lane = kasw::lane();
+  const int tid = kasw::tid();
+  const int32_t wave = kasw::wave_id();
+  if (a.sp_flag[s] != 0) return;
+  const int32_t CH = a.sp_chunks;
+  SpreadTopic S = spread_topic<W>(a, s);
+  const LdsView L = spread_lds(a, lds_raw, W, NW);
+  TopicView& T = S.T;
+  const int32_t N = T.N, cap = T.cap;
+  const int64_t t_begin = kasw::clock_ticks();
+  for (int32_t i = tid; i < N; i += NT) {
+    L.load[i] = a.sp_node[((int64_t)s * 2 + 0) * a.n_max + i];
+    L.rack[i] = (int16_t)a.node_rack[a.scen[s].node_off + i];
+  }
+  if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : (tid == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
+  kasw::sync();
+  // the chunks' orphan lists, moved together at the start of the scenario's list region (ascending, so
+  // a list only ever moves down; 64 * NW entries at a time: read, barrier, write, barrier)
+  const int32_t* oc = a.sp_oc + (int64_t)s * (CH + 2);
+  int32_t total = 0;
+  for (int32_t c = 0; c < CH; ++c) {
+    const int32_t len = oc[c];
+    const int64_t src = ((int64_t)(((int64_t)T.nt * c) / CH)) << 6;
+    if ((int64_t)total != src) {
+      for (int32_t i0 = 0; i0 < len; i0 += NT) {
+        const int32_t v = i0 + tid < len ? T.orph[src + i0 + tid] : 0;
+        kasw::sync();
+        if (i0 + tid < len) T.orph[(int64_t)total + i0 + tid] = v;
+        kasw::sync();
+      }
+    }
+    total += len;
+  }
+  if (tid == 0) L.ctl[KAS_CTL_OC] = total;                      // one list: chunk 0 of p4_lists_parallel holds them all
+  // KAS:168 getNodeProcessingOrder + the non-full nodes in that order, as in fill_topic
+  const int32_t idxN = java_abs_mod(T.hash, N);
+  if (wave == 0) {
+    const int32_t start = (N - idxN) % N;
+    int32_t live_count = 0;
+    for (int32_t base = 0; base < N; base += 64) {
+      const int32_t j = base + lane;
+      int32_t n = j + start; if (n >= N) n -= N;
+      const bool is_live = j < N && L.load[n] < cap;
+      const uint64_t m = kasw::ballot(is_live);
+      if (is_live) L.live[live_count + kasw::count_below(m)] = (int16_t)n;
+      live_count += kasw::popc(m);
+    }
+    kasw::lockstep();
+    if (lane == 0) L.ctl[KAS_CTL_LIVE] = live_count;
+  }
+  kasw::sync();
+  int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t fail_win = -1, fail_row = -1;
+  p4_lists_parallel<W, NW>(L, T, L.ctl[KAS_CTL_LIVE], wave, st, fail_win, fail_row);
+  kasw::sync();
+  if (fail_win >= 0 && fail_win == L.ctl[KAS_CTL_FAILWIN] && lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
+  kasw::sync();
+  TopicOutcome o;
+  o.status = KAS_OK; o.fail_partition = -1; o.moved_replicas = oc[CH]; o.moved_partitions = oc[CH + 1];
+  if (KAS_SPIN_BOUND > 0 && L.ctl[KAS_CTL_WATCHDOG] != 0) o.status = KAS_FAIL_WATCHDOG;
+  else if (L.ctl[KAS_CTL_FAILROW] >= 0) {                       // KAS:183-184
+    o.status = KAS_FAIL_UNASSIGNABLE;
+    o.fail_partition = T.pid_arr ? T.pid_arr[L.ctl[KAS_CTL_FAILROW]] : L.ctl[KAS_CTL_FAILROW];
+  }
+  if (o.status != KAS_OK) {                                     // nothing is returned for a failed topic
+    int32_t* out = a.out + S.td.out_off;
+    const int64_t cells = (int64_t)S.td.n_partitions * S.td.out_width;
+    for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
+    o.moved_replicas = 0; o.moved_partitions = 0;
+  }
+  if (tid == 0) {
+    kas_topic_result tr;
+    tr.status = o.status; tr.fail_partition = o.fail_partition;
+    tr.moved_replicas = o.moved_replicas; tr.moved_partitions = o.moved_partitions;
+    a.topic_results[S.ti] = tr;
+    kas_scenario_result sr;
+    sr.status = o.status; sr.fail_topic = o.status != KAS_OK ? 0 : -1; sr.fail_partition = o.fail_partition;
+    sr.moved_replicas = o.moved_replicas; sr.moved_partitions = o.moved_partitions; sr.reserved = 0;
+    sr.digest = 0;
+    a.scenario_results[s] = sr;
+    if (a.stats) {
+      for (int i = 0; i < 8; ++i) a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + i] = 0;
+      a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 3] = kasw::clock_ticks() - t_begin;   // [3] P4 (with the list moves)
     }
   }
 }

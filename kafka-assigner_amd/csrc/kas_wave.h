@@ -107,6 +107,9 @@ KAS_DEV int lds_atomic_add(int* p, int v) { return atomicAdd(p, v); }
 KAS_DEV void lds_atomic_min(int* p, int v) { atomicMin(p, v); }
 KAS_DEV void lds_atomic_max(int* p, int v) { atomicMax(p, v); }
 
+// counters in HBM that several workgroups add to (spread fill: movement counts of a scenario's chunks)
+KAS_DEV void global_atomic_add(int* p, int v) { atomicAdd(p, v); }
+
 KAS_DEV void lds_atomic_or_u32(uint32_t* p, uint32_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

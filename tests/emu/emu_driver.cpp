@@ -184,6 +184,15 @@ template <int W> void run_order_rounds(void* p) {
   kas::order_scenario_rounds<W>(*r->a, r->s, r->lds);
 }
 
+struct SpreadArgs { const KasLaunch* a; int32_t s, c; unsigned char* lds; };
+template <int W> void run_spread_a(void* p) { SpreadArgs* r = (SpreadArgs*)p; kas::spread_pass_a<W>(*r->a, r->s, r->c, r->lds); }
+template <int W> void run_spread_b(void* p) { SpreadArgs* r = (SpreadArgs*)p; kas::spread_pass_b<W>(*r->a, r->s, r->c, r->lds); }
+template <int W> void run_spread_p4(void* p) { SpreadArgs* r = (SpreadArgs*)p; kas::spread_p4<W, 4>(*r->a, r->s, r->lds); }
+template <int W> void spread_quota_all(const KasLaunch& a) {
+  for (int32_t s = 0; s < a.n_scenarios; ++s)
+    for (int32_t n = 0; n < a.n_max; ++n) kas::spread_quota<W>(a, s, n);
+}
+
 typedef void (*run_fn)(void*);
 template <int NW> run_fn fill_for_w(int Wc) {
   switch (Wc) {                            // the same width classes the product launcher uses
@@ -216,6 +225,7 @@ run_fn rounds_for(int Wc) {
 // over scenarios): lets a CPU test assert that the queue path ran, not only the one-row path
 static long g_last_queue_rows = 0;
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
+static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
 // 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice)
 extern "C" __attribute__((visibility("default")))
@@ -261,6 +271,46 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;
   };
+  // spread fill (same decision as kas_solve_device): passes A and B over one-wavefront workgroups
+  a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
+  g_last_spread = 0;
+  const int32_t CH = (sh.NW == 4 && sh.Wc >= 3 && sh.Wc <= 5 && !(flags & KAS_FLAG_GENERIC_FILL))
+                         ? kas_spread_chunks(sh, b->n_scenarios, kas_batch_single_topic(b), (flags & KAS_FLAG_SPREAD_FILL) != 0) : 0;
+  std::vector<int32_t> sp_hist, sp_quota, sp_node, sp_flag, sp_oc;
+  if (CH > 0) {
+    const size_t S = (size_t)b->n_scenarios, NM = (size_t)sh.n_max;
+    sp_hist.assign(S * (size_t)CH * (size_t)sh.Wc * NM + 1, (int32_t)0xDEADBEEF);
+    sp_quota.assign(S * (size_t)CH * NM + 1, (int32_t)0xDEADBEEF);
+    sp_node.assign(S * 2 * NM + 1, (int32_t)0xDEADBEEF);
+    sp_flag.assign(S + 1, 0);
+    sp_oc.assign(S * (size_t)(CH + 2) + 1, 0);
+    a.sp_hist = sp_hist.data(); a.sp_quota = sp_quota.data(); a.sp_node = sp_node.data();
+    a.sp_flag = sp_flag.data(); a.sp_oc = sp_oc.data(); a.sp_chunks = CH;
+    if ((size_t)kas_fill_lds_layout(sh.n_max, sh.Wc, 1, sh.idmap_entries, sh.need_bsearch, 1).total > lds.size()) return bad("spread fill (LDS)", 0);
+    run_fn fa = sh.Wc == 3 ? run_spread_a<3> : sh.Wc == 4 ? run_spread_a<4> : run_spread_a<5>;
+    run_fn fb = sh.Wc == 3 ? run_spread_b<3> : sh.Wc == 4 ? run_spread_b<4> : run_spread_b<5>;
+    run_fn fp = sh.Wc == 3 ? run_spread_p4<3> : sh.Wc == 4 ? run_spread_p4<4> : run_spread_p4<5>;
+    for (int32_t s = 0; s < b->n_scenarios; ++s)
+      for (int32_t c = 0; c < CH; ++c) {
+        memset(lds.data(), 0xCD, lds.size());
+        SpreadArgs ra{&a, s, c, lds.data()};
+        if (kasw::run_block(fa, &ra, 1) != 0) return bad("spread fill A", s);
+      }
+    if (sh.Wc == 3) spread_quota_all<3>(a); else if (sh.Wc == 4) spread_quota_all<4>(a); else spread_quota_all<5>(a);
+    for (int32_t s = 0; s < b->n_scenarios; ++s)
+      for (int32_t c = 0; c < CH; ++c) {
+        memset(lds.data(), 0xCD, lds.size());
+        SpreadArgs ra{&a, s, c, lds.data()};
+        if (kasw::run_block(fb, &ra, 1) != 0) return bad("spread fill B", s);
+      }
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(lds.data(), 0xCD, lds.size());
+      SpreadArgs ra{&a, s, 0, lds.data()};
+      if (kasw::run_block(fp, &ra, 4) != 0) return bad("spread fill P4", s);
+      g_last_spread += sp_flag[(size_t)s] == 0 ? 1 : 0;
+    }
+    a.flags |= KAS_FLAG_ONLY_FLAGGED;
+  }
   // fill kernel: one workgroup of NW wavefronts per scenario
   run_fn fill = nullptr;
   switch (sh.NW) {
@@ -274,6 +324,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     RunArgs ra{&a, s, lds.data()};
     if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill", s);
   }
+  a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
   // order kernel: one wavefront per G scenarios (ticket form) or per scenario (round form)
   if (tickets) {
     if (sh.G > 1 && b->n_scenarios > sh.G) {
@@ -348,3 +399,6 @@ long kas_emu_last_queue_rows(void) { return g_last_queue_rows; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_fused(void) { return g_last_fused; }
+
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_spread(void) { return g_last_spread; }

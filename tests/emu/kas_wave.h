@@ -103,6 +103,8 @@ KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p 
 
 KAS_DEV int64_t clock_ticks() { return 0; }
 
+KAS_DEV void global_atomic_add(int* p, int v) { *p += v; }   // (one block runs at a time)
+
 KAS_DEV int wave_sum(int v) {
   const int base = g_emu.cur & ~63;
   g_emu.slot[g_emu.cur] = (uint64_t)(int64_t)v;
