@@ -1046,7 +1046,8 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
       }
       if (lane == 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) if (taken[u] > 0) L.load[n[u]] += taken[u];
+        // (only this wave touches these nodes now: the new load follows from the slots read above, no re-read)
+        for (int u = 0; u < U; ++u) if (taken[u] > 0) L.load[n[u]] = cap - slots[u] + taken[u];
       }
       kasw::lockstep();
       j += U;

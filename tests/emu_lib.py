@@ -93,3 +93,10 @@ def emu_solve(fb: FlatBatch, flags: int = 0) -> HostOutputs:
     if rc != 0:
         raise RuntimeError(f"kas_emu_solve_batch rc={rc}: {err.value.decode()}")
     return ho
+
+
+def last_spread() -> int:
+    """Scenarios the spread fill solved itself (not handed back to the one-workgroup kernel) in the last emu_solve."""
+    L = lib()
+    L.kas_emu_last_spread.restype = C.c_int
+    return int(L.kas_emu_last_spread())

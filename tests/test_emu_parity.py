@@ -288,3 +288,40 @@ def test_emu_wide_lists_counts_near_the_field_limit():
     out = want.out[:3800 * 5].reshape(3800, 5)
     assert np.bincount(out[:, 4]).max() > 255 and np.bincount(out.reshape(-1)).max() > 800
     assert_same_outputs(fb, want, emu_solve(fb), "emu wide, counts near the field limit")
+
+
+SPREAD = 32        # KAS_PLAN_SPREAD_FILL
+
+
+@pytest.mark.parametrize("S,P,N,R,RF,actions", [
+    (3, 7000, 90, 18, 3, ("add_k", "remove1", "mixed")),
+    (2, 5000, 100, 20, 5, ("add_k", "mixed")),
+    (2, 3001, 80, 16, 4, G.ACTIONS),             # a last tile that is not full; stranding scenarios
+])
+def test_emu_spread_fill_matches_the_one_workgroup_fill(S, P, N, R, RF, actions):
+    """The spread fill (row scans of a scenario over several one-wavefront workgroups, quota and P4 as
+    kernels of their own) against the oracle and against the one-workgroup kernel, forced onto small
+    single-topic batches."""
+    from emu_lib import last_spread
+    fb = _batch(200 + RF, S, P, N, R, RF, actions)
+    want = oracle_solve(fb)
+    assert_same_outputs(fb, want, emu_solve(fb, flags=SPREAD), "emu spread fill")
+    assert last_spread() == S
+    assert_same_outputs(fb, want, emu_solve(fb), "emu one-workgroup fill")
+    assert last_spread() == 0
+
+
+def test_emu_spread_fill_hands_back_what_it_does_not_cover():
+    """Rows that are not rack-diverse (the general sticky fill's case), rack awareness off, and a batch
+    with a multi-topic scenario: the spread fill hands such scenarios (or the whole batch) back."""
+    from emu_lib import last_spread
+    fb = _batch(77, 3, 2000, 40, 2, 3, ("remove1", "add_k"), cyclic=True)      # cyclic start on 2 racks: co-racked replicas
+    want = oracle_solve(fb)
+    assert_same_outputs(fb, want, emu_solve(fb, flags=SPREAD), "emu spread fill, rows not rack-diverse")
+    assert last_spread() == 0
+    fb = _batch(78, 2, 3000, 60, 12, 3, ("add_k",), rack_aware=False)
+    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb, flags=SPREAD), "emu spread fill, rack awareness off")
+    assert last_spread() == 2
+    fb = _multi_topic_scenarios(3, 2, 3, 900, 40, 8, 3)
+    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb, flags=SPREAD), "emu spread flag, multi-topic batch")
+    assert last_spread() == 0

@@ -318,3 +318,26 @@ def test_solves_in_flight_leave_identical_records():
                        cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "0 scenario records differ" in r.stdout
+
+
+@pytest.mark.gpu
+def test_spread_fill_on_small_batches_and_what_it_hands_back():
+    """KAS_PLAN_SPREAD_FILL: the spread fill (row scans of a scenario over several one-wavefront
+    workgroups; by itself it serves batches of few scenarios of >= 131,072 rows, e.g. configs[4]) on small
+    single-topic batches of every width it is built for, stranding scenarios included, and batches it
+    hands back: rows that are not rack-diverse, a multi-topic batch."""
+    from test_emu_parity import _multi_topic_scenarios
+    for S, P, N, R, RF, acts in ((5, 9000, 120, 20, 3, G.ACTIONS), (3, 6000, 100, 20, 5, ("add_k", "mixed")),
+                                 (3, 4001, 80, 16, 4, G.ACTIONS), (2, 150000, 300, 20, 3, ("mixed",))):
+        fb = _batch(300 + RF, S, P, N, R, RF, acts)
+        want = oracle_solve(fb, threads=0)
+        plan = native.Plan(native.default_context(), fb); plan.set_flags(32)
+        assert "kas_spread_" in plan.describe(), plan.describe()
+        plan.close()
+        assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 32), f"hip spread fill RF {RF}")
+    fb = _batch(77, 3, 2000, 40, 2, 3, ("remove1", "add_k"), cyclic=True)
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host_with_flags(fb, 32), "hip spread fill, rows not rack-diverse")
+    fb = _batch(78, 2, 3000, 60, 12, 3, ("add_k",), rack_aware=False)
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host_with_flags(fb, 32), "hip spread fill, rack awareness off")
+    fb = _multi_topic_scenarios(3, 2, 3, 900, 40, 8, 3)
+    assert_same_outputs(fb, oracle_solve(fb), native.solve_host_with_flags(fb, 32), "hip spread flag, multi-topic batch")
