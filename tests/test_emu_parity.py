@@ -175,13 +175,13 @@ def test_emu_protocols_survive_arbitrary_wave_speeds():
         "from oracle_lib import oracle_solve\n"
         "from parity_util import assert_same_outputs\n"
         "from kafka_assigner_amd import generator as G\n"
-        "for acts, P, N in ((G.ACTIONS, 3000, 60), (('replace1', 'add_k'), 5000, 80)):\n"
+        "for acts, P, N in ((G.ACTIONS, 2000, 60), (('replace1', 'add_k'), 3500, 80)):\n"
         "    fb = _batch(99, 4, P, N, 8, 3, acts)\n"
         "    want = oracle_solve(fb)\n"
         "    for flags in (0, 1 << 12, (8 << 8) | (4 << 12)):\n"
         "        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), 'chaos')\n"
         "for rf, acts in ((5, ('add_k', 'mixed')), (4, G.ACTIONS)):\n"      # the wide ticket form: joint solve, claim lists
-        "    fb = _batch(77, 2, 2500, 120, 12, rf, acts)\n"
+        "    fb = _batch(77, 2, 1500, 120, 12, rf, acts)\n"
         "    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), 'chaos, wide lists')\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -205,9 +205,9 @@ def test_emu_topic_without_rows_next_to_full_width_topics():
 
 
 @pytest.mark.parametrize("P,N,R,RF,actions,rack_aware", [
-    (6000, 120, 12, 5, ("add_k",), False),    # one broker at a time fills up: long single-node queues
-    (6000, 120, 12, 4, ("mixed",), True),     # rack constraints interleave several nodes being filled
-    (3000, 120, 12, 5, G.ACTIONS, True),
+    (3200, 120, 12, 5, ("add_k",), False),    # one broker at a time fills up: long single-node queues
+    (2600, 120, 12, 4, ("mixed",), True),     # rack constraints interleave several nodes being filled
+    (2000, 120, 12, 5, G.ACTIONS, True),
     (777, 40, 10, 4, G.ACTIONS, True),
 ])
 def test_emu_wide_lists_take_the_wide_ticket_form(P, N, R, RF, actions, rack_aware):
@@ -217,7 +217,7 @@ def test_emu_wide_lists_take_the_wide_ticket_form(P, N, R, RF, actions, rack_awa
     want = oracle_solve(fb)
     assert (want.scenario_results["status"] == abi.KAS_OK).any()
     assert_same_outputs(fb, want, emu_solve(fb), "emu wide tickets")
-    if P >= 6000:
+    if P >= 3000:
         assert last_queue_rows() > 0, "the queue path of the wide kernel did not run"
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1 | (2 << 8)), "emu wide tickets after the general fill, 2 waves")
@@ -271,7 +271,7 @@ def test_emu_wide_lists_more_brokers_than_the_side_table_has_room_for():
     """Beyond ~6,500 brokers the wide ticket form's LDS has no room for the joint solve's front[] words
     (one per node): the kernel then runs without side dependencies — same results."""
     from kas_plan_math_py import wide_has_front
-    fb = _batch(41, 1, 7000, 6560, 40, 5, ("add_k",))
+    fb = _batch(41, 1, 2500, 6560, 40, 5, ("add_k",))
     assert not wide_has_front(int(fb.scen["n_nodes"].max()))
     want = oracle_solve(fb)
     assert want.scenario_results["status"][0] == abi.KAS_OK
@@ -294,9 +294,9 @@ SPREAD = 32        # KAS_PLAN_SPREAD_FILL
 
 
 @pytest.mark.parametrize("S,P,N,R,RF,actions", [
-    (3, 7000, 90, 18, 3, ("add_k", "remove1", "mixed")),
-    (2, 5000, 100, 20, 5, ("add_k", "mixed")),
-    (2, 3001, 80, 16, 4, G.ACTIONS),             # a last tile that is not full; stranding scenarios
+    (3, 4000, 90, 18, 3, ("add_k", "remove1", "mixed")),
+    (2, 2500, 100, 20, 5, ("add_k", "mixed")),
+    (2, 1601, 80, 16, 4, G.ACTIONS),             # a last tile that is not full; stranding scenarios
 ])
 def test_emu_spread_fill_matches_the_one_workgroup_fill(S, P, N, R, RF, actions):
     """The spread fill (row scans of a scenario over several one-wavefront workgroups, quota and P4 as
