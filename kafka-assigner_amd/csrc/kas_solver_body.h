@@ -1009,7 +1009,8 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
             abandoned = true;
             break;
           }
-          kasw::spin_pause();
+          // (no s_sleep between polls: the hand-over from window to window is the chain of P4, and the
+          // poll is one LDS read; in flight 362.4k against 358.2k scenarios/s with the pause)
         }
         if (abandoned) { stop = true; break; }
       }
