@@ -931,6 +931,18 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
 // windows stop when they see it.  LDS words other waves write are read through a ballot or a
 // broadcast, so a wave always acts on one answer.
 // ---------------------------------------------------------------------------------------------
+// node positions per hand-over step of the parallel P4.  The step is the chain (window w + 1 takes a
+// position group when window w has published it) and its cost grows with the group: lists 5 wide test
+// five holder racks per position and at configs[4] nearly every orphan lands on the first or second
+// node of the group, so 2 positions (fill 3.4 ms) beat 4 (4.3) and 8 (5.2); at the headline shape
+// (lists 3 wide, rack-conflict stragglers walking a list of few nodes) 4 is best (365k against 360k
+// scenarios/s at 2 or 8).
+#ifndef KAS_P4_U
+#define KAS_P4_U 4
+#endif
+#ifndef KAS_P4_U_WIDE
+#define KAS_P4_U_WIDE 2
+#endif
 template <int W, int NW>
 KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t live_count, int32_t wave,
                                int64_t (&st)[8], int32_t& fail_win, int32_t& fail_row) {
@@ -964,7 +976,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
   const int32_t dw = (lane >= 1 && lane < NW) ? lane : 1;
   const int32_t xw = (wave + NW - dw) % NW;
   const int32_t cap = T.cap, mw = mid_width(T.ow);
-  constexpr int U = 4;                                     // node positions fetched per LDS round trip
+  constexpr int U = W >= 4 ? KAS_P4_U_WIDE : KAS_P4_U;      // node positions fetched per LDS round trip
   int32_t p_nxt = orphan_row(64 * wave + lane);
   MidRaw<W> c_nxt = row_cells(p_nxt);
   for (int32_t w = wave; w < n_win; w += NW) {
