@@ -90,6 +90,11 @@ namespace kas {
 #ifndef KAS_WIDE_VOTE
 #define KAS_WIDE_VOTE 1
 #endif
+// a row votes (and a joint step is tried at all) when it has more than this many rows ahead of it on some
+// node (configs[4], order kernel: 0 -> 46.2 ms, 1 -> 41.2, 2 -> 40.3, 3 -> 39.6, 4 -> 40.2, 6 -> 41.8)
+#ifndef KAS_WIDE_VOTE_DEPTH
+#define KAS_WIDE_VOTE_DEPTH 3
+#endif
 // side dependencies of the joint solve (0: rows that wait on a node that is not named are left out)
 #ifndef KAS_WIDE_SIDE
 #define KAS_WIDE_SIDE 1
@@ -262,7 +267,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         uint64_t nb = 0ull;
         if (run_skip > 0) run_skip -= 1;
 #if KAS_WIDE_VOTE
-        else nb = kasw::ballot(cv && d_any > 1u);           // a row with two or more rows ahead of it on some node
+        else nb = kasw::ballot(cv && d_any > (uint32_t)KAS_WIDE_VOTE_DEPTH);   // a row deep in some queue
 #else
         else nb = kasw::ballot(cv && nz == 1 && d_sum == (uint32_t)KAS_WIDE_NOMINATE);   // third in line on X, free otherwise
 #endif
