@@ -1,17 +1,16 @@
 // kas_order_wide.h — P5 (computePreferenceLists, KAS:202-239), ticket form for replica lists 4 and 5
 // wide (BASELINE.json configs[4]: 1M partitions x 5k brokers, RF 5).  Included by kas_solver_body.h.
 //
-// Same plan as order_tickets<W <= 3> — wave 1 STAGES rows (mid rows from HBM, tickets, ring slots),
-// wave 2 RETIRES finished rows (node index -> broker id, digest, final out row), talking only through
-// the tags of a ring of K tiles of 64 slots — but with TWO solver wavefronts, one per SIMD that the
-// other two leave free: a single wavefront issues one instruction of its dependent chain every ~5
-// cycles (1.1 us per 64-row step at configs[4], 2.1 us with a queue pass), so the solver, not the
-// dependency chain, was what a 1M-row scenario waited for.  The staging wave sorts every row into one
-// of two classes and appends its slot to that class's claim list:
-//   class 1 (wave 0): rows holding a node that >= KAS_WIDE_CHAIN_DENSITY rows of the same 64-row
+// Same plan as order_tickets<W <= 3> — a STAGING wavefront (mid rows from HBM, tickets, ring slots), a
+// RETIRING wavefront (node index -> broker id, digest, final out row), talking only through the tags of
+// a ring of K tiles of 64 slots — but with THREE solver wavefronts, one per SIMD the other two leave
+// free: a single wavefront issues one instruction of its dependent chain every ~5 cycles, so the
+// solver, not the dependency chain, was what a 1M-row scenario waited for.  The staging wave sorts
+// every row into one of two classes and appends its slot to that class's claim list:
+//   class 1 (wave 1): rows holding a node that >= KAS_WIDE_CHAIN_DENSITY rows of the same 64-row
 //     tile hold — the brokers that first fit is filling with consecutive orphans.  All of this
-//     wave's 64 rows in hand sit on those chains, so a queue pass decides many of them at once.
-//   class 0 (wave 3): everything else — rows whose nodes are ~N/W rows apart, almost always ready.
+//     wave's 64 rows in hand sit on those chains, so one joint step decides many of them at once.
+//   class 0 (waves 3, 4): everything else — rows whose nodes are ~N/W rows apart, almost always ready.
 // Tickets make any split exact: a row commits when every earlier row on each of its nodes has
 // (ticket == commits of the node), whichever wave holds them.  No deadlock: each solver claims its
 // class in row order, so the oldest undecided row of the scenario is always in some lane's hand,
@@ -24,17 +23,18 @@
 //   * holders are stored ascending (Sets.newTreeSet, KAS:228) and the picks are the general
 //     "minimum of (count, visit position) over the nodes still in the set" of pick_row<W>
 //     (KAS:263-278), five times; the rotation offsets idx_m = abs(hash) % m travel in the slot.
-//   * queues.  First fit hands consecutive orphans to one node X (at configs[4] each added broker
-//     takes ~981 of them: the P5 dependency chain is ~180k rows long against 15.6k tiles), so rows
-//     in hand that wait on X alone are decided together, as in the 3-wide kernel, generalised:
-//     with X's other holders free, X takes the row's pick r* = the first r with
-//     count[X][r] + (rows ahead in the queue that took r) < T_r, where the thresholds T_0..T_{L-2}
-//     follow from the other holders' counts alone (if X loses pick r, the winner among the others
-//     is fixed, leaves the set, and pick r + 1 is again X against the rest), T_{L-1} = always.
-//     Laid out by rank the counts are prefix sums of the wins; wins -> prefix sums are re-evaluated
-//     until nothing changes (rank r is right after round r at the latest).  Several nodes are
-//     usually being filled at once (rack constraints interleave them): up to KAS_WIDE_QUEUE_PASSES
-//     nodes are served per solver step.
+//   * the joint solve (KAS_WIDE_JOINT).  First fit hands consecutive orphans to one node
+//     (at configs[4] each added broker takes ~981 of them: the P5 dependency chain is ~180k rows long
+//     against 15.6k tiles), rack constraints keep two or three such nodes open at once, and two rows
+//     of a hand often share an old broker.  A solver step therefore decides every row in hand whose
+//     dependencies are in the hand too: rows deep in a queue vote for the KAS_WIDE_HOT nodes that get a
+//     rank layout (rank = ticket - commits), a row may also wait on one more node with a single row
+//     ahead if that row is in the hand (front[]), the set is closed under "every row ahead of me on my
+//     named nodes, and my side row, is in the set", and the picks are relaxed against per-node prefix
+//     sums of the wins (ballot + v_mbcnt over the rank layouts, added to the packed counter words)
+//     until nothing changes: the sequential answer, because the set is closed and the dependencies
+//     acyclic.  KAS_WIDE_JOINT 0 builds the single-node threshold queues of the 3-wide kernel,
+//     generalised to five picks (thresholds T_0..T_{L-2} from the other holders alone), instead.
 #pragma once
 
 namespace kas {

@@ -295,7 +295,7 @@ SPREAD = 32        # KAS_PLAN_SPREAD_FILL
 
 @pytest.mark.parametrize("S,P,N,R,RF,actions", [
     (3, 4000, 90, 18, 3, ("add_k", "remove1", "mixed")),
-    (2, 2500, 100, 20, 5, ("add_k", "mixed")),
+    (2, 1500, 100, 20, 5, ("add_k", "mixed")),
     (2, 1601, 80, 16, 4, G.ACTIONS),             # a last tile that is not full; stranding scenarios
 ])
 def test_emu_spread_fill_matches_the_one_workgroup_fill(S, P, N, R, RF, actions):
