@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
   kas::order_scenario_rounds<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
-// lists 4 and 5 wide: one scenario per workgroup (two solver wavefronts, stager, retirer)
+// lists 4 and 5 wide: one scenario per workgroup (stager, retirer, three solver wavefronts: kas_order_wide.h)
 template <int W>
 __global__ __launch_bounds__(KAS_ORDER_WIDE_BLOCK) void kas_order_wide_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];

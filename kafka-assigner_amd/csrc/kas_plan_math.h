@@ -3,7 +3,9 @@
 // Pure C++ (no HIP calls) so that the exact same planning code runs in the product library
 // (kas_hip.hip) and in the CPU emulation harness under tests/emu/.
 //
-// A solve is two kernels on one stream:
+// A solve is two kernels on one stream (+ a one-workgroup kernel that orders the scenarios for the
+// ticket form, and — for batches of few large single-topic scenarios — the four spread-fill kernels in
+// front of the fill kernel, which then only takes what they hand back):
 //   fill   (P0-P4 + tickets)  one workgroup of NW wavefronts per scenario; LDS = node state
 //   order  (P5)               ticket form: one lane group per scenario, G groups per wavefront,
 //                             LDS = packed 16-bit counters; round form: one wavefront per
