@@ -402,3 +402,53 @@ int kas_emu_last_fused(void) { return g_last_fused; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_spread(void) { return g_last_spread; }
+
+// ---------------------------------------------------------------------------------------------
+// Unit harness for the parallel P4 of the fill kernel (p4_lists_parallel<3, 4>): the caller gives the
+// node state (load, rack, the list of non-full nodes in processing order), the orphan rows in row
+// order and their mid rows; the four wavefronts run the windows exactly as the kernel does.  With
+// KAS_EMU_WAVE_DIV one wave can be made slow, which is how a test provokes one window overtaking
+// another (tests/test_emu_p4_windows.py).  Returns 0, or -100 on divergence / deadlock.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct P4Args { kas::LdsView L; kas::TopicView T; int32_t live_count; int32_t fail_row; };
+void run_p4_unit(void* p) {
+  P4Args* r = (P4Args*)p;
+  int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t fail_win = -1, fail_row = -1;
+  kas::p4_lists_parallel<3, 4>(r->L, r->T, r->live_count, kasw::wave_id(), st, fail_win, fail_row);
+  if (fail_win >= 0 && kasw::lane() == 0) r->fail_row = fail_row;     // (any failing window: the tests place everything)
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default")))
+int kas_emu_p4_unit(int32_t n_nodes, const int32_t* load, const int32_t* rack, int32_t cap, int32_t live_count,
+                    const int32_t* live, int32_t n_orphans, int32_t* orphan_rows, int32_t P, uint16_t* mid,
+                    int32_t* load_out) {
+  const KasLds lay = kas_fill_lds_layout(n_nodes, 3, 4, 0, 0, 1);
+  std::vector<unsigned char> lds((size_t)lay.total + 64, 0xCD);
+  P4Args r;
+  r.L.x = (int32_t*)(lds.data() + lay.off_x);
+  r.L.load = (int32_t*)(lds.data() + lay.off_load);
+  r.L.qrs = (int32_t*)(lds.data() + lay.off_qrs);
+  r.L.rack = (int16_t*)(lds.data() + lay.off_rack);
+  r.L.live = (int16_t*)(lds.data() + lay.off_live);
+  r.L.idmap = (int16_t*)(lds.data() + lay.off_idmap);
+  r.L.ids = (int32_t*)(lds.data() + lay.off_ids);
+  r.L.ring_p = (int32_t*)(lds.data() + lay.off_ring);
+  r.L.ring_meta = r.L.ring_p + KAS_RING_CAP;
+  r.L.ring_rack = (int16_t*)(r.L.ring_meta + KAS_RING_CAP);
+  r.L.ctl = (int32_t*)(lds.data() + lay.off_ctl);
+  for (int32_t i = 0; i < n_nodes; ++i) { r.L.load[i] = load[i]; r.L.rack[i] = (int16_t)rack[i]; }
+  for (int32_t i = 0; i < live_count; ++i) r.L.live[i] = (int16_t)live[i];
+  for (int i = 0; i < KAS_CTL_INTS; ++i) r.L.ctl[i] = i == KAS_CTL_FAILROW ? -1 : (i == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
+  r.L.ctl[KAS_CTL_OC] = n_orphans;                               // one list: chunk 0 holds every orphan
+  r.L.ctl[KAS_CTL_LIVE] = live_count;
+  memset(&r.T, 0, sizeof(r.T));
+  r.T.orph = orphan_rows; r.T.mid = mid;
+  r.T.P = P; r.T.cw = 3; r.T.rf = 3; r.T.ow = 3; r.T.nt = (P + 63) >> 6; r.T.N = n_nodes; r.T.cap = cap;
+  r.live_count = live_count; r.fail_row = -1;
+  if (kasw::run_block(run_p4_unit, &r, 4) != 0) return -100;
+  for (int32_t i = 0; i < n_nodes; ++i) load_out[i] = r.L.load[i];
+  return r.fail_row >= 0 ? 1 : 0;
+}
