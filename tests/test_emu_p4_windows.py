@@ -81,3 +81,62 @@ def run_case(div):
 def test_p4_windows_equal_sequential_first_fit_whatever_the_wave_speeds(div):
     r = run_case(div)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+def random_case(rng):
+    """A list of nodes on three racks with little room each (the last slots of nodes are contested all
+    the time), orphan rows of two kinds: most have their holders on other racks and take the first
+    node with room; one in seventy holds two of the three racks already and walks the list for a node of
+    the third — the orphan that an overtaking window would rob."""
+    n_live = int(rng.integers(12, 30))
+    hold_racks = np.array([3, 4, 5, 6, 0, 1, 2], dtype=np.int32)      # full nodes the rows already sit on
+    n = n_live + len(hold_racks)
+    rack = np.concatenate([rng.integers(0, 3, size=n_live), hold_racks]).astype(np.int32)
+    n_orph = int(rng.integers(300, 700))
+    mid = np.full((n_orph, 4), NONE, dtype=np.uint16)
+    need_total = 0
+    for p in range(n_orph):
+        if rng.random() < 0.015:
+            hs = (n_live + 4 + rng.permutation(3)[:2]).tolist()       # holders on two of the racks 0, 1, 2
+        else:
+            k = int(rng.integers(1, 3))
+            hs = (n_live + rng.permutation(4)[:k]).tolist()           # holders on racks 3..6
+        mid[p, :len(hs)] = hs
+        need_total += 3 - len(hs)
+    cap = need_total + 10
+    room = rng.multinomial(need_total, np.ones(n_live) / n_live).astype(np.int32)
+    load = np.full(n, cap, dtype=np.int32)
+    load[:n_live] = cap - room
+    # three roomy nodes at the end of the list, one per rack: every row finds a place
+    rack = np.concatenate([rack, np.array([0, 1, 2], dtype=np.int32)])
+    load = np.concatenate([load, np.zeros(3, dtype=np.int32)])
+    live = np.concatenate([rng.permutation(n_live), n + np.arange(3)]).astype(np.int32)
+    return cap, load, rack, live, np.arange(n_orph, dtype=np.int32), mid
+
+
+@pytest.mark.parametrize("env", [{"KAS_EMU_WAVE_DIV": "0:25"}, {"KAS_EMU_WAVE_DIV": "1:25"}, {"KAS_EMU_WAVE_DIV": "3:25,2:4"},
+                                 {"KAS_EMU_CHAOS": "5"}])
+def test_p4_windows_random_cases_under_skewed_wave_speeds(env):
+    code = (
+        "import sys, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from emu_lib import lib\n"
+        "from test_emu_p4_windows import random_case, first_fit\n"
+        "L = lib(); L.kas_emu_p4_unit.restype = C.c_int\n"
+        "p = lambda a: a.ctypes.data_as(C.c_void_p)\n"
+        "rng = np.random.default_rng(20260923)\n"
+        "for case in range(60):\n"
+        "    cap, load, rack, live, orph, mid = random_case(rng)\n"
+        "    want_load, want_mid = first_fit(load, rack, cap, live, orph, mid)\n"
+        "    got_mid = mid.copy(); got_load = np.zeros_like(load); o = orph.copy()\n"
+        "    rc = L.kas_emu_p4_unit(C.c_int(len(load)), p(load), p(rack), C.c_int(cap), C.c_int(len(live)), p(live),\n"
+        "                           C.c_int(len(o)), p(o), C.c_int(mid.shape[0]), p(got_mid), p(got_load))\n"
+        "    assert rc == 0, (case, rc)\n"
+        "    bad = np.nonzero((got_mid != want_mid).any(axis=1))[0]\n"
+        "    assert len(bad) == 0 and (got_load == want_load).all(), (case, [(int(b), got_mid[b].tolist(), want_mid[b].tolist()) for b in bad[:3]])\n"
+        "print('ok')\n") % (os.path.join(ROOT, "tests"), ROOT)
+    e = dict(os.environ)
+    e.pop("KAS_EMU_CHAOS", None); e.pop("KAS_EMU_WAVE_DIV", None)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
