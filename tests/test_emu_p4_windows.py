@@ -114,8 +114,7 @@ def random_case(rng):
     return cap, load, rack, live, np.arange(n_orph, dtype=np.int32), mid
 
 
-@pytest.mark.parametrize("env", [{"KAS_EMU_WAVE_DIV": "0:25"}, {"KAS_EMU_WAVE_DIV": "1:25"}, {"KAS_EMU_WAVE_DIV": "3:25,2:4"},
-                                 {"KAS_EMU_CHAOS": "5"}])
+@pytest.mark.parametrize("env", [{"KAS_EMU_WAVE_DIV": "0:25"}, {"KAS_EMU_WAVE_DIV": "3:25,2:4"}, {"KAS_EMU_CHAOS": "5"}])
 def test_p4_windows_random_cases_under_skewed_wave_speeds(env):
     code = (
         "import sys, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
