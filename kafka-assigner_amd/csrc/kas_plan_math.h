@@ -360,6 +360,16 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     if (l.total <= KAS_LDS_LIMIT) { s.lds = l; s.NW = 1; s.with_x = 0; err_total = 0; }
   }
   kas_choose_fused(&s);
+  // two scenarios per solver wavefront by default: a scenario rarely has more than ~20 rows ready
+  // at once, so 32 lanes serve it as well as 64 and the wave's instructions are shared (even a
+  // lone scenario is no faster on 64 lanes: its stager then tickets each tile in two halves).
+  // Counter rows are addressed with 16-bit LDS byte offsets: fewer scenarios per wavefront when the
+  // groups' regions do not fit 64 KiB, no ticket form at all when one region does not — decided
+  // BEFORE the fallback check below, so that a plan no order kernel can serve is refused here and
+  // not at its first launch.
+  s.G = want_groups > 0 ? want_groups : 2;
+  while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.G >>= 1;
+  if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.tickets_ok = 0;
   // the round form of P5 is the universal fallback; a batch that one of the ticket forms serves does
   // not need it to fit (KAS_PLAN_ROUND_ORDER is refused for such a plan, see round_fits)
   s.round_fits = kas_order_round_lds(s.n_max, s.Wc) <= KAS_LDS_LIMIT;
@@ -369,13 +379,6 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +
                 std::to_string(s.Wc) + " needs " + std::to_string(err_total) +
                 " B of LDS (limit 163840)");
-  // counter rows are addressed with 16-bit LDS byte offsets
-  // two scenarios per solver wavefront by default: a scenario rarely has more than ~20 rows ready
-  // at once, so 32 lanes serve it as well as 64 and the wave's instructions are shared (even a
-  // lone scenario is no faster on 64 lanes: its stager then tickets each tile in two halves)
-  s.G = want_groups > 0 ? want_groups : 2;
-  while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.G >>= 1;
-  if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.tickets_ok = 0;
   *sh = s;
   return KAS_E_OK;
 }

@@ -55,14 +55,28 @@ final class NativeAssignmentStrategy {
     /** Outcome of one topic: the new assignment, or the exception the reference would have thrown. */
     static final class TopicOutcome {
         int status, failPartition, movedReplicas, movedPartitions;
+        String topic;            // for the exception texts of KTA:65-69
+        int replicationFactor;
         Map<Integer, List<Integer>> assignment;
+        /** The statuses of include/kas_abi.h as the exceptions (and texts) the reference throws. */
         RuntimeException failure() {
-            if (status == 0) return null;
-            if (status == 1)       // KAS:183-184
-                return new IllegalStateException("Partition " + failPartition + " could not be fully assigned!");
-            if (status == 4) return new ArrayIndexOutOfBoundsException();   // KAS:190 with hashCode() == MIN_VALUE
-            if (status == 6) return new IllegalStateException("skipped: an earlier topic of the run failed");
-            return new IllegalStateException("solver status " + status);
+            switch (status) {
+                case 0: return null;
+                case 1:         // KAS:183-184
+                    return new IllegalStateException("Partition " + failPartition + " could not be fully assigned!");
+                case 2:         // KTA:65-66
+                    return new IllegalStateException("Topic " + topic + " does not have a positive replication factor!");
+                case 3:         // KTA:67-69
+                    return new IllegalStateException("Topic " + topic + " has a higher replication factor ("
+                            + replicationFactor + ") than available brokers!");
+                case 4:         // KAS:190 with hashCode() == Integer.MIN_VALUE
+                    return new ArrayIndexOutOfBoundsException();
+                case 5:         // KTA:58-60 (raised by host mirrors while resolving rf, never by the kernels)
+                    return new IllegalStateException("Topic " + topic + " has a partition with unexpected replication factor");
+                case 6: return new IllegalStateException("skipped: an earlier topic of the run failed");
+                case 7: return new IllegalArgumentException("broker ids must be non-negative and distinct; at most 32768 racks");
+                default: return new IllegalStateException("solver status " + status);
+            }
         }
     }
 
@@ -111,8 +125,9 @@ final class NativeAssignmentStrategy {
         }
         long inInts = HEADER_INTS + 8L * S + 16L * T + 2 * nodePool + curLen + auxLen + ctxLen;
         long outInts = 4L * T + 8L * S + outLen + ctxLen;
-        ByteBuffer in = ByteBuffer.allocateDirect((int) (4 * inInts)).order(ByteOrder.nativeOrder());
-        ByteBuffer out = ByteBuffer.allocateDirect((int) (4 * outInts)).order(ByteOrder.nativeOrder());
+        // (a direct ByteBuffer holds < 2 GiB: a larger batch must be split by the caller, not truncated)
+        ByteBuffer in = ByteBuffer.allocateDirect(Math.toIntExact(4 * inInts)).order(ByteOrder.nativeOrder());
+        ByteBuffer out = ByteBuffer.allocateDirect(Math.toIntExact(4 * outInts)).order(ByteOrder.nativeOrder());
         in.putInt(LAYOUT).putInt(S).putInt(T).putInt((int) nodePool).putInt((int) curLen).putInt((int) auxLen)
           .putInt((int) ctxLen).putInt((int) outLen);
         // ---- descriptors
@@ -202,6 +217,7 @@ final class NativeAssignmentStrategy {
                 for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
                 int ow = Math.max(Math.max(cw, Math.min(sc.topics.get(k).replicationFactor, sc.nodes.size())), 1);
                 TopicOutcome o = new TopicOutcome();
+                o.topic = sc.topics.get(k).topic; o.replicationFactor = sc.topics.get(k).replicationFactor;
                 o.status = out.getInt(4 * (4 * ti)); o.failPartition = out.getInt(4 * (4 * ti + 1));
                 o.movedReplicas = out.getInt(4 * (4 * ti + 2)); o.movedPartitions = out.getInt(4 * (4 * ti + 3));
                 if (o.status == 0) {

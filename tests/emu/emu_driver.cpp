@@ -391,6 +391,22 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   return KAS_E_OK;
 }
 
+// The product's planning decision for a batch shape, without running anything (plan-math tests):
+// out[0..7] = tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok.  Returns kas_shape_batch's code.
+extern "C" __attribute__((visibility("default")))
+int kas_emu_shape(const kas_batch_desc* b, int32_t* out, char* errbuf, int errlen) {
+  KasShape sh;
+  std::string err;
+  const int rc = kas_shape_batch(b, &sh, &err, 0, 0);
+  if (rc != KAS_E_OK) {
+    if (errbuf && errlen > 0) { strncpy(errbuf, err.c_str(), (size_t)errlen - 1); errbuf[errlen - 1] = 0; }
+    return rc;
+  }
+  out[0] = sh.tickets_ok; out[1] = sh.wide_ok; out[2] = sh.round_fits; out[3] = sh.G; out[4] = sh.NW;
+  out[5] = sh.with_x; out[6] = sh.packed_ok; out[7] = sh.fused_ok;
+  return rc;
+}
+
 extern "C" __attribute__((visibility("default")))
 long kas_emu_collectives(void) { return kasw::g_emu.collectives; }
 

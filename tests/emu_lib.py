@@ -100,3 +100,17 @@ def last_spread() -> int:
     L = lib()
     L.kas_emu_last_spread.restype = C.c_int
     return int(L.kas_emu_last_spread())
+
+
+def plan_shape(fb: FlatBatch):
+    """kas_shape_batch's verdict on a batch shape (the product's planning code, nothing is run):
+    (return code, {tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok}, error text)."""
+    L = lib()
+    L.kas_emu_shape.restype = C.c_int
+    L.kas_emu_shape.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(C.c_int32), C.c_char_p, C.c_int]
+    bd = batch_desc(fb)
+    out = (C.c_int32 * 8)()
+    err = C.create_string_buffer(512)
+    rc = L.kas_emu_shape(C.byref(bd), out, err, 512)
+    names = ("tickets_ok", "wide_ok", "round_fits", "G", "NW", "with_x", "packed_ok", "fused_ok")
+    return rc, dict(zip(names, list(out))), err.value.decode()
