@@ -2,14 +2,18 @@
 """bench.py — assignment scenarios/sec on MI355X (BASELINE.json metric).
 
 One "step" = one solve of one batch of synthetic cluster scenarios by the HIP path, with every
-bulk table already resident in HBM (12 batches in flight on 12 streams by default, each with its own
-plan, scratch and outputs; every slot's plan is run once during set-up).  At N=1 the workload is BASELINE.json configs[2] — the
-configuration the metric is quoted on: a batch of 1k independent scenarios of 100k partitions x
-1k brokers x 20 racks, RF 3, each with its own current assignment G(seed+s) and its own broker-set
-perturbation drawn from {remove 1, remove k<=5, add k<=50, remove k<=5 + add j<=50} (SURVEY.md
-8d; 'replace 1' is swapped for the mixed action in the headline because the reference itself
-throws on most such scenarios, see generator.BENCH_ACTIONS — the literal SURVEY mix is measured
-too and reported as config.literal_c3_mix).
+bulk table already resident in HBM.  Twelve batches are in flight on twelve streams by default, and
+they are twelve DIFFERENT batches: every slot has its own current-assignment tables, its own
+broker-set draws, its own plan, scratch and outputs (12 x 2.4 GB of tables).  At N=1 the workload is
+BASELINE.json configs[2] — the configuration the metric is quoted on: a batch of 1k independent
+scenarios of 100k partitions x 1k brokers x 20 racks, RF 3, each with its own current assignment
+G(seed+s) and its own broker-set perturbation drawn from {remove 1, remove k<=5, add k<=50,
+remove k<=5 + add j<=50} ('replace 1' is swapped for the mixed action in the headline
+because the reference itself throws on most such scenarios, see generator.BENCH_ACTIONS — the literal
+SURVEY mix is measured too and reported as config.literal_c3_mix).
+
+The timed region (exactly --steps steps between barriers) is run --repeats times inside one
+invocation; `value` and `ms_per_step` are the MEDIAN repeat's, the spread is in `repeats`.
 
 Multi-GPU: `python bench.py --gpus N` launches its own N ranks (one process per GPU, re-exec under
 torch.distributed.run on 127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set), and
@@ -19,13 +23,19 @@ ranges (sharding.shard_range).  Each step ends with the ONE data-path collective
 an RCCL all-gather of the 32-byte per-scenario result records; its time alone is reported too.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — algorithmic HBM bytes per launch against the 8 TB/s HBM3E peak, at the whole-job
-                 rate (bytes / ms_per_step) and per kernel with ONE batch on the GPU (HIP events
-                 on the launch stream); kernel names come from the plan (kas_plan_describe)
-  cpu_baseline — B1 the CPU oracle (C restatement of the reference Java; no JVM exists here) and
-                 B2 the flat-array CPU solver, each on one core (bounded sample) and scenario-
-                 parallel on every host core inside one C call
-and list-compares EVERY scenario of rank 0's batch with the oracle before reporting.
+  roofline      — algorithmic HBM bytes per launch against the 8 TB/s HBM3E peak, at the whole-job
+                  rate (bytes / ms_per_step) and per kernel with ONE batch on the GPU (HIP events
+                  on the launch stream); kernel names come from the plan (kas_plan_describe);
+                  `traffic` only from a committed PMC profile of the same kernels AND sources
+  cpu_baseline  — B1 the CPU oracle (C restatement of the reference Java; no JVM exists here) and
+                  B2 the flat-array CPU solver, each on one core (bounded sample) and scenario-
+                  parallel on every host core inside one C call
+  end_to_end    — through the host-buffer boundary JNI / the CLI call (kas_solve_host[_select]):
+                  the what-if form (1000 broker sets over ONE snapshot, records of all, rows of one)
+                  and the plain form (every scenario its own tables) with its PCIe rate
+  other_configs — BASELINE.json configs[1] and configs[4] on this GPU with a CPU figure beside each
+and checks, before reporting, the records (status, failing ids, movement, digest of every cell) of
+EVERY slot's last timed solve against the CPU solvers and every list of slot 0 against the oracle.
 
 --stub is the harness self-test (tests/test_bench_harness.py): gloo on CPU tensors and a solve
 that only writes synthetic records, so that the launch / shard / gather / report control flow runs
@@ -58,11 +68,16 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 C3_SHAPE = (1000, 100000, 1000, 20, 3)
 
 
+SLOT_SEED_STRIDE = 1000003   # slot k draws its tables and broker sets from seed + k * this
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="times the timed region (exactly --steps steps) is run; value = the median repeat")
     ap.add_argument("--scenarios", type=int, default=1000,
                     help="scenarios per GPU per step (--scaling weak) or in total (--scaling strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
@@ -74,13 +89,18 @@ def parse_args(argv=None):
     ap.add_argument("--actions", default="", help="comma list overriding the per-scenario action mix "
                     "(remove1,remove_k,add_k,mixed,replace1,add50); default generator.BENCH_ACTIONS")
     ap.add_argument("--check", type=int, default=-1,
-                    help="scenarios of rank 0's batch list-compared against the oracle (-1 = all)")
+                    help="scenarios of slot 0 list-compared against the oracle (-1 = all); the records of every "
+                         "slot are compared either way unless this is 0")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="single-core CPU-baseline sample budget (each)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the one-batch-alone and literal-mix legs")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the one-batch-alone, literal-mix, end-to-end and other-config legs")
     ap.add_argument("--in-flight", type=int, default=12,
                     help="batches in flight: steps are issued round-robin on this many HIP streams, "
-                         "each with its own plan scratch and output tables")
+                         "each slot with its own tables, broker sets, plan scratch and outputs")
+    ap.add_argument("--same-batch", action="store_true",
+                    help="every slot solves slot 0's tables and broker sets (the consistency stress of "
+                         "scripts/stress_inflight.py; not a measurement mode)")
     ap.add_argument("--stats", default="", help="write the per-phase device counters (JSON) here")
     ap.add_argument("--waves", type=int, default=int(os.environ.get("KAS_BENCH_WAVES", "0")),
                     help="wavefronts per scenario workgroup (0 = the plan's choice)")
@@ -116,18 +136,30 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd)
 
 
+def sources_sha16() -> str:
+    """Hash of the kernel sources (csrc/*.hip, *.h + the ABI header): ties a committed profile to the code it
+    was taken from (the built .so is not tracked)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "kafka-assigner_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "kas_abi.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 # -------------------------------------------------------------------------------------------------
 # the two runs behind one interface: HIP (the product) and the CPU stub (harness self-test)
 # -------------------------------------------------------------------------------------------------
 class HipRun:
-    """Inputs in HBM, one plan + output tables + stream per in-flight slot."""
+    """Inputs in HBM; one set of tables + broker sets + plan + output tables + stream per in-flight slot."""
 
     backend = "nccl"
 
     def __init__(self, args, rank, world, local_rank, lo, hi, action_mix):
         import torch
         from kafka_assigner_amd import generator as G, native
-        from kafka_assigner_amd.flatten import node_set_batch
         assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
         assert torch.cuda.device_count() > local_rank, \
             f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)"
@@ -140,14 +172,20 @@ class HipRun:
         self.device_index = local_rank
         S, P, N, R, RF = hi - lo, args.partitions, args.brokers, args.racks, args.rf
         self.S, self.lo = S, lo
-        gen = torch.Generator(device=self.dev)
-        gen.manual_seed(args.seed + 7919 * rank)
-        self.d_cur = G.torch_random_assignment(gen, S, P, N, R, RF, self.dev)          # int32 [S, P, RF]
         self.ctx = native.DeviceContext(local_rank)
         self.n_slots = max(1, min(args.in_flight, args.steps))
+        self.distinct = 1 if args.same_batch else self.n_slots
+        # every slot its own current assignments (slot 0's are the ones rounds 1 and 2 measured)
+        self.d_cur = []
+        for k in range(self.distinct):
+            gen = torch.Generator(device=self.dev)
+            gen.manual_seed(args.seed + 7919 * rank + SLOT_SEED_STRIDE * k)
+            self.d_cur.append(G.torch_random_assignment(gen, S, P, N, R, RF, self.dev))      # int32 [S, P, RF]
         self.slots = []
-        self.fb = None
         self.set_actions(action_mix)
+
+    def slot_seed(self, k):
+        return self.args.seed + SLOT_SEED_STRIDE * (k if self.distinct > 1 else 0)
 
     def set_actions(self, action_mix):
         """(Re)build the per-scenario broker sets and the plans for an action mix."""
@@ -157,30 +195,32 @@ class HipRun:
         args = self.args
         for sl in self.slots:
             sl["plan"].close()
-        self.ids, self.racks, self.actions = [], [], []
-        for s in range(self.S):
-            act, bs = G.scenario_action(args.seed, self.lo + s, args.brokers, args.racks, actions=action_mix)
-            self.actions.append(act); self.ids.append(bs.node_id); self.racks.append(bs.node_rack)
-        self.fb = node_set_batch(self.ids, self.racks, args.partitions, args.rf, args.rf)
         S = self.S
         old = self.slots
         self.slots = []
         for i in range(self.n_slots):
-            plan_ = native.Plan(self.ctx, self.fb)
+            ids, racks, actions = [], [], []
+            for s in range(S):
+                act, bs = G.scenario_action(self.slot_seed(i), self.lo + s, args.brokers, args.racks, actions=action_mix)
+                actions.append(act); ids.append(bs.node_id); racks.append(bs.node_rack)
+            fb = node_set_batch(ids, racks, args.partitions, args.rf, args.rf)
+            plan_ = native.Plan(self.ctx, fb)
             if args.waves or args.groups or args.plan_flags:
                 plan_.set_flags((args.waves << 8) | (args.groups << 12) | args.plan_flags)
             if old:
-                sl = old[i]; sl["plan"] = plan_
+                sl = old[i]
             else:
                 # a dedicated HIP stream per slot, shared by its solver launches and its RCCL
                 # all-gather (handle 0, torch's default stream, would select the library's own)
-                sl = {"plan": plan_,
-                      "out": torch.empty(self.fb.out_len, dtype=torch.int32, device=self.dev),
+                sl = {"out": torch.empty(fb.out_len, dtype=torch.int32, device=self.dev),
                       "tr": torch.zeros(S * 16, dtype=torch.uint8, device=self.dev),
                       "sr": torch.zeros(S * 32, dtype=torch.uint8, device=self.dev),
                       "stream": torch.cuda.Stream(self.dev)}
                 sl["stream"].wait_stream(torch.cuda.current_stream(self.dev))
+            sl.update(plan=plan_, fb=fb, ids=ids, racks=racks, actions=actions,
+                      cur=self.d_cur[i if self.distinct > 1 else 0])
             self.slots.append(sl)
+        self.actions = self.slots[0]["actions"]
         # set-up, not warm-up: every slot's plan runs once so that no slot meets its first launch
         # (scratch first touched, kernels resident) inside the timed region when K is small
         for sl in self.slots:
@@ -189,7 +229,7 @@ class HipRun:
         self.step_no = 0
 
     def solve(self, sl):
-        sl["plan"].solve_device(self.d_cur.data_ptr(), sl["out"].data_ptr(), sl["tr"].data_ptr(),
+        sl["plan"].solve_device(sl["cur"].data_ptr(), sl["out"].data_ptr(), sl["tr"].data_ptr(),
                                 sl["sr"].data_ptr(), stream=sl["stream"].cuda_stream)
 
     def stream_ctx(self, sl):
@@ -221,9 +261,11 @@ class HipRun:
     def algorithmic_bytes(self):
         return self.slots[0]["plan"].algorithmic_bytes
 
-    def host_cur(self, idx):
-        return self.torch.stack([self.d_cur[s] for s in idx]).cpu().numpy() if len(idx) != self.S \
-            else self.d_cur.cpu().numpy()
+    def host_cur(self, slot, idx=None):
+        cur = self.slots[slot]["cur"]
+        if idx is None or len(idx) == self.S:
+            return cur.cpu().numpy()
+        return self.torch.stack([cur[s] for s in idx]).cpu().numpy()
 
     def close(self):
         for sl in self.slots:
@@ -244,6 +286,7 @@ class StubRun:
         self.device_name, self.device_index = "cpu-stub", local_rank
         self.S, self.lo = hi - lo, lo
         self.n_slots = max(1, min(args.in_flight, args.steps))
+        self.distinct = self.n_slots
         self.slots = [{"sr": torch.zeros(self.S * 32, dtype=torch.uint8)} for _ in range(self.n_slots)]
         self.step_no = 0
         self.actions = ["stub"] * self.S
@@ -372,8 +415,17 @@ def run_rank(args) -> int:
             el = float(t.item())
         return el
 
-    elapsed = timed(args.steps, args.warmup)
-    fill_us, order_us, kern_n = run.phase_times()
+    # the timed region, --repeats times: W warm-up steps before the first, then exactly K steps each,
+    # bracketed by barrier + synchronize on both sides, max over ranks; the median repeat is the figure
+    n_rep = max(1, args.repeats)
+    reps, rep_kernel_times = [], []
+    for r in range(n_rep):
+        reps.append(timed(args.steps, args.warmup if r == 0 else 0))
+        rep_kernel_times.append(run.phase_times())
+    order = sorted(range(n_rep), key=lambda r: reps[r])
+    med = order[(n_rep - 1) // 2]
+    elapsed = reps[med]
+    fill_us, order_us, kern_n = rep_kernel_times[med]
 
     if args.stats and rank == 0 and not args.stub:
         st = run.slots[0]["plan"].stats().astype(np.float64)
@@ -387,9 +439,10 @@ def run_rank(args) -> int:
         summary["order_kernel_avg_us"] = order_us
         json.dump(summary, open(args.stats, "w"), indent=1)
 
-    # ---- results of this rank (headline mix), and what the collective handed back ----------------
+    # ---- results of this rank (headline mix): the records EVERY slot's last timed solve left ------
+    slot_records = [run.records_tensor(sl).cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE).copy() for sl in run.slots]
     sl0 = run.slots[0]
-    sr = run.records_tensor(sl0).cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE).copy()
+    sr = slot_records[0]
     ok = int((sr["status"] == abi.KAS_OK).sum())
     gathered_ok = True
     if world > 1:
@@ -404,14 +457,14 @@ def run_rank(args) -> int:
     allgather_us = None
     if world > 1:
         fence()
-        reps = 20
+        n_ag = 20
         t0 = time.perf_counter()
-        for i in range(reps):
+        for i in range(n_ag):
             sl = run.slots[i % run.n_slots]
             with run.stream_ctx(sl):
                 sharding.gather_records(run.records_tensor(sl), total, out=sl["all"])
         fence()
-        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device=run.dev)
+        t = torch.tensor([(time.perf_counter() - t0) / n_ag * 1e6], dtype=torch.float64, device=run.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         allgather_us = float(t.item())
 
@@ -442,25 +495,27 @@ def run_rank(args) -> int:
                    "note": "a failed scenario (the reference's KAS:183-184 stranding at zero slack) skips P5, "
                            "which is why this mix is not the headline"}
         run.set_actions(action_mix)                      # back to the headline mix for the parity leg
-        run.solve(run.slots[0]); run.synchronize()
+        # (set_actions solves every slot once: slot 0's lists are the headline mix's again)
 
     out_line = None
     if rank == 0:
         P, N, R, RF = args.partitions, args.brokers, args.racks, args.rf
-        checked, checked_lists, cpu = 0, 0, None
+        parity, cpu = {"records": 0, "lists": 0, "slots": 0}, None
         if not args.stub:
-            checked, checked_lists, cpu = parity_and_cpu_baselines(args, run, sr, world)
+            parity, cpu = parity_and_cpu_baselines(args, run, slot_records, world)
         alg_bytes = run.algorithmic_bytes()
         value = total * args.steps / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
         achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9          # per GPU: rank 0's bytes per step time
         per_launch = alg_bytes / ((fill_us + order_us) * 1e-6) / 1e9 if (fill_us + order_us) > 0 else 0.0
+        describe = run.describe()
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
             "regime": f"whole-job rate per GPU: algorithmic bytes of one solve / ms_per_step, "
                       f"{run.n_slots} batches in flight",
-            "kernel": run.describe(),
+            "kernel": describe,
+            "kernel_sources_sha16": sources_sha16(),
             "algorithmic_bytes_per_launch": alg_bytes,
             "in_flight_launch": {"fill_kernel_us": fill_us, "order_kernel_us": order_us, "launches_timed": kern_n,
                                  "achieved": per_launch, "frac": per_launch / HBM_PEAK_GBPS,
@@ -475,12 +530,18 @@ def run_rank(args) -> int:
                                            dominant_kernel_achieved=alg_bytes / (max(alone["order_kernel_us"], alone["fill_kernel_us"]) * 1e-6) / 1e9
                                            if a_us > 0 else 0.0)
         shape_c3 = (S, P, N, R, RF) == C3_SHAPE
+        rates = [total * args.steps / e for e in reps]
         out_line = {
             "metric": "assignment scenarios/sec at 100k partitions x 1k brokers RF=3",
             "value": value, "unit": "scenarios/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
+            "repeats": {"n": n_rep, "value_is": "median repeat", "values": rates, "min": min(rates), "max": max(rates),
+                        "spread_pct": 100.0 * (max(rates) - min(rates)) / value if value > 0 else None,
+                        "ms_per_step_each": [1e3 * e / args.steps for e in reps],
+                        "note": f"each repeat = exactly {args.steps} steps between barrier + synchronize; "
+                                f"{args.warmup} warm-up steps before the first"},
             "config": {
                 "workload": f"{'BASELINE.json configs[2]' if shape_c3 else 'custom shape'}: "
                             f"batch of {S} independent scenarios per GPU, "
@@ -492,10 +553,15 @@ def run_rank(args) -> int:
                 "ok_scenarios_rank0": ok, "failed_scenarios_rank0": S - ok,
                 "failed_note": "a failed scenario is the reference's own KAS:183-184 stranding, "
                                "reproduced bit-exactly (status + partition id)",
-                "parity_checked_scenarios": checked, "parity_list_compared_scenarios": checked_lists,
+                "parity_checked_scenarios": parity["records"], "parity_list_compared_scenarios": parity["lists"],
+                "parity_checked_slots": parity["slots"],
+                "parity_note": "records (status, failing topic / partition, movement counts, digest of every emitted "
+                               "cell) of every slot's last timed solve against the CPU solvers; every list of slot 0 "
+                               "against the oracle",
                 "collective": "all_gather of 32-byte result records per step" if world > 1 else "none (1 GPU)",
                 "allgather_alone_us": allgather_us,
-                "batches_in_flight": run.n_slots, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "batches_in_flight": run.n_slots, "distinct_batches_in_flight": run.distinct,
+                "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "setup_solves_per_slot": 0 if args.stub else 1,
                 "literal_c3_mix": literal,
             },
@@ -506,14 +572,28 @@ def run_rank(args) -> int:
             out_line["stub"] = True
             out_line["metric"] = "STUB harness self-test - not a measurement"
             out_line["config"]["gathered_records_ok"] = gathered_ok
-        # PMC-measured HBM traffic of the same command, when a committed profile provides it
+        # PMC-measured HBM traffic: only from a committed profile of the SAME kernels (the plan's own
+        # description) built from the SAME sources — anything else would be a stale number
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if prof.get("scenarios") == S and prof.get("partitions") == P and not args.stub:
-                out_line["roofline"]["traffic"] = prof["hbm_bytes_per_launch"]
-                out_line["roofline"]["traffic_source"] = prof.get("source")
+            if (not args.stub and prof.get("kernel") == describe and
+                    prof.get("kernel_sources_sha16") == roof["kernel_sources_sha16"]):
+                roof["traffic"] = prof["hbm_bytes_per_launch"]
+                roof["traffic_source"] = prof.get("source")
+            elif not args.stub:
+                roof["traffic_note"] = ("profiles/pmc_traffic.json was taken from other kernels or sources "
+                                        f"({prof.get('kernel_sources_sha16')}): not quoted")
         except Exception:
             pass
+        if not args.stub and not args.no_extras and world == 1:
+            try:
+                out_line["end_to_end"] = end_to_end_leg(args, run)
+            except Exception as e:                       # (a leg of its own: never costs the headline line)
+                out_line["end_to_end"] = {"error": repr(e)}
+            try:
+                out_line["other_configs"] = other_configs_leg(args, run)
+            except Exception as e:
+                out_line["other_configs"] = {"error": repr(e)}
         print(json.dumps(out_line), flush=True)
     run.close()
     if world > 1:
@@ -522,60 +602,87 @@ def run_rank(args) -> int:
     return 0
 
 
-def parity_and_cpu_baselines(args, run, sr, world):
-    """Rank 0: compare the whole batch with the oracle (records of every scenario, and the lists of
-    every scenario unless --check bounds them) and time the CPU baselines on the same scenarios."""
+def parity_and_cpu_baselines(args, run, slot_records, world):
+    """Rank 0.  Every slot: the records its last timed solve left against the flat-array CPU solver
+    (B2) on that slot's own tables and broker sets.  Slot 0 in addition: the whole batch with the oracle
+    (B1), every list.  The CPU baselines are timed on the same solves."""
     from kafka_assigner_amd import abi
     from kafka_assigner_amd.flatten import node_set_batch
     from oracle_lib import cpu_fast_solve, host_threads, oracle_solve
     S, P, RF = run.S, args.partitions, args.rf
     n_check = S if args.check < 0 else max(0, min(args.check, S))
     if n_check == 0:
-        return 0, 0, None
+        return {"records": 0, "lists": 0, "slots": 0}, None
+    sr = slot_records[0]
     pick = list(range(n_check))
     bad = np.nonzero(sr["status"] != abi.KAS_OK)[0]
     if len(bad) and int(bad[0]) not in pick:            # keep a failing scenario in a bounded sample
         pick[-1] = int(bad[0])
-    h_cur = run.host_cur(pick)
-    sub = node_set_batch([run.ids[s] for s in pick], [run.racks[s] for s in pick], P, RF, RF, cur=h_cur)
+    sl0 = run.slots[0]
+    h_cur = run.host_cur(0, pick)
+    sub = node_set_batch([sl0["ids"][s] for s in pick], [sl0["racks"][s] for s in pick], P, RF, RF, cur=h_cur)
     cores = host_threads()
+    fields = ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest")
 
-    def median_wall(solve, reps):
-        """The whole batch on every host core inside one C call: median wall time of `reps` solves."""
-        walls, res = [], None
-        for _ in range(reps):
+    def median_wall(solve, batch, n):
+        """The whole batch on every host core inside one C call: median wall time of `n` solves into the same
+        host buffers, after one untimed solve (the GPU figures are warm figures too: no first touch of fresh
+        pages, no NUMA placement of a new buffer, inside a timed call)."""
+        from kafka_assigner_amd.flatten import host_tables
+        into = host_tables(batch)
+        walls, res = [], solve(batch, threads=0, into=into)
+        for _ in range(n):
             t1 = time.perf_counter()
-            res = solve(sub, threads=0)
+            res = solve(batch, threads=0, into=into)
             walls.append(time.perf_counter() - t1)
-        return sorted(walls)[len(walls) // 2], res
+        return (sorted(walls)[len(walls) // 2] if walls else None), res
 
     timed_cpu = not args.no_cpu and world == 1
-    b1_all, want = median_wall(oracle_solve, 3 if timed_cpu else 1)     # B1 (and the checker's answers)
+    b1_all, want = median_wall(oracle_solve, sub, 3 if timed_cpu else 0)      # B1 (and the checker's answers)
     b1_threads = want.threads_used
     ow = RF
-    got_out = run.slots[0]["out"].cpu().numpy() if n_check == S else None
+    got_out = sl0["out"].cpu().numpy() if n_check == S else None
     for i, s in enumerate(pick):
-        for f in ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest"):
-            assert sr[f][s] == want.scenario_results[f][i], f"scenario {s}: {f} differs from the oracle"
+        for f in fields:
+            assert sr[f][s] == want.scenario_results[f][i], f"slot 0 scenario {s}: {f} differs from the oracle"
         rows = got_out[s * P * ow:(s + 1) * P * ow] if got_out is not None else \
-            run.slots[0]["out"][s * P * ow:(s + 1) * P * ow].cpu().numpy()
-        assert (rows == want.out[i * P * ow:(i + 1) * P * ow]).all(), f"scenario {s}: lists differ from the oracle"
-    checked = checked_lists = len(pick)
+            sl0["out"][s * P * ow:(s + 1) * P * ow].cpu().numpy()
+        assert (rows == want.out[i * P * ow:(i + 1) * P * ow]).all(), f"slot 0 scenario {s}: lists differ from the oracle"
+    parity = {"records": len(pick), "lists": len(pick), "slots": 1}
+
+    # every other slot: its own tables, its own broker sets, the records of its last timed solve
+    fast0 = None
+    if n_check == S:
+        for k in range(run.n_slots):
+            sl = run.slots[k]
+            if k > 0 and run.distinct == 1:
+                assert (slot_records[k] == sr).all(), f"slot {k} (same inputs as slot 0) left different records"
+                parity["records"] += S; parity["slots"] += 1
+                continue
+            batch = sub if k == 0 else node_set_batch(sl["ids"], sl["racks"], P, RF, RF, cur=run.host_cur(k))
+            fast = cpu_fast_solve(batch, threads=0)
+            if k == 0:
+                fast0 = fast
+                for f in fields:
+                    assert (fast.scenario_results[f][:S] == want.scenario_results[f][:S]).all(), f"cpu_fast {f} differs from the oracle"
+                assert (fast.out[:S * P * ow] == want.out[:S * P * ow]).all(), "cpu_fast lists differ from the oracle"
+            else:
+                for f in fields:
+                    diff = np.nonzero(slot_records[k][f] != fast.scenario_results[f][:S])[0]
+                    assert diff.size == 0, f"slot {k} scenario {int(diff[0])}: {f} differs from the CPU solver"
+                parity["records"] += S; parity["slots"] += 1
+            del batch
 
     cpu = None
     if timed_cpu:
-        b2_all, fast = median_wall(cpu_fast_solve, 3)   # B2, scenario-parallel on every host core
-        for f in ("status", "fail_partition", "moved_replicas", "moved_partitions", "digest"):
-            assert (fast.scenario_results[f][:len(pick)] == want.scenario_results[f][:len(pick)]).all(), \
-                f"cpu_fast {f} differs from the oracle"
-        assert (fast.out[:len(pick) * P * ow] == want.out[:len(pick) * P * ow]).all(), "cpu_fast lists differ"
+        b2_all, fast0 = median_wall(cpu_fast_solve, sub, 5)
 
         def one_core(solve):
             done, spent, m = 0, 0.0, 4
             t_c0 = time.perf_counter()
             while True:
                 idx = [(done + i) % len(pick) for i in range(m)]
-                part = node_set_batch([run.ids[pick[j]] for j in idx], [run.racks[pick[j]] for j in idx], P, RF, RF,
+                part = node_set_batch([sl0["ids"][pick[j]] for j in idx], [sl0["racks"][pick[j]] for j in idx], P, RF, RF,
                                       cur=h_cur[idx])
                 t2 = time.perf_counter()
                 solve(part, threads=1)
@@ -587,23 +694,221 @@ def parity_and_cpu_baselines(args, run, sr, world):
 
         d1, s1 = one_core(oracle_solve)
         d2, s2 = one_core(cpu_fast_solve)
+        r1, r2 = d1 / s1, d2 / s2
         cpu = {
-            "value": d1 / s1, "unit": "scenarios/s", "cores": 1, "kind": "port",
+            "value": r1, "unit": "scenarios/s", "cores": 1, "kind": "port",
             "sample": f"B1 oracle/kas_oracle.c (C restatement of the reference Java, rescans order[0..] per orphan "
                       f"like KAS:175), 1 thread, {d1} scenarios of the same batch, {s1:.1f} s solve time; "
                       f"no JVM in this image",
             "host_hardware_threads": cores,
             "oracle_all_cores": {"value": len(pick) / b1_all, "unit": "scenarios/s", "cores": b1_threads,
-                                 "sample": f"{len(pick)} scenarios (the whole batch), pthreads inside one C call, "
-                                           f"{b1_all:.2f} s wall (median of 3)"},
-            "cpu_fast": {"value": d2 / s2, "unit": "scenarios/s", "cores": 1, "kind": "port",
+                                 "scaling_efficiency": (len(pick) / b1_all) / (r1 * b1_threads),
+                                 "sample": f"{len(pick)} scenarios (the whole batch), pthreads inside one C call with "
+                                           f"per-thread scratch arenas, {b1_all:.2f} s wall (median of 3, same host buffers)"},
+            "cpu_fast": {"value": r2, "unit": "scenarios/s", "cores": 1, "kind": "port",
                          "sample": f"B2 oracle/kas_cpu_fast.c (flat arrays, full-node skipping, same results: "
                                    f"diffed against B1 on the whole batch), 1 thread, {d2} scenarios, {s2:.1f} s"},
-            "cpu_fast_all_cores": {"value": len(pick) / b2_all, "unit": "scenarios/s", "cores": fast.threads_used,
-                                   "sample": f"{len(pick)} scenarios (the whole batch), pthreads inside one C call, "
-                                             f"{b2_all:.2f} s wall (median of 3)"},
+            "cpu_fast_all_cores": {"value": len(pick) / b2_all, "unit": "scenarios/s", "cores": fast0.threads_used,
+                                   "scaling_efficiency": (len(pick) / b2_all) / (r2 * fast0.threads_used),
+                                   "sample": f"{len(pick)} scenarios per solve, pthreads inside one C call with per-thread "
+                                             f"scratch arenas, {b2_all:.2f} s wall (median of 5, same host buffers)"},
         }
-    return checked, checked_lists, cpu
+    return parity, cpu
+
+
+# -------------------------------------------------------------------------------------------------
+# end to end through the host-buffer boundary (what JNI, the CLI and the C++ mirror call)
+# -------------------------------------------------------------------------------------------------
+def end_to_end_leg(args, run):
+    """SURVEY 8(d)'s second definition of the metric: tables in HOST memory in, results in HOST memory out.
+    (a) what-if: S broker sets over ONE snapshot (one shared cur table), kas_solve_host_select — records of
+    every variant, the rows of one; same batch again and fresh broker sets on every call.  (b) plain: every
+    scenario its own tables, kas_solve_host, pageable and pinned caller buffers, with the PCIe rate."""
+    import ctypes as C
+    from kafka_assigner_amd import abi, generator as G, native
+    from kafka_assigner_amd.flatten import batch_desc, host_tables, node_set_batch
+    from oracle_lib import cpu_fast_solve, oracle_solve
+    S, P, N, R, RF = run.S, args.partitions, args.brokers, args.racks, args.rf
+    L = native.load()
+    ctx = native.DeviceContext(run.device_index)
+    fields = ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest")
+    snapshot = run.host_cur(0, [0])[0]                                  # ONE current assignment [P, RF]
+
+    def variants(seed):
+        ids, racks = [], []
+        for s in range(S):
+            _, bs = G.scenario_action(seed, s, N, R, actions=G.BENCH_ACTIONS)
+            ids.append(bs.node_id); racks.append(bs.node_rack)
+        return node_set_batch(ids, racks, P, RF, RF, shared_cur=True, cur=snapshot)
+
+    sets = [variants(args.seed + 17 + i) for i in range(3)]
+    select = np.asarray([S // 2], dtype=np.int32)
+    cells = P * RF
+    calls = []
+    for fb in sets:                                                     # buffers and descriptors outside the timed calls
+        t, ho = host_tables(fb, out_len=native.selected_out_len(fb, select))
+        calls.append((fb, batch_desc(fb), t, ho))
+
+    def call(i):
+        fb, bd, t, ho = calls[i]
+        native._check(L.kas_solve_host_select(ctx._h, C.byref(bd), C.byref(t), select.ctypes.data_as(C.POINTER(C.c_int32)), 1))
+
+    call(0)                                                             # first call: allocations, plan
+    n = 6
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call(0)
+    same = (time.perf_counter() - t0) / n
+    call(1); call(2)
+    t0 = time.perf_counter()
+    for i in range(n):
+        call(1 + i % 2)                                                 # other broker sets than the call before
+    fresh = (time.perf_counter() - t0) / n
+    hs = ctx.host_stats()
+    # parity: every record of every variant set against the CPU solver, the selected variant's rows against the oracle
+    for fb, _, _, ho in calls:
+        want = cpu_fast_solve(fb, threads=0)
+        for f in fields:
+            assert (ho.scenario_results[f][:S] == want.scenario_results[f][:S]).all(), f"end_to_end what-if: {f} differs"
+        one = node_set_batch([fb.node_id[int(fb.scen['node_off'][select[0]]):int(fb.scen['node_off'][select[0]]) + int(fb.scen['n_nodes'][select[0]])]],
+                             [fb.node_rack[int(fb.scen['node_off'][select[0]]):int(fb.scen['node_off'][select[0]]) + int(fb.scen['n_nodes'][select[0]])]],
+                             P, RF, RF, cur=snapshot)
+        assert (ho.out[:cells] == oracle_solve(one).out[:cells]).all(), "end_to_end what-if: selected rows differ from the oracle"
+    up = 4 * (snapshot.size + 2 * int(sets[0].node_id.size)) + 96 * S
+    res = {
+        "value": S / fresh, "unit": "scenarios/s",
+        "what": f"kas_solve_host_select (the entry JNI's layout-3 payload and whatif.py call): {S} broker-set variants "
+                f"of ONE {P} x {N} x RF {RF} snapshot per call, host buffers in and out, blocking; records of every "
+                f"variant + the rows of one come back; value = fresh broker sets on every call",
+        "what_if_fresh_broker_sets_each_call": {"value": S / fresh, "ms_per_call": 1e3 * fresh},
+        "what_if_same_batch_again": {"value": S / same, "ms_per_call": 1e3 * same},
+        "bytes_up_per_call": up, "bytes_down_per_call": 48 * S + 4 * cells,
+        "parity": f"{3 * S} records against the CPU solver, the selected variant's {P} lists against the oracle",
+        "host_path_counters": {"calls": hs[0], "plans_found_byte_for_byte": hs[1], "device_allocations": hs[2]},
+    }
+    # (b) every scenario its own tables: PCIe-bound
+    m = min(S, 240)
+    sl0 = run.slots[0]
+    fbp = node_set_batch(sl0["ids"][:m], sl0["racks"][:m], P, RF, RF, cur=run.host_cur(0, list(range(m))))
+    bdp = batch_desc(fbp)
+    t_pg, ho_pg = host_tables(fbp)
+    pin_cur, pin_out = native.PinnedArray(fbp.cur.size), native.PinnedArray(fbp.out_len)
+    pin_cur.array[:] = fbp.cur
+    t_pin, ho_pin = host_tables(fbp)
+    t_pin.cur = pin_cur.array.ctypes.data; t_pin.out = pin_out.array.ctypes.data
+    plain = {}
+    for name, t in (("pageable", t_pg), ("pinned", t_pin)):
+        native._check(L.kas_solve_host(ctx._h, C.byref(bdp), C.byref(t)))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            native._check(L.kas_solve_host(ctx._h, C.byref(bdp), C.byref(t)))
+        dt = (time.perf_counter() - t0) / 3
+        plain[name] = {"value": m / dt, "unit": "scenarios/s", "ms_per_call": 1e3 * dt,
+                       "pcie_gb_per_s": 4 * (fbp.cur.size + fbp.out_len) / dt / 1e9}
+    want = cpu_fast_solve(fbp, threads=0)
+    assert (ho_pg.out[:fbp.out_len] == want.out[:fbp.out_len]).all() and (pin_out.array == want.out[:fbp.out_len]).all(), \
+        "end_to_end plain: lists differ from the CPU solver"
+    for f in fields:
+        assert (ho_pin.scenario_results[f][:m] == want.scenario_results[f][:m]).all()
+    plain["what"] = (f"kas_solve_host: {m} scenarios with their own {P} x {RF} tables per call ({4 * fbp.cur.size / 1e6:.0f} MB up, "
+                     f"{4 * fbp.out_len / 1e6:.0f} MB down), cut into scenario ranges whose upload / solve / download overlap; "
+                     f"pinned = caller buffers from kas_host_alloc (DMA without staging)")
+    res["plain_every_scenario_its_own_tables"] = plain
+    pin_cur.close(); pin_out.close()
+    ctx.close()
+    return res
+
+
+# -------------------------------------------------------------------------------------------------
+# BASELINE.json's other single-GPU configurations, each with a CPU figure measured in the same run
+# -------------------------------------------------------------------------------------------------
+def other_configs_leg(args, run):
+    import torch
+    from kafka_assigner_amd import abi, generator as G, native
+    from kafka_assigner_amd.flatten import uniform_batch
+    from oracle_lib import cpu_fast_solve, host_threads
+    dev = run.dev
+    ctx = run.ctx
+    out = {}
+
+    def gpu_ms(fb, n=20):
+        plan = native.Plan(ctx, fb)
+        d_cur = torch.from_numpy(fb.cur).to(dev)
+        d_out = torch.empty(fb.out_len, dtype=torch.int32, device=dev)
+        d_tr = torch.zeros(fb.n_topics * 16, dtype=torch.uint8, device=dev)
+        d_sr = torch.zeros(fb.n_scenarios * 32, dtype=torch.uint8, device=dev)
+        st = torch.cuda.Stream(dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+
+        def go():
+            plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
+        go(); st.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            go()
+        st.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        f_us, o_us, _ = plan.phase_times_us()
+        desc = plan.describe()
+        sr = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE).copy()
+        rows = d_out.cpu().numpy()
+        plan.close()
+        return ms, f_us, o_us, desc, sr, rows
+
+    def cpu_ms(fb, threads, n=3):
+        walls, res = [], None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            res = cpu_fast_solve(fb, threads=threads)
+            walls.append(time.perf_counter() - t0)
+        return 1e3 * sorted(walls)[len(walls) // 2], res
+
+    def check(fb, sr, rows, want, what):
+        for f in ("status", "fail_partition", "moved_replicas", "moved_partitions", "digest"):
+            assert (sr[f] == want.scenario_results[f][:fb.n_scenarios]).all(), f"{what}: {f} differs from the CPU solver"
+        assert (rows == want.out[:fb.out_len]).all(), f"{what}: lists differ from the CPU solver"
+
+    # configs[1]: one scenario, 10k partitions x 100 brokers x 10 racks, RF 3, decommission 1 broker
+    cur = G.random_assignment(0, 10000, 100, 10, 3)
+    bs = G.perturb_brokers(100, 10, remove=[0])
+    fb = uniform_batch(cur[None], bs.node_id[None], bs.node_rack[None], 3)
+    ms, f_us, o_us, desc, sr, rows = gpu_ms(fb, n=200)
+    c1, want = cpu_ms(fb, 1, n=9)
+    check(fb, sr, rows, want, "configs[1]")
+    out["configs[1]"] = {
+        "workload": "one scenario, 10k partitions x 100 brokers x 10 racks, RF 3, decommission 1 broker",
+        "gpu_ms_per_solve": ms, "gpu_fill_kernel_us": f_us, "gpu_order_kernel_us": o_us, "kernel": desc,
+        "cpu_fast_one_core_ms": c1, "cpu_fast_all_cores_ms": c1,
+        "note": "a single scenario has no scenario-level parallelism for the host (all-core = one core) and little for "
+                "the GPU: ~1.6k dependent solver steps; one CPU core and the GPU take about the same time here",
+    }
+    # configs[4]: 1M partitions x 5k brokers x 40 racks, RF 5, remove every 50th broker + add 200; one scenario and a
+    # what-if batch of 16 over the same snapshot (rack map on / off alternating)
+    P5, N5, R5, RF5 = 1000000, 5000, 40, 5
+    cur5 = G.random_assignment(7, P5, N5, R5, RF5)
+    one = G.perturb_brokers(N5, R5, remove=list(range(0, N5, 50)), add=200, rack_aware=True)
+    fb1 = uniform_batch(cur5[None], one.node_id[None], one.node_rack[None], RF5)
+    ms1, f1, o1, desc1, sr1, rows1 = gpu_ms(fb1, n=5)
+    c5_1, want1 = cpu_ms(fb1, 1, n=3)
+    check(fb1, sr1, rows1, want1, "configs[4] x1")
+    nb = 16
+    sets = [G.perturb_brokers(N5, R5, remove=list(range(k % 50, N5, 50)), add=200, rack_aware=(k % 2 == 0)) for k in range(nb)]
+    fbn = uniform_batch(cur5, np.stack([b.node_id for b in sets]), np.stack([b.node_rack for b in sets]), RF5, shared_cur=True)
+    msn, fn_, on_, descn, srn, rowsn = gpu_ms(fbn, n=3)
+    c5_n, wantn = cpu_ms(fbn, 0, n=3)
+    check(fbn, srn, rowsn, wantn, f"configs[4] x{nb}")
+    out["configs[4]"] = {
+        "workload": "1M partitions x 5k brokers x 40 racks, RF 5, remove every 50th broker + add 200 (N = 5100, cap 981)",
+        "one_scenario": {"gpu_ms_per_solve": ms1, "gpu_fill_us": f1, "gpu_order_kernel_us": o1, "kernel": desc1,
+                         "cpu_fast_one_core_ms": c5_1, "moved_replicas": int(sr1["moved_replicas"][0])},
+        f"batch_of_{nb}": {"what": f"{nb} broker-set variants of the same snapshot (rack map on / off alternating) in one batch",
+                           "gpu_ms_per_batch": msn, "gpu_scenarios_per_s": 1e3 * nb / msn, "gpu_fill_us": fn_,
+                           "gpu_order_kernel_us": on_, "kernel": descn,
+                           "cpu_fast_all_cores_ms": c5_n, "cpu_fast_all_cores_scenarios_per_s": 1e3 * nb / c5_n,
+                           "cpu_threads": wantn.threads_used},
+        "host_hardware_threads": host_threads(),
+    }
+    return out
 
 
 def main() -> int:

@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define KAS_ABI_VERSION 3
+#define KAS_ABI_VERSION 4
 
 /* Longest replica list the kernels keep in registers: max(cur_width, rf) <= KAS_MAX_WIDTH. */
 #define KAS_MAX_WIDTH 8
@@ -229,16 +229,59 @@ int kas_solve_device(kas_plan* plan, const kas_tables* device_tables, void* hip_
 /* Block until everything enqueued on the context's own stream has finished. */
 int kas_ctx_synchronize(kas_ctx* ctx);
 
-/* Convenience for host callers (JNI / ctypes / C++ mirror): H2D, solve, D2H, blocking.
- * The context keeps what repeated calls can share: its device buffers only ever grow, and the
- * plans of the most recent batch shapes (descriptors + node tables equal byte for byte) are reused,
- * so a caller that solves the same cluster shape again — the CLI's per-topic loop
- * (KafkaAssignmentGenerator.java:172-184), a JVM calling once per topic — pays no hipMalloc /
- * hipFree and no descriptor upload after the first call.  Calls on one context are serialised. */
+/* Host callers (JNI / ctypes / C++ mirror / the CLI's per-topic loop, KAG:172-186): tables in HOST
+ * memory in, results in HOST memory out, blocking.
+ * The context keeps what repeated calls can share: its device buffers only ever grow, and the plans
+ * of the most recent batch shapes are reused — a plan whose descriptors + node tables are equal byte
+ * for byte is used as is, any other one is rebuilt in place over the scratch it already owns (a
+ * what-if caller changes the broker sets on every call) — so a caller pays no hipMalloc / hipFree
+ * after the first call of a shape.  Calls on one context are serialised.
+ * Copies: a pool in memory HIP knows as pinned (kas_host_alloc, hipHostMalloc, hipHostRegister) is
+ * moved by DMA straight from / to the caller's buffer; pageable memory goes through the runtime's
+ * staging.  Only [first, last] element a descriptor refers to is moved in either direction.  Batches
+ * whose tables are large and laid out scenario by scenario are cut into scenario ranges, and the
+ * upload of one range, the solve of the previous one and the download of the one before run
+ * concurrently on three streams.  On an error after work was enqueued the call drains its streams
+ * before it returns (no kernel or copy is left touching the caller's memory). */
 int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables);
 
+/* The what-if form of the same call (KAG:131-187: one snapshot, many broker sets, ONE assignment
+ * printed): every scenario is solved and reports its 16-byte topic records and its 32-byte scenario
+ * record, but out rows come back only for the scenarios listed in select[0..n_select), packed back to
+ * back in that order (per selected scenario its topics in order, P x out_width ints each;
+ * host_tables->out_len >= their sum; out may be NULL when n_select == 0).  With every scenario's
+ * cur_off pointing at the same rows (the layout of kafka-assigner_amd/whatif.py) a call moves one cur
+ * table and the node tables up and a few kilobytes down.  n_select < 0: every row, in place, exactly as
+ * kas_solve_host. */
+int kas_solve_host_select(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables,
+                          const int32_t* select, int32_t n_select);
+
+/* Pinned host memory for table pools (DMA without staging: see kas_solve_host).  A JNI caller wraps
+ * it with NewDirectByteBuffer, a Python caller with numpy.frombuffer. */
+int  kas_host_alloc(int64_t bytes, void** out_ptr);
+void kas_host_free(void* ptr);
+
+/* Sharding below Python (mirror of kafka-assigner_amd/sharding.py shard_range): scenarios
+ * [*lo, *hi) of `total` belong to rank `rank` of `world` — contiguous, sizes differing by at most one,
+ * the larger shards first. */
+void kas_shard_range(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
+
+/* Scenarios [lo, hi) of a batch as a batch of its own: `out` borrows the arrays of `b` (topic and node
+ * pools narrowed to what the slice refers to) and uses scen_scratch[hi - lo] for the rebased scenario
+ * descriptors; `tables_out` (optional, with `tables`) is the matching view of the result arrays — the
+ * bulk pools stay whole, their offsets are absolute.  Topic descriptors of the slice's scenarios must
+ * not be shared with scenarios outside it. */
+int kas_batch_slice(const kas_batch_desc* b, int64_t lo, int64_t hi, kas_scenario_desc* scen_scratch,
+                    kas_batch_desc* out, const kas_tables* tables, kas_tables* tables_out);
+
+/* One batch over several devices: rank r of n_ctx solves kas_shard_range(S, r, n_ctx) on ctxs[r]
+ * (one host thread per context, kas_solve_host on its slice), no communication — the scenarios are
+ * independent and the caller's host arrays are the gather.  Contexts may sit on the same device. */
+int kas_solve_host_sharded(kas_ctx* const* ctxs, int32_t n_ctx, const kas_batch_desc* batch,
+                           const kas_tables* host_tables);
+
 /* Counters of the host path since kas_ctx_create: calls, calls that found their plan in the
- * context's cache, device allocations made (any pointer may be NULL). */
+ * context's cache byte for byte, device allocations made (any pointer may be NULL). */
 int kas_ctx_host_stats(kas_ctx* ctx, int64_t* calls, int64_t* plan_hits, int64_t* device_allocs);
 
 /* Average device time in microseconds of one solve (both kernels) over the launches recorded since

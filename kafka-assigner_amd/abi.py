@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-KAS_ABI_VERSION = 3
+KAS_ABI_VERSION = 4
 KAS_MAX_WIDTH = 8
 
 KAS_E_OK = 0

@@ -19,6 +19,7 @@
 
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kas_abi.h"
@@ -204,23 +205,31 @@ static int set_error(int code, const std::string& msg) {
       return set_error(KAS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
   } while (0)
 
-// Host-path cache of a context (kas_solve_host): device buffers that only ever grow, and the plan
+// device buffer that only ever grows (plans rebuilt in place, the host path's table buffers)
+struct KasBuf { void* p = nullptr; size_t cap = 0; };
+
+// Host-path cache of a context (kas_solve_host): device buffers that only ever grow, and the plans
 // of the most recent batch shapes — a caller that solves the same cluster shape again (the CLI's
-// per-topic loop, a JVM calling once per topic, a what-if planner) pays neither hipMalloc /
-// hipFree nor the descriptor upload again.
-struct KasHostBuf { void* p = nullptr; size_t cap = 0; };
+// per-topic loop, a JVM calling once per topic) finds its plan byte for byte; a what-if planner that
+// changes the broker sets on every call gets the least recently used plan rebuilt in place over the
+// scratch it already owns.  Neither pays hipMalloc / hipFree after the first call of a shape.
 struct KasCachedPlan {
   kas_plan* plan = nullptr;
   uint64_t key = 0;
   std::vector<unsigned char> desc;      // the bytes the key was computed from (compared on a hit)
+  uint64_t sig = 0;                     // batch size + topic descriptors only: what-if variants of one snapshot share it
   uint64_t last_use = 0;
+  uint64_t call = 0;                    // host call that last used the entry (its ranges must not evict each other)
 };
-#define KAS_HOST_PLAN_CACHE 4
+#define KAS_HOST_PLAN_CACHE 16
+#define KAS_HOST_STREAMS 3
 struct kas_ctx {
   int device;
   hipStream_t stream;
+  hipStream_t hstream[KAS_HOST_STREAMS];   // the host path's chains (upload -> solve -> download of a scenario range)
+  hipEvent_t hevent;                       // "shared pools are up" of the current host call
   std::mutex host_mu;                   // kas_solve_host calls on one context are serialised
-  KasHostBuf h_cur, h_out, h_aux, h_ctx, h_tr, h_sr;
+  KasBuf h_cur, h_out, h_aux, h_ctx, h_tr, h_sr;
   KasCachedPlan plans[KAS_HOST_PLAN_CACHE];
   uint64_t use_clock = 0;
   uint64_t host_calls = 0, host_plan_hits = 0, host_allocs = 0;
@@ -239,27 +248,30 @@ struct kas_plan {
   uint32_t flags;               // KAS_FLAG_*
   KasLds lds, lds_fused;
   int32_t n_scenarios, n_topics;
-  // device copies owned by the plan
-  kas_scenario_desc* d_scen;
-  kas_topic_desc* d_topics;
-  int32_t* d_node_id;
-  int32_t* d_node_rack;
-  int64_t* d_accmask_off;
-  uint64_t* d_accmask;
-  int64_t* d_orph_off;
-  int32_t* d_orph;
-  int32_t* d_perm;
-  int64_t* d_stats;
-  // spread fill scratch (allocated on first use, for sp_alloc_chunks chunks per scenario)
+  // device copies and scratch owned by the plan (grow-only: a plan can be rebuilt for another batch)
+  KasBuf b_scen, b_topics, b_node_id, b_node_rack, b_accmask_off, b_accmask, b_orph_off, b_orph, b_perm, b_stats,
+         b_ord_flag, b_sp_hist, b_sp_quota, b_sp_node, b_sp_flag, b_sp_oc;
+  uint64_t* allocs;             // allocation counter to report to (the context's, or NULL)
   int single_topic;             // every scenario has exactly one topic
-  int32_t sp_alloc_chunks;
-  int32_t* d_sp_hist; int32_t* d_sp_quota; int32_t* d_sp_node; int32_t* d_sp_flag; int32_t* d_sp_oc;
+  int32_t sp_alloc_chunks;      // chunks per scenario the spread-fill scratch is sized for
   hipStream_t last_stream;
   int last_slot;                // timer slot of the most recent solve (-1: none yet)
   // kernel timing: event pairs recorded around every launch on the launch stream
   hipEvent_t ev_start[KAS_TIMER_SLOTS], ev_mid[KAS_TIMER_SLOTS], ev_stop[KAS_TIMER_SLOTS];
   int timer_next, timer_count;
 };
+
+static int kas_buf_reserve(KasBuf* b, size_t bytes, uint64_t* allocs, const char* what) {
+  if (bytes == 0) bytes = 16;
+  if (bytes <= b->cap) return KAS_E_OK;
+  if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+  hipError_t e = hipMalloc(&b->p, bytes);
+  if (e != hipSuccess) { b->p = nullptr; return set_error(KAS_E_NOMEM, std::string(what) + ": " + hipGetErrorString(e)); }
+  b->cap = bytes;
+  if (allocs) *allocs += 1;
+  return KAS_E_OK;
+}
+static void kas_buf_free(KasBuf* b) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -316,8 +328,16 @@ int kas_ctx_create(int device, kas_ctx** out_ctx) {
                                     ", the kernels are built for gfx950 only");
   kas_ctx* c = new kas_ctx();
   c->device = device;
+  c->stream = nullptr; c->hevent = nullptr;
+  for (hipStream_t& h : c->hstream) h = nullptr;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete c; return set_error(KAS_E_HIP, hipGetErrorString(e)); }
+  for (hipStream_t& h : c->hstream)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->hevent, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    kas_ctx_destroy(c);
+    return set_error(KAS_E_HIP, hipGetErrorString(e));
+  }
   *out_ctx = c;
   return KAS_E_OK;
 }
@@ -325,11 +345,13 @@ int kas_ctx_create(int device, kas_ctx** out_ctx) {
 void kas_ctx_destroy(kas_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (hipStream_t h : ctx->hstream) if (h) (void)hipStreamSynchronize(h);
   for (KasCachedPlan& c : ctx->plans) if (c.plan) kas_plan_destroy(c.plan);
-  for (KasHostBuf* b : {&ctx->h_cur, &ctx->h_out, &ctx->h_aux, &ctx->h_ctx, &ctx->h_tr, &ctx->h_sr})
-    if (b->p) (void)hipFree(b->p);
-  (void)hipStreamDestroy(ctx->stream);
+  for (KasBuf* b : {&ctx->h_cur, &ctx->h_out, &ctx->h_aux, &ctx->h_ctx, &ctx->h_tr, &ctx->h_sr}) kas_buf_free(b);
+  if (ctx->hevent) (void)hipEventDestroy(ctx->hevent);
+  for (hipStream_t h : ctx->hstream) if (h) (void)hipStreamDestroy(h);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -344,26 +366,17 @@ void kas_plan_destroy(kas_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
-  (void)hipFree(p->d_scen); (void)hipFree(p->d_topics);
-  (void)hipFree(p->d_node_id); (void)hipFree(p->d_node_rack);
-  (void)hipFree(p->d_accmask_off); (void)hipFree(p->d_accmask); (void)hipFree(p->d_stats);
-  (void)hipFree(p->d_orph_off); (void)hipFree(p->d_orph); (void)hipFree(p->d_perm);
-  (void)hipFree(p->d_sp_hist); (void)hipFree(p->d_sp_quota); (void)hipFree(p->d_sp_node);
-  (void)hipFree(p->d_sp_flag); (void)hipFree(p->d_sp_oc);
+  if (p->last_slot >= 0) (void)hipEventSynchronize(p->ev_stop[p->last_slot]);
+  for (KasBuf* b : {&p->b_scen, &p->b_topics, &p->b_node_id, &p->b_node_rack, &p->b_accmask_off, &p->b_accmask,
+                    &p->b_orph_off, &p->b_orph, &p->b_perm, &p->b_stats, &p->b_ord_flag, &p->b_sp_hist, &p->b_sp_quota,
+                    &p->b_sp_node, &p->b_sp_flag, &p->b_sp_oc})
+    kas_buf_free(b);
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
     if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
     if (p->ev_mid[i]) (void)hipEventDestroy(p->ev_mid[i]);
   }
   delete p;
-}
-
-static int upload(void** dst, const void* src, size_t bytes, hipStream_t st) {
-  *dst = nullptr;
-  size_t alloc = bytes > 0 ? bytes : 16;
-  KAS_HIP_TRY(hipMalloc(dst, alloc));
-  if (bytes > 0) KAS_HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
-  return KAS_E_OK;
 }
 
 // opt every kernel this plan may launch into its dynamic LDS size
@@ -396,89 +409,6 @@ static int kas_plan_set_kernels(kas_plan* p) {
   return KAS_E_OK;
 }
 
-int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan) {
-  if (!ctx || !batch || !out_plan) return set_error(KAS_E_INVALID_ARG, "NULL argument");
-  *out_plan = nullptr;
-  KasShape sh;
-  std::string err;
-  int rc = kas_shape_batch(batch, &sh, &err, 0, 0);
-  if (rc != KAS_E_OK) return set_error(rc, err);
-  KAS_HIP_TRY(hipSetDevice(ctx->device));
-
-  kas_plan* p = new kas_plan();
-  memset((void*)p->ev_start, 0, sizeof(p->ev_start));
-  memset((void*)p->ev_stop, 0, sizeof(p->ev_stop));
-  memset((void*)p->ev_mid, 0, sizeof(p->ev_mid));
-  p->ctx = ctx; p->shape = sh;
-  p->Wc = sh.Wc;
-  p->NW = sh.NW;
-  p->G = sh.G;
-  p->tickets = sh.tickets_ok;
-  p->fused = sh.fused_ok;
-  p->lds = sh.lds; p->lds_fused = sh.lds_fused;
-  p->flags = 0;
-  p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
-  p->d_scen = nullptr; p->d_topics = nullptr; p->d_node_id = nullptr; p->d_node_rack = nullptr;
-  p->d_accmask_off = nullptr; p->d_accmask = nullptr; p->d_stats = nullptr; p->last_stream = ctx->stream;
-  p->last_slot = -1;
-  p->d_orph_off = nullptr; p->d_orph = nullptr; p->d_perm = nullptr;
-  p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
-  p->sp_alloc_chunks = 0;
-  p->d_sp_hist = nullptr; p->d_sp_quota = nullptr; p->d_sp_node = nullptr; p->d_sp_flag = nullptr; p->d_sp_oc = nullptr;
-  p->timer_next = 0; p->timer_count = 0;
-  if (p->lds.total > KAS_LDS_LIMIT) {
-    delete p;
-    return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at the instantiated width");
-  }
-  if (!kas_minimal_ok(p->Wc, p->NW, p->G)) {
-    delete p;
-    return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only lists 3 wide, 4 fill waves");
-  }
-  hipStream_t st = ctx->stream;
-#define KAS_PLAN_TRY(call)                                  \
-  do { int rc_ = (call); if (rc_ != KAS_E_OK) { kas_plan_destroy(p); return rc_; } } while (0)
-  KAS_PLAN_TRY(upload((void**)&p->d_scen, batch->scenarios, sizeof(kas_scenario_desc) * (size_t)batch->n_scenarios, st));
-  KAS_PLAN_TRY(upload((void**)&p->d_topics, batch->topics, sizeof(kas_topic_desc) * (size_t)batch->n_topics, st));
-  KAS_PLAN_TRY(upload((void**)&p->d_node_id, batch->node_id, sizeof(int32_t) * (size_t)batch->node_pool_len, st));
-  KAS_PLAN_TRY(upload((void**)&p->d_node_rack, batch->node_rack, sizeof(int32_t) * (size_t)batch->node_pool_len, st));
-  KAS_PLAN_TRY(upload((void**)&p->d_accmask_off, sh.accmask_off.data(), sizeof(int64_t) * sh.accmask_off.size(), st));
-  {
-    hipError_t e = hipMalloc((void**)&p->d_accmask, sizeof(uint64_t) * (size_t)(sh.accmask_words + 1));
-    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "accept-mask scratch: " + std::string(hipGetErrorString(e))); }
-  }
-  KAS_PLAN_TRY(upload((void**)&p->d_orph_off, sh.orph_off.data(), sizeof(int64_t) * sh.orph_off.size(), st));
-  {
-    hipError_t e = hipMalloc((void**)&p->d_orph, sizeof(int32_t) * (size_t)(sh.orph_ints + 64));
-    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "orphan-list scratch: " + std::string(hipGetErrorString(e))); }
-  }
-  {
-    hipError_t e = hipMalloc((void**)&p->d_perm, sizeof(int32_t) * (size_t)(batch->n_scenarios + 1));
-    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "scenario-order scratch: " + std::string(hipGetErrorString(e))); }
-  }
-  {
-    size_t sb = sizeof(int64_t) * KAS_STATS_PER_SCENARIO * (size_t)(batch->n_scenarios + 1);
-    hipError_t e = hipMalloc((void**)&p->d_stats, sb);
-    if (e == hipSuccess) e = hipMemsetAsync(p->d_stats, 0, sb, st);
-    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_NOMEM, "stats buffer: " + std::string(hipGetErrorString(e))); }
-  }
-  for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
-    if (hipEventCreate(&p->ev_start[i]) != hipSuccess || hipEventCreate(&p->ev_stop[i]) != hipSuccess ||
-        hipEventCreate(&p->ev_mid[i]) != hipSuccess) {
-      kas_plan_destroy(p);
-      return set_error(KAS_E_HIP, "hipEventCreate failed");
-    }
-  }
-  {
-    int rc2 = kas_plan_set_kernels(p);
-    if (rc2 != KAS_E_OK) { kas_plan_destroy(p); return rc2; }
-    hipError_t e = hipStreamSynchronize(st);   // descriptors are resident before the caller may free its copies
-    if (e != hipSuccess) { kas_plan_destroy(p); return set_error(KAS_E_HIP, hipGetErrorString(e)); }
-  }
-#undef KAS_PLAN_TRY
-  *out_plan = p;
-  return KAS_E_OK;
-}
-
 // per-chunk histograms: what the shape allows unless switched off (or the general fill is forced)
 static bool kas_plan_fused(const kas_plan* p) {
   return p->fused && !(p->flags & (KAS_FLAG_TWO_PASS_HIST | KAS_FLAG_GENERIC_FILL));
@@ -487,8 +417,108 @@ static bool kas_plan_fused(const kas_plan* p) {
 // chunks per scenario of the spread fill for this plan's next solve, or 0 (one-workgroup fill kernel)
 static int32_t kas_plan_spread_chunks(const kas_plan* p) {
   if (p->NW != 4 || !kas_spread_for(p->Wc).a || (p->flags & KAS_FLAG_GENERIC_FILL)) return 0;
+  // (the quota kernel puts scenarios on grid.y and nodes on grid.x)
+  if (p->shape.n_max <= 0 || p->n_scenarios > 65535) return 0;
   if (kas_fill_lds_layout(p->shape.n_max, p->Wc, 4, p->shape.idmap_entries, p->shape.need_bsearch, 1).total > KAS_LDS_LIMIT) return 0;
   return kas_spread_chunks(p->shape, p->n_scenarios, p->single_topic != 0, (p->flags & KAS_FLAG_SPREAD_FILL) != 0);
+}
+
+// scratch of the spread fill for the plan's current flags (kas_plan_create / kas_plan_set_flags, never a solve)
+static int kas_plan_spread_scratch(kas_plan* p) {
+  const int32_t chunks = kas_plan_spread_chunks(p);
+  if (chunks > 0) {
+    const size_t S = (size_t)p->n_scenarios, NM = (size_t)(p->shape.n_max > 0 ? p->shape.n_max : 1), C = (size_t)chunks;
+    int rc;
+    if ((rc = kas_buf_reserve(&p->b_sp_hist, 4 * S * C * (size_t)p->Wc * NM, p->allocs, "spread-fill scratch")) != KAS_E_OK ||
+        (rc = kas_buf_reserve(&p->b_sp_quota, 4 * S * C * NM, p->allocs, "spread-fill scratch")) != KAS_E_OK ||
+        (rc = kas_buf_reserve(&p->b_sp_node, 4 * S * 2 * NM, p->allocs, "spread-fill scratch")) != KAS_E_OK ||
+        (rc = kas_buf_reserve(&p->b_sp_flag, 4 * (S + 1), p->allocs, "spread-fill scratch")) != KAS_E_OK ||
+        (rc = kas_buf_reserve(&p->b_sp_oc, 4 * S * (C + 2), p->allocs, "spread-fill scratch")) != KAS_E_OK)
+      return rc;
+  }
+  p->sp_alloc_chunks = chunks;
+  return KAS_E_OK;
+}
+
+// (Re)build a plan for a batch: shape, device copies of the descriptors and node tables, scratch.  The
+// plan's buffers only grow, so rebuilding for a batch of the same size allocates nothing.
+static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
+  KasShape sh;
+  std::string err;
+  int rc = kas_shape_batch(batch, &sh, &err, 0, 0);
+  if (rc != KAS_E_OK) return set_error(rc, err);
+  kas_ctx* ctx = p->ctx;
+  KAS_HIP_TRY(hipSetDevice(ctx->device));
+  // a rebuilt plan may still have its last solve in flight on some stream
+  if (p->last_slot >= 0) KAS_HIP_TRY(hipEventSynchronize(p->ev_stop[p->last_slot]));
+  p->shape = sh;
+  p->Wc = sh.Wc; p->NW = sh.NW; p->G = sh.G;
+  p->tickets = sh.tickets_ok; p->fused = sh.fused_ok;
+  p->lds = sh.lds; p->lds_fused = sh.lds_fused;
+  p->flags = 0;
+  p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
+  p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
+  p->sp_alloc_chunks = 0;
+  p->last_stream = ctx->stream; p->last_slot = -1;
+  p->timer_next = 0; p->timer_count = 0;
+  if (p->lds.total > KAS_LDS_LIMIT)
+    return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at the instantiated width");
+  if (!kas_minimal_ok(p->Wc, p->NW, p->G))
+    return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only lists 3 wide, 4 fill waves");
+  hipStream_t st = ctx->stream;
+  const size_t S = (size_t)batch->n_scenarios, T = (size_t)batch->n_topics, NP = (size_t)batch->node_pool_len;
+  struct Up { KasBuf* b; const void* src; size_t bytes; const char* what; };
+  const Up ups[] = {
+      {&p->b_scen, batch->scenarios, sizeof(kas_scenario_desc) * S, "scenario descriptors"},
+      {&p->b_topics, batch->topics, sizeof(kas_topic_desc) * T, "topic descriptors"},
+      {&p->b_node_id, batch->node_id, sizeof(int32_t) * NP, "node ids"},
+      {&p->b_node_rack, batch->node_rack, sizeof(int32_t) * NP, "node racks"},
+      {&p->b_accmask_off, sh.accmask_off.data(), sizeof(int64_t) * sh.accmask_off.size(), "accept-mask offsets"},
+      {&p->b_orph_off, sh.orph_off.data(), sizeof(int64_t) * sh.orph_off.size(), "orphan-list offsets"},
+  };
+  for (const Up& u : ups) {
+    if ((rc = kas_buf_reserve(u.b, u.bytes, p->allocs, u.what)) != KAS_E_OK) return rc;
+    if (u.bytes > 0) KAS_HIP_TRY(hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, st));
+  }
+  const size_t stats_bytes = sizeof(int64_t) * KAS_STATS_PER_SCENARIO * (S + 1);
+  if ((rc = kas_buf_reserve(&p->b_accmask, sizeof(uint64_t) * (size_t)(sh.accmask_words + 1), p->allocs, "accept-mask scratch")) != KAS_E_OK ||
+      (rc = kas_buf_reserve(&p->b_orph, sizeof(int32_t) * (size_t)(sh.orph_ints + 64), p->allocs, "orphan-list scratch")) != KAS_E_OK ||
+      (rc = kas_buf_reserve(&p->b_perm, sizeof(int32_t) * (S + 1), p->allocs, "scenario-order scratch")) != KAS_E_OK ||
+      (rc = kas_buf_reserve(&p->b_ord_flag, sizeof(int32_t) * (S + 1), p->allocs, "order-form flags")) != KAS_E_OK ||
+      (rc = kas_buf_reserve(&p->b_stats, stats_bytes, p->allocs, "stats buffer")) != KAS_E_OK)
+    return rc;
+  KAS_HIP_TRY(hipMemsetAsync(p->b_stats.p, 0, stats_bytes, st));
+  if ((rc = kas_plan_spread_scratch(p)) != KAS_E_OK) return rc;
+  if ((rc = kas_plan_set_kernels(p)) != KAS_E_OK) return rc;
+  // descriptors are resident before the caller may free its copies
+  KAS_HIP_TRY(hipStreamSynchronize(st));
+  return KAS_E_OK;
+}
+
+static int kas_plan_new(kas_ctx* ctx, const kas_batch_desc* batch, uint64_t* allocs, kas_plan** out_plan) {
+  *out_plan = nullptr;
+  kas_plan* p = new kas_plan();
+  memset((void*)p->ev_start, 0, sizeof(p->ev_start));
+  memset((void*)p->ev_stop, 0, sizeof(p->ev_stop));
+  memset((void*)p->ev_mid, 0, sizeof(p->ev_mid));
+  p->ctx = ctx; p->allocs = allocs; p->last_slot = -1; p->last_stream = ctx->stream;
+  if (hipSetDevice(ctx->device) != hipSuccess) { delete p; return set_error(KAS_E_HIP, "hipSetDevice failed"); }
+  for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
+    if (hipEventCreate(&p->ev_start[i]) != hipSuccess || hipEventCreate(&p->ev_stop[i]) != hipSuccess ||
+        hipEventCreate(&p->ev_mid[i]) != hipSuccess) {
+      kas_plan_destroy(p);
+      return set_error(KAS_E_HIP, "hipEventCreate failed");
+    }
+  }
+  const int rc = kas_plan_build(p, batch);
+  if (rc != KAS_E_OK) { kas_plan_destroy(p); return rc; }
+  *out_plan = p;
+  return KAS_E_OK;
+}
+
+int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan) {
+  if (!ctx || !batch || !out_plan) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  return kas_plan_new(ctx, batch, nullptr, out_plan);
 }
 
 // the launch decisions of kas_solve_device, in one place
@@ -523,14 +553,15 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (!p || !buf || n <= 0) return set_error(KAS_E_INVALID_ARG, "NULL argument");
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool generic = (p->flags & KAS_FLAG_GENERIC_FILL) || !p->shape.with_x;
-  char order[192];
+  char order[256];
+  const char* ctx_tail = (p->shape.any_ctx && (lp.tickets || lp.wide)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.tickets)
-    snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu",
+    snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
-             lp.order_grid, lp.order_block, lp.order_lds);
+             lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
   else if (lp.wide)
-    snprintf(order, sizeof(order), "kas_order_wide_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
-             lp.order_block, lp.order_lds);
+    snprintf(order, sizeof(order), "kas_order_wide_kernel<%d> grid=%ux%u lds=%zu%s", p->Wc, lp.order_grid,
+             lp.order_block, lp.order_lds, ctx_tail);
   else
     snprintf(order, sizeof(order), "kas_order_round_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
              lp.order_block, lp.order_lds);
@@ -559,46 +590,37 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : p->ctx->stream;
   KasLaunch a;
-  a.scen = p->d_scen; a.topics = p->d_topics; a.node_id = p->d_node_id; a.node_rack = p->d_node_rack;
+  a.scen = (const kas_scenario_desc*)p->b_scen.p; a.topics = (const kas_topic_desc*)p->b_topics.p;
+  a.node_id = (const int32_t*)p->b_node_id.p; a.node_rack = (const int32_t*)p->b_node_rack.p;
   a.cur = t->cur; a.out = t->out; a.aux = t->aux; a.ctx = t->ctx;
   a.topic_results = t->topic_results; a.scenario_results = t->scenario_results;
-  a.accmask = p->d_accmask; a.accmask_off = p->d_accmask_off; a.stats = p->d_stats;
-  a.orph = p->d_orph; a.orph_off = p->d_orph_off;
+  a.accmask = (uint64_t*)p->b_accmask.p; a.accmask_off = (const int64_t*)p->b_accmask_off.p;
+  a.stats = (int64_t*)p->b_stats.p;
+  a.orph = (int32_t*)p->b_orph.p; a.orph_off = (const int64_t*)p->b_orph_off.p;
   a.perm = nullptr;
+  a.ord_flag = (int32_t*)p->b_ord_flag.p;
   // the plan's scratch serves one solve at a time: order this solve behind the previous one
   if (p->last_slot >= 0 && p->last_stream != st)
     KAS_HIP_TRY(hipStreamWaitEvent(st, p->ev_stop[p->last_slot], 0));
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
-  a.flags = (p->flags & ~KAS_FLAG_FUSED_HIST) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
+  a.flags = (p->flags & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ORDER_FLAGGED)) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
             (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
   const int slot = p->timer_next;
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
   const int32_t chunks = kas_plan_spread_chunks(p);
-  if (chunks > 0 && chunks != p->sp_alloc_chunks) {               // scratch of the spread fill, on first use
-    (void)hipFree(p->d_sp_hist); (void)hipFree(p->d_sp_quota); (void)hipFree(p->d_sp_node);
-    (void)hipFree(p->d_sp_flag); (void)hipFree(p->d_sp_oc);
-    p->d_sp_hist = nullptr; p->d_sp_quota = nullptr; p->d_sp_node = nullptr; p->d_sp_flag = nullptr; p->d_sp_oc = nullptr;
-    p->sp_alloc_chunks = 0;
-    const size_t S = (size_t)p->n_scenarios, NM = (size_t)(p->shape.n_max > 0 ? p->shape.n_max : 1), C = (size_t)chunks;
-    if (hipMalloc((void**)&p->d_sp_hist, 4 * S * C * (size_t)p->Wc * NM) != hipSuccess ||
-        hipMalloc((void**)&p->d_sp_quota, 4 * S * C * NM) != hipSuccess ||
-        hipMalloc((void**)&p->d_sp_node, 4 * S * 2 * NM) != hipSuccess ||
-        hipMalloc((void**)&p->d_sp_flag, 4 * (S + 1)) != hipSuccess ||
-        hipMalloc((void**)&p->d_sp_oc, 4 * S * (C + 2)) != hipSuccess)
-      return set_error(KAS_E_NOMEM, "spread-fill scratch");
-    p->sp_alloc_chunks = chunks;
-  }
+  if (chunks != p->sp_alloc_chunks)
+    return set_error(KAS_E_INVALID_ARG, "internal: spread-fill scratch not sized for this plan state");
   KAS_HIP_TRY(hipEventRecord(p->ev_start[slot], st));
   if (chunks > 0) {
     const KasSpreadKernels sk = kas_spread_for(p->Wc);
-    a.sp_hist = p->d_sp_hist; a.sp_quota = p->d_sp_quota; a.sp_node = p->d_sp_node; a.sp_flag = p->d_sp_flag;
-    a.sp_oc = p->d_sp_oc; a.sp_chunks = chunks;
-    KAS_HIP_TRY(hipMemsetAsync(p->d_sp_flag, 0, 4 * ((size_t)p->n_scenarios + 1), st));
-    KAS_HIP_TRY(hipMemsetAsync(p->d_sp_oc, 0, 4 * (size_t)p->n_scenarios * ((size_t)chunks + 2), st));
+    a.sp_hist = (int32_t*)p->b_sp_hist.p; a.sp_quota = (int32_t*)p->b_sp_quota.p; a.sp_node = (int32_t*)p->b_sp_node.p;
+    a.sp_flag = (int32_t*)p->b_sp_flag.p; a.sp_oc = (int32_t*)p->b_sp_oc.p; a.sp_chunks = chunks;
+    KAS_HIP_TRY(hipMemsetAsync(a.sp_flag, 0, 4 * ((size_t)p->n_scenarios + 1), st));
+    KAS_HIP_TRY(hipMemsetAsync(a.sp_oc, 0, 4 * (size_t)p->n_scenarios * ((size_t)chunks + 2), st));
     const size_t l1 = (size_t)kas_fill_lds_layout(p->shape.n_max, p->Wc, 1, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
     const size_t l4 = (size_t)kas_fill_lds_layout(p->shape.n_max, p->Wc, 4, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
     const dim3 gc((unsigned)chunks, (unsigned)p->n_scenarios);
@@ -614,9 +636,13 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
   KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
   const int packed = lp.packed;
+  // a Context handed in: the ticket forms flag the scenarios whose counters do not fit their count
+  // fields, and the round form (launched behind them, taking only those) serves them
+  const bool ctx_fallback = p->shape.any_ctx && (tickets || lp.wide);
+  if (ctx_fallback) KAS_HIP_TRY(hipMemsetAsync(a.ord_flag, 0, 4 * ((size_t)p->n_scenarios + 1), st));
   if (lp.pairing) {
     // scenarios that share a solver wavefront should have P5 chains of similar length
-    a.perm = p->d_perm;
+    a.perm = (int32_t*)p->b_perm.p;
     hipLaunchKernelGGL(kas_order_permutation_kernel, dim3(1), dim3(64 * KAS_PERM_WAVES),
                        sizeof(int32_t) * (size_t)(KAS_PERM_BINS + 8), st, a);
     KAS_HIP_TRY(hipGetLastError());
@@ -629,6 +655,13 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   else
     hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
+  if (ctx_fallback) {
+    a.flags |= KAS_FLAG_ORDER_FLAGGED;
+    a.perm = nullptr;
+    hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64),
+                       (size_t)kas_order_round_lds(p->shape.n_max, p->Wc), st, a);
+    KAS_HIP_TRY(hipGetLastError());
+  }
   KAS_HIP_TRY(hipEventRecord(p->ev_stop[slot], st));
   p->last_slot = slot;
   p->timer_next = (slot + 1) % KAS_TIMER_SLOTS;
@@ -702,7 +735,13 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  p->flags = flags & 0xffu & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED);
+  p->flags = flags & 0xffu & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED);
+  // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
+  // plan may still be in flight on the old scratch
+  if (kas_plan_spread_chunks(p) != p->sp_alloc_chunks) {
+    if (p->last_slot >= 0) KAS_HIP_TRY(hipEventSynchronize(p->ev_stop[p->last_slot]));
+    if ((rc = kas_plan_spread_scratch(p)) != KAS_E_OK) return rc;
+  }
   return KAS_E_OK;
 }
 
@@ -712,30 +751,92 @@ int kas_plan_stats(kas_plan* p, int64_t* out, int64_t n) {
   if (n < need) return set_error(KAS_E_INVALID_ARG, "stats buffer too small");
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   KAS_HIP_TRY(hipStreamSynchronize(p->last_stream));
-  if (need > 0) KAS_HIP_TRY(hipMemcpy(out, p->d_stats, sizeof(int64_t) * (size_t)need, hipMemcpyDeviceToHost));
+  if (need > 0) KAS_HIP_TRY(hipMemcpy(out, p->b_stats.p, sizeof(int64_t) * (size_t)need, hipMemcpyDeviceToHost));
   return KAS_E_OK;
 }
 
-// grow-only device buffer of the host path
-static int kas_host_buf(kas_ctx* ctx, KasHostBuf* b, size_t bytes) {
-  if (bytes <= b->cap) return KAS_E_OK;
-  if (b->p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
-  const size_t want = bytes + bytes / 4 + 256;              // headroom: the next batch is rarely the same size
-  hipError_t e = hipMalloc(&b->p, want);
-  if (e != hipSuccess) { b->p = nullptr; return set_error(KAS_E_NOMEM, std::string("host-path buffer: ") + hipGetErrorString(e)); }
-  b->cap = want;
-  ctx->host_allocs += 1;
+// ---------------------------------------------------------------------------------------------
+// host path
+// ---------------------------------------------------------------------------------------------
+int kas_host_alloc(int64_t bytes, void** out_ptr) {
+  if (!out_ptr || bytes < 0) return set_error(KAS_E_INVALID_ARG, "kas_host_alloc: NULL / negative size");
+  *out_ptr = nullptr;
+  hipError_t e = hipHostMalloc(out_ptr, (size_t)(bytes > 0 ? bytes : 16), hipHostMallocPortable);
+  if (e != hipSuccess) { *out_ptr = nullptr; return set_error(KAS_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
   return KAS_E_OK;
 }
 
-static uint64_t kas_fnv64(uint64_t h, const void* data, size_t n) {
+void kas_host_free(void* ptr) { if (ptr) (void)hipHostFree(ptr); }
+
+void kas_shard_range(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi) {
+  if (world < 1) world = 1;
+  if (rank < 0) rank = 0;
+  if (rank >= world) rank = world - 1;
+  if (total < 0) total = 0;
+  const int64_t base = total / world, rem = total % world;
+  const int64_t l = (int64_t)rank * base + (rank < rem ? rank : rem);
+  if (lo) *lo = l;
+  if (hi) *hi = l + base + (rank < rem ? 1 : 0);
+}
+
+int kas_batch_slice(const kas_batch_desc* b, int64_t lo, int64_t hi, kas_scenario_desc* scratch, kas_batch_desc* out,
+                    const kas_tables* tables, kas_tables* tables_out) {
+  if (!b || !out || lo < 0 || hi < lo || hi > b->n_scenarios || (hi > lo && (!scratch || !b->scenarios)))
+    return set_error(KAS_E_INVALID_ARG, "kas_batch_slice: bad range / NULL argument");
+  int64_t tlo = INT64_MAX, thi = 0, nlo = INT64_MAX, nhi = 0;
+  for (int64_t i = lo; i < hi; ++i) {
+    const kas_scenario_desc& sd = b->scenarios[i];
+    if (sd.topic_begin < 0 || sd.topic_count < 0 || (int64_t)sd.topic_begin + sd.topic_count > b->n_topics || sd.n_nodes < 0 ||
+        sd.node_off < 0 || sd.node_off + sd.n_nodes > b->node_pool_len)
+      return set_error(KAS_E_INVALID_ARG, "kas_batch_slice: scenario " + std::to_string(i) + " refers outside the batch");
+    if (sd.topic_count > 0) {
+      if (sd.topic_begin < tlo) tlo = sd.topic_begin;
+      if ((int64_t)sd.topic_begin + sd.topic_count > thi) thi = (int64_t)sd.topic_begin + sd.topic_count;
+    }
+    if (sd.n_nodes > 0) {
+      if (sd.node_off < nlo) nlo = sd.node_off;
+      if (sd.node_off + sd.n_nodes > nhi) nhi = sd.node_off + sd.n_nodes;
+    }
+  }
+  if (tlo > thi) tlo = thi = 0;
+  if (nlo > nhi) nlo = nhi = 0;
+  for (int64_t i = lo; i < hi; ++i) {
+    kas_scenario_desc sd = b->scenarios[i];
+    sd.topic_begin = sd.topic_count > 0 ? (int32_t)(sd.topic_begin - tlo) : 0;
+    sd.node_off = sd.n_nodes > 0 ? sd.node_off - nlo : 0;
+    scratch[i - lo] = sd;
+  }
+  out->n_scenarios = (int32_t)(hi - lo);
+  out->n_topics = (int32_t)(thi - tlo);
+  out->scenarios = scratch;
+  out->topics = b->topics ? b->topics + tlo : nullptr;
+  out->node_id = b->node_id ? b->node_id + nlo : nullptr;
+  out->node_rack = b->node_rack ? b->node_rack + nlo : nullptr;
+  out->node_pool_len = nhi - nlo;
+  if (tables && tables_out) {
+    *tables_out = *tables;
+    tables_out->topic_results = tables->topic_results ? tables->topic_results + tlo : nullptr;
+    tables_out->scenario_results = tables->scenario_results ? tables->scenario_results + lo : nullptr;
+  }
+  return KAS_E_OK;
+}
+
+// word-at-a-time hash of the descriptor bytes (a what-if call hashes megabytes of node tables)
+static uint64_t kas_hash64(uint64_t h, const void* data, size_t n) {
   const unsigned char* p = (const unsigned char*)data;
-  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  for (; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
   return h;
 }
 
-// The plan of this batch from the context's cache (same descriptors and node tables, byte for
-// byte), or a new one that replaces the least recently used entry.
+// The plan of this batch from the context's cache: the one whose descriptors and node tables are the
+// same byte for byte, else the least recently used entry rebuilt in place (or a new one into a free entry).
 static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_plan) {
   *out_plan = nullptr;
   if (b->n_scenarios < 0 || b->n_topics < 0 || b->node_pool_len < 0 ||
@@ -750,69 +851,259 @@ static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_p
   if (sb) memcpy(desc.data() + 16, b->scenarios, sb);
   if (tb) memcpy(desc.data() + 16 + sb, b->topics, tb);
   if (nb) { memcpy(desc.data() + 16 + sb + tb, b->node_id, nb); memcpy(desc.data() + 16 + sb + tb + nb, b->node_rack, nb); }
-  const uint64_t key = kas_fnv64(0xcbf29ce484222325ull, desc.data(), desc.size());
+  const uint64_t key = kas_hash64(0xcbf29ce484222325ull, desc.data(), desc.size());
+  const uint64_t sig = kas_hash64(0x84222325cbf29ce4ull, desc.data(), 8) ^ kas_hash64(0, desc.data() + 16 + sb, tb);   // (S, T) + topic descriptors
   ctx->use_clock += 1;
-  KasCachedPlan* victim = &ctx->plans[0];
+  // hit: the same bytes.  Miss: rebuild the least recently used plan of the same signature in place (a
+  // what-if caller: same snapshot, other broker sets — every buffer is already large enough), else fill a
+  // free entry, else rebuild the least recently used plan of any shape.  Entries this call already uses
+  // (the other scenario ranges of a split call) are never victims.
+  KasCachedPlan *same = nullptr, *empty = nullptr, *lru = nullptr;
   for (KasCachedPlan& c : ctx->plans) {
     if (c.plan && c.key == key && c.desc == desc) {
-      c.last_use = ctx->use_clock;
+      c.last_use = ctx->use_clock; c.call = ctx->host_calls;
       ctx->host_plan_hits += 1;
       *out_plan = c.plan;
       return KAS_E_OK;
     }
-    if (!c.plan) { if (victim->plan) victim = &c; }
-    else if (victim->plan && c.last_use < victim->last_use) victim = &c;
+    if (!c.plan) { if (!empty) empty = &c; continue; }
+    if (c.call == ctx->host_calls) continue;
+    if (c.sig == sig && (!same || c.last_use < same->last_use)) same = &c;
+    if (!lru || c.last_use < lru->last_use) lru = &c;
   }
-  kas_plan* plan = nullptr;
-  int rc = kas_plan_create(ctx, b, &plan);
-  if (rc != KAS_E_OK) return rc;
-  if (victim->plan) kas_plan_destroy(victim->plan);
-  victim->plan = plan; victim->key = key; victim->desc.swap(desc); victim->last_use = ctx->use_clock;
-  *out_plan = plan;
+  KasCachedPlan* victim = same ? same : (empty ? empty : lru);
+  if (!victim) return set_error(KAS_E_NOMEM, "host-path plan cache exhausted by one call");
+  int rc;
+  if (victim->plan) {
+    rc = kas_plan_build(victim->plan, b);                      // in place: its buffers are reused where they are large enough
+    if (rc != KAS_E_OK) { kas_plan_destroy(victim->plan); victim->plan = nullptr; victim->desc.clear(); victim->sig = 0; return rc; }
+  } else {
+    kas_plan* plan = nullptr;
+    rc = kas_plan_new(ctx, b, &ctx->host_allocs, &plan);
+    if (rc != KAS_E_OK) return rc;
+    victim->plan = plan;
+  }
+  victim->key = key; victim->sig = sig; victim->desc.swap(desc); victim->last_use = ctx->use_clock; victim->call = ctx->host_calls;
+  *out_plan = victim->plan;
   return KAS_E_OK;
 }
 
-int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h) {
-  if (!ctx || !batch || !h) return set_error(KAS_E_INVALID_ARG, "NULL argument");
-  std::lock_guard<std::mutex> lock(ctx->host_mu);
+// grow-only device buffer of the host path
+static int kas_host_buf(kas_ctx* ctx, KasBuf* b, size_t bytes) {
+  if (bytes <= b->cap) return KAS_E_OK;
+  // (every host call drains its streams before it returns: nothing is in flight on the old buffer)
+  return kas_buf_reserve(b, bytes + bytes / 4 + 256, &ctx->host_allocs, "host-path buffer");
+}
+
+// one scenario range of a host call: its slice of the batch, its plan, what it moves
+struct KasChain {
+  int64_t lo = 0, hi = 0;                       // scenarios
+  int64_t tlo = 0, thi = 0;                     // topics (absolute indices)
+  std::vector<kas_scenario_desc> scen;          // rebased descriptors of the slice
+  kas_batch_desc bd;
+  kas_plan* plan = nullptr;
+  int64_t cur_lo = 0, cur_hi = 0, out_lo = 0, out_hi = 0;
+};
+
+#define KAS_HOST_SPLIT_MIN_BYTES (48ll << 20)   // tables smaller than this are moved and solved as one range
+#define KAS_HOST_SPLIT_MAX 8
+
+static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h, const int32_t* select,
+                                 int32_t n_select) {
   KAS_HIP_TRY(hipSetDevice(ctx->device));
   ctx->host_calls += 1;
-  kas_plan* plan = nullptr;
-  int rc = kas_host_plan(ctx, batch, &plan);
-  if (rc != KAS_E_OK) return rc;
-  const KasShape& sh = plan->shape;
-  if (h->cur_len < sh.cur_need || h->out_len < sh.out_need || h->aux_len < sh.aux_need ||
-      h->ctx_len < sh.ctx_need)
+  const bool all_rows = n_select < 0;
+  if (!all_rows && n_select > 0 && !select) return set_error(KAS_E_INVALID_ARG, "select == NULL");
+  // the whole batch: validation and the extents of every pool
+  KasShape full;
+  {
+    std::string err;
+    const int rc = kas_shape_batch(batch, &full, &err, 0, 0);
+    if (rc != KAS_E_OK) return set_error(rc, err);
+  }
+  const int64_t S = batch->n_scenarios, T = batch->n_topics;
+  if (h->cur_len < full.cur_need || (all_rows && h->out_len < full.out_need) || h->aux_len < full.aux_need ||
+      h->ctx_len < full.ctx_need)
     return set_error(KAS_E_INVALID_ARG, "a descriptor offset reaches beyond the pool length given in kas_tables");
-  if ((sh.cur_need && !h->cur) || (sh.out_need && !h->out) || (sh.aux_need && !h->aux) || (sh.ctx_need && !h->ctx) ||
-      (batch->n_topics && !h->topic_results) || (batch->n_scenarios && !h->scenario_results))
+  if ((full.cur_need > full.cur_lo && !h->cur) || (all_rows && full.out_need > full.out_lo && !h->out) ||
+      (full.aux_need > full.aux_lo && !h->aux) || (full.ctx_need > full.ctx_lo && !h->ctx) || (T && !h->topic_results) ||
+      (S && !h->scenario_results))
     return set_error(KAS_E_INVALID_ARG, "a table the descriptors refer to is NULL");
-  hipStream_t st = ctx->stream;
-  // (+ 8 ints: the fill kernel's full-row loads re-read the last row for lanes past the end)
-  if ((rc = kas_host_buf(ctx, &ctx->h_cur, sizeof(int32_t) * (size_t)(sh.cur_need + 8))) != KAS_E_OK) return rc;
-  if ((rc = kas_host_buf(ctx, &ctx->h_out, sizeof(int32_t) * (size_t)(sh.out_need + 8))) != KAS_E_OK) return rc;
-  if ((rc = kas_host_buf(ctx, &ctx->h_aux, sizeof(int32_t) * (size_t)(sh.aux_need + 8))) != KAS_E_OK) return rc;
-  if ((rc = kas_host_buf(ctx, &ctx->h_ctx, sizeof(int32_t) * (size_t)(sh.ctx_need + 8))) != KAS_E_OK) return rc;
-  if ((rc = kas_host_buf(ctx, &ctx->h_tr, sizeof(kas_topic_result) * (size_t)(batch->n_topics + 1))) != KAS_E_OK) return rc;
-  if ((rc = kas_host_buf(ctx, &ctx->h_sr, sizeof(kas_scenario_result) * (size_t)(batch->n_scenarios + 1))) != KAS_E_OK) return rc;
-  int32_t *d_cur = (int32_t*)ctx->h_cur.p, *d_out = (int32_t*)ctx->h_out.p, *d_aux = (int32_t*)ctx->h_aux.p,
-          *d_ctx = (int32_t*)ctx->h_ctx.p;
+  // rows of the selected scenarios, packed: where each one goes
+  std::vector<int64_t> sel_off;
+  if (!all_rows) {
+    int64_t at = 0;
+    sel_off.resize((size_t)n_select + 1);
+    for (int32_t k = 0; k < n_select; ++k) {
+      if (select[k] < 0 || select[k] >= S) return set_error(KAS_E_INVALID_ARG, "select: scenario index out of range");
+      sel_off[(size_t)k] = at;
+      const kas_scenario_desc& sd = batch->scenarios[select[k]];
+      for (int32_t t = 0; t < sd.topic_count; ++t) {
+        const kas_topic_desc& td = batch->topics[sd.topic_begin + t];
+        at += (int64_t)td.n_partitions * td.out_width;
+      }
+    }
+    sel_off[(size_t)n_select] = at;
+    if (h->out_len < at || (at > 0 && !h->out))
+      return set_error(KAS_E_INVALID_ARG, "select: out / out_len too small for the selected scenarios' rows");
+  }
+  // device pools: only [lo, need) of each is ever touched, the pointers are rebased so that the
+  // descriptors' absolute offsets apply (+ 8 ints: the fill kernel's full-row loads re-read the last
+  // row for lanes past the end)
+  int rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_cur, sizeof(int32_t) * (size_t)(full.cur_need - full.cur_lo + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_out, sizeof(int32_t) * (size_t)(full.out_need - full.out_lo + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_aux, sizeof(int32_t) * (size_t)(full.aux_need - full.aux_lo + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_ctx, sizeof(int32_t) * (size_t)(full.ctx_need - full.ctx_lo + 8))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_tr, sizeof(kas_topic_result) * (size_t)(T + 1))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_buf(ctx, &ctx->h_sr, sizeof(kas_scenario_result) * (size_t)(S + 1))) != KAS_E_OK) return rc;
+  int32_t* d_cur = (int32_t*)ctx->h_cur.p - full.cur_lo;
+  int32_t* d_out = (int32_t*)ctx->h_out.p - full.out_lo;
+  int32_t* d_aux = (int32_t*)ctx->h_aux.p - full.aux_lo;
+  int32_t* d_ctx = (int32_t*)ctx->h_ctx.p - full.ctx_lo;
   kas_topic_result* d_tr = (kas_topic_result*)ctx->h_tr.p;
   kas_scenario_result* d_sr = (kas_scenario_result*)ctx->h_sr.p;
-  if (sh.cur_need) KAS_HIP_TRY(hipMemcpyAsync(d_cur, h->cur, sizeof(int32_t) * (size_t)sh.cur_need, hipMemcpyHostToDevice, st));
-  if (sh.aux_need) KAS_HIP_TRY(hipMemcpyAsync(d_aux, h->aux, sizeof(int32_t) * (size_t)sh.aux_need, hipMemcpyHostToDevice, st));
-  if (sh.ctx_need) KAS_HIP_TRY(hipMemcpyAsync(d_ctx, h->ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyHostToDevice, st));
-  kas_tables d;
-  memset(&d, 0, sizeof(d));
-  d.cur = d_cur; d.out = d_out; d.aux = d_aux; d.ctx = d_ctx;
-  d.topic_results = d_tr; d.scenario_results = d_sr;
-  rc = kas_solve_device(plan, &d, st);
-  if (rc != KAS_E_OK) return rc;
-  if (sh.out_need) KAS_HIP_TRY(hipMemcpyAsync(h->out, d_out, sizeof(int32_t) * (size_t)sh.out_need, hipMemcpyDeviceToHost, st));
-  if (sh.ctx_need) KAS_HIP_TRY(hipMemcpyAsync(h->ctx, d_ctx, sizeof(int32_t) * (size_t)sh.ctx_need, hipMemcpyDeviceToHost, st));
-  if (batch->n_topics) KAS_HIP_TRY(hipMemcpyAsync(h->topic_results, d_tr, sizeof(kas_topic_result) * (size_t)batch->n_topics, hipMemcpyDeviceToHost, st));
-  if (batch->n_scenarios) KAS_HIP_TRY(hipMemcpyAsync(h->scenario_results, d_sr, sizeof(kas_scenario_result) * (size_t)batch->n_scenarios, hipMemcpyDeviceToHost, st));
-  KAS_HIP_TRY(hipStreamSynchronize(st));
+
+  // ---- scenario ranges (chains).  Large tables laid out scenario by scenario are cut so that the upload
+  // of one range, the solve of the previous one and the download of the one before overlap.
+  const int64_t bytes_in = 4 * (full.cur_need - full.cur_lo);
+  const int64_t bytes_out = all_rows ? 4 * (full.out_need - full.out_lo) : 0;
+  int K = 1;
+  if (bytes_in + bytes_out >= KAS_HOST_SPLIT_MIN_BYTES && S >= 2) {
+    K = (int)((bytes_in + bytes_out) / (KAS_HOST_SPLIT_MIN_BYTES / 2));
+    if (K > KAS_HOST_SPLIT_MAX) K = KAS_HOST_SPLIT_MAX;
+    if (K > S) K = (int)S;
+  }
+  std::vector<KasChain> chains;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    chains.assign((size_t)K, KasChain());
+    bool ok = true;
+    for (int i = 0; i < K && ok; ++i) {
+      KasChain& c = chains[(size_t)i];
+      kas_shard_range(S, i, K, &c.lo, &c.hi);
+      c.scen.resize((size_t)(c.hi - c.lo) + 1);
+      if ((rc = kas_batch_slice(batch, c.lo, c.hi, c.scen.data(), &c.bd, nullptr, nullptr)) != KAS_E_OK) return rc;
+      c.tlo = c.bd.topics ? (int64_t)(c.bd.topics - batch->topics) : 0;
+      c.thi = c.tlo + c.bd.n_topics;
+      if (K > 1) {
+        // extents of the range; ranges must own disjoint, ascending stretches of topics, cur and out
+        KasShape sh;
+        std::string err;
+        if ((rc = kas_shape_batch(&c.bd, &sh, &err, 0, 0)) != KAS_E_OK) return set_error(rc, err);
+        c.cur_lo = sh.cur_lo; c.cur_hi = sh.cur_need; c.out_lo = sh.out_lo; c.out_hi = sh.out_need;
+        if (i > 0) {
+          const KasChain& q = chains[(size_t)i - 1];
+          ok = c.tlo >= q.thi && c.cur_lo >= q.cur_hi && c.out_lo >= q.out_hi;
+        }
+      } else {
+        c.cur_lo = full.cur_lo; c.cur_hi = full.cur_need; c.out_lo = full.out_lo; c.out_hi = full.out_need;
+      }
+    }
+    if (ok) break;
+    K = 1;                                                     // shared or interleaved tables: one range
+  }
+  for (KasChain& c : chains)
+    if ((rc = kas_host_plan(ctx, &c.bd, &c.plan)) != KAS_E_OK) return rc;
+
+  // ---- enqueue.  From here on every exit drains the streams first.
+  hipStream_t s0 = ctx->hstream[0];
+  hipError_t he = hipSuccess;
+  int fail_rc = KAS_E_OK;
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && he == hipSuccess) { he = e; fail_rc = set_error(KAS_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+    return he == hipSuccess;
+  };
+  auto drain = [&]() { for (hipStream_t st : ctx->hstream) (void)hipStreamSynchronize(st); };
+  // pools every range reads (aux, Context) go up first; the other streams wait for them
+  if (full.aux_need > full.aux_lo)
+    hip_ok(hipMemcpyAsync(d_aux + full.aux_lo, h->aux + full.aux_lo, 4 * (size_t)(full.aux_need - full.aux_lo), hipMemcpyHostToDevice, s0), "upload aux");
+  if (full.ctx_need > full.ctx_lo)
+    hip_ok(hipMemcpyAsync(d_ctx + full.ctx_lo, h->ctx + full.ctx_lo, 4 * (size_t)(full.ctx_need - full.ctx_lo), hipMemcpyHostToDevice, s0), "upload ctx");
+  if (K > 1 && he == hipSuccess) {
+    hip_ok(hipEventRecord(ctx->hevent, s0), "record");
+    for (int k = 1; k < KAS_HOST_STREAMS; ++k) hip_ok(hipStreamWaitEvent(ctx->hstream[k], ctx->hevent, 0), "wait");
+  }
+  auto download = [&](const KasChain& c, hipStream_t st) {
+    if (all_rows && c.out_hi > c.out_lo)
+      hip_ok(hipMemcpyAsync(h->out + c.out_lo, d_out + c.out_lo, 4 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, st), "download out");
+    if (c.thi > c.tlo)
+      hip_ok(hipMemcpyAsync(h->topic_results + c.tlo, d_tr + c.tlo, sizeof(kas_topic_result) * (size_t)(c.thi - c.tlo), hipMemcpyDeviceToHost, st), "download topic results");
+    if (c.hi > c.lo)
+      hip_ok(hipMemcpyAsync(h->scenario_results + c.lo, d_sr + c.lo, sizeof(kas_scenario_result) * (size_t)(c.hi - c.lo), hipMemcpyDeviceToHost, st), "download scenario results");
+  };
+  // software-pipelined issue order (upload i, solve i, download i - 1): with pageable host memory the
+  // copies block the issuing thread, and this order still lets the device overlap them with the solves
+  for (int i = 0; i < K && he == hipSuccess && fail_rc == KAS_E_OK; ++i) {
+    KasChain& c = chains[(size_t)i];
+    hipStream_t st = ctx->hstream[i % KAS_HOST_STREAMS];
+    if (c.cur_hi > c.cur_lo)
+      hip_ok(hipMemcpyAsync(d_cur + c.cur_lo, h->cur + c.cur_lo, 4 * (size_t)(c.cur_hi - c.cur_lo), hipMemcpyHostToDevice, st), "upload cur");
+    if (he != hipSuccess) break;
+    kas_tables d;
+    memset(&d, 0, sizeof(d));
+    d.cur = d_cur; d.out = d_out; d.aux = d_aux; d.ctx = d_ctx;
+    d.topic_results = d_tr + c.tlo; d.scenario_results = d_sr + c.lo;
+    const int src = kas_solve_device(c.plan, &d, st);
+    if (src != KAS_E_OK) { fail_rc = src; break; }
+    if (i > 0) download(chains[(size_t)i - 1], ctx->hstream[(i - 1) % KAS_HOST_STREAMS]);
+  }
+  if (he == hipSuccess && fail_rc == KAS_E_OK) download(chains[(size_t)K - 1], ctx->hstream[(K - 1) % KAS_HOST_STREAMS]);
+  if (he != hipSuccess || fail_rc != KAS_E_OK) { drain(); return fail_rc; }
+  drain();
+  // Context counters back; the selected scenarios' rows, packed
+  if (full.ctx_need > full.ctx_lo)
+    hip_ok(hipMemcpyAsync(h->ctx + full.ctx_lo, d_ctx + full.ctx_lo, 4 * (size_t)(full.ctx_need - full.ctx_lo), hipMemcpyDeviceToHost, s0), "download ctx");
+  if (!all_rows) {
+    for (int32_t k = 0; k < n_select && he == hipSuccess; ++k) {
+      const kas_scenario_desc& sd = batch->scenarios[select[k]];
+      int64_t at = sel_off[(size_t)k];
+      for (int32_t t = 0; t < sd.topic_count && he == hipSuccess; ++t) {
+        const kas_topic_desc& td = batch->topics[sd.topic_begin + t];
+        const int64_t cells = (int64_t)td.n_partitions * td.out_width;
+        if (cells > 0)
+          hip_ok(hipMemcpyAsync(h->out + at, d_out + td.out_off, 4 * (size_t)cells, hipMemcpyDeviceToHost, s0), "download selected rows");
+        at += cells;
+      }
+    }
+  }
+  (void)hipStreamSynchronize(s0);
+  return he == hipSuccess ? KAS_E_OK : fail_rc;
+}
+
+int kas_solve_host_select(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h, const int32_t* select, int32_t n_select) {
+  if (!ctx || !batch || !h) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  return kas_solve_host_locked(ctx, batch, h, select, n_select);
+}
+
+int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h) {
+  return kas_solve_host_select(ctx, batch, h, nullptr, -1);
+}
+
+int kas_solve_host_sharded(kas_ctx* const* ctxs, int32_t n_ctx, const kas_batch_desc* batch, const kas_tables* h) {
+  if (!ctxs || n_ctx < 1 || !batch || !h) return set_error(KAS_E_INVALID_ARG, "NULL argument / no context");
+  for (int32_t r = 0; r < n_ctx; ++r) if (!ctxs[r]) return set_error(KAS_E_INVALID_ARG, "ctxs[r] == NULL");
+  if (n_ctx == 1) return kas_solve_host(ctxs[0], batch, h);
+  std::vector<int> rcs((size_t)n_ctx, KAS_E_OK);
+  std::vector<std::string> errs((size_t)n_ctx);
+  std::vector<std::thread> threads;
+  for (int32_t r = 0; r < n_ctx; ++r) {
+    threads.emplace_back([&, r]() {
+      int64_t lo = 0, hi = 0;
+      kas_shard_range(batch->n_scenarios, r, n_ctx, &lo, &hi);
+      if (hi <= lo) return;
+      std::vector<kas_scenario_desc> scratch((size_t)(hi - lo));
+      kas_batch_desc bd;
+      kas_tables ht;
+      int rc = kas_batch_slice(batch, lo, hi, scratch.data(), &bd, h, &ht);
+      if (rc == KAS_E_OK) rc = kas_solve_host(ctxs[r], &bd, &ht);
+      rcs[(size_t)r] = rc;
+      if (rc != KAS_E_OK) errs[(size_t)r] = g_last_error;      // (thread-local: carried to the caller below)
+    });
+  }
+  for (std::thread& t : threads) t.join();
+  for (int32_t r = 0; r < n_ctx; ++r)
+    if (rcs[(size_t)r] != KAS_E_OK) return set_error(rcs[(size_t)r], "shard " + std::to_string(r) + ": " + errs[(size_t)r]);
   return KAS_E_OK;
 }
 

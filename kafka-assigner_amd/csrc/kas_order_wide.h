@@ -162,8 +162,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   constexpr int T = W - 1;                                  // replica indices whose counts decide a pick
   const int lane = kasw::lane();
   const int32_t wave = kasw::wave_id();
-  const bool have_s = s_index < a.n_scenarios;
-  const int32_t s = have_s ? s_index : a.n_scenarios;
+  const bool have_s0 = s_index < a.n_scenarios;
+  const int32_t s = have_s0 ? s_index : a.n_scenarios;
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   uint64_t* cnt = (uint64_t*)lds_raw;                       // [nmax + 1]: + the padding holder's row
   uint64_t* dep = (uint64_t*)(lds_raw + kas_align16(8 * (int64_t)(nmax + 1)));                  // lane mask per node
@@ -183,10 +183,31 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 
   kas_scenario_desc sd;
   sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
-  if (have_s) sd = a.scen[s];
+  if (have_s0) sd = a.scen[s];
   const int32_t* g_node_id = a.node_id + sd.node_off;
   constexpr int NB = KAS_WIDE_BULK_SOLVERS;
-  for (int32_t n = lane + 64 * wave; n <= nmax; n += 64 * KAS_WIDE_WAVES) { cnt[n] = 0ull; dep[n] = 0ull; run[n] = 0; if (has_front) front[n] = 0u; }
+  // Context handed in (kas_solver_body.h, ctx_gain_bound): it seeds the 10-bit count fields; a scenario
+  // whose counters would not stay below 1023 is left to the round form.  (workgroup-uniform)
+  bool have_s = have_s0;
+  int32_t* g_ctx = nullptr;
+  int32_t ccols = 0;
+  if (have_s0 && sd.ctx_off >= 0 && sd.ctx_width > 0 && a.ctx != nullptr) {
+    g_ctx = a.ctx + sd.ctx_off;
+    ccols = sd.ctx_width < W ? sd.ctx_width : W;
+    const bool over = ctx_over_limit(g_ctx, sd.n_nodes, sd.ctx_width, ccols, (uint32_t)KAS_PACKED_TICKET_LIMIT,
+                                     ctx_gain_bound(a, sd), lane, 64);
+    if (kasw::ballot(over) != 0ull) {
+      have_s = false; g_ctx = nullptr; ccols = 0;
+      if (wave == 0 && lane == 0 && a.ord_flag) a.ord_flag[s] = 1;
+    }
+  }
+  for (int32_t n = lane + 64 * wave; n <= nmax; n += 64 * KAS_WIDE_WAVES) {
+    uint64_t x = 0ull;
+    if (n < sd.n_nodes)
+      for (int32_t r = 0; r < ccols; ++r)
+        x |= (uint64_t)(uint32_t)g_ctx[(int64_t)n * sd.ctx_width + r] << (r < 3 ? 10 * r : 32 + 10 * (r - 3));
+    cnt[n] = x; dep[n] = 0ull; run[n] = 0; if (has_front) front[n] = 0u;
+  }
   for (int32_t k = wave; k < K; k += KAS_WIDE_WAVES) ring[k * 64 + lane].tag = KAS_TAG_FREE;
   for (int32_t k = wave; k < KAS_WIDE_HOT * (1 + NB); k += KAS_WIDE_WAVES) rank_owner_all[k * 64 + lane] = 0u;
   if (wave == 2 && lane < 2) lstate[lane] = 0u;
@@ -884,6 +905,12 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
     kasw::lds_atomic_add_u64(&gdig[0], digest);
     kasw::lockstep();
     if (have_s && lane == 0) a.scenario_results[s].digest = gdig[0];
+    // the Context goes back: every row has been retired, so every commit is in the counter rows
+    for (int32_t n = lane; n < sd.n_nodes && ccols > 0; n += 64) {
+      const uint64_t x = cnt[n];
+      for (int32_t r = 0; r < ccols; ++r)
+        g_ctx[(int64_t)n * sd.ctx_width + r] = (int32_t)((x >> (r < 3 ? 10 * r : 32 + 10 * (r - 3))) & KAS_WIDE_FIELD_MASK);
+    }
     if (KAS_SPIN_BOUND > 0 && have_s && lane == 0 && *(volatile uint32_t*)wd != 0u) {
       a.scenario_results[s].status = KAS_FAIL_WATCHDOG;
       a.scenario_results[s].fail_topic = -1; a.scenario_results[s].fail_partition = -1;

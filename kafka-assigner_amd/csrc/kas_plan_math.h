@@ -34,6 +34,8 @@ struct KasLaunch {
   int32_t* orph;                // scratch: orphan row lists, one region per scenario
   const int64_t* orph_off;      // [n_scenarios] offset of the region in int32 elements
   int32_t* perm;                // scratch: order in which the order kernel takes the scenarios, or NULL
+  int32_t* ord_flag;            // [n_scenarios] != 0: a ticket-form order kernel left the scenario to the round form
+                                // (a Context counter too large for its count fields), or NULL
   int64_t* stats;               // [n_scenarios][KAS_STATS_PER_SCENARIO] device counters, or NULL
   // spread fill (large single-topic scenarios: passes A and B over many one-wavefront workgroups)
   int32_t* sp_hist;             // [S][chunks][W][n_max] sweep histograms of the chunks (pass A)
@@ -56,6 +58,7 @@ struct KasLaunch {
 #define KAS_FLAG_FUSED_HIST   16u  // set by the launcher: per-chunk histograms, no chunk-count pass (KasShape::fused_ok)
 #define KAS_FLAG_SPREAD_FILL  32u  // spread fill also for small scenarios, with few chunks (testing / comparison)
 #define KAS_FLAG_ONLY_FLAGGED 64u  // set by the launcher: the fill kernel takes only the scenarios the spread fill handed back
+#define KAS_FLAG_ORDER_FLAGGED 128u // set by the launcher: the round-form order kernel takes only scenarios with ord_flag set
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
@@ -198,7 +201,9 @@ struct KasShape {
   int32_t need_bsearch = 0;
   int32_t tickets_ok = 1;             // the ticket form of P5 is applicable to every scenario
   int32_t with_x = 1;                 // LDS has room for the histogram / quota table of the fast fill
-  int32_t packed_ok = 1;              // every scenario's ticket bound fits 10-bit counter fields
+  int32_t packed_ok = 1;              // every scenario's ticket bound fits 10-bit counter fields and no Context is handed in
+  int32_t bound_small = 1;            // every scenario's ticket bound fits 10-bit counter fields
+  int32_t any_ctx = 0;                // some scenario hands a Context in / wants it back
   int32_t wide_ok = 0;                // lists 4 or 5 wide and the wide ticket form is applicable
   int32_t round_fits = 1;             // the round form's LDS (int32 counters + 64-bit masks) fits 160 KiB
   int32_t fused_ok = 0;               // rack-diverse fill with per-chunk histograms (no chunk-count pass)
@@ -212,6 +217,9 @@ struct KasShape {
   int32_t G = 1;                      // lane groups (= scenarios) per wavefront, ticket form
   int64_t algorithmic_bytes = 0;
   int64_t cur_need = 0, out_need = 0, aux_need = 0, ctx_need = 0;  // minimum pool lengths
+  // first element of each pool a descriptor refers to (== *_need when none does): a batch that is a
+  // slice of a larger one (kas_batch_slice) touches [lo, need) only, and the host path moves only that
+  int64_t cur_lo = 0, out_lo = 0, aux_lo = 0, ctx_lo = 0;
   KasLds lds{};
 };
 
@@ -265,6 +273,8 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   if (b->n_scenarios > 0 && (!b->scenarios)) return fail(KAS_E_INVALID_ARG, "scenarios == NULL");
   if (b->n_topics > 0 && !b->topics) return fail(KAS_E_INVALID_ARG, "topics == NULL");
   KasShape s;
+  const int64_t kNone = INT64_MAX;
+  s.cur_lo = s.out_lo = s.aux_lo = s.ctx_lo = kNone;
   s.accmask_off.assign((size_t)b->n_scenarios, 0);
   s.orph_off.assign((size_t)b->n_scenarios, 0);
   int64_t max_range_fit = 0;
@@ -283,14 +293,18 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (range >= 1 && range <= KAS_IDMAP_CAP) { if (range > max_range_fit) max_range_fit = range; }
       else s.need_bsearch = 1;      // sparse ids (or unsorted: the kernel reports BAD_NODES)
     }
-    // Context handed in (KAS:360-369): its counter sums are data, so ticket magnitudes cannot be
-    // bounded here -> round form
+    // Context handed in (KAS:360-369).  The ticket forms seed their count fields from it and write
+    // them back (tickets and commit counts start at zero in every solve, so only the FIELD width
+    // matters): the kernel checks "largest counter + rows a node can gain < field limit" per scenario
+    // and leaves a scenario that fails it to the round form (ord_flag), which therefore has to fit.
+    // 4 x uint16 counter rows: the packed 3 x 10-bit row keeps the commits as the sum of its counts.
     if (sd.ctx_off >= 0) {
-      s.tickets_ok = 0;
+      s.any_ctx = 1;
       if (sd.ctx_width < 1 || sd.ctx_width > KAS_MAX_WIDTH)
         return fail(KAS_E_INVALID_ARG, "scenario " + std::to_string(i) + ": ctx_width outside [1,8]");
       int64_t e = sd.ctx_off + (int64_t)sd.n_nodes * sd.ctx_width;
       if (e > s.ctx_need) s.ctx_need = e;
+      if (sd.n_nodes > 0 && sd.ctx_off < s.ctx_lo) s.ctx_lo = sd.ctx_off;
       s.algorithmic_bytes += 8ll * sd.n_nodes * sd.ctx_width;
     }
     if (sd.n_nodes > s.n_max) s.n_max = sd.n_nodes;
@@ -313,10 +327,13 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       int64_t ce = td.cur_off + P * td.cur_width, oe = td.out_off + P * td.out_width;
       if (ce > s.cur_need) s.cur_need = ce;
       if (oe > s.out_need) s.out_need = oe;
+      if (ce > td.cur_off && td.cur_off < s.cur_lo) s.cur_lo = td.cur_off;
+      if (oe > td.out_off && td.out_off < s.out_lo) s.out_lo = td.out_off;
       const int64_t aux_offs[3] = {td.cur_len_off, td.in_partitions_off, td.part_id_off};
       for (int64_t ao : aux_offs) {
         if (ao < -1) return fail(KAS_E_INVALID_ARG, where + "aux offset < -1");
         if (ao >= 0 && ao + P > s.aux_need) s.aux_need = ao + P;
+        if (ao >= 0 && P > 0 && ao < s.aux_lo) s.aux_lo = ao;
       }
       int64_t w = (int64_t)td.cur_width * ((P + 63) / 64);
       if (w > words) words = w;
@@ -332,17 +349,22 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (td.name_hash == (int32_t)0x80000000) s.tickets_ok = 0;   // KAS:190 index error: round form
     }
     if (ticket_bound >= KAS_TICKET_LIMIT) s.tickets_ok = 0;
-    if (ticket_bound >= KAS_PACKED_TICKET_LIMIT) s.packed_ok = 0;
+    if (ticket_bound >= KAS_PACKED_TICKET_LIMIT) s.bound_small = 0;
     s.accmask_off[(size_t)i] = s.accmask_words;
     s.accmask_words += words > 0 ? words : 1;
     s.orph_off[(size_t)i] = s.orph_ints;
     s.orph_ints += rows > 0 ? rows : 64;
   }
+  if (s.cur_lo == kNone || s.cur_lo > s.cur_need) s.cur_lo = s.cur_need;
+  if (s.out_lo == kNone || s.out_lo > s.out_need) s.out_lo = s.out_need;
+  if (s.aux_lo == kNone || s.aux_lo > s.aux_need) s.aux_lo = s.aux_need;
+  if (s.ctx_lo == kNone || s.ctx_lo > s.ctx_need) s.ctx_lo = s.ctx_need;
   s.idmap_entries = (int32_t)max_range_fit;
   s.Wc = kas_width_class(s.W);
   // lists 4 and 5 wide: the wide ticket form (kas_order_wide.h) under the same conditions plus 10-bit
   // count fields and 16-bit LDS offsets of its 8-byte counter rows; beyond 5: round form
-  s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.packed_ok && 8 * ((int64_t)s.n_max + 1) <= 65536 &&
+  s.packed_ok = s.bound_small && !s.any_ctx;
+  s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_small && 8 * ((int64_t)s.n_max + 1) <= 65536 &&
               kas_order_wide_lds(s.n_max) <= KAS_LDS_LIMIT;
   if (s.Wc > 3) s.tickets_ok = 0;              // ring slots / packed counter rows hold lists up to 3
   // widest fill workgroup whose LDS carve-up fits: 4 wavefronts per scenario by default
@@ -373,7 +395,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // the round form of P5 is the universal fallback; a batch that one of the ticket forms serves does
   // not need it to fit (KAS_PLAN_ROUND_ORDER is refused for such a plan, see round_fits)
   s.round_fits = kas_order_round_lds(s.n_max, s.Wc) <= KAS_LDS_LIMIT;
-  if (err_total == 0 && !s.round_fits && !(s.tickets_ok || s.wide_ok))
+  if (err_total == 0 && !s.round_fits && (!(s.tickets_ok || s.wide_ok) || s.any_ctx))
     err_total = kas_order_round_lds(s.n_max, s.Wc);
   if (err_total)
     return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +

@@ -1931,6 +1931,31 @@ KAS_DEV void ticket_picks(const uint32_t (&f0)[3], const uint32_t (&f1)[3], int3
   w1 = (int32_t)((key_lo < key_hi ? key_lo : key_hi) & 3u);
 }
 
+// Context handed in (KAS:360-369) and the ticket forms.  Tickets and commit counts start at zero in every
+// solve, so a Context only seeds the count fields of the counter rows (and is read back from them at
+// the end); what has to hold is "largest counter + rows the node can gain in this solve < field limit".
+// ctx_gain_bound = the second term: the sum of the topics' caps (KAS:65-71), the same bound the plan
+// keeps below the ticket limits (kas_shape_batch).  A scenario that fails the test is left to the round
+// form (KasLaunch::ord_flag, KAS_FLAG_ORDER_FLAGGED): every wavefront of the workgroup evaluates the
+// test over the whole table by itself, so they agree without a word of LDS.
+KAS_DEV uint32_t ctx_gain_bound(const KasLaunch& a, const kas_scenario_desc& sd) {
+  int64_t b = 0;
+  for (int32_t k = 0; k < sd.topic_count; ++k) {
+    const kas_topic_desc td = a.topics[sd.topic_begin + k];
+    if (td.rf >= 1 && td.rf <= sd.n_nodes) b += ((int64_t)td.n_partitions * td.rf + sd.n_nodes - 1) / sd.n_nodes;
+  }
+  return b > 0x7fffffff ? 0x7fffffffu : (uint32_t)b;
+}
+// some counter of columns [0, cols) of rows li, li + stride, ... does not leave room for `gain` more below `limit`
+KAS_DEV bool ctx_over_limit(const int32_t* g_ctx, int32_t N, int32_t ctxw, int32_t cols, uint32_t limit, uint32_t gain,
+                            int32_t li, int32_t stride) {
+  bool over = false;
+  const uint32_t room = limit > gain ? limit - gain : 0u;   // counters must stay below this (negative ones read as huge)
+  for (int32_t n = li; n < N; n += stride)
+    for (int32_t r = 0; r < cols; ++r) over = over || (uint32_t)g_ctx[(int64_t)n * ctxw + r] >= room;
+  return over;
+}
+
 // PK: counter rows are one uint32 of three 10-bit counts (commits on the node = their sum) instead
 // of 4 x uint16 — half the LDS, for scenarios whose per-node row count stays below 1023.
 template <int W, int G, bool PK>
@@ -1943,8 +1968,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   const int lane = kasw::lane();
   const int32_t wave = kasw::wave_id();
   const int32_t g = lane / GL, li = lane % GL;
-  const bool have_s = first_scenario + g < a.n_scenarios;
-  const int32_t s = have_s ? (a.perm ? a.perm[first_scenario + g] : first_scenario + g) : a.n_scenarios;
+  const bool have_s0 = first_scenario + g < a.n_scenarios;
+  const int32_t s = have_s0 ? (a.perm ? a.perm[first_scenario + g] : first_scenario + g) : a.n_scenarios;
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   const int32_t cnt_base = g * kas_order_ticket_group_bytes(a.n_max, G, PK);   // LDS byte offset of this group's region
   unsigned char* cnt = lds_raw + cnt_base;                  // [nmax + 1] rows: + the padding holder's row
@@ -1959,11 +1984,35 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 
   kas_scenario_desc sd;
   sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;
-  if (have_s) sd = a.scen[s];
+  if (have_s0) sd = a.scen[s];
   const int32_t N = sd.n_nodes;
   const int32_t* g_node_id = a.node_id + sd.node_off;
+  // Context handed in (4 x uint16 counter rows only: the plan never pairs a Context with the packed rows)
+  bool have_s = have_s0;
+  int32_t* g_ctx = nullptr;
+  int32_t ccols = 0;
+  if constexpr (!PK) {
+    const bool ctx_s = have_s0 && sd.ctx_off >= 0 && sd.ctx_width > 0 && a.ctx != nullptr;
+    if (kasw::ballot(ctx_s) != 0ull) {                       // (wave-uniform; no Context anywhere: nothing to do)
+      constexpr uint64_t GLM = GL == 64 ? ~0ull : ((1ull << GL) - 1ull);
+      bool over = false;
+      if (ctx_s) {
+        g_ctx = a.ctx + sd.ctx_off;
+        ccols = sd.ctx_width < W ? sd.ctx_width : W;
+        over = ctx_over_limit(g_ctx, N, sd.ctx_width, ccols, 65536u, ctx_gain_bound(a, sd), li, GL);
+      }
+      const bool flagged = ((kasw::ballot(over) >> (g * GL)) & GLM) != 0ull;   // my scenario goes to the round form
+      if (flagged) { have_s = false; g_ctx = nullptr; ccols = 0; }
+      if (flagged && wave == 0 && li == 0 && a.ord_flag) a.ord_flag[s] = 1;
+    }
+  }
   for (int32_t n = li + GL * wave; n < N; n += 3 * GL) {
-    if (PK) ((uint32_t*)cnt)[n] = 0u; else ((uint64_t*)cnt)[n] = 0ull;
+    if (PK) ((uint32_t*)cnt)[n] = 0u;
+    else {
+      uint64_t x = 0ull;                                     // count[n][0..2] from the Context, commits 0
+      for (int32_t r = 0; r < ccols; ++r) x |= (uint64_t)(uint32_t)g_ctx[(int64_t)n * sd.ctx_width + r] << (16 * r);
+      ((uint64_t*)cnt)[n] = x;
+    }
     run[n] = 0; dep[n] = 0u;
   }
   if (wave == 0 && li == 0) {
@@ -2430,6 +2479,14 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     kasw::lds_atomic_add_u64(&gdig[g], digest);
     kasw::lockstep();
     if (have_s && li == 0) a.scenario_results[s].digest = gdig[g];
+    // the Context goes back (KAS:360-369): every row of the scenario has been retired, so every commit
+    // is in the counter rows (the solver adds before it marks a slot done)
+    if constexpr (!PK) {
+      for (int32_t n = li; n < N && ccols > 0; n += GL) {
+        const uint64_t x = ((const uint64_t*)cnt)[n];
+        for (int32_t r = 0; r < ccols; ++r) g_ctx[(int64_t)n * sd.ctx_width + r] = (int32_t)((x >> (16 * r)) & 0xffffu);
+      }
+    }
     if (KAS_SPIN_BOUND > 0 && have_s && li == 0 && *(volatile uint32_t*)wd != 0u) {
       a.scenario_results[s].status = KAS_FAIL_WATCHDOG;
       a.scenario_results[s].fail_topic = -1; a.scenario_results[s].fail_partition = -1;
@@ -2547,6 +2604,7 @@ template <int W>
 KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   constexpr int CS = cnt_stride<W>();
   const int lane = kasw::lane();
+  if ((a.flags & KAS_FLAG_ORDER_FLAGGED) && a.ord_flag[s] == 0) return;   // a ticket form did this one
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
   int32_t* cnt = (int32_t*)lds_raw;

@@ -115,10 +115,12 @@ class HostOutputs:
     ctx: np.ndarray                  # int32 ctx pool after the solve
 
 
-def host_tables(fb: FlatBatch) -> "tuple[abi.Tables, HostOutputs]":
-    """Allocate host outputs and build a kas_tables of HOST pointers."""
+def host_tables(fb: FlatBatch, out_len: Optional[int] = None) -> "tuple[abi.Tables, HostOutputs]":
+    """Allocate host outputs and build a kas_tables of HOST pointers (out_len: cells of the out array when
+    only selected scenarios' rows come back, kas_solve_host_select)."""
+    n_out = fb.out_len if out_len is None else out_len
     ho = HostOutputs(
-        out=np.full(max(fb.out_len, 1), -2, dtype=np.int32),
+        out=np.full(max(n_out, 1), -2, dtype=np.int32),
         topic_results=np.zeros(max(fb.n_topics, 1), dtype=abi.TOPIC_RESULT_DTYPE),
         scenario_results=np.zeros(max(fb.n_scenarios, 1), dtype=abi.SCENARIO_RESULT_DTYPE),
         ctx=fb.ctx.copy(),
@@ -131,7 +133,7 @@ def host_tables(fb: FlatBatch) -> "tuple[abi.Tables, HostOutputs]":
     t.topic_results = ho.topic_results.ctypes.data
     t.scenario_results = ho.scenario_results.ctypes.data
     t.cur_len = int(fb.cur.shape[0])
-    t.out_len = int(fb.out_len)
+    t.out_len = int(n_out)
     t.aux_len = int(fb.aux.shape[0])
     t.ctx_len = int(ho.ctx.shape[0])
     return t, ho

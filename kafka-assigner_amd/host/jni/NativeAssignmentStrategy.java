@@ -17,17 +17,20 @@ import java.util.TreeSet;
 final class NativeAssignmentStrategy {
     static { System.loadLibrary("kas_jni"); }
 
-    static final int LAYOUT = 2;         // KAS_JNI_LAYOUT of kas_jni.cpp
+    static final int LAYOUT = 3;         // KAS_JNI_LAYOUT of kas_jni.cpp
     static final int WIDTH = 8;          // KAS_MAX_WIDTH
-    static final int HEADER_INTS = 8;    // {LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen}
+    static final int HEADER_INTS = 12;   // {LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen, device, nSelect, 0, 0}
+    /** HIP device the calls of this JVM run on (one native context per device). */
+    static volatile int device = 0;
 
     /** One batch: S scenarios, each a broker set + rack map and an ordered run of topics that share
      *  one Context.  Layout of `in` (int32 / int64 fields, native order): header[8], S scenario
      *  descriptors (32 bytes: nNodes, topicBegin, topicCount, ctxWidth, long nodeOff, long ctxOff),
      *  T topic descriptors (64 bytes: nameHash, nPartitions, curWidth, rf, outWidth, reserved,
      *  long curOff, outOff, curLenOff, inPartitionsOff, partIdOff), nodeId[], nodeRack[], cur[],
-     *  aux[], ctx[].  Layout of `out`: T topic results (status, failPartition, movedReplicas,
-     *  movedPartitions), S scenario results (32 bytes), out[], ctx[]. */
+     *  aux[], ctx[], select[].  Layout of `out`: T topic results (status, failPartition, movedReplicas,
+     *  movedPartitions), S scenario results (32 bytes), out[], ctx[].  nSelect = -1: out[] holds every
+     *  row; nSelect >= 0 (what-if): only the rows of the scenarios select[] names, packed in that order. */
     static native int solveBatch(ByteBuffer in, ByteBuffer out);
 
     /** One topic of a scenario, in the reference's own argument types (KAS:40-43). */
@@ -98,17 +101,43 @@ final class NativeAssignmentStrategy {
     /** The batch path: every scenario is independent, the topics of a scenario run in order
      *  against its Context and the first failure skips the rest (the CLI run aborts there). */
     static List<List<TopicOutcome>> solveScenarios(List<ScenarioRequest> batch) {
+        return solveScenarios(batch, null);
+    }
+
+    /** The what-if form (KAG:131-187: one snapshot, many broker sets, ONE assignment printed): every
+     *  scenario is solved and reports status and movement counts, but only the scenarios whose index is
+     *  in `select` (ascending) get their `assignment` maps — the rows of the others never leave the GPU.
+     *  select == null: every scenario's rows come back. */
+    static List<List<TopicOutcome>> solveScenarios(List<ScenarioRequest> batch, int[] select) {
         final int S = batch.size();
         int T = 0;
         long nodePool = 0, curLen = 0, auxLen = 0, ctxLen = 0, outLen = 0;
         // rows of a topic: keys(cur) UNION partitions, ascending (a member of `partitions` without a
         // current list is an all-orphan row, KAS:150-157)
+        // A what-if batch hands the SAME currentAssignment (and partitions) objects to every scenario: such
+        // topics share one cur table and one set of aux arrays in the payload (identity, not equality — no
+        // table is ever compared), so S broker sets over one snapshot upload the snapshot once.
         List<List<TreeMap<Integer, List<Integer>>>> rowsOf = new ArrayList<List<TreeMap<Integer, List<Integer>>>>();
+        java.util.IdentityHashMap<Object, java.util.IdentityHashMap<Object, TreeMap<Integer, List<Integer>>>> seen =
+            new java.util.IdentityHashMap<Object, java.util.IdentityHashMap<Object, TreeMap<Integer, List<Integer>>>>();
+        java.util.IdentityHashMap<Object, long[]> placed = new java.util.IdentityHashMap<Object, long[]>();   // rows -> {curOff, auxOff}
+        final Object NO_PARTITIONS = new Object();
         for (ScenarioRequest sc : batch) {
             List<TreeMap<Integer, List<Integer>>> perTopic = new ArrayList<TreeMap<Integer, List<Integer>>>();
             for (TopicRequest t : sc.topics) {
-                TreeMap<Integer, List<Integer>> rows = new TreeMap<Integer, List<Integer>>(t.currentAssignment);
-                if (t.partitions != null)
+                java.util.IdentityHashMap<Object, TreeMap<Integer, List<Integer>>> byParts = seen.get(t.currentAssignment);
+                if (byParts == null) {
+                    byParts = new java.util.IdentityHashMap<Object, TreeMap<Integer, List<Integer>>>();
+                    seen.put(t.currentAssignment, byParts);
+                }
+                final Object partsKey = t.partitions != null ? t.partitions : NO_PARTITIONS;
+                TreeMap<Integer, List<Integer>> rows = byParts.get(partsKey);
+                final boolean shared = rows != null;
+                if (!shared) {
+                    rows = new TreeMap<Integer, List<Integer>>(t.currentAssignment);
+                    byParts.put(partsKey, rows);
+                }
+                if (!shared && t.partitions != null)
                     for (int part : t.partitions)
                         if (!rows.containsKey(part)) rows.put(part, new ArrayList<Integer>());
                 int cw = 0;
@@ -116,20 +145,47 @@ final class NativeAssignmentStrategy {
                 int ow = Math.max(Math.max(cw, Math.min(t.replicationFactor, sc.nodes.size())), 1);
                 if (ow > WIDTH) throw new IllegalStateException("replica lists longer than " + WIDTH);
                 perTopic.add(rows);
-                curLen += (long) rows.size() * cw; auxLen += 3L * rows.size(); outLen += (long) rows.size() * ow;
+                if (!shared) { curLen += (long) rows.size() * cw; auxLen += 3L * rows.size(); }
+                outLen += (long) rows.size() * ow;
                 ++T;
             }
             rowsOf.add(perTopic);
             nodePool += sc.nodes.size();
             if (sc.counters != null) ctxLen += (long) sc.nodes.size() * WIDTH;
         }
-        long inInts = HEADER_INTS + 8L * S + 16L * T + 2 * nodePool + curLen + auxLen + ctxLen;
-        long outInts = 4L * T + 8L * S + outLen + ctxLen;
+        boolean[] wanted = new boolean[S];
+        long selLen = 0;
+        if (select != null) {
+            int prev = -1;
+            for (int s : select) {
+                if (s <= prev || s >= S) throw new IllegalArgumentException("select must be ascending scenario indices");
+                prev = s; wanted[s] = true;
+            }
+        }
+        {   // rows of the selected scenarios (all of them when select == null)
+            int s = 0;
+            for (ScenarioRequest sc : batch) {
+                List<TreeMap<Integer, List<Integer>>> perTopic = rowsOf.get(s);
+                for (int k = 0; k < sc.topics.size(); ++k) {
+                    TreeMap<Integer, List<Integer>> rows = perTopic.get(k);
+                    int cw = 0;
+                    for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
+                    int ow = Math.max(Math.max(cw, Math.min(sc.topics.get(k).replicationFactor, sc.nodes.size())), 1);
+                    if (select == null || wanted[s]) selLen += (long) rows.size() * ow;
+                }
+                ++s;
+            }
+        }
+        final int nSelect = select == null ? -1 : select.length;
+        final long retLen = select == null ? outLen : selLen;       // ints of out[] that come back
+        long inInts = HEADER_INTS + 8L * S + 16L * T + 2 * nodePool + curLen + auxLen + ctxLen + Math.max(nSelect, 0);
+        long outInts = 4L * T + 8L * S + retLen + ctxLen;
         // (a direct ByteBuffer holds < 2 GiB: a larger batch must be split by the caller, not truncated)
         ByteBuffer in = ByteBuffer.allocateDirect(Math.toIntExact(4 * inInts)).order(ByteOrder.nativeOrder());
         ByteBuffer out = ByteBuffer.allocateDirect(Math.toIntExact(4 * outInts)).order(ByteOrder.nativeOrder());
-        in.putInt(LAYOUT).putInt(S).putInt(T).putInt((int) nodePool).putInt((int) curLen).putInt((int) auxLen)
-          .putInt((int) ctxLen).putInt((int) outLen);
+        in.putInt(LAYOUT).putInt(S).putInt(T).putInt(Math.toIntExact(nodePool)).putInt(Math.toIntExact(curLen))
+          .putInt(Math.toIntExact(auxLen)).putInt(Math.toIntExact(ctxLen)).putInt(Math.toIntExact(retLen))
+          .putInt(device).putInt(nSelect).putInt(0).putInt(0);
         // ---- descriptors
         long nodeOff = 0, ctxOff = 0;
         int topicBegin = 0;
@@ -148,12 +204,18 @@ final class NativeAssignmentStrategy {
                 int p = rows.size(), cw = 0;
                 for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
                 int ow = Math.max(Math.max(cw, Math.min(t.replicationFactor, sc.nodes.size())), 1);
+                long[] at = placed.get(rows);                       // a shared table keeps the offsets of its first use
+                if (at == null) {
+                    at = new long[] {curOff, auxOff};
+                    placed.put(rows, at);
+                    curOff += (long) p * cw; auxOff += 3L * p;
+                }
                 in.putInt(t.topic.hashCode()).putInt(p).putInt(cw).putInt(t.replicationFactor).putInt(ow).putInt(0)
-                  .putLong(curOff).putLong(outOff)
-                  .putLong(auxOff + p)         // curLen[P]
-                  .putLong(auxOff + 2L * p)    // inPartitions[P]
-                  .putLong(auxOff);            // partId[P]
-                curOff += (long) p * cw; outOff += (long) p * ow; auxOff += 3L * p;
+                  .putLong(at[0]).putLong(outOff)
+                  .putLong(at[1] + p)          // curLen[P]
+                  .putLong(at[1] + 2L * p)     // inPartitions[P]
+                  .putLong(at[1]);             // partId[P]
+                outOff += (long) p * ow;
             }
         }
         // ---- node pools: ids ascending; rack = dense index of the rack string, a broker without a
@@ -174,18 +236,23 @@ final class NativeAssignmentStrategy {
                 in.putInt(k);
             }
         }
-        // ---- cur pool, then aux pool (per topic: partId[P], curLen[P], inPartitions[P])
+        // ---- cur pool, then aux pool (per topic: partId[P], curLen[P], inPartitions[P]); a shared table is
+        // written where it was first placed and nowhere else
+        java.util.IdentityHashMap<Object, Boolean> written = new java.util.IdentityHashMap<Object, Boolean>();
         for (int s = 0; s < S; ++s)
             for (TreeMap<Integer, List<Integer>> rows : rowsOf.get(s)) {
+                if (written.put(rows, Boolean.TRUE) != null) continue;
                 int cw = 0;
                 for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
                 for (List<Integer> l : rows.values())
                     for (int k = 0; k < cw; ++k) in.putInt(k < l.size() ? l.get(k) : -1);
             }
+        written.clear();
         for (int s = 0; s < S; ++s)
             for (int k = 0; k < batch.get(s).topics.size(); ++k) {
                 TopicRequest t = batch.get(s).topics.get(k);
                 TreeMap<Integer, List<Integer>> rows = rowsOf.get(s).get(k);
+                if (written.put(rows, Boolean.TRUE) != null) continue;
                 for (int part : rows.keySet()) in.putInt(part);
                 for (List<Integer> l : rows.values()) in.putInt(l.size());
                 for (int part : rows.keySet()) in.putInt(t.partitions == null || t.partitions.contains(part) ? 1 : 0);
@@ -201,13 +268,14 @@ final class NativeAssignmentStrategy {
                     in.putInt(v != null ? v : 0);
                 }
         }
+        if (select != null) for (int s : select) in.putInt(s);
         int rc = solveBatch(in, out);
         if (rc != 0) throw new IllegalStateException("native solver error " + rc);
         // ---- results
         List<List<TopicOutcome>> result = new ArrayList<List<TopicOutcome>>();
         int ti = 0;
         long rowBase = 4L * T + 8L * S;      // int index of out[] inside `out`
-        long ctxBase = rowBase + outLen;
+        long ctxBase = rowBase + retLen;
         for (int s = 0; s < S; ++s) {
             ScenarioRequest sc = batch.get(s);
             List<TopicOutcome> outcomes = new ArrayList<TopicOutcome>();
@@ -220,7 +288,8 @@ final class NativeAssignmentStrategy {
                 o.topic = sc.topics.get(k).topic; o.replicationFactor = sc.topics.get(k).replicationFactor;
                 o.status = out.getInt(4 * (4 * ti)); o.failPartition = out.getInt(4 * (4 * ti + 1));
                 o.movedReplicas = out.getInt(4 * (4 * ti + 2)); o.movedPartitions = out.getInt(4 * (4 * ti + 3));
-                if (o.status == 0) {
+                final boolean haveRows = select == null || wanted[s];
+                if (o.status == 0 && haveRows) {
                     o.assignment = new TreeMap<Integer, List<Integer>>();
                     long row = 0;
                     for (int part : rows.keySet()) {
@@ -233,7 +302,7 @@ final class NativeAssignmentStrategy {
                         ++row;
                     }
                 }
-                rowBase += (long) rows.size() * ow;
+                if (haveRows) rowBase += (long) rows.size() * ow;
                 outcomes.add(o);
             }
             if (sc.counters != null) {

@@ -10,12 +10,17 @@
 // compiles it against tests/jni_stub/jni.h.
 //
 // Payload (int32 units, native byte order; written by NativeAssignmentStrategy.java):
-//   in :  header[8] = {KAS_JNI_LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen}
+//   in :  header[12] = {KAS_JNI_LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen,
+//                       device, nSelect, 0, 0}
 //         scenario descriptors  S x 8 ints   (kas_scenario_desc, 32 bytes each)
 //         topic descriptors     T x 16 ints  (kas_topic_desc, 64 bytes each)
-//         nodeId[nodePoolLen] nodeRack[nodePoolLen] cur[curLen] aux[auxLen] ctx[ctxLen]
+//         nodeId[nodePoolLen] nodeRack[nodePoolLen] cur[curLen] aux[auxLen] ctx[ctxLen] select[max(nSelect, 0)]
 //   out:  topicResults T x 4 ints, scenarioResults S x 8 ints, out[outLen], ctx[ctxLen]
-// Offsets inside the descriptors index these pools exactly as in kas_abi.h.
+// Offsets inside the descriptors index these pools exactly as in kas_abi.h.  device = HIP device the
+// call runs on (one kas_ctx per device, created on first use).  nSelect = -1: out[] holds every row in
+// place (kas_solve_host); nSelect >= 0: the what-if form (kas_solve_host_select) — every scenario
+// reports its records, out[] holds only the rows of the scenarios select[] names, packed in that order
+// (KAG:177-186 prints ONE assignment however many broker sets were tried).
 #if defined(__has_include)
 #if __has_include(<jni.h>)
 #define KAS_HAVE_JNI 1
@@ -32,12 +37,12 @@
 
 #include "kas_abi.h"
 
-#define KAS_JNI_LAYOUT 2
+#define KAS_JNI_LAYOUT 3
 
 namespace {
-std::mutex g_mu;          // guards the lazily created context; kas_solve_host serialises its own callers
-kas_ctx* g_ctx = nullptr;
-constexpr int kHeaderInts = 8;
+std::mutex g_mu;          // guards the lazily created contexts; kas_solve_host serialises its own callers
+std::vector<kas_ctx*> g_ctx;   // one per HIP device
+constexpr int kHeaderInts = 12;
 }  // namespace
 
 extern "C" JNIEXPORT jint JNICALL
@@ -48,8 +53,10 @@ Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jc
   const int64_t in_ints = env->GetDirectBufferCapacity(jin) / 4, out_ints = env->GetDirectBufferCapacity(jout) / 4;
   if (in_ints < kHeaderInts || in[0] != KAS_JNI_LAYOUT) return KAS_E_INVALID_ARG;
   const int64_t S = in[1], T = in[2], npool = in[3], cur_len = in[4], aux_len = in[5], ctx_len = in[6], out_len = in[7];
-  if (S < 0 || T < 0 || npool < 0 || cur_len < 0 || aux_len < 0 || ctx_len < 0 || out_len < 0) return KAS_E_INVALID_ARG;
-  const int64_t need_in = kHeaderInts + 8 * S + 16 * T + 2 * npool + cur_len + aux_len + ctx_len;
+  const int32_t device = in[8], n_select = in[9];
+  if (S < 0 || T < 0 || npool < 0 || cur_len < 0 || aux_len < 0 || ctx_len < 0 || out_len < 0 || device < 0 || n_select < -1)
+    return KAS_E_INVALID_ARG;
+  const int64_t need_in = kHeaderInts + 8 * S + 16 * T + 2 * npool + cur_len + aux_len + ctx_len + (n_select > 0 ? n_select : 0);
   const int64_t need_out = 4 * T + 8 * S + out_len + ctx_len;
   if (in_ints < need_in || out_ints < need_out) return KAS_E_INVALID_ARG;
 
@@ -66,7 +73,8 @@ Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jc
   const int32_t* node_rack = p; p += npool;
   const int32_t* cur = p; p += cur_len;
   const int32_t* aux = p; p += aux_len;
-  const int32_t* ctx_in = p;
+  const int32_t* ctx_in = p; p += ctx_len;
+  const int32_t* select = p;
 
   static_assert(sizeof(kas_topic_result) == 16 && sizeof(kas_scenario_result) == 32, "payload layout");
   std::vector<kas_topic_result> tr((size_t)T);
@@ -88,16 +96,20 @@ Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jc
   t.topic_results = tr.data(); t.scenario_results = sr.data();
   t.cur_len = cur_len; t.out_len = out_len; t.aux_len = aux_len; t.ctx_len = ctx_len;
 
+  kas_ctx* ctx = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_ctx) {
-      int rc = kas_ctx_create(0, &g_ctx);
+    if (g_ctx.empty()) g_ctx.assign((size_t)(kas_device_count() > 0 ? kas_device_count() : 1), nullptr);
+    if ((size_t)device >= g_ctx.size()) return KAS_E_INVALID_ARG;
+    if (!g_ctx[(size_t)device]) {
+      int rc = kas_ctx_create(device, &g_ctx[(size_t)device]);
       if (rc != KAS_E_OK) return rc;
     }
+    ctx = g_ctx[(size_t)device];
   }
   // the context keeps its device buffers and the plans of recent batch shapes: a JVM that calls
   // once per topic or per what-if round pays no allocation after the first call
-  int rc = kas_solve_host(g_ctx, &bd, &t);
+  int rc = n_select < 0 ? kas_solve_host(ctx, &bd, &t) : kas_solve_host_select(ctx, &bd, &t, select, n_select);
   if (rc != KAS_E_OK) return rc;
   if (T) memcpy(out_tr, tr.data(), sizeof(kas_topic_result) * (size_t)T);
   if (S) memcpy(out_sr, sr.data(), sizeof(kas_scenario_result) * (size_t)S);

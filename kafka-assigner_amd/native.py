@@ -23,7 +23,8 @@ SYMBOLS = [
     "kas_ctx_create", "kas_ctx_destroy", "kas_ctx_synchronize", "kas_plan_create",
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
     "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
-    "kas_plan_describe", "kas_ctx_host_stats",
+    "kas_plan_describe", "kas_ctx_host_stats", "kas_solve_host_select", "kas_host_alloc", "kas_host_free",
+    "kas_shard_range", "kas_batch_slice", "kas_solve_host_sharded",
 ]
 
 _LIB = None
@@ -71,6 +72,18 @@ def load():
     L.kas_solve_device.argtypes = [C.c_void_p, C.POINTER(abi.Tables), C.c_void_p]
     L.kas_solve_host.restype = C.c_int
     L.kas_solve_host.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
+    L.kas_solve_host_select.restype = C.c_int
+    L.kas_solve_host_select.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
+                                        C.POINTER(C.c_int32), C.c_int32]
+    L.kas_solve_host_sharded.restype = C.c_int
+    L.kas_solve_host_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
+    L.kas_host_alloc.restype = C.c_int; L.kas_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
+    L.kas_host_free.restype = None; L.kas_host_free.argtypes = [C.c_void_p]
+    L.kas_shard_range.restype = None
+    L.kas_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.kas_batch_slice.restype = C.c_int
+    L.kas_batch_slice.argtypes = [C.POINTER(abi.BatchDesc), C.c_int64, C.c_int64, C.POINTER(abi.ScenarioDesc),
+                                  C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables), C.POINTER(abi.Tables)]
     L.kas_plan_kernel_time_us.restype = C.c_int
     L.kas_plan_kernel_time_us.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.kas_plan_phase_times_us.restype = C.c_int
@@ -211,6 +224,72 @@ def solve_host(fb: FlatBatch, ctx: Optional[DeviceContext] = None) -> HostOutput
     t, ho = host_tables(fb)
     _check(L.kas_solve_host(ctx._h, C.byref(bd), C.byref(t)))
     return ho
+
+
+def selected_out_len(fb: FlatBatch, select) -> int:
+    """int32 cells kas_solve_host_select returns for the scenarios in `select` (their rows, packed)."""
+    n = 0
+    for s in select:
+        sd = fb.scen[int(s)]
+        t = fb.topics[int(sd["topic_begin"]): int(sd["topic_begin"]) + int(sd["topic_count"])]
+        n += int((t["n_partitions"].astype(np.int64) * t["out_width"]).sum())
+    return n
+
+
+def solve_host_select(fb: FlatBatch, select, ctx: Optional[DeviceContext] = None, ho: Optional[HostOutputs] = None,
+                      tables=None) -> HostOutputs:
+    """kas_solve_host_select: every scenario is solved and reports its records, rows come back only
+    for the scenarios in `select`, packed in that order (the what-if form: one assignment printed)."""
+    L = load()
+    ctx = ctx or default_context()
+    bd = batch_desc(fb)
+    sel = np.ascontiguousarray(select, dtype=np.int32)
+    if tables is None:
+        tables, ho = host_tables(fb, out_len=selected_out_len(fb, sel))
+    _check(L.kas_solve_host_select(ctx._h, C.byref(bd), C.byref(tables),
+                                   sel.ctypes.data_as(C.POINTER(C.c_int32)), int(sel.size)))
+    return ho
+
+
+def solve_host_sharded(fb: FlatBatch, ctxs) -> HostOutputs:
+    """kas_solve_host_sharded: contiguous scenario ranges over several contexts (devices), one host
+    thread each; the caller's host arrays are the gather."""
+    L = load()
+    bd = batch_desc(fb)
+    t, ho = host_tables(fb)
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(L.kas_solve_host_sharded(arr, len(ctxs), C.byref(bd), C.byref(t)))
+    return ho
+
+
+class PinnedArray:
+    """int32 numpy array over kas_host_alloc memory (pinned: kas_solve_host moves it by DMA without staging)."""
+
+    def __init__(self, n: int):
+        self._lib = load()
+        self._p = C.c_void_p()
+        _check(self._lib.kas_host_alloc(4 * max(int(n), 1), C.byref(self._p)))
+        buf = (C.c_int32 * max(int(n), 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=np.int32)[:int(n)]
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.kas_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_range(total: int, rank: int, world: int):
+    """kas_shard_range (the C mirror of sharding.shard_range)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    load().kas_shard_range(total, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 def solve_host_with_flags(fb: FlatBatch, flags: int, ctx: Optional[DeviceContext] = None) -> HostOutputs:

@@ -18,9 +18,92 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <unistd.h>
 
 #include "kas_abi.h"
+
+/* Per-thread scratch arena.  A scenario needs a few MB of scratch (holder lists, loads, Context
+ * counters); calloc / malloc / free per scenario meant an mmap + page faults + munmap each time and,
+ * with 256 threads doing that at once, serialisation in the kernel's mm locks: the all-core baselines of
+ * round 2 scaled 9-11x on 256 hardware threads.  Each worker thread now owns one block that it bumps
+ * through and rewinds (mark / release); a block that turns out too small is replaced by a larger one at
+ * the next rewind to empty, so after its first scenario a thread allocates nothing. */
+typedef struct kas_arena {
+  unsigned char* base;
+  size_t cap, used;
+  void* spill[64];        /* allocations that did not fit the block (freed at the rewind to empty) */
+  int n_spill;
+  size_t spill_bytes;
+  int depth;              /* marks outstanding: spills are only freed when the outermost one is released */
+} kas_arena;
+
+static __thread kas_arena* kas_tls_arena;     /* arena of the scenario loop running on this thread, or NULL */
+
+static void* kas_scratch_alloc(size_t bytes, int zero) {
+  kas_arena* a = kas_tls_arena;
+  bytes = (bytes + 63) & ~(size_t)63;
+  if (bytes == 0) bytes = 64;
+  void* p = NULL;
+  if (a && a->used + bytes <= a->cap) {
+    p = a->base + a->used;
+    a->used += bytes;
+  } else {
+    p = malloc(bytes);
+    if (a && p && a->n_spill < 64) { a->spill[a->n_spill++] = p; a->spill_bytes += bytes; }
+    /* (no arena, or more than 64 spills in one scenario: the pointer is simply not reclaimed before the
+     * thread ends — never the case for the shapes the solvers allocate: <= 8 blocks per topic) */
+  }
+  if (p && zero) memset(p, 0, bytes);
+  return p;
+}
+static size_t kas_scratch_mark(void) {
+  if (!kas_tls_arena) return 0;
+  kas_tls_arena->depth += 1;
+  return kas_tls_arena->used;
+}
+static void kas_scratch_release(size_t mark) {
+  kas_arena* a = kas_tls_arena;
+  if (!a) return;
+  a->used = mark;
+  a->depth -= 1;
+  if (a->depth == 0 && a->n_spill > 0) {        /* nothing is live: free what spilled and make room for it next time */
+    for (int i = 0; i < a->n_spill; ++i) free(a->spill[i]);
+    const size_t want = a->cap + a->spill_bytes + (a->cap + a->spill_bytes) / 4 + 4096;
+    free(a->base);
+    a->base = (unsigned char*)malloc(want);
+    a->cap = a->base ? want : 0;
+    a->n_spill = 0; a->spill_bytes = 0;
+  }
+}
+/* Arenas outlive the call that made them: worker threads are created per batch call and a thread sees
+ * only S / n_threads scenarios of it (4 at 1000 scenarios on 256 threads), so a block that had to be grown
+ * inside every call would never pay for itself.  A thread takes an arena from the process-wide pool when
+ * it starts and hands it back, block and all, when it ends. */
+#define KAS_ARENA_POOL 1024
+static pthread_mutex_t kas_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static kas_arena* kas_pool[KAS_ARENA_POOL];
+static int kas_pool_n;
+
+static kas_arena* kas_arena_acquire(void) {
+  kas_arena* a = NULL;
+  pthread_mutex_lock(&kas_pool_mu);
+  if (kas_pool_n > 0) a = kas_pool[--kas_pool_n];
+  pthread_mutex_unlock(&kas_pool_mu);
+  if (!a) a = (kas_arena*)calloc(1, sizeof(kas_arena));
+  kas_tls_arena = a;
+  return a;
+}
+static void kas_arena_return(kas_arena* a) {
+  kas_tls_arena = NULL;
+  if (!a) return;
+  for (int i = 0; i < a->n_spill; ++i) free(a->spill[i]);
+  a->n_spill = 0; a->spill_bytes = 0; a->used = 0; a->depth = 0;
+  pthread_mutex_lock(&kas_pool_mu);
+  if (kas_pool_n < KAS_ARENA_POOL) { kas_pool[kas_pool_n++] = a; a = NULL; }
+  pthread_mutex_unlock(&kas_pool_mu);
+  if (a) { free(a->base); free(a); }
+}
 
 typedef int (*kas_topic_fn)(int32_t name_hash, int32_t P, const int32_t* part_id,
                             const int32_t* cur, int32_t cur_width, const int32_t* cur_len,
@@ -43,7 +126,8 @@ static void kas_loop_scenario(const kas_batch_desc* b, const kas_tables* t, int3
   const int32_t* node_rack = b->node_rack + sd->node_off;
 
   const int32_t cw = KAS_MAX_WIDTH;
-  int32_t* counter = (int32_t*)calloc((size_t)(N > 0 ? N : 1) * cw, sizeof(int32_t));
+  const size_t scratch_mark = kas_scratch_mark();
+  int32_t* counter = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1) * cw, 1);
   if (sd->ctx_off >= 0 && sd->ctx_width > 0)
     for (int32_t n = 0; n < N; ++n)
       for (int32_t r = 0; r < sd->ctx_width && r < cw; ++r)
@@ -74,17 +158,22 @@ static void kas_loop_scenario(const kas_batch_desc* b, const kas_tables* t, int3
     }
     sr->moved_replicas += tr->moved_replicas;
     sr->moved_partitions += tr->moved_partitions;
+    /* (summed in a local: two 32-byte records share a cache line, and a read-modify-write of
+     * sr->digest per cell made the threads of neighbouring scenarios fight over it — with that, two
+     * threads were SLOWER than one, and 256 threads 9x one) */
+    uint64_t dg = 0;
     for (int32_t p = 0; p < td->n_partitions; ++p)
       for (int32_t r = 0; r < td->out_width; ++r) {
         const int32_t v = out[(int64_t)p * td->out_width + r];
-        if (v != -1) sr->digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, v);
+        if (v != -1) dg += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, v);
       }
+    sr->digest += dg;
   }
   if (sd->ctx_off >= 0 && sd->ctx_width > 0)
     for (int32_t n = 0; n < N; ++n)
       for (int32_t r = 0; r < sd->ctx_width && r < cw; ++r)
         t->ctx[sd->ctx_off + (int64_t)n * sd->ctx_width + r] = counter[(int64_t)n * cw + r];
-  free(counter);
+  kas_scratch_release(scratch_mark);
 }
 
 typedef struct {
@@ -96,11 +185,13 @@ typedef struct {
 
 static void* kas_loop_worker(void* arg) {
   kas_loop_shared* sh = (kas_loop_shared*)arg;
+  kas_arena* arena = kas_arena_acquire();
   for (;;) {
     const int32_t s = __atomic_fetch_add(&sh->next, 1, __ATOMIC_RELAXED);
     if (s >= sh->b->n_scenarios) break;
     kas_loop_scenario(sh->b, sh->t, s, sh->solve);
   }
+  kas_arena_return(arena);
   return NULL;
 }
 
@@ -116,7 +207,9 @@ static int kas_loop_batch(const kas_batch_desc* b, const kas_tables* t, kas_topi
   if (n_threads <= 0) n_threads = kas_loop_host_threads();
   if (n_threads > b->n_scenarios) n_threads = b->n_scenarios > 0 ? b->n_scenarios : 1;
   if (n_threads == 1) {
+    kas_arena* arena = kas_arena_acquire();
     for (int32_t s = 0; s < b->n_scenarios; ++s) kas_loop_scenario(b, t, s, solve);
+    kas_arena_return(arena);
     return 1;
   }
   kas_loop_shared sh;

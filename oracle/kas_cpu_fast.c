@@ -101,7 +101,9 @@ int kas_cpu_fast_solve_topic(int32_t name_hash, int32_t P, const int32_t* part_i
 
   /* one block: load[N] live[N] hold[P][hw] hrk[P][hw] hcnt[P] */
   const size_t Pn = (size_t)(P > 0 ? P : 1), Nn = (size_t)(N > 0 ? N : 1);
-  int32_t* block = (int32_t*)malloc(sizeof(int32_t) * (2 * Nn + 2 * Pn * (size_t)hw + Pn));
+  kas_arena* own_arena = kas_tls_arena == NULL ? kas_arena_acquire() : NULL;   /* (a direct caller outside the batch loop) */
+  const size_t scratch_mark = kas_scratch_mark();          /* the calling thread's arena (kas_batch_loop.h) */
+  int32_t* block = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (2 * Nn + 2 * Pn * (size_t)hw + Pn), 0);
   int32_t* load = block;
   int32_t* live = load + Nn;
   int32_t* hold = live + Nn;
@@ -114,7 +116,7 @@ int kas_cpu_fast_solve_topic(int32_t name_hash, int32_t P, const int32_t* part_i
   im.N = N; im.node_id = node_id; im.direct = NULL; im.min_id = N > 0 ? node_id[0] : 0;
   im.range = N > 0 ? (int64_t)node_id[N - 1] - node_id[0] + 1 : 0;
   if (N > 0 && im.range <= FAST_DIRECT_TABLE_LIMIT && im.range <= 64 * (int64_t)N + 1024) {
-    im.direct = (int32_t*)malloc(sizeof(int32_t) * (size_t)im.range);
+    im.direct = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)im.range, 0);
     for (int64_t i = 0; i < im.range; ++i) im.direct[i] = -1;
     for (int32_t i = 0; i < N; ++i) im.direct[node_id[i] - im.min_id] = i;
   }
@@ -240,8 +242,8 @@ int kas_cpu_fast_solve_topic(int32_t name_hash, int32_t P, const int32_t* part_i
     for (int64_t i = 0; i < cells; ++i) out[i] = -1;
     res->moved_replicas = 0; res->moved_partitions = 0;
   }
-  free(im.direct);
-  free(block);
+  kas_scratch_release(scratch_mark);
+  if (own_arena) kas_arena_return(own_arena);
   return res->status;
 }
 

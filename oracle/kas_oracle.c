@@ -263,12 +263,15 @@ int kas_oracle_solve_topic(int32_t name_hash, int32_t P, const int32_t* part_id,
   m.N = N; m.node_id = node_id; m.node_rack = node_rack; m.P = P;
   m.cap = get_max_replicas_per_node(N, n_in, rf);                                  /* KAS:45 */
   m.hw = (cur_width > rf ? cur_width : rf); if (m.hw < 1) m.hw = 1;
-  m.load = (int32_t*)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));             /* KAS:46 */
-  m.holders = (int32_t*)malloc(sizeof(int32_t) * (size_t)(P > 0 ? P : 1) * m.hw);
-  m.hcnt = (int32_t*)calloc((size_t)(P > 0 ? P : 1), sizeof(int32_t));
-  int32_t* rem = (int32_t*)malloc(sizeof(int32_t) * (size_t)(P > 0 ? P : 1));
-  int32_t* idx_sorted = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
-  int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+  kas_arena* own_arena = kas_tls_arena == NULL ? kas_arena_acquire() : NULL;   /* (a direct caller outside the batch loop) */
+  /* scratch from the calling thread's arena (kas_batch_loop.h): no malloc / free per topic */
+  const size_t scratch_mark = kas_scratch_mark();
+  m.load = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1), 1);          /* KAS:46 */
+  m.holders = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)(P > 0 ? P : 1) * m.hw, 0);
+  m.hcnt = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)(P > 0 ? P : 1), 1);
+  int32_t* rem = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)(P > 0 ? P : 1), 0);
+  int32_t* idx_sorted = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)N, 0);
+  int32_t* order = (int32_t*)kas_scratch_alloc(sizeof(int32_t) * (size_t)N, 0);
 
   fill_nodes_from_assignment(&m, cur, cur_width, cur_len);                         /* KAS:49 */
   get_orphaned_replicas(&m, in_partitions, rf, rem);                               /* KAS:52 */
@@ -291,7 +294,8 @@ int kas_oracle_solve_topic(int32_t name_hash, int32_t P, const int32_t* part_id,
     movement(cur, cur_width, cur_len, out, out_width, P,
              &res->moved_replicas, &res->moved_partitions);
   }
-  free(m.load); free(m.holders); free(m.hcnt); free(rem); free(idx_sorted); free(order);
+  kas_scratch_release(scratch_mark);
+  if (own_arena) kas_arena_return(own_arena);
   return res->status;
 }
 

@@ -226,6 +226,8 @@ run_fn rounds_for(int Wc) {
 static long g_last_queue_rows = 0;
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
+static int g_last_order_form = 0;   // 1: ticket form (lists <= 3 wide), 2: wide ticket form, 0: round form (the last solve's plan)
+static int g_last_flagged = 0; // scenarios a ticket form left to the round form (Context counters too large for its fields)
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
 // 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice)
 extern "C" __attribute__((visibility("default")))
@@ -239,6 +241,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   }
   const bool tickets = sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER);
   const bool wide = sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER);
+  g_last_order_form = tickets ? 1 : (wide ? 2 : 0);
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
   const bool fused = sh.fused_ok && !(flags & KAS_FLAG_TWO_PASS_HIST) && !(flags & KAS_FLAG_GENERIC_FILL);
@@ -264,6 +267,9 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.orph = orph.data(); a.orph_off = sh.orph_off.data();
   std::vector<int32_t> perm((size_t)b->n_scenarios + 1, -1);
   a.perm = nullptr;
+  std::vector<int32_t> ord_flag((size_t)b->n_scenarios + 1, 0);   // scenarios a ticket form leaves to the round form
+  a.ord_flag = ord_flag.data();
+  g_last_flagged = 0;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch;
   a.flags = (flags & 0xffu & ~KAS_FLAG_FUSED_HIST) | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u);
@@ -388,6 +394,18 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
       if (kasw::run_block(f, &ra, 1) != 0) return bad("order (rounds)", s);
     }
   }
+  if (sh.any_ctx && (tickets || wide)) {
+    // as kas_solve_device: the round form behind a ticket form, taking only what that one flagged
+    a.flags |= KAS_FLAG_ORDER_FLAGGED;
+    a.perm = nullptr;
+    run_fn f = rounds_for(sh.Wc);
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      g_last_flagged += ord_flag[(size_t)s] != 0 ? 1 : 0;
+      memset(lds.data(), 0xCD, lds.size());
+      RunArgs ra{&a, s, lds.data()};
+      if (kasw::run_block(f, &ra, 1) != 0) return bad("order (rounds, flagged)", s);
+    }
+  }
   return KAS_E_OK;
 }
 
@@ -418,6 +436,12 @@ int kas_emu_last_fused(void) { return g_last_fused; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_spread(void) { return g_last_spread; }
+
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_flagged(void) { return g_last_flagged; }
+
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_order_form(void) { return g_last_order_form; }
 
 // ---------------------------------------------------------------------------------------------
 // Unit harness for the parallel P4 of the fill kernel (p4_lists_parallel<3, 4>): the caller gives the

@@ -114,3 +114,17 @@ def plan_shape(fb: FlatBatch):
     rc = L.kas_emu_shape(C.byref(bd), out, err, 512)
     names = ("tickets_ok", "wide_ok", "round_fits", "G", "NW", "with_x", "packed_ok", "fused_ok")
     return rc, dict(zip(names, list(out))), err.value.decode()
+
+
+def last_flagged() -> int:
+    """Scenarios a ticket form left to the round form in the last emu_solve (Context counters beyond its count fields)."""
+    L = lib()
+    L.kas_emu_last_flagged.restype = C.c_int
+    return int(L.kas_emu_last_flagged())
+
+
+def last_order_form() -> int:
+    """Order kernel of the last emu_solve: 1 ticket form (lists <= 3 wide), 2 wide ticket form, 0 round form."""
+    L = lib()
+    L.kas_emu_last_order_form.restype = C.c_int
+    return int(L.kas_emu_last_order_form())

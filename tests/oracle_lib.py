@@ -70,9 +70,9 @@ def host_threads() -> int:
     return int(lib().kas_oracle_host_threads())
 
 
-def _solve(fn_st, fn_mt, fb: FlatBatch, threads: int, what: str) -> HostOutputs:
+def _solve(fn_st, fn_mt, fb: FlatBatch, threads: int, what: str, into=None) -> HostOutputs:
     bd = batch_desc(fb)
-    t, ho = host_tables(fb)
+    t, ho = into if into is not None else host_tables(fb)
     if threads == 1:
         rc = fn_st(C.byref(bd), C.byref(t))
         if rc != 0:
@@ -86,14 +86,16 @@ def _solve(fn_st, fn_mt, fb: FlatBatch, threads: int, what: str) -> HostOutputs:
     return ho
 
 
-def oracle_solve(fb: FlatBatch, threads: int = 1) -> HostOutputs:
+def oracle_solve(fb: FlatBatch, threads: int = 1, into=None) -> HostOutputs:
     """Solve a flattened batch with the CPU oracle; same semantics as kas_solve_host.
-    threads != 1: scenario-parallel inside the one C call (0 = every hardware thread)."""
+    threads != 1: scenario-parallel inside the one C call (0 = every hardware thread).
+    into = (kas_tables, HostOutputs) from flatten.host_tables: solve into these buffers again (timing
+    loops: no allocation and no first touch of fresh pages inside the timed call)."""
     L = lib()
-    return _solve(L.kas_oracle_solve_batch, L.kas_oracle_solve_batch_mt, fb, threads, "kas_oracle_solve_batch")
+    return _solve(L.kas_oracle_solve_batch, L.kas_oracle_solve_batch_mt, fb, threads, "kas_oracle_solve_batch", into)
 
 
-def cpu_fast_solve(fb: FlatBatch, threads: int = 1) -> HostOutputs:
+def cpu_fast_solve(fb: FlatBatch, threads: int = 1, into=None) -> HostOutputs:
     """The same batch by the flat-array CPU baseline (oracle/kas_cpu_fast.c)."""
     L = fast_lib()
-    return _solve(L.kas_cpu_fast_solve_batch, L.kas_cpu_fast_solve_batch_mt, fb, threads, "kas_cpu_fast_solve_batch")
+    return _solve(L.kas_cpu_fast_solve_batch, L.kas_cpu_fast_solve_batch_mt, fb, threads, "kas_cpu_fast_solve_batch", into)

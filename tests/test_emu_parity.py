@@ -325,3 +325,104 @@ def test_emu_spread_fill_hands_back_what_it_does_not_cover():
     fb = _multi_topic_scenarios(3, 2, 3, 900, 40, 8, 3)
     assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb, flags=SPREAD), "emu spread flag, multi-topic batch")
     assert last_spread() == 0
+
+
+# ---- ticket forms with a Context handed in (KAS:59-62; how KTA:70-71 calls the solver on EVERY topic) ----
+def _with_context(fb, values):
+    """Give every scenario of a single-topic batch a Context: ctx_width 8, counters from values(s, n_nodes)."""
+    from kafka_assigner_amd.flatten import FlatBatch
+    scen = fb.scen.copy()
+    ctx, off = [], 0
+    for s in range(fb.n_scenarios):
+        n = int(scen["n_nodes"][s])
+        tab = np.asarray(values(s, n), dtype=np.int32).reshape(n, 8)
+        scen["ctx_width"][s] = 8
+        scen["ctx_off"][s] = off
+        ctx.append(tab.reshape(-1)); off += n * 8
+    return FlatBatch(scen=scen, topics=fb.topics, node_id=fb.node_id, node_rack=fb.node_rack, cur=fb.cur, aux=fb.aux,
+                     ctx=np.concatenate(ctx), out_len=fb.out_len)
+
+
+def _random_counters(seed, hi):
+    def values(s, n):
+        return np.random.default_rng(seed + s).integers(0, hi, size=(n, 8))
+    return values
+
+
+@pytest.mark.parametrize("P,N,R,RF,form", [(3000, 60, 10, 3, 1), (1500, 40, 8, 2, 1), (1200, 50, 10, 5, 2), (900, 40, 8, 4, 2)])
+def test_emu_ticket_forms_take_a_context_in_and_hand_it_back(P, N, R, RF, form):
+    """A Context no longer sends a scenario to the one-wavefront round form: the ticket kernels seed
+    their count fields from it and write them back (the counters of columns >= list width pass through
+    untouched).  Same lists, same counters as the oracle — and the plan really chose the ticket form."""
+    from emu_lib import last_flagged, last_order_form
+    fb = _with_context(_batch(808 + RF, 4, P, N, R, RF, G.BENCH_ACTIONS), _random_counters(5, 60))
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).any()
+    got = emu_solve(fb)
+    assert last_order_form() == form and last_flagged() == 0
+    assert_same_outputs(fb, want, got, f"emu ticket form {form} with a Context")
+    assert (got.ctx != fb.ctx).any()                                     # the counters moved ...
+    np.testing.assert_array_equal(got.ctx.reshape(-1, 8)[:, RF:], fb.ctx.reshape(-1, 8)[:, RF:])   # ... only below the list width
+    assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round form with the same Context")
+
+
+def test_emu_context_counters_beyond_the_count_fields_go_to_the_round_form():
+    """Per scenario, on the device: largest counter + rows a node can gain must stay inside the count
+    fields (16 bits for lists <= 3 wide, 10 bits for the wide form), else the scenario is flagged and the
+    round form (int32 counters), launched behind the ticket kernel, solves it.  Two of four scenarios
+    each; a negative counter (never produced by the reference, but an int in its map) counts as large."""
+    from emu_lib import last_flagged, last_order_form
+
+    def big3(s, n):
+        v = np.random.default_rng(s).integers(0, 500, size=(n, 8))
+        if s == 1: v[n // 2, 1] = 65535
+        if s == 2: v[3, 0] = -4
+        return v
+    fb = _with_context(_batch(515, 4, 2000, 50, 10, 3, G.BENCH_ACTIONS), big3)
+    want = oracle_solve(fb)
+    got = emu_solve(fb, flags=1 << 12)
+    assert last_order_form() == 1 and last_flagged() == 2
+    assert_same_outputs(fb, want, got, "emu ticket form, two scenarios flagged")
+    assert_same_outputs(fb, want, emu_solve(fb), "emu ticket form, two scenarios per wavefront, two flagged")
+
+    def big5(s, n):
+        v = np.random.default_rng(s).integers(0, 300, size=(n, 8))
+        if s == 0: v[1, 4] = 1000
+        if s == 3: v[n - 1, 2] = 70000
+        return v
+    fb = _with_context(_batch(516, 4, 1000, 50, 10, 5, ("add_k", "mixed")), big5)
+    want = oracle_solve(fb)
+    got = emu_solve(fb)
+    assert last_order_form() == 2 and last_flagged() == 2
+    assert_same_outputs(fb, want, got, "emu wide ticket form, two scenarios flagged")
+
+
+def test_emu_per_topic_calls_carry_the_context_like_the_cli_loop():
+    """KAG:172-184 through the per-topic drop-in: one call per topic, the Context of call k is the
+    input of call k + 1 — every call takes the ticket form, and the chain equals one oracle run over
+    the whole scenario."""
+    from emu_lib import last_order_form
+    N, R, RF = 40, 8, 3
+    act, bs = G.scenario_action(9, 0, N, R, actions=("remove1",), max_add=4)
+    racks = {int(b): "r%d" % int(r) for b, r in zip(bs.node_id, bs.node_rack)}
+    brokers = [int(b) for b in bs.node_id]
+    topics = [Topic("topic-%d" % t, {p: row.tolist() for p, row in enumerate(G.random_assignment(40 + t, 500 + 37 * t, N, R, RF))}, RF)
+              for t in range(4)]
+    whole = flatten([Scenario(brokers=brokers, racks=racks, topics=topics, want_context=True)])
+    want = oracle_solve(whole)
+    assert (want.topic_results["status"][:2] == abi.KAS_OK).all()
+    from kafka_assigner_amd.flatten import unflatten_context
+    counters, outs = None, []
+    for k, t in enumerate(topics):
+        fb = flatten([Scenario(brokers=brokers, racks=racks, topics=[t], context=counters, want_context=True)])
+        got = emu_solve(fb)
+        assert last_order_form() == 1
+        assert got.topic_results["status"][0] == want.topic_results["status"][k]
+        assert got.topic_results["fail_partition"][0] == want.topic_results["fail_partition"][k]
+        outs.append(got.out[:fb.out_len])
+        if got.topic_results["status"][0] != abi.KAS_OK:
+            break                                                        # the CLI run ends here (KAG:173-184)
+        counters = unflatten_context(fb, got.ctx, 0)
+    done = np.concatenate(outs)
+    np.testing.assert_array_equal(done, want.out[:done.size])
+    assert counters == unflatten_context(whole, want.ctx, 0)

@@ -14,7 +14,7 @@ from oracle_lib import oracle_solve
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "kafka-assigner_amd", "host", "jni", "kas_jni.cpp")
-WIDTH, HEADER = 8, 8
+WIDTH, HEADER = 8, 12
 
 
 class StubBuffer(C.Structure):
@@ -38,16 +38,21 @@ def shim():
     return fn
 
 
-def _payload(fb):
-    """The batch payload NativeAssignmentStrategy.solveScenarios() writes (layout 2): header,
-    scenario and topic descriptors as the C structs, node pools, cur, aux, ctx."""
+def _payload(fb, select=None, device=0):
+    """The batch payload NativeAssignmentStrategy.solveScenarios() writes (layout 3): header (with the
+    device and the number of selected scenarios, -1 = every row comes back), scenario and topic
+    descriptors as the C structs, node pools, cur, aux, ctx, select."""
+    from kafka_assigner_amd.native import selected_out_len
     S, T = fb.n_scenarios, fb.n_topics
     cur = fb.cur if fb.cur.size else np.zeros(0, np.int32)
-    hdr = np.asarray([2, S, T, fb.node_id.size, cur.size, fb.aux.size, fb.ctx.size, fb.out_len], dtype=np.int32)
+    sel = np.zeros(0, np.int32) if select is None else np.asarray(select, dtype=np.int32)
+    ret_len = fb.out_len if select is None else selected_out_len(fb, sel)
+    hdr = np.asarray([3, S, T, fb.node_id.size, cur.size, fb.aux.size, fb.ctx.size, ret_len,
+                      device, -1 if select is None else sel.size, 0, 0], dtype=np.int32)
     parts = [hdr, fb.scen[:S].view(np.int32).reshape(-1), fb.topics[:T].view(np.int32).reshape(-1),
-             fb.node_id, fb.node_rack, cur, fb.aux, fb.ctx]
+             fb.node_id, fb.node_rack, cur, fb.aux, fb.ctx, sel]
     inp = np.concatenate([np.ascontiguousarray(x, dtype=np.int32).reshape(-1) for x in parts])
-    out = np.full(4 * T + 8 * S + fb.out_len + fb.ctx.size, -7, dtype=np.int32)
+    out = np.full(4 * T + 8 * S + ret_len + fb.ctx.size, -7, dtype=np.int32)
     return inp, out
 
 
@@ -56,23 +61,26 @@ def _call(shim, inp, out):
     return shim(None, None, C.byref(bi), C.byref(bo))
 
 
-def _unpack(fb, out):
+def _unpack(fb, out, ret_len=None):
     S, T = fb.n_scenarios, fb.n_topics
+    ret_len = fb.out_len if ret_len is None else ret_len
     tr = out[:4 * T].view(abi.TOPIC_RESULT_DTYPE)
     sr = out[4 * T:4 * T + 8 * S].view(abi.SCENARIO_RESULT_DTYPE)
-    rows = out[4 * T + 8 * S:4 * T + 8 * S + fb.out_len]
-    ctx = out[4 * T + 8 * S + fb.out_len:]
+    rows = out[4 * T + 8 * S:4 * T + 8 * S + ret_len]
+    ctx = out[4 * T + 8 * S + ret_len:]
     return tr, sr, rows, ctx
 
 
 def test_shim_rejects_short_buffers_and_unknown_layouts_without_a_gpu(shim):
     out = np.zeros(64, dtype=np.int32)
-    hdr_only = np.asarray([2, 1, 1, 5, 8, 12, 0, 8], dtype=np.int32)           # tables missing
+    hdr_only = np.asarray([3, 1, 1, 5, 8, 12, 0, 8, 0, -1, 0, 0], dtype=np.int32)   # tables missing
     assert _call(shim, hdr_only, out) == -1                                    # KAS_E_INVALID_ARG
-    old_layout = np.zeros(64, dtype=np.int32); old_layout[0] = 97              # layout 1 started with a hash
+    old_layout = np.zeros(64, dtype=np.int32); old_layout[0] = 2               # layout 2: 8-int header, no device
     assert _call(shim, old_layout, out) == -1
-    neg = np.asarray([2, -1, 0, 0, 0, 0, 0, 0], dtype=np.int32)
+    neg = np.asarray([3, -1, 0, 0, 0, 0, 0, 0, 0, -1, 0, 0], dtype=np.int32)
     assert _call(shim, neg, out) == -1
+    bad_dev = np.asarray([3, 0, 0, 0, 0, 0, 0, 0, -2, -1, 0, 0], dtype=np.int32)
+    assert _call(shim, bad_dev, out) == -1
 
 
 @pytest.mark.gpu
@@ -128,3 +136,31 @@ def test_shim_batch_payload_many_scenarios_and_topics(shim):
         np.testing.assert_array_equal(rows, want.out[:fb.out_len])
         ok_ctx = np.ones(fb.ctx.size, dtype=bool)
         np.testing.assert_array_equal(ctx[ok_ctx], want.ctx[:fb.ctx.size][ok_ctx])
+
+
+@pytest.mark.gpu
+def test_shim_what_if_payload_returns_records_for_all_and_rows_for_the_selected(shim):
+    """Layout 3's what-if form: 24 broker-set variants over ONE shared current assignment (every topic
+    descriptor points at the same cur rows), rows requested for two of them.  Records of all 24 and the
+    rows of the two must be the oracle's; an out-of-range device index is refused."""
+    from kafka_assigner_amd import generator as G
+    from kafka_assigner_amd.native import selected_out_len
+    from test_emu_parity import _batch
+    P, N, R, RF, S = 20000, 200, 10, 3, 24
+    fb = _batch(31, S, P, N, R, RF, G.BENCH_ACTIONS)
+    fb.cur = G.random_assignment(31, P, N, R, RF).reshape(-1).copy()
+    fb.topics["cur_off"] = 0
+    want = oracle_solve(fb, threads=0)
+    select = [3, 17]
+    inp, out = _payload(fb, select=select)
+    assert _call(shim, inp, out) == 0
+    tr, sr, rows, _ = _unpack(fb, out, selected_out_len(fb, select))
+    for f in ("status", "fail_partition", "moved_replicas", "moved_partitions"):
+        np.testing.assert_array_equal(tr[f], want.topic_results[f][:S])
+    for f in ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest"):
+        np.testing.assert_array_equal(sr[f], want.scenario_results[f][:S])
+    cells = P * RF
+    for k, s_ in enumerate(select):
+        np.testing.assert_array_equal(rows[k * cells:(k + 1) * cells], want.out[s_ * cells:(s_ + 1) * cells])
+    inp, out = _payload(fb, select=select, device=63)
+    assert _call(shim, inp, out) == -1
