@@ -230,6 +230,8 @@ def selected_out_len(fb: FlatBatch, select) -> int:
     """int32 cells kas_solve_host_select returns for the scenarios in `select` (their rows, packed)."""
     n = 0
     for s in select:
+        if not 0 <= int(s) < fb.n_scenarios:
+            continue                       # (the library refuses the call: KAS_E_INVALID_ARG)
         sd = fb.scen[int(s)]
         t = fb.topics[int(sd["topic_begin"]): int(sd["topic_begin"]) + int(sd["topic_count"])]
         n += int((t["n_partitions"].astype(np.int64) * t["out_width"]).sum())

@@ -1,0 +1,86 @@
+#!/bin/bash
+# One GPU trip (gpurun -- 'bash scripts/gpu_trip.sh NAME STEP...'): every step writes its log under
+# gpurun_out/NAME/ and prints one summary line, so that a trip's outcome can be read from the tail.
+#   tests      pytest -m gpu (the driver's round-end suite)
+#   smoke      __graft_entry__.smoke()
+#   bench      bench.py at the driver's command line (--gpus 1 --steps 20 --warmup 5)
+#   benchq     bench.py without the CPU / end-to-end / other-config legs (quick headline figure + counters)
+#   alone      one batch in flight (per-kernel durations free of other launches)
+#   configs    BASELINE configs[1], configs[3]'s share, configs[4] (x1 rack map on / off, x8, x64)
+#   stress     scripts/stress_inflight.py --suite 1000
+#   trace      rocprofv3 --kernel-trace --stats: one batch alone, default, configs[4]
+#   pmc        rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one batch in flight)
+#   sq         rocprofv3 --pmc SQ_* passes, one batch alone and twelve in flight
+#   ab:LIB     benchq with KAS_HIP_LIB=variants/libkas_hip_LIB.so (tuning builds, scripts/build_variant.sh)
+#   c5:LIB     configs[4] x1 with that tuning build (LIB = - for the product library)
+set -u
+NAME=$1; shift
+O=gpurun_out/$NAME
+mkdir -p $O
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+val() { grep -o "\"$1\": [0-9.]*" "$2" | head -1 | cut -d' ' -f2; }
+c5() {  # $1 = log stem, extra bench flags follow
+  local stem=$1; shift
+  timeout 300 python bench.py --no-cpu --no-extras --repeats 1 --check 1 --scenarios 1 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --in-flight 1 --steps 6 --warmup 1 "$@" > $O/$stem.log 2>&1
+  echo "$stem: ms_per_step $(val ms_per_step $O/$stem.log) $(grep -o '"in_flight_launch": {[^}]*' $O/$stem.log | cut -c1-110)"
+}
+for step in "$@"; do
+  case $step in
+    tests)
+      timeout 1800 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
+      tail -12 $O/pytest_gpu.log | cut -c1-220 ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log; tail -2 $O/smoke.log | cut -c1-200 ;;
+    bench)
+      timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmdline.log 2>&1; echo "exit $?" >> $O/bench_driver_cmdline.log
+      echo "bench: value $(val value $O/bench_driver_cmdline.log) $(grep -o '"repeats": {[^}]*' $O/bench_driver_cmdline.log | cut -c1-260)"; tail -1 $O/bench_driver_cmdline.log | cut -c1-120
+      grep -v '^{' $O/bench_driver_cmdline.log | tail -5 | cut -c1-300 ;;
+    benchq)
+      timeout 600 python bench.py --no-cpu --check 0 --no-extras --stats $O/stats_default.json > $O/bench_quick.log 2>&1; echo "exit $?" >> $O/bench_quick.log
+      echo "benchq: value $(val value $O/bench_quick.log) $(grep -o '"values": \[[^]]*' $O/bench_quick.log | cut -c1-200)" ;;
+    alone)
+      timeout 300 python bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps 10 --in-flight 1 --stats $O/stats_one_batch_in_flight.json > $O/bench_one_batch_in_flight.log 2>&1
+      echo "alone: ms_per_step $(val ms_per_step $O/bench_one_batch_in_flight.log) $(grep -o '"in_flight_launch": {[^}]*' $O/bench_one_batch_in_flight.log | cut -c1-110)" ;;
+    configs)
+      timeout 300 python bench.py --no-cpu --no-extras --repeats 1 --check 1 --scenarios 1 --partitions 10000 --brokers 100 --racks 10 --actions remove1 --in-flight 1 --steps 50 --warmup 5 > $O/bench_config2_single_scenario.log 2>&1
+      echo "configs[1]: ms_per_step $(val ms_per_step $O/bench_config2_single_scenario.log)"
+      timeout 900 python bench.py --no-cpu --no-extras --repeats 3 --check 64 --scenarios 8000 --actions add50 --in-flight 2 --steps 4 --warmup 1 > $O/bench_config4_8000_scenarios_add50.log 2>&1
+      echo "configs[3] share: value $(val value $O/bench_config4_8000_scenarios_add50.log)"
+      c5 bench_config5_c5 --actions c5 --stats $O/stats_config5_c5.json
+      c5 bench_config5_c5_norack --actions c5_norack --stats $O/stats_config5_c5_norack.json
+      timeout 300 python bench.py --no-cpu --no-extras --repeats 1 --check 2 --scenarios 8 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 5 --warmup 1 > $O/bench_config5_x8.log 2>&1
+      echo "configs[4] x8: ms_per_step $(val ms_per_step $O/bench_config5_x8.log)"
+      timeout 600 python bench.py --no-cpu --no-extras --repeats 1 --check 2 --scenarios 64 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 3 --warmup 1 > $O/bench_config5_x64.log 2>&1
+      echo "configs[4] x64: ms_per_step $(val ms_per_step $O/bench_config5_x64.log) $(grep -o '"in_flight_launch": {[^}]*' $O/bench_config5_x64.log | cut -c1-110)" ;;
+    stress)
+      timeout 900 python scripts/stress_inflight.py --suite 1000 > $O/stress_inflight.log 2>&1; echo "stress exit $?" >> $O/stress_inflight.log; grep -v "plan:" $O/stress_inflight.log | cut -c1-220 ;;
+    trace)
+      cd /tmp
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_trace_one_batch_in_flight -o trace -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --in-flight 1 --steps 20 > $R/$O/prof_trace_f1.log 2>&1; echo "trace (alone) exit $?"
+      timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_trace_default -o trace -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 2 > $R/$O/prof_trace_default.log 2>&1; echo "trace (default) exit $?"
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_trace_config5 -o trace -- python $R/bench.py --no-cpu --no-extras --repeats 1 --check 0 --scenarios 1 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 6 --warmup 1 > $R/$O/prof_trace_c5.log 2>&1; echo "trace (configs[4]) exit $?"
+      cd $R ;;
+    pmc)
+      cd /tmp
+      timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_fetch -o fetch -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps 2 --warmup 1 --in-flight 1 > $R/$O/prof_fetch.log 2>&1; echo "fetch exit $?"
+      timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_write -o write -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps 2 --warmup 1 --in-flight 1 > $R/$O/prof_write.log 2>&1; echo "write exit $?"
+      cd $R ;;
+    sq)
+      cd /tmp
+      for mode in 1 12; do
+        timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $R/$O/prof_sq1_f$mode -o sq1 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq1_f$mode.log 2>&1; echo "sq1 f$mode exit $?"
+        timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_sq2_f$mode -o sq2 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq2_f$mode.log 2>&1; echo "sq2 f$mode exit $?"
+      done
+      cd $R ;;
+    ab:*)
+      lib=${step#ab:}
+      KAS_HIP_LIB=variants/libkas_hip_$lib.so timeout 400 python bench.py --no-cpu --check 0 --no-extras --repeats 3 > $O/bench_v_$lib.log 2>&1
+      echo "ab $lib: value $(val value $O/bench_v_$lib.log) $(grep -o '"values": \[[^]]*' $O/bench_v_$lib.log | cut -c1-120) $(grep -o '"one_batch_alone": {[^}]*' $O/bench_v_$lib.log | cut -c1-140)"
+      grep -v '^{' $O/bench_v_$lib.log | tail -2 | cut -c1-200 ;;
+    c5:*)
+      lib=${step#c5:}
+      if [ "$lib" == "-" ]; then c5 bench_c5_product --actions c5; else KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5_v_$lib --actions c5; fi ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
