@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "kas_abi.h"
@@ -225,6 +226,38 @@ static int kas_loop_batch(const kas_batch_desc* b, const kas_tables* t, kas_topi
   for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
   free(th);
   return started > 0 ? started : 1;
+}
+
+/* How much parallelism does this host actually give the process?  n_threads threads each run the same
+ * fixed register-only integer loop; returns the wall time in seconds.  (time at 1 thread) x n / (time at
+ * n threads) = the cores the threads really got — a container with a CPU quota reports 256 hardware
+ * threads and delivers a fraction of them, which bounds any all-core baseline measured in it. */
+typedef struct { uint64_t iters; volatile uint64_t sink; } kas_probe_arg;
+static __attribute__((unused)) void* kas_probe_worker(void* p) {
+  kas_probe_arg* a = (kas_probe_arg*)p;
+  uint64_t x = 88172645463325252ull;
+  for (uint64_t i = 0; i < a->iters; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; }
+  a->sink = x;
+  return NULL;
+}
+static __attribute__((unused)) double kas_loop_parallelism_probe(int n_threads, uint64_t iters) {
+  if (n_threads < 1) n_threads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  kas_probe_arg* args = (kas_probe_arg*)malloc(sizeof(kas_probe_arg) * (size_t)n_threads);
+  if (!th || !args) { free(th); free(args); return -1.0; }
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  int started = 0;
+  for (int i = 0; i < n_threads; ++i) {
+    args[i].iters = iters; args[i].sink = 0;
+    if (pthread_create(&th[i], NULL, kas_probe_worker, &args[i]) != 0) break;
+    ++started;
+  }
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  free(th); free(args);
+  if (started != n_threads) return -1.0;
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
 #endif /* KAS_BATCH_LOOP_H */

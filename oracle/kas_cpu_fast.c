@@ -263,5 +263,9 @@ int kas_cpu_fast_solve_batch_mt(const kas_batch_desc* b, const kas_tables* t, in
 KAS_FAST_API
 int kas_cpu_fast_host_threads(void) { return kas_loop_host_threads(); }
 
+/* seconds n_threads threads take for a fixed register-only loop each (kas_batch_loop.h) */
+KAS_FAST_API
+double kas_cpu_fast_parallelism_probe(int n_threads, uint64_t iters) { return kas_loop_parallelism_probe(n_threads, iters); }
+
 KAS_FAST_API
 int kas_cpu_fast_abi_version(void) { return KAS_ABI_VERSION; }

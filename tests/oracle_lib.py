@@ -99,3 +99,28 @@ def cpu_fast_solve(fb: FlatBatch, threads: int = 1, into=None) -> HostOutputs:
     """The same batch by the flat-array CPU baseline (oracle/kas_cpu_fast.c)."""
     L = fast_lib()
     return _solve(L.kas_cpu_fast_solve_batch, L.kas_cpu_fast_solve_batch_mt, fb, threads, "kas_cpu_fast_solve_batch", into)
+
+
+def delivered_parallelism(n_threads: int = 0, iters: int = 200_000_000) -> dict:
+    """What the host really gives this process: the same register-only loop on 1 thread and on n_threads
+    (0 = every hardware thread); cores = t1 * n / tn.  A container with a CPU quota reports all hardware
+    threads of the machine and delivers a fraction of them."""
+    import os
+    L = fast_lib()
+    L.kas_cpu_fast_parallelism_probe.restype = C.c_double
+    L.kas_cpu_fast_parallelism_probe.argtypes = [C.c_int, C.c_uint64]
+    n = n_threads if n_threads > 0 else host_threads()
+    t1 = min(L.kas_cpu_fast_parallelism_probe(1, iters) for _ in range(3))      # (best of three each: noisy neighbours)
+    tn = min(L.kas_cpu_fast_parallelism_probe(n, iters) for _ in range(3))
+    info = {"threads": n, "seconds_1_thread": t1, "seconds_n_threads": tn,
+            "cores_delivered": (t1 * n / tn) if tn > 0 else None}
+    try:
+        info["sched_affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_" + os.path.basename(path)] = open(path).read().strip()
+        except Exception:
+            pass
+    return info
