@@ -2,9 +2,10 @@
 """bench.py — assignment scenarios/sec on MI355X (BASELINE.json metric).
 
 One "step" = one solve of one batch of synthetic cluster scenarios by the HIP path, with every
-bulk table already resident in HBM.  Twelve batches are in flight on twelve streams by default, and
-they are twelve DIFFERENT batches: every slot has its own current-assignment tables, its own
-broker-set draws, its own plan, scratch and outputs (12 x 2.4 GB of tables).  At N=1 the workload is
+bulk table already resident in HBM.  Eight batches are in flight on eight streams by default (round 3:
+6 to 10 measure the same within noise, 12 and more are ~4 % slower — the order kernel's workgroups then
+oversubscribe the CUs), and they are eight DIFFERENT batches: every slot has its own current-assignment
+tables, its own broker-set draws, its own plan, scratch and outputs (8 x 2.4 GB of tables).  At N=1 the workload is
 BASELINE.json configs[2] — the configuration the metric is quoted on: a batch of 1k independent
 scenarios of 100k partitions x 1k brokers x 20 racks, RF 3, each with its own current assignment
 G(seed+s) and its own broker-set perturbation drawn from {remove 1, remove k<=5, add k<=50,
@@ -95,7 +96,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the one-batch-alone, literal-mix, end-to-end and other-config legs")
-    ap.add_argument("--in-flight", type=int, default=12,
+    ap.add_argument("--in-flight", type=int, default=8,
                     help="batches in flight: steps are issued round-robin on this many HIP streams, "
                          "each slot with its own tables, broker sets, plan scratch and outputs")
     ap.add_argument("--same-batch", action="store_true",

@@ -631,6 +631,11 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
     KAS_HIP_TRY(hipGetLastError());
     a.flags |= KAS_FLAG_ONLY_FLAGGED;                              // what is left: scenarios handed back (not rack-diverse, ...)
   }
+#ifdef KAS_TUNE_ORDER_ONLY
+  // tuning builds only (with -DKAS_TUNE_NO_ROW_STORES, which leaves the mid rows in place): the fill kernel
+  // runs in the plan's first solve, every later solve is the order kernel alone — its rate at saturation
+  if (p->last_slot < 0)
+#endif
   hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
@@ -647,7 +652,14 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
                        sizeof(int32_t) * (size_t)(KAS_PERM_BINS + 8), st, a);
     KAS_HIP_TRY(hipGetLastError());
   }
+#ifdef KAS_TUNE_SKIP_ORDER
+  // tuning builds only: the fill kernel alone at saturation (the results are then unfinished rows)
+  if (false) {
+  } else if (true) {
+  } else if (tickets)
+#else
   if (tickets)
+#endif
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
                        lp.order_lds, st, a);
   else if (lp.wide)

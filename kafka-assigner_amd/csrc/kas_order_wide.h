@@ -178,6 +178,13 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   // node's position in that row's list << 8 | lane (joint solve, side dependencies)
   uint32_t* front = wd + 4;                                 // [nmax + 1], if the LDS has room for it
   const bool has_front = kas_order_wide_has_front(a.n_max) != 0;
+  // heat[n] = the last tile in which >= KAS_WIDE_CHAIN_DENSITY rows held node n (staging wave only): a node
+  // first fit is filling stays "hot" for KAS_WIDE_HEAT tiles, and rows holding a hot node go to the chain
+  // solver even when they are the only such row of their tile (rack conflicts send part of a run of
+  // orphans to the next brokers, which then see one row per tile or fewer: sorted by tile density alone
+  // those rows land in a bulk solver's hand and every one of them cuts the chain solver's queue in two)
+  uint16_t* heat = (uint16_t*)((unsigned char*)front + (has_front ? kas_align16(4 * (int64_t)(nmax + 1)) : 0));
+  const bool has_heat = kas_order_wide_has_heat(a.n_max) != 0;
   // padding holder: a ticket that always matches its commits; never picked (pick_row looks at Lp cells)
   const int32_t dummy_e = (KAS_WIDE_DUMMY_TICKET << 16) | (nmax * 8);
 
@@ -207,6 +214,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       for (int32_t r = 0; r < ccols; ++r)
         x |= (uint64_t)(uint32_t)g_ctx[(int64_t)n * sd.ctx_width + r] << (r < 3 ? 10 * r : 32 + 10 * (r - 3));
     cnt[n] = x; dep[n] = 0ull; run[n] = 0; if (has_front) front[n] = 0u;
+    if (has_heat) heat[n] = 0x8000u;                         // (not hot at tile 0)
   }
   for (int32_t k = wave; k < K; k += KAS_WIDE_WAVES) ring[k * 64 + lane].tag = KAS_TAG_FREE;
   for (int32_t k = wave; k < KAS_WIDE_HOT * (1 + NB); k += KAS_WIDE_WAVES) rank_owner_all[k * 64 + lane] = 0u;
@@ -790,14 +798,19 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       kasw::lockstep();
       uint32_t tk[W];
       bool dense = false;                                   // a node of mine that many rows of this tile hold
+      uint32_t ht[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) ht[q] = has_heat ? (uint32_t)heat[hn[q]] : 0x8000u;
 #pragma unroll
       for (int q = 0; q < W; ++q) {
-        dense = dense || (q < Lp && kasw::popc(m[q]) >= KAS_WIDE_CHAIN_DENSITY);
+        const bool dq = q < Lp && kasw::popc(m[q]) >= KAS_WIDE_CHAIN_DENSITY;
+        dense = dense || dq || (q < Lp && has_heat && ((uint32_t)(jl - (int32_t)ht[q]) & 0xffffu) <= (uint32_t)KAS_WIDE_HEAT);
         tk[q] = base[q] + (uint32_t)kasw::count_below(m[q]);
         // the lowest lane holding the node moves its running count on and clears the mask
         const uint32_t wn = (m[q] & lt) == 0ull ? hn[q] : pad;
         run[wn] = (uint16_t)(base[q] + (uint32_t)kasw::popc(m[q]));
         dep[wn] = 0ull;
+        if (has_heat && dq) heat[wn] = (uint16_t)jl;
       }
       kasw::lockstep();                                     // the next tile's masks start from zero
       if (staging) {

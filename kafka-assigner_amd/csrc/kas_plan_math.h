@@ -102,17 +102,24 @@ KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_
 // int32 counter row stride of the round form: 3-wide rows are padded to one 16-byte LDS read
 KAS_ABI_FN int32_t kas_cnt_stride(int32_t W) { return W == 3 ? 4 : W; }
 
-// dwords per node of the fused histogram layout: NW x W uint16 per-chunk counts, later NW int32 quotas
+// Fused histogram layout of the fill kernel (with_x = 2): ONE block of kas_fused_block_words() dwords per
+// node holds everything the kernel keeps per node:
+//   pass A      words 0 .. ceil(NW W / 2) - 1: uint16 hist[NW][W], candidates per chunk and sweep
+//   after Q     words 0 .. NW - 1: int32 quota left when chunk w starts; word NW: load; word NW + 1: qrs
+//   always      low half of the last word: the node's rack index (int16)
+// The block length is odd, so the words of consecutive nodes fall on different LDS banks (a stride of 6
+// dwords reaches only every other bank: twice the conflicts on every node-indexed access).
 KAS_ABI_FN int32_t kas_fused_block_words(int32_t W, int32_t NW) {
   const int32_t h = (NW * W + 1) / 2;
-  return h > NW ? h : NW;
+  const int32_t b = (h > NW + 2 ? h : NW + 2) + 1;
+  return b | 1;
 }
 
 // with_x = 0: no histogram / quota table (only the general sticky fill is possible then)
 //          1: hist[W][n] int32, then qc[NW][n] int32 over the same words (two passes over cur + a
-//             chunk-count pass)
-//          2: fused — node-major blocks of kas_fused_block_words() dwords: uint16 hist[n][NW][W]
-//             counted per chunk in the first pass, then int32 qc[n][NW] (no chunk-count pass)
+//             chunk-count pass); load[], qrs[], rack[] are arrays of their own
+//          2: fused — node-major blocks (above): uint16 hist[n][NW][W] counted per chunk in the first
+//             pass, then int32 qc[n][NW] (no chunk-count pass), load, qrs and rack inside the block
 KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int32_t idmap_entries,
                                          int32_t need_bsearch, int32_t with_x) {
   KasLds L;
@@ -120,13 +127,21 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
   int64_t o = 0;
   const int64_t xr = with_x == 2 ? kas_fused_block_words(W, NW) : (with_x ? (W > NW ? W : NW) : 0);
   L.off_x = (int32_t)o;     o = kas_align16(o + 4 * n * xr);
-  // lists wider than the workgroup has waves leave histogram rows NW..W-1 unused once the quota
-  // pass has consumed them: load[] (written by that pass, per node, after its reads) lives there
-  if (with_x == 1 && W > NW) L.off_load = L.off_x + (int32_t)(4 * n * NW);
-  else { L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n); }
-  L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
-  L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
-  L.off_live = L.off_qrs;                      // P4's list of non-full nodes: qrs is dead after pass B
+  if (with_x == 2) {
+    // node state inside the blocks; P4's list of non-full nodes gets an array of its own
+    L.off_load = L.off_x + 4 * NW;
+    L.off_qrs = L.off_x + 4 * (NW + 1);
+    L.off_rack = L.off_x + 4 * (int32_t)(xr - 1);
+    L.off_live = (int32_t)o;  o = kas_align16(o + 2 * n);
+  } else {
+    // lists wider than the workgroup has waves leave histogram rows NW..W-1 unused once the quota
+    // pass has consumed them: load[] (written by that pass, per node, after its reads) lives there
+    if (with_x == 1 && W > NW) L.off_load = L.off_x + (int32_t)(4 * n * NW);
+    else { L.off_load = (int32_t)o;  o = kas_align16(o + 4 * n); }
+    L.off_qrs = (int32_t)o;   o = kas_align16(o + 4 * n);
+    L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
+    L.off_live = L.off_qrs;                      // P4's list of non-full nodes: qrs is dead after pass B
+  }
   L.off_idmap = (int32_t)o; o = kas_align16(o + 2 * (int64_t)(idmap_entries > 0 ? idmap_entries : 1));
   L.off_ids = (int32_t)o;   if (need_bsearch) o = kas_align16(o + 4 * n);
   L.off_ring = (int32_t)o;  o = kas_align16(o + KAS_RING_CAP * (4 + 4 + 2 * (int64_t)W));
@@ -179,9 +194,20 @@ KAS_ABI_FN int32_t kas_order_wide_has_front(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
   return (int64_t)kas_order_wide_lds_core(n_max) + kas_align16(4 * (n + 1)) <= KAS_LDS_LIMIT ? 1 : 0;
 }
+// heat[] of the staging wave (class by node heat, KAS_WIDE_HEAT): uint16 per node, kept only while there is room
+#ifndef KAS_WIDE_HEAT
+#define KAS_WIDE_HEAT 4
+#endif
+KAS_ABI_FN int32_t kas_order_wide_has_heat(int32_t n_max) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  if (KAS_WIDE_HEAT <= 0) return 0;
+  return (int64_t)kas_order_wide_lds_core(n_max) + (kas_order_wide_has_front(n_max) ? kas_align16(4 * (n + 1)) : 0) +
+         kas_align16(2 * (n + 1)) <= KAS_LDS_LIMIT ? 1 : 0;
+}
 KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
-  return kas_order_wide_lds_core(n_max) + (kas_order_wide_has_front(n_max) ? kas_align16(4 * (n + 1)) : 0);
+  return kas_order_wide_lds_core(n_max) + (kas_order_wide_has_front(n_max) ? kas_align16(4 * (n + 1)) : 0) +
+         (kas_order_wide_has_heat(n_max) ? kas_align16(2 * (n + 1)) : 0);
 }
 #define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]

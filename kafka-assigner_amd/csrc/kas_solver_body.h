@@ -117,9 +117,10 @@ struct RowWords { uint32_t v[D]; };
 // LDS of the fill kernel (kas_fill_lds_layout)
 struct LdsView {
   int32_t* x;           // hist[W][N], then qc[NW][N]
-  int32_t* load;
-  int32_t* qrs;
-  int16_t* rack;
+  int32_t* load;        // node state: words of node n at load[n * ns], qrs[n * ns], rack[n * rs] (lds_load / lds_qrs /
+  int32_t* qrs;         // lds_rack).  Dense arrays (ns = rs = 1), or — fused histogram layout — words of the node's
+  int16_t* rack;        // own block in x (ns = block words, rs = 2 ns): see kas_fill_lds_layout
+  int32_t ns, rs;
   int16_t* live;
   int16_t* idmap;
   int32_t* ids;
@@ -128,6 +129,10 @@ struct LdsView {
   int16_t* ring_rack;   // [W][KAS_RING_CAP]
   int32_t* ctl;
 };
+
+KAS_DEV int32_t& lds_load(const LdsView& L, int32_t n) { return L.load[kasw::mul24(n, L.ns)]; }
+KAS_DEV int32_t& lds_qrs(const LdsView& L, int32_t n) { return L.qrs[kasw::mul24(n, L.ns)]; }
+KAS_DEV int16_t& lds_rack(const LdsView& L, int32_t n) { return L.rack[kasw::mul24(n, L.rs)]; }
 
 struct NodeMap {
   int32_t n;            // N
@@ -257,7 +262,7 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
 #pragma unroll
     for (int u = 0; u < U; ++u) n[u] = (int32_t)L.live[j + u < live_count ? j + u : j];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { slots[u] = cap - L.load[n[u]]; rk[u] = (int32_t)L.rack[n[u]]; }
+    for (int u = 0; u < U; ++u) { slots[u] = cap - lds_load(L, n[u]); rk[u] = (int32_t)lds_rack(L, n[u]); }
     int32_t taken[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -286,13 +291,13 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
     }
     if (lane == 0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) if (taken[u] > 0) L.load[n[u]] += taken[u];
+      for (int u = 0; u < U; ++u) if (taken[u] > 0) lds_load(L, n[u]) += taken[u];
     }
     kasw::lockstep();
     j += U;
   }
   // drop the leading nodes that are now full from future windows
-  while (head < live_count && L.load[(int32_t)L.live[head]] >= cap) ++head;
+  while (head < live_count && lds_load(L, (int32_t)L.live[head]) >= cap) ++head;
   return fail_lane;
 }
 
@@ -475,7 +480,7 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
   for (int r = 0; r < W; ++r) {
     const bool acc = (accbits >> r) & 1u;
     const int32_t n = idx[r] >= 0 ? idx[r] : 0;
-    const int32_t rk = racks ? racks[r] : (int32_t)L.rack[n];   // the caller may have looked it up already
+    const int32_t rk = racks ? racks[r] : (int32_t)lds_rack(L, n);   // the caller may have looked it up already
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       const bool here = acc && hc == k;
@@ -582,23 +587,23 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
       int32_t n = -1;
       if (r < len) n = node_lookup(L, nm, row[r]);         // node != null (KAS:119-120)
       bool elig = n >= 0;
-      const int32_t rk = elig ? (int32_t)L.rack[n] : -1;
+      const int32_t rk = elig ? (int32_t)lds_rack(L, n) : -1;
 #pragma unroll
       for (int r2 = 0; r2 < W - 1; ++r2) {
         if (r2 < r) {                                       // wave-uniform
           const uint64_t aw = kasw::load_shared_u64(accmask + (int64_t)r2 * nt + tile);
           if (elig && ((aw >> lane) & 1ull)) {
             const int32_t n2 = node_lookup(L, nm, row[r2]);
-            if ((int32_t)L.rack[n2] == rk) elig = false;    // rack.canAccept (KAS:346-348)
+            if ((int32_t)lds_rack(L, n2) == rk) elig = false;    // rack.canAccept (KAS:346-348)
           }
         }
       }
-      const bool took = elig && L.load[n] < cap;            // size() < capacity (KAS:322)
+      const bool took = elig && lds_load(L, n) < cap;            // size() < capacity (KAS:322)
       kasw::lockstep();                                     // every lane saw the pre-tile load
-      if (took) kasw::lds_atomic_add(&L.load[n], 1);
+      if (took) kasw::lds_atomic_add(&lds_load(L, n), 1);
       kasw::lockstep();
       bool accepted = took;
-      uint64_t todo = kasw::ballot(took && L.load[n] > cap);
+      uint64_t todo = kasw::ballot(took && lds_load(L, n) > cap);
       if (todo != 0) {
         KAS_COUNT(st[7]);
         // some node overflowed inside this tile: keep its first (cap - load_before) lanes
@@ -607,10 +612,10 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
           const int32_t t = kasw::shfl(n, leader);
           const bool same_l = took && n == t;
           const uint64_t same = kasw::ballot(same_l);
-          const int32_t before = L.load[t] - kasw::popc(same);
+          const int32_t before = lds_load(L, t) - kasw::popc(same);
           if (same_l) accepted = before + kasw::count_below(same) < cap;
           kasw::lockstep();                                 // all lanes read load[t]
-          if (lane == leader) L.load[t] = cap;
+          if (lane == leader) lds_load(L, t) = cap;
           todo &= ~same;
         }
         kasw::lockstep();
@@ -674,7 +679,7 @@ KAS_DEV bool fill_pass_a_range(const LdsView& L, const TopicView& T, const NodeM
     for (int d = 0; d < D; ++d)
 #pragma unroll
       for (int r = 0; r < W; ++r)
-        rk[d][r] = idx[d][r] >= 0 ? (int32_t)L.rack[idx[d][r]] : -1 - r;   // invalid: never equal
+        rk[d][r] = idx[d][r] >= 0 ? (int32_t)lds_rack(L, idx[d][r]) : -1 - r;   // invalid: never equal
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -693,7 +698,9 @@ KAS_DEV bool fill_pass_a(const LdsView& L, const TopicView& T, const NodeMap& nm
 }
 
 template <int W, int NW>
-constexpr int fused_block_words() { return ((NW * W + 1) / 2) > NW ? ((NW * W + 1) / 2) : NW; }   // == kas_fused_block_words
+constexpr int fused_block_words() {                                     // == kas_fused_block_words
+  return ((((NW * W + 1) / 2) > NW + 2 ? ((NW * W + 1) / 2) : NW + 2) + 1) | 1;
+}
 
 // A1, fused form: wave w scans chunk w (the rows pass B will walk) and counts per chunk: x is node-major,
 // kas_fused_block_words() dwords per node holding uint16 hist[n][w][r] (a chunk has < 65536 rows: the
@@ -715,7 +722,7 @@ KAS_DEV bool fill_pass_a_fused(const LdsView& L, const TopicView& T, const NodeM
     for (int d = 0; d < D; ++d)
 #pragma unroll
       for (int r = 0; r < W; ++r)
-        rk[d][r] = idx[d][r] >= 0 ? (int32_t)L.rack[idx[d][r]] : -1 - r;   // invalid: never equal
+        rk[d][r] = idx[d][r] >= 0 ? (int32_t)lds_rack(L, idx[d][r]) : -1 - r;   // invalid: never equal
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -739,10 +746,11 @@ template <int W, int NW>
 KAS_DEV void fill_quota_fused(const LdsView& L, const TopicView& T, int32_t tid) {
   const int32_t N = T.N;
   constexpr int BW = fused_block_words<W, NW>();
+  constexpr int HW = (NW * W + 1) / 2;                       // words that hold the uint16 counts
   for (int32_t n = tid; n < N; n += 64 * NW) {
-    uint32_t words[BW];
+    uint32_t words[HW];
 #pragma unroll
-    for (int k = 0; k < BW; ++k) words[k] = (uint32_t)L.x[n * BW + k];
+    for (int k = 0; k < HW; ++k) words[k] = (uint32_t)L.x[n * BW + k];
     int32_t h[NW][W], tot[W];
 #pragma unroll
     for (int r = 0; r < W; ++r) tot[r] = 0;
@@ -763,8 +771,8 @@ KAS_DEV void fill_quota_fused(const LdsView& L, const TopicView& T, int32_t tid)
       cum = rs == W ? (sat ? T.cap : cum + c) : cum;
       rs = sat ? r : rs;
     }
-    L.load[n] = cum;
-    L.qrs[n] = (int32_t)(((uint32_t)rs << 28) | (uint32_t)q);
+    lds_load(L, n) = cum;
+    lds_qrs(L, n) = (int32_t)(((uint32_t)rs << 28) | (uint32_t)q);
     int32_t rem = q;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -793,8 +801,8 @@ KAS_DEV void fill_quota(const LdsView& L, const TopicView& T, int32_t tid) {
       cum = rs == W ? (sat ? T.cap : cum + c) : cum;
       rs = sat ? r : rs;
     }
-    L.load[n] = cum;
-    L.qrs[n] = (int32_t)(((uint32_t)rs << 28) | (uint32_t)q);
+    lds_load(L, n) = cum;
+    lds_qrs(L, n) = (int32_t)(((uint32_t)rs << 28) | (uint32_t)q);
 #pragma unroll
     for (int w = 0; w < NW; ++w) L.x[w * N + n] = NW == 1 ? q : 0;
   }
@@ -817,7 +825,7 @@ KAS_DEV void fill_chunk_count(const LdsView& L, const TopicView& T, const NodeMa
     for (int d = 0; d < D; ++d)
 #pragma unroll
       for (int r = 0; r < W; ++r)
-        rs[d][r] = idx[d][r] >= 0 ? (int32_t)((uint32_t)L.qrs[idx[d][r]] >> 28) : -1;
+        rs[d][r] = idx[d][r] >= 0 ? (int32_t)((uint32_t)lds_qrs(L, idx[d][r]) >> 28) : -1;
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -830,7 +838,7 @@ template <int NW>
 KAS_DEV void fill_chunk_prefix(const LdsView& L, const TopicView& T, int32_t tid) {
   const int32_t N = T.N;
   for (int32_t n = tid; n < N; n += 64 * NW) {
-    int32_t rem = L.qrs[n] & 0x0fffffff;
+    int32_t rem = lds_qrs(L, n) & 0x0fffffff;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const int32_t c = L.x[w * N + n];
@@ -856,7 +864,7 @@ KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const No
     for (int r = 0; r < W; ++r) {
       idx[r] = r < len ? node_lookup_as<DIRECT>(L, nm, ids[r]) : -1;
       nn[r] = idx[r] >= 0 ? idx[r] : 0;
-      const int32_t rs = (int32_t)((uint32_t)L.qrs[nn[r]] >> 28);
+      const int32_t rs = (int32_t)((uint32_t)lds_qrs(L, nn[r]) >> 28);
       sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
       counting |= (idx[r] >= 0 && r == rs) ? (1u << r) : 0u;
       before[r] = qc[nn[r] * QS];                           // quota left before this tile
@@ -990,7 +998,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     int32_t hc = 0, hr[W];                                  // holders are a prefix of the row
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      hr[k] = (p >= 0 && c_cur[k] >= 0) ? (int32_t)L.rack[c_cur[k]] : -1;
+      hr[k] = (p >= 0 && c_cur[k] >= 0) ? (int32_t)lds_rack(L, c_cur[k]) : -1;
       hc += (p >= 0 && c_cur[k] >= 0) ? 1 : 0;
     }
     int32_t need = p >= 0 ? T.rf - hc : 0;
@@ -1030,7 +1038,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
 #pragma unroll
       for (int u = 0; u < U; ++u) n[u] = (int32_t)L.live[j + u < live_count ? j + u : j];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { slots[u] = cap - L.load[n[u]]; rk[u] = (int32_t)L.rack[n[u]]; }
+      for (int u = 0; u < U; ++u) { slots[u] = cap - lds_load(L, n[u]); rk[u] = (int32_t)lds_rack(L, n[u]); }
       int32_t taken[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1060,7 +1068,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
       if (lane == 0) {
 #pragma unroll
         // (only this wave touches these nodes now: the new load follows from the slots read above, no re-read)
-        for (int u = 0; u < U; ++u) if (taken[u] > 0) L.load[n[u]] = cap - slots[u] + taken[u];
+        for (int u = 0; u < U; ++u) if (taken[u] > 0) lds_load(L, n[u]) = cap - slots[u] + taken[u];
       }
       kasw::lockstep();
       j += U;
@@ -1079,7 +1087,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     // done: full nodes at the front of the live list need not be looked at again
     if (lane == 0) {
       int32_t head = L.ctl[KAS_CTL_HEAD];
-      while (head < live_count && L.load[(int32_t)L.live[head]] >= cap) ++head;
+      while (head < live_count && lds_load(L, (int32_t)L.live[head]) >= cap) ++head;
       kasw::lds_atomic_max(&L.ctl[KAS_CTL_HEAD], head);
       prog[wave] = (uint64_t)(uint32_t)(w + 1) << 32;
     }
@@ -1185,9 +1193,27 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   const int32_t cap = T.cap;
 
   // ---- per-topic node state (KAS:46, 73-99): region A of the LDS carve-up -------------------
-  for (int32_t i = tid; i < N; i += NT) {
-    L.load[i] = 0;
-    L.rack[i] = (int16_t)g_node_rack[i];
+  // rack-diverse form of the sticky fill unless switched off or the quota word cannot hold cap
+  // (a topic without rows takes the general form: the row stream of the fast form re-reads the last
+  // row for lanes past the end and there is no row to read)
+  const bool try_fast = P > 0 && T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && cap >= 0 && cap < (1 << 28);
+  // per-chunk histograms (no chunk-count pass) when the launcher says the layout fits (lists <= 3 wide)
+  const bool fused = W <= 3 && NW > 1 && (a.flags & KAS_FLAG_FUSED_HIST) != 0u;
+  if (fused) {
+    // the node's block: counts (and, in the same words later, quotas, load, qrs) zero, then its rack
+    constexpr int BW = fused_block_words<(W <= 3 ? W : 3), (NW > 1 ? NW : 2)>();
+    for (int32_t i = tid; i < N; i += NT) {
+#pragma unroll
+      for (int k = 0; k < BW - 1; ++k) L.x[i * BW + k] = 0;
+      lds_rack(L, i) = (int16_t)g_node_rack[i];
+    }
+  } else {
+    for (int32_t i = tid; i < N; i += NT) {
+      lds_load(L, i) = 0;
+      lds_rack(L, i) = (int16_t)g_node_rack[i];
+    }
+    if (try_fast)
+      for (int32_t i = tid; i < N * W; i += NT) L.x[i] = 0;
   }
   if (nm.range != 0u) {
     for (uint32_t i = (uint32_t)tid; i < nm.range; i += (uint32_t)NT) L.idmap[i] = (int16_t)-1;
@@ -1195,14 +1221,6 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     for (int32_t i = tid; i < N; i += NT) L.ids[i] = g_node_id[i];
   }
   if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : (tid == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
-  // rack-diverse form of the sticky fill unless switched off or the quota word cannot hold cap
-  // (a topic without rows takes the general form: the row stream of the fast form re-reads the last
-  // row for lanes past the end and there is no row to read)
-  const bool try_fast = P > 0 && T.cw > 0 && !(a.flags & KAS_FLAG_GENERIC_FILL) && cap >= 0 && cap < (1 << 28);
-  // per-chunk histograms (no chunk-count pass) when the launcher says the layout fits (lists <= 3 wide)
-  const bool fused = W <= 3 && NW > 1 && (a.flags & KAS_FLAG_FUSED_HIST) != 0u;
-  if (try_fast)
-    for (int32_t i = tid; i < N * (fused ? fused_block_words<W, NW>() : W); i += NT) L.x[i] = 0;
   kasw::sync();
   if (nm.range != 0u)
     for (int32_t i = tid; i < N; i += NT) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
@@ -1224,7 +1242,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     fast = L.ctl[KAS_CTL_VIOL] == 0;
     if (!fast) {
       // the general fill starts from load == 0; for wide lists load[] shares LDS with a histogram row
-      for (int32_t i = tid; i < N; i += NT) L.load[i] = 0;
+      for (int32_t i = tid; i < N; i += NT) lds_load(L, i) = 0;
       kasw::sync();
     }
   }
@@ -1274,7 +1292,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
     for (int32_t base = 0; base < N; base += 64) {
       const int32_t j = base + lane;
       int32_t n = j + start; if (n >= N) n -= N;
-      const bool is_live = j < N && L.load[n] < cap;
+      const bool is_live = j < N && lds_load(L, n) < cap;
       const uint64_t m = kasw::ballot(is_live);
       if (is_live) L.live[live_count + kasw::count_below(m)] = (int16_t)n;
       live_count += kasw::popc(m);
@@ -1339,6 +1357,9 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
   L.qrs = (int32_t*)(lds_raw + lay.off_qrs);
   L.rack = (int16_t*)(lds_raw + lay.off_rack);
   L.live = (int16_t*)(lds_raw + lay.off_live);
+  // fused layout: load, qrs and rack are words of the node's own block (kas_fill_lds_layout)
+  L.ns = (W <= 3 && NW > 1 && (a.flags & KAS_FLAG_FUSED_HIST) && !(a.flags & KAS_FLAG_GENERIC_FILL)) ? kas_fused_block_words(W, NW) : 1;
+  L.rs = L.ns > 1 ? 2 * L.ns : 1;
   L.idmap = (int16_t*)(lds_raw + lay.off_idmap);
   L.ids = (int32_t*)(lds_raw + lay.off_ids);
   L.ring_p = (int32_t*)(lds_raw + lay.off_ring);
@@ -1486,6 +1507,7 @@ KAS_DEV LdsView spread_lds(const KasLaunch& a, unsigned char* lds_raw, int W, in
   L.qrs = (int32_t*)(lds_raw + lay.off_qrs);
   L.rack = (int16_t*)(lds_raw + lay.off_rack);
   L.live = (int16_t*)(lds_raw + lay.off_live);
+  L.ns = 1; L.rs = 1;
   L.idmap = (int16_t*)(lds_raw + lay.off_idmap);
   L.ids = (int32_t*)(lds_raw + lay.off_ids);
   L.ring_p = (int32_t*)(lds_raw + lay.off_ring);
@@ -1501,7 +1523,7 @@ KAS_DEV void spread_node_tables(const KasLaunch& a, int32_t s, const LdsView& L,
   const kas_scenario_desc sd = a.scen[s];
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int32_t* g_node_rack = a.node_rack + sd.node_off;
-  for (int32_t i = tid; i < nm.n; i += nt_threads) L.rack[i] = (int16_t)g_node_rack[i];
+  for (int32_t i = tid; i < nm.n; i += nt_threads) lds_rack(L, i) = (int16_t)g_node_rack[i];
   for (uint32_t i = (uint32_t)tid; i < nm.range; i += (uint32_t)nt_threads) L.idmap[i] = (int16_t)-1;
   kasw::sync();
   for (int32_t i = tid; i < nm.n; i += nt_threads) L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] = (int16_t)i;
@@ -1593,7 +1615,7 @@ KAS_DEV void spread_pass_b(const KasLaunch& a, int32_t s, int32_t c, unsigned ch
   const int32_t N = T.N;
   spread_node_tables(a, s, L, S.nm, 64);
   for (int32_t n = lane; n < N; n += 64) {
-    L.qrs[n] = a.sp_node[((int64_t)s * 2 + 1) * a.n_max + n];
+    lds_qrs(L, n) = a.sp_node[((int64_t)s * 2 + 1) * a.n_max + n];
     L.x[n] = a.sp_quota[((int64_t)s * CH + c) * a.n_max + n];
   }
   kasw::sync();
@@ -1625,8 +1647,8 @@ KAS_DEV void spread_p4(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   const int32_t N = T.N, cap = T.cap;
   const int64_t t_begin = kasw::clock_ticks();
   for (int32_t i = tid; i < N; i += NT) {
-    L.load[i] = a.sp_node[((int64_t)s * 2 + 0) * a.n_max + i];
-    L.rack[i] = (int16_t)a.node_rack[a.scen[s].node_off + i];
+    lds_load(L, i) = a.sp_node[((int64_t)s * 2 + 0) * a.n_max + i];
+    lds_rack(L, i) = (int16_t)a.node_rack[a.scen[s].node_off + i];
   }
   if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : (tid == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
   kasw::sync();
@@ -1656,7 +1678,7 @@ KAS_DEV void spread_p4(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
     for (int32_t base = 0; base < N; base += 64) {
       const int32_t j = base + lane;
       int32_t n = j + start; if (n >= N) n -= N;
-      const bool is_live = j < N && L.load[n] < cap;
+      const bool is_live = j < N && lds_load(L, n) < cap;
       const uint64_t m = kasw::ballot(is_live);
       if (is_live) L.live[live_count + kasw::count_below(m)] = (int16_t)n;
       live_count += kasw::popc(m);
@@ -2217,15 +2239,17 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         const uint64_t nbg = (kasw::ballot(need) >> (g * GL)) & GLM;
         const int32_t v = gnext + kasw::popc(nbg & ((1ull << li) - 1ull));
         const int32_t tile = v / GL, slot = (tile & (K - 1)) * 64 + g * GL + (v % GL);
+        // (the slot is used through selects, not behind a branch on its tag: the compiler then keeps the
+        // ONE 16-byte LDS read — behind a branch it read the tag, tested it and fetched the row in a second,
+        // dependent round trip in every step of the chain.  The staging wave writes a slot with one 16-byte
+        // store, so a tag that says "staged" never comes with an older row.)
         const RingSlot sl = ring[need ? slot : my_slot];
         const bool taken = need && sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (tile & KAS_TAG_JMASK);
         const bool saw_end = need && sl.tag == KAS_TAG_END;
-        if (taken) {
-          e0 = sl.c[0]; e1 = sl.c[1]; e2 = sl.c[2];
-          meta = sl.tag >> 26;
-          my_slot = slot;
-          cv = true;
-        }
+        e0 = taken ? sl.c[0] : e0; e1 = taken ? sl.c[1] : e1; e2 = taken ? sl.c[2] : e2;
+        meta = taken ? sl.tag >> 26 : meta;
+        my_slot = taken ? slot : my_slot;
+        cv = cv || taken;
         gnext += kasw::popc((kasw::ballot(taken) >> (g * GL)) & GLM);
         const uint64_t endb = kasw::ballot(saw_end);         // (a collective: not behind a short-circuit)
         gfin = gfin || ((endb >> (g * GL)) & GLM) != 0ull;
@@ -2267,6 +2291,9 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     const uint32_t pad = (uint32_t)nmax;
     const int32_t dummy_tk = PK ? 3 * 0x3ff : 0;
     TileIter itl = tile_iter_begin(have_s);
+#ifdef KAS_STAGER_PRIO
+    kasw::set_priority<KAS_STAGER_PRIO>();                  // tuning builds: the staging wave above the retiring one
+#endif
     int32_t jl = 0;                                         // tiles staged (group-uniform)
     bool endl = false;
     bool pf_valid = false, pf_end = false;
@@ -2410,17 +2437,22 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         for (int q = 0; q < W; ++q) if (q < (r.kw >> 27)) r.row[q] = q < r.Lp ? r.id[q] : -1;
 #else
 #pragma unroll
-        for (int q = 0; q < W; ++q) {
-          if (q < r.Lp) {
-            r.row[q] = r.id[q];
-            digest += kas_digest_cell((uint32_t)r.kw & 0x7ffffffu, (uint32_t)r.p, (uint32_t)q, r.id[q]);
-          }
-        }
-        // -1 behind a list shorter than the row (rare: the mid row this came from lives elsewhere)
-        if (r.Lp < (r.kw >> 27)) {
+        for (int q = 0; q < W; ++q)
+          if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.kw & 0x7ffffffu, (uint32_t)r.p, (uint32_t)q, r.id[q]);
+#ifndef KAS_TUNE_NO_ROW_STORES
+        if (r.Lp == W && (r.kw >> 27) == W) {                 // the usual row: full width, one W-dword store
+          RowW<W> o;
+#pragma unroll
+          for (int q = 0; q < W; ++q) o.v[q] = r.id[q];
+          *reinterpret_cast<RowW<W>*>(r.row) = o;
+        } else {
+#pragma unroll
+          for (int q = 0; q < W; ++q) if (q < r.Lp) r.row[q] = r.id[q];
+          // -1 behind a list shorter than the row (rare: the mid row this came from lives elsewhere)
 #pragma unroll
           for (int q = 0; q < W; ++q) if (q >= r.Lp && q < (r.kw >> 27)) r.row[q] = -1;
         }
+#endif
 #endif
       }
       r.on = false;

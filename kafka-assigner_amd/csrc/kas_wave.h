@@ -87,6 +87,9 @@ KAS_DEV int32_t opaque(int32_t v) {
   return v;
 }
 
+// a * b for small non-negative factors (node index x block stride): the full-rate 24-bit multiply
+KAS_DEV int32_t mul24(int32_t a, int32_t b) { return (int32_t)__umul24((unsigned)a, (unsigned)b); }
+
 KAS_DEV int popc(uint64_t m) { return __popcll((unsigned long long)m); }
 
 // index of the lowest set bit; m must be non-zero

@@ -80,7 +80,7 @@ for step in "$@"; do
       grep -v '^{' $O/bench_v_$lib.log | tail -2 | cut -c1-200 ;;
     c5:*)
       lib=${step#c5:}
-      if [ "$lib" == "-" ]; then c5 bench_c5_product --actions c5; else KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5_v_$lib --actions c5; fi ;;
+      if [ "$lib" == "-" ]; then c5 bench_c5_product --actions c5; else KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5_v_$lib --actions c5 --stats $O/stats_c5_$lib.json; fi ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -32,10 +32,10 @@ from oracle_lib import oracle_solve  # noqa: E402
 # in the plan's description, bench.py flags).  The first is the headline shape (BASELINE.json configs[2]).
 SUITE = [
     ("headline: fill<3,4> per-chunk histograms + packed ticket form, 2 scenarios per wavefront",
-     "kas_order_ticket_kernel<3,2,true>", []),
-    ("one scenario per solver wavefront (G = 1)", "kas_order_ticket_kernel<3,1,true>", ["--groups", "1"]),
-    ("4 x uint16 counter rows", "kas_order_ticket_kernel<3,2,false>", ["--plan-flags", "4"]),
-    ("histogram for the whole topic + chunk-count pass", "kas_fill_kernel<3,4>[quota]", ["--plan-flags", "8"]),
+     "kas_order_ticket_kernel<3,2,true>", ["--in-flight", "12"]),
+    ("one scenario per solver wavefront (G = 1)", "kas_order_ticket_kernel<3,1,true>", ["--groups", "1", "--in-flight", "12"]),
+    ("4 x uint16 counter rows", "kas_order_ticket_kernel<3,2,false>", ["--plan-flags", "4", "--in-flight", "12"]),
+    ("histogram for the whole topic + chunk-count pass", "kas_fill_kernel<3,4>[quota]", ["--plan-flags", "8", "--in-flight", "12"]),
     ("lists 5 wide: wide ticket form (five wavefronts, class lists, joint solve)", "kas_order_wide_kernel<5>",
      ["--scenarios", "96", "--partitions", "40000", "--brokers", "600", "--racks", "40", "--rf", "5",
       "--actions", "add_k,mixed", "--in-flight", "6"]),

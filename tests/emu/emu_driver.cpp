@@ -473,6 +473,7 @@ int kas_emu_p4_unit(int32_t n_nodes, const int32_t* load, const int32_t* rack, i
   r.L.qrs = (int32_t*)(lds.data() + lay.off_qrs);
   r.L.rack = (int16_t*)(lds.data() + lay.off_rack);
   r.L.live = (int16_t*)(lds.data() + lay.off_live);
+  r.L.ns = 1; r.L.rs = 1;
   r.L.idmap = (int16_t*)(lds.data() + lay.off_idmap);
   r.L.ids = (int32_t*)(lds.data() + lay.off_ids);
   r.L.ring_p = (int32_t*)(lds.data() + lay.off_ring);

@@ -86,6 +86,7 @@ KAS_DEV void repoll() { rendezvous(K_LOCKSTEP); }   // lets the other waves run
 
 KAS_DEV int32_t opaque(int32_t v) { return v; }
 
+KAS_DEV int32_t mul24(int32_t a, int32_t b) { return a * b; }
 KAS_DEV int popc(uint64_t m) { return __builtin_popcountll(m); }
 KAS_DEV int first_lane(uint64_t m) { return __builtin_ctzll(m); }
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
