@@ -46,5 +46,29 @@ j = {"scenarios": 1000, "partitions": 100000,
      "fetch_kb": {"fill": res[("FETCH_SIZE", "fill")], "order": res[("FETCH_SIZE", "order")]},
      "write_kb": {"fill": res[("WRITE_SIZE", "fill")], "order": res[("WRITE_SIZE", "order")]},
      "read_correction_measured": corr}
+# which kernels and sources the numbers belong to: bench.py quotes them only for the same ones
+for log in (os.path.join(d, "prof_fetch.log"), os.path.join(d, "prof_write.log")):
+    try:
+        line = json.loads([ln for ln in open(log) if ln.startswith("{")][-1])
+        j["kernel"] = line["roofline"]["kernel"]
+        j["kernel_sources_sha16"] = line["roofline"]["kernel_sources_sha16"]
+        break
+    except Exception:
+        pass
 json.dump(j, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(j, indent=1))
+
+# SQ counter passes (gpu_trip.sh sq): average per dispatch, per kernel, per mode (batches in flight)
+sq = collections.defaultdict(list)
+for mode_dir in glob.glob(os.path.join(d, "prof_sq*_f*")):
+    mode = mode_dir.rsplit("_f", 1)[1]
+    for f in glob.glob(os.path.join(mode_dir, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "kas_" in r["Kernel_Name"]:
+                sq[(mode, r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+if sq:
+    with open(f"profiles/{tag}_pmc_sq_counters.csv", "w") as out:
+        out.write("batches_in_flight,kernel,dispatches,counter,avg_value_per_dispatch\n")
+        for (mode, k, c), v in sorted(sq.items(), key=lambda kv: (int(kv[0][0]), kv[0][1], kv[0][2])):
+            out.write(f'{mode},"{k}",{len(v)},{c},{sum(v) / len(v):.1f}\n')
+    print(f"profiles/{tag}_pmc_sq_counters.csv written")

@@ -10,7 +10,7 @@
 #   stress     scripts/stress_inflight.py --suite 1000
 #   trace      rocprofv3 --kernel-trace --stats: one batch alone, default, configs[4]
 #   pmc        rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one batch in flight)
-#   sq         rocprofv3 --pmc SQ_* passes, one batch alone and twelve in flight
+#   sq         rocprofv3 --pmc SQ_* passes, one batch alone and eight in flight
 #   ab:LIB     benchq with KAS_HIP_LIB=variants/libkas_hip_LIB.so (tuning builds, scripts/build_variant.sh)
 #   c5:LIB     configs[4] x1 with that tuning build (LIB = - for the product library)
 set -u
@@ -68,7 +68,7 @@ for step in "$@"; do
       cd $R ;;
     sq)
       cd /tmp
-      for mode in 1 12; do
+      for mode in 1 8; do
         timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $R/$O/prof_sq1_f$mode -o sq1 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq1_f$mode.log 2>&1; echo "sq1 f$mode exit $?"
         timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_sq2_f$mode -o sq2 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq2_f$mode.log 2>&1; echo "sq2 f$mode exit $?"
       done
