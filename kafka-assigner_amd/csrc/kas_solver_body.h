@@ -1825,6 +1825,24 @@ KAS_DEV void order_permutation(const KasLaunch& a, unsigned char* lds_raw) {
 #ifndef KAS_IDLE_NAP
 #define KAS_IDLE_NAP 4
 #endif
+#ifndef KAS_SOLVER_PRIO
+#define KAS_SOLVER_PRIO 3
+#endif
+// retiring wave: rows per lane whose id reads are in flight together (two such batches alternate)
+#ifndef KAS_RETIRE_UR
+#define KAS_RETIRE_UR 2
+#endif
+// diagnostics build: rows in hand / rows ready per solver step, iterations of the retiring wave (kas_plan_stats [15], [7], [4], [5])
+#ifndef KAS_ORDER_DIAG
+#define KAS_ORDER_DIAG 0
+#endif
+// solver: lanes left without a row after the claim (of 64) from which on the wave naps (s_sleep argument; 0 = never)
+#ifndef KAS_STARVE_NAP
+#define KAS_STARVE_NAP 0
+#endif
+#ifndef KAS_STARVE_MIN
+#define KAS_STARVE_MIN 16
+#endif
 #ifndef KAS_RUN_MIN_GAIN
 #define KAS_RUN_MIN_GAIN 3
 #endif
@@ -2068,10 +2086,10 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     RingSlot nx;
     nx.tag = KAS_TAG_FREE; nx.c[0] = 0; nx.c[1] = 0; nx.c[2] = 0;
 #endif
-    int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0, n_cur = 0;
+    int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0, n_cur = 0, n_rdy = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
     const int64_t t_begin = kasw::clock_ticks();
-    kasw::set_priority<3>();                               // the chain: first call on the SIMD's issue slots
+    kasw::set_priority<KAS_SOLVER_PRIO>();                 // the chain: first call on the SIMD's issue slots
     for (;;) {
       kasw::repoll();                                      // LDS is re-read below
       n_iter += 1;
@@ -2110,7 +2128,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
                      d2 = ((uint32_t)e2 >> 16) - com[2];
       const uint32_t d_any = d0 | d1 | d2, d_sum = d0 + d1 + d2;
       bool ready = cv && d_any == 0u;
-      if (KAS_COUNTERS_ON && a.stats) n_cur += kasw::popc((kasw::ballot(cv) >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)));
+      if ((KAS_COUNTERS_ON || KAS_ORDER_DIAG) && a.stats) n_cur += kasw::popc((kasw::ballot(cv) >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)));
       // ---- runs.  First fit hands consecutive orphans to one node until it is full, so the rows
       // in hand often queue on ONE node X (tickets t, t+1, ...) while their other holders are
       // free.  Such a queue is decided in this iteration: its rows differ from "ready" only in
@@ -2205,6 +2223,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       int32_t w0, w1;
       ticket_picks(f0, f1, meta, w0, w1);
       const int32_t w2 = 3 - w0 - w1;
+      if (KAS_ORDER_DIAG && a.stats) n_rdy += kasw::popc((kasw::ballot(ready) >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull)));
       if (ready) {
         const int32_t Lp = (meta >> 3) & 3;
         const int32_t ad0 = (w0 == 0 ? e0 : (w0 == 1 ? e1 : e2)) & 0xffff;
@@ -2255,6 +2274,12 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         gfin = gfin || ((endb >> (g * GL)) & GLM) != 0ull;
       }
       const bool fin = gfin && !cv;
+#if KAS_STARVE_NAP > 0
+      // Lanes that wanted a row and found none staged: the staging wave is behind.  Stepping on with a
+      // thin hand costs a full step's instructions for a few rows — at raised priority, i.e. taken from
+      // the very waves that have to catch up — so the solver lets them.
+      if (kasw::popc(kasw::ballot(!cv && !gfin)) >= KAS_STARVE_MIN) kasw::nap<KAS_STARVE_NAP>();
+#endif
 #else
       if (!cv && nv) {                                     // the look-ahead row becomes current
         e0 = nx.c[0]; e1 = nx.c[1]; e2 = nx.c[2];
@@ -2279,6 +2304,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
       st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
       st[14] = run_rows; st[6] = n_runs; st[15] = n_cur;
+      if (KAS_ORDER_DIAG) st[7] = n_rdy;
     }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ stager: tickets + staging
@@ -2358,8 +2384,15 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const uint32_t s2 = ab_hi < c2 ? c2 : ab_hi;
       const uint32_t mid_hi = ab_hi < c2 ? ab_hi : c2;
       const uint32_t s1 = ab_lo < mid_hi ? mid_hi : ab_lo;
+#ifdef KAS_TUNE_STAGER_LIGHT
+      // timing experiment (wrong rows): no sort, every row full
+      const int32_t Lp = 3;
+      uint32_t hn[3] = {c0 < pad ? c0 : pad, c1 < pad ? c1 : pad, c2 < pad ? c2 : pad};
+      (void)s0; (void)s1; (void)s2;
+#else
       const int32_t Lp = (s0 < pad ? 1 : 0) + (s1 < pad ? 1 : 0) + (s2 < pad ? 1 : 0);
       uint32_t hn[3] = {s0 < pad ? s0 : pad, s1 < pad ? s1 : pad, s2 < pad ? s2 : pad};
+#endif
       // ---- tickets for the tile (wave-wide lockstep).  One 32-bit lane mask per node: a 64-lane
       // group takes its tile as two ascending halves.
       uint32_t tk[3] = {0u, 0u, 0u};
@@ -2396,11 +2429,16 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           enc[q] = (int32_t)(((q < Lp ? tk[q] : (uint32_t)dummy_tk) << 16) | (uint32_t)(cnt_base + (int32_t)hn[q] * RB));
         const int32_t lut = Lp == 3 ? (rot & 0x3f) : (Lp == 2 ? ((rot >> 6) & 0x3f) : KAS_ROT_IDENT);
         RingSlot o;
+#ifdef KAS_TUNE_STAGER_LIGHT
+        (void)lut;
+        o.c[0] = enc[0]; o.c[1] = enc[1]; o.c[2] = enc[2];
+#else
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           const int32_t r = (lut >> (2 * t)) & 3;
           o.c[t] = r == 0 ? enc[0] : (r == 1 ? enc[1] : enc[2]);
         }
+#endif
         // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane: an
         // empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
         const int32_t bits = Lp == 3 ? ((rot >> 12) & 7) : 0;
@@ -2420,10 +2458,13 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     // broker ids, digest, the final out row.  A finished slot is copied to registers and freed for
     // the stager at once; the node index -> broker id reads (L2) of two batches of UR rows per
     // lane are in flight alternately, so their latency is not in the slot's way.
-    constexpr int UR = 2;                                   // rows per lane per batch
+    constexpr int UR = KAS_RETIRE_UR;                       // rows per lane per batch
     constexpr int RSH = PK ? 2 : 3;                         // log2(bytes per counter row)
     struct Retired { bool on; int32_t id[3], Lp, p, kw; int32_t* row; };   // kw = topic | row width << 27
     TileIter itr = tile_iter_begin(have_s);
+#ifdef KAS_RETIRER_PRIO
+    kasw::set_priority<KAS_RETIRER_PRIO>();                 // tuning builds
+#endif
     int32_t jr = 0;
     bool fin = false;
     uint64_t digest = 0;
@@ -2473,7 +2514,11 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         for (int q = 0; q < W; ++q) {
           const int32_t e = w[q] == 0 ? sl.c[0] : (w[q] == 1 ? sl.c[1] : sl.c[2]);
           const int32_t node = q < r.Lp ? ((e & 0xffff) - cnt_base) >> RSH : 0;
+#ifdef KAS_TUNE_RETIRE_NOLOOKUP
+          r.id[q] = node;                                 // timing experiment (wrong rows): no node index -> broker id read
+#else
           r.id[q] = g_node_id[node];                      // 4 KB table per scenario: L2-resident
+#endif
         }
         return true;
       }
@@ -2489,9 +2534,11 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
       for (int q = 0; q < 3; ++q) { ra[u].id[q] = 0; rb[u].id[q] = 0; }
     }
+    int64_t r_iter = 0, r_idle = 0;
     for (;;) {
       bool retired = false;
       kasw::repoll();
+      r_iter += 1;
 #pragma unroll
       for (int u = 0; u < UR; ++u) finish(ra[u]);
 #pragma unroll
@@ -2504,7 +2551,11 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       if (kasw::ballot(!fin) == 0) break;
       const bool progress = kasw::ballot(retired) != 0;
       if (watchdog_poll(wd, progress, wd_idle)) break;
-      if (!progress) kasw::nap<KAS_IDLE_NAP>();
+      if (!progress) { r_idle += 1; kasw::nap<KAS_IDLE_NAP>(); }
+    }
+    if (KAS_ORDER_DIAG && a.stats && have_s && li == 0) {
+      int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      st[4] = r_iter; st[5] = r_idle;
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) { finish(ra[u]); finish(rb[u]); }

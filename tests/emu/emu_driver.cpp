@@ -364,8 +364,8 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if (getenv("KAS_EMU_STATS")) {
       for (int32_t s = 0; s < b->n_scenarios; ++s) {
         const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
-        fprintf(stderr, "emu stats s=%d solver_iter=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld\n", s,
-                (long long)st[9], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12]);
+        fprintf(stderr, "emu stats s=%d solver_iter=%lld queue_passes=%lld run_rounds=%lld run_rows=%lld blocked=%lld stager_iter=%lld\n", s,
+                (long long)st[9], (long long)st[6], (long long)st[10], (long long)st[14], (long long)st[11], (long long)st[12]);
       }
     }
   } else if (wide) {
