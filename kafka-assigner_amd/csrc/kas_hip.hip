@@ -621,12 +621,13 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
     a.sp_flag = (int32_t*)p->b_sp_flag.p; a.sp_oc = (int32_t*)p->b_sp_oc.p; a.sp_chunks = chunks;
     KAS_HIP_TRY(hipMemsetAsync(a.sp_flag, 0, 4 * ((size_t)p->n_scenarios + 1), st));
     KAS_HIP_TRY(hipMemsetAsync(a.sp_oc, 0, 4 * (size_t)p->n_scenarios * ((size_t)chunks + 2), st));
-    const size_t l1 = (size_t)kas_fill_lds_layout(p->shape.n_max, p->Wc, 1, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
+    const size_t la = (size_t)kas_spread_scan_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
+    const size_t lb = (size_t)kas_spread_scan_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries, p->shape.need_bsearch, 2).total;
     const size_t l4 = (size_t)kas_fill_lds_layout(p->shape.n_max, p->Wc, 4, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
     const dim3 gc((unsigned)chunks, (unsigned)p->n_scenarios);
-    hipLaunchKernelGGL(sk.a, gc, dim3(64), l1, st, a);
+    hipLaunchKernelGGL(sk.a, gc, dim3(64), la, st, a);
     hipLaunchKernelGGL(sk.q, dim3((unsigned)((p->shape.n_max + 255) / 256), (unsigned)p->n_scenarios), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(sk.b, gc, dim3(64), l1, st, a);
+    hipLaunchKernelGGL(sk.b, gc, dim3(64), lb, st, a);
     hipLaunchKernelGGL(sk.p4, dim3((unsigned)p->n_scenarios), dim3(256), l4, st, a);
     KAS_HIP_TRY(hipGetLastError());
     a.flags |= KAS_FLAG_ONLY_FLAGGED;                              // what is left: scenarios handed back (not rack-diverse, ...)

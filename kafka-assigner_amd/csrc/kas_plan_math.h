@@ -150,6 +150,28 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
   return L;
 }
 
+// Layouts of the spread fill's scan kernels (one wavefront per workgroup, many workgroups per scenario): only
+// what the pass touches, so that two of them fit a CU at 5,000 brokers (the full layout above is 145 KB there
+// and ran the scans of a 64-scenario batch at one wavefront per CU).
+//   pass A (mode 1)  x = uint16 hist[W][n] (a chunk has fewer than 65,536 rows: kas_spread_chunks), rack, idmap
+//   pass B (mode 2)  x = int32 quota[n] of the chunk, qrs[n], rack, idmap
+KAS_ABI_FN KasLds kas_spread_scan_lds(int32_t n_max, int32_t W, int32_t idmap_entries, int32_t need_bsearch, int32_t mode) {
+  KasLds L;
+  int64_t n = n_max > 0 ? n_max : 1;
+  int64_t o = 0;
+  L.off_x = (int32_t)o;     o = kas_align16(o + (mode == 1 ? 2 * n * W : 4 * n));
+  L.off_load = L.off_x;                                    // (not used by the scans)
+  L.off_qrs = (int32_t)o;   if (mode == 2) o = kas_align16(o + 4 * n);
+  L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
+  L.off_live = L.off_qrs;
+  L.off_idmap = (int32_t)o; o = kas_align16(o + 2 * (int64_t)(idmap_entries > 0 ? idmap_entries : 1));
+  L.off_ids = (int32_t)o;   if (need_bsearch) o = kas_align16(o + 4 * n);
+  L.off_ring = (int32_t)o;                                 // (no orphan window in the scans)
+  L.off_ctl = (int32_t)o;   o = kas_align16(o + 4 * KAS_CTL_INTS);
+  L.total = (int32_t)o;
+  return L;
+}
+
 // ticket form of order: per lane group (= scenario) one counter row per node + the padding
 // holder's row (uint64 = 4 x uint16: count[node][0..2] + commits; or, packed, uint32 = three 10-bit
 // counts when no node ever holds 1023 rows of the scenario), uint32 lane mask per node [n_max],
@@ -279,11 +301,13 @@ static inline int32_t kas_spread_chunks(const KasShape& s, int32_t n_scenarios, 
   // the layout of a one-wavefront workgroup (histogram rows, node tables) must fit as well
   if (kas_fill_lds_layout(s.n_max, s.Wc, 1, s.idmap_entries, s.need_bsearch, 1).total > KAS_LDS_LIMIT) return 0;
   const int64_t tiles = ((int64_t)s.max_partitions + 63) / 64;
-  if (force) return (int32_t)(tiles >= 6 ? 6 : (tiles > 0 ? tiles : 1));
+  // (pass A counts a chunk's rows per node and sweep in uint16 cells: a chunk stays below 1,023 tiles)
+  if (force) return (int32_t)(tiles >= 6 * 1023 ? 0 : (tiles >= 6 ? 6 : (tiles > 0 ? tiles : 1)));
   if (n_scenarios > 64 || tiles < 2048) return 0;
   int64_t ch = 512 / n_scenarios;
   if (ch > 256) ch = 256;
   while (ch > 1 && tiles / ch < 16) ch >>= 1;
+  while ((tiles + ch - 1) / ch >= 1023) ch <<= 1;          // (uint16 cells: more, shorter chunks)
   return (int32_t)(ch >= 4 ? ch : 0);
 }
 

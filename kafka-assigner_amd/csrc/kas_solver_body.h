@@ -663,7 +663,8 @@ KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const No
 // P2, rack-diverse form: passes A1, Q, A2, prefix, B (see the header comment).
 // ---------------------------------------------------------------------------------------------
 // A1: tiles wave, wave+NW, ... ; returns this lane's "not rack-diverse" verdict
-template <int W, bool DIRECT>
+// H16: hist[W][n] as uint16 cells, two to a dword (fewer than 65,536 rows in the range: the spread fill's chunks)
+template <int W, bool DIRECT, bool H16 = false>
 KAS_DEV bool fill_pass_a_range(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t tile0,
                                int32_t stride, int32_t t_end) {
   constexpr int D = KAS_TILES_AHEAD;
@@ -687,7 +688,13 @@ KAS_DEV bool fill_pass_a_range(const LdsView& L, const TopicView& T, const NodeM
 #pragma unroll
         for (int r2 = 0; r2 < r; ++r2) viol = viol || rk[d][r] == rk[d][r2];
 #pragma unroll
-      for (int r = 0; r < W; ++r) if (idx[d][r] >= 0) kasw::lds_atomic_add(&L.x[r * N + idx[d][r]], 1);
+      for (int r = 0; r < W; ++r) {
+        if (idx[d][r] >= 0) {
+          const int32_t cell = r * N + idx[d][r];
+          if (H16) kasw::lds_atomic_add(&L.x[cell >> 1], 1 << (16 * (cell & 1)));
+          else kasw::lds_atomic_add(&L.x[cell], 1);
+        }
+      }
     }
   });
   return viol;
@@ -1499,8 +1506,10 @@ KAS_DEV SpreadTopic spread_topic(const KasLaunch& a, int32_t s) {
   return S;
 }
 
-KAS_DEV LdsView spread_lds(const KasLaunch& a, unsigned char* lds_raw, int W, int NW) {
-  const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch, 1);
+// mode 0: the layout of the one-workgroup fill (spread_p4); 1, 2: the slim layouts of the scans (kas_spread_scan_lds)
+KAS_DEV LdsView spread_lds(const KasLaunch& a, unsigned char* lds_raw, int W, int NW, int mode = 0) {
+  const KasLds lay = mode == 0 ? kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch, 1)
+                               : kas_spread_scan_lds(a.n_max, W, a.idmap_entries, a.need_bsearch, mode);
   LdsView L;
   L.x = (int32_t*)(lds_raw + lay.off_x);
   L.load = (int32_t*)(lds_raw + lay.off_load);
@@ -1554,19 +1563,20 @@ KAS_DEV void spread_pass_a(const KasLaunch& a, int32_t s, int32_t c, unsigned ch
     if (lane == 0) a.sp_flag[s] = 1;
     return;
   }
-  const LdsView L = spread_lds(a, lds_raw, W, 1);
+  const LdsView L = spread_lds(a, lds_raw, W, 1, 1);
   const TopicView& T = S.T;
   const int32_t N = T.N;
   spread_node_tables(a, s, L, S.nm, 64);
-  for (int32_t i = lane; i < N * W; i += 64) L.x[i] = 0;
+  for (int32_t i = lane; i < (N * W + 1) / 2; i += 64) L.x[i] = 0;   // uint16 cells
   kasw::sync();
   const int32_t t0 = (int32_t)(((int64_t)T.nt * c) / CH), t1 = (int32_t)(((int64_t)T.nt * (c + 1)) / CH);
-  const bool viol = fill_pass_a_range<W, true>(L, T, S.nm, t0, 1, t1);
+  const bool viol = fill_pass_a_range<W, true, true>(L, T, S.nm, t0, 1, t1);
   if (kasw::ballot(viol) != 0ull && lane == 0) a.sp_flag[s] = 1;   // not rack-diverse: the general fill's case
   kasw::sync();
   int32_t* g = a.sp_hist + ((int64_t)s * CH + c) * W * a.n_max;
+  const uint16_t* h = (const uint16_t*)L.x;
   for (int32_t r = 0; r < W; ++r)
-    for (int32_t n = lane; n < N; n += 64) g[(int64_t)r * a.n_max + n] = L.x[r * N + n];
+    for (int32_t n = lane; n < N; n += 64) g[(int64_t)r * a.n_max + n] = (int32_t)h[r * N + n];
 }
 
 // phase Q: node n of scenario s (no LDS; any launch shape)
@@ -1610,7 +1620,7 @@ KAS_DEV void spread_pass_b(const KasLaunch& a, int32_t s, int32_t c, unsigned ch
   if (a.sp_flag[s] != 0) return;                                 // (written by an earlier kernel: uniform)
   const int32_t CH = a.sp_chunks;
   SpreadTopic S = spread_topic<W>(a, s);
-  const LdsView L = spread_lds(a, lds_raw, W, 1);
+  const LdsView L = spread_lds(a, lds_raw, W, 1, 2);
   const TopicView& T = S.T;
   const int32_t N = T.N;
   spread_node_tables(a, s, L, S.nm, 64);
