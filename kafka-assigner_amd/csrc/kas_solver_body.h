@@ -2394,15 +2394,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const uint32_t s2 = ab_hi < c2 ? c2 : ab_hi;
       const uint32_t mid_hi = ab_hi < c2 ? ab_hi : c2;
       const uint32_t s1 = ab_lo < mid_hi ? mid_hi : ab_lo;
-#ifdef KAS_TUNE_STAGER_LIGHT
-      // timing experiment (wrong rows): no sort, every row full
-      const int32_t Lp = 3;
-      uint32_t hn[3] = {c0 < pad ? c0 : pad, c1 < pad ? c1 : pad, c2 < pad ? c2 : pad};
-      (void)s0; (void)s1; (void)s2;
-#else
       const int32_t Lp = (s0 < pad ? 1 : 0) + (s1 < pad ? 1 : 0) + (s2 < pad ? 1 : 0);
       uint32_t hn[3] = {s0 < pad ? s0 : pad, s1 < pad ? s1 : pad, s2 < pad ? s2 : pad};
-#endif
       // ---- tickets for the tile (wave-wide lockstep).  One 32-bit lane mask per node: a 64-lane
       // group takes its tile as two ascending halves.
       uint32_t tk[3] = {0u, 0u, 0u};
@@ -2439,16 +2432,11 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           enc[q] = (int32_t)(((q < Lp ? tk[q] : (uint32_t)dummy_tk) << 16) | (uint32_t)(cnt_base + (int32_t)hn[q] * RB));
         const int32_t lut = Lp == 3 ? (rot & 0x3f) : (Lp == 2 ? ((rot >> 6) & 0x3f) : KAS_ROT_IDENT);
         RingSlot o;
-#ifdef KAS_TUNE_STAGER_LIGHT
-        (void)lut;
-        o.c[0] = enc[0]; o.c[1] = enc[1]; o.c[2] = enc[2];
-#else
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           const int32_t r = (lut >> (2 * t)) & 3;
           o.c[t] = r == 0 ? enc[0] : (r == 1 ? enc[1] : enc[2]);
         }
-#endif
         // a row nobody holds (KAS:205-214 never lists it), or no row of this tile for my lane: an
         // empty list (Lp = 0, padding holders only) keeps the lane's row counters in step
         const int32_t bits = Lp == 3 ? ((rot >> 12) & 7) : 0;
@@ -2524,11 +2512,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
         for (int q = 0; q < W; ++q) {
           const int32_t e = w[q] == 0 ? sl.c[0] : (w[q] == 1 ? sl.c[1] : sl.c[2]);
           const int32_t node = q < r.Lp ? ((e & 0xffff) - cnt_base) >> RSH : 0;
-#ifdef KAS_TUNE_RETIRE_NOLOOKUP
-          r.id[q] = node;                                 // timing experiment (wrong rows): no node index -> broker id read
-#else
           r.id[q] = g_node_id[node];                      // 4 KB table per scenario: L2-resident
-#endif
         }
         return true;
       }

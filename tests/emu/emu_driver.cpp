@@ -425,6 +425,22 @@ int kas_emu_shape(const kas_batch_desc* b, int32_t* out, char* errbuf, int errle
   return rc;
 }
 
+// spread fill planning: chunks per scenario for a batch of n_scenarios single-topic scenarios of this shape
+// (0: the one-workgroup fill kernel), and the LDS of its scan kernels (pass A, pass B, the one-workgroup layout)
+extern "C" __attribute__((visibility("default")))
+int kas_emu_spread_plan(const kas_batch_desc* b, int32_t* out) {
+  KasShape sh;
+  std::string err;
+  const int rc = kas_shape_batch(b, &sh, &err, 0, 0);
+  if (rc != KAS_E_OK) return rc;
+  out[0] = kas_spread_chunks(sh, b->n_scenarios, kas_batch_single_topic(b), false);
+  out[1] = kas_spread_scan_lds(sh.n_max, sh.Wc, sh.idmap_entries, sh.need_bsearch, 1).total;
+  out[2] = kas_spread_scan_lds(sh.n_max, sh.Wc, sh.idmap_entries, sh.need_bsearch, 2).total;
+  out[3] = kas_fill_lds_layout(sh.n_max, sh.Wc, 1, sh.idmap_entries, sh.need_bsearch, 1).total;
+  out[4] = (int32_t)(((int64_t)sh.max_partitions + 63) / 64);
+  return rc;
+}
+
 extern "C" __attribute__((visibility("default")))
 long kas_emu_collectives(void) { return kasw::g_emu.collectives; }
 

@@ -128,3 +128,15 @@ def last_order_form() -> int:
     L = lib()
     L.kas_emu_last_order_form.restype = C.c_int
     return int(L.kas_emu_last_order_form())
+
+
+def spread_plan(fb: FlatBatch):
+    """Spread-fill planning for a batch shape (nothing is run): chunks per scenario (0 = one-workgroup fill), LDS
+    bytes of the scan kernels (pass A, pass B) and of the one-workgroup layout they used to carry, tiles per scenario."""
+    L = lib()
+    L.kas_emu_spread_plan.restype = C.c_int
+    L.kas_emu_spread_plan.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(C.c_int32)]
+    bd = batch_desc(fb)
+    out = (C.c_int32 * 5)()
+    rc = L.kas_emu_spread_plan(C.byref(bd), out)
+    return rc, dict(zip(("chunks", "lds_a", "lds_b", "lds_full", "tiles"), list(out)))

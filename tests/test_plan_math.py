@@ -3,7 +3,7 @@ same header: which order kernel serves a shape, and that a shape no kernel can s
 plan time (KAS_E_UNSUPPORTED) rather than at its first launch."""
 import numpy as np
 
-from emu_lib import plan_shape
+from emu_lib import plan_shape, spread_plan
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import node_set_batch
 
@@ -42,3 +42,20 @@ def test_shape_that_no_order_kernel_serves_is_refused_at_plan_time():
 def test_wide_lists_take_the_wide_ticket_form_also_where_the_round_form_does_not_fit():
     rc, sh, _ = _shape(5100, 5, P=100000)
     assert rc == 0 and sh["wide_ok"] == 1 and sh["tickets_ok"] == 0
+
+
+def test_spread_scan_kernels_fit_two_to_a_cu_at_5000_brokers_and_their_chunks_fit_uint16_cells():
+    """Round 3: passes A and B of the spread fill carry only what they touch (71 / 61 KB instead of the
+    one-workgroup layout's 145 KB at BASELINE configs[4]), and pass A counts in uint16 cells: a chunk stays
+    below 1,023 tiles of 64 rows, whatever the batch size asks for."""
+    ids = [np.arange(5100, dtype=np.int32)]
+    racks = [(np.arange(5100) % 40).astype(np.int32)]
+    for S in (1, 8, 64):
+        rc, sp = spread_plan(node_set_batch(ids * S, racks * S, 1000000, 5, 5))
+        assert rc == 0 and sp["chunks"] >= 4, (S, sp)
+        assert (sp["tiles"] + sp["chunks"] - 1) // sp["chunks"] < 1023, (S, sp)
+        assert 2 * sp["lds_a"] <= 160 * 1024 and 2 * sp["lds_b"] <= 160 * 1024 and sp["lds_full"] > 80 * 1024, sp
+    assert spread_plan(node_set_batch(ids * 64, racks * 64, 1000000, 5, 5))[1]["chunks"] == 16
+    # small scenarios and big batches stay with the one-workgroup kernel
+    assert spread_plan(node_set_batch(ids * 2, racks * 2, 100000, 5, 5))[1]["chunks"] == 0
+    assert spread_plan(node_set_batch(ids * 65, racks * 65, 1000000, 5, 5))[1]["chunks"] == 0
