@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle stress (not part of the pytest suites): random shapes (8..500 brokers,
 300..20000 partitions, RF 2..3, every action mix, 1..8 scenarios per batch) for N seconds, each batch
-solved with the default plan, one scenario per solver wavefront, and 4 x uint16 counter rows, and
-compared bit for bit with the CPU oracle.  Usage: python scripts/stress_gpu.py SECONDS
+solved with the default plan, one scenario per solver wavefront, 4 x uint16 counter rows, and the spread fill
+forced, and compared bit for bit with the CPU oracle.  Usage: python scripts/stress_gpu.py SECONDS
 (round 1: 21,494 batches x 3 plan variants in 150 s on an MI355X, all identical)."""
 import sys, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
@@ -22,8 +22,9 @@ while time.time() - t0 < float(sys.argv[1]):
     S = int(rng.choice([1, 2, 3, 5, 8]))
     fb = _batch(seed, S, P, N, R, RF, acts)
     want = oracle_solve(fb)
-    for flags in ((0, 1 << 12, 4) if RF <= 3 else (0, 2, 1)):
+    # (32 = KAS_PLAN_SPREAD_FILL: the row scans over one-wavefront workgroups with their slim LDS layouts)
+    for flags in ((0, 1 << 12, 4, 32) if RF <= 3 else (0, 2, 1, 32)):
         got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
     n += 1
-print("stress ok:", n, "random batches x 3 plan variants")
+print("stress ok:", n, "random batches x 4 plan variants")
