@@ -94,9 +94,9 @@ __global__ __launch_bounds__(64) void kas_spread_b_kernel(KasLaunch a) {
   kas::spread_pass_b<W>(a, (int32_t)blockIdx.y, (int32_t)blockIdx.x, kas_lds);
 }
 template <int W>
-__global__ __launch_bounds__(256) void kas_spread_p4_kernel(KasLaunch a) {
+__global__ __launch_bounds__(64 * KAS_SPREAD_P4_WAVES) void kas_spread_p4_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::spread_p4<W, 4>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::spread_p4<W, KAS_SPREAD_P4_WAVES>(a, (int32_t)blockIdx.x, kas_lds);
 }
 struct KasSpreadKernels { void (*a)(KasLaunch); void (*q)(KasLaunch); void (*b)(KasLaunch); void (*p4)(KasLaunch); };
 template <int W>
@@ -623,12 +623,12 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
     KAS_HIP_TRY(hipMemsetAsync(a.sp_oc, 0, 4 * (size_t)p->n_scenarios * ((size_t)chunks + 2), st));
     const size_t la = (size_t)kas_spread_scan_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
     const size_t lb = (size_t)kas_spread_scan_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries, p->shape.need_bsearch, 2).total;
-    const size_t l4 = (size_t)kas_fill_lds_layout(p->shape.n_max, p->Wc, 4, p->shape.idmap_entries, p->shape.need_bsearch, 1).total;
+    const size_t l4 = (size_t)kas_spread_scan_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries, p->shape.need_bsearch, 3).total;
     const dim3 gc((unsigned)chunks, (unsigned)p->n_scenarios);
     hipLaunchKernelGGL(sk.a, gc, dim3(64), la, st, a);
     hipLaunchKernelGGL(sk.q, dim3((unsigned)((p->shape.n_max + 255) / 256), (unsigned)p->n_scenarios), dim3(256), 0, st, a);
     hipLaunchKernelGGL(sk.b, gc, dim3(64), lb, st, a);
-    hipLaunchKernelGGL(sk.p4, dim3((unsigned)p->n_scenarios), dim3(256), l4, st, a);
+    hipLaunchKernelGGL(sk.p4, dim3((unsigned)p->n_scenarios), dim3(64 * KAS_SPREAD_P4_WAVES), l4, st, a);
     KAS_HIP_TRY(hipGetLastError());
     a.flags |= KAS_FLAG_ONLY_FLAGGED;                              // what is left: scenarios handed back (not rack-diverse, ...)
   }

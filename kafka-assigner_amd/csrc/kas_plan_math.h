@@ -95,6 +95,13 @@ struct KasLds {
 #define KAS_CTL_OC 8          // [NW] orphans found per chunk
 #define KAS_CTL_WATCHDOG 7    // debug builds (KAS_SPIN_BOUND): a P4 wait ran past its bound
 
+// wavefronts of the spread fill's P4 kernel (one workgroup per scenario).  A window of 64 orphans costs its wave
+// ~3.5 us (row reads, rack lookups, two hand-over steps), the hand-over chain 0.44 us per step: with four waves
+// the waves were the pace (configs[4]: 3.4k windows, 3.0 ms), not the chain; KAS_CTL_OC / KAS_CTL_PROG hold 8.
+#ifndef KAS_SPREAD_P4_WAVES
+#define KAS_SPREAD_P4_WAVES 8
+#endif
+
 #define KAS_TICKET_LIMIT 65535  // tickets (= 16-bit counters of the order kernel) stay below this
 
 KAS_ABI_FN int32_t kas_align16(int64_t v) { return (int32_t)((v + 15) & ~(int64_t)15); }
@@ -155,15 +162,18 @@ KAS_ABI_FN KasLds kas_fill_lds_layout(int32_t n_max, int32_t W, int32_t NW, int3
 // and ran the scans of a 64-scenario batch at one wavefront per CU).
 //   pass A (mode 1)  x = uint16 hist[W][n] (a chunk has fewer than 65,536 rows: kas_spread_chunks), rack, idmap
 //   pass B (mode 2)  x = int32 quota[n] of the chunk, qrs[n], rack, idmap
+//   P4     (mode 3)  load[n] (in x), the list of non-full nodes (in qrs), rack — no id tables
 KAS_ABI_FN KasLds kas_spread_scan_lds(int32_t n_max, int32_t W, int32_t idmap_entries, int32_t need_bsearch, int32_t mode) {
   KasLds L;
   int64_t n = n_max > 0 ? n_max : 1;
   int64_t o = 0;
   L.off_x = (int32_t)o;     o = kas_align16(o + (mode == 1 ? 2 * n * W : 4 * n));
-  L.off_load = L.off_x;                                    // (not used by the scans)
+  L.off_load = L.off_x;                                    // (P4: the loads; not used by the scans)
   L.off_qrs = (int32_t)o;   if (mode == 2) o = kas_align16(o + 4 * n);
+  if (mode == 3) o = kas_align16(o + 2 * n);               // (P4: int16 live[n])
   L.off_rack = (int32_t)o;  o = kas_align16(o + 2 * n);
   L.off_live = L.off_qrs;
+  if (mode == 3) { idmap_entries = 0; need_bsearch = 0; }
   L.off_idmap = (int32_t)o; o = kas_align16(o + 2 * (int64_t)(idmap_entries > 0 ? idmap_entries : 1));
   L.off_ids = (int32_t)o;   if (need_bsearch) o = kas_align16(o + 4 * n);
   L.off_ring = (int32_t)o;                                 // (no orphan window in the scans)

@@ -956,7 +956,7 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
 #define KAS_P4_U 4
 #endif
 #ifndef KAS_P4_U_WIDE
-#define KAS_P4_U_WIDE 2
+#define KAS_P4_U_WIDE 1
 #endif
 template <int W, int NW>
 KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t live_count, int32_t wave,
@@ -1021,6 +1021,13 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
         stop = true;
         break;
       }
+      // (the nodes of the position group and their racks do not change: read before the wait, so that what
+      // follows it — the chain from window to window — is one LDS round trip for the loads)
+      int32_t n[U], slots[U], rk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) n[u] = (int32_t)L.live[j + u < live_count ? j + u : j];
+#pragma unroll
+      for (int u = 0; u < U; ++u) rk[u] = (int32_t)lds_rack(L, n[u]);
       if (w > 0 && NW > 1) {                                // until every earlier window is done with [j, j + U)
         const int32_t upto = j + U < live_count ? j + U : live_count;
         const bool watch = lane >= 1 && lane < NW && w - dw >= 0;
@@ -1041,11 +1048,8 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
         }
         if (abandoned) { stop = true; break; }
       }
-      int32_t n[U], slots[U], rk[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) n[u] = (int32_t)L.live[j + u < live_count ? j + u : j];
-#pragma unroll
-      for (int u = 0; u < U; ++u) { slots[u] = cap - lds_load(L, n[u]); rk[u] = (int32_t)lds_rack(L, n[u]); }
+      for (int u = 0; u < U; ++u) slots[u] = cap - lds_load(L, n[u]);
       int32_t taken[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1652,7 +1656,7 @@ KAS_DEV void spread_p4(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   if (a.sp_flag[s] != 0) return;
   const int32_t CH = a.sp_chunks;
   SpreadTopic S = spread_topic<W>(a, s);
-  const LdsView L = spread_lds(a, lds_raw, W, NW);
+  const LdsView L = spread_lds(a, lds_raw, W, NW, 3);
   TopicView& T = S.T;
   const int32_t N = T.N, cap = T.cap;
   const int64_t t_begin = kasw::clock_ticks();

@@ -187,7 +187,7 @@ template <int W> void run_order_rounds(void* p) {
 struct SpreadArgs { const KasLaunch* a; int32_t s, c; unsigned char* lds; };
 template <int W> void run_spread_a(void* p) { SpreadArgs* r = (SpreadArgs*)p; kas::spread_pass_a<W>(*r->a, r->s, r->c, r->lds); }
 template <int W> void run_spread_b(void* p) { SpreadArgs* r = (SpreadArgs*)p; kas::spread_pass_b<W>(*r->a, r->s, r->c, r->lds); }
-template <int W> void run_spread_p4(void* p) { SpreadArgs* r = (SpreadArgs*)p; kas::spread_p4<W, 4>(*r->a, r->s, r->lds); }
+template <int W> void run_spread_p4(void* p) { SpreadArgs* r = (SpreadArgs*)p; kas::spread_p4<W, KAS_SPREAD_P4_WAVES>(*r->a, r->s, r->lds); }
 template <int W> void spread_quota_all(const KasLaunch& a) {
   for (int32_t s = 0; s < a.n_scenarios; ++s)
     for (int32_t n = 0; n < a.n_max; ++n) kas::spread_quota<W>(a, s, n);
@@ -312,7 +312,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(lds.data(), 0xCD, lds.size());
       SpreadArgs ra{&a, s, 0, lds.data()};
-      if (kasw::run_block(fp, &ra, 4) != 0) return bad("spread fill P4", s);
+      if (kasw::run_block(fp, &ra, KAS_SPREAD_P4_WAVES) != 0) return bad("spread fill P4", s);
       g_last_spread += sp_flag[(size_t)s] == 0 ? 1 : 0;
     }
     a.flags |= KAS_FLAG_ONLY_FLAGGED;
