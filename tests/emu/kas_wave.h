@@ -23,7 +23,7 @@
 
 #define KAS_DEV static inline
 #define KAS_DEV_COLD static
-#define KAS_EMU_MAX_LANES 512
+#define KAS_EMU_MAX_LANES 1024
 
 namespace kasw {
 
