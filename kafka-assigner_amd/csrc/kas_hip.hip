@@ -554,7 +554,9 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool generic = (p->flags & KAS_FLAG_GENERIC_FILL) || !p->shape.with_x;
   char order[256];
-  const char* ctx_tail = (p->shape.any_ctx && (lp.tickets || lp.wide)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
+  const char* ctx_tail = (lp.wide && p->shape.wide_checked)
+                             ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
+                             : (p->shape.any_ctx && (lp.tickets || lp.wide)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.tickets)
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
@@ -605,7 +607,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   p->last_stream = st;
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
-  a.flags = (p->flags & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ORDER_FLAGGED)) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
+  a.flags = (p->flags & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ORDER_FLAGGED | KAS_FLAG_WIDE_CHECK)) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
             (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
@@ -644,8 +646,14 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   const int packed = lp.packed;
   // a Context handed in: the ticket forms flag the scenarios whose counters do not fit their count
   // fields, and the round form (launched behind them, taking only those) serves them
-  const bool ctx_fallback = p->shape.any_ctx && (tickets || lp.wide);
+  // lists 4-5 wide and a node that may hold 1023 .. 2039 rows: the wide form checks its 10-bit count fields when
+  // the last row has retired and flags a scenario that outgrew them.  Its rows are finished (on wrong counts) by
+  // then and its mid rows gone, so it is solved again from `cur`: fill kernel, then round form, both taking only
+  // the flagged scenarios.
+  const bool wide_recheck = lp.wide && p->shape.wide_checked;
+  const bool ctx_fallback = (p->shape.any_ctx && (tickets || lp.wide)) || wide_recheck;
   if (ctx_fallback) KAS_HIP_TRY(hipMemsetAsync(a.ord_flag, 0, 4 * ((size_t)p->n_scenarios + 1), st));
+  if (wide_recheck) a.flags |= KAS_FLAG_WIDE_CHECK;
   if (lp.pairing) {
     // scenarios that share a solver wavefront should have P5 chains of similar length
     a.perm = (int32_t*)p->b_perm.p;
@@ -668,6 +676,13 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   else
     hipLaunchKernelGGL(kas_order_round_for(p->Wc), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
+  if (wide_recheck) {
+    KasLaunch af = a;
+    af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~KAS_FLAG_WIDE_CHECK;
+    af.sp_flag = a.ord_flag;                                 // (same meaning: != 0, this kernel takes the scenario)
+    hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, af);
+    KAS_HIP_TRY(hipGetLastError());
+  }
   if (ctx_fallback) {
     a.flags |= KAS_FLAG_ORDER_FLAGGED;
     a.perm = nullptr;

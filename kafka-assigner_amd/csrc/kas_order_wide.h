@@ -17,9 +17,17 @@
 // and its tickets are all due.  One scenario per workgroup.
 //
 // What differs from the 3-wide kernel:
-//   * count[n][0..5) live in one uint64 per node as five 10-bit fields (bits 0, 10, 20, 32, 42)
-//     plus the commits on n (their sum) at bit 52.  Applicable while no node can hold 1023 rows of the scenario
-//     (the plan checks the bound; configs[4] has cap 981).
+//   * count[n][0..5) live in one uint64 per node as five count fields (bits 0, 10, 20, 32, 42) read as 10-bit
+//     values, plus the commits on n (their sum) in the 11 bits from bit 53.  Safe a priori while no node can
+//     hold 1023 rows of the scenario (the plan checks the bound; configs[4] has cap 981).  Up to 2039 rows per
+//     node (round 3) the kernel runs all the same and CHECKS: a count that outgrows 10 bits carries into the
+//     next field — or, for fields 2 and 4, which have 12 and 11 bits of room, grows past 1023 in place — so
+//     when the last row has retired "the five fields add up to the commits, and field 2 is below 1024" holds
+//     for every node exactly if no count was ever misread (counts only grow, and the counts a row of a joint
+//     step sees are counts the node really reaches).  The commits themselves cannot be touched: field 4 would
+//     have to pass 2047.  So a scenario that fails the check was solved on wrong counts but to the end (every
+//     pick is one of the row's holders whatever the counts, the relaxation rounds end with the dependency
+//     depth), it is flagged (KasLaunch::ord_flag) and solved again — fill and round form — behind this kernel.
 //   * holders are stored ascending (Sets.newTreeSet, KAS:228) and the picks are the general
 //     "minimum of (count, visit position) over the nodes still in the set" of pick_row<W>
 //     (KAS:263-278), five times; the rotation offsets idx_m = abs(hash) % m travel in the slot.
@@ -100,7 +108,8 @@ namespace kas {
 #define KAS_WIDE_SIDE 1
 #endif
 #define KAS_WIDE_FIELD_MASK 0x3ffu
-#define KAS_WIDE_DUMMY_TICKET 0xfff                      // the padding holder's ticket == its row's commits field
+#define KAS_WIDE_COMMIT_SHIFT 53                          // commits of a node: 11 bits from here (bit 21 of the high word)
+#define KAS_WIDE_DUMMY_TICKET 0x7ff                      // the padding holder's ticket == its row's commits field
 
 struct alignas(16) WideSlot { int32_t tag; int32_t e[5]; int32_t rot; int32_t spare; };
 // tag: KAS_TAG_FREE / KAS_TAG_END as in the 3-wide kernel
@@ -112,11 +121,12 @@ struct alignas(16) WideSlot { int32_t tag; int32_t e[5]; int32_t rot; int32_t sp
 // slot.rot = TileIter::rot of a wide iterator: idx_m = Math.abs(hash) % m (KAS:190) for set sizes m = 1..5, 3 bits each
 // at bit 3 m (computed per topic by tile_next_topic)
 
-// counter row of a node: five 10-bit counts at bits 0, 10, 20, 32, 42 (.. 51) and the number of rows
-// that committed on the node (= their sum, kept separately so that readiness is one shift) in the
-// 12 bits from bit 52 (a node holds fewer than 1023 rows of the scenario: the plan checks)
+// counter row of a node: five counts at bits 0, 10, 20, 32, 42 (read as 10-bit fields; field 2 has room up to
+// bit 31, field 4 up to bit 52) and the number of rows that committed on the node (= their sum, kept
+// separately so that readiness is one shift) in the 11 bits from bit 53 (a node holds fewer than
+// KAS_WIDE_COMMIT_LIMIT rows of the scenario: the plan checks)
 KAS_DEV uint64_t wide_field_unit(int r) {                   // + 1 on count field r and on the commits
-  return (1ull << 52) +
+  return (1ull << KAS_WIDE_COMMIT_SHIFT) +
          (r == 0 ? 1ull : r == 1 ? (1ull << 10) : r == 2 ? (1ull << 20) : r == 3 ? (1ull << 32) : (1ull << 42));
 }
 
@@ -222,7 +232,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   kasw::sync();
   if (wave == 0 && lane == 0) {
     // the padding holder's row: counts that never matter, commits == the dummy ticket
-    cnt[nmax] = ((uint64_t)KAS_WIDE_DUMMY_TICKET << 52) | ((uint64_t)0xfffffu << 32) | 0x3fffffffull;
+    cnt[nmax] = ((uint64_t)KAS_WIDE_DUMMY_TICKET << KAS_WIDE_COMMIT_SHIFT) | ((uint64_t)0xfffffu << 32) | 0x3fffffffull;
     gdig[0] = 0ull;
     *wd = 0u;
   }
@@ -266,7 +276,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
                                hi & KAS_WIDE_FIELD_MASK, (hi >> 10) & KAS_WIDE_FIELD_MASK};
 #pragma unroll
         for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];   // (the last index is never compared: dead code)
-        d[q] = ((uint32_t)e[q] >> 16) - (hi >> 20);           // ticket - commits on the node
+        d[q] = ((uint32_t)e[q] >> 16) - (hi >> (KAS_WIDE_COMMIT_SHIFT - 32));   // ticket - commits on the node
 #if KAS_WIDE_JOINT
         xlo[q] = lo; xhi[q] = hi;
 #endif
@@ -923,6 +933,21 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       const uint64_t x = cnt[n];
       for (int32_t r = 0; r < ccols; ++r)
         g_ctx[(int64_t)n * sd.ctx_width + r] = (int32_t)((x >> (r < 3 ? 10 * r : 32 + 10 * (r - 3))) & KAS_WIDE_FIELD_MASK);
+    }
+    // ... and without a Context, where the plan could not bound the counts a priori: did every count stay
+    // inside the 10 bits it is read with?  (header of this file)
+    if ((a.flags & KAS_FLAG_WIDE_CHECK) && have_s && ccols == 0 && a.ord_flag) {
+      bool bad = false;
+      for (int32_t n = lane; n < sd.n_nodes; n += 64) {
+        const uint64_t x = cnt[n];
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        const uint32_t f2 = lo >> 20, f4 = (hi >> 10) & 0x7ffu;                  // (with their room)
+        const uint32_t sum = (lo & KAS_WIDE_FIELD_MASK) + ((lo >> 10) & KAS_WIDE_FIELD_MASK) + f2 +
+                             (hi & KAS_WIDE_FIELD_MASK) + f4;
+        bad = bad || sum != (hi >> (KAS_WIDE_COMMIT_SHIFT - 32)) || f2 > KAS_WIDE_FIELD_MASK ||
+              (W > 4 ? false : f4 != 0u);
+      }
+      if (kasw::ballot(bad) != 0ull && lane == 0) a.ord_flag[s] = 1;
     }
     if (KAS_SPIN_BOUND > 0 && have_s && lane == 0 && *(volatile uint32_t*)wd != 0u) {
       a.scenario_results[s].status = KAS_FAIL_WATCHDOG;

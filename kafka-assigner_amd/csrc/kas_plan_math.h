@@ -59,6 +59,7 @@ struct KasLaunch {
 #define KAS_FLAG_SPREAD_FILL  32u  // spread fill also for small scenarios, with few chunks (testing / comparison)
 #define KAS_FLAG_ONLY_FLAGGED 64u  // set by the launcher: the fill kernel takes only the scenarios the spread fill handed back
 #define KAS_FLAG_ORDER_FLAGGED 128u // set by the launcher: the round-form order kernel takes only scenarios with ord_flag set
+#define KAS_FLAG_WIDE_CHECK   256u  // set by the launcher (KasShape::wide_checked): the wide ticket form checks its count fields at the end
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
@@ -191,6 +192,11 @@ KAS_ABI_FN KasLds kas_spread_scan_lds(int32_t n_max, int32_t W, int32_t idmap_en
 #define KAS_RING_SLOTS 4
 #endif
 #define KAS_PACKED_TICKET_LIMIT 1023
+// wide ticket form (kas_order_wide.h): the commits of a node are an 11-bit field, and count field 4 — 11 bits,
+// next to it — must not carry into them whatever the counts do: a node holds fewer rows than this.  Between
+// KAS_PACKED_TICKET_LIMIT and this bound the 10-bit count fields are not safe a priori; the kernel checks them
+// when the last row has retired (KasShape::wide_checked).
+#define KAS_WIDE_COMMIT_LIMIT 2040
 KAS_ABI_FN int32_t kas_order_ticket_group_bytes(int32_t n_max, int32_t G, int32_t packed) {
   int64_t n = n_max > 0 ? n_max : 1;
   (void)G;
@@ -263,6 +269,9 @@ struct KasShape {
   int32_t bound_small = 1;            // every scenario's ticket bound fits 10-bit counter fields
   int32_t any_ctx = 0;                // some scenario hands a Context in / wants it back
   int32_t wide_ok = 0;                // lists 4 or 5 wide and the wide ticket form is applicable
+  int32_t bound_mid = 1;              // every scenario's ticket bound is below KAS_WIDE_COMMIT_LIMIT
+  int32_t wide_checked = 0;           // wide_ok with a ticket bound of 1023 or more somewhere: the kernel checks its count
+                                      // fields at the end and a scenario that outgrew them is solved again (fill + round form)
   int32_t round_fits = 1;             // the round form's LDS (int32 counters + 64-bit masks) fits 160 KiB
   int32_t fused_ok = 0;               // rack-diverse fill with per-chunk histograms (no chunk-count pass)
   KasLds lds_fused{};                 // its LDS carve-up (valid when fused_ok)
@@ -410,6 +419,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     }
     if (ticket_bound >= KAS_TICKET_LIMIT) s.tickets_ok = 0;
     if (ticket_bound >= KAS_PACKED_TICKET_LIMIT) s.bound_small = 0;
+    if (ticket_bound >= KAS_WIDE_COMMIT_LIMIT) s.bound_mid = 0;
     s.accmask_off[(size_t)i] = s.accmask_words;
     s.accmask_words += words > 0 ? words : 1;
     s.orph_off[(size_t)i] = s.orph_ints;
@@ -424,8 +434,12 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // lists 4 and 5 wide: the wide ticket form (kas_order_wide.h) under the same conditions plus 10-bit
   // count fields and 16-bit LDS offsets of its 8-byte counter rows; beyond 5: round form
   s.packed_ok = s.bound_small && !s.any_ctx;
-  s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_small && 8 * ((int64_t)s.n_max + 1) <= 65536 &&
-              kas_order_wide_lds(s.n_max) <= KAS_LDS_LIMIT;
+  // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
+  // to the round form — which must then fit)
+  s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&
+              kas_order_wide_lds(s.n_max) <= KAS_LDS_LIMIT &&
+              (s.bound_small || kas_order_round_lds(s.n_max, s.Wc) <= KAS_LDS_LIMIT);
+  s.wide_checked = s.wide_ok && !s.bound_small;
   if (s.Wc > 3) s.tickets_ok = 0;              // ring slots / packed counter rows hold lists up to 3
   // widest fill workgroup whose LDS carve-up fits: 4 wavefronts per scenario by default
   int err_total = 0;

@@ -53,7 +53,10 @@ for step in "$@"; do
       timeout 300 python bench.py --no-cpu --no-extras --repeats 1 --check 2 --scenarios 8 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 5 --warmup 1 > $O/bench_config5_x8.log 2>&1
       echo "configs[4] x8: ms_per_step $(val ms_per_step $O/bench_config5_x8.log)"
       timeout 600 python bench.py --no-cpu --no-extras --repeats 1 --check 2 --scenarios 64 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 3 --warmup 1 > $O/bench_config5_x64.log 2>&1
-      echo "configs[4] x64: ms_per_step $(val ms_per_step $O/bench_config5_x64.log) $(grep -o '"in_flight_launch": {[^}]*' $O/bench_config5_x64.log | cut -c1-110)" ;;
+      echo "configs[4] x64: ms_per_step $(val ms_per_step $O/bench_config5_x64.log) $(grep -o '"in_flight_launch": {[^}]*' $O/bench_config5_x64.log | cut -c1-110)"
+      # beyond the 10-bit bound of the wide form's count fields (1,079 rows per broker): wide form with its check, and the round form it used to drop to
+      c5 bench_1100k_5k_rf5_wide_checked --actions c5 --partitions 1100000
+      c5 bench_1100k_5k_rf5_round_form --actions c5 --partitions 1100000 --plan-flags 2 --steps 1 --warmup 1 ;;
     stress)
       timeout 900 python scripts/stress_inflight.py --suite 1000 > $O/stress_inflight.log 2>&1; echo "stress exit $?" >> $O/stress_inflight.log; grep -v "plan:" $O/stress_inflight.log | cut -c1-220 ;;
     trace)
@@ -102,6 +105,9 @@ d = json.load(open(sys.argv[1]))
 print("   stats:", " ".join("%s %.0f" % (k, d[k]["mean"]) for k in ("solver_iterations", "solver_blocked", "stager_iterations", "stager_idle", "p5_rounds_or_queue_steps", "order_us", "solver_rows_in_hand", "p2_ranked_tiles_wave0", "p4_windows", "p4_steps") if k in d))
 PY
       ;;
+    big)
+      c5 bench_1100k_5k_rf5_wide_checked --actions c5 --partitions 1100000
+      c5 bench_1100k_5k_rf5_round_form --actions c5 --partitions 1100000 --plan-flags 2 --steps 1 --warmup 1 ;;
     c5:*)
       lib=${step#c5:}
       if [ "$lib" == "-" ]; then c5 bench_c5_product --actions c5; else KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5_v_$lib --actions c5 --stats $O/stats_c5_$lib.json; fi ;;

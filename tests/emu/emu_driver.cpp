@@ -369,6 +369,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
       }
     }
   } else if (wide) {
+    if (sh.wide_checked) a.flags |= KAS_FLAG_WIDE_CHECK;   // as kas_solve_device
     run_fn f = sh.Wc == 4 ? run_order_wide<4> : run_order_wide<5>;
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(lds.data(), 0xCD, lds.size());
@@ -394,7 +395,20 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
       if (kasw::run_block(f, &ra, 1) != 0) return bad("order (rounds)", s);
     }
   }
-  if (sh.any_ctx && (tickets || wide)) {
+  const bool wide_recheck = wide && sh.wide_checked;
+  if (wide_recheck) {
+    // as kas_solve_device: a scenario whose counts outgrew the wide form's fields is filled again ...
+    KasLaunch af = a;
+    af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~KAS_FLAG_WIDE_CHECK;
+    af.sp_flag = ord_flag.data();
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(lds.data(), 0xCD, lds.size());
+      RunArgs ra{&af, s, lds.data()};
+      if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill (flagged by the wide form)", s);
+    }
+    a.flags &= ~KAS_FLAG_WIDE_CHECK;
+  }
+  if ((sh.any_ctx && (tickets || wide)) || wide_recheck) {
     // as kas_solve_device: the round form behind a ticket form, taking only what that one flagged
     a.flags |= KAS_FLAG_ORDER_FLAGGED;
     a.perm = nullptr;
@@ -410,7 +424,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
 }
 
 // The product's planning decision for a batch shape, without running anything (plan-math tests):
-// out[0..7] = tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok.  Returns kas_shape_batch's code.
+// out[0..8] = tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok, wide_checked.  Returns kas_shape_batch's code.
 extern "C" __attribute__((visibility("default")))
 int kas_emu_shape(const kas_batch_desc* b, int32_t* out, char* errbuf, int errlen) {
   KasShape sh;
@@ -421,7 +435,7 @@ int kas_emu_shape(const kas_batch_desc* b, int32_t* out, char* errbuf, int errle
     return rc;
   }
   out[0] = sh.tickets_ok; out[1] = sh.wide_ok; out[2] = sh.round_fits; out[3] = sh.G; out[4] = sh.NW;
-  out[5] = sh.with_x; out[6] = sh.packed_ok; out[7] = sh.fused_ok;
+  out[5] = sh.with_x; out[6] = sh.packed_ok; out[7] = sh.fused_ok; out[8] = sh.wide_checked;
   return rc;
 }
 

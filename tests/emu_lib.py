@@ -104,20 +104,21 @@ def last_spread() -> int:
 
 def plan_shape(fb: FlatBatch):
     """kas_shape_batch's verdict on a batch shape (the product's planning code, nothing is run):
-    (return code, {tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok}, error text)."""
+    (return code, {tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok, wide_checked}, error text)."""
     L = lib()
     L.kas_emu_shape.restype = C.c_int
     L.kas_emu_shape.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(C.c_int32), C.c_char_p, C.c_int]
     bd = batch_desc(fb)
-    out = (C.c_int32 * 8)()
+    out = (C.c_int32 * 9)()
     err = C.create_string_buffer(512)
     rc = L.kas_emu_shape(C.byref(bd), out, err, 512)
-    names = ("tickets_ok", "wide_ok", "round_fits", "G", "NW", "with_x", "packed_ok", "fused_ok")
+    names = ("tickets_ok", "wide_ok", "round_fits", "G", "NW", "with_x", "packed_ok", "fused_ok", "wide_checked")
     return rc, dict(zip(names, list(out))), err.value.decode()
 
 
 def last_flagged() -> int:
-    """Scenarios a ticket form left to the round form in the last emu_solve (Context counters beyond its count fields)."""
+    """Scenarios a ticket form left to the round form in the last emu_solve (Context counters beyond its count fields;
+    wide form: counts that outgrew the fields, found by its check at the end)."""
     L = lib()
     L.kas_emu_last_flagged.restype = C.c_int
     return int(L.kas_emu_last_flagged())

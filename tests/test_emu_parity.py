@@ -290,6 +290,66 @@ def test_emu_wide_lists_counts_near_the_field_limit():
     assert_same_outputs(fb, want, emu_solve(fb), "emu wide, counts near the field limit")
 
 
+@pytest.mark.timeout(900)
+def test_emu_wide_lists_a_broker_holding_1023_rows_or_more_keeps_the_wide_ticket_form():
+    """Round 3: up to 2,039 rows per broker the wide form runs and checks its 10-bit count fields when the last row
+    has retired (they add up to the commits, field 2 stays below 1024).  Five-wide lists over 22 brokers, 4,600
+    partitions: a broker holds 1,046 rows, at most 360 of them at one list position — nothing outgrows its field,
+    the scenario is solved by the wide form alone."""
+    from emu_lib import last_flagged, last_order_form, plan_shape
+    fb = _batch(31, 1, 4600, 20, 10, 5, ("add_k",), rack_aware=False)
+    rc, sh, err = plan_shape(fb)
+    assert rc == 0 and sh["wide_ok"] == 1 and sh["wide_checked"] == 1, (rc, sh, err)
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).all()
+    assert np.bincount(want.out[:4600 * 5]).max() >= 1023
+    got = emu_solve(fb)
+    assert last_order_form() == 2 and last_flagged() == 0
+    assert_same_outputs(fb, want, got, "emu wide, 1046 rows per broker")
+
+
+def _wide_batch_whose_counts_outgrow_the_fields():
+    """Scenario 0: one replica per partition in four-wide rows over two brokers (count[broker][0] reaches 1,050);
+    scenario 1: a balanced two-replica assignment over nine brokers that nothing has to be moved in."""
+    from kafka_assigner_amd.flatten import FlatBatch
+    P, W = 2100, 4
+    rng = np.random.default_rng(5)
+    scen = np.zeros(2, dtype=abi.SCENARIO_DESC_DTYPE)
+    topics = np.zeros(2, dtype=abi.TOPIC_DESC_DTYPE)
+    node_id = np.array([7, 9, 1, 2, 3, 4, 5, 6, 8, 10, 12], dtype=np.int32)
+    node_rack = np.array([0, 1, 0, 1, 2, 3, 4, 5, 6, 7, 8], dtype=np.int32)
+    scen[0] = (2, 0, 1, 0, 0, -1)                  # two brokers, rf 1: 1,050 rows each, all at position 0
+    scen[1] = (9, 1, 1, 0, 2, -1)                  # nine brokers, rf 2: 467 rows each
+    topics[0] = (3644, P, 1, 1, W, 0, 0, 0, -1, -1, -1)                # (cur one wide, rf 1, rows of the batch's width)
+    topics[1] = (3644, P, 2, 2, W, 0, P, P * W, -1, -1, -1)
+    cur0 = rng.choice(np.array([7, 9, 11]), size=(P, 1)).astype(np.int32)   # (11 is gone: its rows are orphans)
+    ids1 = np.array([1, 2, 3, 4, 5, 6, 8, 10, 12])
+    rows = np.arange(P)
+    cur1 = np.stack([ids1[rows % 9], ids1[(rows + 1 + (rows // 9) % 7) % 9]], axis=1).astype(np.int32)   # balanced: nothing moves
+    fb = FlatBatch(scen=scen, topics=topics, node_id=node_id, node_rack=node_rack,
+                   cur=np.concatenate([cur0.reshape(-1), cur1.reshape(-1)]).astype(np.int32),
+                   aux=np.zeros(0, np.int32), ctx=np.zeros(0, np.int32), out_len=2 * P * W)
+    return fb, P, W
+
+
+@pytest.mark.timeout(900)
+def test_emu_wide_lists_counts_that_outgrow_the_fields_are_found_and_the_scenario_is_solved_again():
+    """One replica per partition in four-wide rows over two brokers: every row a broker holds counts at list position
+    0, so count[broker][0] passes 1023 and carries into the next field.  The wide form finishes the scenario on wrong
+    counts, its check at the end flags it, and the fill kernel and the round form solve it again from `cur` —
+    beside a scenario of the same batch that stays inside the fields and is not touched."""
+    from emu_lib import last_flagged, last_order_form, plan_shape
+    fb, P, W = _wide_batch_whose_counts_outgrow_the_fields()
+    rc, sh, err = plan_shape(fb)
+    assert rc == 0 and sh["wide_ok"] == 1 and sh["wide_checked"] == 1, (rc, sh, err)
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).all()
+    assert np.bincount(want.out[:P * W].reshape(P, W)[:, 0]).max() >= 1024
+    got = emu_solve(fb)
+    assert last_order_form() == 2 and last_flagged() == 1
+    assert_same_outputs(fb, want, got, "emu wide, count[.][0] beyond 1023")
+
+
 SPREAD = 32        # KAS_PLAN_SPREAD_FILL
 
 

@@ -44,6 +44,21 @@ def test_wide_lists_take_the_wide_ticket_form_also_where_the_round_form_does_not
     assert rc == 0 and sh["wide_ok"] == 1 and sh["tickets_ok"] == 0
 
 
+def test_wide_form_is_kept_up_to_2039_rows_per_broker_with_its_count_fields_checked():
+    """Round 3: lists 4-5 wide.  Below 1,023 rows per broker the 10-bit count fields are safe a priori; from there up
+    to 2,039 (the 11-bit commits field) the wide form runs with its check at the end; beyond that the round form."""
+    rc, sh, _ = _shape(5000, 5, P=1000000)           # BASELINE configs[4]: 1,000 rows per broker
+    assert rc == 0 and sh["wide_ok"] == 1 and sh["wide_checked"] == 0
+    rc, sh, _ = _shape(5000, 5, P=1100000)           # 1,100
+    assert rc == 0 and sh["wide_ok"] == 1 and sh["wide_checked"] == 1 and sh["round_fits"] == 1
+    rc, sh, _ = _shape(100, 4, P=50000)              # 2,000
+    assert rc == 0 and sh["wide_ok"] == 1 and sh["wide_checked"] == 1
+    rc, sh, _ = _shape(100, 4, P=51000)              # 2,040: the round form
+    assert rc == 0 and sh["wide_ok"] == 0 and sh["wide_checked"] == 0 and sh["round_fits"] == 1
+    rc, sh, _ = _shape(6200, 5, P=1300000)           # 1,049 rows per broker, but no room for the round form to fall back on
+    assert (rc != 0) or sh["wide_checked"] == 0
+
+
 def test_spread_scan_kernels_fit_two_to_a_cu_at_5000_brokers_and_their_chunks_fit_uint16_cells():
     """Round 3: passes A and B of the spread fill carry only what they touch (71 / 61 KB instead of the
     one-workgroup layout's 145 KB at BASELINE configs[4]), and pass A counts in uint16 cells: a chunk stays
