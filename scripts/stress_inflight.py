@@ -42,6 +42,9 @@ SUITE = [
     ("lists 4 wide: wide ticket form", "kas_order_wide_kernel<4>",
      ["--scenarios", "96", "--partitions", "40000", "--brokers", "600", "--racks", "40", "--rf", "4",
       "--actions", "add_k,mixed,remove_k", "--in-flight", "6"]),
+    ("lists 5 wide, 1,150 rows per broker: wide ticket form with its count fields checked at the end", "count fields checked",
+     ["--scenarios", "32", "--partitions", "46000", "--brokers", "200", "--racks", "20", "--rf", "5",
+      "--actions", "add_k,mixed", "--in-flight", "4"]),
     ("spread fill (row scans over one-wavefront workgroups, kas_spread_p4_kernel) + wide ticket form", "kas_spread_",
      ["--scenarios", "16", "--partitions", "140000", "--brokers", "800", "--racks", "40", "--rf", "5",
       "--actions", "add_k,mixed", "--in-flight", "3"]),
