@@ -463,9 +463,13 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // groups' regions do not fit 64 KiB, no ticket form at all when one region does not — decided
   // BEFORE the fallback check below, so that a plan no order kernel can serve is refused here and
   // not at its first launch.
+  // (what is addressed that way are the counter rows, which come first in a group's region: with ONE group they
+  // have to end below 64 KiB, not the lane masks and ticket counts behind them — round 3: one group serves up to
+  // 8,191 brokers instead of 4,680.  Several groups keep the old rule, every region below 64 KiB: where two
+  // regions no longer fit that, one scenario per wavefront at three workgroups per CU is the better plan anyway.)
   s.G = want_groups > 0 ? want_groups : 2;
   while (s.G > 1 && (int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.G >>= 1;
-  if ((int64_t)s.G * kas_order_ticket_group_bytes(s.n_max, s.G, 0) > 65536) s.tickets_ok = 0;
+  if (s.G == 1 && (8 * ((int64_t)s.n_max + 1) > 65536 || kas_order_ticket_lds(s.n_max, 1, 0) > KAS_LDS_LIMIT)) s.tickets_ok = 0;
   // the round form of P5 is the universal fallback; a batch that one of the ticket forms serves does
   // not need it to fit (KAS_PLAN_ROUND_ORDER is refused for such a plan, see round_fits)
   s.round_fits = kas_order_round_lds(s.n_max, s.Wc) <= KAS_LDS_LIMIT;

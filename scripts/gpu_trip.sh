@@ -107,7 +107,10 @@ PY
       ;;
     big)
       c5 bench_1100k_5k_rf5_wide_checked --actions c5 --partitions 1100000
-      c5 bench_1100k_5k_rf5_round_form --actions c5 --partitions 1100000 --plan-flags 2 --steps 1 --warmup 1 ;;
+      c5 bench_1100k_5k_rf5_round_form --actions c5 --partitions 1100000 --plan-flags 2 --steps 1 --warmup 1
+      # lists 3 wide at 5,000 brokers: one group of the ticket form (round 2: the round form from 4,680 brokers on)
+      c5 bench_1m_5k_rf3_ticket_form --actions c5 --rf 3
+      c5 bench_1m_5k_rf3_round_form --actions c5 --rf 3 --plan-flags 2 --steps 1 --warmup 1 ;;
     c5:*)
       lib=${step#c5:}
       if [ "$lib" == "-" ]; then c5 bench_c5_product --actions c5; else KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5_v_$lib --actions c5 --stats $O/stats_c5_$lib.json; fi ;;

@@ -350,6 +350,23 @@ def test_emu_wide_lists_counts_that_outgrow_the_fields_are_found_and_the_scenari
     assert_same_outputs(fb, want, got, "emu wide, count[.][0] beyond 1023")
 
 
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("N,P", [(5000, 12000), (7400, 9000)])
+def test_emu_lists_3_wide_keep_the_ticket_form_up_to_8191_brokers(N, P):
+    """Round 3: one scenario per solver wavefront is limited by where its counter rows end (8 B per broker below
+    64 KiB), not by its whole LDS region: the ticket form serves up to 8,191 brokers (round 2: 4,680, the round
+    form beyond — which does not even fit from 6,800 on)."""
+    from emu_lib import last_order_form, plan_shape
+    fb = _batch(4242, 2, P, N, 25, 3, ("add_k", "mixed"))
+    rc, sh, err = plan_shape(fb)
+    assert rc == 0 and sh["tickets_ok"] == 1 and sh["G"] == 1, (rc, sh, err)
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).all()
+    got = emu_solve(fb)
+    assert last_order_form() == 1
+    assert_same_outputs(fb, want, got, f"emu ticket form, {N} brokers")
+
+
 SPREAD = 32        # KAS_PLAN_SPREAD_FILL
 
 

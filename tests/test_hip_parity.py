@@ -336,6 +336,22 @@ def test_wide_lists_a_broker_holding_1023_rows_or_more_keeps_the_wide_ticket_for
     assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip wide form, 110k x 500 x RF 5 (cap 1100)")
 
 
+@pytest.mark.parametrize("N,P", [(5000, 200000), (7400, 60000)])
+def test_lists_3_wide_keep_the_ticket_form_up_to_8191_brokers(N, P):
+    """Round 3: one scenario per solver wavefront is limited by where its counter rows end (8 B per broker below
+    64 KiB): 5,000 brokers x RF 3 used to take the one-wavefront round form (4,680 was the limit), and from 6,800
+    brokers on nothing served the shape."""
+    fb = _batch(4242, 4, P, N, 25, 3, ("add_k", "mixed"))
+    plan = native.Plan(native.default_context(), fb)
+    assert "kas_order_ticket_kernel<3,1," in plan.describe(), plan.describe()
+    plan.close()
+    want = oracle_solve(fb, threads=0)
+    assert (want.scenario_results["status"] == abi.KAS_OK).all()
+    assert_same_outputs(fb, want, native.solve_host(fb), f"hip ticket form, {N} brokers")
+    if N == 5000:
+        assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip round form, 5000 brokers")
+
+
 def test_1_1m_partitions_5k_brokers_rf5_keeps_the_wide_ticket_form():
     """The shape VERDICT round 2 named (1.1M x 5k, RF 5: a broker holds up to 1,079 rows — beyond the 10-bit bound of
     the wide form's count fields, which sent it to the one-wavefront round form, seconds per scenario): at full size,

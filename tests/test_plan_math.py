@@ -24,19 +24,27 @@ def test_groups_shrink_before_the_ticket_form_is_given_up():
     # 14 B of LDS per broker and scenario: two groups fit 64 KiB of 16-bit offsets up to ~2,340 brokers
     rc, sh, _ = _shape(3000, 3)
     assert rc == 0 and sh["tickets_ok"] == 1 and sh["G"] == 1
-    rc, sh, _ = _shape(5000, 3)                      # one group no longer fits: round form (24 B per broker)
-    assert rc == 0 and sh["tickets_ok"] == 0 and sh["round_fits"] == 1
+    # round 3: one group is limited by where its COUNTER ROWS end (8 B per broker below 64 KiB), not its whole region
+    rc, sh, _ = _shape(5000, 3)                      # (round 2: round form from 4,680 brokers on)
+    assert rc == 0 and sh["tickets_ok"] == 1 and sh["G"] == 1 and sh["round_fits"] == 1
+    rc, sh, _ = _shape(8191, 3)                      # the last broker count whose padding row has a 16-bit offset
+    assert rc == 0 and sh["tickets_ok"] == 1 and sh["G"] == 1 and sh["round_fits"] == 0
+    rc, _, err = _shape(8192, 3)
+    assert rc == abi.KAS_E_UNSUPPORTED and "LDS" in err
 
 
 def test_shape_that_no_order_kernel_serves_is_refused_at_plan_time():
     """at ~7,000 brokers x RF 3 the round form does not fit 160 KiB and the ticket form's
     counter rows leave the 16-bit offset range; the plan used to be created (tickets_ok was cleared
-    after the fallback check) and failed at its first launch with KAS_E_HIP."""
-    rc, _, err = _shape(7000, 3)
+    after the fallback check) and failed at its first launch with KAS_E_HIP.
+    (Round 3: the ticket form's limit moved to 8,191 brokers, so the shapes nothing serves start there.)"""
+    rc, _, err = _shape(9000, 3)
     assert rc == abi.KAS_E_UNSUPPORTED, (rc, err)
     assert "LDS" in err
+    rc, sh, _ = _shape(7000, 3)                      # beyond the round form's limit, inside the ticket form's
+    assert rc == 0 and sh["tickets_ok"] == 1 and sh["round_fits"] == 0
     rc, sh, _ = _shape(6800, 3)                      # just inside the round form's limit
-    assert rc == 0 and sh["tickets_ok"] == 0 and sh["round_fits"] == 1
+    assert rc == 0 and sh["tickets_ok"] == 1 and sh["round_fits"] == 1
 
 
 def test_wide_lists_take_the_wide_ticket_form_also_where_the_round_form_does_not_fit():
