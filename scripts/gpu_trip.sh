@@ -12,8 +12,9 @@
 #   pmc        rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one batch in flight)
 #   sq         rocprofv3 --pmc SQ_* passes, one batch alone and eight in flight
 #   ab:LIB     benchq with KAS_HIP_LIB=variants/libkas_hip_LIB.so (tuning builds, scripts/build_variant.sh)
-#   part:F[:N]  benchq with the CU partition: F fill CUs per XCD, N batches in flight
 #   c5:LIB     configs[4] x1 with that tuning build (LIB = - for the product library)
+#   random     scripts/stress_gpu.py 150: random shapes against the oracle, every plan variant
+#   big        shapes beyond round 2's limits: 1.1M x 5k x RF 5 (checked wide form / round form), 1M x 5k x RF 3 (ticket / round form)
 set -u
 NAME=$1; shift
 O=gpurun_out/$NAME
@@ -90,11 +91,6 @@ except Exception as e:
     print("   no stats:", e)
 PY
       grep -v '^{' $O/bench_v_$lib.log | tail -2 | cut -c1-200 ;;
-    part:*)      # part:F[:N] product library, F fill CUs per XCD (0 = shared), N batches in flight (default 8)
-      spec=${step#part:}; f=${spec%%:*}; nfl=8; [ "$spec" != "$f" ] && nfl=${spec#*:}
-      timeout 400 python bench.py --no-cpu --check 0 --no-extras --repeats 3 --fill-cus $f --in-flight $nfl ${PART_EXTRA:-} > $O/bench_part_${f}_$nfl.log 2>&1
-      echo "part fill_cus=$f in_flight=$nfl: value $(val value $O/bench_part_${f}_$nfl.log) $(grep -o '"values": \[[^]]*' $O/bench_part_${f}_$nfl.log | cut -c1-120) $(grep -o '"in_flight_launch": {[^}]*' $O/bench_part_${f}_$nfl.log | cut -c1-110)"
-      grep -v '^{' $O/bench_part_${f}_$nfl.log | grep -v amdgpu.ids | tail -2 | cut -c1-200 ;;
     ab1:*)
       lib=${step#ab1:}
       KAS_HIP_LIB=variants/libkas_hip_$lib.so timeout 400 python bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps 10 --in-flight 1 --stats $O/stats_v1_$lib.json > $O/bench_v1_$lib.log 2>&1
@@ -105,6 +101,8 @@ d = json.load(open(sys.argv[1]))
 print("   stats:", " ".join("%s %.0f" % (k, d[k]["mean"]) for k in ("solver_iterations", "solver_blocked", "stager_iterations", "stager_idle", "p5_rounds_or_queue_steps", "order_us", "solver_rows_in_hand", "p2_ranked_tiles_wave0", "p4_windows", "p4_steps") if k in d))
 PY
       ;;
+    random)   # randomised GPU-vs-oracle stress, 150 s of batches
+      timeout 400 python scripts/stress_gpu.py 150 > $O/stress_random.log 2>&1; echo "random stress exit $?" >> $O/stress_random.log; tail -2 $O/stress_random.log ;;
     big)
       c5 bench_1100k_5k_rf5_wide_checked --actions c5 --partitions 1100000
       c5 bench_1100k_5k_rf5_round_form --actions c5 --partitions 1100000 --plan-flags 2 --steps 1 --warmup 1

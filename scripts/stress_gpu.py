@@ -10,9 +10,56 @@ from test_emu_parity import _batch
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from kafka_assigner_amd import native, generator as G
+from kafka_assigner_amd import abi
+from kafka_assigner_amd.flatten import FlatBatch
 rng = np.random.default_rng(2026)
-t0 = time.time(); n = 0; q_rows = 0
+
+
+def thin_wide_batch(rng):
+    """Rows 4-5 wide holding 1-2 replicas over 2-4 brokers, 1,023 .. 2,039 rows per broker: the wide ticket form
+    with its count fields checked at the end — rf 1 puts every row of a broker at list position 0, so its count
+    passes 1,023 and the scenario is flagged and solved again (fill + round form); rf 2 stays inside the fields."""
+    W = int(rng.choice([4, 5])); rf = int(rng.choice([1, 2])); N = int(rng.choice([2, 3, 4]))
+    P = int(rng.integers(1023 * N // rf + 1, 2039 * N // rf))
+    S = int(rng.choice([1, 2, 3]))
+    scen = np.zeros(S, dtype=abi.SCENARIO_DESC_DTYPE); topics = np.zeros(S, dtype=abi.TOPIC_DESC_DTYPE)
+    ids_all, racks_all, curs = [], [], []
+    for s in range(S):
+        ids = np.sort(rng.choice(np.arange(1, 60), size=N, replace=False)).astype(np.int32)
+        gone = 77
+        rows = np.arange(P)
+        cur = np.stack([ids[(rows + k + (rows // N) % N) % N] for k in range(rf)], axis=1).astype(np.int32)
+        hit = rng.random(P) < float(rng.choice([0.0, 0.05, 0.3] if rf == 1 else [0.0, 0.0, 0.004]))   # (rf 2 at zero slack strands easily)
+        cur[hit, 0] = gone                                       # rows of a broker that is gone: orphans
+        scen[s] = (N, s, 1, 0, s * N, -1)
+        topics[s] = (int(rng.integers(1, 1 << 30)), P, rf, rf, W, 0, s * P * rf, s * P * W, -1, -1, -1)
+        ids_all.append(ids); racks_all.append(np.arange(N, dtype=np.int32)); curs.append(cur.reshape(-1))
+    return FlatBatch(scen=scen, topics=topics, node_id=np.concatenate(ids_all), node_rack=np.concatenate(racks_all),
+                     cur=np.concatenate(curs).astype(np.int32), aux=np.zeros(0, np.int32), ctx=np.zeros(0, np.int32),
+                     out_len=S * P * W), f"thin W{W} rf{rf} N{N} P{P} S{S}"
+
+
+t0 = time.time(); n = 0; q_rows = 0; n_thin = 0; n_big = 0
 while time.time() - t0 < float(sys.argv[1]):
+    kind = rng.random()
+    if kind < 0.12:                                              # the checked wide form and its second solve
+        fb, what = thin_wide_batch(rng)
+        want = oracle_solve(fb)
+        for flags in (0, 2):
+            got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
+            assert_same_outputs(fb, want, got, f"{what} flags {flags}")
+        n += 1; n_thin += 1
+        continue
+    if kind < 0.17:                                              # lists 3 wide, 3,000 .. 7,400 brokers: one group of the ticket form
+        N = int(rng.choice([3000, 5000, 7400])); P = int(rng.choice([8000, 30000]))
+        seed = int(rng.integers(1 << 30)); S = int(rng.choice([1, 2, 3]))
+        fb = _batch(seed, S, P, N, int(rng.choice([10, 25, 40])), int(rng.choice([2, 3])), ("add_k", "mixed", "remove_k"))
+        want = oracle_solve(fb)
+        for flags in (0, 4):
+            got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
+            assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} big-N flags {flags}")
+        n += 1; n_big += 1
+        continue
     N = int(rng.choice([8, 12, 20, 33, 64, 100, 150, 300, 500]))
     R = int(rng.choice([2, 3, 5, 8, 10, 20])); R = min(R, N)
     RF = int(rng.choice([2, 3, 3, 3, 4, 5])); RF = min(RF, R)     # 4, 5: the wide ticket form
@@ -27,4 +74,4 @@ while time.time() - t0 < float(sys.argv[1]):
         got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
     n += 1
-print("stress ok:", n, "random batches x 4 plan variants")
+print("stress ok:", n, "random batches x 2-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-7,400 brokers")
