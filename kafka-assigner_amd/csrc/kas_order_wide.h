@@ -41,24 +41,14 @@
 //     named nodes, and my side row, is in the set", and the picks are relaxed against per-node prefix
 //     sums of the wins (ballot + v_mbcnt over the rank layouts, added to the packed counter words)
 //     until nothing changes: the sequential answer, because the set is closed and the dependencies
-//     acyclic.  KAS_WIDE_JOINT 0 builds the single-node threshold queues of the 3-wide kernel,
-//     generalised to five picks (thresholds T_0..T_{L-2} from the other holders alone), instead.
+//     acyclic.  (Round 2 also carried the single-node threshold queues of the 3-wide kernel, generalised to
+//     five picks, as a build switch: 57.0 ms against 39.6 ms at configs[4]; removed in round 3, git has it.)
 #pragma once
 
 namespace kas {
 
-#ifndef KAS_WIDE_QUEUE_PASSES
-#define KAS_WIDE_QUEUE_PASSES 2
-#endif
-// a row waiting on exactly one node with this many rows ahead of it nominates that node
-#ifndef KAS_WIDE_NOMINATE
-#define KAS_WIDE_NOMINATE 2
-#endif
-// rows a queue must decide beyond the one that was ready anyway for the pass to count as paying;
-// below that the next nominations are skipped (1, 2, 4 ... up to KAS_WIDE_BACKOFF_MAX steps)
-// (measured at configs[4], round 2: gain >= 1 without back-off 83 ms, the 3-wide kernel's
-// gain >= 3 with back-off up to 16 steps 93 ms; nominating rank-1 rows as well 188 ms — the passes
-// are then spent on two-row queues while the long ones wait)
+// rows a joint step must decide beyond the ones that were ready anyway for it to count as paying;
+// below that the next attempts are skipped (1, 2, 4 ... up to KAS_WIDE_BACKOFF_MAX steps)
 #ifndef KAS_WIDE_MIN_GAIN
 #define KAS_WIDE_MIN_GAIN 1
 #endif
@@ -80,21 +70,14 @@ namespace kas {
 #define KAS_WIDE_STAGER 0
 #define KAS_WIDE_CHAIN_SOLVER 1
 #define KAS_WIDE_RETIRER 2
-// A queue usually breaks at a row that also waits for a row of its own tile; that row is free one
-// step later.  Skipping the queue pass of that step lets the next pass take the whole rest of the
-// queue instead of two passes taking half each.
+// steps without a joint attempt after one that paid (0: none)
 #ifndef KAS_WIDE_SKIP_AFTER_PASS
 #define KAS_WIDE_SKIP_AFTER_PASS 0
 #endif
-// Joint solve (KAS_WIDE_JOINT 1, the default): every row in hand whose pending holders are all among
-// KAS_WIDE_HOT nominated nodes — and whose predecessors on those nodes are in hand and decidable too — is
-// decided in one step, rows that sit in TWO queues included (0: the single-node threshold queues above).
-#ifndef KAS_WIDE_JOINT
-#define KAS_WIDE_JOINT 1
-#endif
-// naming the nodes of the joint solve: 0 = by rows that are third in line on one node and wait for nothing
-// else; k > 0 = every row with two or more rows ahead of it names its deepest queue, and the most named
-// nodes among the first KAS_WIDE_HOT + k names are taken
+// Joint solve: every row in hand whose pending holders are all among KAS_WIDE_HOT named nodes — and whose
+// predecessors on those nodes are in hand and decidable too — is decided in one step, rows that sit in TWO
+// queues included.  Naming: every row deep in a queue names its deepest one, and the most named nodes among
+// the first KAS_WIDE_HOT + KAS_WIDE_VOTE names are taken.
 #ifndef KAS_WIDE_VOTE
 #define KAS_WIDE_VOTE 1
 #endif
@@ -265,9 +248,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       // the counter rows of the row in hand
       int32_t c[W][W];                                      // c[k][r] = count[holder k][replica index r]
       uint32_t d[W];                                        // rows still ahead of mine on holder k
-#if KAS_WIDE_JOINT
       uint32_t xlo[W], xhi[W];                              // the counter rows as loaded (joint solve: packed adds)
-#endif
 #pragma unroll
       for (int q = 0; q < W; ++q) {
         const uint64_t x = *(const uint64_t*)(lds_raw + (e[q] & 0xffff));
@@ -277,17 +258,13 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
         for (int r = 0; r < W; ++r) c[q][r] = (int32_t)f[r];   // (the last index is never compared: dead code)
         d[q] = ((uint32_t)e[q] >> 16) - (hi >> (KAS_WIDE_COMMIT_SHIFT - 32));   // ticket - commits on the node
-#if KAS_WIDE_JOINT
         xlo[q] = lo; xhi[q] = hi;
-#endif
       }
       uint32_t d_any = 0u, d_sum = 0u;
-      int32_t nz = 0;                                       // holders I wait on
 #pragma unroll
-      for (int q = 0; q < W; ++q) { d_any |= d[q]; d_sum += d[q]; nz += d[q] != 0u ? 1 : 0; }
+      for (int q = 0; q < W; ++q) { d_any |= d[q]; d_sum += d[q]; }
       bool ready = cv && d_any == 0u;
       bool ready_q = false;                                 // decided inside a queue in this step
-#if KAS_WIDE_JOINT
       // ---- joint solve.  Up to KAS_WIDE_HOT nodes are named by rows that wait on one node only (the
       // brokers first fit is filling).  A row in hand is ELIGIBLE when it waits on named nodes only and,
       // on each of them, every row ahead of it (ranks 0 .. its own - 1, rank = ticket - commits) is in
@@ -305,27 +282,18 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       {
         uint64_t nb = 0ull;
         if (run_skip > 0) run_skip -= 1;
-#if KAS_WIDE_VOTE
         else nb = kasw::ballot(cv && d_any > (uint32_t)KAS_WIDE_VOTE_DEPTH);   // a row deep in some queue
-#else
-        else nb = kasw::ballot(cv && nz == 1 && d_sum == (uint32_t)KAS_WIDE_NOMINATE);   // third in line on X, free otherwise
-#endif
         if (nb != 0ull) {
           constexpr int KH = KAS_WIDE_HOT;
 #ifdef KAS_WIDE_DIAG
           const int64_t dg_t0 = kasw::clock_ticks();
 #endif
           int32_t my_ax = 0;
-#if KAS_WIDE_VOTE
           {                                                 // a row names the node on which most rows are ahead of it
             uint32_t dm = 0u;
 #pragma unroll
             for (int q = 0; q < W; ++q) { my_ax = d[q] > dm ? (e[q] & 0xffff) : my_ax; dm = d[q] > dm ? d[q] : dm; }
           }
-#else
-#pragma unroll
-          for (int q = 0; q < W; ++q) my_ax = d[q] != 0u ? (e[q] & 0xffff) : my_ax;       // (a nominating row waits on one node)
-#endif
           int32_t dcol[W];
 #pragma unroll
           for (int q = 0; q < W; ++q) dcol[q] = (int32_t)d[q];
@@ -333,7 +301,6 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           uint32_t kx[KH], d_hot = 0u;                      // my rank in its queue
           {
             uint64_t rest = nb;
-#if KAS_WIDE_VOTE
             // the KH most named nodes among the first KH + KAS_WIDE_VOTE candidates (names of the lowest lanes)
             constexpr int KC = KH + KAS_WIDE_VOTE;
             int32_t cand_ax[KC], cand_n[KC];
@@ -347,11 +314,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
                 rest &= ~sup;
               }
             }
-#endif
 #pragma unroll
             for (int h = 0; h < KH; ++h) {
               int32_t ax = -1;                              // (no holder entry has this address)
-#if KAS_WIDE_VOTE
               {
                 int32_t best = 0;
 #pragma unroll
@@ -359,10 +324,6 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
                 for (int k = 0; k < KC; ++k) cand_n[k] = cand_ax[k] == ax ? 0 : cand_n[k];
               }
-#else
-              if (rest != 0ull) ax = kasw::read_lane(my_ax, kasw::first_lane(rest));
-              rest &= ~kasw::ballot(my_ax == ax);
-#endif
               hq[h] = -1;
 #pragma unroll
               for (int q = 0; q < W; ++q) hq[h] = (e[q] & 0xffff) == ax ? q : hq[h];
@@ -547,132 +508,9 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
           }
         }
       }
-#else
-      // ---- queues: rows in hand that hold one node X and wait for nothing but X
-      {
-        uint64_t nb = 0ull;
-        if (run_skip > 0) run_skip -= 1;
-        else nb = kasw::ballot(cv && nz == 1 && d_sum == (uint32_t)KAS_WIDE_NOMINATE);   // third in line on X, free otherwise
-        int32_t my_ax = 0;
-#pragma unroll
-        for (int q = 0; q < W; ++q) my_ax = d[q] != 0u ? (e[q] & 0xffff) : my_ax;       // (a nominating row waits on one node)
-#pragma unroll 1
-        for (int pass = 0; pass < KAS_WIDE_QUEUE_PASSES && nb != 0ull; ++pass) {
-          const int32_t ax = kasw::read_lane(my_ax, kasw::first_lane(nb));              // X's counter row
-          int32_t hx = -1;                                  // where X sits in my (ascending) list
-#pragma unroll
-          for (int q = 0; q < W; ++q) hx = (e[q] & 0xffff) == ax ? q : hx;
-          const int32_t hq = hx >= 0 ? hx : 0;
-          int32_t dcol[W];
-#pragma unroll
-          for (int q = 0; q < W; ++q) dcol[q] = (int32_t)d[q];
-          const uint32_t kx = (uint32_t)sel<W>(dcol, hq);    // my rank in X's queue
-          // candidates: rows in hand that hold X and wait for nothing else (rank 0 = the ready one)
-          const bool cand = cv && !ready_q && hx >= 0 && d_sum == kx && kx < 64u;
-          n_runs += 1;
-          const uint32_t seq = (uint32_t)(n_runs & 0xffffff);             // never 0: stale and initial entries differ
-          if (cand) rank_owner[(int32_t)kx] = (seq << 8) | (uint32_t)lane;
-          kasw::lockstep();
-          const uint32_t ow = rank_owner[lane];             // rank view: lane = rank
-          kasw::lockstep();
-          const bool have = (ow >> 8) == seq;
-          const uint64_t hb = kasw::ballot(have);
-          const int32_t qlen = ~hb != 0ull ? kasw::first_lane(~hb) : 64;   // ranks 0..qlen-1 are all in hand
-          const bool member = cand && (int32_t)kx < qlen;
-#ifdef KAS_WIDE_DIAG
-          dg_hold += kasw::popc(kasw::ballot(cv && hx >= 0));
-          dg_cand += kasw::popc(kasw::ballot(cand));
-          dg_qlen += qlen;
-          dg_inhand += kasw::popc(kasw::ballot(cv));
-#endif
-          const int32_t gain = kasw::popc(kasw::ballot(member && kx > 0u));
-          if (gain < KAS_WIDE_MIN_GAIN) {
-            run_backoff = run_backoff == 0 ? 1 : (run_backoff < KAS_WIDE_BACKOFF_MAX ? 2 * run_backoff : KAS_WIDE_BACKOFF_MAX);
-            run_skip = KAS_WIDE_BACKOFF_MAX > 0 ? run_backoff : 0;
-          } else {
-            if (gain > KAS_WIDE_MIN_GAIN) run_backoff = 0;
-            run_skip = KAS_WIDE_SKIP_AFTER_PASS;            // steps without a queue pass after one that paid
-            // thresholds of my row against X (relative to X's counts now): X takes pick r iff
-            // count[X][r] + (wins of the rows ahead of me at r) < T_r, the other holders being free
-            int32_t cX[W];
-#pragma unroll
-            for (int r = 0; r < W; ++r) {
-              int32_t col[W];
-#pragma unroll
-              for (int q = 0; q < W; ++q) col[q] = c[q][r];
-              cX[r] = sel<W>(col, hq);
-            }
-            const uint32_t xbit = 1u << hq;
-            uint32_t alive_o = ((1u << Lp) - 1u) & ~xbit;
-            int32_t tpack = 0;
-#pragma unroll
-            for (int r = 0; r < T; ++r) {
-              const uint32_t setmask = alive_o | xbit;
-              const int32_t m = __builtin_popcount(setmask);
-              const int32_t idx = (rot >> (3 * m)) & 7;
-              int32_t keys[W], best = 0x7fffffff, rank = idx, rrX = 0;
-#pragma unroll
-              for (int k = 0; k < W; ++k) {
-                const int32_t in = (int32_t)((setmask >> k) & 1u);
-                const int32_t rr = rank >= m ? rank - m : rank;
-                const bool other = ((alive_o >> k) & 1u) != 0u;
-                keys[k] = other ? ((c[k][r] << 3) | rr) : 0x7fffffff;
-                best = keys[k] < best ? keys[k] : best;
-                rrX = hq == k ? rr : rrX;
-                rank += in;
-              }
-              int32_t bestk = 0;
-#pragma unroll
-              for (int k = 1; k < W; ++k) bestk = keys[k] == best ? k : bestk;
-              // (c << 3 | rrX) < best  <=>  c < ceil((best - rrX) / 8); nobody else left: always
-              int32_t t = alive_o != 0u ? ((best - rrX + 7) >> 3) - cX[r] : 127;
-              t = t < 0 ? 0 : (t > 127 ? 127 : t);
-              tpack |= t << (8 * r);
-              alive_o = alive_o != 0u ? (alive_o & ~(1u << bestk)) : 0u;   // the winner among the others leaves
-            }
-            const int32_t th = kasw::shfl(tpack, have ? (int32_t)(ow & 0xffu) : lane);   // owner -> rank view
-            const bool act = lane < qlen;
-            int32_t pre[T];
-#pragma unroll
-            for (int r = 0; r < T; ++r) pre[r] = 0;
-            for (;;) {
-              n_relax += 1;
-              bool won = false, moved = false;
-              int32_t np[T];
-#pragma unroll
-              for (int r = 0; r < T; ++r) {
-                const bool win = act && !won && pre[r] < ((th >> (8 * r)) & 0xff);
-                won = won || win;
-                np[r] = kasw::count_below(kasw::ballot(win));
-              }
-#pragma unroll
-              for (int r = 0; r < T; ++r) { moved = moved || (act && np[r] != pre[r]); pre[r] = np[r]; }
-              if (kasw::ballot(moved) == 0ull) break;
-            }
-            int32_t ppack = 0;
-#pragma unroll
-            for (int r = 0; r < T; ++r) ppack |= pre[r] << (8 * r);
-            const int32_t back = kasw::shfl(ppack, member ? (int32_t)kx : lane);   // rank view -> owner
-#pragma unroll
-            for (int q = 0; q < W; ++q)
-#pragma unroll
-              for (int r = 0; r < T; ++r)
-                c[q][r] += (member && hx == q) ? ((back >> (8 * r)) & 0xff) : 0;
-            n_run_rows += (member && kx > 0u) ? 1 : 0;
-            ready_q = ready_q || member;
-          }
-          nb &= ~kasw::ballot(my_ax == ax);                 // next: a nominated row of another node
-        }
-      }
-#endif
       ready = ready || ready_q;
       if (ready) {                                          // (a step in which nothing is ready skips all of it)
-#if KAS_WIDE_JOINT
         if (!have_pos) pick_row_packed<W>(c, Lp, cv, rot, pos);          // (wave-uniform test)
-#else
-        int32_t pos[W];
-        pick_row_packed<W>(c, Lp, cv, rot, pos);
-#endif
         // updateCountersFromList (KAS:254-261): count[node][r] += 1 (positions behind the list: + 0)
         int32_t tag = KAS_WTAG_DONE | (Lp << 15);
 #pragma unroll
@@ -718,7 +556,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
         if (cls == 1) {
           st[8] = kasw::clock_ticks() - t_begin; st[9] = n_iter; st[10] = n_relax; st[11] = n_blocked;
-          st[14] = run_rows; st[6] = KAS_WIDE_JOINT ? n_closure : n_runs;
+          st[14] = run_rows; st[6] = n_closure;
 #ifdef KAS_WIDE_DIAG
           st[4] = dg_hold; st[5] = dg_cand; st[7] = dg_qlen; st[3] = dg_inhand;
           st[0] = dg_c1; st[1] = dg_c2; st[2] = dg_c4; st[13] = dg_steps;

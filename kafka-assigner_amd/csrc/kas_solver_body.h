@@ -1823,13 +1823,6 @@ KAS_DEV void order_permutation(const KasLaunch& a, unsigned char* lds_raw) {
 #ifndef KAS_RING_SLOTS
 #define KAS_RING_SLOTS 4
 #endif
-#ifndef KAS_RETIRE_PAD_STYLE
-#define KAS_RETIRE_PAD_STYLE 0
-#endif
-// solver lanes claim rows dynamically (1) or own a column of the ring (0: round 1's form)
-#ifndef KAS_CLAIM_ROWS
-#define KAS_CLAIM_ROWS 1
-#endif
 // rows a run must decide beyond the ones that were ready anyway for its path to pay
 // a row waiting on exactly one node with this many rows ahead of it nominates the node
 #ifndef KAS_RUN_NOMINATE
@@ -2083,7 +2076,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     // ------------------------------------------------------------------ solver: LDS only
     // cur = the row being decided, nxt = the lane's following row, read ahead from the ring so
     // that taking it costs no LDS round trip of its own
-#if KAS_CLAIM_ROWS
     // Rows are not tied to lanes: a lane without a row CLAIMS the next unclaimed row of its scenario
     // (rows in tile order: virtual row v = tile * GL + column lives in ring slot (tile % K, column)),
     // so the GL lanes of a group always hold the oldest rows that are still undecided — a lane
@@ -2093,13 +2085,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     int32_t my_slot = lane;                                  // ring slot of the row in hand
     bool cv = false, gfin = false;
     int32_t e0 = dummy_addr, e1 = dummy_addr, e2 = dummy_addr, meta = 0;
-#else
-    int32_t j = 0;                                           // rows this lane has committed
-    bool cv = false, nv = false, fin = false;
-    int32_t e0 = dummy_addr, e1 = dummy_addr, e2 = dummy_addr, meta = 0;
-    RingSlot nx;
-    nx.tag = KAS_TAG_FREE; nx.c[0] = 0; nx.c[1] = 0; nx.c[2] = 0;
-#endif
     int64_t n_iter = 0, n_blocked = 0, n_relax = 0, n_run_rows = 0, n_runs = 0, n_cur = 0, n_rdy = 0;
     int32_t run_skip = 0, run_backoff = 0;                   // wave-uniform
     const int64_t t_begin = kasw::clock_ticks();
@@ -2109,10 +2094,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       n_iter += 1;
       // one LDS round trip per iteration: the three counter rows (+ the look-ahead slot / the slot
       // of the row claimed at the end of the previous iteration)
-#if !KAS_CLAIM_ROWS
-      const int32_t jn = j + (cv ? 1 : 0);
-      const RingSlot sl = ring[(jn & (K - 1)) * 64 + lane];
-#endif
       uint32_t f0[3], f1[3], com[3];                        // count[.][0], count[.][1], commits per holder
       const int32_t es[3] = {e0, e1, e2};
       if constexpr (PK) {
@@ -2130,12 +2111,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           com[q] = (uint32_t)(x >> 48);
         }
       }
-#if !KAS_CLAIM_ROWS
-      if (!nv && !fin) {
-        if (sl.tag >= 0 && (sl.tag & KAS_TAG_JMASK) == (jn & KAS_TAG_JMASK)) { nx = sl; nv = true; }
-        else if (sl.tag == KAS_TAG_END && !cv) fin = true;
-      }
-#endif
       // rows still ahead of mine on each holder: ticket - commits on the node; 0 everywhere ==
       // every earlier row holding any of my nodes has committed
       const uint32_t d0 = ((uint32_t)e0 >> 16) - com[0], d1 = ((uint32_t)e1 >> 16) - com[1],
@@ -2254,15 +2229,9 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
           kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad1), Lp > 1 ? (1ull << 16) + (1ull << 48) : 0ull);
           kasw::lds_atomic_add_u64((uint64_t*)(lds_raw + ad2), Lp > 2 ? (1ull << 32) + (1ull << 48) : 0ull);
         }
-#if KAS_CLAIM_ROWS
         ring[my_slot].tag = KAS_TAG_DONE | w0 | (w1 << 2) | (Lp << 4);
-#else
-        ring[(j & (K - 1)) * 64 + lane].tag = KAS_TAG_DONE | w0 | (w1 << 2) | (Lp << 4);
-        j += 1;
-#endif
         cv = false;
       }
-#if KAS_CLAIM_ROWS
       {
         // lanes without a row claim the next rows of their group in order; a claimed row is taken if
         // its tile has been staged (tiles are staged whole, so the rows taken are a prefix of the
@@ -2293,13 +2262,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       // thin hand costs a full step's instructions for a few rows — at raised priority, i.e. taken from
       // the very waves that have to catch up — so the solver lets them.
       if (kasw::popc(kasw::ballot(!cv && !gfin)) >= KAS_STARVE_MIN) kasw::nap<KAS_STARVE_NAP>();
-#endif
-#else
-      if (!cv && nv) {                                     // the look-ahead row becomes current
-        e0 = nx.c[0]; e1 = nx.c[1]; e2 = nx.c[2];
-        meta = nx.tag >> 26;
-        cv = true; nv = false;
-      }
 #endif
       if (kasw::ballot(!fin) == 0) break;
       const bool progress = kasw::ballot(ready) != 0;
@@ -2472,13 +2434,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     uint64_t digest = 0;
     auto finish = [&](Retired& r) {
       if (r.on) {
-#if KAS_RETIRE_PAD_STYLE == 1
-#pragma unroll
-        for (int q = 0; q < W; ++q)
-          if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.kw & 0x7ffffffu, (uint32_t)r.p, (uint32_t)q, r.id[q]);
-#pragma unroll
-        for (int q = 0; q < W; ++q) if (q < (r.kw >> 27)) r.row[q] = q < r.Lp ? r.id[q] : -1;
-#else
 #pragma unroll
         for (int q = 0; q < W; ++q)
           if (q < r.Lp) digest += kas_digest_cell((uint32_t)r.kw & 0x7ffffffu, (uint32_t)r.p, (uint32_t)q, r.id[q]);
@@ -2495,7 +2450,6 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
           for (int q = 0; q < W; ++q) if (q >= r.Lp && q < (r.kw >> 27)) r.row[q] = -1;
         }
-#endif
 #endif
       }
       r.on = false;

@@ -30,11 +30,7 @@ KAS_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x 
 
 // (the builtin takes the predicate itself: __ballot(int) made the compiler materialise 0 / 1 in a VGPR
 // and compare it again wherever the predicate was an AND of lane masks)
-#ifdef KAS_OLD_BALLOT
-KAS_DEV uint64_t ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
-#else
 KAS_DEV uint64_t ballot(bool p) { return (uint64_t)__builtin_amdgcn_ballot_w64(p); }
-#endif
 
 KAS_DEV int shfl(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
@@ -100,9 +96,6 @@ KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }
 // popc(m & lanemask_lt()): bits of m below this lane (v_mbcnt_lo / v_mbcnt_hi: two instructions, m may
 // differ per lane)
 KAS_DEV int count_below(uint64_t m) {
-#ifdef KAS_OLD_COUNT_BELOW
-  return __popcll((unsigned long long)(m & ((1ull << (threadIdx.x & 63u)) - 1ull)));
-#endif
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 

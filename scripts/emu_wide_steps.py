@@ -33,7 +33,7 @@ fb = node_set_batch([bs.node_id], [bs.node_rack], P, 5, 5, cur=cur)
 want = oracle_solve(fb)
 print("oracle status", want.scenario_results["status"].tolist(), "moved", want.scenario_results["moved_replicas"].tolist())
 t0 = time.time()
-flags = os.environ.get("KAS_EMU_CFLAGS", "").split()     # e.g. "-DKAS_WIDE_DIAG -DKAS_WIDE_JOINT=0"
+flags = os.environ.get("KAS_EMU_CFLAGS", "").split()     # e.g. "-DKAS_WIDE_DIAG -DKAS_WIDE_VOTE_DEPTH=2"
 solve = variant_solver("v" + "".join(c for c in "_".join(flags) if c.isalnum() or c == "_"), flags) if flags else emu_solve
 got = solve(fb)
 print("emu %.1f s" % (time.time() - t0))
