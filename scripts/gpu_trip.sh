@@ -102,7 +102,7 @@ print("   stats:", " ".join("%s %.0f" % (k, d[k]["mean"]) for k in ("solver_iter
 PY
       ;;
     random)   # randomised GPU-vs-oracle stress, 150 s of batches
-      timeout 400 python scripts/stress_gpu.py 150 > $O/stress_random.log 2>&1; echo "random stress exit $?" >> $O/stress_random.log; tail -2 $O/stress_random.log ;;
+      timeout 400 python scripts/stress_gpu.py 150 ${STRESS_SEED:-2026} > $O/stress_random.log 2>&1; echo "random stress exit $?" >> $O/stress_random.log; tail -2 $O/stress_random.log ;;
     big)
       c5 bench_1100k_5k_rf5_wide_checked --actions c5 --partitions 1100000
       c5 bench_1100k_5k_rf5_round_form --actions c5 --partitions 1100000 --plan-flags 2 --steps 1 --warmup 1

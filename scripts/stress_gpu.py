@@ -12,7 +12,7 @@ from parity_util import assert_same_outputs
 from kafka_assigner_amd import native, generator as G
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import FlatBatch
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)   # python scripts/stress_gpu.py SECONDS [SEED]
 
 
 def thin_wide_batch(rng):
