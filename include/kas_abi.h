@@ -88,10 +88,12 @@ extern "C" {
                                        Kafka broker ids are non-negative), or node_rack[]
                                        outside [0, 32767]                                    */
 
-#define KAS_FAIL_WATCHDOG        8  /* debug builds of the library only (-DKAS_SPIN_BOUND=n): a
-                                       wavefront polled n times without progress; the scenario's
-                                       rows are unspecified.  The product build has no bound and
-                                       never reports this                                     */
+#define KAS_FAIL_WATCHDOG        8  /* internal error, reported instead of a hung GPU: a wavefront
+                                       polled KAS_SPIN_BOUND times (2^25: seconds) for another
+                                       wavefront of its workgroup without progress; the scenario's
+                                       rows are unspecified.  No input is known to cause it.  (Fill
+                                       kernel and order kernels for lists <= 3 wide; the wide form
+                                       carries the bound in test builds only)                      */
 
 /* One topic of one scenario.  Offsets are in int32 elements into the named pool. */
 typedef struct kas_topic_desc {

@@ -299,7 +299,7 @@ const char* kas_status_string(int status) {
     case KAS_FAIL_RF_MISMATCH: return "partition with unexpected replication factor (KTA:58-60)";
     case KAS_SKIPPED: return "skipped: an earlier topic of the scenario failed";
     case KAS_FAIL_BAD_NODES: return "node table not strictly ascending / non-negative, or rack out of range";
-    case KAS_FAIL_WATCHDOG: return "debug build: a wavefront polled past KAS_SPIN_BOUND without progress";
+    case KAS_FAIL_WATCHDOG: return "a wavefront polled past KAS_SPIN_BOUND without progress (internal error: the solve was abandoned instead of hanging)";
     default: return "unknown status";
   }
 }

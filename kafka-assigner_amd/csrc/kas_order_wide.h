@@ -166,7 +166,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
   uint64_t* gdig = (uint64_t*)(clist + 2 * K * 64);
   uint32_t* lstate = (uint32_t*)(gdig + 1);                 // [2] rows appended to each list | 1 << 31 once staging has ended
   uint32_t* rank_owner_all = (uint32_t*)(gdig + 2);         // [1 + NB][KAS_WIDE_HOT][64] queue scratch of the solvers: rank -> lane
-  uint32_t* wd = rank_owner_all + 64 * KAS_WIDE_HOT * (1 + KAS_WIDE_BULK_SOLVERS);       // watchdog word (debug builds, see watchdog_poll)
+  uint32_t* wd = rank_owner_all + 64 * KAS_WIDE_HOT * (1 + KAS_WIDE_BULK_SOLVERS);       // watchdog word (see watchdog_poll)
   // front[n] = the class-1 solver's row in hand that is next to commit on node n: step stamp << 11 | the
   // node's position in that row's list << 8 | lane (joint solve, side dependencies)
   uint32_t* front = wd + 4;                                 // [nmax + 1], if the LDS has room for it
@@ -547,7 +547,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       const bool fin = gfin && !cv;
       if (kasw::ballot(!fin) == 0) break;
       const bool progress = kasw::ballot(ready) != 0;
-      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (watchdog_poll<KAS_WIDE_SPIN_BOUND>(wd, progress, wd_idle)) break;
       if (!progress) { n_blocked += 1; kasw::spin_pause(); }
     }
     if (a.stats && have_s) {
@@ -616,7 +616,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       }
       if (kasw::ballot(staging) == 0) {                     // nothing to stage: skip the ticket work, poll again
         if (kasw::ballot(!endl) == 0) break;
-        if (watchdog_poll(wd, false, wd_idle)) break;
+        if (watchdog_poll<KAS_WIDE_SPIN_BOUND>(wd, false, wd_idle)) break;
         f_idle += 1;
         kasw::nap<KAS_IDLE_NAP>();
         continue;
@@ -689,7 +689,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         if (staging) jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;
-      if (watchdog_poll(wd, true, wd_idle)) break;
+      if (watchdog_poll<KAS_WIDE_SPIN_BOUND>(wd, true, wd_idle)) break;
     }
     if (a.stats && have_s && lane == 0) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
@@ -759,7 +759,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       retired = gather(rb) || retired;
       if (kasw::ballot(!fin) == 0) break;
       const bool progress = kasw::ballot(retired) != 0;
-      if (watchdog_poll(wd, progress, wd_idle)) break;
+      if (watchdog_poll<KAS_WIDE_SPIN_BOUND>(wd, progress, wd_idle)) break;
       if (!progress) kasw::nap<KAS_IDLE_NAP>();
     }
     finish(ra); finish(rb);
@@ -787,7 +787,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       }
       if (kasw::ballot(bad) != 0ull && lane == 0) a.ord_flag[s] = 1;
     }
-    if (KAS_SPIN_BOUND > 0 && have_s && lane == 0 && *(volatile uint32_t*)wd != 0u) {
+    if (KAS_WIDE_SPIN_BOUND > 0 && have_s && lane == 0 && *(volatile uint32_t*)wd != 0u) {
       a.scenario_results[s].status = KAS_FAIL_WATCHDOG;
       a.scenario_results[s].fail_topic = -1; a.scenario_results[s].fail_partition = -1;
     }

@@ -94,7 +94,7 @@ struct KasLds {
 #define KAS_CTL_MOVED_R 3
 #define KAS_CTL_MOVED_P 4
 #define KAS_CTL_OC 8          // [NW] orphans found per chunk
-#define KAS_CTL_WATCHDOG 7    // debug builds (KAS_SPIN_BOUND): a P4 wait ran past its bound
+#define KAS_CTL_WATCHDOG 7    // a P4 wait ran past its bound (KAS_SPIN_BOUND)
 
 // wavefronts of the spread fill's P4 kernel (one workgroup per scenario).  A window of 64 orphans costs its wave
 // ~3.5 us (row reads, rack lookups, two hand-over steps), the hand-over chain 0.44 us per step: with four waves

@@ -74,14 +74,26 @@
 #define KAS_COUNTERS_ON 0
 #endif
 
-// Hang containment.  The order kernels' three wavefronts and the P4 windows of the fill kernel wait
-// for each other by polling LDS words; a protocol error there would spin forever and take the GPU
-// with it.  A debug build (-DKAS_SPIN_BOUND=n, scripts/build_variant.sh) bounds every such loop: a
-// wavefront that polls n times without making progress raises the workgroup's watchdog word, every
-// polling loop of the workgroup leaves when it sees the word, and the scenario is reported as
-// KAS_FAIL_WATCHDOG instead of hanging.  The product build (KAS_SPIN_BOUND 0) has none of this.
+// Hang containment.  The order kernels' wavefronts and the P4 windows of the fill kernel wait for each other by
+// polling LDS words; a protocol error there would spin forever and take the GPU with it.  Every such loop is
+// bounded: a wavefront that polls KAS_SPIN_BOUND times without making progress raises the workgroup's watchdog
+// word, every polling loop of the workgroup leaves when it sees the word, and the scenario is reported as
+// KAS_FAIL_WATCHDOG instead of hanging.  Product build (round 3): 2^25 polls — 1.3 s of the tightest loop (a P4
+// window waiting for its predecessors), ~15 s of a solver's; no wait between resident wavefronts of one workgroup
+// lasts a millisecond — and the word is read on every 4096th idle poll only, which costs nothing measurable
+// (362.8k against 362.9k scenarios/s, three A/B pairs).  Test builds use small bounds (-DKAS_SPIN_BOUND=n, below
+// 65536: checked on every poll); -DKAS_SPIN_BOUND=0 compiles the containment out.
+// The wide ticket form keeps the bound for test builds only: with it the kernel needs two more VGPRs and its chain
+// solver's step — the critical path of configs[4] — gets 1.4 % slower (38.55 -> 39.10 ms, three A/B pairs).
 #ifndef KAS_SPIN_BOUND
-#define KAS_SPIN_BOUND 0
+#define KAS_SPIN_BOUND (1 << 25)
+#define KAS_WIDE_SPIN_BOUND 0
+#endif
+#ifndef KAS_WIDE_SPIN_BOUND
+#define KAS_WIDE_SPIN_BOUND KAS_SPIN_BOUND
+#endif
+#ifndef KAS_SPIN_CHECK
+#define KAS_SPIN_CHECK 4096
 #endif
 // test hook of the debug build: the staging wavefront stops handing out rows after this many tiles
 #ifndef KAS_TEST_STALL_AFTER
@@ -92,16 +104,22 @@ namespace kas {
 
 // one poll of a bounded loop: `progress` (wave-uniform) = this iteration did something; returns
 // true when the loop must be left (watchdog raised by this or another wavefront)
+template <int BOUND = KAS_SPIN_BOUND>
 KAS_DEV bool watchdog_poll(uint32_t* wd, bool progress, int32_t& idle) {
-#if KAS_SPIN_BOUND > 0
-  idle = progress ? 0 : idle + 1;
-  if (idle > KAS_SPIN_BOUND && kasw::lane() == 0) *(volatile uint32_t*)wd = 1u;
-  kasw::repoll();
-  return kasw::ballot(*(volatile uint32_t*)wd != 0u) != 0ull;
-#else
-  (void)wd; (void)progress; (void)idle;
-  return false;
-#endif
+  if constexpr (BOUND > 0) {
+    if (progress) { idle = 0; return false; }             // (wave-uniform; nothing else on the path of a step that did something)
+    idle = kasw::uniform(idle + 1);
+    // a large bound: the word is looked at on every KAS_SPIN_CHECK-th poll without progress only (a wavefront
+    // that keeps making progress never looks; it stalls soon enough if the workgroup is stuck)
+    constexpr int32_t every = BOUND >= 65536 ? KAS_SPIN_CHECK : 1;
+    if (every > 1 && (idle & (every - 1)) != every - 1) return false;
+    if (idle > BOUND && kasw::lane() == 0) *(volatile uint32_t*)wd = 1u;
+    kasw::repoll();
+    return kasw::ballot(*(volatile uint32_t*)wd != 0u) != 0ull;
+  } else {
+    (void)wd; (void)progress; (void)idle;
+    return false;
+  }
 }
 
 struct TopicOutcome {
@@ -2027,7 +2045,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
   RingSlot* ring = (RingSlot*)(lds_raw + G * kas_order_ticket_group_bytes(a.n_max, G, PK));
   uint64_t* gdig = (uint64_t*)(ring + K * 64);
   uint32_t* rank_owner = (uint32_t*)(gdig + G);             // [64] run scratch of the solver: rank -> lane
-  uint32_t* wd = rank_owner + 64;                           // watchdog word (debug builds, see watchdog_poll)
+  uint32_t* wd = rank_owner + 64;                           // watchdog word (see watchdog_poll)
 
   kas_scenario_desc sd;
   sd.n_nodes = 0; sd.topic_begin = 0; sd.topic_count = 0; sd.ctx_width = 0; sd.node_off = 0; sd.ctx_off = -1;

@@ -39,6 +39,9 @@ KAS_DEV int read_lane(int v, int uniform_lane) {
   return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(uniform_lane));
 }
 
+// a value every lane of the wavefront holds alike, moved to a scalar register (branches on it are scalar branches)
+KAS_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 KAS_DEV void sync() { __syncthreads(); }
 
 // Ordering point for a section that only ONE wave of the workgroup executes: this wave's

@@ -76,6 +76,8 @@ KAS_DEV int shfl(int v, int src_lane) {
 
 KAS_DEV int read_lane(int v, int uniform_lane) { return shfl(v, uniform_lane); }
 
+KAS_DEV int uniform(int v) { return v; }                  // (hardware: v_readfirstlane)
+
 KAS_DEV void sync() { rendezvous(K_SYNC); }
 KAS_DEV void lockstep() { rendezvous(K_LOCKSTEP); }
 KAS_DEV void wave_sync() { rendezvous(K_WAVESYNC); }

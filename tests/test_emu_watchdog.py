@@ -1,4 +1,4 @@
-"""Hang containment (debug builds, -DKAS_SPIN_BOUND=n): every loop in which the wavefronts of a
+"""Hang containment (KAS_SPIN_BOUND; the product build bounds at 2^25 polls, these tests at far fewer): every loop in which the wavefronts of a
 workgroup wait for each other is bounded; a wavefront that polls n times without progress raises
 the workgroup's watchdog word, all polling loops leave, and the scenario reports
 KAS_FAIL_WATCHDOG instead of hanging the GPU.  Checked on the CPU emulator of the kernel source:
@@ -35,3 +35,15 @@ def test_a_stalled_staging_wavefront_is_reported_not_hung():
         np.testing.assert_array_equal(got.scenario_results["status"][ok], abi.KAS_FAIL_WATCHDOG)
         # scenarios that had already failed in the fill kernel never reach the order kernel's rows
         np.testing.assert_array_equal(got.scenario_results["status"][~ok], want.scenario_results["status"][~ok])
+
+
+def test_a_large_bound_is_checked_on_every_4096th_idle_poll_and_still_ends_the_solve():
+    """The product's form of the check (bounds of 65536 and more): the watchdog word is read on every
+    KAS_SPIN_CHECK-th poll without progress only.  Same stalled staging wavefront, smallest such bound."""
+    solve = variant_solver("stalled_sparse", ["-DKAS_SPIN_BOUND=65536", "-DKAS_SPIN_CHECK=4096", "-DKAS_TEST_STALL_AFTER=2"])
+    fb = _batch(78, 2, 1500, 120, 12, 3, ("add_k", "remove1"))
+    want = oracle_solve(fb)
+    ok = want.scenario_results["status"] == abi.KAS_OK
+    assert ok.any()
+    got = solve(fb)
+    np.testing.assert_array_equal(got.scenario_results["status"][ok], abi.KAS_FAIL_WATCHDOG)
