@@ -22,8 +22,45 @@ static Tramp g_tramp;
 static void lane_entry() {
   g_tramp.fn(g_tramp.arg);
   g_emu.state[g_emu.cur] = S_DONE;
-  swapcontext(&g_emu.lane_ctx[g_emu.cur], &g_emu.main_ctx);
+  kas_emu_switch(&g_emu.lane_ctx[g_emu.cur], &g_emu.main_ctx);
+  abort();                                                   // a finished fiber is never resumed
 }
+
+#if KAS_EMU_FAST_SWITCH
+// kas_emu_switch(from, to): push the callee-saved registers, park the stack pointer in *from, take
+// *to's, pop, return into the other fiber.  (MXCSR / x87 control words are the process defaults in
+// every fiber and nothing here changes them.)
+asm(".text\n"
+    ".globl kas_emu_switch\n"
+    ".hidden kas_emu_switch\n"
+    ".type kas_emu_switch,@function\n"
+    "kas_emu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq (%rsi), %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size kas_emu_switch, .-kas_emu_switch\n");
+
+// a fresh fiber: six zeroed registers, then lane_entry as the address the first switch returns to,
+// entered with the stack the ABI promises a function (rsp + 8 a multiple of 16)
+static void make_fiber(Ctx* c, char* stack, size_t bytes) {
+  uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 64);
+  for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+  sp[6] = (void*)&lane_entry;
+  sp[7] = nullptr;
+  c->sp = sp;
+}
+#else
+static void make_fiber(Ctx* c, char* stack, size_t bytes) {
+  getcontext(&c->uc);
+  c->uc.uc_stack.ss_sp = stack;
+  c->uc.uc_stack.ss_size = bytes;
+  c->uc.uc_link = &g_emu.main_ctx.uc;
+  makecontext(&c->uc, lane_entry, 0);
+}
+#endif
 
 // KAS_EMU_CHAOS=<seed>: waves no longer advance in step.  Each round a wave whose lanes have all
 // arrived at a collective is released only with probability 1/2 (never none of them), and now and
@@ -72,11 +109,7 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
   e.n_lanes = n;
   for (int i = 0; i < n; ++i) {
     e.state[i] = S_RUNNABLE; e.kind[i] = K_NONE;
-    getcontext(&e.lane_ctx[i]);
-    e.lane_ctx[i].uc_stack.ss_sp = g_stacks + (size_t)i * STACK_BYTES;
-    e.lane_ctx[i].uc_stack.ss_size = STACK_BYTES;
-    e.lane_ctx[i].uc_link = &e.main_ctx;
-    makecontext(&e.lane_ctx[i], lane_entry, 0);
+    make_fiber(&e.lane_ctx[i], g_stacks + (size_t)i * STACK_BYTES, STACK_BYTES);
   }
   for (;;) {
     // 1. run every runnable fiber until it parks at a collective or finishes
@@ -85,7 +118,7 @@ int run_block(void (*fn)(void*), void* arg, int n_waves) {
       if (e.state[i] == S_DONE) { ++done; continue; }
       if (e.state[i] != S_RUNNABLE) continue;
       e.cur = i;
-      swapcontext(&e.main_ctx, &e.lane_ctx[i]);
+      kas_emu_switch(&e.main_ctx, &e.lane_ctx[i]);
       ++ran;
       if (e.state[i] == S_DONE) ++done;
     }

@@ -30,9 +30,22 @@ namespace kasw {
 enum Kind { K_NONE = 0, K_BALLOT, K_SHFL, K_SYNC, K_LOCKSTEP, K_SUM, K_SUM64, K_WAVESYNC };
 enum State { S_RUNNABLE = 0, S_PARKED, S_DONE };
 
+// Fiber switch.  x86-64: six callee-saved registers and the stack pointer, no system call
+// (glibc's swapcontext saves the signal mask with one per switch: a third of an emulated solve).
+// Elsewhere, or with -DKAS_EMU_UCONTEXT: ucontext.
+#if defined(__x86_64__) && !defined(KAS_EMU_UCONTEXT)
+#define KAS_EMU_FAST_SWITCH 1
+struct Ctx { void* sp; };
+extern "C" void kas_emu_switch(Ctx* from, Ctx* to);
+#else
+#define KAS_EMU_FAST_SWITCH 0
+struct Ctx { ucontext_t uc; };
+KAS_DEV void kas_emu_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, &to->uc); }
+#endif
+
 struct Emu {
-  ucontext_t main_ctx;
-  ucontext_t lane_ctx[KAS_EMU_MAX_LANES];
+  Ctx main_ctx;
+  Ctx lane_ctx[KAS_EMU_MAX_LANES];
   int state[KAS_EMU_MAX_LANES];
   int kind[KAS_EMU_MAX_LANES];
   int n_lanes;
@@ -52,7 +65,7 @@ KAS_DEV void rendezvous(int k) {
   Emu& e = g_emu;
   e.kind[e.cur] = k;
   e.state[e.cur] = S_PARKED;
-  swapcontext(&e.lane_ctx[e.cur], &e.main_ctx);
+  kas_emu_switch(&e.lane_ctx[e.cur], &e.main_ctx);
 }
 
 KAS_DEV uint64_t ballot(bool p) {
