@@ -2,17 +2,31 @@
 300..20000 partitions, RF 2..3, every action mix, 1..8 scenarios per batch) for N seconds, each batch
 solved with the default plan, one scenario per solver wavefront, 4 x uint16 counter rows, and the spread fill
 forced, and compared bit for bit with the CPU oracle.  Usage: python scripts/stress_gpu.py SECONDS
-(round 1: 21,494 batches x 3 plan variants in 150 s on an MI355X, all identical)."""
+(round 1: 21,494 batches x 3 plan variants in 150 s on an MI355X, all identical).
+With --emu the same draws go through the CPU fiber emulator of the kernel source instead (no GPU; KAS_EMU_CHAOS=<seed> /
+KAS_EMU_WAVE_DIV=w:k in the environment change the wave schedules): python scripts/stress_gpu.py SECONDS [SEED] --emu"""
 import sys, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 from test_emu_parity import _batch
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
-from kafka_assigner_amd import native, generator as G
+from kafka_assigner_amd import generator as G
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import FlatBatch
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)   # python scripts/stress_gpu.py SECONDS [SEED]
+EMU = "--emu" in sys.argv
+argv = [a for a in sys.argv if a != "--emu"]
+rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 2026)   # python scripts/stress_gpu.py SECONDS [SEED]
+if EMU:
+    from emu_lib import emu_solve
+
+    def solve(fb, flags=0):
+        return emu_solve(fb, flags=flags)
+else:
+    from kafka_assigner_amd import native
+
+    def solve(fb, flags=0):
+        return native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
 
 
 def thin_wide_batch(rng):
@@ -40,13 +54,13 @@ def thin_wide_batch(rng):
 
 
 t0 = time.time(); n = 0; q_rows = 0; n_thin = 0; n_big = 0
-while time.time() - t0 < float(sys.argv[1]):
+while time.time() - t0 < float(argv[1]):
     kind = rng.random()
     if kind < 0.12:                                              # the checked wide form and its second solve
         fb, what = thin_wide_batch(rng)
         want = oracle_solve(fb)
         for flags in (0, 2):
-            got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
+            got = solve(fb, flags)
             assert_same_outputs(fb, want, got, f"{what} flags {flags}")
         n += 1; n_thin += 1
         continue
@@ -56,7 +70,7 @@ while time.time() - t0 < float(sys.argv[1]):
         fb = _batch(seed, S, P, N, int(rng.choice([10, 25, 40])), int(rng.choice([2, 3])), ("add_k", "mixed", "remove_k"))
         want = oracle_solve(fb)
         for flags in (0, 4):
-            got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
+            got = solve(fb, flags)
             assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} big-N flags {flags}")
         n += 1; n_big += 1
         continue
@@ -71,7 +85,7 @@ while time.time() - t0 < float(sys.argv[1]):
     want = oracle_solve(fb)
     # (32 = KAS_PLAN_SPREAD_FILL: the row scans over one-wavefront workgroups with their slim LDS layouts)
     for flags in ((0, 1 << 12, 4, 32) if RF <= 3 else (0, 2, 1, 32)):
-        got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
+        got = solve(fb, flags)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
     n += 1
-print("stress ok:", n, "random batches x 2-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-7,400 brokers")
+print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 2-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-7,400 brokers")
