@@ -24,7 +24,7 @@ final class NativeAssignmentStrategy {
     static volatile int device = 0;
 
     /** One batch: S scenarios, each a broker set + rack map and an ordered run of topics that share
-     *  one Context.  Layout of `in` (int32 / int64 fields, native order): header[8], S scenario
+     *  one Context.  Layout of `in` (int32 / int64 fields, native order): header[12] (HEADER_INTS), S scenario
      *  descriptors (32 bytes: nNodes, topicBegin, topicCount, ctxWidth, long nodeOff, long ctxOff),
      *  T topic descriptors (64 bytes: nameHash, nPartitions, curWidth, rf, outWidth, reserved,
      *  long curOff, outOff, curLenOff, inPartitionsOff, partIdOff), nodeId[], nodeRack[], cur[],
