@@ -2,6 +2,8 @@
 
   literal : oracle/literal_ref.py  (line-by-line Python restatement of the Java)
   oracle  : oracle/kas_oracle.c    (C restatement, via ctypes)
+  emu     : the product's kernel SOURCE (csrc/kas_solver_body.h, kas_order_wide.h) stepped on the CPU fiber
+            emulator (tests/emu) behind the product's host mirror — test infrastructure, no GPU
   hip     : the product — kafka_assigner_amd.KafkaTopicAssigner over the C ABI and HIP kernels
             (GPU only; tests using it are marked @pytest.mark.gpu)
 
@@ -59,6 +61,17 @@ class OracleAssigner:
         return result
 
 
+class EmuAssigner(OracleAssigner):
+    """KTA:42-72 host logic from the product mirror, solve by the kernel source on the emulator."""
+
+    def generate_assignment(self, topic, cur, brokers, racks, desired_rf):
+        from emu_lib import emu_solve
+        rf = A.resolve_replication_factor(topic, cur, len(set(brokers)), desired_rf)
+        result, _ = A._solve_one(emu_solve, topic, cur, racks, set(brokers),
+                                 set(cur.keys()), rf, self.assignment_context)
+        return result
+
+
 class HipAssigner:
     def __init__(self):
         self._impl = A.KafkaTopicAssigner()
@@ -74,6 +87,7 @@ class HipAssigner:
 IMPLS = {
     "literal": LiteralAssigner,
     "oracle": OracleAssigner,
+    "emu": EmuAssigner,
     "hip": HipAssigner,
 }
 
@@ -81,5 +95,6 @@ IMPLS = {
 ALL_IMPLS = [
     pytest.param("literal", id="literal"),
     pytest.param("oracle", id="oracle"),
+    pytest.param("emu", id="emu"),
     pytest.param("hip", id="hip", marks=pytest.mark.gpu),
 ]
