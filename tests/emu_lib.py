@@ -42,29 +42,58 @@ def _compile_command(so: str, flags, warn=False):
             "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-o", so, _deps()[0]]
 
 
+def _builder_gone(marker: str) -> bool:
+    """The compile that wrote `marker` is no longer running (a killed test run leaves markers behind)."""
+    try:
+        txt = open(marker).read().strip()
+        age = time.time() - os.path.getmtime(marker)
+    except OSError:
+        return False                                        # the marker has just gone: the build finished
+    if not txt:
+        return age > 30                                     # created, pid not written yet
+    try:
+        os.kill(int(txt), 0)
+        return False
+    except (ProcessLookupError, ValueError):
+        return True
+    except PermissionError:
+        return False
+
+
 def _start_build(so: str, flags, warn=False) -> None:
     """Start the compile of a stale shared object in a process of its own and return.  It writes to a
-    temporary name and renames (a half-written file is never loaded); `so.building` exists while it
-    runs, so that other processes (the tests that spawn interpreters) wait for it instead of
-    compiling the same file again."""
+    temporary name and renames (a half-written file is never loaded); `so.building` (holding the
+    compiling shell's pid) exists while it runs, so that other processes (the tests that spawn
+    interpreters) wait for it instead of compiling the same file again."""
     if not _stale(so):
         return
     marker = so + ".building"
     try:
         os.close(os.open(marker, os.O_CREAT | os.O_EXCL | os.O_WRONLY))
     except FileExistsError:
-        if time.time() - os.path.getmtime(marker) < 900:
+        if not _builder_gone(marker):
             return                                          # somebody is on it
-        os.utime(marker)                                    # left behind by a killed run: take over
+        try:
+            os.remove(marker)                               # left behind by a killed run: take over
+        except OSError:
+            pass
+        return _start_build(so, flags, warn)
     tmp = so + ".tmp%d" % os.getpid()
     cmd = " ".join(shlex.quote(c) for c in _compile_command(tmp, flags, warn))
-    subprocess.Popen(["/bin/sh", "-c", f"{cmd} && mv -f {shlex.quote(tmp)} {shlex.quote(so)}; rm -f {shlex.quote(marker)}"])
+    proc = subprocess.Popen(["/bin/sh", "-c", f"{cmd} && mv -f {shlex.quote(tmp)} {shlex.quote(so)}; rm -f {shlex.quote(marker)}"])
+    try:
+        with open(marker, "r+") as f:
+            f.write(str(proc.pid))
+    except OSError:
+        pass                                                # (already finished and removed)
 
 
-def _finish_build(so: str, flags=()) -> str:
+def _finish_build(so: str, flags=(), warn=False) -> str:
     marker = so + ".building"
     t0 = time.time()
     while os.path.exists(marker):
+        if _builder_gone(marker):
+            _start_build(so, list(flags), warn)             # takes the marker over
         if time.time() - t0 > 900:
             raise TimeoutError(f"{marker} has been there for 15 minutes")
         time.sleep(0.2)
@@ -85,7 +114,7 @@ def _start_all_stale() -> None:
 
 def build_emu() -> str:
     _start_all_stale()
-    return _finish_build(os.path.join(EMU_DIR, "libkas_emu.so"))
+    return _finish_build(os.path.join(EMU_DIR, "libkas_emu.so"), [], warn=True)
 
 
 def build_emu_variant(name: str, flags) -> str:
