@@ -12,7 +12,10 @@ from kafka_assigner_amd.flatten import FlatBatch, HostOutputs, batch_desc, host_
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
-CSRC = os.path.join(ROOT, "kafka-assigner_amd", "csrc")
+# KAS_EMU_CSRC=<dir>: the emulator suite against a patched copy of the kernel sources (experiments/*.patch applied to a
+# scratch tree); its shared objects then go to KAS_EMU_OUT (default <dir>/emu_build), never next to the product's
+CSRC = os.environ.get("KAS_EMU_CSRC") or os.path.join(ROOT, "kafka-assigner_amd", "csrc")
+OUT_DIR = (os.environ.get("KAS_EMU_OUT") or os.path.join(CSRC, "emu_build")) if os.environ.get("KAS_EMU_CSRC") else EMU_DIR
 _LIB = None
 
 
@@ -103,18 +106,19 @@ def _finish_build(so: str, flags=(), warn=False) -> str:
 
 
 def _variant_path(name: str) -> str:
-    return os.path.join(EMU_DIR, f"libkas_emu_{name}.so")
+    return os.path.join(OUT_DIR, f"libkas_emu_{name}.so")
 
 
 def _start_all_stale() -> None:
-    _start_build(os.path.join(EMU_DIR, "libkas_emu.so"), [], warn=True)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    _start_build(os.path.join(OUT_DIR, "libkas_emu.so"), [], warn=True)
     for name, flags in TEST_VARIANTS.items():
         _start_build(_variant_path(name), flags)
 
 
 def build_emu() -> str:
     _start_all_stale()
-    return _finish_build(os.path.join(EMU_DIR, "libkas_emu.so"), [], warn=True)
+    return _finish_build(os.path.join(OUT_DIR, "libkas_emu.so"), [], warn=True)
 
 
 def build_emu_variant(name: str, flags) -> str:
