@@ -1,0 +1,178 @@
+// tools/ab_harness.cpp — A/B of builds of the C-ABI library without Python: the same seeded batch, resident in HBM,
+// through every library named on the command line (dlopen, one after the other); per library the fill / order
+// kernel durations (kas_plan_phase_times_us: HIP events on the launch stream), the plan's kernel string, and a
+// checksum of the result records, which must be the same for all of them.  Seconds from process start to result
+// (no torch import): made for the short end of a GPU budget.  TEST / MEASUREMENT TOOLING, not a product path.
+//   hipcc -O2 -std=c++17 -I include -o tools/ab_harness tools/ab_harness.cpp -ldl
+//   tools/ab_harness c3 SCENARIOS REPS lib.so [lib2.so ...]    100k partitions x 1k brokers x 20 racks x RF 3, remove 1 broker
+//   tools/ab_harness c5 1 REPS lib.so [...]                    1M x 5k x 40 racks x RF 5, remove every 50th + add 200
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kas_abi.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+  uint32_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 32); }
+  uint32_t below(uint32_t n) { return (uint32_t)(((uint64_t)next() * n) >> 32); }
+};
+
+struct Api {
+  void* h = nullptr;
+  int (*ctx_create)(int, kas_ctx**);
+  void (*ctx_destroy)(kas_ctx*);
+  int (*plan_create)(kas_ctx*, const kas_batch_desc*, kas_plan**);
+  void (*plan_destroy)(kas_plan*);
+  int (*plan_describe)(const kas_plan*, char*, int);
+  int (*solve_device)(kas_plan*, const kas_tables*, void*);
+  int (*ctx_synchronize)(kas_ctx*);
+  int (*phase_times)(kas_plan*, double*, double*, int*);
+  const char* (*last_error)(void);
+  bool load(const char* path) {
+    h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen %s: %s\n", path, dlerror()); return false; }
+#define SYM(field, name) field = (decltype(field))dlsym(h, name); if (!field) { fprintf(stderr, "%s: no %s\n", path, name); return false; }
+    SYM(ctx_create, "kas_ctx_create") SYM(ctx_destroy, "kas_ctx_destroy") SYM(plan_create, "kas_plan_create")
+    SYM(plan_destroy, "kas_plan_destroy") SYM(plan_describe, "kas_plan_describe") SYM(solve_device, "kas_solve_device")
+    SYM(ctx_synchronize, "kas_ctx_synchronize") SYM(phase_times, "kas_plan_phase_times_us") SYM(last_error, "kas_last_error")
+#undef SYM
+    return true;
+  }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 5) { fprintf(stderr, "usage: %s c3|c5 SCENARIOS REPS lib.so [lib.so ...]\n", argv[0]); return 1; }
+  const auto t_start = std::chrono::steady_clock::now();
+  const bool c5 = strcmp(argv[1], "c5") == 0;
+  const int S = atoi(argv[2]), reps = atoi(argv[3]);
+  const int32_t P = c5 ? 1000000 : 100000, N0 = c5 ? 5000 : 1000, R = c5 ? 40 : 20, RF = c5 ? 5 : 3;
+  // ---- the batch (host): G-like start — RF distinct racks per partition, one broker inside each — and the action
+  std::vector<int32_t> cur((size_t)S * P * RF), node_id, node_rack;
+  std::vector<kas_scenario_desc> scen((size_t)S);
+  std::vector<kas_topic_desc> topics((size_t)S);
+  for (int s = 0; s < S; ++s) {
+    Rng g(1000 + s);
+    int32_t* c = cur.data() + (size_t)s * P * RF;
+    const uint32_t per_rack = (uint32_t)(N0 / R);
+    for (int32_t p = 0; p < P; ++p) {
+      int32_t racks[8];
+      for (int r = 0; r < RF; ++r) {
+        for (;;) {
+          const int32_t k = (int32_t)g.below((uint32_t)R);
+          bool dup = false;
+          for (int q = 0; q < r; ++q) dup = dup || racks[q] == k;
+          if (!dup) { racks[r] = k; break; }
+        }
+        c[(size_t)p * RF + r] = racks[r] + R * (int32_t)g.below(per_rack);      // broker b sits on rack b mod R
+      }
+    }
+    const int64_t off = (int64_t)node_id.size();
+    int32_t n = 0;
+    const int32_t gone = (s * 37 + 11) % N0;
+    for (int32_t b = 0; b < N0 + (c5 ? 200 : 0); ++b) {
+      const bool removed = c5 ? (b < N0 && b % 50 == 0) : b == gone;
+      if (removed) continue;
+      node_id.push_back(b); node_rack.push_back(b % R); ++n;
+    }
+    scen[s] = kas_scenario_desc{n, s, 1, 0, off, -1};
+    kas_topic_desc td;
+    memset(&td, 0, sizeof td);
+    td.name_hash = 3644; td.n_partitions = P; td.cur_width = RF; td.rf = RF; td.out_width = RF;
+    td.cur_off = (int64_t)s * P * RF; td.out_off = (int64_t)s * P * RF;
+    td.cur_len_off = -1; td.in_partitions_off = -1; td.part_id_off = -1;
+    topics[s] = td;
+  }
+  kas_batch_desc bd;
+  bd.n_scenarios = S; bd.n_topics = S; bd.scenarios = scen.data(); bd.topics = topics.data();
+  bd.node_id = node_id.data(); bd.node_rack = node_rack.data(); bd.node_pool_len = (int64_t)node_id.size();
+  const auto t_gen = std::chrono::steady_clock::now();
+  if (const char* emu = getenv("AB_EMU")) {
+    // no GPU at hand: the same batch through the CPU emulator of the kernel source (tests/emu/libkas_emu.so) — checks
+    // the descriptors this tool builds, nothing else
+    void* h = dlopen(emu, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen %s: %s\n", emu, dlerror()); return 3; }
+    auto solve = (int (*)(const kas_batch_desc*, const kas_tables*, unsigned, char*, int))dlsym(h, "kas_emu_solve_batch");
+    if (!solve) { fprintf(stderr, "%s: no kas_emu_solve_batch\n", emu); return 3; }
+    std::vector<int32_t> out(cur.size(), -1);
+    std::vector<kas_topic_result> tr((size_t)S);
+    std::vector<kas_scenario_result> sr((size_t)S);
+    kas_tables ht;
+    memset(&ht, 0, sizeof ht);
+    ht.cur = cur.data(); ht.out = out.data(); ht.topic_results = tr.data(); ht.scenario_results = sr.data();
+    ht.cur_len = ht.out_len = (int64_t)cur.size();
+    char err[512] = "";
+    const int rc = solve(&bd, &ht, 0u, err, (int)sizeof err);
+    uint64_t sum = 0;
+    for (const kas_scenario_result& r : sr)
+      sum += r.digest * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)r.status * 1315423911ull + (uint64_t)(uint32_t)r.moved_replicas;
+    printf("emulator rc %d %s records %016llx\n", rc, err, (unsigned long long)sum);
+    for (int s = 0; s < S && s < 4; ++s)
+      printf("  scenario %d: status %d moved_replicas %d moved_partitions %d digest %016llx\n", s, sr[s].status, sr[s].moved_replicas,
+             sr[s].moved_partitions, (unsigned long long)sr[s].digest);
+    return rc;
+  }
+  // ---- tables in HBM
+  int32_t *d_cur = nullptr, *d_out = nullptr;
+  kas_topic_result* d_tr = nullptr;
+  kas_scenario_result* d_sr = nullptr;
+  const size_t cells = cur.size();
+  HIP_OK(hipMalloc(&d_cur, 4 * cells)); HIP_OK(hipMalloc(&d_out, 4 * cells));
+  HIP_OK(hipMalloc(&d_tr, sizeof(kas_topic_result) * S)); HIP_OK(hipMalloc(&d_sr, sizeof(kas_scenario_result) * S));
+  HIP_OK(hipMemcpy(d_cur, cur.data(), 4 * cells, hipMemcpyHostToDevice));
+  kas_tables t;
+  memset(&t, 0, sizeof t);
+  t.cur = d_cur; t.out = d_out; t.topic_results = d_tr; t.scenario_results = d_sr;
+  t.cur_len = (int64_t)cells; t.out_len = (int64_t)cells;
+  printf("%s: %d scenario(s) of %d partitions x %d brokers x RF %d, %d timed solves per library; generated in %.2f s\n", argv[1], S, P,
+         N0, RF, reps, std::chrono::duration<double>(t_gen - t_start).count());
+  uint64_t first_sum = 0;
+  bool all_same = true;
+  for (int li = 4; li < argc; ++li) {
+    Api api;
+    if (!api.load(argv[li])) return 3;
+    kas_ctx* ctx = nullptr;
+    kas_plan* plan = nullptr;
+    if (api.ctx_create(0, &ctx) != 0) { fprintf(stderr, "%s: kas_ctx_create: %s\n", argv[li], api.last_error()); return 4; }
+    if (api.plan_create(ctx, &bd, &plan) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
+    char what[1024];
+    api.plan_describe(plan, what, sizeof what);
+    HIP_OK(hipMemset(d_out, 0xff, 4 * cells)); HIP_OK(hipMemset(d_sr, 0, sizeof(kas_scenario_result) * S));
+    if (api.solve_device(plan, &t, nullptr) != 0 || api.ctx_synchronize(ctx) != 0) { fprintf(stderr, "%s: solve: %s\n", argv[li], api.last_error()); return 5; }
+    double f = 0, o = 0;
+    int n = 0;
+    api.phase_times(plan, &f, &o, &n);                       // (resets the accumulator: the first solve is warm-up)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r)
+      if (api.solve_device(plan, &t, nullptr) != 0) { fprintf(stderr, "%s: solve: %s\n", argv[li], api.last_error()); return 5; }
+    if (api.ctx_synchronize(ctx) != 0) { fprintf(stderr, "%s: sync: %s\n", argv[li], api.last_error()); return 5; }
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+    api.phase_times(plan, &f, &o, &n);
+    std::vector<kas_scenario_result> sr((size_t)S);
+    HIP_OK(hipMemcpy(sr.data(), d_sr, sizeof(kas_scenario_result) * S, hipMemcpyDeviceToHost));
+    uint64_t sum = 0;
+    int ok = 0;
+    int64_t moved = 0;
+    for (const kas_scenario_result& r : sr) {
+      sum += r.digest * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)r.status * 1315423911ull + (uint64_t)(uint32_t)r.moved_replicas;
+      ok += r.status == KAS_OK; moved += r.moved_replicas;
+    }
+    if (li == 4) first_sum = sum; else all_same = all_same && sum == first_sum;
+    printf("%-44s fill %9.1f us  order %9.1f us  (%d launches, %.3f ms per solve by the host clock)  ok %d/%d moved %lld  records %016llx\n   %s\n",
+           argv[li], f, o, n, wall_ms, ok, S, (long long)moved, (unsigned long long)sum, what);
+    api.plan_destroy(plan);
+    api.ctx_destroy(ctx);
+  }
+  printf("%s; total %.1f s\n", all_same ? "records identical across the libraries" : "RECORDS DIFFER",
+         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+  return all_same ? 0 : 6;
+}
