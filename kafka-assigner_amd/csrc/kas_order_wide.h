@@ -118,32 +118,38 @@ KAS_DEV uint64_t wide_field_unit(int r) {                   // + 1 on count fiel
 // recounted.  c[k][r] = count[holder k][r], holders ascending; pos[r] = list position picked for r.
 template <int W>
 KAS_DEV void pick_row_packed(const int32_t (&c)[W][W], int32_t Lp, bool valid, int32_t rot, int32_t (&pos)[W]) {
-  uint32_t alive = valid ? ((1u << Lp) - 1u) : 0u;
+  // Straight-line arithmetic, no compare / select pairs (on gfx950 each costs a wait state besides its two issue
+  // slots, and this function is most of a relaxation round of the chain solver's joint step):
+  //   alive4   nibble k = 8 while holder k is still to be picked
+  //   t        8 * (rank of the next set member + idx) + k, so that (t mod 8 m) is visit rank << 3 | list position
+  //   key      count << 6 | visit rank << 3 | list position, bit 30 set for a holder that is not alive: the minimum
+  //            names its own position (a dead row picks some position < W; nothing reads it)
+  uint32_t alive4 = valid ? (0x88888888u & ((1u << (4 * Lp)) - 1u)) : 0u;
   int32_t m = valid ? Lp : 0;
 #pragma unroll
   for (int r = 0; r < W; ++r) {
     if (r == W - 1) {                                       // at most one node is left: nothing to compare
       int32_t ps = W - 1;
 #pragma unroll
-      for (int k = W - 2; k >= 0; --k) ps = ((alive >> k) & 1u) ? k : ps;
+      for (int k = W - 2; k >= 0; --k) ps = ((alive4 >> (4 * k + 3)) & 1u) ? k : ps;
       pos[r] = ps;
       break;
     }
-    const int32_t idx = (rot >> (3 * m)) & 7;
-    int32_t keys[W], best = 0x7fffffff, rank = idx;         // rank of the next set member + idx
+    const uint32_t m8 = (uint32_t)m << 3;
+    uint32_t t = (uint32_t)((rot >> (3 * m)) & 7) << 3;
+    uint32_t best = 0x7fffffffu;
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      const int32_t in = (int32_t)((alive >> k) & 1u);
-      const int32_t rr = rank >= m ? rank - m : rank;
-      keys[k] = in ? ((c[k][r] << 3) | rr) : 0x7fffffff;
-      best = keys[k] < best ? keys[k] : best;
-      rank += in;
+      const uint32_t in8 = (alive4 >> (4 * k)) & 0xfu;      // 8 or 0
+      const uint32_t wrapped = t - m8;                      // (huge when t < 8 m)
+      const uint32_t rr8k = wrapped < t ? wrapped : t;
+      const uint32_t key = ((uint32_t)c[k][r] << 6) | rr8k | ((in8 ^ 8u) << 27);
+      best = key < best ? key : best;
+      t += in8 + 1u;
     }
-    int32_t ps = 0;
-#pragma unroll
-    for (int k = 1; k < W; ++k) ps = keys[k] == best ? k : ps;
+    const int32_t ps = (int32_t)(best & 7u);
     pos[r] = ps;
-    alive &= ~(1u << ps);                                   // nodeSet.remove (KAS:232)
+    alive4 &= ~(0xfu << (4 * ps));                          // nodeSet.remove (KAS:232)
     m -= m > 0 ? 1 : 0;
   }
 }
@@ -294,9 +300,6 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
             for (int q = 0; q < W; ++q) { my_ax = d[q] > dm ? (e[q] & 0xffff) : my_ax; dm = d[q] > dm ? d[q] : dm; }
           }
-          int32_t dcol[W];
-#pragma unroll
-          for (int q = 0; q < W; ++q) dcol[q] = (int32_t)d[q];
           int32_t hq[KH];                                   // where named node h sits in my (ascending) list, or -1
           uint32_t kx[KH], d_hot = 0u;                      // my rank in its queue
           {
@@ -325,9 +328,14 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
                 for (int k = 0; k < KC; ++k) cand_n[k] = cand_ax[k] == ax ? 0 : cand_n[k];
               }
               hq[h] = -1;
+              uint32_t kk = 0u;                             // (found together with the position: one chain of selects)
 #pragma unroll
-              for (int q = 0; q < W; ++q) hq[h] = (e[q] & 0xffff) == ax ? q : hq[h];
-              kx[h] = hq[h] >= 0 ? (uint32_t)sel<W>(dcol, hq[h]) : 0u;
+              for (int q = 0; q < W; ++q) {
+                const bool hit = (e[q] & 0xffff) == ax;
+                hq[h] = hit ? q : hq[h];
+                kk = hit ? d[q] : kk;
+              }
+              kx[h] = kk;
               d_hot += kx[h];
             }
           }

@@ -2340,6 +2340,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
     uint32_t pf_w0 = ~0u, pf_w1 = ~0u;                      // the read-ahead tile's mid row as two dwords of uint16
                                                             // cells, AS LOADED (unpacked when it is staged)
     int32_t pf_rot = KAS_ROT_IDENT;
+    const uint16_t* rowp = (const uint16_t*)a.out;          // my row of the read-ahead tile (mid rows)
     int64_t f_iter = 0, f_idle = 0;
     for (;;) {
       kasw::repoll();
@@ -2352,29 +2353,48 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const bool staging = !endl && room && pf_valid && !stalled;
       const bool staging_end = staging && pf_end;
       // unpack: uint16 node indices, 0xffff = none (sorts last, like ~0)
-      const uint32_t c0 = staging ? (pf_w0 & 0xffffu) : ~0u, c1 = staging ? (pf_w0 >> 16) : ~0u,
-                     c2 = staging ? (pf_w1 & 0xffffu) : ~0u;
+      const uint32_t w0m = staging ? pf_w0 : ~0u, w1m = staging ? pf_w1 : ~0u;
+      const uint32_t c0 = w0m & 0xffffu, c1 = w0m >> 16, c2 = w1m & 0xffffu;
       const int32_t rot = pf_rot;
       endl = endl || staging_end;
       pf_valid = pf_valid && !staging;
-      if (!pf_valid && !endl) {                             // read ahead: the tile after that
-        pf_valid = true;
-        pf_w0 = ~0u; pf_w1 = ~0u;
+      // read ahead: the tile after that.  The usual step — the next tile of the same topic, rows of the batch's
+      // width — is straight-line code: the iterator moves on by selects, the lane's row pointer by a constant, and
+      // ONE predicate guards the load; a topic change, the end of the rows and rows narrower than the batch
+      // share a side branch the whole wave skips (nested per-group ifs cost this wave ~30 scalar instructions
+      // of exec-mask bookkeeping per tile, and its instruction stream is the kernel's pace)
+      constexpr int MWC = mid_width_of<W>();
+      const bool want = !pf_valid && !endl;
+      const int32_t nrow0 = itl.row0 + GL;
+      const bool usual = W >= 2 && want && !itl.exhausted && nrow0 < itl.tP && itl.tow == W;
+      pf_valid = pf_valid || want;
+      pf_w0 = want ? ~0u : pf_w0; pf_w1 = want ? ~0u : pf_w1;
+      itl.row0 = usual ? nrow0 : itl.row0;
+      rowp = usual ? rowp + GL * MWC : rowp;
+      if (usual && nrow0 + li < itl.tP) {
+        // the fill kernel's mid row; nothing is computed from it before it is staged
+        if constexpr (W == 3) {
+          const RowWords<2> r = *(const RowWords<2>*)rowp;
+          pf_w0 = r.v[0]; pf_w1 = r.v[1];
+        } else if constexpr (W == 2) {
+          pf_w0 = *(const uint32_t*)rowp;
+        }
+      }
+      if (want && !usual) {                                 // (rare)
         if (tile_next<GL>(itl, a, sd)) {
           const int32_t p = itl.row0 + li;
           pf_rot = itl.rot;
+          rowp = (const uint16_t*)a.out + tile_mid_offset(itl) + (int64_t)p * mid_width(itl.tow);
           if (p < itl.tP) {
-            // the fill kernel's mid row; nothing is computed from it before it is staged
-            const uint16_t* row = (const uint16_t*)a.out + tile_mid_offset(itl) + (int64_t)p * mid_width(itl.tow);
             if (W == 3 && itl.tow == 3) {
-              const RowWords<2> r = *(const RowWords<2>*)row;
+              const RowWords<2> r = *(const RowWords<2>*)rowp;
               pf_w0 = r.v[0]; pf_w1 = r.v[1];
             } else if (W == 2 && itl.tow == 2) {
-              pf_w0 = *(const uint32_t*)row;
-            } else {                                        // narrower rows of a wider batch: cell by cell (rare)
-              uint32_t v0 = (uint32_t)row[0], v1 = 0xffffu, v2 = 0xffffu;
-              if (W > 1 && itl.tow > 1) v1 = (uint32_t)row[1];
-              if (W > 2 && itl.tow > 2) v2 = (uint32_t)row[2];
+              pf_w0 = *(const uint32_t*)rowp;
+            } else {                                        // narrower rows of a wider batch: cell by cell
+              uint32_t v0 = (uint32_t)rowp[0], v1 = 0xffffu, v2 = 0xffffu;
+              if (W > 1 && itl.tow > 1) v1 = (uint32_t)rowp[1];
+              if (W > 2 && itl.tow > 2) v2 = (uint32_t)rowp[2];
               pf_w0 = v0 | (v1 << 16); pf_w1 = v2 | 0xffff0000u;
             }
           }
@@ -2398,7 +2418,8 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
       const uint32_t s2 = ab_hi < c2 ? c2 : ab_hi;
       const uint32_t mid_hi = ab_hi < c2 ? ab_hi : c2;
       const uint32_t s1 = ab_lo < mid_hi ? mid_hi : ab_lo;
-      const int32_t Lp = (s0 < pad ? 1 : 0) + (s1 < pad ? 1 : 0) + (s2 < pad ? 1 : 0);
+      // holders of the row: a cell is a node index (< 32768, a plan limit) or KAS_MID_NONE — bit 15 tells them apart
+      const int32_t Lp = 3 - __builtin_popcount(w0m & 0x80008000u) - (int32_t)((w1m >> 15) & 1u);
       uint32_t hn[3] = {s0 < pad ? s0 : pad, s1 < pad ? s1 : pad, s2 < pad ? s2 : pad};
       // ---- tickets for the tile (wave-wide lockstep).  One 32-bit lane mask per node: a 64-lane
       // group takes its tile as two ascending halves.
@@ -2434,7 +2455,10 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 #pragma unroll
         for (int q = 0; q < 3; ++q)
           enc[q] = (int32_t)(((q < Lp ? tk[q] : (uint32_t)dummy_tk) << 16) | (uint32_t)(cnt_base + (int32_t)hn[q] * RB));
-        const int32_t lut = Lp == 3 ? (rot & 0x3f) : (Lp == 2 ? ((rot >> 6) & 0x3f) : KAS_ROT_IDENT);
+        // (a list of one holder may take the two-holder order as well: whichever of the first two stored positions
+        // it lands in, the padding holders beside it never win a pick — one shift instead of a three-way choice
+        // that the compiler turns into exec-mask branches)
+        const int32_t lut = (rot >> (Lp == 3 ? 0 : 6)) & 0x3f;
         RingSlot o;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {

@@ -1,11 +1,19 @@
 #!/bin/bash
-O=gpurun_out/r4k; mkdir -p $O
-for v in c5p4old c5slim; do
-  KAS_HIP_LIB=variants/libkas_hip_$v.so timeout 200 python bench.py --no-cpu --no-extras --repeats 1 --check 2 --scenarios 64 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 3 --warmup 1 > $O/x64_$v.log 2>&1
-  echo "$v x64: rc=$? ms_per_step $(grep -o '"ms_per_step": [0-9.]*' $O/x64_$v.log | head -1) $(grep -o '"in_flight_launch": {[^}]*' $O/x64_$v.log | cut -c1-110)"
-  KAS_HIP_LIB=variants/libkas_hip_$v.so timeout 100 python bench.py --no-cpu --no-extras --repeats 1 --check 2 --scenarios 8 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 5 --warmup 1 > $O/x8_$v.log 2>&1
-  echo "$v x8: ms_per_step $(grep -o '"ms_per_step": [0-9.]*' $O/x8_$v.log | head -1) $(grep -o '"in_flight_launch": {[^}]*' $O/x8_$v.log | cut -c1-110)"
-done
-cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-KAS_HIP_LIB=$R/variants/libkas_hip_c5slim.so timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_x64 -o trace -- python $R/bench.py --no-cpu --no-extras --repeats 1 --check 0 --scenarios 64 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 3 --warmup 1 > $R/$O/prof_x64.log 2>&1
-cd $R; grep "kas_" $O/prof_x64/*kernel_stats.csv | cut -d, -f1-4 | cut -c1-120
+# one-off (round 3, last session): in-flight parity of the wide families with the new library against the old one, SQ instruction counters alone
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=gpurun_out/r03g
+mkdir -p $R/$O
+export TMPDIR=/tmp
+P=$R/kafka-assigner_amd/csrc/libkas_hip.so
+OLD=$R/variants/libkas_hip_r3e.so
+H=$R/tools/ab_harness
+cd $R
+AB_INFLIGHT=6:18:2 timeout 30 $H shape:100000:1000:40:5 96 2 $OLD $P > $O/ab_inflight_w5_96x6.log 2>&1; echo "exit $?" >> $O/ab_inflight_w5_96x6.log; grep -v "^   kas_" $O/ab_inflight_w5_96x6.log
+AB_INFLIGHT=6:18:2 timeout 30 $H shape:100000:1000:40:4 96 2 $OLD $P > $O/ab_inflight_w4_96x6.log 2>&1; echo "exit $?" >> $O/ab_inflight_w4_96x6.log; grep -v "^   kas_" $O/ab_inflight_w4_96x6.log
+AB_INFLIGHT=3:9:2 timeout 30 $H shape:1000000:5000:40:5 4 1 $OLD $P > $O/ab_inflight_c5_4x3.log 2>&1; echo "exit $?" >> $O/ab_inflight_c5_4x3.log; grep -v "^   kas_" $O/ab_inflight_c5_4x3.log
+AB_INFLIGHT=8:24:2 AB_FLAGS=4096 timeout 30 $H c3mix 500 2 $OLD $P > $O/ab_inflight_c3mix_g1.log 2>&1; echo "exit $?" >> $O/ab_inflight_c3mix_g1.log; grep -v "^   kas_" $O/ab_inflight_c3mix_g1.log
+cd /tmp
+timeout 40 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $R/$O/prof_sq1_f1 -o sq1 -- $H c3mix 1000 2 $P > $R/$O/prof_sq1_f1.log 2>&1; echo "sq1 exit $?"
+timeout 40 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_sq2_f1 -o sq2 -- $H c3mix 1000 2 $P > $R/$O/prof_sq2_f1.log 2>&1; echo "sq2 exit $?"
+timeout 40 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_sq2_old_f1 -o sq2 -- $H c3mix 1000 2 $OLD > $R/$O/prof_sq2_old_f1.log 2>&1; echo "sq2 (old library) exit $?"
+cd $R

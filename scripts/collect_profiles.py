@@ -55,6 +55,22 @@ for log in (os.path.join(d, "prof_fetch.log"), os.path.join(d, "prof_write.log")
         break
     except Exception:
         pass
+if "kernel" not in j:
+    # the workload was tools/ab_harness (scripts/gpu_ab_profiles.sh), not bench.py: its log carries the plan's kernel
+    # string; the sources are the tree's (the in-tree library the harness ran was built from them)
+    for log in (os.path.join(d, "prof_fetch.log"), os.path.join(d, "prof_write.log")):
+        try:
+            lines = [ln.strip() for ln in open(log) if ln.startswith("   kas_")]
+            if lines:
+                sys.path.insert(0, os.getcwd())
+                import bench
+                j["kernel"] = lines[-1]
+                j["kernel_sources_sha16"] = bench.sources_sha16()
+                j["source"] += ("; workload: tools/ab_harness c3mix 1000 (BASELINE configs[2]'s shape and kernels, its own seeded "
+                                "tables and remove / add action mix, one batch alone, no Python in the process)")
+                break
+        except Exception:
+            pass
 json.dump(j, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(j, indent=1))
 

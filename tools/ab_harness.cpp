@@ -5,7 +5,13 @@
 // (no torch import): made for the short end of a GPU budget.  TEST / MEASUREMENT TOOLING, not a product path.
 //   hipcc -O2 -std=c++17 -I include -o tools/ab_harness tools/ab_harness.cpp -ldl
 //   tools/ab_harness c3 SCENARIOS REPS lib.so [lib2.so ...]    100k partitions x 1k brokers x 20 racks x RF 3, remove 1 broker
+//   tools/ab_harness c3mix SCENARIOS REPS lib.so [...]         the same tables; per scenario remove 1 / remove <= 5 / add <= 50 / both
 //   tools/ab_harness c5 1 REPS lib.so [...]                    1M x 5k x 40 racks x RF 5, remove every 50th + add 200
+//   tools/ab_harness c5norack 1 REPS lib.so [...]              the same with every broker its own rack (--disable_rack_awareness)
+//   tools/ab_harness shape:P:N:R:RF SCENARIOS REPS lib.so [...]   any shape, remove 1 broker
+//   AB_INFLIGHT=K:STEPS:REPEATS  in addition: K plans on K streams (own out tables, the same cur), STEPS solves round-robin
+//                                between two synchronisations, REPEATS times: scenarios/s by the host clock (bench.py's regime)
+//   AB_FLAGS=n                   kas_plan_set_flags(n) on every plan (KAS_PLAN_* of include/kas_abi.h)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -38,6 +44,7 @@ struct Api {
   int (*ctx_synchronize)(kas_ctx*);
   int (*phase_times)(kas_plan*, double*, double*, int*);
   const char* (*last_error)(void);
+  int (*set_flags)(kas_plan*, unsigned);
   bool load(const char* path) {
     h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", path, dlerror()); return false; }
@@ -45,6 +52,7 @@ struct Api {
     SYM(ctx_create, "kas_ctx_create") SYM(ctx_destroy, "kas_ctx_destroy") SYM(plan_create, "kas_plan_create")
     SYM(plan_destroy, "kas_plan_destroy") SYM(plan_describe, "kas_plan_describe") SYM(solve_device, "kas_solve_device")
     SYM(ctx_synchronize, "kas_ctx_synchronize") SYM(phase_times, "kas_plan_phase_times_us") SYM(last_error, "kas_last_error")
+    SYM(set_flags, "kas_plan_set_flags")
 #undef SYM
     return true;
   }
@@ -53,9 +61,11 @@ struct Api {
 int main(int argc, char** argv) {
   if (argc < 5) { fprintf(stderr, "usage: %s c3|c5 SCENARIOS REPS lib.so [lib.so ...]\n", argv[0]); return 1; }
   const auto t_start = std::chrono::steady_clock::now();
-  const bool c5 = strcmp(argv[1], "c5") == 0;
+  const std::string mode = argv[1];
+  const bool c5 = mode == "c5" || mode == "c5norack", mix = mode == "c3mix", norack = mode == "c5norack";
   const int S = atoi(argv[2]), reps = atoi(argv[3]);
-  const int32_t P = c5 ? 1000000 : 100000, N0 = c5 ? 5000 : 1000, R = c5 ? 40 : 20, RF = c5 ? 5 : 3;
+  int32_t P = c5 ? 1000000 : 100000, N0 = c5 ? 5000 : 1000, R = c5 ? 40 : 20, RF = c5 ? 5 : 3;
+  if (mode.rfind("shape:", 0) == 0 && sscanf(mode.c_str(), "shape:%d:%d:%d:%d", &P, &N0, &R, &RF) != 4) { fprintf(stderr, "shape:P:N:R:RF\n"); return 1; }
   // ---- the batch (host): G-like start — RF distinct racks per partition, one broker inside each — and the action
   std::vector<int32_t> cur((size_t)S * P * RF), node_id, node_rack;
   std::vector<kas_scenario_desc> scen((size_t)S);
@@ -78,11 +88,16 @@ int main(int argc, char** argv) {
     }
     const int64_t off = (int64_t)node_id.size();
     int32_t n = 0;
-    const int32_t gone = (s * 37 + 11) % N0;
-    for (int32_t b = 0; b < N0 + (c5 ? 200 : 0); ++b) {
-      const bool removed = c5 ? (b < N0 && b % 50 == 0) : b == gone;
+    // the scenario's broker set: which of 0..N0-1 go, how many of N0, N0 + 1, ... come
+    const int kind = mix ? s % 4 : 0;
+    const int n_gone = c5 ? 0 : (kind == 0 ? 1 : (kind == 2 ? 0 : 1 + s % 5));
+    const int n_new = c5 ? 200 : ((kind == 2 || kind == 3) ? (s == 2 ? 50 : 1 + (s * 7) % 50) : 0);
+    std::vector<char> gone_b((size_t)N0, 0);
+    for (int j = 0; j < n_gone; ++j) gone_b[(size_t)(((int64_t)s * 37 + 11 + (int64_t)j * 97) % N0)] = 1;
+    for (int32_t b = 0; b < N0 + n_new; ++b) {
+      const bool removed = b < N0 && (c5 ? b % 50 == 0 : gone_b[(size_t)b] != 0);
       if (removed) continue;
-      node_id.push_back(b); node_rack.push_back(b % R); ++n;
+      node_id.push_back(b); node_rack.push_back(norack ? n : b % R); ++n;
     }
     scen[s] = kas_scenario_desc{n, s, 1, 0, off, -1};
     kas_topic_desc td;
@@ -144,6 +159,8 @@ int main(int argc, char** argv) {
     kas_plan* plan = nullptr;
     if (api.ctx_create(0, &ctx) != 0) { fprintf(stderr, "%s: kas_ctx_create: %s\n", argv[li], api.last_error()); return 4; }
     if (api.plan_create(ctx, &bd, &plan) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
+    const unsigned flags = getenv("AB_FLAGS") ? (unsigned)strtoul(getenv("AB_FLAGS"), nullptr, 0) : 0u;
+    if (flags && api.set_flags(plan, flags) != 0) { fprintf(stderr, "%s: kas_plan_set_flags: %s\n", argv[li], api.last_error()); return 4; }
     char what[1024];
     api.plan_describe(plan, what, sizeof what);
     HIP_OK(hipMemset(d_out, 0xff, 4 * cells)); HIP_OK(hipMemset(d_sr, 0, sizeof(kas_scenario_result) * S));
@@ -169,6 +186,47 @@ int main(int argc, char** argv) {
     if (li == 4) first_sum = sum; else all_same = all_same && sum == first_sum;
     printf("%-44s fill %9.1f us  order %9.1f us  (%d launches, %.3f ms per solve by the host clock)  ok %d/%d moved %lld  records %016llx\n   %s\n",
            argv[li], f, o, n, wall_ms, ok, S, (long long)moved, (unsigned long long)sum, what);
+    if (const char* inf = getenv("AB_INFLIGHT")) {
+      int K = 8, steps = 20, repeats = 3;
+      sscanf(inf, "%d:%d:%d", &K, &steps, &repeats);
+      std::vector<kas_plan*> plans((size_t)K);
+      std::vector<hipStream_t> streams((size_t)K);
+      std::vector<kas_tables> tabs((size_t)K, t);
+      for (int k = 0; k < K; ++k) {
+        if (api.plan_create(ctx, &bd, &plans[k]) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
+        if (flags) api.set_flags(plans[k], flags);
+        HIP_OK(hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking));
+        int32_t* o = nullptr; kas_topic_result* tr = nullptr; kas_scenario_result* srk = nullptr;
+        HIP_OK(hipMalloc(&o, 4 * cells)); HIP_OK(hipMalloc(&tr, sizeof(kas_topic_result) * S)); HIP_OK(hipMalloc(&srk, sizeof(kas_scenario_result) * S));
+        tabs[k].out = o; tabs[k].topic_results = tr; tabs[k].scenario_results = srk;
+        if (api.solve_device(plans[k], &tabs[k], streams[k]) != 0) { fprintf(stderr, "solve: %s\n", api.last_error()); return 5; }   // set-up solve
+      }
+      HIP_OK(hipDeviceSynchronize());
+      printf("   in flight, %d plans x %d steps:", K, steps);
+      for (int rep = 0; rep < repeats; ++rep) {
+        const auto a0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < steps; ++i)
+          if (api.solve_device(plans[i % K], &tabs[i % K], streams[i % K]) != 0) { fprintf(stderr, "solve: %s\n", api.last_error()); return 5; }
+        HIP_OK(hipDeviceSynchronize());
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
+        printf(" %.1fk scenarios/s", (double)S * steps / sec / 1e3);
+      }
+      // every slot's records must be the batch's
+      bool slots_ok = true;
+      for (int k = 0; k < K; ++k) {
+        std::vector<kas_scenario_result> srk((size_t)S);
+        HIP_OK(hipMemcpy(srk.data(), tabs[k].scenario_results, sizeof(kas_scenario_result) * S, hipMemcpyDeviceToHost));
+        uint64_t sk = 0;
+        for (const kas_scenario_result& r : srk)
+          sk += r.digest * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)r.status * 1315423911ull + (uint64_t)(uint32_t)r.moved_replicas;
+        slots_ok = slots_ok && sk == sum;
+        api.plan_destroy(plans[k]);
+        HIP_OK(hipStreamDestroy(streams[k]));
+        HIP_OK(hipFree(tabs[k].out)); HIP_OK(hipFree(tabs[k].topic_results)); HIP_OK(hipFree(tabs[k].scenario_results));
+      }
+      printf("  (every slot's records %s)\n", slots_ok ? "equal the batch's" : "DIFFER");
+      all_same = all_same && slots_ok;
+    }
     api.plan_destroy(plan);
     api.ctx_destroy(ctx);
   }
