@@ -9,6 +9,8 @@
 //   tools/ab_harness c5 1 REPS lib.so [...]                    1M x 5k x 40 racks x RF 5, remove every 50th + add 200
 //   tools/ab_harness c5norack 1 REPS lib.so [...]              the same with every broker its own rack (--disable_rack_awareness)
 //   tools/ab_harness shape:P:N:R:RF SCENARIOS REPS lib.so [...]   any shape, remove 1 broker
+//   tools/ab_harness multi:P:N:R SCENARIOS REPS lib.so [...]      three topics per scenario ("topic-0..2": lists 3, 2 and 3 wide, P rows
+//                                                                 each): topic changes and rows narrower than the batch in the order kernels
 //   AB_INFLIGHT=K:STEPS:REPEATS  in addition: K plans on K streams (own out tables, the same cur), STEPS solves round-robin
 //                                between two synchronisations, REPEATS times: scenarios/s by the host clock (bench.py's regime)
 //   AB_FLAGS=n                   kas_plan_set_flags(n) on every plan (KAS_PLAN_* of include/kas_abi.h)
@@ -67,24 +69,42 @@ int main(int argc, char** argv) {
   int32_t P = c5 ? 1000000 : 100000, N0 = c5 ? 5000 : 1000, R = c5 ? 40 : 20, RF = c5 ? 5 : 3;
   if (mode.rfind("shape:", 0) == 0 && sscanf(mode.c_str(), "shape:%d:%d:%d:%d", &P, &N0, &R, &RF) != 4) { fprintf(stderr, "shape:P:N:R:RF\n"); return 1; }
   // ---- the batch (host): G-like start — RF distinct racks per partition, one broker inside each — and the action
-  std::vector<int32_t> cur((size_t)S * P * RF), node_id, node_rack;
+  const bool multi = mode.rfind("multi:", 0) == 0;
+  if (multi) { RF = 3; if (sscanf(mode.c_str(), "multi:%d:%d:%d", &P, &N0, &R) != 3) { fprintf(stderr, "multi:P:N:R\n"); return 1; } }
+  const int T = multi ? 3 : 1;
+  const int32_t t_rf[3] = {RF, multi ? 2 : RF, RF};
+  const int32_t t_hash[3] = {multi ? -1139260654 : 3644, -1139260653, -1139260652};
+  int64_t cells_per_scen = 0;
+  for (int k = 0; k < T; ++k) cells_per_scen += (int64_t)P * t_rf[k];
+  std::vector<int32_t> cur((size_t)S * cells_per_scen), node_id, node_rack;
   std::vector<kas_scenario_desc> scen((size_t)S);
-  std::vector<kas_topic_desc> topics((size_t)S);
+  std::vector<kas_topic_desc> topics((size_t)S * T);
   for (int s = 0; s < S; ++s) {
     Rng g(1000 + s);
-    int32_t* c = cur.data() + (size_t)s * P * RF;
     const uint32_t per_rack = (uint32_t)(N0 / R);
-    for (int32_t p = 0; p < P; ++p) {
-      int32_t racks[8];
-      for (int r = 0; r < RF; ++r) {
-        for (;;) {
-          const int32_t k = (int32_t)g.below((uint32_t)R);
-          bool dup = false;
-          for (int q = 0; q < r; ++q) dup = dup || racks[q] == k;
-          if (!dup) { racks[r] = k; break; }
+    int64_t toff = (int64_t)s * cells_per_scen;
+    for (int k = 0; k < T; ++k) {
+      const int32_t rf = t_rf[k];
+      int32_t* c = cur.data() + toff;
+      for (int32_t p = 0; p < P; ++p) {
+        int32_t racks[8];
+        for (int r = 0; r < rf; ++r) {
+          for (;;) {
+            const int32_t kk = (int32_t)g.below((uint32_t)R);
+            bool dup = false;
+            for (int q = 0; q < r; ++q) dup = dup || racks[q] == kk;
+            if (!dup) { racks[r] = kk; break; }
+          }
+          c[(size_t)p * rf + r] = racks[r] + R * (int32_t)g.below(per_rack);      // broker b sits on rack b mod R
         }
-        c[(size_t)p * RF + r] = racks[r] + R * (int32_t)g.below(per_rack);      // broker b sits on rack b mod R
       }
+      kas_topic_desc td;
+      memset(&td, 0, sizeof td);
+      td.name_hash = t_hash[k]; td.n_partitions = P; td.cur_width = rf; td.rf = rf; td.out_width = rf;
+      td.cur_off = toff; td.out_off = toff;
+      td.cur_len_off = -1; td.in_partitions_off = -1; td.part_id_off = -1;
+      topics[(size_t)s * T + k] = td;
+      toff += (int64_t)P * rf;
     }
     const int64_t off = (int64_t)node_id.size();
     int32_t n = 0;
@@ -99,16 +119,10 @@ int main(int argc, char** argv) {
       if (removed) continue;
       node_id.push_back(b); node_rack.push_back(norack ? n : b % R); ++n;
     }
-    scen[s] = kas_scenario_desc{n, s, 1, 0, off, -1};
-    kas_topic_desc td;
-    memset(&td, 0, sizeof td);
-    td.name_hash = 3644; td.n_partitions = P; td.cur_width = RF; td.rf = RF; td.out_width = RF;
-    td.cur_off = (int64_t)s * P * RF; td.out_off = (int64_t)s * P * RF;
-    td.cur_len_off = -1; td.in_partitions_off = -1; td.part_id_off = -1;
-    topics[s] = td;
+    scen[s] = kas_scenario_desc{n, s * T, T, 0, off, -1};
   }
   kas_batch_desc bd;
-  bd.n_scenarios = S; bd.n_topics = S; bd.scenarios = scen.data(); bd.topics = topics.data();
+  bd.n_scenarios = S; bd.n_topics = S * T; bd.scenarios = scen.data(); bd.topics = topics.data();
   bd.node_id = node_id.data(); bd.node_rack = node_rack.data(); bd.node_pool_len = (int64_t)node_id.size();
   const auto t_gen = std::chrono::steady_clock::now();
   if (const char* emu = getenv("AB_EMU")) {
@@ -119,7 +133,7 @@ int main(int argc, char** argv) {
     auto solve = (int (*)(const kas_batch_desc*, const kas_tables*, unsigned, char*, int))dlsym(h, "kas_emu_solve_batch");
     if (!solve) { fprintf(stderr, "%s: no kas_emu_solve_batch\n", emu); return 3; }
     std::vector<int32_t> out(cur.size(), -1);
-    std::vector<kas_topic_result> tr((size_t)S);
+    std::vector<kas_topic_result> tr((size_t)S * T);
     std::vector<kas_scenario_result> sr((size_t)S);
     kas_tables ht;
     memset(&ht, 0, sizeof ht);
@@ -142,7 +156,7 @@ int main(int argc, char** argv) {
   kas_scenario_result* d_sr = nullptr;
   const size_t cells = cur.size();
   HIP_OK(hipMalloc(&d_cur, 4 * cells)); HIP_OK(hipMalloc(&d_out, 4 * cells));
-  HIP_OK(hipMalloc(&d_tr, sizeof(kas_topic_result) * S)); HIP_OK(hipMalloc(&d_sr, sizeof(kas_scenario_result) * S));
+  HIP_OK(hipMalloc(&d_tr, sizeof(kas_topic_result) * S * T)); HIP_OK(hipMalloc(&d_sr, sizeof(kas_scenario_result) * S));
   HIP_OK(hipMemcpy(d_cur, cur.data(), 4 * cells, hipMemcpyHostToDevice));
   kas_tables t;
   memset(&t, 0, sizeof t);
@@ -197,7 +211,7 @@ int main(int argc, char** argv) {
         if (flags) api.set_flags(plans[k], flags);
         HIP_OK(hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking));
         int32_t* o = nullptr; kas_topic_result* tr = nullptr; kas_scenario_result* srk = nullptr;
-        HIP_OK(hipMalloc(&o, 4 * cells)); HIP_OK(hipMalloc(&tr, sizeof(kas_topic_result) * S)); HIP_OK(hipMalloc(&srk, sizeof(kas_scenario_result) * S));
+        HIP_OK(hipMalloc(&o, 4 * cells)); HIP_OK(hipMalloc(&tr, sizeof(kas_topic_result) * S * T)); HIP_OK(hipMalloc(&srk, sizeof(kas_scenario_result) * S));
         tabs[k].out = o; tabs[k].topic_results = tr; tabs[k].scenario_results = srk;
         if (api.solve_device(plans[k], &tabs[k], streams[k]) != 0) { fprintf(stderr, "solve: %s\n", api.last_error()); return 5; }   // set-up solve
       }
