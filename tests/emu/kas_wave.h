@@ -114,6 +114,8 @@ KAS_DEV void lds_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 KAS_DEV void lds_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }
 
+KAS_DEV uint32_t load_shared_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+KAS_DEV void store_shared_u32(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 KAS_DEV uint64_t load_shared_u64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
 KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
 
