@@ -100,6 +100,7 @@ template <int P> KAS_DEV void set_priority() {}
 KAS_DEV void repoll() { rendezvous(K_LOCKSTEP); }   // lets the other waves run
 
 KAS_DEV int32_t opaque(int32_t v) { return v; }
+KAS_DEV int32_t pinned(int32_t v) { return v; }               // (hardware: a value the compiler must have in a register HERE)
 
 KAS_DEV int32_t mul24(int32_t a, int32_t b) { return a * b; }
 KAS_DEV int popc(uint64_t m) { return __builtin_popcountll(m); }
