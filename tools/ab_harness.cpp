@@ -125,6 +125,19 @@ int main(int argc, char** argv) {
   bd.n_scenarios = S; bd.n_topics = S * T; bd.scenarios = scen.data(); bd.topics = topics.data();
   bd.node_id = node_id.data(); bd.node_rack = node_rack.data(); bd.node_pool_len = (int64_t)node_id.size();
   const auto t_gen = std::chrono::steady_clock::now();
+  if (const char* dump = getenv("AB_DUMP")) {
+    // the batch as raw int32 arrays for a checker outside this tool (tests/test_ab_harness.py: the oracle on the same tables):
+    // header {S, T, P, RF of topic 0..2}, per scenario {n_nodes}, node_id pool, node_rack pool, cur pool
+    FILE* f = fopen(dump, "wb");
+    if (!f) { perror(dump); return 3; }
+    const int32_t head[6] = {S, T, P, t_rf[0], t_rf[1], t_rf[2]};
+    fwrite(head, 4, 6, f);
+    for (int s = 0; s < S; ++s) fwrite(&scen[s].n_nodes, 4, 1, f);
+    fwrite(node_id.data(), 4, node_id.size(), f);
+    fwrite(node_rack.data(), 4, node_rack.size(), f);
+    fwrite(cur.data(), 4, cur.size(), f);
+    fclose(f);
+  }
   if (const char* emu = getenv("AB_EMU")) {
     // no GPU at hand: the same batch through the CPU emulator of the kernel source (tests/emu/libkas_emu.so) — checks
     // the descriptors this tool builds, nothing else
@@ -145,7 +158,7 @@ int main(int argc, char** argv) {
     for (const kas_scenario_result& r : sr)
       sum += r.digest * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)r.status * 1315423911ull + (uint64_t)(uint32_t)r.moved_replicas;
     printf("emulator rc %d %s records %016llx\n", rc, err, (unsigned long long)sum);
-    for (int s = 0; s < S && s < 4; ++s)
+    for (int s = 0; s < S && (s < 4 || getenv("AB_DUMP")); ++s)
       printf("  scenario %d: status %d moved_replicas %d moved_partitions %d digest %016llx\n", s, sr[s].status, sr[s].moved_replicas,
              sr[s].moved_partitions, (unsigned long long)sr[s].digest);
     return rc;
