@@ -12,6 +12,9 @@
 #   pmc        rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one batch in flight)
 #   sq         rocprofv3 --pmc SQ_* passes, one batch alone and eight in flight
 #   ab:LIB     benchq with KAS_HIP_LIB=variants/libkas_hip_LIB.so (tuning builds, scripts/build_variant.sh)
+#   abh:LIB    tools/ab_harness (no Python: seconds): product against variants/libkas_hip_LIB.so on seeded batches — kernel
+#              durations, in-flight rate, record checksums (scripts/gpu_ab_quick.sh; LIB must hold every kernel the batches
+#              launch: build it with -- -DKAS_MINIMAL_INSTANCES=0)
 #   c5:LIB     configs[4] x1 with that tuning build (LIB = - for the product library)
 #   random     scripts/stress_gpu.py 150: random shapes against the oracle, every plan variant
 #   big        shapes beyond round 2's limits: 1.1M x 5k x RF 5 (checked wide form / round form), 1M x 5k x RF 3 (ticket / round form)
@@ -78,6 +81,8 @@ for step in "$@"; do
         timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_sq2_f$mode -o sq2 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq2_f$mode.log 2>&1; echo "sq2 f$mode exit $?"
       done
       cd $R ;;
+    abh:*)
+      bash scripts/gpu_ab_quick.sh variants/libkas_hip_${step#abh:}.so | grep -v "^   kas_" ;;
     ab:*)
       lib=${step#ab:}
       KAS_HIP_LIB=variants/libkas_hip_$lib.so timeout 400 python bench.py --no-cpu --check 0 --no-extras --repeats 3 --stats $O/stats_v_$lib.json > $O/bench_v_$lib.log 2>&1
