@@ -299,7 +299,11 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  * exist so that the alternative forms can be tested and timed on the same inputs.
  *   KAS_PLAN_GENERIC_FILL  always run the general multi-sweep sticky fill instead of the
  *                          rack-diverse histogram/quota form
- *   KAS_PLAN_ROUND_ORDER   always run the tile-round preference ordering instead of the ticket form
+ *   KAS_PLAN_ROUND_ORDER   always run the tile-round preference ordering instead of the relaxation / ticket forms
+ *   KAS_PLAN_TICKET_ORDER  lists <= 3 wide without a Context: the ticket form of the preference ordering (three
+ *                          wavefronts per pair of scenarios) where the relaxation form (one wavefront per scenario,
+ *                          kas_order_relax.h) would run; KAS_PLAN_WIDE_COUNTERS and KAS_PLAN_GROUPS(n != 0), which
+ *                          only mean something to the ticket form, imply it
  *   KAS_PLAN_WIDE_COUNTERS ticket form with 4 x uint16 counter rows even where three 10-bit counts
  *                          in one uint32 would do
  *   KAS_PLAN_TWO_PASS_HIST rack-diverse fill with one histogram for the whole topic and a separate
@@ -315,6 +319,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_WIDE_COUNTERS 4u
 #define KAS_PLAN_TWO_PASS_HIST 8u
 #define KAS_PLAN_SPREAD_FILL  32u
+#define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
 #define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);

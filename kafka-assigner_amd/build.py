@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libkas_hip.so")
 SOURCES = ["kas_hip.hip"]
-HEADERS = ["kas_solver_body.h", "kas_order_wide.h", "kas_plan_math.h", "kas_wave.h"]
+HEADERS = ["kas_solver_body.h", "kas_order_wide.h", "kas_order_relax.h", "kas_plan_math.h", "kas_wave.h"]
 
 
 def hipcc() -> str:

@@ -1,0 +1,326 @@
+// kas_order_relax.h — order kernel, RELAXATION form: P5 (computePreferenceLists, KAS:202-239 with the
+// PreferenceListOrderTracker of KAS:244-302) for lists up to 3 wide, one wavefront per scenario, no Context.
+// Included at the end of kas_solver_body.h (namespace kas, the helpers of that file).
+//
+// What P5 is: rows in ascending order; row p reads count[n][0], count[n][1] of its own holders, picks (least count,
+// first in the rotated visit order wins ties), then adds 1 to count[list[r]][r] for every list position.  Row p
+// therefore depends on the earlier rows that hold one of its nodes and on nothing else.
+//
+// The form.  64 consecutive rows are one tile, lane i evaluates row i of the tile, and every earlier tile is
+// finished when a tile starts.  Inside the tile the sequential answer is the fixed point of
+//     outcome(i) = picks( committed counts + what the rows j < i of the tile that hold the same node add )
+// and "what the earlier rows add" is obtained from the LDS itself: an LDS atomic add with return gives every lane
+// the word before the instruction plus the addends of the LOWER lanes of that instruction that named the same word
+// — the LDS serves the lanes of one instruction in ascending lane order (kas_wave.h, lds_add_rtn_u32: measured, and
+// re-checked by kas_ctx_create's self-test).  For that to be a prefix over ROWS, the tile's 192 (row, cell) pairs
+// are added in row-major order: pair v = 3 row + cell is lane v mod 64 of instruction v div 64, three instructions
+// per tile, so that an earlier row's pair is an earlier instruction or a lower lane of the same one, whichever
+// cell of its row the node sits in.  (Adding cell k of every row with instruction k — the obvious layout — is wrong:
+// a node is the first cell of one row and the second of another, and a lane would then see the additions of LATER
+// rows made by an earlier instruction.  The emulator runs every LDS atomic as an instruction of its own for this
+// reason.)  The same physical lane is therefore two things: "row lane" i evaluates row i, "pair lane" l adds the
+// pairs l, 64 + l, 128 + l; they meet in a 16-byte staging slot per row: the row lane puts the addends of its
+// current outcome there (cells 0..2), the pair lanes take theirs, add, and put what the add returned back into the
+// same cell of the slot, the row lane reads the slot: the counter words as its row would see them if every earlier
+// row of the tile had committed its current outcome.  If no lane's outcome changed, the words already hold the
+// tile's commits (the additions stay); otherwise the additions are taken back (ds_sub_u32) and made again with the
+// new outcomes.  Lane i is right once every lane below it is, so the loop ends after at most 65 evaluations, and
+// the fixed point of an acyclic system is unique: it is the sequential result.  Emulator, bench-shaped scenarios
+// (100k rows, 1000 brokers): 3.3 evaluations per tile on average — including the stretch of consecutive orphans
+// that first fit put on one broker each, the chains the ticket forms need queues for: only near-ties ever change a
+// pick, so a chain of 13 rows on one broker is right after two or three evaluations.
+//
+// Counter word of a node (uint32, LDS, 4 bytes x (n_max + 1)): count[n][0] in bits 4..15, count[n][1] in bits
+// 20..31 (count[n][2] is never read for lists 3 wide: the last position has one candidate).  A pick is the minimum
+// of three keys  count << 20 | visit position << 2 | cell:  for the first pick  x << 16 | tag  (one
+// v_lshl_or_b32: the second count falls off the top), for the second  x & 0xfff00000 | tag  (one v_and_or_b32).
+// Cells stay in the order the fill kernel left them; the visit order of KAS:188-200 / KAS:263-278 — ascending
+// holders, rotated by abs(hash) mod set size — is in the tags: with rank = how many of the row's other holders are
+// smaller, the first pick over three holders visits a holder at position (idx3 + rank) mod 3 and the second visits
+// the two that are left in ascending (idx2 = 0) or descending order.  Tags are computed once per tile.  Rows per
+// node stay below 1023 (the plan's bound for the packed ticket form), far inside the 12-bit fields.  What an
+// outcome adds to which cell comes from a 16-entry table in LDS indexed by the outcome.
+//
+// Tiles whose 64 rows all hold three brokers in rows of the batch's width take the straight-line evaluation above;
+// any other tile (the last tile of a topic, rows with fewer holders after a reduced replication factor, topics
+// narrower than the batch) takes the same loop with per-lane list lengths.  HBM: mid rows in (8 B per row, read one
+// tile ahead), final rows out (12 B), broker ids from the L2-resident node table.
+//
+// Applicable where the packed ticket form is (KasShape::relax_ok): lists <= 3 wide, no Context handed in, no
+// topic hash of Integer.MIN_VALUE, ticket bound below 1023.  Everything else keeps the ticket / round forms.
+#pragma once
+
+namespace kas {
+
+#define KAS_RELAX_F0_ONE 0x10u         // count[n][0] += 1
+#define KAS_RELAX_F1_ONE 0x100000u     // count[n][1] += 1
+#define KAS_RELAX_F1_MASK 0xfff00000u
+#define KAS_RELAX_PAD_WORD 0xfff0fff0u // counter word of the padding node: only ever gets + 0
+
+// staging slot of a row / entry of the outcome table: what the row adds to its cells 0..2
+struct alignas(16) RelaxSlot { uint32_t v[4]; };
+
+// per-topic constants of the picks (wave-uniform: scalar registers)
+struct RelaxTopic {
+  int32_t idx2, idx3;
+  uint32_t vp3;                        // 4-bit field per rank: first pick over three holders, visit position << 2
+  uint32_t ord2;                       // 4-bit field per rank: second pick's order among the two left, << 2
+};
+
+KAS_DEV RelaxTopic relax_topic(int32_t name_hash) {
+  RelaxTopic t;
+  t.idx2 = java_abs_mod(name_hash, 2);
+  t.idx3 = java_abs_mod(name_hash, 3);
+  t.vp3 = 0u; t.ord2 = 0u;
+#pragma unroll
+  for (int rank = 0; rank < 3; ++rank) {
+    int32_t vp = t.idx3 + rank;                              // order[(idx + i) mod n] = sorted[i]  (KAS:193-197)
+    vp -= vp >= 3 ? 3 : 0;
+    t.vp3 |= (uint32_t)(vp << 2) << (4 * rank);
+    // two holders left, ascending a < b: visited (a, b) when idx2 == 0, (b, a) when idx2 == 1
+    t.ord2 |= (uint32_t)((t.idx2 ? 2 - rank : rank) << 2) << (4 * rank);
+  }
+  return t;
+}
+
+// The picks of one row, any list length (KAS:225-236 over KAS:263-278), cells in any order.  x[k] = counter word of
+// cell k, valid[k] = the cell holds a broker, rank[k] = holders of the row below it.  Returns first pick | second
+// pick << 2 as cell indices (0 where the list is shorter).
+KAS_DEV int32_t relax_eval_generic(const uint32_t (&x)[3], const bool (&valid)[3], const int32_t (&rank)[3], int32_t Lp,
+                                   const RelaxTopic& t) {
+  const int32_t idx_m0 = Lp == 3 ? t.idx3 : (Lp == 2 ? t.idx2 : 0);
+  uint32_t best = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int32_t vp = idx_m0 + rank[k];
+    vp -= vp >= Lp ? Lp : 0;
+    const uint32_t key = (((x[k] >> 4) & 0xfffu) << 8) | ((uint32_t)vp << 2) | (uint32_t)k;
+    best = (valid[k] && key < best) ? key : best;
+  }
+  const int32_t w0 = Lp >= 1 ? (int32_t)(best & 3u) : 0;
+  best = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // two left (Lp == 3): ascending or descending by idx2; one left: no choice
+    const int32_t ord = (Lp == 3 && t.idx2) ? 2 - rank[k] : rank[k];
+    const uint32_t key = ((x[k] >> 20) << 8) | ((uint32_t)ord << 2) | (uint32_t)k;
+    best = (valid[k] && k != w0 && key < best) ? key : best;
+  }
+  const int32_t w1 = Lp >= 2 ? (int32_t)(best & 3u) : 0;
+  return w0 | (w1 << 2);
+}
+
+template <int W>
+KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+  static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
+  const int lane = kasw::lane();
+  const kas_scenario_desc sd = a.scen[s];
+  const int32_t N = sd.n_nodes;
+  const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
+  uint32_t* cnt = (uint32_t*)lds_raw;                       // [nmax + 1]: + the padding node's word
+  RelaxSlot* lut = (RelaxSlot*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [16] by outcome
+  RelaxSlot* stage = lut + 16;                              // [64] by row of the tile
+  const int32_t* g_node_id = a.node_id + sd.node_off;
+  const int64_t t_begin = kasw::clock_ticks();
+  for (int32_t n = lane; n < N; n += 64) cnt[n] = 0u;
+  if (lane == 0) cnt[nmax] = KAS_RELAX_PAD_WORD;
+  if (lane < 16) {
+    RelaxSlot e;
+    const int32_t w0 = lane & 3, w1 = lane >> 2;
+    const bool ok = w0 < 3 && w1 < 3 && w0 != w1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e.v[k] = !ok ? 0u : (k == w0 ? KAS_RELAX_F0_ONE : (k == w1 ? KAS_RELAX_F1_ONE : 0u));
+    e.v[3] = ok ? (uint32_t)(3 - w0 - w1) : 0u;            // the cell that goes last
+    lut[lane] = e;
+  }
+  // my three pairs (as a pair lane): pair v = 64 t + lane is cell v mod 3 of row v div 3
+  const uint32_t* pslot[3];                                 // where the pair's addend comes from and its sum goes back
+  const uint16_t* pcell[3];                                 // where the pair's node index is staged
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int32_t v = 64 * t + lane, r = v / 3, k = v - 3 * r;
+    pslot[t] = &stage[r].v[k];
+    pcell[t] = (const uint16_t*)&stage[r] + k;
+  }
+  kasw::lockstep();
+
+  uint64_t digest = 0;
+  int32_t n_tiles = 0, n_evals = 0, n_slow = 0;             // (wave-uniform)
+  bool stuck = false;
+  for (int32_t k = 0; k < sd.topic_count; ++k) {
+    const int32_t ti = sd.topic_begin + k;
+    if (a.topic_results[ti].status != KAS_OK) continue;     // (a failed or skipped topic emits nothing)
+    const kas_topic_desc td = a.topics[ti];
+    const int32_t P = td.n_partitions, ow = td.out_width;
+    if (P <= 0) continue;
+    int32_t* out = a.out + td.out_off;
+    const uint16_t* mid = mid_base(out, P, ow);
+    const RelaxTopic rt = relax_topic(td.name_hash);
+    const int32_t nt = (P + 63) >> 6;
+    const bool full_width = W == 3 && ow == 3;
+    MidRaw<W> nxr = mid_load_raw<W>(mid, ow, lane < P ? lane : 0, lane < P);   // next tile's mid row (read ahead)
+    for (int32_t tile = 0; tile < nt; ++tile) {
+      const int32_t p = (tile << 6) + lane;
+      const bool active = p < P;
+      const MidRaw<W> raw = nxr;
+      {
+        const int32_t pn = p + 64;
+        nxr = mid_load_raw<W>(mid, ow, pn < P ? pn : 0, pn < P);
+      }
+      n_tiles += 1;
+      // ---- cells of my row (row lane): node index or KAS_MID_NONE (0xffff, bit 15)
+      uint32_t c[3];
+      if (ow == W) {
+        c[0] = raw.w[0] & 0xffffu; c[1] = raw.w[0] >> 16; c[2] = W == 3 ? (raw.w[1] & 0xffffu) : KAS_MID_NONE;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c[q] = q < W ? (raw.w[q] & 0xffffu) : KAS_MID_NONE;
+      }
+      // ---- hand the cells to the pair lanes: slot = (cell 0 | cell 1 << 16, cell 2, -, -)
+      {
+        RelaxSlot sl;
+        sl.v[0] = c[0] | (c[1] << 16); sl.v[1] = c[2] | 0xffff0000u; sl.v[2] = 0u; sl.v[3] = 0u;
+        kasw::lockstep();                                    // (the previous tile's slot has been read)
+        stage[lane] = sl;
+        kasw::lockstep();
+      }
+      uint32_t* padr[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const uint32_t n = (uint32_t)*pcell[t];
+        padr[t] = cnt + (n < (uint32_t)nmax ? n : (uint32_t)nmax);   // no holder: the padding node, and + 0
+      }
+      // counter words of my cells as the previous tile left them
+      uint32_t x[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) x[q] = cnt[c[q] < (uint32_t)nmax ? c[q] : (uint32_t)nmax];
+      kasw::lockstep();
+      // the usual tile: 64 rows, three holders each, rows of the batch's width
+      bool fast = false;
+      if constexpr (W == 3) {
+        if (full_width && ((tile + 1) << 6) <= P)
+          fast = kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
+      }
+      uint32_t padd[3] = {0u, 0u, 0u};                       // what my pairs added last
+      int32_t oc_prev = -1;
+      uint32_t last_cell = 0u;
+      bool valid[3];
+      int32_t rank[3], Lp = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { valid[q] = active && (c[q] & 0x8000u) == 0u; Lp += valid[q] ? 1 : 0; }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        rank[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rank[q] += (j != q && valid[j] && c[j] < c[q]) ? 1 : 0;
+      }
+      // tags of the straight-line evaluation (three holders): visit position / order << 2 | cell
+      uint32_t tag0[3], tag1[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        tag0[q] = ((rt.vp3 >> (4 * rank[q])) & 0xcu) | (uint32_t)q;
+        tag1[q] = ((rt.ord2 >> (4 * rank[q])) & 0xcu) | (uint32_t)q;
+      }
+      for (int32_t it = 0;; ++it) {
+        n_evals += 1;
+        // (lane i is right after evaluation i + 1, so 65 evaluations always suffice: more means the LDS did not hand
+        // the additions out in lane order — give up with a status instead of looping)
+        if (it > 66) { stuck = true; break; }
+        int32_t oc;
+        if (fast) {
+          // first pick: count[.][0], first strictly smaller in visit order == minimum of (count, visit position)
+          const uint32_t k00 = (x[0] << 16) | tag0[0], k01 = (x[1] << 16) | tag0[1], k02 = (x[2] << 16) | tag0[2];
+          const uint32_t kmin = k00 < k01 ? (k00 < k02 ? k00 : k02) : (k01 < k02 ? k01 : k02);
+          const uint32_t w0 = kmin & 3u;
+          // second pick: count[.][1] over the two that are left
+          const uint32_t k10 = (x[0] & KAS_RELAX_F1_MASK) | tag1[0], k11 = (x[1] & KAS_RELAX_F1_MASK) | tag1[1],
+                         k12 = (x[2] & KAS_RELAX_F1_MASK) | tag1[2];
+          const uint32_t lo = w0 == 0u ? k11 : k10, hi = w0 == 2u ? k11 : k12;
+          const uint32_t w1 = (lo < hi ? lo : hi) & 3u;
+          oc = (int32_t)(w0 | (w1 << 2));
+        } else {
+          oc = relax_eval_generic(x, valid, rank, Lp, rt);
+        }
+        if (kasw::ballot(oc != oc_prev) == 0ull) break;      // nobody's outcome moved: the words hold the tile's commits
+        // ---- my row's addends into its slot
+        RelaxSlot sl;
+        if (fast) {
+          sl = lut[oc];
+        } else {
+          const int32_t w0 = oc & 3, w1 = (oc >> 2) & 3;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            sl.v[q] = (Lp >= 1 && q == w0) ? KAS_RELAX_F0_ONE : ((Lp >= 2 && q == w1) ? KAS_RELAX_F1_ONE : 0u);
+          sl.v[3] = (uint32_t)(3 - w0 - w1);
+        }
+        last_cell = sl.v[3];
+        stage[lane] = sl;
+        kasw::lockstep();
+        // ---- pair lanes: take the previous additions back, add in row-major order, hand the sums back
+        uint32_t nadd[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) nadd[t] = *pslot[t];
+        if (oc_prev >= 0) {                                   // (wave-uniform)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
+        }
+        kasw::lockstep();
+        uint32_t got[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          got[t] = kasw::lds_add_rtn_u32(padr[t], nadd[t]);
+          kasw::lockstep();                                  // (one instruction at a time, lanes in order: the hardware's order)
+          padd[t] = nadd[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) *(uint32_t*)pslot[t] = got[t];
+        kasw::lockstep();
+        const RelaxSlot back = stage[lane];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) x[q] = back.v[q];
+        oc_prev = oc;
+      }
+      // ---- the final row: broker ids in list order, digest
+      if (fast) {
+        const uint32_t q0 = (uint32_t)oc_prev & 3u, q1 = ((uint32_t)oc_prev >> 2) & 3u, q2 = last_cell;
+        const uint32_t l0 = q0 == 0u ? c[0] : (q0 == 1u ? c[1] : c[2]);
+        const uint32_t l1 = q1 == 0u ? c[0] : (q1 == 1u ? c[1] : c[2]);
+        const uint32_t l2 = q2 == 0u ? c[0] : (q2 == 1u ? c[1] : c[2]);
+        RowW<3> o;
+        o.v[0] = g_node_id[l0]; o.v[1] = g_node_id[l1]; o.v[2] = g_node_id[l2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)q, o.v[q]);
+        if constexpr (W == 3) *reinterpret_cast<RowW<3>*>(out + (int64_t)p * 3) = o;
+      } else {
+        n_slow += 1;
+        if (active) {
+          const int32_t w0 = oc_prev & 3, w1 = (oc_prev >> 2) & 3, w2 = 3 - w0 - w1;
+          const int32_t w[3] = {w0, w1, w2};
+#pragma unroll
+          for (int r = 0; r < W; ++r) {
+            if (r < ow) {
+              const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
+              const int32_t id = r < Lp ? g_node_id[cell] : -1;
+              out[(int64_t)p * ow + r] = id;
+              if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
+            }
+          }
+        }
+      }
+    }
+  }
+  const uint64_t dsum = kasw::wave_sum_u64(digest);
+  if (lane == 0) {
+    a.scenario_results[s].digest = dsum;
+    if (stuck) {
+      a.scenario_results[s].status = KAS_FAIL_WATCHDOG;
+      a.scenario_results[s].fail_topic = -1; a.scenario_results[s].fail_partition = -1;
+    }
+    if (a.stats) {
+      int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      st[8] = kasw::clock_ticks() - t_begin; st[9] = n_evals; st[12] = n_tiles; st[13] = n_slow;
+    }
+  }
+}
+
+}  // namespace kas

@@ -60,6 +60,8 @@ struct KasLaunch {
 #define KAS_FLAG_ONLY_FLAGGED 64u  // set by the launcher: the fill kernel takes only the scenarios the spread fill handed back
 #define KAS_FLAG_ORDER_FLAGGED 128u // set by the launcher: the round-form order kernel takes only scenarios with ord_flag set
 #define KAS_FLAG_WIDE_CHECK   256u  // set by the launcher (KasShape::wide_checked): the wide ticket form checks its count fields at the end
+#define KAS_FLAG_TICKET_ORDER 0x10000u // lists <= 3 wide: the ticket form of P5 where the relaxation form would run (testing / comparison);
+                                       // KAS_PLAN_GROUPS(n) and KAS_PLAN_WIDE_COUNTERS, which only mean something to the ticket form, imply it
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
@@ -249,6 +251,16 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 }
 #define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
+// relaxation form of P5 (kas_order_relax.h), one wavefront per scenario: one uint32 counter word per node + the
+// padding node's, a 16-entry outcome table, a 16-byte staging slot per row of the tile
+KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  return kas_align16(kas_align16(4 * (n + 1)) + 16 * 16 + 64 * 16);
+}
+// does a flag word (KAS_PLAN_* / KAS_FLAG_*) ask for the ticket form where the relaxation form is applicable?
+KAS_ABI_FN int32_t kas_flags_want_tickets(uint32_t flags) {
+  return (flags & (KAS_FLAG_TICKET_ORDER | KAS_FLAG_WIDE_COUNTERS)) != 0u || ((flags >> 12) & 0xfu) != 0u;
+}
 KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {
   int64_t n = n_max > 0 ? n_max : 1;
   return kas_align16(kas_align16(4 * n * kas_cnt_stride(W)) + 8 * n + 64);
@@ -269,6 +281,7 @@ struct KasShape {
   int32_t bound_small = 1;            // every scenario's ticket bound fits 10-bit counter fields
   int32_t any_ctx = 0;                // some scenario hands a Context in / wants it back
   int32_t wide_ok = 0;                // lists 4 or 5 wide and the wide ticket form is applicable
+  int32_t relax_ok = 0;               // lists <= 3 wide and the relaxation form (kas_order_relax.h) is applicable to every scenario
   int32_t bound_mid = 1;              // every scenario's ticket bound is below KAS_WIDE_COMMIT_LIMIT
   int32_t wide_checked = 0;           // wide_ok with a ticket bound of 1023 or more somewhere: the kernel checks its count
                                       // fields at the end and a scenario that outgrew them is solved again (fill + round form)
@@ -434,6 +447,9 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // lists 4 and 5 wide: the wide ticket form (kas_order_wide.h) under the same conditions plus 10-bit
   // count fields and 16-bit LDS offsets of its 8-byte counter rows; beyond 5: round form
   s.packed_ok = s.bound_small && !s.any_ctx;
+  // relaxation form: what the packed ticket form asks for (no Context, no KAS:190 index error, rows per node
+  // inside the count fields) — decided before the 16-bit-offset limits of the ticket form below, which it does not have
+  s.relax_ok = s.Wc <= 3 && s.tickets_ok && s.packed_ok && kas_order_relax_lds(s.n_max) <= KAS_LDS_LIMIT;
   // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
   // to the round form — which must then fit)
   s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&
@@ -473,7 +489,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // the round form of P5 is the universal fallback; a batch that one of the ticket forms serves does
   // not need it to fit (KAS_PLAN_ROUND_ORDER is refused for such a plan, see round_fits)
   s.round_fits = kas_order_round_lds(s.n_max, s.Wc) <= KAS_LDS_LIMIT;
-  if (err_total == 0 && !s.round_fits && (!(s.tickets_ok || s.wide_ok) || s.any_ctx))
+  if (err_total == 0 && !s.round_fits && (!(s.tickets_ok || s.wide_ok || s.relax_ok) || s.any_ctx))
     err_total = kas_order_round_lds(s.n_max, s.Wc);
   if (err_total)
     return fail(KAS_E_UNSUPPORTED, "broker count " + std::to_string(s.n_max) + " x width " +

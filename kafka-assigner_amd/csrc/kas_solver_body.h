@@ -2778,3 +2778,4 @@ KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char*
 }  // namespace kas
 
 #include "kas_order_wide.h"
+#include "kas_order_relax.h"

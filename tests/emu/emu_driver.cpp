@@ -212,6 +212,10 @@ template <int W> void run_order_wide(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
 }
+template <int W> void run_order_relax(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  if constexpr (W <= 3) kas::order_relax<W>(*r->a, r->s, r->lds);
+}
 template <int W> void run_order_rounds(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_scenario_rounds<W>(*r->a, r->s, r->lds);
@@ -259,10 +263,12 @@ run_fn rounds_for(int Wc) {
 static long g_last_queue_rows = 0;
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
-static int g_last_order_form = 0;   // 1: ticket form (lists <= 3 wide), 2: wide ticket form, 0: round form (the last solve's plan)
+static int g_last_order_form = 0;   // 1: ticket form (lists <= 3 wide), 2: wide ticket form, 3: relaxation form, 0: round form (the last solve's plan)
+static long g_last_relax_tiles = 0, g_last_relax_evals = 0, g_last_relax_slow = 0;   // relaxation form: tiles, evaluations, tiles off the straight-line path
 static int g_last_flagged = 0; // scenarios a ticket form left to the round form (Context counters too large for its fields)
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
-// 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice)
+// 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice),
+// bit 16 = KAS_FLAG_TICKET_ORDER (the ticket form where the relaxation form would run)
 extern "C" __attribute__((visibility("default")))
 int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen) {
   KasShape sh;
@@ -272,9 +278,12 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if (errbuf && errlen > 0) { strncpy(errbuf, err.c_str(), (size_t)errlen - 1); errbuf[errlen - 1] = 0; }
     return rc;
   }
-  const bool tickets = sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER);
+  // (the launch decisions of kas_launch_plan in kas_hip.hip)
+  const bool relax = sh.relax_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !(kas_flags_want_tickets(flags) && sh.tickets_ok);
+  const bool tickets = !relax && sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER);
   const bool wide = sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER);
-  g_last_order_form = tickets ? 1 : (wide ? 2 : 0);
+  g_last_order_form = relax ? 3 : (tickets ? 1 : (wide ? 2 : 0));
+  g_last_relax_tiles = 0; g_last_relax_evals = 0; g_last_relax_slow = 0;
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
   const bool fused = sh.fused_ok && !(flags & KAS_FLAG_TWO_PASS_HIST) && !(flags & KAS_FLAG_GENERIC_FILL);
@@ -285,6 +294,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     return KAS_E_UNSUPPORTED;
   }
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
+  if ((size_t)kas_order_relax_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_relax_lds(sh.n_max);
   if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
   if (lds_bytes < sizeof(int32_t) * (KAS_PERM_BINS + 8)) lds_bytes = sizeof(int32_t) * (KAS_PERM_BINS + 8);
   std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
@@ -305,7 +315,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   g_last_flagged = 0;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch;
-  a.flags = (flags & 0xffu & ~KAS_FLAG_FUSED_HIST) | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u);
+  a.flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER) & ~KAS_FLAG_FUSED_HIST) | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u);
   auto bad = [&](const char* what, int32_t s) {
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;
@@ -364,8 +374,24 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill", s);
   }
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
-  // order kernel: one wavefront per G scenarios (ticket form) or per scenario (round form)
-  if (tickets) {
+  // order kernel: one wavefront per scenario (relaxation form, round form), three per G scenarios (ticket form)
+  if (relax) {
+    run_fn f = sh.Wc <= 2 ? run_order_relax<2> : run_order_relax<3>;
+    // exactly the LDS the product launches the kernel with, and a guard behind it: the hardware drops what a
+    // workgroup writes beyond its allocation and reads zeros there — here that must not pass unnoticed
+    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max);
+    std::vector<unsigned char> rl(relax_bytes + 4096);
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(rl.data(), 0xCD, relax_bytes);
+      memset(rl.data() + relax_bytes, 0xA5, 4096);
+      RunArgs ra{&a, s, rl.data()};
+      if (kasw::run_block(f, &ra, 1) != 0) return bad("order (relaxation)", s);
+      for (size_t i = 0; i < 4096; ++i)
+        if (rl[relax_bytes + i] != 0xA5) return bad("order (relaxation): LDS written beyond kas_order_relax_lds()", s);
+      const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      g_last_relax_evals += (long)st[9]; g_last_relax_tiles += (long)st[12]; g_last_relax_slow += (long)st[13];
+    }
+  } else if (tickets) {
     if (sh.G > 1 && b->n_scenarios > sh.G) {
       a.perm = perm.data();                              // the permutation kernel: one workgroup
       memset(lds.data(), 0xCD, lds.size());
@@ -457,7 +483,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
 }
 
 // The product's planning decision for a batch shape, without running anything (plan-math tests):
-// out[0..8] = tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok, wide_checked.  Returns kas_shape_batch's code.
+// out[0..9] = tickets_ok, wide_ok, round_fits, G, NW, with_x, packed_ok, fused_ok, wide_checked, relax_ok.  Returns kas_shape_batch's code.
 extern "C" __attribute__((visibility("default")))
 int kas_emu_shape(const kas_batch_desc* b, int32_t* out, char* errbuf, int errlen) {
   KasShape sh;
@@ -468,7 +494,7 @@ int kas_emu_shape(const kas_batch_desc* b, int32_t* out, char* errbuf, int errle
     return rc;
   }
   out[0] = sh.tickets_ok; out[1] = sh.wide_ok; out[2] = sh.round_fits; out[3] = sh.G; out[4] = sh.NW;
-  out[5] = sh.with_x; out[6] = sh.packed_ok; out[7] = sh.fused_ok; out[8] = sh.wide_checked;
+  out[5] = sh.with_x; out[6] = sh.packed_ok; out[7] = sh.fused_ok; out[8] = sh.wide_checked; out[9] = sh.relax_ok;
   return rc;
 }
 
@@ -505,6 +531,10 @@ int kas_emu_last_flagged(void) { return g_last_flagged; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_order_form(void) { return g_last_order_form; }
+
+// relaxation form of the last kas_emu_solve_batch: out[0..2] = tiles, evaluations, tiles off the straight-line path
+extern "C" __attribute__((visibility("default")))
+void kas_emu_last_relax_stats(long* out) { out[0] = g_last_relax_tiles; out[1] = g_last_relax_evals; out[2] = g_last_relax_slow; }
 
 // ---------------------------------------------------------------------------------------------
 // Unit harness for the parallel P4 of the fill kernel (p4_lists_parallel<3, 4>): the caller gives the

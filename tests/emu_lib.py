@@ -32,6 +32,7 @@ TEST_VARIANTS = {
 def _deps():
     return [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "kas_wave.h"),
             os.path.join(CSRC, "kas_solver_body.h"), os.path.join(CSRC, "kas_order_wide.h"),
+            os.path.join(CSRC, "kas_order_relax.h"),
             os.path.join(CSRC, "kas_plan_math.h"), os.path.join(ROOT, "include", "kas_abi.h")]
 
 
@@ -197,10 +198,10 @@ def plan_shape(fb: FlatBatch):
     L.kas_emu_shape.restype = C.c_int
     L.kas_emu_shape.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(C.c_int32), C.c_char_p, C.c_int]
     bd = batch_desc(fb)
-    out = (C.c_int32 * 9)()
+    out = (C.c_int32 * 10)()
     err = C.create_string_buffer(512)
     rc = L.kas_emu_shape(C.byref(bd), out, err, 512)
-    names = ("tickets_ok", "wide_ok", "round_fits", "G", "NW", "with_x", "packed_ok", "fused_ok", "wide_checked")
+    names = ("tickets_ok", "wide_ok", "round_fits", "G", "NW", "with_x", "packed_ok", "fused_ok", "wide_checked", "relax_ok")
     return rc, dict(zip(names, list(out))), err.value.decode()
 
 
@@ -213,10 +214,23 @@ def last_flagged() -> int:
 
 
 def last_order_form() -> int:
-    """Order kernel of the last emu_solve: 1 ticket form (lists <= 3 wide), 2 wide ticket form, 0 round form."""
+    """Order kernel of the last emu_solve: 1 ticket form (lists <= 3 wide), 2 wide ticket form, 3 relaxation form,
+    0 round form."""
     L = lib()
     L.kas_emu_last_order_form.restype = C.c_int
     return int(L.kas_emu_last_order_form())
+
+
+TICKET_ORDER = 0x10000     # KAS_PLAN_TICKET_ORDER: the ticket form where the relaxation form would run
+
+
+def last_relax_stats():
+    """Relaxation form of the last emu_solve: (tiles, evaluations, tiles off the straight-line path)."""
+    L = lib()
+    L.kas_emu_last_relax_stats.restype = None
+    out = (C.c_long * 3)()
+    L.kas_emu_last_relax_stats(out)
+    return tuple(int(v) for v in out)
 
 
 def spread_plan(fb: FlatBatch):
