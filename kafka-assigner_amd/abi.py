@@ -26,6 +26,14 @@ KAS_SKIPPED = 6
 KAS_FAIL_BAD_NODES = 7
 KAS_FAIL_WATCHDOG = 8
 
+# plan flags (kas_plan_set_flags; include/kas_abi.h)
+KAS_PLAN_GENERIC_FILL = 1
+KAS_PLAN_ROUND_ORDER = 2
+KAS_PLAN_WIDE_COUNTERS = 4
+KAS_PLAN_TWO_PASS_HIST = 8
+KAS_PLAN_SPREAD_FILL = 32
+KAS_PLAN_TICKET_ORDER = 0x10000
+
 STATUS_NAMES = {
     KAS_OK: "OK",
     KAS_FAIL_UNASSIGNABLE: "FAIL_UNASSIGNABLE",

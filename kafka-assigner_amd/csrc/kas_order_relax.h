@@ -110,6 +110,32 @@ KAS_DEV int32_t relax_eval_generic(const uint32_t (&x)[3], const bool (&valid)[3
   return w0 | (w1 << 2);
 }
 
+// One relaxation step of a tile, as the pair lanes see it: the rows' addends are in their staging slots; take the
+// previous additions back, add the pairs in row-major order (three instructions, lanes ascending), put what each add
+// returned into the pair's cell of its row's slot.  Afterwards every row lane finds in its slot the counter words
+// of its cells as its row would see them with the current outcomes of all earlier rows of the tile committed.
+KAS_DEV void relax_pairs(const uint32_t* const (&pslot)[3], uint32_t* const (&padr)[3], uint32_t (&padd)[3], bool undo) {
+  kasw::lockstep();                                          // the rows' slots are written
+  uint32_t nadd[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) nadd[t] = *pslot[t];
+  if (undo) {                                                // (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
+  }
+  kasw::lockstep();
+  uint32_t got[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    got[t] = kasw::lds_add_rtn_u32(padr[t], nadd[t]);
+    kasw::lockstep();                                        // (one instruction at a time, lanes in order: the hardware's order)
+    padd[t] = nadd[t];
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) *(uint32_t*)pslot[t] = got[t];
+  kasw::lockstep();
+}
+
 template <int W>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
@@ -118,20 +144,28 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   const int32_t N = sd.n_nodes;
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   uint32_t* cnt = (uint32_t*)lds_raw;                       // [nmax + 1]: + the padding node's word
-  RelaxSlot* lut = (RelaxSlot*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [16] by outcome
-  RelaxSlot* stage = lut + 16;                              // [64] by row of the tile
+  RelaxSlot* lut = (RelaxSlot*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [16] by outcome: addends of cells 0..2
+  RelaxSlot* sel = lut + 16;                                // [16] by outcome: byte selectors of list positions 0..2
+  uint32_t* tagtab = (uint32_t*)(sel + 16);                 // [8] by the order of a row's three cells: its six tags
+  RelaxSlot* stage = (RelaxSlot*)(tagtab + 8);              // [64] by row of the tile
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int64_t t_begin = kasw::clock_ticks();
   for (int32_t n = lane; n < N; n += 64) cnt[n] = 0u;
   if (lane == 0) cnt[nmax] = KAS_RELAX_PAD_WORD;
   if (lane < 16) {
-    RelaxSlot e;
-    const int32_t w0 = lane & 3, w1 = lane >> 2;
+    RelaxSlot e, f;
+    const int32_t w0 = lane & 3, w1 = lane >> 2, w2 = 3 - w0 - w1;
     const bool ok = w0 < 3 && w1 < 3 && w0 != w1;
 #pragma unroll
     for (int k = 0; k < 3; ++k) e.v[k] = !ok ? 0u : (k == w0 ? KAS_RELAX_F0_ONE : (k == w1 ? KAS_RELAX_F1_ONE : 0u));
-    e.v[3] = ok ? (uint32_t)(3 - w0 - w1) : 0u;            // the cell that goes last
+    e.v[3] = 0u;
+    // list position r takes cell w_r: bytes 2 w_r, 2 w_r + 1 of the mid row (v_perm_b32 selector, high half zero)
+    const int32_t w[3] = {w0, w1, w2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) f.v[r] = ok ? (0x0c0c0000u | (uint32_t)((2 * w[r] + 1) << 8) | (uint32_t)(2 * w[r])) : 0x0c0c0c0cu;
+    f.v[3] = 0u;
     lut[lane] = e;
+    sel[lane] = f;
   }
   // my three pairs (as a pair lane): pair v = 64 t + lane is cell v mod 3 of row v div 3
   const uint32_t* pslot[3];                                 // where the pair's addend comes from and its sum goes back
@@ -158,6 +192,21 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     const RelaxTopic rt = relax_topic(td.name_hash);
     const int32_t nt = (P + 63) >> 6;
     const bool full_width = W == 3 && ow == 3;
+    // the topic's tags by the order of a row's cells: bit 0 = cell 0 < cell 1, bit 1 = cell 0 < cell 2, bit 2 = cell 1 <
+    // cell 2;  word = first-pick tags of cells 0..2 (4 bits each), then the second-pick tags
+    kasw::lockstep();
+    if (lane < 8) {
+      const int32_t ab = lane & 1, ac = (lane >> 1) & 1, bc = (lane >> 2) & 1;
+      const int32_t rank[3] = {(1 - ab) + (1 - ac), ab + (1 - bc), ac + bc};
+      uint32_t w = 0u;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        w |= (((rt.vp3 >> (4 * rank[q])) & 0xcu) | (uint32_t)q) << (4 * q);
+        w |= (((rt.ord2 >> (4 * rank[q])) & 0xcu) | (uint32_t)q) << (12 + 4 * q);
+      }
+      tagtab[lane] = w;
+    }
+    kasw::lockstep();
     MidRaw<W> nxr = mid_load_raw<W>(mid, ow, lane < P ? lane : 0, lane < P);   // next tile's mid row (read ahead)
     for (int32_t tile = 0; tile < nt; ++tile) {
       const int32_t p = (tile << 6) + lane;
@@ -176,34 +225,82 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
         for (int q = 0; q < 3; ++q) c[q] = q < W ? (raw.w[q] & 0xffffu) : KAS_MID_NONE;
       }
-      // ---- hand the cells to the pair lanes: slot = (cell 0 | cell 1 << 16, cell 2, -, -)
-      {
-        RelaxSlot sl;
-        sl.v[0] = c[0] | (c[1] << 16); sl.v[1] = c[2] | 0xffff0000u; sl.v[2] = 0u; sl.v[3] = 0u;
-        kasw::lockstep();                                    // (the previous tile's slot has been read)
-        stage[lane] = sl;
-        kasw::lockstep();
-      }
-      uint32_t* padr[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const uint32_t n = (uint32_t)*pcell[t];
-        padr[t] = cnt + (n < (uint32_t)nmax ? n : (uint32_t)nmax);   // no holder: the padding node, and + 0
-      }
-      // counter words of my cells as the previous tile left them
-      uint32_t x[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) x[q] = cnt[c[q] < (uint32_t)nmax ? c[q] : (uint32_t)nmax];
-      kasw::lockstep();
       // the usual tile: 64 rows, three holders each, rows of the batch's width
       bool fast = false;
       if constexpr (W == 3) {
         if (full_width && ((tile + 1) << 6) <= P)
           fast = kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
       }
+      // ---- hand the cells to the pair lanes: slot = (cell 0 | cell 1 << 16, cell 2 | none << 16, -, -)
+      kasw::lockstep();                                      // (the previous tile's slot has been read)
+      {
+        uint32_t* sl = (uint32_t*)&stage[lane];
+        RowWords<2> two;
+        two.v[0] = c[0] | (c[1] << 16); two.v[1] = c[2] | 0xffff0000u;
+        *(RowWords<2>*)sl = two;
+      }
+      kasw::lockstep();
+      uint32_t* padr[3];
       uint32_t padd[3] = {0u, 0u, 0u};                       // what my pairs added last
-      int32_t oc_prev = -1;
-      uint32_t last_cell = 0u;
+      if constexpr (W == 3) {
+        if (fast) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) padr[t] = cnt + (uint32_t)*pcell[t];
+          // counter words of my cells as the previous tile left them
+          uint32_t x0 = cnt[c[0]], x1 = cnt[c[1]], x2 = cnt[c[2]];
+          // my row's six tags from the order of its cells
+          const uint32_t oidx = ((c[0] - c[1]) >> 31) | (((c[0] - c[2]) >> 31) << 1) | (((c[1] - c[2]) >> 31) << 2);
+          const uint32_t tw = tagtab[oidx];
+          const uint32_t t00 = tw & 15u, t01 = (tw >> 4) & 15u, t02 = (tw >> 8) & 15u;
+          const uint32_t t10 = (tw >> 12) & 15u, t11 = (tw >> 16) & 15u, t12 = (tw >> 20) & 15u;
+          kasw::lockstep();
+          int32_t oc_prev = -1;
+          for (int32_t it = 0;; ++it) {
+            n_evals += 1;
+            // (lane i is right after evaluation i + 1, so 65 evaluations always suffice: more means the LDS did not
+            // hand the additions out in lane order — give up with a status instead of looping)
+            if (it > 66) { stuck = true; break; }
+            // first pick: count[.][0], first strictly smaller in visit order == minimum of (count, visit position)
+            const uint32_t k00 = (x0 << 16) | t00, k01 = (x1 << 16) | t01, k02 = (x2 << 16) | t02;
+            const uint32_t kmin = k00 < k01 ? (k00 < k02 ? k00 : k02) : (k01 < k02 ? k01 : k02);
+            const uint32_t w0 = kmin & 3u;
+            // second pick: count[.][1] over the two that are left
+            const uint32_t k10 = (x0 & KAS_RELAX_F1_MASK) | t10, k11 = (x1 & KAS_RELAX_F1_MASK) | t11,
+                           k12 = (x2 & KAS_RELAX_F1_MASK) | t12;
+            const uint32_t lo = w0 == 0u ? k11 : k10, hi = w0 == 2u ? k11 : k12;
+            const uint32_t w1 = (lo < hi ? lo : hi) & 3u;
+            const int32_t oc = (int32_t)(w0 | (w1 << 2));
+            if (kasw::ballot(oc != oc_prev) == 0ull) break;  // nobody's outcome moved: the words hold the tile's commits
+            stage[lane] = lut[oc];                           // my row's addends into its slot
+            relax_pairs(pslot, padr, padd, it > 0);
+            const RelaxSlot back = stage[lane];
+            x0 = back.v[0]; x1 = back.v[1]; x2 = back.v[2];
+            oc_prev = oc;
+          }
+          // ---- the final row: broker ids in list order, digest
+          const RelaxSlot sv = sel[oc_prev < 0 ? 0 : oc_prev];
+          const uint32_t l0 = kasw::perm_bytes(raw.w[1], raw.w[0], sv.v[0]);
+          const uint32_t l1 = kasw::perm_bytes(raw.w[1], raw.w[0], sv.v[1]);
+          const uint32_t l2 = kasw::perm_bytes(raw.w[1], raw.w[0], sv.v[2]);
+          RowW<3> o;
+          o.v[0] = g_node_id[l0]; o.v[1] = g_node_id[l1]; o.v[2] = g_node_id[l2];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)q, o.v[q]);
+          *reinterpret_cast<RowW<3>*>(out + (int64_t)p * 3) = o;
+          continue;
+        }
+      }
+      // ---- any other tile: per-lane list lengths
+      n_slow += 1;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const uint32_t n = (uint32_t)*pcell[t];
+        padr[t] = cnt + (n < (uint32_t)nmax ? n : (uint32_t)nmax);   // no holder: the padding node, and + 0
+      }
+      uint32_t x[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) x[q] = cnt[c[q] < (uint32_t)nmax ? c[q] : (uint32_t)nmax];
+      kasw::lockstep();
       bool valid[3];
       int32_t rank[3], Lp = 0;
 #pragma unroll
@@ -214,96 +311,35 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
         for (int j = 0; j < 3; ++j) rank[q] += (j != q && valid[j] && c[j] < c[q]) ? 1 : 0;
       }
-      // tags of the straight-line evaluation (three holders): visit position / order << 2 | cell
-      uint32_t tag0[3], tag1[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        tag0[q] = ((rt.vp3 >> (4 * rank[q])) & 0xcu) | (uint32_t)q;
-        tag1[q] = ((rt.ord2 >> (4 * rank[q])) & 0xcu) | (uint32_t)q;
-      }
+      int32_t oc_prev = -1;
       for (int32_t it = 0;; ++it) {
         n_evals += 1;
-        // (lane i is right after evaluation i + 1, so 65 evaluations always suffice: more means the LDS did not hand
-        // the additions out in lane order — give up with a status instead of looping)
         if (it > 66) { stuck = true; break; }
-        int32_t oc;
-        if (fast) {
-          // first pick: count[.][0], first strictly smaller in visit order == minimum of (count, visit position)
-          const uint32_t k00 = (x[0] << 16) | tag0[0], k01 = (x[1] << 16) | tag0[1], k02 = (x[2] << 16) | tag0[2];
-          const uint32_t kmin = k00 < k01 ? (k00 < k02 ? k00 : k02) : (k01 < k02 ? k01 : k02);
-          const uint32_t w0 = kmin & 3u;
-          // second pick: count[.][1] over the two that are left
-          const uint32_t k10 = (x[0] & KAS_RELAX_F1_MASK) | tag1[0], k11 = (x[1] & KAS_RELAX_F1_MASK) | tag1[1],
-                         k12 = (x[2] & KAS_RELAX_F1_MASK) | tag1[2];
-          const uint32_t lo = w0 == 0u ? k11 : k10, hi = w0 == 2u ? k11 : k12;
-          const uint32_t w1 = (lo < hi ? lo : hi) & 3u;
-          oc = (int32_t)(w0 | (w1 << 2));
-        } else {
-          oc = relax_eval_generic(x, valid, rank, Lp, rt);
-        }
-        if (kasw::ballot(oc != oc_prev) == 0ull) break;      // nobody's outcome moved: the words hold the tile's commits
-        // ---- my row's addends into its slot
+        const int32_t oc = relax_eval_generic(x, valid, rank, Lp, rt);
+        if (kasw::ballot(oc != oc_prev) == 0ull) break;
         RelaxSlot sl;
-        if (fast) {
-          sl = lut[oc];
-        } else {
-          const int32_t w0 = oc & 3, w1 = (oc >> 2) & 3;
+        const int32_t w0 = oc & 3, w1 = (oc >> 2) & 3;
 #pragma unroll
-          for (int q = 0; q < 3; ++q)
-            sl.v[q] = (Lp >= 1 && q == w0) ? KAS_RELAX_F0_ONE : ((Lp >= 2 && q == w1) ? KAS_RELAX_F1_ONE : 0u);
-          sl.v[3] = (uint32_t)(3 - w0 - w1);
-        }
-        last_cell = sl.v[3];
+        for (int q = 0; q < 3; ++q)
+          sl.v[q] = (Lp >= 1 && q == w0) ? KAS_RELAX_F0_ONE : ((Lp >= 2 && q == w1) ? KAS_RELAX_F1_ONE : 0u);
+        sl.v[3] = 0u;
         stage[lane] = sl;
-        kasw::lockstep();
-        // ---- pair lanes: take the previous additions back, add in row-major order, hand the sums back
-        uint32_t nadd[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) nadd[t] = *pslot[t];
-        if (oc_prev >= 0) {                                   // (wave-uniform)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
-        }
-        kasw::lockstep();
-        uint32_t got[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          got[t] = kasw::lds_add_rtn_u32(padr[t], nadd[t]);
-          kasw::lockstep();                                  // (one instruction at a time, lanes in order: the hardware's order)
-          padd[t] = nadd[t];
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) *(uint32_t*)pslot[t] = got[t];
-        kasw::lockstep();
+        relax_pairs(pslot, padr, padd, it > 0);
         const RelaxSlot back = stage[lane];
 #pragma unroll
         for (int q = 0; q < 3; ++q) x[q] = back.v[q];
         oc_prev = oc;
       }
-      // ---- the final row: broker ids in list order, digest
-      if (fast) {
-        const uint32_t q0 = (uint32_t)oc_prev & 3u, q1 = ((uint32_t)oc_prev >> 2) & 3u, q2 = last_cell;
-        const uint32_t l0 = q0 == 0u ? c[0] : (q0 == 1u ? c[1] : c[2]);
-        const uint32_t l1 = q1 == 0u ? c[0] : (q1 == 1u ? c[1] : c[2]);
-        const uint32_t l2 = q2 == 0u ? c[0] : (q2 == 1u ? c[1] : c[2]);
-        RowW<3> o;
-        o.v[0] = g_node_id[l0]; o.v[1] = g_node_id[l1]; o.v[2] = g_node_id[l2];
+      if (active && oc_prev >= 0) {
+        const int32_t w0 = oc_prev & 3, w1 = (oc_prev >> 2) & 3, w2 = 3 - w0 - w1;
+        const int32_t w[3] = {w0, w1, w2};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)q, o.v[q]);
-        if constexpr (W == 3) *reinterpret_cast<RowW<3>*>(out + (int64_t)p * 3) = o;
-      } else {
-        n_slow += 1;
-        if (active) {
-          const int32_t w0 = oc_prev & 3, w1 = (oc_prev >> 2) & 3, w2 = 3 - w0 - w1;
-          const int32_t w[3] = {w0, w1, w2};
-#pragma unroll
-          for (int r = 0; r < W; ++r) {
-            if (r < ow) {
-              const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
-              const int32_t id = r < Lp ? g_node_id[cell] : -1;
-              out[(int64_t)p * ow + r] = id;
-              if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
-            }
+        for (int r = 0; r < W; ++r) {
+          if (r < ow) {
+            const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
+            const int32_t id = r < Lp ? g_node_id[cell] : -1;
+            out[(int64_t)p * ow + r] = id;
+            if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
           }
         }
       }

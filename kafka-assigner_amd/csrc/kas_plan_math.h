@@ -252,10 +252,11 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 #define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 // relaxation form of P5 (kas_order_relax.h), one wavefront per scenario: one uint32 counter word per node + the
-// padding node's, a 16-entry outcome table, a 16-byte staging slot per row of the tile
+// padding node's, two 16-entry outcome tables (addends, list selectors), 8 tag words, a 16-byte staging slot per
+// row of the tile
 KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
-  return kas_align16(kas_align16(4 * (n + 1)) + 16 * 16 + 64 * 16);
+  return kas_align16(kas_align16(4 * (n + 1)) + 2 * 16 * 16 + 8 * 4 + 64 * 16);
 }
 // does a flag word (KAS_PLAN_* / KAS_FLAG_*) ask for the ticket form where the relaxation form is applicable?
 KAS_ABI_FN int32_t kas_flags_want_tickets(uint32_t flags) {

@@ -86,6 +86,9 @@ KAS_DEV int32_t opaque(int32_t v) {
   return v;
 }
 
+// v_perm_b32: result byte i = byte sel[i] of the eight bytes hi:lo (0..3 = lo, 4..7 = hi), 0x0c = 0x00
+KAS_DEV uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
 // a * b for small non-negative factors (node index x block stride): the full-rate 24-bit multiply
 KAS_DEV int32_t mul24(int32_t a, int32_t b) { return (int32_t)__umul24((unsigned)a, (unsigned)b); }
 

@@ -31,8 +31,10 @@ from oracle_lib import oracle_solve  # noqa: E402
 # The kernel families and plan variants a solve can launch, each at a shape that takes it (name, must appear
 # in the plan's description, bench.py flags).  The first is the headline shape (BASELINE.json configs[2]).
 SUITE = [
-    ("headline: fill<3,4> per-chunk histograms + packed ticket form, 2 scenarios per wavefront",
-     "kas_order_ticket_kernel<3,2,true>", ["--in-flight", "12"]),
+    ("headline: fill<3,4> per-chunk histograms + relaxation form of the order kernel",
+     "kas_order_relax_kernel<3>", ["--in-flight", "12"]),
+    ("packed ticket form, 2 scenarios per wavefront (KAS_PLAN_TICKET_ORDER)",
+     "kas_order_ticket_kernel<3,2,true>", ["--plan-flags", "65536", "--in-flight", "12"]),
     ("one scenario per solver wavefront (G = 1)", "kas_order_ticket_kernel<3,1,true>", ["--groups", "1", "--in-flight", "12"]),
     ("4 x uint16 counter rows", "kas_order_ticket_kernel<3,2,false>", ["--plan-flags", "4", "--in-flight", "12"]),
     ("histogram for the whole topic + chunk-count pass", "kas_fill_kernel<3,4>[quota]", ["--plan-flags", "8", "--in-flight", "12"]),
@@ -48,9 +50,12 @@ SUITE = [
     ("spread fill (row scans over one-wavefront workgroups, kas_spread_p4_kernel) + wide ticket form", "kas_spread_",
      ["--scenarios", "16", "--partitions", "140000", "--brokers", "800", "--racks", "40", "--rf", "5",
       "--actions", "add_k,mixed", "--in-flight", "3"]),
-    ("spread fill, lists 3 wide + ticket form", "kas_spread_",
+    ("spread fill, lists 3 wide + relaxation form", "kas_spread_",
      ["--scenarios", "24", "--partitions", "140000", "--brokers", "1000", "--racks", "20", "--rf", "3",
       "--actions", "add_k,mixed", "--in-flight", "4"]),
+    ("spread fill, lists 3 wide + ticket form", "kas_order_ticket_kernel<3,",
+     ["--scenarios", "24", "--partitions", "140000", "--brokers", "1000", "--racks", "20", "--rf", "3",
+      "--actions", "add_k,mixed", "--in-flight", "4", "--plan-flags", "65536"]),
 ]
 
 

@@ -103,6 +103,17 @@ KAS_DEV int32_t opaque(int32_t v) { return v; }
 KAS_DEV int32_t pinned(int32_t v) { return v; }               // (hardware: a value the compiler must have in a register HERE)
 
 KAS_DEV int32_t mul24(int32_t a, int32_t b) { return a * b; }
+// (hardware: v_perm_b32; selectors 0..7 and 0x0c are the ones the kernels use)
+KAS_DEV uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) {
+  const uint64_t src = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t s = (sel >> (8 * i)) & 0xffu;
+    const uint32_t b = s < 8u ? (uint32_t)((src >> (8 * s)) & 0xffu) : (s == 0x0cu ? 0u : 0xffu);
+    r |= b << (8 * i);
+  }
+  return r;
+}
 KAS_DEV int popc(uint64_t m) { return __builtin_popcountll(m); }
 KAS_DEV int first_lane(uint64_t m) { return __builtin_ctzll(m); }
 KAS_DEV uint64_t lanemask_lt() { return (1ull << lane()) - 1ull; }

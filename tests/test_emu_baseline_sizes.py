@@ -9,7 +9,7 @@ import pytest
 from kafka_assigner_amd import abi
 from kafka_assigner_amd import generator as G
 from kafka_assigner_amd.flatten import uniform_batch
-from emu_lib import emu_solve, last_order_form, last_queue_rows, last_spread
+from emu_lib import TICKET_ORDER, emu_solve, last_order_form, last_queue_rows, last_relax_stats, last_spread
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_emu_parity import _batch
@@ -24,18 +24,24 @@ def test_emu_config2_10k_partitions_100_brokers_decommission_one():
         want = oracle_solve(fb)
         assert want.scenario_results["status"][0] == abi.KAS_OK
         assert_same_outputs(fb, want, emu_solve(fb), f"emu C2 seed {seed}")
+        assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), f"emu C2 seed {seed}, ticket form")
         assert_same_outputs(fb, want, emu_solve(fb, flags=2), f"emu C2 seed {seed}, round form")
 
 
 def test_emu_config3_full_size_scenarios_every_action_every_plan_variant():
     """configs[2]'s scenario: 100k partitions x 1k brokers x 20 racks, RF 3, the four action kinds — the kernels the
-    bench launches (fill with per-chunk histograms + 3-wide ticket form, two scenarios per wavefront, packed counter
-    rows) and every other form the plan can be made to take."""
+    bench launches (fill with per-chunk histograms + the relaxation form of the order kernel) and every other form the
+    plan can be made to take (the 3-wide ticket form, two scenarios per wavefront, packed counter rows, first)."""
     fb = _batch(2024, 4, 100000, 1000, 20, 3, G.ACTIONS)
     want = oracle_solve(fb)
     assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 2
     assert_same_outputs(fb, want, emu_solve(fb), "emu C3")
-    assert last_queue_rows() > 1000, "the queue path of the 3-wide solver did not run"
+    assert last_order_form() == 3, "not the relaxation form"
+    tiles, evals, slow = last_relax_stats()
+    assert tiles > 3000 and evals < 4 * tiles, ("evaluations per tile", tiles, evals)     # measured 3.3
+    assert slow <= 2 * 4, ("only the last tile of a topic leaves the straight-line path", slow)
+    assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu C3, ticket form")
+    assert last_order_form() == 1 and last_queue_rows() > 1000, "the queue path of the 3-wide solver did not run"
     for flags, what in ((1, "general fill"), (2, "round form"), (4, "4 x uint16 counter rows"), (8, "chunk-count pass"),
                         ((1 << 8) | (1 << 12), "1 fill wave, 1 scenario per wavefront"),
                         ((2 << 8) | (2 << 12), "2 fill waves, 2 scenarios per wavefront")):
@@ -50,6 +56,8 @@ def test_emu_config4_exact_action_add_brokers_1000_to_1049():
     assert (want.scenario_results["status"] == abi.KAS_OK).all()
     assert (want.scenario_results["moved_replicas"] > 10000).all()
     assert_same_outputs(fb, want, emu_solve(fb), "emu C4 add 50")
+    assert last_order_form() == 3
+    assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu C4 add 50, ticket form")
 
 
 @pytest.mark.timeout(900)

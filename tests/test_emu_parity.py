@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import emu_solve, last_queue_rows
+from emu_lib import TICKET_ORDER, emu_solve, last_queue_rows
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_oracle_vs_literal import scenarios
@@ -38,7 +38,8 @@ def test_emu_equals_oracle_small_odd_inputs_without_context_io(sc):
     fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=False,
                            topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
     want = oracle_solve(fb)
-    assert_same_outputs(fb, want, emu_solve(fb), "emu (no ctx)")
+    assert_same_outputs(fb, want, emu_solve(fb), "emu (no ctx): relaxation form where applicable")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu (no ctx), ticket form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=4 | (1 << 12)), "emu (no ctx), wide counters, 1 scenario per wave")
 
 
@@ -80,6 +81,7 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
     # every workgroup width, and the round form of the preference ordering
     for nw, g in ((1, 1), (2, 2), (8, 4)):
@@ -142,7 +144,8 @@ def test_emu_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
     assert (fb.scen["ctx_off"] < 0).all() and (fb.scen["topic_count"] == 3).all()
     want = oracle_solve(fb)
     assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 4      # and some that fail or are skipped
-    assert_same_outputs(fb, want, emu_solve(fb), "emu multi-topic tickets")
+    assert_same_outputs(fb, want, emu_solve(fb), "emu multi-topic, relaxation form")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu multi-topic tickets")
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu multi-topic rounds")
     assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 12) | (2 << 8)), "emu multi-topic, 2 scenarios per wave")
 
@@ -155,9 +158,10 @@ def test_emu_queue_path_runs_and_agrees():
     fb = _batch(4321, 4, 6000, 100, 10, 3, ("add_k", "mixed"))
     want = oracle_solve(fb)
     assert (want.scenario_results["status"] == abi.KAS_OK).any()
-    for flags in (0, 1 << 12, 4 | (4 << 12)):
+    for flags in (TICKET_ORDER, 1 << 12, 4 | (4 << 12)):
         assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu flags {flags:#x}")
         assert last_queue_rows() > 20, "the queue path did not run"
+    assert_same_outputs(fb, want, emu_solve(fb), "emu relaxation form")
 
 
 def test_emu_protocols_survive_arbitrary_wave_speeds():
@@ -178,7 +182,7 @@ def test_emu_protocols_survive_arbitrary_wave_speeds():
         "for acts, P, N in ((G.ACTIONS, 2000, 60), (('replace1', 'add_k'), 3500, 80)):\n"
         "    fb = _batch(99, 4, P, N, 8, 3, acts)\n"
         "    want = oracle_solve(fb)\n"
-        "    for flags in (0, 1 << 12, (8 << 8) | (4 << 12)):\n"
+        "    for flags in (0, 0x10000, 1 << 12, (8 << 8) | (4 << 12)):\n"
         "        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), 'chaos')\n"
         "for rf, acts in ((5, ('add_k', 'mixed')), (4, G.ACTIONS)):\n"      # the wide ticket form: joint solve, claim lists
         "    fb = _batch(77, 2, 1500, 120, 12, rf, acts)\n"
@@ -362,9 +366,12 @@ def test_emu_lists_3_wide_keep_the_ticket_form_up_to_8191_brokers(N, P):
     assert rc == 0 and sh["tickets_ok"] == 1 and sh["G"] == 1, (rc, sh, err)
     want = oracle_solve(fb)
     assert (want.scenario_results["status"] == abi.KAS_OK).all()
-    got = emu_solve(fb)
+    got = emu_solve(fb, flags=TICKET_ORDER)
     assert last_order_form() == 1
     assert_same_outputs(fb, want, got, f"emu ticket form, {N} brokers")
+    got = emu_solve(fb)
+    assert last_order_form() == 3
+    assert_same_outputs(fb, want, got, f"emu relaxation form, {N} brokers")
 
 
 SPREAD = 32        # KAS_PLAN_SPREAD_FILL

@@ -9,7 +9,7 @@ import numpy as np
 
 from kafka_assigner_amd import abi
 from kafka_assigner_amd import generator as G
-from emu_lib import variant_solver
+from emu_lib import TICKET_ORDER, variant_solver
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_emu_parity import _batch
@@ -21,6 +21,7 @@ def test_bounded_build_without_a_fault_equals_the_oracle():
         fb = _batch(77, 3, P, N, R, RF, acts)
         want = oracle_solve(fb)
         assert_same_outputs(fb, want, solve(fb), "bounded build")
+        assert_same_outputs(fb, want, solve(fb, flags=TICKET_ORDER), "bounded build, ticket form")
         assert not (want.scenario_results["status"] == abi.KAS_FAIL_WATCHDOG).any()
 
 
@@ -29,7 +30,8 @@ def test_a_stalled_staging_wavefront_is_reported_not_hung():
     for RF in (3, 5):                                   # order_tickets<3, ...> and order_tickets_wide<5>
         fb = _batch(78, 3, 1500, 120, 12, RF, ("add_k", "remove1"))
         want = oracle_solve(fb)
-        got = solve(fb)                                  # returns: that is the point
+        got = solve(fb, flags=TICKET_ORDER)              # returns: that is the point (the relaxation form has one
+                                                         # wavefront per scenario and nobody to wait for)
         ok = want.scenario_results["status"] == abi.KAS_OK
         assert ok.any()
         np.testing.assert_array_equal(got.scenario_results["status"][ok], abi.KAS_FAIL_WATCHDOG)
@@ -45,5 +47,5 @@ def test_a_large_bound_is_checked_on_every_4096th_idle_poll_and_still_ends_the_s
     want = oracle_solve(fb)
     ok = want.scenario_results["status"] == abi.KAS_OK
     assert ok.any()
-    got = solve(fb)
+    got = solve(fb, flags=TICKET_ORDER)
     np.testing.assert_array_equal(got.scenario_results["status"][ok], abi.KAS_FAIL_WATCHDOG)

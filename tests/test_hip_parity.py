@@ -14,6 +14,7 @@ from test_emu_parity import _batch, _multi_topic_scenarios
 from test_oracle_vs_literal import scenarios
 
 pytestmark = pytest.mark.gpu
+TICKET_ORDER = abi.KAS_PLAN_TICKET_ORDER      # the ticket form of P5 where the relaxation form would run
 
 
 def test_device_is_gfx950_and_library_loaded():
@@ -38,11 +39,13 @@ def test_hip_equals_oracle_small_odd_inputs(sc):
 @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
 @given(scenarios())
 def test_hip_equals_oracle_small_odd_inputs_without_context_io(sc):
-    """No Context in or out: lists up to 3 wide take the ticket form of P5."""
+    """No Context in or out: lists up to 3 wide take the relaxation form of P5 (KAS_PLAN_TICKET_ORDER: the ticket form)."""
     brokers, racks, topics = sc
     fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=False,
                            topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
-    assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip (no ctx)")
+    want = oracle_solve(fb)
+    assert_same_outputs(fb, want, native.solve_host(fb), "hip (no ctx)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip (no ctx), ticket form")
 
 
 @pytest.mark.parametrize("P,N,R,RF,actions", [
@@ -57,6 +60,7 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, native.solve_host(fb), "hip")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip ticket form")
     # the general multi-sweep sticky fill must agree with the rack-diverse histogram/quota form,
     # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
@@ -155,7 +159,7 @@ def test_one_plan_orders_its_solves_across_streams():
     want = oracle_solve(fb, threads=0)
     ctx = native.default_context()
     plan = native.Plan(ctx, fb)
-    assert "kas_fill_kernel<3,4>[quota, chunk histograms]" in plan.describe() and "kas_order_ticket_kernel<3,2,true>" in plan.describe()
+    assert "kas_fill_kernel<3,4>[quota, chunk histograms]" in plan.describe() and "kas_order_relax_kernel<3>" in plan.describe()
     dev = torch.device("cuda", ctx.device)
     d_cur = torch.from_numpy(fb.cur).to(dev)
     streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
@@ -175,6 +179,8 @@ def test_one_plan_orders_its_solves_across_streams():
         np.testing.assert_array_equal(sr["digest"], want.scenario_results["digest"])
     plan.set_flags(2)
     assert "kas_order_round_kernel<3>" in plan.describe()
+    plan.set_flags(TICKET_ORDER)
+    assert "kas_order_ticket_kernel<3,2,true>" in plan.describe()
     plan.close()
 
 
@@ -343,11 +349,14 @@ def test_lists_3_wide_keep_the_ticket_form_up_to_8191_brokers(N, P):
     brokers on nothing served the shape."""
     fb = _batch(4242, 4, P, N, 25, 3, ("add_k", "mixed"))
     plan = native.Plan(native.default_context(), fb)
+    assert "kas_order_relax_kernel<3>" in plan.describe(), plan.describe()
+    plan.set_flags(TICKET_ORDER)
     assert "kas_order_ticket_kernel<3,1," in plan.describe(), plan.describe()
     plan.close()
     want = oracle_solve(fb, threads=0)
     assert (want.scenario_results["status"] == abi.KAS_OK).all()
-    assert_same_outputs(fb, want, native.solve_host(fb), f"hip ticket form, {N} brokers")
+    assert_same_outputs(fb, want, native.solve_host(fb), f"hip relaxation form, {N} brokers")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), f"hip ticket form, {N} brokers")
     if N == 5000:
         assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip round form, 5000 brokers")
 
@@ -393,7 +402,8 @@ def test_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
     fb = _multi_topic_scenarios(77, 6, 3, 5000, 120, 12, 3)
     want = oracle_solve(fb)
     assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 6
-    assert_same_outputs(fb, want, native.solve_host(fb), "hip multi-topic tickets")
+    assert_same_outputs(fb, want, native.solve_host(fb), "hip multi-topic, relaxation form")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip multi-topic tickets")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip multi-topic rounds")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2 << 12), "hip multi-topic, 2 scenarios per wave")
 
@@ -445,11 +455,19 @@ def test_device_resident_tables_and_what_if_shared_cur():
     assert n == 1 and avg_us > 0
     assert plan.algorithmic_bytes == fb.algorithmic_bytes()
     stats = plan.stats()
-    assert stats.shape == (S, 16) and (stats[:, 1] > 0).all() and (stats[:, 9] > 0).all()
-    # the ticket form decided rows inside queues (rows waiting in line on one node commit together):
-    # the parity above covers that path, not only the one-row-per-step path
     ok = sr["status"] == abi.KAS_OK
-    assert ok.any() and (stats[ok, 14] > 0).any() and (stats[ok, 6] > 0).any()
+    # relaxation form: evaluations ([9]) and tiles ([12]) per scenario — a handful of evaluations per 64-row tile
+    assert stats.shape == (S, 16) and (stats[:, 1] > 0).all() and ok.any()
+    assert (stats[ok, 12] == (P + 63) // 64).all() and (stats[ok, 9] >= 2 * stats[ok, 12]).all() and (stats[ok, 9] < 12 * stats[ok, 12]).all()
+    # the ticket form decides rows inside queues (rows waiting in line on one node commit together):
+    # its parity run covers that path, not only the one-row-per-step path
+    plan.set_flags(TICKET_ORDER)
+    d_out.fill_(-7)
+    plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
+    st.synchronize()
+    np.testing.assert_array_equal(d_out.cpu().numpy(), want.out[:fb.out_len])
+    stats = plan.stats()
+    assert (stats[:, 9] > 0).all() and (stats[ok, 14] > 0).any() and (stats[ok, 6] > 0).any()
     plan.close()
 
 
