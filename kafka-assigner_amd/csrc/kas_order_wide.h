@@ -409,7 +409,8 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
             int32_t ev[KH], ahead = 1;
 #pragma unroll
             for (int h = 0; h < KH; ++h) ev[h] = kasw::shfl(mine, own[h]);   // is the row of rank `lane` still in the set
-            if (use_side) ahead = kasw::shfl(mine, pl);     // ... and the row ahead on my side node
+            if (KAS_WIDE_SIDE) ahead = kasw::shfl(mine, pl);   // ... and the row ahead on my side node (issued with the shuffles
+                                                               // above: no branch of its own; pl = my lane without a side table)
             bool ok = elig && (ahead != 0 || !side);
 #pragma unroll
             for (int h = 0; h < KH; ++h) {
@@ -485,16 +486,24 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
 #pragma unroll
               for (int r = 0; r < W; ++r) inv |= (r < Lp ? r : 0) << (3 * pos[r]);   // (every holder gets one pick)
               bool moved = false;
-              if (KAS_WIDE_SIDE && cls != 0 && has_front) { // wave-uniform
-                const int32_t got = kasw::shfl(inv, pl);
+              // (the side shuffle is issued with the ones below, not behind a branch of its own: a branch is a basic
+              // block, and the compiler waits for the LDS at its end — one exposed round trip per relaxation round;
+              // without a side table pl is the lane itself and side is false)
+              const int32_t got = KAS_WIDE_SIDE ? kasw::shfl(inv, pl) : 0;
+              int32_t vin[KH];
+#pragma unroll
+              for (int h = 0; h < KH; ++h) {
+                const int32_t rh = on[h] ? ((inv >> sh3[h]) & 7) : 7;     // the replica index node h takes in my row
+                vin[h] = kasw::shfl(rh, src_in[h]);
+              }
+              if (KAS_WIDE_SIDE) {
                 const int32_t nrs = side ? ((got >> (3 * pk)) & 7) : 7;
                 moved = nrs != rs;
                 rs = nrs;
               }
 #pragma unroll
               for (int h = 0; h < KH; ++h) {
-                const int32_t rh = on[h] ? ((inv >> sh3[h]) & 7) : 7;     // the replica index node h takes in my row
-                const int32_t v = kasw::shfl(rh, src_in[h]);
+                const int32_t v = vin[h];
                 const int32_t v2 = lane < qlen[h] ? v : 7;
                 uint32_t pack = (uint32_t)kasw::count_below(kasw::ballot(v2 == 0));
                 pack |= (uint32_t)kasw::count_below(kasw::ballot(v2 == 1)) << 10;
@@ -533,13 +542,18 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
       {
         const bool need = !cv && !gfin;
         const uint64_t nbm = kasw::ballot(need);
-        const uint32_t st = *(volatile uint32_t*)&lstate[cls];
-        kasw::repoll();                                      // list and slots are read after the count that covers them
-        const int32_t staged = (int32_t)(st & 0x7fffffffu);
         const int32_t k = kasw::count_below(nbm);
         const int32_t at = (cn + k) * stride + first;
+        const uint32_t st_raw = kasw::load_shared_u32(&lstate[cls]);
+        kasw::repoll();                                      // list and slots are read after the count that covers them
+        // (the list entry is read right behind the count, not behind the test on it: the LDS serves a wave's reads in
+        // issue order, so an entry the count covers is the one the staging wave wrote before it published the count —
+        // and the two reads are one round trip instead of two on the step's critical path)
+        const int32_t listed_slot = kasw::pinned((int32_t)my_list[at & (K * 64 - 1)]);
+        const uint32_t st = (uint32_t)kasw::pinned((int32_t)st_raw);   // (first use of the count: behind the second read's issue)
+        const int32_t staged = (int32_t)(st & 0x7fffffffu);
         const bool take = need && at < staged;
-        const int32_t slot = take ? (int32_t)my_list[at & (K * 64 - 1)] : my_slot;
+        const int32_t slot = take ? listed_slot : my_slot;
         const WideSlot sl = ring[slot];
         if (take) {
 #pragma unroll
@@ -693,7 +707,7 @@ KAS_DEV void order_tickets_wide(const KasLaunch& a, int32_t s_index, unsigned ch
         listed[0] += kasw::popc(b0); listed[1] += kasw::popc(b1);
         kasw::lockstep();
         const uint32_t endbit = kasw::ballot(staging_end) != 0ull ? 0x80000000u : 0u;
-        if (lane < 2) *(volatile uint32_t*)&lstate[lane] = (uint32_t)(lane == 0 ? listed[0] : listed[1]) | endbit;
+        if (lane < 2) kasw::store_shared_u32(&lstate[lane], (uint32_t)(lane == 0 ? listed[0] : listed[1]) | endbit);
         if (staging) jl += 1;
       }
       if (kasw::ballot(!endl) == 0) break;

@@ -89,6 +89,14 @@ KAS_DEV int32_t opaque(int32_t v) {
 // v_perm_b32: result byte i = byte sel[i] of the eight bytes hi:lo (0..3 = lo, 4..7 = hi), 0x0c = 0x00
 KAS_DEV uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
+// A value that must be in its register at this point of the program: a load feeding it is issued before, and cannot be
+// sunk into the branch that uses it (the compiler does that to a load whose result only one side of a test needs —
+// which puts the load's latency behind the test's).
+KAS_DEV int32_t pinned(int32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // a * b for small non-negative factors (node index x block stride): the full-rate 24-bit multiply
 KAS_DEV int32_t mul24(int32_t a, int32_t b) { return (int32_t)__umul24((unsigned)a, (unsigned)b); }
 
@@ -147,6 +155,16 @@ KAS_DEV uint64_t load_shared_u64(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// A word of LDS another wave of the workgroup writes / reads (list counts, flags): a relaxed atomic access, NOT a volatile
+// one — `*(volatile uint32_t*)p` on a pointer the compiler holds as generic is a FLAT load (sc0 sc1) that the wave then
+// waits for with vmcnt(0); the atomic form keeps the LDS address space and becomes ds_read_b32 / ds_write_b32.  Re-read
+// on every call: callers put kasw::repoll() where the order against other LDS accesses matters.
+KAS_DEV uint32_t load_shared_u32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+KAS_DEV void store_shared_u32(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
