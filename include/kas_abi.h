@@ -278,7 +278,10 @@ int kas_batch_slice(const kas_batch_desc* b, int64_t lo, int64_t hi, kas_scenari
 
 /* One batch over several devices: rank r of n_ctx solves kas_shard_range(S, r, n_ctx) on ctxs[r]
  * (one host thread per context, kas_solve_host on its slice), no communication — the scenarios are
- * independent and the caller's host arrays are the gather.  Contexts may sit on the same device. */
+ * independent and the caller's host arrays are the gather.  Contexts may sit on the same device.
+ * A shard moves the whole extent of `out` / `ctx` its scenarios refer to, so the extents of consecutive
+ * shards must not overlap (pools laid out in scenario order, the usual case); a batch whose extents do
+ * overlap is solved on ctxs[0] alone — same results, no sharding. */
 int kas_solve_host_sharded(kas_ctx* const* ctxs, int32_t n_ctx, const kas_batch_desc* batch,
                            const kas_tables* host_tables);
 

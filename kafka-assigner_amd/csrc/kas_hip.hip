@@ -1112,7 +1112,9 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     if (e != hipSuccess && he == hipSuccess) { he = e; fail_rc = set_error(KAS_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
     return he == hipSuccess;
   };
-  auto drain = [&]() { for (hipStream_t st : ctx->hstream) (void)hipStreamSynchronize(st); };
+  // every stream is drained whatever happened; an error that only surfaces at a synchronisation (a kernel fault, a
+  // failed copy) is the call's error: the caller must never read out / ctx / records of a solve that did not finish
+  auto drain = [&]() { for (hipStream_t st : ctx->hstream) hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"); };
   // pools every range reads (aux, Context) go up first; the other streams wait for them
   if (full.aux_need > full.aux_lo)
     hip_ok(hipMemcpyAsync(d_aux + full.aux_lo, h->aux + full.aux_lo, 4 * (size_t)(full.aux_need - full.aux_lo), hipMemcpyHostToDevice, s0), "upload aux");
@@ -1147,8 +1149,8 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     if (i > 0) download(chains[(size_t)i - 1], ctx->hstream[(i - 1) % KAS_HOST_STREAMS]);
   }
   if (he == hipSuccess && fail_rc == KAS_E_OK) download(chains[(size_t)K - 1], ctx->hstream[(K - 1) % KAS_HOST_STREAMS]);
-  if (he != hipSuccess || fail_rc != KAS_E_OK) { drain(); return fail_rc; }
   drain();
+  if (he != hipSuccess || fail_rc != KAS_E_OK) return fail_rc != KAS_E_OK ? fail_rc : KAS_E_HIP;
   // Context counters back; the selected scenarios' rows, packed
   if (full.ctx_need > full.ctx_lo)
     hip_ok(hipMemcpyAsync(h->ctx + full.ctx_lo, d_ctx + full.ctx_lo, 4 * (size_t)(full.ctx_need - full.ctx_lo), hipMemcpyDeviceToHost, s0), "download ctx");
@@ -1165,7 +1167,7 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
       }
     }
   }
-  (void)hipStreamSynchronize(s0);
+  hip_ok(hipStreamSynchronize(s0), "hipStreamSynchronize");
   return he == hipSuccess ? KAS_E_OK : fail_rc;
 }
 
@@ -1183,6 +1185,29 @@ int kas_solve_host_sharded(kas_ctx* const* ctxs, int32_t n_ctx, const kas_batch_
   if (!ctxs || n_ctx < 1 || !batch || !h) return set_error(KAS_E_INVALID_ARG, "NULL argument / no context");
   for (int32_t r = 0; r < n_ctx; ++r) if (!ctxs[r]) return set_error(KAS_E_INVALID_ARG, "ctxs[r] == NULL");
   if (n_ctx == 1) return kas_solve_host(ctxs[0], batch, h);
+  // Every shard downloads the whole extent of `out` (and round-trips the whole extent of `ctx`) its scenarios refer
+  // to: with pools that are not laid out in scenario order one shard's download would overwrite rows or Context
+  // counters another has already delivered.  Such a batch is solved on one context (same results, no overlap).
+  {
+    int64_t out_end = -1, ctx_end = -1;
+    bool disjoint = true;
+    for (int32_t r = 0; r < n_ctx && disjoint; ++r) {
+      int64_t lo = 0, hi = 0;
+      kas_shard_range(batch->n_scenarios, r, n_ctx, &lo, &hi);
+      if (hi <= lo) continue;
+      std::vector<kas_scenario_desc> scratch((size_t)(hi - lo));
+      kas_batch_desc bd;
+      kas_tables ht;
+      KasShape sh;
+      std::string err;
+      int rc = kas_batch_slice(batch, lo, hi, scratch.data(), &bd, h, &ht);
+      if (rc == KAS_E_OK) rc = kas_shape_batch(&bd, &sh, &err, 0, 0);
+      if (rc != KAS_E_OK) return rc == KAS_E_OK ? rc : set_error(rc, "shard " + std::to_string(r) + ": " + (err.empty() ? g_last_error : err));
+      if (sh.out_need > sh.out_lo) { disjoint = disjoint && sh.out_lo >= out_end; out_end = sh.out_need; }
+      if (sh.ctx_need > sh.ctx_lo) { disjoint = disjoint && sh.ctx_lo >= ctx_end; ctx_end = sh.ctx_need; }
+    }
+    if (!disjoint) return kas_solve_host(ctxs[0], batch, h);
+  }
   std::vector<int> rcs((size_t)n_ctx, KAS_E_OK);
   std::vector<std::string> errs((size_t)n_ctx);
   std::vector<std::thread> threads;

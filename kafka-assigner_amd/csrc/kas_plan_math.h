@@ -194,6 +194,8 @@ KAS_ABI_FN KasLds kas_spread_scan_lds(int32_t n_max, int32_t W, int32_t idmap_en
 #define KAS_RING_SLOTS 4
 #endif
 #define KAS_PACKED_TICKET_LIMIT 1023
+// relaxation form (kas_order_relax.h): 12-bit count fields, no tickets — a node holds fewer rows than this
+#define KAS_RELAX_ROW_LIMIT 4095
 // wide ticket form (kas_order_wide.h): the commits of a node are an 11-bit field, and count field 4 — 11 bits,
 // next to it — must not carry into them whatever the counts do: a node holds fewer rows than this.  Between
 // KAS_PACKED_TICKET_LIMIT and this bound the 10-bit count fields are not safe a priori; the kernel checks them
@@ -356,6 +358,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   if (b->n_scenarios > 0 && (!b->scenarios)) return fail(KAS_E_INVALID_ARG, "scenarios == NULL");
   if (b->n_topics > 0 && !b->topics) return fail(KAS_E_INVALID_ARG, "topics == NULL");
   KasShape s;
+  int32_t relax_inputs_ok = 1;         // no KAS:190 index error, no int overflow, rows per node inside the relaxation form's fields
   const int64_t kNone = INT64_MAX;
   s.cur_lo = s.out_lo = s.aux_lo = s.ctx_lo = kNone;
   s.accmask_off.assign((size_t)b->n_scenarios, 0);
@@ -426,12 +429,13 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       // a ticket on node n counts the rows that hold n so far in the scenario
       if (td.rf >= 1 && td.rf <= sd.n_nodes && sd.n_nodes > 0) {
         const int64_t prod = P * (int64_t)td.rf;
-        if (prod >= (1ll << 31)) s.tickets_ok = 0;
+        if (prod >= (1ll << 31)) { s.tickets_ok = 0; relax_inputs_ok = 0; }
         ticket_bound += (prod + sd.n_nodes - 1) / sd.n_nodes;
       }
-      if (td.name_hash == (int32_t)0x80000000) s.tickets_ok = 0;   // KAS:190 index error: round form
+      if (td.name_hash == (int32_t)0x80000000) { s.tickets_ok = 0; relax_inputs_ok = 0; }   // KAS:190 index error: round form
     }
     if (ticket_bound >= KAS_TICKET_LIMIT) s.tickets_ok = 0;
+    if (ticket_bound >= KAS_RELAX_ROW_LIMIT) relax_inputs_ok = 0;
     if (ticket_bound >= KAS_PACKED_TICKET_LIMIT) s.bound_small = 0;
     if (ticket_bound >= KAS_WIDE_COMMIT_LIMIT) s.bound_mid = 0;
     s.accmask_off[(size_t)i] = s.accmask_words;
@@ -448,9 +452,10 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // lists 4 and 5 wide: the wide ticket form (kas_order_wide.h) under the same conditions plus 10-bit
   // count fields and 16-bit LDS offsets of its 8-byte counter rows; beyond 5: round form
   s.packed_ok = s.bound_small && !s.any_ctx;
-  // relaxation form: what the packed ticket form asks for (no Context, no KAS:190 index error, rows per node
-  // inside the count fields) — decided before the 16-bit-offset limits of the ticket form below, which it does not have
-  s.relax_ok = s.Wc <= 3 && s.tickets_ok && s.packed_ok && kas_order_relax_lds(s.n_max) <= KAS_LDS_LIMIT;
+  // relaxation form: no Context, no KAS:190 index error, rows per node inside its 12-bit count fields (4,095: the
+  // packed ticket form stops at 1,023, the ticket forms at 65,535 tickets) — and none of the ticket form's 16-bit LDS
+  // offsets, so the broker count is limited by the fill kernel's LDS only
+  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && !s.any_ctx && kas_order_relax_lds(s.n_max) <= KAS_LDS_LIMIT;
   // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
   // to the round form — which must then fit)
   s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&

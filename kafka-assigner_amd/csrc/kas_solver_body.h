@@ -83,11 +83,13 @@
 // lasts a millisecond — and the word is read on every 4096th idle poll only, which costs nothing measurable
 // (362.8k against 362.9k scenarios/s, three A/B pairs).  Test builds use small bounds (-DKAS_SPIN_BOUND=n, below
 // 65536: checked on every poll); -DKAS_SPIN_BOUND=0 compiles the containment out.
-// The wide ticket form keeps the bound for test builds only: with it the kernel needs two more VGPRs and its chain
-// solver's step — the critical path of configs[4] — gets 1.4 % slower (38.55 -> 39.10 ms, three A/B pairs).
+// Round 4: the wide ticket form carries the bound in the product build as well (rounds 1-3: test builds only — two
+// more VGPRs and 1.4 % on its chain solver's step, the critical path of configs[4]: a protocol slip there was a hung
+// GPU instead of a status, and that kernel is the most intricate one; the step's three LDS round trips removed in the
+// same round paid for it three times over).  The relaxation form has no wavefront waiting for another; its loop is
+// bounded by construction (65 evaluations per tile) and reports KAS_FAIL_WATCHDOG if it ever is not.
 #ifndef KAS_SPIN_BOUND
 #define KAS_SPIN_BOUND (1 << 25)
-#define KAS_WIDE_SPIN_BOUND 0
 #endif
 #ifndef KAS_WIDE_SPIN_BOUND
 #define KAS_WIDE_SPIN_BOUND KAS_SPIN_BOUND

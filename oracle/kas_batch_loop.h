@@ -33,8 +33,8 @@
 typedef struct kas_arena {
   unsigned char* base;
   size_t cap, used;
-  void* spill[64];        /* allocations that did not fit the block (freed at the rewind to empty) */
-  int n_spill;
+  void** spill;           /* allocations that did not fit the block (freed at the rewind to empty); grows as needed */
+  int n_spill, spill_cap;
   size_t spill_bytes;
   int depth;              /* marks outstanding: spills are only freed when the outermost one is released */
 } kas_arena;
@@ -51,9 +51,17 @@ static void* kas_scratch_alloc(size_t bytes, int zero) {
     a->used += bytes;
   } else {
     p = malloc(bytes);
-    if (a && p && a->n_spill < 64) { a->spill[a->n_spill++] = p; a->spill_bytes += bytes; }
-    /* (no arena, or more than 64 spills in one scenario: the pointer is simply not reclaimed before the
-     * thread ends — never the case for the shapes the solvers allocate: <= 8 blocks per topic) */
+    if (a && p) {
+      /* every spilled block is tracked (a scenario of many large topics on a cold arena spills ~6 blocks per
+       * topic) and every spilled byte counted, so that the block that replaces the arena is large enough */
+      if (a->n_spill == a->spill_cap) {
+        const int cap = a->spill_cap ? 2 * a->spill_cap : 64;
+        void** grown = (void**)realloc(a->spill, sizeof(void*) * (size_t)cap);
+        if (grown) { a->spill = grown; a->spill_cap = cap; }
+      }
+      if (a->n_spill < a->spill_cap) a->spill[a->n_spill++] = p;
+      a->spill_bytes += bytes;
+    }
   }
   if (p && zero) memset(p, 0, bytes);
   return p;
@@ -103,7 +111,7 @@ static void kas_arena_return(kas_arena* a) {
   pthread_mutex_lock(&kas_pool_mu);
   if (kas_pool_n < KAS_ARENA_POOL) { kas_pool[kas_pool_n++] = a; a = NULL; }
   pthread_mutex_unlock(&kas_pool_mu);
-  if (a) { free(a->base); free(a); }
+  if (a) { free(a->base); free(a->spill); free(a); }
 }
 
 typedef int (*kas_topic_fn)(int32_t name_hash, int32_t P, const int32_t* part_id,

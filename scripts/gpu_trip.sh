@@ -79,6 +79,9 @@ for step in "$@"; do
       for mode in 1 8; do
         timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $R/$O/prof_sq1_f$mode -o sq1 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq1_f$mode.log 2>&1; echo "sq1 f$mode exit $?"
         timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_sq2_f$mode -o sq2 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq2_f$mode.log 2>&1; echo "sq2 f$mode exit $?"
+        # per-pipe: cycles a pipe spends on instructions (quad-cycle units, summed over waves), round 4
+        timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES --output-format csv -d $R/$O/prof_sq3_f$mode -o sq3 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq3_f$mode.log 2>&1; echo "sq3 f$mode exit $?"
+        timeout 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LDS_ATOMIC_RETURN SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/$O/prof_sq4_f$mode -o sq4 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq4_f$mode.log 2>&1; echo "sq4 f$mode exit $?"
       done
       cd $R ;;
     abh:*)

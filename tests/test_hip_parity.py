@@ -541,3 +541,23 @@ def test_spread_fill_on_small_batches_and_what_it_hands_back():
     assert_same_outputs(fb, oracle_solve(fb), native.solve_host_with_flags(fb, 32), "hip spread fill, rack awareness off")
     fb = _multi_topic_scenarios(3, 2, 3, 900, 40, 8, 3)
     assert_same_outputs(fb, oracle_solve(fb), native.solve_host_with_flags(fb, 32), "hip spread flag, multi-topic batch")
+
+
+def test_random_shapes_against_the_oracle_for_a_bounded_slice():
+    """scripts/stress_gpu.py inside the driver-run suite (round 3 ran it by hand only): random shapes — 8 to 12,000
+    brokers, 300 to 30,000 partitions, RF 2-5, every action mix, 1-8 scenarios per batch, thin rows 4-5 wide that
+    overflow a count field of the wide form — each batch through one to four plan variants (relaxation form, ticket
+    forms, round form, general fill, spread fill), every output compared with the oracle.  ~12 s of batches; the seed
+    changes with the day so that successive driver runs draw different batches, and is printed."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seed = int(time.time() // 86400)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_gpu.py"), "12", str(seed)],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "stress ok:" in r.stdout, (seed, r.stdout[-2000:], r.stderr[-2000:])
+    n = int(r.stdout.split("stress ok:")[1].split()[0])
+    assert n >= 100, (seed, r.stdout[-500:])
+    print(r.stdout.strip().splitlines()[-1])
