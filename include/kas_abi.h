@@ -243,7 +243,7 @@ int kas_ctx_synchronize(kas_ctx* ctx);
  * staging.  Only [first, last] element a descriptor refers to is moved in either direction.  Batches
  * whose tables are large and laid out scenario by scenario are cut into scenario ranges, and the
  * upload of one range, the solve of the previous one and the download of the one before run
- * concurrently on three streams.  On an error after work was enqueued the call drains its streams
+ * concurrently on eight streams.  On an error after work was enqueued the call drains its streams
  * before it returns (no kernel or copy is left touching the caller's memory). */
 int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables);
 

@@ -273,7 +273,9 @@ struct KasCachedPlan {
   uint64_t call = 0;                    // host call that last used the entry (its ranges must not evict each other)
 };
 #define KAS_HOST_PLAN_CACHE 16
-#define KAS_HOST_STREAMS 3
+#ifndef KAS_HOST_STREAMS
+#define KAS_HOST_STREAMS 8   // (round 4: 3 -> 8, a chain per scenario range: 11.0k -> 12.9k scenarios/s through kas_solve_host, gpurun_out/r4n)
+#endif
 struct kas_ctx {
   int device;
   hipStream_t stream;
@@ -450,7 +452,7 @@ void kas_plan_destroy(kas_plan* p) {
 static int kas_plan_set_kernels(kas_plan* p) {
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (p->fused && p->lds_fused.total > p->lds.total ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD));
-  if (p->Wc <= 3 && kas_order_ticket_for(p->Wc, p->G, 0))
+  if (p->Wc <= 3 && p->tickets && kas_order_ticket_for(p->Wc, p->G, 0))   // (beyond 8,191 brokers only the relaxation form applies)
     for (int pk = 0; pk < 2; ++pk)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,

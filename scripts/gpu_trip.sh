@@ -109,6 +109,10 @@ d = json.load(open(sys.argv[1]))
 print("   stats:", " ".join("%s %.0f" % (k, d[k]["mean"]) for k in ("solver_iterations", "solver_blocked", "stager_iterations", "stager_idle", "p5_rounds_or_queue_steps", "order_us", "solver_rows_in_hand", "p2_ranked_tiles_wave0", "p4_windows", "p4_steps") if k in d))
 PY
       ;;
+    pcie)     # the host link: copies of the host path's sizes and of 256 MB, pageable / pinned, one and both directions
+      timeout 120 tools/pcie_probe 36 8 > $O/pcie_36MB.log 2>&1; timeout 120 tools/pcie_probe 256 4 > $O/pcie_256MB.log 2>&1; tail -n 30 $O/pcie_256MB.log | cut -c1-130 ;;
+    probe)    # what a SIMD issues per cycle (tools/issue_probe)
+      timeout 200 tools/issue_probe 300 > $O/issue_probe.log 2>&1; echo "issue_probe exit $?" ;;
     random)   # randomised GPU-vs-oracle stress, 150 s of batches
       timeout 400 python scripts/stress_gpu.py 150 ${STRESS_SEED:-2026} > $O/stress_random.log 2>&1; echo "random stress exit $?" >> $O/stress_random.log; tail -2 $O/stress_random.log ;;
     big)

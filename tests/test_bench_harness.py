@@ -47,6 +47,21 @@ def test_bench_spawns_its_own_ranks_and_gathers_records(scaling, scenarios, expe
     assert abs(line["value"] - sum(expect_sizes) * 5 / (line["ms_per_step"] * 5e-3)) < 1e-6 * line["value"]
 
 
+@pytest.mark.parametrize("scaling,scenarios,expect_sizes", [
+    ("weak", 3, [3] * 8),
+    ("strong", 13, [2, 2, 2, 2, 2, 1, 1, 1]),
+])
+def test_bench_world_of_eight_over_gloo(scaling, scenarios, expect_sizes):
+    """The driver's 8-GPU launch on CPU: eight ranks, weak and strong (ragged shards), every rank's records gathered."""
+    r = _run(["--stub", "--gpus", "8", "--steps", "3", "--warmup", "1", "--scenarios", str(scenarios),
+              "--scaling", scaling, "--in-flight", "2"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and cfg["world_size"] == 8 and cfg["scenarios_per_gpu"] == expect_sizes
+    assert cfg["gathered_records_ok"] is True and cfg["allgather_alone_us"] > 0
+
+
 def test_bench_single_rank_stub_line():
     r = _run(["--stub", "--steps", "3", "--warmup", "1", "--scenarios", "5"])
     assert r.returncode == 0, r.stderr[-3000:]
