@@ -366,7 +366,7 @@ def test_wide_lists_a_broker_holding_1023_rows_or_more_keeps_the_wide_ticket_for
     assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip wide form, 110k x 500 x RF 5 (cap 1100)")
 
 
-@pytest.mark.parametrize("N,P", [(9000, 40000), (13000, 60000)])
+@pytest.mark.parametrize("N,P", [(9000, 40000), (12000, 60000)])
 def test_lists_3_wide_beyond_8191_brokers_take_the_relaxation_form(N, P):
     """Round 4: the relaxation form keeps 4 B of LDS per broker and has no 16-bit LDS offsets, so lists <= 3 wide
     without a Context are served up to where the fill kernel's LDS ends (13,492 brokers); rounds 1-3 refused these
