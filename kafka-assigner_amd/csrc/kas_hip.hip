@@ -637,8 +637,8 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
                              ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
                              : (p->shape.any_ctx && (lp.tickets || lp.wide)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax)
-    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d> grid=%ux%u lds=%zu", p->Wc, lp.order_grid, lp.order_block,
-             lp.order_lds);
+    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows] grid=%ux%u lds=%zu", p->Wc,
+             kas_relax_double_tiles(p->flags, p->n_scenarios) ? 128 : 64, lp.order_grid, lp.order_block, lp.order_lds);
   else if (lp.tickets)
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
@@ -690,7 +690,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.n_scenarios = p->n_scenarios; a.n_max = p->shape.n_max;
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
   a.flags = (p->flags & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ORDER_FLAGGED | KAS_FLAG_WIDE_CHECK)) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
-            (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u);
+            (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u) |
+            (kas_relax_double_tiles(p->flags, p->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
   const int slot = p->timer_next;
@@ -835,7 +836,9 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  p->flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
+  if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))
+    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_RELAX_TILES: 0 (by batch size), 1 (64 rows) or 2 (double tiles)");
+  p->flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
   // plan may still be in flight on the old scratch

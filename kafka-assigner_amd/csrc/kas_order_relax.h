@@ -56,9 +56,19 @@ namespace kas {
 #define KAS_RELAX_F1_ONE 0x100000u     // count[n][1] += 1
 #define KAS_RELAX_F1_MASK 0xfff00000u
 #define KAS_RELAX_PAD_WORD 0xfff0fff0u // counter word of the padding node: only ever gets + 0
+#define KAS_RELAX_PICK_BITS 0x00100010u // (row word >> cell) & this: what the row adds to the counter word of that cell
 
-// staging slot of a row / entry of the outcome table: what the row adds to its cells 0..2
-struct alignas(16) RelaxSlot { uint32_t v[4]; };
+// The row word: what a row's current outcome adds, for all of its cells at once — bit 4 + c set when cell c is the
+// first pick, bit 20 + c when it is the second.  (word >> cell) & KAS_RELAX_PICK_BITS is the cell's addend.
+KAS_DEV uint32_t relax_row_word(uint32_t w0, uint32_t w1) { return (KAS_RELAX_F0_ONE << w0) | (KAS_RELAX_F1_ONE << w1); }
+
+// A lane's pairs: pair v = 64 t + lane is cell v mod 3 of row v div 3 of the (double) tile; its staging word is
+// stage[v] — the pair lanes touch consecutive words, the row lanes words 3 i .. 3 i + 2: both free of bank conflicts.
+struct RelaxPairs {
+  uint32_t* slot;                      // stage + lane: pair t's word is slot[64 t]
+  const uint32_t* row[6];              // the row word of the pair's row
+  uint32_t cell[6];                    // the pair's cell
+};
 
 // per-topic constants of the picks (wave-uniform: scalar registers)
 struct RelaxTopic {
@@ -110,30 +120,74 @@ KAS_DEV int32_t relax_eval_generic(const uint32_t (&x)[3], const bool (&valid)[3
   return w0 | (w1 << 2);
 }
 
-// One relaxation step of a tile, as the pair lanes see it: the rows' addends are in their staging slots; take the
-// previous additions back, add the pairs in row-major order (three instructions, lanes ascending), put what each add
-// returned into the pair's cell of its row's slot.  Afterwards every row lane finds in its slot the counter words
-// of its cells as its row would see them with the current outcomes of all earlier rows of the tile committed.
-KAS_DEV void relax_pairs(const uint32_t* const (&pslot)[3], uint32_t* const (&padr)[3], uint32_t (&padd)[3], bool undo) {
-  kasw::lockstep();                                          // the rows' slots are written
-  uint32_t nadd[3];
+// One relaxation step of a tile, as the pair lanes see it: the rows' words are in rbuf; take the previous additions
+// back, add the pairs in row-major order (NP instructions, lanes ascending), put what each add returned into the
+// pair's staging word.  Afterwards every row lane finds in stage[3 i + c] the counter word of its cell c as its row
+// would see it with the current outcomes of all earlier rows of the tile committed.
+template <int NP>
+KAS_DEV void relax_pairs(const RelaxPairs& pp, uint32_t* const (&padr)[6], uint32_t (&padd)[6], bool undo) {
+  kasw::lockstep();                                          // the row words are written
+  uint32_t nadd[NP];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) nadd[t] = *pslot[t];
+  for (int t = 0; t < NP; ++t) nadd[t] = (*pp.row[t] >> pp.cell[t]) & KAS_RELAX_PICK_BITS;
   if (undo) {                                                // (wave-uniform)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
+    for (int t = 0; t < NP; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
   }
   kasw::lockstep();
-  uint32_t got[3];
+  uint32_t got[NP];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < NP; ++t) {
     got[t] = kasw::lds_add_rtn_u32(padr[t], nadd[t]);
     kasw::lockstep();                                        // (one instruction at a time, lanes in order: the hardware's order)
     padd[t] = nadd[t];
   }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) *(uint32_t*)pslot[t] = got[t];
+  for (int t = 0; t < NP; ++t) pp.slot[64 * t] = got[t];
   kasw::lockstep();
+}
+
+// The six tags of a row whose three cells all hold a broker, from the order of its cells (tagtab, per topic).
+struct RelaxTags { uint32_t t0[3], t1[3]; };
+
+KAS_DEV RelaxTags relax_tags(const uint32_t (&c)[3], const uint32_t* tagtab) {
+  const uint32_t oidx = ((c[0] - c[1]) >> 31) | (((c[0] - c[2]) >> 31) << 1) | (((c[1] - c[2]) >> 31) << 2);
+  const uint32_t tw = tagtab[oidx];
+  RelaxTags g;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { g.t0[q] = (tw >> (4 * q)) & 15u; g.t1[q] = (tw >> (12 + 4 * q)) & 15u; }
+  return g;
+}
+
+// The picks of a row with three holders: first pick | second pick << 2 (cell indices).
+KAS_DEV int32_t relax_eval3(const uint32_t (&x)[3], const RelaxTags& g) {
+  // first pick: count[.][0], first strictly smaller in visit order == minimum of (count, visit position)
+  const uint32_t k00 = (x[0] << 16) | g.t0[0], k01 = (x[1] << 16) | g.t0[1], k02 = (x[2] << 16) | g.t0[2];
+  const uint32_t kmin = k00 < k01 ? (k00 < k02 ? k00 : k02) : (k01 < k02 ? k01 : k02);
+  const uint32_t w0 = kmin & 3u;
+  // second pick: count[.][1] over the two that are left
+  const uint32_t k10 = (x[0] & KAS_RELAX_F1_MASK) | g.t1[0], k11 = (x[1] & KAS_RELAX_F1_MASK) | g.t1[1],
+                 k12 = (x[2] & KAS_RELAX_F1_MASK) | g.t1[2];
+  const uint32_t lo = w0 == 0u ? k11 : k10, hi = w0 == 2u ? k11 : k12;
+  const uint32_t w1 = (lo < hi ? lo : hi) & 3u;
+  return (int32_t)(w0 | (w1 << 2));
+}
+
+// The final row of a partition with three holders: broker ids in list order out, its digest back.  List position r
+// takes cell w_r: bytes 2 w_r, 2 w_r + 1 of the mid row (v_perm_b32 selector, high half zero).
+template <class Raw>
+KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node_id, int32_t* out, uint32_t k, int32_t p) {
+  const uint32_t w0 = (uint32_t)oc & 3u, w1 = ((uint32_t)oc >> 2) & 3u, w2 = 3u - w0 - w1;
+  const uint32_t l0 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w0 * 0x0202u);
+  const uint32_t l1 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w1 * 0x0202u);
+  const uint32_t l2 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w2 * 0x0202u);
+  RowW<3> o;
+  o.v[0] = g_node_id[l0]; o.v[1] = g_node_id[l1]; o.v[2] = g_node_id[l2];
+  uint64_t d = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) d += kas_digest_cell(k, (uint32_t)p, (uint32_t)q, o.v[q]);
+  *reinterpret_cast<RowW<3>*>(out + (int64_t)p * 3) = o;
+  return d;
 }
 
 template <int W>
@@ -144,40 +198,25 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   const int32_t N = sd.n_nodes;
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   uint32_t* cnt = (uint32_t*)lds_raw;                       // [nmax + 1]: + the padding node's word
-  RelaxSlot* lut = (RelaxSlot*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [16] by outcome: addends of cells 0..2
-  RelaxSlot* sel = lut + 16;                                // [16] by outcome: byte selectors of list positions 0..2
-  uint32_t* tagtab = (uint32_t*)(sel + 16);                 // [8] by the order of a row's three cells: its six tags
-  RelaxSlot* stage = (RelaxSlot*)(tagtab + 8);              // [64] by row of the tile
+  uint32_t* tagtab = (uint32_t*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [8] by the order of a row's three cells: its six tags
+  uint32_t* rbuf = tagtab + 8;                              // [128] row words of the (double) tile
+  uint32_t* stage = rbuf + 128;                             // [384] by pair of the (double) tile
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int64_t t_begin = kasw::clock_ticks();
   for (int32_t n = lane; n < N; n += 64) cnt[n] = 0u;
   if (lane == 0) cnt[nmax] = KAS_RELAX_PAD_WORD;
-  if (lane < 16) {
-    RelaxSlot e, f;
-    const int32_t w0 = lane & 3, w1 = lane >> 2, w2 = 3 - w0 - w1;
-    const bool ok = w0 < 3 && w1 < 3 && w0 != w1;
+  RelaxPairs pp;
+  pp.slot = stage + lane;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) e.v[k] = !ok ? 0u : (k == w0 ? KAS_RELAX_F0_ONE : (k == w1 ? KAS_RELAX_F1_ONE : 0u));
-    e.v[3] = 0u;
-    // list position r takes cell w_r: bytes 2 w_r, 2 w_r + 1 of the mid row (v_perm_b32 selector, high half zero)
-    const int32_t w[3] = {w0, w1, w2};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) f.v[r] = ok ? (0x0c0c0000u | (uint32_t)((2 * w[r] + 1) << 8) | (uint32_t)(2 * w[r])) : 0x0c0c0c0cu;
-    f.v[3] = 0u;
-    lut[lane] = e;
-    sel[lane] = f;
+  for (int t = 0; t < 6; ++t) {
+    const int32_t v = 64 * t + lane, r = v / 3;
+    pp.row[t] = rbuf + r;
+    pp.cell[t] = (uint32_t)(v - 3 * r);
   }
-  // my three pairs (as a pair lane): pair v = 64 t + lane is cell v mod 3 of row v div 3
-  const uint32_t* pslot[3];                                 // where the pair's addend comes from and its sum goes back
-  const uint16_t* pcell[3];                                 // where the pair's node index is staged
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int32_t v = 64 * t + lane, r = v / 3, k = v - 3 * r;
-    pslot[t] = &stage[r].v[k];
-    pcell[t] = (const uint16_t*)&stage[r] + k;
-  }
+  uint32_t* const mine = stage + 3 * lane;                  // (row lane) my row's three words; + 192 for the second row
   kasw::lockstep();
 
+  const bool dual_on = (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;   // (kas_relax_double_tiles)
   uint64_t digest = 0;
   int32_t n_tiles = 0, n_evals = 0, n_slow = 0;             // (wave-uniform)
   bool stuck = false;
@@ -207,16 +246,15 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       tagtab[lane] = w;
     }
     kasw::lockstep();
-    MidRaw<W> nxr = mid_load_raw<W>(mid, ow, lane < P ? lane : 0, lane < P);   // next tile's mid row (read ahead)
-    for (int32_t tile = 0; tile < nt; ++tile) {
+    auto load_tile = [&](int32_t t) -> MidRaw<W> {
+      const int32_t pn = (t << 6) + lane;
+      return mid_load_raw<W>(mid, ow, pn < P ? pn : 0, pn < P);
+    };
+    MidRaw<W> nx0 = load_tile(0), nx1 = load_tile(1);       // the mid rows of the next two tiles (read ahead)
+    for (int32_t tile = 0; tile < nt;) {
       const int32_t p = (tile << 6) + lane;
       const bool active = p < P;
-      const MidRaw<W> raw = nxr;
-      {
-        const int32_t pn = p + 64;
-        nxr = mid_load_raw<W>(mid, ow, pn < P ? pn : 0, pn < P);
-      }
-      n_tiles += 1;
+      const MidRaw<W> raw = nx0;
       // ---- cells of my row (row lane): node index or KAS_MID_NONE (0xffff, bit 15)
       uint32_t c[3];
       if (ow == W) {
@@ -227,32 +265,65 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       }
       // the usual tile: 64 rows, three holders each, rows of the batch's width
       bool fast = false;
+      uint32_t* padr[6];
+      uint32_t padd[6] = {0u, 0u, 0u, 0u, 0u, 0u};           // what my pairs added last
       if constexpr (W == 3) {
         if (full_width && ((tile + 1) << 6) <= P)
           fast = kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
+        // ---- two usual tiles in a row: one double tile of 128 rows, lane i evaluates rows i and 64 + i.  The same
+        // fixed point (row-major pairs over six instructions), twice the work per LDS round trip.
+        if (dual_on && fast && ((tile + 2) << 6) <= P) {
+          const MidRaw<W> rawb = nx1;
+          const uint32_t cb[3] = {rawb.w[0] & 0xffffu, rawb.w[0] >> 16, rawb.w[1] & 0xffffu};
+          if (kasw::ballot(((cb[0] | cb[1] | cb[2]) & 0x8000u) != 0u) == 0ull) {
+            nx0 = load_tile(tile + 2); nx1 = load_tile(tile + 3);
+            n_tiles += 2;
+            kasw::lockstep();                                // (the previous tile's words have been read)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { mine[q] = c[q]; mine[192 + q] = cb[q]; }
+            kasw::lockstep();
+#pragma unroll
+            for (int t = 0; t < 6; ++t) padr[t] = cnt + pp.slot[64 * t];
+            uint32_t xa[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
+            uint32_t xb[3] = {cnt[cb[0]], cnt[cb[1]], cnt[cb[2]]};
+            const RelaxTags ga = relax_tags(c, tagtab), gb = relax_tags(cb, tagtab);
+            kasw::lockstep();
+            int32_t pa = -1, pb = -1;
+            for (int32_t it = 0;; ++it) {
+              n_evals += 2;
+              if (it > 130) { stuck = true; break; }         // (row i is right after evaluation i + 1: 129 suffice)
+              const int32_t oa = relax_eval3(xa, ga), ob = relax_eval3(xb, gb);
+              if (kasw::ballot(oa != pa || ob != pb) == 0ull) break;
+              rbuf[lane] = relax_row_word((uint32_t)oa & 3u, (uint32_t)oa >> 2);
+              rbuf[64 + lane] = relax_row_word((uint32_t)ob & 3u, (uint32_t)ob >> 2);
+              relax_pairs<6>(pp, padr, padd, it > 0);
+#pragma unroll
+              for (int q = 0; q < 3; ++q) { xa[q] = mine[q]; xb[q] = mine[192 + q]; }
+              pa = oa; pb = ob;
+            }
+            digest += relax_retire3(raw, pa < 0 ? 4 : pa, g_node_id, out, (uint32_t)k, p);
+            digest += relax_retire3(rawb, pb < 0 ? 4 : pb, g_node_id, out, (uint32_t)k, p + 64);
+            tile += 2;
+            continue;
+          }
+        }
       }
-      // ---- hand the cells to the pair lanes: slot = (cell 0 | cell 1 << 16, cell 2 | none << 16, -, -)
-      kasw::lockstep();                                      // (the previous tile's slot has been read)
-      {
-        uint32_t* sl = (uint32_t*)&stage[lane];
-        RowWords<2> two;
-        two.v[0] = c[0] | (c[1] << 16); two.v[1] = c[2] | 0xffff0000u;
-        *(RowWords<2>*)sl = two;
-      }
+      nx0 = nx1;
+      nx1 = load_tile(tile + 2);
+      tile += 1;
+      n_tiles += 1;
+      // ---- hand the cells to the pair lanes
+      kasw::lockstep();                                      // (the previous tile's words have been read)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) mine[q] = c[q];
       kasw::lockstep();
-      uint32_t* padr[3];
-      uint32_t padd[3] = {0u, 0u, 0u};                       // what my pairs added last
       if constexpr (W == 3) {
         if (fast) {
 #pragma unroll
-          for (int t = 0; t < 3; ++t) padr[t] = cnt + (uint32_t)*pcell[t];
+          for (int t = 0; t < 3; ++t) padr[t] = cnt + pp.slot[64 * t];
           // counter words of my cells as the previous tile left them
-          uint32_t x0 = cnt[c[0]], x1 = cnt[c[1]], x2 = cnt[c[2]];
-          // my row's six tags from the order of its cells
-          const uint32_t oidx = ((c[0] - c[1]) >> 31) | (((c[0] - c[2]) >> 31) << 1) | (((c[1] - c[2]) >> 31) << 2);
-          const uint32_t tw = tagtab[oidx];
-          const uint32_t t00 = tw & 15u, t01 = (tw >> 4) & 15u, t02 = (tw >> 8) & 15u;
-          const uint32_t t10 = (tw >> 12) & 15u, t11 = (tw >> 16) & 15u, t12 = (tw >> 20) & 15u;
+          uint32_t x[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
+          const RelaxTags g = relax_tags(c, tagtab);          // my row's six tags from the order of its cells
           kasw::lockstep();
           int32_t oc_prev = -1;
           for (int32_t it = 0;; ++it) {
@@ -260,33 +331,15 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
             // (lane i is right after evaluation i + 1, so 65 evaluations always suffice: more means the LDS did not
             // hand the additions out in lane order — give up with a status instead of looping)
             if (it > 66) { stuck = true; break; }
-            // first pick: count[.][0], first strictly smaller in visit order == minimum of (count, visit position)
-            const uint32_t k00 = (x0 << 16) | t00, k01 = (x1 << 16) | t01, k02 = (x2 << 16) | t02;
-            const uint32_t kmin = k00 < k01 ? (k00 < k02 ? k00 : k02) : (k01 < k02 ? k01 : k02);
-            const uint32_t w0 = kmin & 3u;
-            // second pick: count[.][1] over the two that are left
-            const uint32_t k10 = (x0 & KAS_RELAX_F1_MASK) | t10, k11 = (x1 & KAS_RELAX_F1_MASK) | t11,
-                           k12 = (x2 & KAS_RELAX_F1_MASK) | t12;
-            const uint32_t lo = w0 == 0u ? k11 : k10, hi = w0 == 2u ? k11 : k12;
-            const uint32_t w1 = (lo < hi ? lo : hi) & 3u;
-            const int32_t oc = (int32_t)(w0 | (w1 << 2));
+            const int32_t oc = relax_eval3(x, g);
             if (kasw::ballot(oc != oc_prev) == 0ull) break;  // nobody's outcome moved: the words hold the tile's commits
-            stage[lane] = lut[oc];                           // my row's addends into its slot
-            relax_pairs(pslot, padr, padd, it > 0);
-            const RelaxSlot back = stage[lane];
-            x0 = back.v[0]; x1 = back.v[1]; x2 = back.v[2];
+            rbuf[lane] = relax_row_word((uint32_t)oc & 3u, (uint32_t)oc >> 2);
+            relax_pairs<3>(pp, padr, padd, it > 0);
+            x[0] = mine[0]; x[1] = mine[1]; x[2] = mine[2];
             oc_prev = oc;
           }
           // ---- the final row: broker ids in list order, digest
-          const RelaxSlot sv = sel[oc_prev < 0 ? 0 : oc_prev];
-          const uint32_t l0 = kasw::perm_bytes(raw.w[1], raw.w[0], sv.v[0]);
-          const uint32_t l1 = kasw::perm_bytes(raw.w[1], raw.w[0], sv.v[1]);
-          const uint32_t l2 = kasw::perm_bytes(raw.w[1], raw.w[0], sv.v[2]);
-          RowW<3> o;
-          o.v[0] = g_node_id[l0]; o.v[1] = g_node_id[l1]; o.v[2] = g_node_id[l2];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)q, o.v[q]);
-          *reinterpret_cast<RowW<3>*>(out + (int64_t)p * 3) = o;
+          digest += relax_retire3(raw, oc_prev < 0 ? 4 : oc_prev, g_node_id, out, (uint32_t)k, p);
           continue;
         }
       }
@@ -294,7 +347,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       n_slow += 1;
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        const uint32_t n = (uint32_t)*pcell[t];
+        const uint32_t n = pp.slot[64 * t];
         padr[t] = cnt + (n < (uint32_t)nmax ? n : (uint32_t)nmax);   // no holder: the padding node, and + 0
       }
       uint32_t x[3];
@@ -317,17 +370,11 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
         if (it > 66) { stuck = true; break; }
         const int32_t oc = relax_eval_generic(x, valid, rank, Lp, rt);
         if (kasw::ballot(oc != oc_prev) == 0ull) break;
-        RelaxSlot sl;
-        const int32_t w0 = oc & 3, w1 = (oc >> 2) & 3;
+        const uint32_t w0 = (uint32_t)oc & 3u, w1 = ((uint32_t)oc >> 2) & 3u;
+        rbuf[lane] = (Lp >= 1 ? KAS_RELAX_F0_ONE << w0 : 0u) | (Lp >= 2 ? KAS_RELAX_F1_ONE << w1 : 0u);
+        relax_pairs<3>(pp, padr, padd, it > 0);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-          sl.v[q] = (Lp >= 1 && q == w0) ? KAS_RELAX_F0_ONE : ((Lp >= 2 && q == w1) ? KAS_RELAX_F1_ONE : 0u);
-        sl.v[3] = 0u;
-        stage[lane] = sl;
-        relax_pairs(pslot, padr, padd, it > 0);
-        const RelaxSlot back = stage[lane];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) x[q] = back.v[q];
+        for (int q = 0; q < 3; ++q) x[q] = mine[q];
         oc_prev = oc;
       }
       if (active && oc_prev >= 0) {

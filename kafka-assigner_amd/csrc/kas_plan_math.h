@@ -62,6 +62,10 @@ struct KasLaunch {
 #define KAS_FLAG_WIDE_CHECK   256u  // set by the launcher (KasShape::wide_checked): the wide ticket form checks its count fields at the end
 #define KAS_FLAG_TICKET_ORDER 0x10000u // lists <= 3 wide: the ticket form of P5 where the relaxation form would run (testing / comparison);
                                        // KAS_PLAN_GROUPS(n) and KAS_PLAN_WIDE_COUNTERS, which only mean something to the ticket form, imply it
+#define KAS_FLAG_RELAX_TILES_64  0x20000u // relaxation form: tiles of 64 rows whatever the batch size (KAS_PLAN_RELAX_TILES(1))
+#define KAS_FLAG_RELAX_TILES_128 0x40000u // relaxation form: double tiles whatever the batch size (KAS_PLAN_RELAX_TILES(2))
+#define KAS_FLAG_RELAX_DUAL      0x80000u // set by the launcher (kas_relax_double_tiles): double tiles in this launch
+#define KAS_RELAX_DUAL_BELOW 512         // batches of fewer scenarios than this take double tiles unless told otherwise
 
 // Byte offsets into the dynamic LDS of the fill kernel.
 //   x       sweep histogram hist[W][n], then per-chunk quota qc[NW][n]
@@ -254,11 +258,19 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 #define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 // relaxation form of P5 (kas_order_relax.h), one wavefront per scenario: one uint32 counter word per node + the
-// padding node's, two 16-entry outcome tables (addends, list selectors), 8 tag words, a 16-byte staging slot per
-// row of the tile
+// padding node's, 8 tag words, a row word per row and a staging word per (row, cell) pair of a double tile (128 rows)
 KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max) {
   int64_t n = n_max > 0 ? n_max : 1;
-  return kas_align16(kas_align16(4 * (n + 1)) + 2 * 16 * 16 + 8 * 4 + 64 * 16);
+  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + 128 * 4 + 384 * 4);
+}
+// Relaxation form: double tiles (128 rows, two rows per lane) in this launch?  A double tile halves the LDS round
+// trips a scenario waits for (one batch of 1000 alone: order kernel 2.0 -> 1.7 ms) at ~1.2 x the LDS operations per row
+// (3.97 evaluations per 128 rows against 3.26 per 64): right when the GPU is not full of wavefronts — few scenarios
+// per launch — and wrong when it is (eight batches of 1000 in flight: 535k against 580k scenarios/s).
+KAS_ABI_FN int32_t kas_relax_double_tiles(uint32_t flags, int32_t n_scenarios) {
+  if (flags & KAS_FLAG_RELAX_TILES_128) return 1;
+  if (flags & KAS_FLAG_RELAX_TILES_64) return 0;
+  return n_scenarios < KAS_RELAX_DUAL_BELOW ? 1 : 0;
 }
 // does a flag word (KAS_PLAN_* / KAS_FLAG_*) ask for the ticket form where the relaxation form is applicable?
 KAS_ABI_FN int32_t kas_flags_want_tickets(uint32_t flags) {

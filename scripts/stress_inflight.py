@@ -32,7 +32,9 @@ from oracle_lib import oracle_solve  # noqa: E402
 # in the plan's description, bench.py flags).  The first is the headline shape (BASELINE.json configs[2]).
 SUITE = [
     ("headline: fill<3,4> per-chunk histograms + relaxation form of the order kernel",
-     "kas_order_relax_kernel<3>", ["--in-flight", "12"]),
+     "kas_order_relax_kernel<3>[tiles of 64 rows]", ["--in-flight", "12"]),
+    ("relaxation form over double tiles (KAS_PLAN_RELAX_TILES(2): what batches of fewer than 512 scenarios take)",
+     "kas_order_relax_kernel<3>[tiles of 128 rows]", ["--plan-flags", "262144", "--in-flight", "12"]),
     ("packed ticket form, 2 scenarios per wavefront (KAS_PLAN_TICKET_ORDER)",
      "kas_order_ticket_kernel<3,2,true>", ["--plan-flags", "65536", "--in-flight", "12"]),
     ("one scenario per solver wavefront (G = 1)", "kas_order_ticket_kernel<3,1,true>", ["--groups", "1", "--in-flight", "12"]),

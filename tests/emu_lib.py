@@ -222,6 +222,8 @@ def last_order_form() -> int:
 
 
 TICKET_ORDER = 0x10000     # KAS_PLAN_TICKET_ORDER: the ticket form where the relaxation form would run
+RELAX_TILES_64 = 0x20000   # KAS_PLAN_RELAX_TILES(1): relaxation form over tiles of 64 rows whatever the batch size
+RELAX_TILES_128 = 0x40000  # KAS_PLAN_RELAX_TILES(2): double tiles whatever the batch size
 
 
 def last_relax_stats():

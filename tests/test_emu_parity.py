@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import TICKET_ORDER, emu_solve, last_queue_rows
+from emu_lib import RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_oracle_vs_literal import scenarios
@@ -82,6 +82,8 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu relaxation form, tiles of 64 rows")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_128), "emu relaxation form, double tiles")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
     # every workgroup width, and the round form of the preference ordering
     for nw, g in ((1, 1), (2, 2), (8, 4)):
@@ -146,6 +148,7 @@ def test_emu_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
     assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 4      # and some that fail or are skipped
     assert_same_outputs(fb, want, emu_solve(fb), "emu multi-topic, relaxation form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu multi-topic tickets")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu multi-topic, relaxation form over tiles of 64 rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu multi-topic rounds")
     assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 12) | (2 << 8)), "emu multi-topic, 2 scenarios per wave")
 

@@ -15,6 +15,8 @@ from test_oracle_vs_literal import scenarios
 
 pytestmark = pytest.mark.gpu
 TICKET_ORDER = abi.KAS_PLAN_TICKET_ORDER      # the ticket form of P5 where the relaxation form would run
+TILES_64 = abi.KAS_PLAN_RELAX_TILES_64        # relaxation form over tiles of 64 rows / double tiles whatever the batch size
+TILES_128 = abi.KAS_PLAN_RELAX_TILES_128      # (by itself: double tiles for batches of fewer than 512 scenarios)
 
 
 def test_device_is_gfx950_and_library_loaded():
@@ -46,6 +48,7 @@ def test_hip_equals_oracle_small_odd_inputs_without_context_io(sc):
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, native.solve_host(fb), "hip (no ctx)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip (no ctx), ticket form")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip (no ctx), relaxation form, tiles of 64 rows")
 
 
 @pytest.mark.parametrize("P,N,R,RF,actions", [
@@ -61,6 +64,8 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, native.solve_host(fb), "hip")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip ticket form")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip relaxation form, tiles of 64 rows")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_128), "hip relaxation form, double tiles")
     # the general multi-sweep sticky fill must agree with the rack-diverse histogram/quota form,
     # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
@@ -101,6 +106,8 @@ def test_config3_shape_full_size_scenarios():
     want = oracle_solve(fb)
     got = native.solve_host(fb)
     assert_same_outputs(fb, want, got, "C3")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "C3 relaxation form over tiles of 64 rows (what a batch of 1000 takes)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "C3 ticket form")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 4), "C3 4 x uint16 counter rows")
@@ -132,6 +139,7 @@ def test_config4_exact_action_add_brokers_1000_to_1049_full_size():
     assert (want.scenario_results["status"] == abi.KAS_OK).all()
     assert (want.scenario_results["moved_replicas"] > 10000).all()      # 14k-16k orphans each
     assert_same_outputs(fb, want, native.solve_host(fb), "C4 add 50")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "C4 add 50, tiles of 64 rows")
 
 
 def test_config5_full_size_1m_partitions_5k_brokers_rf5_rack_on_and_off():
@@ -181,6 +189,10 @@ def test_one_plan_orders_its_solves_across_streams():
     assert "kas_order_round_kernel<3>" in plan.describe()
     plan.set_flags(TICKET_ORDER)
     assert "kas_order_ticket_kernel<3,2,true>" in plan.describe()
+    plan.set_flags(0)
+    assert "kas_order_relax_kernel<3>[tiles of 128 rows]" in plan.describe()      # 24 scenarios: a latency-bound launch
+    plan.set_flags(TILES_64)
+    assert "kas_order_relax_kernel<3>[tiles of 64 rows]" in plan.describe()
     plan.close()
 
 
@@ -445,6 +457,7 @@ def test_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
     assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 6
     assert_same_outputs(fb, want, native.solve_host(fb), "hip multi-topic, relaxation form")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip multi-topic tickets")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip multi-topic, relaxation form over tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip multi-topic rounds")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2 << 12), "hip multi-topic, 2 scenarios per wave")
 
