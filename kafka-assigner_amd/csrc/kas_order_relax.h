@@ -190,7 +190,9 @@ KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node
   return d;
 }
 
-template <int W>
+// DUAL: the instance that takes double tiles (a kernel of its own: it needs 91 vector registers, the instance without
+// them 56 — two of its wavefronts fit where one wavefront of the fill kernel does)
+template <int W, bool DUAL>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
   const int lane = kasw::lane();
@@ -199,8 +201,8 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   uint32_t* cnt = (uint32_t*)lds_raw;                       // [nmax + 1]: + the padding node's word
   uint32_t* tagtab = (uint32_t*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [8] by the order of a row's three cells: its six tags
-  uint32_t* rbuf = tagtab + 8;                              // [128] row words of the (double) tile
-  uint32_t* stage = rbuf + 128;                             // [384] by pair of the (double) tile
+  uint32_t* rbuf = tagtab + 8;                              // [64 | 128] row words of the (double) tile
+  uint32_t* stage = rbuf + (DUAL ? 128 : 64);               // [192 | 384] by pair of the (double) tile
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int64_t t_begin = kasw::clock_ticks();
   for (int32_t n = lane; n < N; n += 64) cnt[n] = 0u;
@@ -216,7 +218,6 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   uint32_t* const mine = stage + 3 * lane;                  // (row lane) my row's three words; + 192 for the second row
   kasw::lockstep();
 
-  const bool dual_on = (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;   // (kas_relax_double_tiles)
   uint64_t digest = 0;
   int32_t n_tiles = 0, n_evals = 0, n_slow = 0;             // (wave-uniform)
   bool stuck = false;
@@ -272,7 +273,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
           fast = kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
         // ---- two usual tiles in a row: one double tile of 128 rows, lane i evaluates rows i and 64 + i.  The same
         // fixed point (row-major pairs over six instructions), twice the work per LDS round trip.
-        if (dual_on && fast && ((tile + 2) << 6) <= P) {
+        if constexpr (DUAL) if (fast && ((tile + 2) << 6) <= P) {
           const MidRaw<W> rawb = nx1;
           const uint32_t cb[3] = {rawb.w[0] & 0xffffu, rawb.w[0] >> 16, rawb.w[1] & 0xffffu};
           if (kasw::ballot(((cb[0] | cb[1] | cb[2]) & 0x8000u) != 0u) == 0ull) {

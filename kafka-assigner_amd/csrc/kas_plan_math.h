@@ -258,10 +258,13 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 #define KAS_ORDER_WIDE_BLOCK (64 * (3 + KAS_WIDE_BULK_SOLVERS))   // staging, retiring and the solver wavefronts
 // round form of order: int32 count[n_max][CS] + uint64 lane masks [n_max]
 // relaxation form of P5 (kas_order_relax.h), one wavefront per scenario: one uint32 counter word per node + the
-// padding node's, 8 tag words, a row word per row and a staging word per (row, cell) pair of a double tile (128 rows)
-KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max) {
+// padding node's, 8 tag words, a row word per row and a staging word per (row, cell) pair of a tile (64 rows; the
+// instance with double tiles: 128).  5,072 bytes at 1,000 brokers: four of these workgroups fit in the LDS that four
+// workgroups of the fill kernel leave free on a CU.
+KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles) {
   int64_t n = n_max > 0 ? n_max : 1;
-  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + 128 * 4 + 384 * 4);
+  const int64_t rows = double_tiles ? 128 : 64;
+  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4);
 }
 // Relaxation form: double tiles (128 rows, two rows per lane) in this launch?  A double tile halves the LDS round
 // trips a scenario waits for (one batch of 1000 alone: order kernel 2.0 -> 1.7 ms) at ~1.2 x the LDS operations per row
@@ -467,7 +470,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // relaxation form: no Context, no KAS:190 index error, rows per node inside its 12-bit count fields (4,095: the
   // packed ticket form stops at 1,023, the ticket forms at 65,535 tickets) — and none of the ticket form's 16-bit LDS
   // offsets, so the broker count is limited by the fill kernel's LDS only
-  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && !s.any_ctx && kas_order_relax_lds(s.n_max) <= KAS_LDS_LIMIT;
+  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && !s.any_ctx && kas_order_relax_lds(s.n_max, 1) <= KAS_LDS_LIMIT;
   // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
   // to the round form — which must then fit)
   s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&
