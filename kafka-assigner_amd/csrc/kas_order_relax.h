@@ -19,10 +19,12 @@
 // a node is the first cell of one row and the second of another, and a lane would then see the additions of LATER
 // rows made by an earlier instruction.  The emulator runs every LDS atomic as an instruction of its own for this
 // reason.)  The same physical lane is therefore two things: "row lane" i evaluates row i, "pair lane" l adds the
-// pairs l, 64 + l, 128 + l; they meet in a 16-byte staging slot per row: the row lane puts the addends of its
-// current outcome there (cells 0..2), the pair lanes take theirs, add, and put what the add returned back into the
-// same cell of the slot, the row lane reads the slot: the counter words as its row would see them if every earlier
-// row of the tile had committed its current outcome.  If no lane's outcome changed, the words already hold the
+// pairs l, 64 + l, 128 + l.  They meet in LDS words: the row lane publishes its current outcome as one ROW WORD (bit
+// 4 + c: cell c is the first pick, bit 20 + c: the second), a pair lane reads the word of its pair's row, shifts it by
+// its cell and masks it — its addend —, adds, and puts what the add returned into the pair's STAGING WORD stage[v];
+// the row lane reads stage[3 i .. 3 i + 2]: the counter words as its row would see them if every earlier row of the
+// tile had committed its current outcome.  (Pair lanes touch consecutive words, row lanes words at stride 3: no bank
+// conflicts on either side.  The first version met in a 16-byte slot per row and was a third slower for it.)  If no lane's outcome changed, the words already hold the
 // tile's commits (the additions stay); otherwise the additions are taken back (ds_sub_u32) and made again with the
 // new outcomes.  Lane i is right once every lane below it is, so the loop ends after at most 65 evaluations, and
 // the fixed point of an acyclic system is unique: it is the sequential result.  Emulator, bench-shaped scenarios
@@ -38,16 +40,18 @@
 // holders, rotated by abs(hash) mod set size — is in the tags: with rank = how many of the row's other holders are
 // smaller, the first pick over three holders visits a holder at position (idx3 + rank) mod 3 and the second visits
 // the two that are left in ascending (idx2 = 0) or descending order.  Tags are computed once per tile.  Rows per
-// node stay below 1023 (the plan's bound for the packed ticket form), far inside the 12-bit fields.  What an
-// outcome adds to which cell comes from a 16-entry table in LDS indexed by the outcome.
+// node stay below 4095 (KAS_RELAX_ROW_LIMIT): the 12-bit fields.
 //
 // Tiles whose 64 rows all hold three brokers in rows of the batch's width take the straight-line evaluation above;
 // any other tile (the last tile of a topic, rows with fewer holders after a reduced replication factor, topics
-// narrower than the batch) takes the same loop with per-lane list lengths.  HBM: mid rows in (8 B per row, read one
-// tile ahead), final rows out (12 B), broker ids from the L2-resident node table.
+// narrower than the batch) takes the same loop with per-lane list lengths.  The DUAL instance solves two usual tiles
+// in a row as one tile of 128 rows (two rows per lane, six pair instructions): fewer LDS round trips per scenario,
+// more LDS operations per row, 91 instead of 59 vector registers — for launches that do not fill the GPU
+// (kas_relax_double_tiles).  HBM: mid rows in (8 B per row, read two tiles ahead), final rows out (12 B), broker ids
+// from the L2-resident node table.
 //
-// Applicable where the packed ticket form is (KasShape::relax_ok): lists <= 3 wide, no Context handed in, no
-// topic hash of Integer.MIN_VALUE, ticket bound below 1023.  Everything else keeps the ticket / round forms.
+// Applicable (KasShape::relax_ok) to lists <= 3 wide with no Context handed in, no topic hash of Integer.MIN_VALUE
+// and fewer than 4095 rows per node.  Everything else keeps the ticket / round forms.
 #pragma once
 
 namespace kas {
