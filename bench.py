@@ -851,8 +851,12 @@ def other_configs_leg(args, run):
     ctx = run.ctx
     out = {}
 
-    def gpu_ms(fb, n=20):
+    def gpu_ms(fb, n=20, flags=0):
         plan = native.Plan(ctx, fb)
+        if flags:
+            plan.set_flags(flags)
+        d_ctx0 = torch.from_numpy(fb.ctx).to(dev) if fb.ctx is not None and fb.ctx.size else None
+        d_ctx = d_ctx0.clone() if d_ctx0 is not None else None
         d_cur = torch.from_numpy(fb.cur).to(dev)
         d_out = torch.empty(fb.out_len, dtype=torch.int32, device=dev)
         d_tr = torch.zeros(fb.n_topics * 16, dtype=torch.uint8, device=dev)
@@ -861,7 +865,11 @@ def other_configs_leg(args, run):
         st.wait_stream(torch.cuda.current_stream(dev))
 
         def go():
-            plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
+            if d_ctx is not None:
+                with torch.cuda.stream(st):
+                    d_ctx.copy_(d_ctx0, non_blocking=True)               # every solve starts from the same Context (a 1 KB copy)
+            plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
+                              ctx=d_ctx.data_ptr() if d_ctx is not None else 0, stream=st.cuda_stream)
         go(); st.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -873,6 +881,8 @@ def other_configs_leg(args, run):
         sr = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE).copy()
         rows = d_out.cpu().numpy()
         plan.close()
+        if d_ctx is not None:
+            return ms, f_us, o_us, desc, sr, rows, d_ctx.cpu().numpy()
         return ms, f_us, o_us, desc, sr, rows
 
     def cpu_ms(fb, threads, n=3):
@@ -895,9 +905,24 @@ def other_configs_leg(args, run):
     ms, f_us, o_us, desc, sr, rows = gpu_ms(fb, n=200)
     c1, want = cpu_ms(fb, 1, n=9)
     check(fb, sr, rows, want, "configs[1]")
+    # the same call as the reference's adapter makes it (KTA:19-23, 70-71): with the instance's Context handed in and
+    # wanted back — counters as a few earlier topics would have left them; relaxation form and, asked for, ticket form
+    import dataclasses
+    scen_c = fb.scen.copy()
+    scen_c["ctx_width"] = 3
+    scen_c["ctx_off"] = 0
+    ctx0 = np.random.default_rng(1).integers(0, 300, size=int(fb.scen["n_nodes"][0]) * 3).astype(np.int32)
+    fbc = dataclasses.replace(fb, scen=scen_c, ctx=ctx0)
+    want_c = cpu_fast_solve(fbc, threads=1)
+    with_ctx = {}
+    for name, flags in (("relaxation_form", 0), ("ticket_form", abi.KAS_PLAN_TICKET_ORDER)):
+        ms_c, f_c, o_c, desc_c, sr_c, rows_c, ctx_c = gpu_ms(fbc, n=200, flags=flags)
+        assert (rows_c == want_c.out[:fbc.out_len]).all() and (ctx_c == want_c.ctx).all(), "configs[1] with a Context: differs from the CPU solver"
+        with_ctx[name] = {"gpu_ms_per_solve": ms_c, "gpu_order_kernel_us": o_c, "kernel": desc_c}
     out["configs[1]"] = {
         "workload": "one scenario, 10k partitions x 100 brokers x 10 racks, RF 3, decommission 1 broker",
         "gpu_ms_per_solve": ms, "gpu_fill_kernel_us": f_us, "gpu_order_kernel_us": o_us, "kernel": desc,
+        "with_the_adapters_context_in_and_out": with_ctx,
         "cpu_fast_one_core_ms": c1, "cpu_fast_all_cores_ms": c1,
         "note": "a single scenario has no scenario-level parallelism for the host (all-core = one core) and little for "
                 "the GPU: ~1.6k dependent solver steps; one CPU core and the GPU take about the same time here",

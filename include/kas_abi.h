@@ -303,7 +303,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_GENERIC_FILL  always run the general multi-sweep sticky fill instead of the
  *                          rack-diverse histogram/quota form
  *   KAS_PLAN_ROUND_ORDER   always run the tile-round preference ordering instead of the relaxation / ticket forms
- *   KAS_PLAN_TICKET_ORDER  lists <= 3 wide without a Context: the ticket form of the preference ordering (three
+ *   KAS_PLAN_TICKET_ORDER  lists <= 3 wide: the ticket form of the preference ordering (three
  *                          wavefronts per pair of scenarios) where the relaxation form (one wavefront per scenario,
  *                          kas_order_relax.h) would run; KAS_PLAN_WIDE_COUNTERS and KAS_PLAN_GROUPS(n != 0), which
  *                          only mean something to the ticket form, imply it

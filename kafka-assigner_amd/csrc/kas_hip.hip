@@ -3,7 +3,7 @@
 // A solve is three launches on one stream (device code in kas_solver_body.h):
 //   kas_fill_kernel<W, NW>              P0-P4: one workgroup of NW wavefronts per scenario
 //   kas_order_permutation_kernel        scenarios by descending P5 chain length
-//   kas_order_relax_kernel<W,DUAL>      P5, relaxation form: one wavefront per scenario (lists <= 3 wide, no Context)
+//   kas_order_relax_kernel<W,DUAL,CTX>  P5, relaxation form: one wavefront per scenario (lists <= 3 wide)
 //   (or kas_order_ticket_kernel<W, G, PK>, behind kas_order_permutation_kernel: solver / stager / retirer wavefronts
 //    per G scenarios; kas_order_wide_kernel<W> for lists 4 and 5 wide; kas_order_round_kernel<W>, the round form)
 // Scenarios share nothing, so there is no inter-workgroup communication at all: each workgroup
@@ -109,12 +109,13 @@ __global__ __launch_bounds__(128) void kas_lds_order_selftest_kernel(unsigned in
   if (nbad) atomicAdd(bad, nbad);
 }
 
-// lists up to 3 wide, no Context: the relaxation form, one wavefront (= one workgroup) per scenario (kas_order_relax.h)
+// lists up to 3 wide: the relaxation form, one wavefront (= one workgroup) per scenario (kas_order_relax.h)
 // (DUAL: the instance with double tiles, kas_relax_double_tiles)
-template <int W, bool DUAL>
+// (CTX: the instance for batches in which some scenario hands a Context in or wants it back)
+template <int W, bool DUAL, bool CTX>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
 // lists 4 and 5 wide: one scenario per workgroup (stager, retirer, three solver wavefronts: kas_order_wide.h)
@@ -166,7 +167,7 @@ static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<5, 4>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
-static kas_kernel_fn kas_order_relax_for(int, int) { return nullptr; }
+static kas_kernel_fn kas_order_relax_for(int, int, int) { return nullptr; }
 static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_kernels_w<5>() : KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #elif defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES != 0
 // tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
@@ -180,7 +181,10 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
 }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
 static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
-static kas_kernel_fn kas_order_relax_for(int, int dual) { return dual ? kas_order_relax_kernel<3, true> : kas_order_relax_kernel<3, false>; }
+static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx) {
+  if (ctx) return dual ? kas_order_relax_kernel<3, true, true> : kas_order_relax_kernel<3, false, true>;
+  return dual ? kas_order_relax_kernel<3, true, false> : kas_order_relax_kernel<3, false, false>;
+}
 static KasSpreadKernels kas_spread_for(int) { return KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #else
 static bool kas_minimal_ok(int, int, int) { return true; }
@@ -227,9 +231,12 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
 static kas_kernel_fn kas_order_wide_for(int Wc) {
   return Wc == 4 ? kas_order_wide_kernel<4> : kas_order_wide_kernel<5>;
 }
-static kas_kernel_fn kas_order_relax_for(int Wc, int dual) {
-  if (Wc <= 2) return kas_order_relax_kernel<2, false>;     // (double tiles are rows of three holders)
-  if (Wc == 3) return dual ? kas_order_relax_kernel<3, true> : kas_order_relax_kernel<3, false>;
+static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx) {
+  if (Wc <= 2) return ctx ? kas_order_relax_kernel<2, false, true> : kas_order_relax_kernel<2, false, false>;   // (double tiles are rows of three holders)
+  if (Wc == 3) {
+    if (ctx) return dual ? kas_order_relax_kernel<3, true, true> : kas_order_relax_kernel<3, false, true>;
+    return dual ? kas_order_relax_kernel<3, true, false> : kas_order_relax_kernel<3, false, false>;
+  }
   return nullptr;
 }
 static KasSpreadKernels kas_spread_for(int Wc) {
@@ -461,10 +468,10 @@ static int kas_plan_set_kernels(kas_plan* p) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kas_order_ticket_lds(p->shape.n_max, p->G, pk) + KAS_TUNE_ORDER_LDS_PAD));
   for (int dual = 0; dual < 2; ++dual)
-    if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual))
-      KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual),
+    if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx))
+      KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kas_order_relax_lds(p->shape.n_max, dual)));
+                                    kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx)));
   if (p->shape.round_fits)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -608,7 +615,7 @@ struct KasLaunchPlan {
 };
 static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   KasLaunchPlan lp;
-  lp.relax = p->shape.relax_ok && p->ctx->lds_lane_order_ok && kas_order_relax_for(p->Wc, 0) != nullptr &&
+  lp.relax = p->shape.relax_ok && p->ctx->lds_lane_order_ok && kas_order_relax_for(p->Wc, 0, 0) != nullptr &&
              !(p->flags & KAS_FLAG_ROUND_ORDER) && !(kas_flags_want_tickets(p->flags) && p->tickets);
   lp.tickets = !lp.relax && p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
   lp.packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
@@ -618,7 +625,7 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD;
   if (lp.relax) {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
-    lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios));
+    lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios), p->shape.any_ctx);
   } else if (lp.tickets) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
     lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed) + KAS_TUNE_ORDER_LDS_PAD;
@@ -639,10 +646,10 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   char order[256];
   const char* ctx_tail = (lp.wide && p->shape.wide_checked)
                              ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
-                             : (p->shape.any_ctx && (lp.tickets || lp.wide)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
+                             : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax)
-    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows] grid=%ux%u lds=%zu", p->Wc,
-             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, lp.order_grid, lp.order_block, lp.order_lds);
+    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows] grid=%ux%u lds=%zu%s", p->Wc,
+             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
   else if (lp.tickets)
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
@@ -733,7 +740,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   // then and its mid rows gone, so it is solved again from `cur`: fill kernel, then round form, both taking only
   // the flagged scenarios.
   const bool wide_recheck = lp.wide && p->shape.wide_checked;
-  const bool ctx_fallback = (p->shape.any_ctx && (tickets || lp.wide)) || wide_recheck;
+  const bool ctx_fallback = (p->shape.any_ctx && (tickets || lp.wide || lp.relax)) || wide_recheck;
   if (ctx_fallback) KAS_HIP_TRY(hipMemsetAsync(a.ord_flag, 0, 4 * ((size_t)p->n_scenarios + 1), st));
   if (wide_recheck) a.flags |= KAS_FLAG_WIDE_CHECK;
   if (lp.pairing) {
@@ -744,7 +751,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
     KAS_HIP_TRY(hipGetLastError());
   }
   if (lp.relax)
-    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
                        lp.order_lds, st, a);

@@ -1,5 +1,5 @@
 // kas_order_relax.h — order kernel, RELAXATION form: P5 (computePreferenceLists, KAS:202-239 with the
-// PreferenceListOrderTracker of KAS:244-302) for lists up to 3 wide, one wavefront per scenario, no Context.
+// PreferenceListOrderTracker of KAS:244-302) for lists up to 3 wide, one wavefront per scenario.
 // Included at the end of kas_solver_body.h (namespace kas, the helpers of that file).
 //
 // What P5 is: rows in ascending order; row p reads count[n][0], count[n][1] of its own holders, picks (least count,
@@ -50,8 +50,9 @@
 // (kas_relax_double_tiles).  HBM: mid rows in (8 B per row, read two tiles ahead), final rows out (12 B), broker ids
 // from the L2-resident node table.
 //
-// Applicable (KasShape::relax_ok) to lists <= 3 wide with no Context handed in, no topic hash of Integer.MIN_VALUE
-// and fewer than 4095 rows per node.  Everything else keeps the ticket / round forms.
+// Applicable (KasShape::relax_ok) to lists <= 3 wide with no topic hash of Integer.MIN_VALUE and fewer than 4095 rows
+// per node; a Context handed in (the CTX instances) must leave room for them in its columns 0 and 1, checked per
+// scenario by the kernel.  Everything else keeps the ticket / round forms.
 #pragma once
 
 namespace kas {
@@ -179,12 +180,16 @@ KAS_DEV int32_t relax_eval3(const uint32_t (&x)[3], const RelaxTags& g) {
 
 // The final row of a partition with three holders: broker ids in list order out, its digest back.  List position r
 // takes cell w_r: bytes 2 w_r, 2 w_r + 1 of the mid row (v_perm_b32 selector, high half zero).
+// (cnt2 != nullptr: a Context goes back — count[.][2] of the last position's holder, never read by these lists, is kept
+// as an increment per node beside the counter words)
 template <class Raw>
-KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node_id, int32_t* out, uint32_t k, int32_t p) {
+KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node_id, int32_t* out, uint32_t k, int32_t p,
+                               uint32_t* cnt2 = nullptr) {
   const uint32_t w0 = (uint32_t)oc & 3u, w1 = ((uint32_t)oc >> 2) & 3u, w2 = 3u - w0 - w1;
   const uint32_t l0 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w0 * 0x0202u);
   const uint32_t l1 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w1 * 0x0202u);
   const uint32_t l2 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w2 * 0x0202u);
+  if (cnt2) kasw::lds_add_u32(cnt2 + l2, 1u);
   RowW<3> o;
   o.v[0] = g_node_id[l0]; o.v[1] = g_node_id[l1]; o.v[2] = g_node_id[l2];
   uint64_t d = 0;
@@ -196,7 +201,10 @@ KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node
 
 // DUAL: the instance that takes double tiles (a kernel of its own: it needs 91 vector registers, the instance without
 // them 56 — two of its wavefronts fit where one wavefront of the fill kernel does)
-template <int W, bool DUAL>
+// CTX: the instance for batches in which some scenario hands a Context in or wants it back (KAS:360-369): the counter
+// words start from the Context's columns 0 and 1, a third array counts what the rows add to column 2, and all three go
+// back at the end.  A scenario whose counters would leave the 12-bit fields is left to the round form (ord_flag).
+template <int W, bool DUAL, bool CTX>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
   const int lane = kasw::lane();
@@ -207,9 +215,34 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   uint32_t* tagtab = (uint32_t*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [8] by the order of a row's three cells: its six tags
   uint32_t* rbuf = tagtab + 8;                              // [64 | 128] row words of the (double) tile
   uint32_t* stage = rbuf + (DUAL ? 128 : 64);               // [192 | 384] by pair of the (double) tile
+  uint32_t* cnt2 = nullptr;                                 // (CTX) [nmax] what the rows add to count[n][2]
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int64_t t_begin = kasw::clock_ticks();
-  for (int32_t n = lane; n < N; n += 64) cnt[n] = 0u;
+  int32_t* g_ctx = nullptr;
+  int32_t ccols = 0;
+  if constexpr (CTX) {
+    cnt2 = stage + (DUAL ? 384 : 192);
+    if (sd.ctx_off >= 0 && sd.ctx_width > 0 && a.ctx != nullptr) {           // (wave-uniform)
+      g_ctx = a.ctx + sd.ctx_off;
+      ccols = sd.ctx_width < W ? sd.ctx_width : W;
+      // columns 0 and 1 live in 12-bit fields: the Context's value + every row this scenario can add must fit
+      const bool over = ctx_over_limit(g_ctx, N, sd.ctx_width, ccols < 2 ? ccols : 2, KAS_RELAX_ROW_LIMIT + 1u,
+                                       ctx_gain_bound(a, sd), lane, 64);
+      if (kasw::ballot(over) != 0ull) {
+        if (lane == 0 && a.ord_flag) a.ord_flag[s] = 1;       // the round form takes this scenario
+        return;
+      }
+    }
+  }
+  for (int32_t n = lane; n < N; n += 64) {
+    uint32_t w = 0u;
+    if constexpr (CTX) {
+      if (ccols > 0) w |= (uint32_t)g_ctx[(int64_t)n * sd.ctx_width] << 4;
+      if (ccols > 1) w |= (uint32_t)g_ctx[(int64_t)n * sd.ctx_width + 1] << 20;
+      cnt2[n] = 0u;
+    }
+    cnt[n] = w;
+  }
   if (lane == 0) cnt[nmax] = KAS_RELAX_PAD_WORD;
   RelaxPairs pp;
   pp.slot = stage + lane;
@@ -306,8 +339,8 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
               for (int q = 0; q < 3; ++q) { xa[q] = mine[q]; xb[q] = mine[192 + q]; }
               pa = oa; pb = ob;
             }
-            digest += relax_retire3(raw, pa < 0 ? 4 : pa, g_node_id, out, (uint32_t)k, p);
-            digest += relax_retire3(rawb, pb < 0 ? 4 : pb, g_node_id, out, (uint32_t)k, p + 64);
+            digest += relax_retire3(raw, pa < 0 ? 4 : pa, g_node_id, out, (uint32_t)k, p, cnt2);
+            digest += relax_retire3(rawb, pb < 0 ? 4 : pb, g_node_id, out, (uint32_t)k, p + 64, cnt2);
             tile += 2;
             continue;
           }
@@ -344,7 +377,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
             oc_prev = oc;
           }
           // ---- the final row: broker ids in list order, digest
-          digest += relax_retire3(raw, oc_prev < 0 ? 4 : oc_prev, g_node_id, out, (uint32_t)k, p);
+          digest += relax_retire3(raw, oc_prev < 0 ? 4 : oc_prev, g_node_id, out, (uint32_t)k, p, cnt2);
           continue;
         }
       }
@@ -390,11 +423,23 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
           if (r < ow) {
             const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
             const int32_t id = r < Lp ? g_node_id[cell] : -1;
+            if constexpr (CTX) { if (r == 2 && r < Lp) kasw::lds_add_u32(cnt2 + cell, 1u); }
             out[(int64_t)p * ow + r] = id;
             if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
           }
         }
       }
+    }
+  }
+  if constexpr (CTX) {
+    // the Context goes back (KAS:360-369): every row has retired, the words hold every commit
+    kasw::lockstep();
+    for (int32_t n = lane; n < N && ccols > 0; n += 64) {
+      const uint32_t w = cnt[n];
+      int32_t* row = g_ctx + (int64_t)n * sd.ctx_width;
+      row[0] = (int32_t)((w >> 4) & 0xfffu);
+      if (ccols > 1) row[1] = (int32_t)(w >> 20);
+      if (ccols > 2) row[2] += (int32_t)cnt2[n];
     }
   }
   const uint64_t dsum = kasw::wave_sum_u64(digest);

@@ -261,10 +261,11 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 // padding node's, 8 tag words, a row word per row and a staging word per (row, cell) pair of a tile (64 rows; the
 // instance with double tiles: 128).  5,072 bytes at 1,000 brokers: four of these workgroups fit in the LDS that four
 // workgroups of the fill kernel leave free on a CU.
-KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles) {
+// (with_ctx: the instance for batches with a Context keeps a second uint32 per node: what the rows add to count[n][2])
+KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles, int32_t with_ctx) {
   int64_t n = n_max > 0 ? n_max : 1;
   const int64_t rows = double_tiles ? 128 : 64;
-  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4);
+  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4 + (with_ctx ? 4 * n : 0));
 }
 // Relaxation form: double tiles (128 rows, two rows per lane) in this launch?  A double tile halves the LDS round
 // trips a scenario waits for (one batch of 1000 alone: order kernel 2.0 -> 1.7 ms) at ~1.2 x the LDS operations per row
@@ -467,10 +468,12 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // lists 4 and 5 wide: the wide ticket form (kas_order_wide.h) under the same conditions plus 10-bit
   // count fields and 16-bit LDS offsets of its 8-byte counter rows; beyond 5: round form
   s.packed_ok = s.bound_small && !s.any_ctx;
-  // relaxation form: no Context, no KAS:190 index error, rows per node inside its 12-bit count fields (4,095: the
-  // packed ticket form stops at 1,023, the ticket forms at 65,535 tickets) — and none of the ticket form's 16-bit LDS
-  // offsets, so the broker count is limited by the fill kernel's LDS only
-  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && !s.any_ctx && kas_order_relax_lds(s.n_max, 1) <= KAS_LDS_LIMIT;
+  // relaxation form: no KAS:190 index error, rows per node inside its 12-bit count fields (4,095: the packed ticket
+  // form stops at 1,023, the ticket forms at 65,535 tickets) — and none of the ticket form's 16-bit LDS offsets, so
+  // the broker count is limited by the fill kernel's LDS only.  A Context handed in is checked per scenario by the
+  // kernel (its counters + the rows to come must fit the fields; else the round form, which fits whenever a batch
+  // with a Context is accepted at all)
+  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && kas_order_relax_lds(s.n_max, 1, s.any_ctx) <= KAS_LDS_LIMIT;
   // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
   // to the round form — which must then fit)
   s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&

@@ -212,9 +212,9 @@ template <int W> void run_order_wide(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
 }
-template <int W, bool DUAL> void run_order_relax(void* p) {
+template <int W, bool DUAL, bool CTX> void run_order_relax(void* p) {
   RunArgs* r = (RunArgs*)p;
-  if constexpr (W <= 3) kas::order_relax<W, DUAL>(*r->a, r->s, r->lds);
+  if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX>(*r->a, r->s, r->lds);
 }
 template <int W> void run_order_rounds(void* p) {
   RunArgs* r = (RunArgs*)p;
@@ -295,7 +295,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     return KAS_E_UNSUPPORTED;
   }
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
-  if ((size_t)kas_order_relax_lds(sh.n_max, 1) > lds_bytes) lds_bytes = (size_t)kas_order_relax_lds(sh.n_max, 1);
+  if ((size_t)kas_order_relax_lds(sh.n_max, 1, 1) > lds_bytes) lds_bytes = (size_t)kas_order_relax_lds(sh.n_max, 1, 1);
   if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
   if (lds_bytes < sizeof(int32_t) * (KAS_PERM_BINS + 8)) lds_bytes = sizeof(int32_t) * (KAS_PERM_BINS + 8);
   std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
@@ -379,10 +379,12 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
   // order kernel: one wavefront per scenario (relaxation form, round form), three per G scenarios (ticket form)
   if (relax) {
-    run_fn f = sh.Wc <= 2 ? run_order_relax<2, false> : ((a.flags & KAS_FLAG_RELAX_DUAL) ? run_order_relax<3, true> : run_order_relax<3, false>);
+    const bool rdual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
+    run_fn f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true> : (rdual ? run_order_relax<3, true, true> : run_order_relax<3, false, true>))
+                          : (sh.Wc <= 2 ? run_order_relax<2, false, false> : (rdual ? run_order_relax<3, true, false> : run_order_relax<3, false, false>));
     // exactly the LDS the product launches the kernel with, and a guard behind it: the hardware drops what a
     // workgroup writes beyond its allocation and reads zeros there — here that must not pass unnoticed
-    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u);
+    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx);
     std::vector<unsigned char> rl(relax_bytes + 4096);
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(rl.data(), 0xCD, relax_bytes);
@@ -470,7 +472,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     }
     a.flags &= ~KAS_FLAG_WIDE_CHECK;
   }
-  if ((sh.any_ctx && (tickets || wide)) || wide_recheck) {
+  if ((sh.any_ctx && (tickets || wide || relax)) || wide_recheck) {
     // as kas_solve_device: the round form behind a ticket form, taking only what that one flagged
     a.flags |= KAS_FLAG_ORDER_FLAGGED;
     a.perm = nullptr;

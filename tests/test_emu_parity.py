@@ -445,12 +445,20 @@ def test_emu_ticket_forms_take_a_context_in_and_hand_it_back(P, N, R, RF, form):
     fb = _with_context(_batch(808 + RF, 4, P, N, R, RF, G.BENCH_ACTIONS), _random_counters(5, 60))
     want = oracle_solve(fb)
     assert (want.scenario_results["status"] == abi.KAS_OK).any()
-    got = emu_solve(fb)
+    got = emu_solve(fb, flags=TICKET_ORDER)
     assert last_order_form() == form and last_flagged() == 0
     assert_same_outputs(fb, want, got, f"emu ticket form {form} with a Context")
     assert (got.ctx != fb.ctx).any()                                     # the counters moved ...
     np.testing.assert_array_equal(got.ctx.reshape(-1, 8)[:, RF:], fb.ctx.reshape(-1, 8)[:, RF:])   # ... only below the list width
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu round form with the same Context")
+    if RF <= 3:
+        # round 4: lists up to 3 wide take the relaxation form with a Context too (counter words seeded from its
+        # columns 0 and 1, column 2 counted beside them), at both tile sizes
+        for flags, what in ((0, "by batch size"), (RELAX_TILES_64, "tiles of 64 rows"), (RELAX_TILES_128, "double tiles")):
+            got = emu_solve(fb, flags=flags)
+            assert last_order_form() == 3 and last_flagged() == 0
+            assert_same_outputs(fb, want, got, f"emu relaxation form with a Context, {what}")
+            np.testing.assert_array_equal(got.ctx.reshape(-1, 8)[:, RF:], fb.ctx.reshape(-1, 8)[:, RF:])
 
 
 def test_emu_context_counters_beyond_the_count_fields_go_to_the_round_form():
@@ -470,7 +478,20 @@ def test_emu_context_counters_beyond_the_count_fields_go_to_the_round_form():
     got = emu_solve(fb, flags=1 << 12)
     assert last_order_form() == 1 and last_flagged() == 2
     assert_same_outputs(fb, want, got, "emu ticket form, two scenarios flagged")
-    assert_same_outputs(fb, want, emu_solve(fb), "emu ticket form, two scenarios per wavefront, two flagged")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form, two scenarios per wavefront, two flagged")
+    # the relaxation form keeps columns 0 and 1 in 12-bit fields: counter + rows to come must stay below 4096
+    def big12(s, n):
+        v = np.random.default_rng(s).integers(0, 500, size=(n, 8))
+        if s == 0: v[n // 3, 0] = 4000                                  # + up to 150 rows: over
+        if s == 1: v[n // 2, 1] = 65535
+        if s == 2: v[3, 0] = -4
+        if s == 3: v[5, 2] = 1 << 30                                    # column 2 is not a field: stays
+        return v
+    fb12 = _with_context(_batch(515, 4, 2000, 50, 10, 3, G.BENCH_ACTIONS), big12)
+    want12 = oracle_solve(fb12)
+    got = emu_solve(fb12)
+    assert last_order_form() == 3 and last_flagged() == 3
+    assert_same_outputs(fb12, want12, got, "emu relaxation form, three scenarios flagged")
 
     def big5(s, n):
         v = np.random.default_rng(s).integers(0, 300, size=(n, 8))
@@ -499,17 +520,18 @@ def test_emu_per_topic_calls_carry_the_context_like_the_cli_loop():
     want = oracle_solve(whole)
     assert (want.topic_results["status"][:2] == abi.KAS_OK).all()
     from kafka_assigner_amd.flatten import unflatten_context
-    counters, outs = None, []
-    for k, t in enumerate(topics):
-        fb = flatten([Scenario(brokers=brokers, racks=racks, topics=[t], context=counters, want_context=True)])
-        got = emu_solve(fb)
-        assert last_order_form() == 1
-        assert got.topic_results["status"][0] == want.topic_results["status"][k]
-        assert got.topic_results["fail_partition"][0] == want.topic_results["fail_partition"][k]
-        outs.append(got.out[:fb.out_len])
-        if got.topic_results["status"][0] != abi.KAS_OK:
-            break                                                        # the CLI run ends here (KAG:173-184)
-        counters = unflatten_context(fb, got.ctx, 0)
-    done = np.concatenate(outs)
-    np.testing.assert_array_equal(done, want.out[:done.size])
-    assert counters == unflatten_context(whole, want.ctx, 0)
+    for flags, form in ((0, 3), (TICKET_ORDER, 1)):                      # (round 4: the relaxation form; round 3: tickets)
+        counters, outs = None, []
+        for k, t in enumerate(topics):
+            fb = flatten([Scenario(brokers=brokers, racks=racks, topics=[t], context=counters, want_context=True)])
+            got = emu_solve(fb, flags=flags)
+            assert last_order_form() == form
+            assert got.topic_results["status"][0] == want.topic_results["status"][k]
+            assert got.topic_results["fail_partition"][0] == want.topic_results["fail_partition"][k]
+            outs.append(got.out[:fb.out_len])
+            if got.topic_results["status"][0] != abi.KAS_OK:
+                break                                                    # the CLI run ends here (KAG:173-184)
+            counters = unflatten_context(fb, got.ctx, 0)
+        done = np.concatenate(outs)
+        np.testing.assert_array_equal(done, want.out[:done.size])
+        assert counters == unflatten_context(whole, want.ctx, 0)

@@ -336,13 +336,22 @@ def test_ticket_forms_take_a_context_in_and_hand_it_back(P, N, R, RF, kernel):
     from test_emu_parity import _random_counters, _with_context
     fb = _with_context(_batch(606 + RF, 6, P, N, R, RF, G.BENCH_ACTIONS), _random_counters(7, 90))
     plan = native.Plan(native.default_context(), fb)
+    if RF <= 3:
+        # round 4: by itself the plan takes the relaxation form with a Context too; the ticket form when asked
+        assert f"kas_order_relax_kernel<{RF}>" in plan.describe() and "Context in/out" in plan.describe(), plan.describe()
+        plan.set_flags(TICKET_ORDER)
     assert kernel in plan.describe() and "Context in/out" in plan.describe(), plan.describe()
     plan.close()
     want = oracle_solve(fb, threads=0)
-    got = native.solve_host(fb)
+    got = native.solve_host_with_flags(fb, TICKET_ORDER) if RF <= 3 else native.solve_host(fb)
     assert_same_outputs(fb, want, got, "hip ticket form with a Context")
     assert (got.ctx != fb.ctx).any()
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "hip round form with the same Context")
+    if RF <= 3:
+        for flags, what in ((0, "by batch size"), (TILES_64, "tiles of 64 rows"), (TILES_128, "double tiles")):
+            got = native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
+            assert_same_outputs(fb, want, got, f"hip relaxation form with a Context, {what}")
+            np.testing.assert_array_equal(got.ctx.reshape(-1, 8)[:, RF:], fb.ctx.reshape(-1, 8)[:, RF:])
 
     def big(s, n):
         v = np.random.default_rng(s).integers(0, 200, size=(n, 8))
@@ -350,7 +359,18 @@ def test_ticket_forms_take_a_context_in_and_hand_it_back(P, N, R, RF, kernel):
         if s == 2: v[0, 0] = -1
         return v
     fb = _with_context(_batch(707 + RF, 6, P, N, R, RF, G.BENCH_ACTIONS), big)
-    assert_same_outputs(fb, oracle_solve(fb, threads=0), native.solve_host(fb), "hip ticket form, three scenarios flagged for the round form")
+    want = oracle_solve(fb, threads=0)
+    assert_same_outputs(fb, want, native.solve_host(fb), "hip, three scenarios flagged for the round form")
+    if RF <= 3:
+        assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip ticket form, three scenarios flagged for the round form")
+
+        def big12(s, n):                                                 # the relaxation form's 12-bit fields
+            v = np.random.default_rng(s).integers(0, 200, size=(n, 8))
+            if s in (0, 3): v[n // 3, s % 2] = 4095 - 20                 # + the rows to come: over
+            if s == 5: v[7, 2] = 1 << 29                                 # column 2 is no field: stays in the relaxation form
+            return v
+        fb = _with_context(_batch(808 + RF, 6, P, N, R, RF, G.BENCH_ACTIONS), big12)
+        assert_same_outputs(fb, oracle_solve(fb, threads=0), native.solve_host(fb), "hip relaxation form, two scenarios flagged for the round form")
 
 
 def test_wide_lists_a_broker_holding_1023_rows_or_more_keeps_the_wide_ticket_form_and_its_counts_are_checked():
