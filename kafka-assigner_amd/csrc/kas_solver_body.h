@@ -1155,22 +1155,22 @@ KAS_DEV void pick_row(const int32_t (&c)[W][W], int32_t Lp, bool valid, const in
   for (int r = 0; r < W; ++r) {
     const int32_t m = __builtin_popcount(alive);
     const int32_t idx = sel<W + 1>(idxm, m);
-    int32_t keys[W];
-    int32_t best = 0x7fffffff;
+    // 64-bit keys: the counters are Java ints handed in with the Context — any value (count << 3 would wrap from 2^28)
+    int64_t keys[W];
+    int64_t best = 0x7fffffffffffffffll;
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       int32_t rr = __builtin_popcount(alive & ((1u << k) - 1u)) + idx;
       rr -= rr >= m ? m : 0;
-      // arithmetic form of "alive bit k ? (count << 3 | rr) : INT_MAX" (no exec branches)
-      const int32_t dead = (int32_t)((((alive >> k) & 1u) - 1u) & 0x7fffffffu);
-      keys[k] = ((c[k][r] << 3) | rr) | dead;
+      // "alive bit k ? (count << 3 | rr) : INT64_MAX"
+      keys[k] = ((alive >> k) & 1u) ? (((int64_t)c[k][r] << 3) | (int64_t)rr) : 0x7fffffffffffffffll;
       best = keys[k] < best ? keys[k] : best;
     }
     int32_t ps = 0;
 #pragma unroll
     for (int k = 1; k < W; ++k) ps = keys[k] == best ? k : ps;
     pos[r] = ps;
-    cnt_r[r] = best >> 3;
+    cnt_r[r] = (int32_t)(best >> 3);
     alive &= ~(1u << ps);                                // nodeSet.remove (KAS:232)
   }
 }

@@ -29,6 +29,26 @@ else:
         return native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
 
 
+def with_context(fb, rng):
+    """Every scenario of a single-topic batch hands a Context in and wants it back: a random width (narrower and wider
+    than the lists), counters as earlier topics would have left them — now and then one that leaves the relaxation
+    form's 12-bit fields or the ticket form's 16, or is negative: that scenario must go to the round form."""
+    scen = fb.scen.copy()
+    width = int(rng.choice([1, 2, 3, 4, 8]))
+    ctx, off = [], 0
+    for s in range(fb.n_scenarios):
+        n = int(scen["n_nodes"][s])
+        tab = rng.integers(0, int(rng.choice([1, 50, 400, 3000])), size=(n, width)).astype(np.int32)
+        roll = rng.random()
+        if roll < 0.15: tab[int(rng.integers(n)), int(rng.integers(width))] = int(rng.choice([4090, 5000, 65535, 70000, 1 << 29]))
+        elif roll < 0.2: tab[int(rng.integers(n)), 0] = -int(rng.integers(1, 9))
+        scen["ctx_width"][s] = width
+        scen["ctx_off"][s] = off
+        ctx.append(tab.reshape(-1)); off += n * width
+    return FlatBatch(scen=scen, topics=fb.topics, node_id=fb.node_id, node_rack=fb.node_rack, cur=fb.cur, aux=fb.aux,
+                     ctx=np.concatenate(ctx), out_len=fb.out_len)
+
+
 def thin_wide_batch(rng):
     """Rows 4-5 wide holding 1-2 replicas over 2-4 brokers, 1,023 .. 2,039 rows per broker: the wide ticket form
     with its count fields checked at the end — rf 1 puts every row of a broker at list position 0, so its count
@@ -53,7 +73,7 @@ def thin_wide_batch(rng):
                      out_len=S * P * W), f"thin W{W} rf{rf} N{N} P{P} S{S}"
 
 
-t0 = time.time(); n = 0; q_rows = 0; n_thin = 0; n_big = 0
+t0 = time.time(); n = 0; q_rows = 0; n_thin = 0; n_big = 0; n_ctx = 0
 while time.time() - t0 < float(argv[1]):
     kind = rng.random()
     if kind < 0.12:                                              # the checked wide form and its second solve
@@ -82,6 +102,14 @@ while time.time() - t0 < float(argv[1]):
     seed = int(rng.integers(1 << 30))
     S = int(rng.choice([1, 2, 3, 5, 8]))
     fb = _batch(seed, S, P, N, R, RF, acts)
+    if rng.random() < 0.3:                                       # with the Context the reference's adapter always hands in
+        fb = with_context(fb, rng)
+        want = oracle_solve(fb)
+        for flags in ((0, 1 << 16, 2, 0x20000, 0x40000) if RF <= 3 else (0, 2)):
+            got = solve(fb, flags)
+            assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} Context width {int(fb.scen['ctx_width'][0])} flags {flags}")
+        n += 1; n_ctx += 1
+        continue
     want = oracle_solve(fb)
     # (0 = the relaxation form of the order kernel for lists <= 3 wide, 1 << 12 / 4 = its ticket forms;
     # 32 = KAS_PLAN_SPREAD_FILL: the row scans over one-wavefront workgroups with their slim LDS layouts)
@@ -89,4 +117,4 @@ while time.time() - t0 < float(argv[1]):
         got = solve(fb, flags)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
     n += 1
-print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 1-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-12,000 brokers; seed", int(argv[2]) if len(argv) > 2 else 2026)
+print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 1-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-12,000 brokers,", n_ctx, "with a Context in and out; seed", int(argv[2]) if len(argv) > 2 else 2026)

@@ -487,6 +487,17 @@ def test_emu_context_counters_beyond_the_count_fields_go_to_the_round_form():
         if s == 2: v[3, 0] = -4
         if s == 3: v[5, 2] = 1 << 30                                    # column 2 is not a field: stays
         return v
+    # (1 << 30 in a counter the round form compares: its pick keys are 64 bits wide — round 4's random stress found the
+    # 32-bit `count << 3` of earlier rounds wrapping from 2^28 on)
+    def huge(s, n):
+        v = np.random.default_rng(s).integers(0, 50, size=(n, 8))
+        v[n // 2, s % 3] = (1 << 29) + s
+        if s == 1: v[2, 1] = (1 << 30) + 5
+        return v
+    fbh = _with_context(_batch(517, 4, 900, 40, 8, 3, G.BENCH_ACTIONS), huge)
+    wanth = oracle_solve(fbh)
+    for flags in (0, TICKET_ORDER, 2):
+        assert_same_outputs(fbh, wanth, emu_solve(fbh, flags=flags), f"emu Context counters of 2^29 and 2^30, flags {flags:#x}")
     fb12 = _with_context(_batch(515, 4, 2000, 50, 10, 3, G.BENCH_ACTIONS), big12)
     want12 = oracle_solve(fb12)
     got = emu_solve(fb12)
