@@ -291,8 +291,14 @@ struct kas_ctx {
   hipStream_t stream;
   hipStream_t hstream[KAS_HOST_STREAMS];   // the host path's chains (upload -> solve -> download of a scenario range)
   hipEvent_t hevent;                       // "shared pools are up" of the current host call
+  // a call cut into scenario ranges: every upload on one stream, every download on another (copies of one direction
+  // queue behind each other anyway, and the two directions only run at the same time when no stream carries both),
+  // the solves on hstream[]; events hand a range from upload to solve to download
+  hipStream_t hup, hdown;
+  hipEvent_t hev_up[KAS_HOST_STREAMS], hev_done[KAS_HOST_STREAMS];
   std::mutex host_mu;                   // kas_solve_host calls on one context are serialised
   KasBuf h_cur, h_out, h_aux, h_ctx, h_tr, h_sr;
+  KasBuf h_tr_pin, h_sr_pin;            // pinned HOST staging of the result records (see kas_solve_host_locked)
   KasCachedPlan plans[KAS_HOST_PLAN_CACHE];
   uint64_t use_clock = 0;
   uint64_t host_calls = 0, host_plan_hits = 0, host_allocs = 0;
@@ -392,12 +398,31 @@ int kas_ctx_create(int device, kas_ctx** out_ctx) {
                                     ", the kernels are built for gfx950 only");
   kas_ctx* c = new kas_ctx();
   c->device = device;
-  c->stream = nullptr; c->hevent = nullptr;
+  c->stream = nullptr; c->hevent = nullptr; c->hup = nullptr; c->hdown = nullptr;
   for (hipStream_t& h : c->hstream) h = nullptr;
+  for (hipEvent_t& ev : c->hev_up) ev = nullptr;
+  for (hipEvent_t& ev : c->hev_done) ev = nullptr;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  // The host path's streams each get a hardware queue of their own: the runtime maps ordinary streams onto a pool of
+  // GPU_MAX_HW_QUEUES (default 4) queues, and ten streams sharing four queues made the upload of one scenario range
+  // wait behind the kernels of another (a copy trace of the plain path: uploads in bursts of three, 13.5 ms per call
+  // against 9.6 ms with 16 queues).  A stream created with a CU mask is not pooled — the mask is a property of the
+  // queue — and the mask here is every CU.
+  auto own_queue_stream = [&](hipStream_t* st) {
+    const int words = (prop.multiProcessorCount + 31) / 32;
+    std::vector<uint32_t> all((size_t)words, 0xffffffffu);
+    if (prop.multiProcessorCount % 32) all[(size_t)words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, all.data()) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  };
   for (hipStream_t& h : c->hstream)
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h, hipStreamNonBlocking);
+    if (e == hipSuccess) e = own_queue_stream(&h);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->hevent, hipEventDisableTiming);
+  if (e == hipSuccess) e = own_queue_stream(&c->hup);
+  if (e == hipSuccess) e = own_queue_stream(&c->hdown);
+  for (hipEvent_t& ev : c->hev_up) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  for (hipEvent_t& ev : c->hev_done) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e != hipSuccess) {
     kas_ctx_destroy(c);
     return set_error(KAS_E_HIP, hipGetErrorString(e));
@@ -426,9 +451,16 @@ void kas_ctx_destroy(kas_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t h : ctx->hstream) if (h) (void)hipStreamSynchronize(h);
+  if (ctx->hup) (void)hipStreamSynchronize(ctx->hup);
+  if (ctx->hdown) (void)hipStreamSynchronize(ctx->hdown);
   for (KasCachedPlan& c : ctx->plans) if (c.plan) kas_plan_destroy(c.plan);
   for (KasBuf* b : {&ctx->h_cur, &ctx->h_out, &ctx->h_aux, &ctx->h_ctx, &ctx->h_tr, &ctx->h_sr}) kas_buf_free(b);
+  for (KasBuf* b : {&ctx->h_tr_pin, &ctx->h_sr_pin}) { if (b->p) (void)hipHostFree(b->p); b->p = nullptr; b->cap = 0; }
   if (ctx->hevent) (void)hipEventDestroy(ctx->hevent);
+  for (hipEvent_t ev : ctx->hev_up) if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->hev_done) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->hup) (void)hipStreamDestroy(ctx->hup);
+  if (ctx->hdown) (void)hipStreamDestroy(ctx->hdown);
   for (hipStream_t h : ctx->hstream) if (h) (void)hipStreamDestroy(h);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1045,6 +1077,18 @@ static int kas_host_buf(kas_ctx* ctx, KasBuf* b, size_t bytes) {
   return kas_buf_reserve(b, bytes + bytes / 4 + 256, &ctx->host_allocs, "host-path buffer");
 }
 
+// grow-only pinned host buffer of the host path
+static int kas_host_pinned(kas_ctx* ctx, KasBuf* b, size_t bytes) {
+  if (bytes <= b->cap) return KAS_E_OK;
+  if (b->p) (void)hipHostFree(b->p);
+  b->p = nullptr; b->cap = 0;
+  const size_t want = bytes + bytes / 4 + 256;
+  if (hipHostMalloc(&b->p, want, hipHostMallocDefault) != hipSuccess) { b->p = nullptr; return set_error(KAS_E_NOMEM, "hipHostMalloc failed (host-path record staging)"); }
+  b->cap = want;
+  ctx->host_allocs += 1;
+  return KAS_E_OK;
+}
+
 // one scenario range of a host call: its slice of the batch, its plan, what it moves
 struct KasChain {
   int64_t lo = 0, hi = 0;                       // scenarios
@@ -1107,6 +1151,14 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   if ((rc = kas_host_buf(ctx, &ctx->h_ctx, sizeof(int32_t) * (size_t)(full.ctx_need - full.ctx_lo + 8))) != KAS_E_OK) return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_tr, sizeof(kas_topic_result) * (size_t)(T + 1))) != KAS_E_OK) return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_sr, sizeof(kas_scenario_result) * (size_t)(S + 1))) != KAS_E_OK) return rc;
+  // The result records come back through pinned staging of the context's own: the caller's record arrays are ordinary
+  // (pageable) memory even when its bulk tables are pinned, and a copy to pageable memory blocks the issuing thread
+  // until the stream gets there — every range's records would hold the next range's upload back until its own solve
+  // has finished (a memory-copy trace of the plain path showed exactly that: uploads 2-3 ms apart).
+  if ((rc = kas_host_pinned(ctx, &ctx->h_tr_pin, sizeof(kas_topic_result) * (size_t)(T + 1))) != KAS_E_OK) return rc;
+  if ((rc = kas_host_pinned(ctx, &ctx->h_sr_pin, sizeof(kas_scenario_result) * (size_t)(S + 1))) != KAS_E_OK) return rc;
+  kas_topic_result* p_tr = (kas_topic_result*)ctx->h_tr_pin.p;
+  kas_scenario_result* p_sr = (kas_scenario_result*)ctx->h_sr_pin.p;
   int32_t* d_cur = (int32_t*)ctx->h_cur.p - full.cur_lo;
   int32_t* d_out = (int32_t*)ctx->h_out.p - full.out_lo;
   int32_t* d_aux = (int32_t*)ctx->h_aux.p - full.aux_lo;
@@ -1165,31 +1217,40 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   };
   // every stream is drained whatever happened; an error that only surfaces at a synchronisation (a kernel fault, a
   // failed copy) is the call's error: the caller must never read out / ctx / records of a solve that did not finish
-  auto drain = [&]() { for (hipStream_t st : ctx->hstream) hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"); };
-  // pools every range reads (aux, Context) go up first; the other streams wait for them
+  auto drain = [&]() {
+    for (hipStream_t st : ctx->hstream) hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+    hip_ok(hipStreamSynchronize(ctx->hup), "hipStreamSynchronize");
+    hip_ok(hipStreamSynchronize(ctx->hdown), "hipStreamSynchronize");
+  };
+  static_assert(KAS_HOST_SPLIT_MAX <= KAS_HOST_STREAMS, "one event pair per scenario range");
+  // one range: everything on s0.  Several: uploads on hup, solves on hstream[i], downloads on hdown.
+  hipStream_t s_up = K > 1 ? ctx->hup : s0, s_down = K > 1 ? ctx->hdown : s0;
+  // pools every range reads (aux, Context) go up first (the ranges' own uploads queue behind them on the same stream)
   if (full.aux_need > full.aux_lo)
-    hip_ok(hipMemcpyAsync(d_aux + full.aux_lo, h->aux + full.aux_lo, 4 * (size_t)(full.aux_need - full.aux_lo), hipMemcpyHostToDevice, s0), "upload aux");
+    hip_ok(hipMemcpyAsync(d_aux + full.aux_lo, h->aux + full.aux_lo, 4 * (size_t)(full.aux_need - full.aux_lo), hipMemcpyHostToDevice, s_up), "upload aux");
   if (full.ctx_need > full.ctx_lo)
-    hip_ok(hipMemcpyAsync(d_ctx + full.ctx_lo, h->ctx + full.ctx_lo, 4 * (size_t)(full.ctx_need - full.ctx_lo), hipMemcpyHostToDevice, s0), "upload ctx");
-  if (K > 1 && he == hipSuccess) {
-    hip_ok(hipEventRecord(ctx->hevent, s0), "record");
-    for (int k = 1; k < KAS_HOST_STREAMS; ++k) hip_ok(hipStreamWaitEvent(ctx->hstream[k], ctx->hevent, 0), "wait");
-  }
-  auto download = [&](const KasChain& c, hipStream_t st) {
+    hip_ok(hipMemcpyAsync(d_ctx + full.ctx_lo, h->ctx + full.ctx_lo, 4 * (size_t)(full.ctx_need - full.ctx_lo), hipMemcpyHostToDevice, s_up), "upload ctx");
+  auto download = [&](int i) {
+    const KasChain& c = chains[(size_t)i];
+    if (K > 1) hip_ok(hipStreamWaitEvent(s_down, ctx->hev_done[i], 0), "wait");
     if (all_rows && c.out_hi > c.out_lo)
-      hip_ok(hipMemcpyAsync(h->out + c.out_lo, d_out + c.out_lo, 4 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, st), "download out");
+      hip_ok(hipMemcpyAsync(h->out + c.out_lo, d_out + c.out_lo, 4 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, s_down), "download out");
     if (c.thi > c.tlo)
-      hip_ok(hipMemcpyAsync(h->topic_results + c.tlo, d_tr + c.tlo, sizeof(kas_topic_result) * (size_t)(c.thi - c.tlo), hipMemcpyDeviceToHost, st), "download topic results");
+      hip_ok(hipMemcpyAsync(p_tr + c.tlo, d_tr + c.tlo, sizeof(kas_topic_result) * (size_t)(c.thi - c.tlo), hipMemcpyDeviceToHost, s_down), "download topic results");
     if (c.hi > c.lo)
-      hip_ok(hipMemcpyAsync(h->scenario_results + c.lo, d_sr + c.lo, sizeof(kas_scenario_result) * (size_t)(c.hi - c.lo), hipMemcpyDeviceToHost, st), "download scenario results");
+      hip_ok(hipMemcpyAsync(p_sr + c.lo, d_sr + c.lo, sizeof(kas_scenario_result) * (size_t)(c.hi - c.lo), hipMemcpyDeviceToHost, s_down), "download scenario results");
   };
   // software-pipelined issue order (upload i, solve i, download i - 1): with pageable host memory the
   // copies block the issuing thread, and this order still lets the device overlap them with the solves
   for (int i = 0; i < K && he == hipSuccess && fail_rc == KAS_E_OK; ++i) {
     KasChain& c = chains[(size_t)i];
-    hipStream_t st = ctx->hstream[i % KAS_HOST_STREAMS];
+    hipStream_t st = K > 1 ? ctx->hstream[i % KAS_HOST_STREAMS] : s0;
     if (c.cur_hi > c.cur_lo)
-      hip_ok(hipMemcpyAsync(d_cur + c.cur_lo, h->cur + c.cur_lo, 4 * (size_t)(c.cur_hi - c.cur_lo), hipMemcpyHostToDevice, st), "upload cur");
+      hip_ok(hipMemcpyAsync(d_cur + c.cur_lo, h->cur + c.cur_lo, 4 * (size_t)(c.cur_hi - c.cur_lo), hipMemcpyHostToDevice, s_up), "upload cur");
+    if (K > 1) {
+      hip_ok(hipEventRecord(ctx->hev_up[i], s_up), "record");
+      hip_ok(hipStreamWaitEvent(st, ctx->hev_up[i], 0), "wait");
+    }
     if (he != hipSuccess) break;
     kas_tables d;
     memset(&d, 0, sizeof(d));
@@ -1197,11 +1258,16 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     d.topic_results = d_tr + c.tlo; d.scenario_results = d_sr + c.lo;
     const int src = kas_solve_device(c.plan, &d, st);
     if (src != KAS_E_OK) { fail_rc = src; break; }
-    if (i > 0) download(chains[(size_t)i - 1], ctx->hstream[(i - 1) % KAS_HOST_STREAMS]);
+    if (K > 1) hip_ok(hipEventRecord(ctx->hev_done[i], st), "record");
+    if (i > 0) download(i - 1);
   }
-  if (he == hipSuccess && fail_rc == KAS_E_OK) download(chains[(size_t)K - 1], ctx->hstream[(K - 1) % KAS_HOST_STREAMS]);
+  if (he == hipSuccess && fail_rc == KAS_E_OK) download(K - 1);
   drain();
   if (he != hipSuccess || fail_rc != KAS_E_OK) return fail_rc != KAS_E_OK ? fail_rc : KAS_E_HIP;
+  for (const KasChain& c : chains) {                           // (only what the ranges own: as the direct copies did)
+    if (c.thi > c.tlo) memcpy(h->topic_results + c.tlo, p_tr + c.tlo, sizeof(kas_topic_result) * (size_t)(c.thi - c.tlo));
+    if (c.hi > c.lo) memcpy(h->scenario_results + c.lo, p_sr + c.lo, sizeof(kas_scenario_result) * (size_t)(c.hi - c.lo));
+  }
   // Context counters back; the selected scenarios' rows, packed
   if (full.ctx_need > full.ctx_lo)
     hip_ok(hipMemcpyAsync(h->ctx + full.ctx_lo, d_ctx + full.ctx_lo, 4 * (size_t)(full.ctx_need - full.ctx_lo), hipMemcpyDeviceToHost, s0), "download ctx");
