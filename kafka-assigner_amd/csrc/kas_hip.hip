@@ -1240,8 +1240,11 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     if (c.hi > c.lo)
       hip_ok(hipMemcpyAsync(p_sr + c.lo, d_sr + c.lo, sizeof(kas_scenario_result) * (size_t)(c.hi - c.lo), hipMemcpyDeviceToHost, s_down), "download scenario results");
   };
-  // software-pipelined issue order (upload i, solve i, download i - 1): with pageable host memory the
-  // copies block the issuing thread, and this order still lets the device overlap them with the solves
+  // software-pipelined issue order (upload i, solve i, download i - 2): with pageable host memory the copies block
+  // the issuing thread, and this order still lets the device overlap them with the solves.  (A range's solve takes
+  // about as long as three uploads: behind upload i the solve of range i - 1 is still running, that of i - 2 is done —
+  // a lag of one made the thread wait ~1 ms per range: 15.6 ms per call of eight ranges.)
+  const int lag = K >= 3 ? 2 : 1;
   for (int i = 0; i < K && he == hipSuccess && fail_rc == KAS_E_OK; ++i) {
     KasChain& c = chains[(size_t)i];
     hipStream_t st = K > 1 ? ctx->hstream[i % KAS_HOST_STREAMS] : s0;
@@ -1259,9 +1262,9 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     const int src = kas_solve_device(c.plan, &d, st);
     if (src != KAS_E_OK) { fail_rc = src; break; }
     if (K > 1) hip_ok(hipEventRecord(ctx->hev_done[i], st), "record");
-    if (i > 0) download(i - 1);
+    if (i >= lag) download(i - lag);
   }
-  if (he == hipSuccess && fail_rc == KAS_E_OK) download(K - 1);
+  for (int i = K - lag < 0 ? 0 : K - lag; i < K && he == hipSuccess && fail_rc == KAS_E_OK; ++i) download(i);
   drain();
   if (he != hipSuccess || fail_rc != KAS_E_OK) return fail_rc != KAS_E_OK ? fail_rc : KAS_E_HIP;
   for (const KasChain& c : chains) {                           // (only what the ranges own: as the direct copies did)
