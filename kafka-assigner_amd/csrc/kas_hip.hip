@@ -403,24 +403,10 @@ int kas_ctx_create(int device, kas_ctx** out_ctx) {
   for (hipEvent_t& ev : c->hev_up) ev = nullptr;
   for (hipEvent_t& ev : c->hev_done) ev = nullptr;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  // The host path's streams each get a hardware queue of their own: the runtime maps ordinary streams onto a pool of
-  // GPU_MAX_HW_QUEUES (default 4) queues, and ten streams sharing four queues made the upload of one scenario range
-  // wait behind the kernels of another (a copy trace of the plain path: uploads in bursts of three, 13.5 ms per call
-  // against 9.6 ms with 16 queues).  A stream created with a CU mask is not pooled — the mask is a property of the
-  // queue — and the mask here is every CU.
-  auto own_queue_stream = [&](hipStream_t* st) {
-    const int words = (prop.multiProcessorCount + 31) / 32;
-    std::vector<uint32_t> all((size_t)words, 0xffffffffu);
-    if (prop.multiProcessorCount % 32) all[(size_t)words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
-    if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, all.data()) == hipSuccess) return hipSuccess;
-    (void)hipGetLastError();
-    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-  };
   for (hipStream_t& h : c->hstream)
-    if (e == hipSuccess) e = own_queue_stream(&h);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->hevent, hipEventDisableTiming);
-  if (e == hipSuccess) e = own_queue_stream(&c->hup);
-  if (e == hipSuccess) e = own_queue_stream(&c->hdown);
+  // (hup / hdown: made by the first host call that is cut into ranges, kas_host_copy_streams)
   for (hipEvent_t& ev : c->hev_up) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   for (hipEvent_t& ev : c->hev_done) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -1099,6 +1085,31 @@ struct KasChain {
   int64_t cur_lo = 0, cur_hi = 0, out_lo = 0, out_hi = 0;
 };
 
+// The two copy streams of a host call that is cut into scenario ranges, made on first use.  They get hardware queues
+// of their own: the runtime maps ordinary streams onto a pool of GPU_MAX_HW_QUEUES (default 4) queues, and an upload
+// that shares a queue with the solve of another range waits behind its kernels (a copy trace of the plain path:
+// uploads in bursts of three).  A stream created with a CU mask is not pooled — the mask is a property of the queue —
+// and the mask here is every CU.  Only these two: a process that holds dozens of queues is time-sliced by the
+// hardware scheduler (every stream of the host path on a queue of its own, two contexts alive: configs[4]'s 35 ms
+// chain kernel ran 13 % slower, configs[3]'s share fell from 590k to 341k scenarios/s).
+static int kas_host_copy_streams(kas_ctx* c) {
+  if (c->hup && c->hdown) return KAS_E_OK;
+  hipDeviceProp_t prop;
+  KAS_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+  const int words = (prop.multiProcessorCount + 31) / 32;
+  std::vector<uint32_t> all((size_t)words, 0xffffffffu);
+  if (prop.multiProcessorCount % 32) all[(size_t)words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+  for (hipStream_t* st : {&c->hup, &c->hdown}) {
+    if (*st) continue;
+    if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, all.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      *st = nullptr;
+      KAS_HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    }
+  }
+  return KAS_E_OK;
+}
+
 #define KAS_HOST_SPLIT_MIN_BYTES (48ll << 20)   // tables smaller than this are moved and solved as one range
 #define KAS_HOST_SPLIT_MAX 8
 
@@ -1217,10 +1228,11 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   };
   // every stream is drained whatever happened; an error that only surfaces at a synchronisation (a kernel fault, a
   // failed copy) is the call's error: the caller must never read out / ctx / records of a solve that did not finish
+  if (K > 1 && (rc = kas_host_copy_streams(ctx)) != KAS_E_OK) return rc;
   auto drain = [&]() {
     for (hipStream_t st : ctx->hstream) hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
-    hip_ok(hipStreamSynchronize(ctx->hup), "hipStreamSynchronize");
-    hip_ok(hipStreamSynchronize(ctx->hdown), "hipStreamSynchronize");
+    if (ctx->hup) hip_ok(hipStreamSynchronize(ctx->hup), "hipStreamSynchronize");
+    if (ctx->hdown) hip_ok(hipStreamSynchronize(ctx->hdown), "hipStreamSynchronize");
   };
   static_assert(KAS_HOST_SPLIT_MAX <= KAS_HOST_STREAMS, "one event pair per scenario range");
   // one range: everything on s0.  Several: uploads on hup, solves on hstream[i], downloads on hdown.

@@ -26,11 +26,21 @@ L = native.load()
 ctx = native.DeviceContext(0)
 bd = batch_desc(fb)
 t, ho = host_tables(fb)
-if mode == "pinned":
+def calls(what, t):
+    for i in range(4):
+        t0 = time.perf_counter()
+        native._check(L.kas_solve_host(ctx._h, C.byref(bd), C.byref(t)))
+        print("%s call %d: %.2f ms" % (what, i, 1e3 * (time.perf_counter() - t0)), flush=True)
+
+
+if mode in ("pageable", "both"):
+    calls("pageable", t)
+if mode in ("pinned", "both"):
+    if "torch" in sys.argv:
+        import torch
+        x = torch.zeros(1 << 20, device="cuda"); torch.cuda.synchronize()
     pc, po = native.PinnedArray(fb.cur.size), native.PinnedArray(fb.out_len)
     pc.array[:] = fb.cur
-    t.cur = pc.array.ctypes.data; t.out = po.array.ctypes.data
-for i in range(4):
-    t0 = time.perf_counter()
-    native._check(L.kas_solve_host(ctx._h, C.byref(bd), C.byref(t)))
-    print("call %d: %.2f ms" % (i, 1e3 * (time.perf_counter() - t0)), flush=True)
+    t2, ho2 = host_tables(fb)
+    t2.cur = pc.array.ctypes.data; t2.out = po.array.ctypes.data
+    calls("pinned", t2)
