@@ -837,6 +837,41 @@ def end_to_end_leg(args, run):
                      f"pinned = caller buffers from kas_host_alloc (DMA without staging)")
     res["plain_every_scenario_its_own_tables"] = plain
     pin_cur.close(); pin_out.close()
+    # (c) the call the reference's adapter makes (KTA:70-71): ONE topic, its Context handed in and wanted back, host
+    # buffers in and out, blocking — BASELINE configs[1]'s topic (10k partitions x 100 brokers x RF 3, decommission 1)
+    import dataclasses
+    from kafka_assigner_amd.flatten import uniform_batch
+    cur1 = G.random_assignment(0, 10000, 100, 10, 3)
+    bs1 = G.perturb_brokers(100, 10, remove=[0])
+    fb1 = uniform_batch(cur1[None], bs1.node_id[None], bs1.node_rack[None], 3)
+    scen1 = fb1.scen.copy(); scen1["ctx_width"] = 3; scen1["ctx_off"] = 0
+    ctx_in = np.random.default_rng(1).integers(0, 300, size=int(fb1.scen["n_nodes"][0]) * 3).astype(np.int32)
+    fb1 = dataclasses.replace(fb1, scen=scen1, ctx=ctx_in)
+    bd1 = batch_desc(fb1)
+    t1, ho1 = host_tables(fb1)
+    native._check(L.kas_solve_host(ctx._h, C.byref(bd1), C.byref(t1)))
+    want1 = cpu_fast_solve(fb1, threads=1)
+    assert (ho1.out[:fb1.out_len] == want1.out[:fb1.out_len]).all() and (ho1.ctx == want1.ctx).all(), \
+        "end_to_end per-topic call: differs from the CPU solver"
+    n1 = 200
+    t0 = time.perf_counter()
+    for _ in range(n1):
+        ho1.ctx[:] = ctx_in                                             # every call starts from the same Context
+        native._check(L.kas_solve_host(ctx._h, C.byref(bd1), C.byref(t1)))
+    per_call = (time.perf_counter() - t0) / n1
+    tc = []
+    for _ in range(9):
+        t0 = time.perf_counter(); cpu_fast_solve(fb1, threads=1); tc.append(time.perf_counter() - t0)
+    to = []
+    for _ in range(5):
+        t0 = time.perf_counter(); oracle_solve(fb1); to.append(time.perf_counter() - t0)
+    res["per_topic_call_with_context"] = {
+        "what": "kas_solve_host, one 10k x 100 x RF 3 topic with the adapter's Context in and out (120 KB up, 120 KB down), "
+                "blocking: the drop-in for one getRackAwareAssignment call",
+        "gpu_ms_per_call": 1e3 * per_call,
+        "cpu_fast_one_core_ms": 1e3 * sorted(tc)[len(tc) // 2],
+        "oracle_one_core_ms": 1e3 * sorted(to)[len(to) // 2],
+    }
     ctx.close()
     return res
 
