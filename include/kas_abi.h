@@ -317,6 +317,9 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_RELAX_TILES(n) relaxation form: 1 = tiles of 64 rows, 2 = double tiles (128 rows, two rows per lane: fewer
  *                          LDS round trips per scenario, more LDS operations per row), 0 = by batch size (double
  *                          tiles for batches of fewer than 512 scenarios, where the GPU is not full of wavefronts)
+ *   KAS_PLAN_NO_RTN_QUOTA  rack-diverse fill with per-chunk histograms: draw a node's quota with separate LDS atomics,
+ *                          reads and a ranking of the tiles in which it runs out, instead of one atomic-with-return
+ *                          per list position
  *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup of the fill kernel: 1, 2 or 4
  *   KAS_PLAN_GROUPS(n)     scenarios per wavefront of the ticket-form order kernel: 1, 2 or 4
  *                          (0 = the plan's choice for either) */
@@ -327,6 +330,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_SPREAD_FILL  32u
 #define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_RELAX_TILES(n) (((uint32_t)(n) & 3u) << 17)
+#define KAS_PLAN_NO_RTN_QUOTA 0x200000u
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
 #define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);

@@ -35,6 +35,7 @@ KAS_PLAN_SPREAD_FILL = 32
 KAS_PLAN_TICKET_ORDER = 0x10000
 KAS_PLAN_RELAX_TILES_64 = 0x20000     # KAS_PLAN_RELAX_TILES(1)
 KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)
+KAS_PLAN_NO_RTN_QUOTA = 0x200000
 
 STATUS_NAMES = {
     KAS_OK: "OK",

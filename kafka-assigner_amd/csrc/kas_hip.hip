@@ -720,7 +720,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.idmap_entries = p->shape.idmap_entries; a.need_bsearch = p->shape.need_bsearch;
   a.flags = (p->flags & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ORDER_FLAGGED | KAS_FLAG_WIDE_CHECK)) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
             (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u) |
-            (kas_relax_double_tiles(p->flags, p->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u);
+            (kas_relax_double_tiles(p->flags, p->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
+            ((p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA)) ? KAS_FLAG_LANE_ORDER : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
   const int slot = p->timer_next;
@@ -867,7 +868,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   if (rc != KAS_E_OK) return rc;
   if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_RELAX_TILES: 0 (by batch size), 1 (64 rows) or 2 (double tiles)");
-  p->flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
+  p->flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
   // plan may still be in flight on the old scratch

@@ -65,6 +65,8 @@ struct KasLaunch {
 #define KAS_FLAG_RELAX_TILES_64  0x20000u // relaxation form: tiles of 64 rows whatever the batch size (KAS_PLAN_RELAX_TILES(1))
 #define KAS_FLAG_RELAX_TILES_128 0x40000u // relaxation form: double tiles whatever the batch size (KAS_PLAN_RELAX_TILES(2))
 #define KAS_FLAG_RELAX_DUAL      0x80000u // set by the launcher (kas_relax_double_tiles): double tiles in this launch
+#define KAS_FLAG_LANE_ORDER      0x100000u // set by the launcher: the LDS hands the lanes of one atomic instruction out in lane order here (self-test)
+#define KAS_FLAG_NO_RTN_QUOTA    0x200000u // KAS_PLAN_NO_RTN_QUOTA: the fill draws its quota without the atomic-with-return (testing / comparison)
 #define KAS_RELAX_DUAL_BELOW 512         // batches of fewer scenarios than this take double tiles unless told otherwise
 
 // Byte offsets into the dynamic LDS of the fill kernel.

@@ -891,7 +891,12 @@ KAS_DEV void fill_chunk_prefix(const LdsView& L, const TopicView& T, int32_t tid
 
 // B + P3 over chunk `wave`; orphans go to the chunk's list; returns the number of orphans
 // (FUSED: the quota words are x[n * BW + wave] of the node-major layout, else x[wave * N + n])
-template <int W, bool DIRECT, int QS>
+// RTN: the quota is drawn with one LDS atomic-with-return per list position — a node only ever counts at its own
+// position r*, so all its draws of a tile are lanes of ONE instruction, served in ascending lane = row order
+// (kas_wave.h, lds_add_rtn_u32; the launcher sets KAS_FLAG_LANE_ORDER where kas_ctx_create's self-test saw that order):
+// what comes back is the quota left for exactly this row, no read before, no read after, no ranking of a tile in
+// which a quota runs out.
+template <int W, bool DIRECT, int QS, bool RTN = false>
 KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t t0, int32_t t1,
                                   int32_t* qc, int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();
@@ -908,10 +913,21 @@ KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const No
       const int32_t rs = (int32_t)((uint32_t)lds_qrs(L, nn[r]) >> 28);
       sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
       counting |= (idx[r] >= 0 && r == rs) ? (1u << r) : 0u;
-      before[r] = qc[nn[r] * QS];                           // quota left before this tile
+      if constexpr (!RTN) before[r] = qc[nn[r] * QS];         // quota left before this tile
     }
     uint32_t accbits = sure;
-    if (kasw::ballot(counting != 0u) != 0) {
+    if constexpr (RTN) {
+      if (kasw::ballot(counting != 0u) != 0) {
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+          kasw::lockstep();
+          int32_t left = 0;                                    // (only the drawing lanes execute the add)
+          if ((counting >> r) & 1u) left = (int32_t)kasw::lds_add_rtn_u32((uint32_t*)&qc[nn[r] * QS], 0xffffffffu);
+          accbits |= (((counting >> r) & 1u) && left > 0) ? (1u << r) : 0u;
+        }
+        kasw::lockstep();
+      }
+    } else if (kasw::ballot(counting != 0u) != 0) {
       kasw::lockstep();                                     // every lane saw the pre-tile quota
 #pragma unroll
       for (int r = 0; r < W; ++r) if ((counting >> r) & 1u) kasw::lds_atomic_add(&qc[nn[r] * QS], -1);
@@ -955,13 +971,13 @@ KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const No
   });
   return ocount;
 }
-template <int W, int NW, bool DIRECT, bool FUSED = false>
+template <int W, int NW, bool DIRECT, bool FUSED = false, bool RTN = false>
 KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave,
                             int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
   const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
   constexpr int QS = FUSED ? fused_block_words<W, NW>() : 1;     // stride of a node's quota word
   int32_t* qc = FUSED ? L.x + wave : L.x + wave * T.N;
-  return fill_pass_b_range<W, DIRECT, QS>(L, T, nm, t0, t1, qc, moved_r, moved_p, st);
+  return fill_pass_b_range<W, DIRECT, QS, RTN>(L, T, nm, t0, t1, qc, moved_r, moved_p, st);
 }
 
 
@@ -1300,8 +1316,12 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
         fill_quota_fused<W, NW>(L, T, tid);
         kasw::sync();
         { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
-        oc = nm.range != 0u ? fill_pass_b<W, NW, true, true>(L, T, nm, wave, moved_r, moved_p, st)
-                            : fill_pass_b<W, NW, false, true>(L, T, nm, wave, moved_r, moved_p, st);
+        if (a.flags & KAS_FLAG_LANE_ORDER)                     // (workgroup-uniform)
+          oc = nm.range != 0u ? fill_pass_b<W, NW, true, true, true>(L, T, nm, wave, moved_r, moved_p, st)
+                              : fill_pass_b<W, NW, false, true, true>(L, T, nm, wave, moved_r, moved_p, st);
+        else
+          oc = nm.range != 0u ? fill_pass_b<W, NW, true, true>(L, T, nm, wave, moved_r, moved_p, st)
+                              : fill_pass_b<W, NW, false, true>(L, T, nm, wave, moved_r, moved_p, st);
         done = true;
       }
     }

@@ -113,7 +113,7 @@ while time.time() - t0 < float(argv[1]):
     want = oracle_solve(fb)
     # (0 = the relaxation form of the order kernel for lists <= 3 wide, 1 << 12 / 4 = its ticket forms;
     # 32 = KAS_PLAN_SPREAD_FILL: the row scans over one-wavefront workgroups with their slim LDS layouts)
-    for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000) if RF <= 3 else (0, 2, 1, 32)):
+    for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000, 0x200000) if RF <= 3 else (0, 2, 1, 32)):
         got = solve(fb, flags)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
     n += 1

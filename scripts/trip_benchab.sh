@@ -6,7 +6,7 @@ O=gpurun_out/$1; shift; mkdir -p $O
 for round in 1 2; do
   for lib in "$@"; do
     b=$(basename $lib .so)
-    KAS_HIP_LIB=$lib timeout 300 python bench.py $BENCH_ARGS --no-cpu --check 0 --no-extras --repeats 3 --steps 20 --warmup 5 > $O/bench_${b}_$round.log 2>&1
+    KAS_HIP_LIB=$lib timeout 300 python bench.py $BENCH_ARGS --no-cpu --check ${BENCH_CHECK:-0} --no-extras --repeats 3 --steps 20 --warmup 5 > $O/bench_${b}_$round.log 2>&1
     python - $O/bench_${b}_$round.log $b <<'PY'
 import json, sys
 for l in open(sys.argv[1]):

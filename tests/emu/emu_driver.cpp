@@ -269,7 +269,7 @@ static int g_last_flagged = 0; // scenarios a ticket form left to the round form
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
 // 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice),
 // bit 16 = KAS_FLAG_TICKET_ORDER (the ticket form where the relaxation form would run), bits 17 / 18 = tiles of 64 rows /
-// double tiles in the relaxation form whatever the batch size
+// double tiles in the relaxation form whatever the batch size, bit 21 = KAS_FLAG_NO_RTN_QUOTA
 extern "C" __attribute__((visibility("default")))
 int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen) {
   KasShape sh;
@@ -318,7 +318,8 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.need_bsearch = sh.need_bsearch;
   a.flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128) & ~KAS_FLAG_FUSED_HIST) |
             (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u) |
-            (kas_relax_double_tiles(flags, b->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u);
+            (kas_relax_double_tiles(flags, b->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
+            ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER);
   auto bad = [&](const char* what, int32_t s) {
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;

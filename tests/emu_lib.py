@@ -224,6 +224,7 @@ def last_order_form() -> int:
 TICKET_ORDER = 0x10000     # KAS_PLAN_TICKET_ORDER: the ticket form where the relaxation form would run
 RELAX_TILES_64 = 0x20000   # KAS_PLAN_RELAX_TILES(1): relaxation form over tiles of 64 rows whatever the batch size
 RELAX_TILES_128 = 0x40000  # KAS_PLAN_RELAX_TILES(2): double tiles whatever the batch size
+NO_RTN_QUOTA = 0x200000    # KAS_PLAN_NO_RTN_QUOTA: the fill draws its quota without the atomic-with-return
 
 
 def last_relax_stats():

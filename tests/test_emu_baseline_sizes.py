@@ -47,7 +47,7 @@ def test_emu_config3_full_size_scenarios_every_action_every_plan_variant():
     assert slow <= 2 * 4, ("only the last tile of a topic leaves the straight-line path", slow)
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu C3, ticket form")
     assert last_order_form() == 1 and last_queue_rows() > 1000, "the queue path of the 3-wide solver did not run"
-    for flags, what in ((1, "general fill"), (2, "round form"), (4, "4 x uint16 counter rows"), (8, "chunk-count pass"),
+    for flags, what in ((1, "general fill"), (0x200000, "quota drawn without the atomic-with-return"), (2, "round form"), (4, "4 x uint16 counter rows"), (8, "chunk-count pass"),
                         ((1 << 8) | (1 << 12), "1 fill wave, 1 scenario per wavefront"),
                         ((2 << 8) | (2 << 12), "2 fill waves, 2 scenarios per wavefront")):
         assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu C3 {what}")

@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows
+from emu_lib import NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_oracle_vs_literal import scenarios
@@ -84,6 +84,7 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu relaxation form, tiles of 64 rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_128), "emu relaxation form, double tiles")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=NO_RTN_QUOTA), "emu fill, quota drawn without the atomic-with-return")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
     # every workgroup width, and the round form of the preference ordering
     for nw, g in ((1, 1), (2, 2), (8, 4)):

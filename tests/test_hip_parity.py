@@ -66,6 +66,7 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip ticket form")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip relaxation form, tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_128), "hip relaxation form, double tiles")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "hip fill, quota drawn without the atomic-with-return")
     # the general multi-sweep sticky fill must agree with the rack-diverse histogram/quota form,
     # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
@@ -108,6 +109,7 @@ def test_config3_shape_full_size_scenarios():
     assert_same_outputs(fb, want, got, "C3")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "C3 relaxation form over tiles of 64 rows (what a batch of 1000 takes)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "C3 ticket form")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "C3 quota drawn without the atomic-with-return")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 4), "C3 4 x uint16 counter rows")
