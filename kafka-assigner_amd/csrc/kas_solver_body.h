@@ -908,9 +908,18 @@ KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const No
     uint32_t sure = 0, counting = 0;
 #pragma unroll
     for (int r = 0; r < W; ++r) {
-      idx[r] = r < len ? node_lookup_as<DIRECT>(L, nm, ids[r]) : -1;
+      int32_t rs;
+      if constexpr (RTN && DIRECT) {
+        // (the id table was rewritten behind the quota pass: node index | r* << 14 in one 16-bit word, fill_topic)
+        const uint32_t d = (uint32_t)ids[r] - (uint32_t)nm.min_id;
+        const uint32_t raw = (r < len && d < nm.range) ? (uint32_t)(uint16_t)L.idmap[d] : 0xffffu;
+        idx[r] = raw != 0xffffu ? (int32_t)(raw & 0x3fffu) : -1;
+        rs = (int32_t)(raw >> 14);
+      } else {
+        idx[r] = r < len ? node_lookup_as<DIRECT>(L, nm, ids[r]) : -1;
+        rs = (int32_t)((uint32_t)lds_qrs(L, idx[r] >= 0 ? idx[r] : 0) >> 28);
+      }
       nn[r] = idx[r] >= 0 ? idx[r] : 0;
-      const int32_t rs = (int32_t)((uint32_t)lds_qrs(L, nn[r]) >> 28);
       sure |= (idx[r] >= 0 && r < rs) ? (1u << r) : 0u;
       counting |= (idx[r] >= 0 && r == rs) ? (1u << r) : 0u;
       if constexpr (!RTN) before[r] = qc[nn[r] * QS];         // quota left before this tile
@@ -1316,9 +1325,20 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
         fill_quota_fused<W, NW>(L, T, tid);
         kasw::sync();
         { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
-        if (a.flags & KAS_FLAG_LANE_ORDER)                     // (workgroup-uniform)
-          oc = nm.range != 0u ? fill_pass_b<W, NW, true, true, true>(L, T, nm, wave, moved_r, moved_p, st)
-                              : fill_pass_b<W, NW, false, true, true>(L, T, nm, wave, moved_r, moved_p, st);
+        if (a.flags & KAS_FLAG_LANE_ORDER) {                   // (workgroup-uniform)
+          if (nm.range != 0u) {
+            // pass B reads ONE 16-bit word per cell: node index | r* << 14 (no node has index 0x3fff: the LDS ends
+            // at 13,492 brokers; an id that is no broker keeps 0xffff) — the id table is not looked up again for
+            // this topic (P4 works on node indices)
+            for (int32_t i = tid; i < N; i += NT)
+              L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] =
+                  (int16_t)(uint16_t)((uint32_t)i | (((uint32_t)lds_qrs(L, i) >> 28) << 14));
+            kasw::sync();
+            oc = fill_pass_b<W, NW, true, true, true>(L, T, nm, wave, moved_r, moved_p, st);
+          } else {
+            oc = fill_pass_b<W, NW, false, true, true>(L, T, nm, wave, moved_r, moved_p, st);
+          }
+        }
         else
           oc = nm.range != 0u ? fill_pass_b<W, NW, true, true>(L, T, nm, wave, moved_r, moved_p, st)
                               : fill_pass_b<W, NW, false, true>(L, T, nm, wave, moved_r, moved_p, st);
