@@ -597,6 +597,32 @@ def run_rank(args) -> int:
                                         f"({prof.get('kernel_sources_sha16')}): not quoted")
         except Exception:
             pass
+        # which pipe is nearest its ceiling: the per-pipe utilisation of the committed SQ-counter passes of this very
+        # command line (scripts/pipe_table.py; eight batches in flight, whole job), HBM from the traffic above at this
+        # run's rate.  Counters cannot be collected inside a timed run: the table is a committed measurement.
+        if not args.stub and (S, P, N, R, RF) == C3_SHAPE and run.n_slots == 8:
+            try:
+                import csv
+                pipes = {}
+                with open(os.path.join(ROOT, "profiles", "r04_pipe_utilisation.csv")) as f:
+                    for row in csv.DictReader(f):
+                        if row["batches_in_flight"] == "8" and row["kernel"] == "fill+order" and row["fraction_of_capacity"]:
+                            pipes[row["quantity"]] = float(row["fraction_of_capacity"])
+                table = {"valu_pipe_busy": pipes.get("VALU pipe busy, counter"),
+                         "salu_issue_busy": pipes.get("SALU issue busy"),
+                         "lds_array_busy": pipes.get("LDS array busy"),
+                         "lds_array_busy_without_bank_conflicts": pipes.get("LDS array busy without bank-conflict cycles")}
+                if roof.get("traffic"):
+                    table["hbm_busy"] = roof["traffic"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                near = max(((k, v) for k, v in table.items() if v is not None and k != "lds_array_busy_without_bank_conflicts"),
+                           key=lambda kv: kv[1])
+                roof["pipes"] = dict(table, nearest_ceiling={"pipe": near[0], "frac": near[1]},
+                                     source="profiles/r04_pipe_utilisation.csv (rocprofv3 SQ counter passes of bench.py, eight "
+                                            "batches in flight, fill + order kernels over the ms_per_step window; units in the file)",
+                                     note="no pipe is saturated: the job is bound by how many wavefronts stay resident "
+                                          "(3 of 8 per SIMD, parked half of their time), DESIGN.md section 4.7")
+            except Exception:
+                pass
         if not args.stub and not args.no_extras and world == 1:
             try:
                 out_line["end_to_end"] = end_to_end_leg(args, run)
