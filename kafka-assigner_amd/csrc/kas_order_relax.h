@@ -32,15 +32,15 @@
 // that first fit put on one broker each, the chains the ticket forms need queues for: only near-ties ever change a
 // pick, so a chain of 13 rows on one broker is right after two or three evaluations.
 //
-// Counter word of a node (uint32, LDS, 4 bytes x (n_max + 1)): count[n][0] in bits 4..15, count[n][1] in bits
-// 20..31 (count[n][2] is never read for lists 3 wide: the last position has one candidate).  A pick is the minimum
-// of three keys  count << 20 | visit position << 2 | cell:  for the first pick  x << 16 | tag  (one
-// v_lshl_or_b32: the second count falls off the top), for the second  x & 0xfff00000 | tag  (one v_and_or_b32).
+// Counter word of a node (uint32, LDS, 4 bytes x (n_max + 1)): count[n][0] in bits 0..15, count[n][1] in bits
+// 16..31 (count[n][2] is never read for lists 3 wide: the last position has one candidate).  A pick is the minimum
+// of three keys  count << 16 | visit position << 2 | cell:  for the first pick  x << 16 | tag  (one
+// v_lshl_or_b32: the second count falls off the top), for the second  x & 0xffff0000 | tag  (one v_and_or_b32).
 // Cells stay in the order the fill kernel left them; the visit order of KAS:188-200 / KAS:263-278 — ascending
 // holders, rotated by abs(hash) mod set size — is in the tags: with rank = how many of the row's other holders are
 // smaller, the first pick over three holders visits a holder at position (idx3 + rank) mod 3 and the second visits
 // the two that are left in ascending (idx2 = 0) or descending order.  Tags are computed once per tile.  Rows per
-// node stay below 4095 (KAS_RELAX_ROW_LIMIT): the 12-bit fields.
+// node stay below 65535 (KAS_RELAX_ROW_LIMIT): the 16-bit fields.
 //
 // Tiles whose 64 rows all hold three brokers in rows of the batch's width take the straight-line evaluation above;
 // any other tile (the last tile of a topic, rows with fewer holders after a reduced replication factor, topics
@@ -50,21 +50,21 @@
 // (kas_relax_double_tiles).  HBM: mid rows in (8 B per row, read two tiles ahead), final rows out (12 B), broker ids
 // from the L2-resident node table.
 //
-// Applicable (KasShape::relax_ok) to lists <= 3 wide with no topic hash of Integer.MIN_VALUE and fewer than 4095 rows
-// per node; a Context handed in (the CTX instances) must leave room for them in its columns 0 and 1, checked per
+// Applicable (KasShape::relax_ok) to lists <= 3 wide with no topic hash of Integer.MIN_VALUE and fewer than 65535
+// rows per node; a Context handed in (the CTX instances) must leave room for them in its columns 0 and 1, checked per
 // scenario by the kernel.  Everything else keeps the ticket / round forms.
 #pragma once
 
 namespace kas {
 
-#define KAS_RELAX_F0_ONE 0x10u         // count[n][0] += 1
-#define KAS_RELAX_F1_ONE 0x100000u     // count[n][1] += 1
-#define KAS_RELAX_F1_MASK 0xfff00000u
+#define KAS_RELAX_F0_ONE 0x1u          // count[n][0] += 1   (bits 0..15)
+#define KAS_RELAX_F1_ONE 0x10000u      // count[n][1] += 1   (bits 16..31)
+#define KAS_RELAX_F1_MASK 0xffff0000u
 #define KAS_RELAX_PAD_WORD 0xfff0fff0u // counter word of the padding node: only ever gets + 0
-#define KAS_RELAX_PICK_BITS 0x00100010u // (row word >> cell) & this: what the row adds to the counter word of that cell
+#define KAS_RELAX_PICK_BITS 0x00010001u // (row word >> cell) & this: what the row adds to the counter word of that cell
 
-// The row word: what a row's current outcome adds, for all of its cells at once — bit 4 + c set when cell c is the
-// first pick, bit 20 + c when it is the second.  (word >> cell) & KAS_RELAX_PICK_BITS is the cell's addend.
+// The row word: what a row's current outcome adds, for all of its cells at once — bit c set when cell c is the
+// first pick, bit 16 + c when it is the second.  (word >> cell) & KAS_RELAX_PICK_BITS is the cell's addend.
 KAS_DEV uint32_t relax_row_word(uint32_t w0, uint32_t w1) { return (KAS_RELAX_F0_ONE << w0) | (KAS_RELAX_F1_ONE << w1); }
 
 // A lane's pairs: pair v = 64 t + lane is cell v mod 3 of row v div 3 of the (double) tile; its staging word is
@@ -109,7 +109,7 @@ KAS_DEV int32_t relax_eval_generic(const uint32_t (&x)[3], const bool (&valid)[3
   for (int k = 0; k < 3; ++k) {
     int32_t vp = idx_m0 + rank[k];
     vp -= vp >= Lp ? Lp : 0;
-    const uint32_t key = (((x[k] >> 4) & 0xfffu) << 8) | ((uint32_t)vp << 2) | (uint32_t)k;
+    const uint32_t key = ((x[k] & 0xffffu) << 8) | ((uint32_t)vp << 2) | (uint32_t)k;
     best = (valid[k] && key < best) ? key : best;
   }
   const int32_t w0 = Lp >= 1 ? (int32_t)(best & 3u) : 0;
@@ -118,7 +118,7 @@ KAS_DEV int32_t relax_eval_generic(const uint32_t (&x)[3], const bool (&valid)[3
   for (int k = 0; k < 3; ++k) {
     // two left (Lp == 3): ascending or descending by idx2; one left: no choice
     const int32_t ord = (Lp == 3 && t.idx2) ? 2 - rank[k] : rank[k];
-    const uint32_t key = ((x[k] >> 20) << 8) | ((uint32_t)ord << 2) | (uint32_t)k;
+    const uint32_t key = ((x[k] >> 16) << 8) | ((uint32_t)ord << 2) | (uint32_t)k;
     best = (valid[k] && k != w0 && key < best) ? key : best;
   }
   const int32_t w1 = Lp >= 2 ? (int32_t)(best & 3u) : 0;
@@ -203,7 +203,7 @@ KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node
 // them 56 — two of its wavefronts fit where one wavefront of the fill kernel does)
 // CTX: the instance for batches in which some scenario hands a Context in or wants it back (KAS:360-369): the counter
 // words start from the Context's columns 0 and 1, a third array counts what the rows add to column 2, and all three go
-// back at the end.  A scenario whose counters would leave the 12-bit fields is left to the round form (ord_flag).
+// back at the end.  A scenario whose counters would leave the 16-bit fields is left to the round form (ord_flag).
 template <int W, bool DUAL, bool CTX>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
@@ -225,7 +225,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     if (sd.ctx_off >= 0 && sd.ctx_width > 0 && a.ctx != nullptr) {           // (wave-uniform)
       g_ctx = a.ctx + sd.ctx_off;
       ccols = sd.ctx_width < W ? sd.ctx_width : W;
-      // columns 0 and 1 live in 12-bit fields: the Context's value + every row this scenario can add must fit
+      // columns 0 and 1 live in 16-bit fields: the Context's value + every row this scenario can add must fit
       const bool over = ctx_over_limit(g_ctx, N, sd.ctx_width, ccols < 2 ? ccols : 2, KAS_RELAX_ROW_LIMIT + 1u,
                                        ctx_gain_bound(a, sd), lane, 64);
       if (kasw::ballot(over) != 0ull) {
@@ -237,8 +237,8 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   for (int32_t n = lane; n < N; n += 64) {
     uint32_t w = 0u;
     if constexpr (CTX) {
-      if (ccols > 0) w |= (uint32_t)g_ctx[(int64_t)n * sd.ctx_width] << 4;
-      if (ccols > 1) w |= (uint32_t)g_ctx[(int64_t)n * sd.ctx_width + 1] << 20;
+      if (ccols > 0) w |= (uint32_t)g_ctx[(int64_t)n * sd.ctx_width];
+      if (ccols > 1) w |= (uint32_t)g_ctx[(int64_t)n * sd.ctx_width + 1] << 16;
       cnt2[n] = 0u;
     }
     cnt[n] = w;
@@ -437,8 +437,8 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     for (int32_t n = lane; n < N && ccols > 0; n += 64) {
       const uint32_t w = cnt[n];
       int32_t* row = g_ctx + (int64_t)n * sd.ctx_width;
-      row[0] = (int32_t)((w >> 4) & 0xfffu);
-      if (ccols > 1) row[1] = (int32_t)(w >> 20);
+      row[0] = (int32_t)(w & 0xffffu);
+      if (ccols > 1) row[1] = (int32_t)(w >> 16);
       if (ccols > 2) row[2] += (int32_t)cnt2[n];
     }
   }

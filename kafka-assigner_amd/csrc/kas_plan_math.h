@@ -200,8 +200,8 @@ KAS_ABI_FN KasLds kas_spread_scan_lds(int32_t n_max, int32_t W, int32_t idmap_en
 #define KAS_RING_SLOTS 4
 #endif
 #define KAS_PACKED_TICKET_LIMIT 1023
-// relaxation form (kas_order_relax.h): 12-bit count fields, no tickets — a node holds fewer rows than this
-#define KAS_RELAX_ROW_LIMIT 4095
+// relaxation form (kas_order_relax.h): 16-bit count fields, no tickets — a node holds fewer rows than this
+#define KAS_RELAX_ROW_LIMIT 65535
 // wide ticket form (kas_order_wide.h): the commits of a node are an 11-bit field, and count field 4 — 11 bits,
 // next to it — must not carry into them whatever the counts do: a node holds fewer rows than this.  Between
 // KAS_PACKED_TICKET_LIMIT and this bound the 10-bit count fields are not safe a priori; the kernel checks them
@@ -470,8 +470,8 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // lists 4 and 5 wide: the wide ticket form (kas_order_wide.h) under the same conditions plus 10-bit
   // count fields and 16-bit LDS offsets of its 8-byte counter rows; beyond 5: round form
   s.packed_ok = s.bound_small && !s.any_ctx;
-  // relaxation form: no KAS:190 index error, rows per node inside its 12-bit count fields (4,095: the packed ticket
-  // form stops at 1,023, the ticket forms at 65,535 tickets) — and none of the ticket form's 16-bit LDS offsets, so
+  // relaxation form: no KAS:190 index error, rows per node inside its 16-bit count fields (65,535, where the ticket
+  // forms' 16-bit tickets end too; the packed ticket form stops at 1,023) — and none of the ticket form's 16-bit LDS offsets, so
   // the broker count is limited by the fill kernel's LDS only.  A Context handed in is checked per scenario by the
   // kernel (its counters + the rows to come must fit the fields; else the round form, which fits whenever a batch
   // with a Context is accepted at all)

@@ -32,7 +32,7 @@ else:
 def with_context(fb, rng):
     """Every scenario of a single-topic batch hands a Context in and wants it back: a random width (narrower and wider
     than the lists), counters as earlier topics would have left them — now and then one that leaves the relaxation
-    form's 12-bit fields or the ticket form's 16, or is negative: that scenario must go to the round form."""
+    form's and the ticket form's 16-bit fields, or is negative: that scenario must go to the round form."""
     scen = fb.scen.copy()
     width = int(rng.choice([1, 2, 3, 4, 8]))
     ctx, off = [], 0

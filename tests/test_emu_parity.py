@@ -480,10 +480,10 @@ def test_emu_context_counters_beyond_the_count_fields_go_to_the_round_form():
     assert last_order_form() == 1 and last_flagged() == 2
     assert_same_outputs(fb, want, got, "emu ticket form, two scenarios flagged")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form, two scenarios per wavefront, two flagged")
-    # the relaxation form keeps columns 0 and 1 in 12-bit fields: counter + rows to come must stay below 4096
+    # the relaxation form keeps columns 0 and 1 in 16-bit fields: counter + rows to come must stay below 65536
     def big12(s, n):
         v = np.random.default_rng(s).integers(0, 500, size=(n, 8))
-        if s == 0: v[n // 3, 0] = 4000                                  # + up to 150 rows: over
+        if s == 0: v[n // 3, 0] = 65500                                 # + up to 150 rows: over
         if s == 1: v[n // 2, 1] = 65535
         if s == 2: v[3, 0] = -4
         if s == 3: v[5, 2] = 1 << 30                                    # column 2 is not a field: stays
@@ -547,3 +547,25 @@ def test_emu_per_topic_calls_carry_the_context_like_the_cli_loop():
         done = np.concatenate(outs)
         np.testing.assert_array_equal(done, want.out[:done.size])
         assert counters == unflatten_context(whole, want.ctx, 0)
+
+
+def test_emu_many_rows_per_broker_keep_the_relaxation_form_up_to_16_bit_counts():
+    """Round 4, last session: the relaxation form's count fields are 16 bits wide (the first version had 12 and handed
+    a broker with 4,095 rows or more to the ticket form).  90,000 partitions on 63 brokers: 4,286 rows per broker;
+    70,000 partitions on 3 brokers at RF 3: every broker holds every row — beyond the fields, the round form."""
+    from emu_lib import last_order_form, plan_shape
+    bs = G.perturb_brokers(60, 10, add=3, rack_aware=False)              # (with racks the reference strands at this density)
+    fb = uniform_batch(G.random_assignment(61, 90000, 60, 10, 3)[None], bs.node_id[None], bs.node_rack[None], 3)
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).all()
+    assert np.bincount(want.out[:90000 * 3]).max() > 4095
+    for flags in (0, RELAX_TILES_64, TICKET_ORDER):
+        got = emu_solve(fb, flags=flags)
+        assert last_order_form() == (1 if flags == TICKET_ORDER else 3)
+        assert_same_outputs(fb, want, got, f"emu 4,286 rows per broker, flags {flags:#x}")
+    bs3 = G.perturb_brokers(3, 3)
+    fb = uniform_batch(G.random_assignment(62, 70000, 3, 3, 3)[None], bs3.node_id[None], bs3.node_rack[None], 3)
+    rc, sh, _ = plan_shape(fb)
+    assert rc == 0 and sh["relax_ok"] == 0 and sh["tickets_ok"] == 0
+    assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu 70k rows per broker: round form")
+    assert last_order_form() == 0

@@ -366,9 +366,10 @@ def test_ticket_forms_take_a_context_in_and_hand_it_back(P, N, R, RF, kernel):
     if RF <= 3:
         assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip ticket form, three scenarios flagged for the round form")
 
-        def big12(s, n):                                                 # the relaxation form's 12-bit fields
+        def big12(s, n):                                                 # the relaxation form's 16-bit fields
             v = np.random.default_rng(s).integers(0, 200, size=(n, 8))
-            if s in (0, 3): v[n // 3, s % 2] = 4095 - 20                 # + the rows to come: over
+            if s in (0, 3): v[n // 3, s % 2] = 65535 - 20                # + the rows to come: over
+            if s == 1: v[n // 4, 0] = 4095; v[n // 4 + 1, 1] = 30000     # (inside the fields: stays in the relaxation form)
             if s == 5: v[7, 2] = 1 << 29                                 # column 2 is no field: stays in the relaxation form
             return v
         fb = _with_context(_batch(808 + RF, 6, P, N, R, RF, G.BENCH_ACTIONS), big12)
@@ -637,3 +638,20 @@ def test_random_shapes_against_the_oracle_for_a_bounded_slice():
     n = int(r.stdout.split("stress ok:")[1].split()[0])
     assert n >= 100, (seed, r.stdout[-500:])
     print(r.stdout.strip().splitlines()[-1])
+
+
+def test_many_rows_per_broker_keep_the_relaxation_form_up_to_16_bit_counts():
+    """The relaxation form's count fields are 16 bits wide: a broker holding 4,095 rows of the scenario or more no
+    longer sends the batch to the ticket form (round 4's first version: 12-bit fields).  90,000 partitions on 63
+    brokers, rack awareness off (with racks the reference itself strands at this density): 4,286 rows per broker."""
+    bs = G.perturb_brokers(60, 10, add=3, rack_aware=False)
+    fb = uniform_batch(np.stack([G.random_assignment(61 + i, 90000, 60, 10, 3) for i in range(3)]),
+                       np.stack([bs.node_id] * 3), np.stack([bs.node_rack] * 3), 3)
+    want = oracle_solve(fb, threads=0)
+    assert (want.scenario_results["status"] == abi.KAS_OK).any()
+    plan = native.Plan(native.default_context(), fb)
+    assert "kas_order_relax_kernel<3>" in plan.describe(), plan.describe()
+    plan.close()
+    assert_same_outputs(fb, want, native.solve_host(fb), "hip 4,286 rows per broker, relaxation form")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip 4,286 rows per broker, tiles of 64 rows")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip 4,286 rows per broker, ticket form")
