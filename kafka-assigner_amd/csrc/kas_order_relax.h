@@ -178,24 +178,75 @@ KAS_DEV int32_t relax_eval3(const uint32_t (&x)[3], const RelaxTags& g) {
   return (int32_t)(w0 | (w1 << 2));
 }
 
-// The final row of a partition with three holders: broker ids in list order out, its digest back.  List position r
-// takes cell w_r: bytes 2 w_r, 2 w_r + 1 of the mid row (v_perm_b32 selector, high half zero).
+// The final rows of a tile whose rows all hold three brokers, in two halves.  relax_list3: list position r takes cell
+// w_r — bytes 2 w_r, 2 w_r + 1 of the mid row (v_perm_b32 selector, high half zero) — as node indices.  The broker ids
+// of those nodes are ASKED FOR where the tile is decided (RelaxPend) and the rows go out one step later
+// (relax_flush): the first version loaded the ids and stored the row on the spot, which made the wavefront wait for an L2
+// round trip and then for the store's acknowledgement on every tile — a third of the kernel's time on its one chain.
 // (cnt2 != nullptr: a Context goes back — count[.][2] of the last position's holder, never read by these lists, is kept
 // as an increment per node beside the counter words)
 template <class Raw>
-KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node_id, int32_t* out, uint32_t k, int32_t p,
-                               uint32_t* cnt2 = nullptr) {
+KAS_DEV void relax_list3(const Raw& raw, int32_t oc, uint32_t (&l)[3], uint32_t* cnt2 = nullptr) {
   const uint32_t w0 = (uint32_t)oc & 3u, w1 = ((uint32_t)oc >> 2) & 3u, w2 = 3u - w0 - w1;
-  const uint32_t l0 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w0 * 0x0202u);
-  const uint32_t l1 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w1 * 0x0202u);
-  const uint32_t l2 = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w2 * 0x0202u);
-  if (cnt2) kasw::lds_add_u32(cnt2 + l2, 1u);
-  RowW<3> o;
-  o.v[0] = g_node_id[l0]; o.v[1] = g_node_id[l1]; o.v[2] = g_node_id[l2];
+  l[0] = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w0 * 0x0202u);
+  l[1] = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w1 * 0x0202u);
+  l[2] = kasw::perm_bytes(raw.w[1], raw.w[0], 0x0c0c0100u + w2 * 0x0202u);
+  if (cnt2) kasw::lds_add_u32(cnt2 + l[2], 1u);
+}
+
+// final rows on their way: the broker ids of NB rows per lane (rows p, p + 64), asked for (kasw::gload_u32_async) and
+// not to be looked at before the step's kasw::wait_loads()
+template <int NB>
+struct RelaxPend {
+  uint32_t id[NB][3];
+  int32_t p;
+  int32_t n;                           // rows per lane that are pending: 0, 1 or 2 (wave-uniform)
+};
+
+// A mid row asked for (row p must exist: the caller clamps) and, one step later, taken: the layout of mid_load_raw —
+// FULLW, rows of the template width, as mid_width_of<W>() / 2 dwords, others cell by cell; cells past the row's width and
+// rows past the topic's end read as KAS_MID_NONE.  Every word is asked for by exactly ONE unconditional statement (a cell
+// the row does not have re-reads its last one and is masked when taken): a request under a condition would make the
+// compiler merge two definitions of the variable with a register copy — of a register whose load is still in flight.
+template <int W, bool FULLW>
+KAS_DEV void mid_request(MidRaw<W>& r, const uint16_t* mid, int32_t ow, int32_t p) {
+  if constexpr (FULLW) {                                    // (packed rows: the dword of a 6-byte row is 2-byte aligned)
+    const uint32_t off = (uint32_t)p * (uint32_t)(2 * W);
+    kasw::gload_u32_async<0>(r.w[0], mid, off);
+    if constexpr (W == 3) kasw::gload_u16_async<4>(r.w[1], mid, off);
+  } else {
+    const uint32_t off = (uint32_t)p * (uint32_t)(2 * mid_width(ow));
+#pragma unroll
+    for (int k = 0; k < W; ++k) kasw::gload_u16_async<0>(r.w[k], mid, off + 2u * (uint32_t)(k < ow ? k : ow - 1));
+  }
+}
+template <int W, bool FULLW>
+KAS_DEV MidRaw<W> mid_take(const MidRaw<W>& r, int32_t ow, bool active) {
+  MidRaw<W> o;
+#pragma unroll
+  for (int k = 0; k < W; ++k) o.w[k] = (active && (FULLW ? k < (W + 1) / 2 : k < ow)) ? r.w[k] : 0xffffffffu;
+  return o;
+}
+
+// the pending rows go out (one 12-byte store each); returns their digest
+template <int NB>
+KAS_DEV uint64_t relax_flush(RelaxPend<NB>& pend, int32_t* out, uint32_t k) {
   uint64_t d = 0;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) d += kas_digest_cell(k, (uint32_t)p, (uint32_t)q, o.v[q]);
-  *reinterpret_cast<RowW<3>*>(out + (int64_t)p * 3) = o;
+  for (int b = 0; b < NB; ++b) {
+    if (b < pend.n) {                                        // (wave-uniform)
+      RowW<3> o;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        o.v[q] = (int32_t)pend.id[b][q];
+        d += kas_digest_cell(k, (uint32_t)(pend.p + 64 * b), (uint32_t)q, o.v[q]);
+      }
+#if !defined(KAS_TUNE_NO_ROW_STORES)                          // (tuning builds: the mid rows stay, the kernel can run again)
+      *reinterpret_cast<RowW<3>*>(out + (int64_t)(pend.p + 64 * b) * 3) = o;
+#endif
+    }
+  }
+  pend.n = 0;
   return d;
 }
 
@@ -204,9 +255,15 @@ KAS_DEV uint64_t relax_retire3(const Raw& raw, int32_t oc, const int32_t* g_node
 // CTX: the instance for batches in which some scenario hands a Context in or wants it back (KAS:360-369): the counter
 // words start from the Context's columns 0 and 1, a third array counts what the rows add to column 2, and all three go
 // back at the end.  A scenario whose counters would leave the 16-bit fields is left to the round form (ord_flag).
+// issue priority of the relaxation form's wavefront among the waves of its SIMD (s_setprio 0..3): its loop is ONE dependency
+// chain, the fill kernel's wavefronts beside it have four tiles of independent work in flight each
+#ifndef KAS_RELAX_PRIO
+#define KAS_RELAX_PRIO 0
+#endif
 template <int W, bool DUAL, bool CTX>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
+  if constexpr (KAS_RELAX_PRIO > 0) kasw::set_priority<KAS_RELAX_PRIO>();
   const int lane = kasw::lane();
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
@@ -258,17 +315,19 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   uint64_t digest = 0;
   int32_t n_tiles = 0, n_evals = 0, n_slow = 0;             // (wave-uniform)
   bool stuck = false;
+  const int32_t* rec_next = (a.flags & KAS_FLAG_ORPHAN_RECS) ? a.recs + a.rec_off[s] : nullptr;   // the next topic's orphan records
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
-    if (a.topic_results[ti].status != KAS_OK) continue;     // (a failed or skipped topic emits nothing)
     const kas_topic_desc td = a.topics[ti];
+    const int32_t* const rec_topic = rec_next;
+    if (rec_next) rec_next += kas_rec_topic_ints(td.n_partitions);
+    if (a.topic_results[ti].status != KAS_OK) continue;     // (a failed or skipped topic emits nothing)
     const int32_t P = td.n_partitions, ow = td.out_width;
     if (P <= 0) continue;
     int32_t* out = a.out + td.out_off;
     const uint16_t* mid = mid_base(out, P, ow);
     const RelaxTopic rt = relax_topic(td.name_hash);
     const int32_t nt = (P + 63) >> 6;
-    const bool full_width = W == 3 && ow == 3;
     // the topic's tags by the order of a row's cells: bit 0 = cell 0 < cell 1, bit 1 = cell 0 < cell 2, bit 2 = cell 1 <
     // cell 2;  word = first-pick tags of cells 0..2 (4 bits each), then the second-pick tags
     kasw::lockstep();
@@ -284,152 +343,290 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       tagtab[lane] = w;
     }
     kasw::lockstep();
-    auto load_tile = [&](int32_t t) -> MidRaw<W> {
-      const int32_t pn = (t << 6) + lane;
-      return mid_load_raw<W>(mid, ow, pn < P ? pn : 0, pn < P);
-    };
-    MidRaw<W> nx0 = load_tile(0), nx1 = load_tile(1);       // the mid rows of the next two tiles (read ahead)
-    for (int32_t tile = 0; tile < nt;) {
-      const int32_t p = (tile << 6) + lane;
-      const bool active = p < P;
-      const MidRaw<W> raw = nx0;
-      // ---- cells of my row (row lane): node index or KAS_MID_NONE (0xffff, bit 15)
-      uint32_t c[3];
-      if (ow == W) {
-        c[0] = raw.w[0] & 0xffffu; c[1] = raw.w[0] >> 16; c[2] = W == 3 ? (raw.w[1] & 0xffffu) : KAS_MID_NONE;
+    // (rows of the batch's width, the usual case, and narrower ones: two instances of the topic's row loop)
+    const uint16_t* umid = kasw::uniform_ptr(mid);
+    const int32_t* uid = kasw::uniform_ptr(g_node_id);
+    auto topic_rows = [&](auto fullw_tag) {
+      constexpr bool FULLW = decltype(fullw_tag)::value;
+      // Mid rows: raw[] = the rows of this step (one tile; two for the instance with double tiles), in registers; nx[] =
+      // the rows behind them, asked for one step ago.  Every global access of a step sits at ONE point of it, its end:
+      // there the wavefront waits (the only place it does) for what it asked for a whole step ago — the next rows, the
+      // broker ids of the step's predecessor, whose final rows then go out — and makes its new requests; nothing before
+      // the same point of the next step looks at them.  The requests are loads the compiler does not see
+      // (kasw::gload_*_async: its own wait insertion put a vmcnt(0) behind the requests of the same iteration).
+      constexpr int NB = DUAL ? 2 : 1;
+      auto row_exists = [&](int32_t t) -> bool { return ((t << 6) + lane) < P; };
+      auto request_tile = [&](MidRaw<W>& r, int32_t t) {
+        const int32_t pn = (t << 6) + lane;
+        mid_request<W, FULLW>(r, umid, ow, pn < P ? pn : 0);
+      };
+      MidRaw<W> raw[NB], nx[NB];
+      RelaxPend<NB> pend;
+      pend.n = 0; pend.p = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) { raw[b].w[q] = 0xffffffffu; nx[b].w[q] = 0xffffffffu; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pend.id[b][q] = 0u;
+      }
+      // Orphan records (KasLaunch::recs; rows of the batch's width, tiles of 64 rows, no Context).  The fill kernel left a
+      // KAS_MID_ORPHAN cell in every orphan row and per tile an info word — first record | records << 25 —, P4 completed
+      // the records: the orphan rows of a tile take their cells from them (in row order = record order).  The info word
+      // is asked for three tiles ahead, the tile's records two tiles ahead — when its info has arrived —, both beside
+      // the mid rows at the step's one wait; the rows are put right where they arrive, so nothing else lives across a step.
+      constexpr bool RECS_OK = FULLW && W == 3 && !DUAL && !CTX;
+      const bool use_recs = RECS_OK && rec_topic != nullptr;   // (wave-uniform)
+      const int32_t* uinfo = kasw::uniform_ptr(rec_topic);
+      const int32_t* urec = uinfo + ((nt + 1) & ~1);
+      uint32_t info_nx = 0u, rec_nx[2] = {0u, 0u};
+      uint32_t info_1 = 0u;                                   // info word of the tile whose rows arrive at the next wait
+      auto request_info = [&](int32_t t) {
+        kasw::gload_u32_async_if<0>(info_nx, uinfo, (uint32_t)(t < nt ? t : nt - 1) << 2, use_recs);
+      };
+      auto request_recs = [&](uint32_t info) {
+        const uint32_t off = ((info & (KAS_REC_ROWS_LIMIT - 1)) + (uint32_t)lane) << 3;
+        const bool on = use_recs && (uint32_t)lane < (info >> 25);
+        kasw::gload_u32_async_if<0>(rec_nx[0], urec, off, on);
+        kasw::gload_u32_async_if<4>(rec_nx[1], urec, off, on);
+      };
+      // the rows of a tile as they arrived -> with its orphan rows taken from the records that arrived with them
+      auto merge_recs = [&](MidRaw<W>& r, uint32_t info) {
+        const uint32_t c0 = r.w[0] & 0xffffu, c1 = r.w[0] >> 16, c2 = r.w[1] & 0xffffu;
+        const bool orphan = c0 == KAS_MID_ORPHAN || c1 == KAS_MID_ORPHAN || c2 == KAS_MID_ORPHAN;
+        const uint64_t om = kasw::ballot(orphan);
+        if ((uint32_t)kasw::popc(om) != (info >> 25)) stuck = true;   // (the fill kernel's count and its marks disagree: never)
+        if (om != 0ull) {                                     // (wave-uniform)
+          const int32_t rank = kasw::count_below(om);
+          const uint32_t s0 = (uint32_t)kasw::shfl((int)rec_nx[0], rank), s1 = (uint32_t)kasw::shfl((int)rec_nx[1], rank);
+          r.w[0] = orphan ? s0 : r.w[0];
+          r.w[1] = orphan ? (s1 & 0xffffu) : r.w[1];
+        }
+      };
+#pragma unroll
+      for (int b = 0; b < NB; ++b) request_tile(nx[b], b);
+      if constexpr (RECS_OK) request_info(0);
+      kasw::wait_loads();
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
+      if constexpr (RECS_OK) {
+        kasw::arrived(info_nx);
+        const uint32_t info_0 = use_recs ? (uint32_t)kasw::uniform((int)info_nx) : 0u;
+        request_recs(info_0);
+        request_info(1);
+        kasw::wait_loads();
+        kasw::arrived(rec_nx[0]); kasw::arrived(rec_nx[1]); kasw::arrived(info_nx);
+        raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(0));
+        if (use_recs) merge_recs(raw[0], info_0);
+        info_1 = (use_recs && 1 < nt) ? (uint32_t)kasw::uniform((int)info_nx) : 0u;
       } else {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) c[q] = q < W ? (raw.w[q] & 0xffffu) : KAS_MID_NONE;
+        for (int b = 0; b < NB; ++b) raw[b] = mid_take<W, FULLW>(nx[b], ow, row_exists(b));
       }
-      // the usual tile: 64 rows, three holders each, rows of the batch's width
-      bool fast = false;
-      uint32_t* padr[6];
-      uint32_t padd[6] = {0u, 0u, 0u, 0u, 0u, 0u};           // what my pairs added last
-      if constexpr (W == 3) {
-        if (full_width && ((tile + 1) << 6) <= P)
-          fast = kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
-        // ---- two usual tiles in a row: one double tile of 128 rows, lane i evaluates rows i and 64 + i.  The same
-        // fixed point (row-major pairs over six instructions), twice the work per LDS round trip.
-        if constexpr (DUAL) if (fast && ((tile + 2) << 6) <= P) {
-          const MidRaw<W> rawb = nx1;
-          const uint32_t cb[3] = {rawb.w[0] & 0xffffu, rawb.w[0] >> 16, rawb.w[1] & 0xffffu};
-          if (kasw::ballot(((cb[0] | cb[1] | cb[2]) & 0x8000u) != 0u) == 0ull) {
-            nx0 = load_tile(tile + 2); nx1 = load_tile(tile + 3);
-            n_tiles += 2;
-            kasw::lockstep();                                // (the previous tile's words have been read)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { mine[q] = c[q]; mine[192 + q] = cb[q]; }
-            kasw::lockstep();
+      for (int b = 0; b < NB; ++b) request_tile(nx[b], NB + b);
+      if constexpr (RECS_OK) { request_recs(info_1); request_info(2); }
+      for (int32_t tile = 0; tile < nt;) {
+        const int32_t p = (tile << 6) + lane;
+        const bool active = p < P;
+        // ---- cells of my row (row lane): node index or KAS_MID_NONE (0xffff, bit 15)
+        uint32_t c[3];
+        if constexpr (FULLW) {
+          c[0] = raw[0].w[0] & 0xffffu; c[1] = raw[0].w[0] >> 16; c[2] = W == 3 ? (raw[0].w[1] & 0xffffu) : KAS_MID_NONE;
+        } else {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) padr[t] = cnt + pp.slot[64 * t];
-            uint32_t xa[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
-            uint32_t xb[3] = {cnt[cb[0]], cnt[cb[1]], cnt[cb[2]]};
-            const RelaxTags ga = relax_tags(c, tagtab), gb = relax_tags(cb, tagtab);
-            kasw::lockstep();
-            int32_t pa = -1, pb = -1;
-            for (int32_t it = 0;; ++it) {
-              n_evals += 2;
-              if (it > 130) { stuck = true; break; }         // (row i is right after evaluation i + 1: 129 suffice)
-              const int32_t oa = relax_eval3(xa, ga), ob = relax_eval3(xb, gb);
-              if (kasw::ballot(oa != pa || ob != pb) == 0ull) break;
-              rbuf[lane] = relax_row_word((uint32_t)oa & 3u, (uint32_t)oa >> 2);
-              rbuf[64 + lane] = relax_row_word((uint32_t)ob & 3u, (uint32_t)ob >> 2);
-              relax_pairs<6>(pp, padr, padd, it > 0);
+          for (int q = 0; q < 3; ++q) c[q] = q < W ? (raw[0].w[q] & 0xffffu) : KAS_MID_NONE;
+        }
+        // the usual tile: 64 rows, three holders each, rows of the batch's width
+        bool fast = false;
+        uint32_t* padr[6];
+        uint32_t padd[6] = {0u, 0u, 0u, 0u, 0u, 0u};           // what my pairs added last
+        int32_t step = 1;                                      // tiles this step takes (wave-uniform)
+        int32_t req_n = 0;                                     // rows per lane whose final rows this step asks the ids for
+        uint32_t req_l[NB][3];                                 // ... their lists as node indices
 #pragma unroll
-              for (int q = 0; q < 3; ++q) { xa[q] = mine[q]; xb[q] = mine[192 + q]; }
-              pa = oa; pb = ob;
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) req_l[b][q] = 0u;
+        if constexpr (W == 3) {
+          if (FULLW && ((tile + 1) << 6) <= P)
+            fast = kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
+          // ---- two usual tiles in a row: one double tile of 128 rows, lane i evaluates rows i and 64 + i.  The same
+          // fixed point (row-major pairs over six instructions), twice the work per LDS round trip.
+          if constexpr (DUAL) if (fast && ((tile + 2) << 6) <= P) {
+            const uint32_t cb[3] = {raw[NB - 1].w[0] & 0xffffu, raw[NB - 1].w[0] >> 16, raw[NB - 1].w[1] & 0xffffu};
+            if (kasw::ballot(((cb[0] | cb[1] | cb[2]) & 0x8000u) != 0u) == 0ull) {
+              n_tiles += 2;
+              kasw::lockstep();                                // (the previous tile's words have been read)
+#pragma unroll
+              for (int q = 0; q < 3; ++q) { mine[q] = c[q]; mine[192 + q] = cb[q]; }
+              kasw::lockstep();
+#pragma unroll
+              for (int t = 0; t < 6; ++t) padr[t] = cnt + pp.slot[64 * t];
+              uint32_t xa[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
+              uint32_t xb[3] = {cnt[cb[0]], cnt[cb[1]], cnt[cb[2]]};
+              const RelaxTags ga = relax_tags(c, tagtab), gb = relax_tags(cb, tagtab);
+              kasw::lockstep();
+              int32_t pa = -1, pb = -1;
+              for (int32_t it = 0;; ++it) {
+                n_evals += 2;
+                if (it > 130) { stuck = true; break; }         // (row i is right after evaluation i + 1: 129 suffice)
+                const int32_t oa = relax_eval3(xa, ga), ob = relax_eval3(xb, gb);
+                if (kasw::ballot(oa != pa || ob != pb) == 0ull) break;
+                rbuf[lane] = relax_row_word((uint32_t)oa & 3u, (uint32_t)oa >> 2);
+                rbuf[64 + lane] = relax_row_word((uint32_t)ob & 3u, (uint32_t)ob >> 2);
+                relax_pairs<6>(pp, padr, padd, it > 0);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { xa[q] = mine[q]; xb[q] = mine[192 + q]; }
+                pa = oa; pb = ob;
+              }
+              relax_list3(raw[0], pa < 0 ? 4 : pa, req_l[0], cnt2);
+              relax_list3(raw[NB - 1], pb < 0 ? 4 : pb, req_l[NB - 1], cnt2);
+              req_n = 2;
+              step = 2;
             }
-            digest += relax_retire3(raw, pa < 0 ? 4 : pa, g_node_id, out, (uint32_t)k, p, cnt2);
-            digest += relax_retire3(rawb, pb < 0 ? 4 : pb, g_node_id, out, (uint32_t)k, p + 64, cnt2);
-            tile += 2;
-            continue;
           }
         }
-      }
-      nx0 = nx1;
-      nx1 = load_tile(tile + 2);
-      tile += 1;
-      n_tiles += 1;
-      // ---- hand the cells to the pair lanes
-      kasw::lockstep();                                      // (the previous tile's words have been read)
+        if (step == 1) {
+          n_tiles += 1;
+          // ---- hand the cells to the pair lanes
+          kasw::lockstep();                                    // (the previous tile's words have been read)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) mine[q] = c[q];
-      kasw::lockstep();
-      if constexpr (W == 3) {
-        if (fast) {
-#pragma unroll
-          for (int t = 0; t < 3; ++t) padr[t] = cnt + pp.slot[64 * t];
-          // counter words of my cells as the previous tile left them
-          uint32_t x[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
-          const RelaxTags g = relax_tags(c, tagtab);          // my row's six tags from the order of its cells
+          for (int q = 0; q < 3; ++q) mine[q] = c[q];
           kasw::lockstep();
-          int32_t oc_prev = -1;
-          for (int32_t it = 0;; ++it) {
-            n_evals += 1;
-            // (lane i is right after evaluation i + 1, so 65 evaluations always suffice: more means the LDS did not
-            // hand the additions out in lane order — give up with a status instead of looping)
-            if (it > 66) { stuck = true; break; }
-            const int32_t oc = relax_eval3(x, g);
-            if (kasw::ballot(oc != oc_prev) == 0ull) break;  // nobody's outcome moved: the words hold the tile's commits
-            rbuf[lane] = relax_row_word((uint32_t)oc & 3u, (uint32_t)oc >> 2);
-            relax_pairs<3>(pp, padr, padd, it > 0);
-            x[0] = mine[0]; x[1] = mine[1]; x[2] = mine[2];
-            oc_prev = oc;
+          bool usual = false;
+          if constexpr (W == 3) usual = fast;
+          if (usual) {
+            if constexpr (W == 3) {
+#pragma unroll
+              for (int t = 0; t < 3; ++t) padr[t] = cnt + pp.slot[64 * t];
+              // counter words of my cells as the previous tile left them
+              uint32_t x[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
+              const RelaxTags g = relax_tags(c, tagtab);        // my row's six tags from the order of its cells
+              kasw::lockstep();
+              int32_t oc_prev = -1;
+              for (int32_t it = 0;; ++it) {
+                n_evals += 1;
+                // (lane i is right after evaluation i + 1, so 65 evaluations always suffice: more means the LDS did not
+                // hand the additions out in lane order — give up with a status instead of looping)
+                if (it > 66) { stuck = true; break; }
+                const int32_t oc = relax_eval3(x, g);
+                if (kasw::ballot(oc != oc_prev) == 0ull) break;  // nobody's outcome moved: the words hold the tile's commits
+                rbuf[lane] = relax_row_word((uint32_t)oc & 3u, (uint32_t)oc >> 2);
+                relax_pairs<3>(pp, padr, padd, it > 0);
+                x[0] = mine[0]; x[1] = mine[1]; x[2] = mine[2];
+                oc_prev = oc;
+              }
+              // ---- the final row: its list as node indices now, broker ids and the store one step later
+              relax_list3(raw[0], oc_prev < 0 ? 4 : oc_prev, req_l[0], cnt2);
+              req_n = 1;
+            }
+          } else {
+            // ---- any other tile: per-lane list lengths
+            n_slow += 1;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              const uint32_t n = pp.slot[64 * t];
+              padr[t] = cnt + (n < (uint32_t)nmax ? n : (uint32_t)nmax);   // no holder: the padding node, and + 0
+            }
+            uint32_t x[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) x[q] = cnt[c[q] < (uint32_t)nmax ? c[q] : (uint32_t)nmax];
+            kasw::lockstep();
+            bool valid[3];
+            int32_t rank[3], Lp = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { valid[q] = active && (c[q] & 0x8000u) == 0u; Lp += valid[q] ? 1 : 0; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              rank[q] = 0;
+#pragma unroll
+              for (int j = 0; j < 3; ++j) rank[q] += (j != q && valid[j] && c[j] < c[q]) ? 1 : 0;
+            }
+            int32_t oc_prev = -1;
+            for (int32_t it = 0;; ++it) {
+              n_evals += 1;
+              if (it > 66) { stuck = true; break; }
+              const int32_t oc = relax_eval_generic(x, valid, rank, Lp, rt);
+              if (kasw::ballot(oc != oc_prev) == 0ull) break;
+              const uint32_t w0 = (uint32_t)oc & 3u, w1 = ((uint32_t)oc >> 2) & 3u;
+              rbuf[lane] = (Lp >= 1 ? KAS_RELAX_F0_ONE << w0 : 0u) | (Lp >= 2 ? KAS_RELAX_F1_ONE << w1 : 0u);
+              relax_pairs<3>(pp, padr, padd, it > 0);
+#pragma unroll
+              for (int q = 0; q < 3; ++q) x[q] = mine[q];
+              oc_prev = oc;
+            }
+            if (active && oc_prev >= 0) {
+              const int32_t w0 = oc_prev & 3, w1 = (oc_prev >> 2) & 3, w2 = 3 - w0 - w1;
+              const int32_t w[3] = {w0, w1, w2};
+#pragma unroll
+              for (int r = 0; r < W; ++r) {
+                if (r < ow) {
+                  const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
+                  const int32_t id = r < Lp ? g_node_id[cell] : -1;
+                  if constexpr (CTX) { if (r == 2 && r < Lp) kasw::lds_add_u32(cnt2 + cell, 1u); }
+                  out[(int64_t)p * ow + r] = id;
+                  if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
+                }
+              }
+            }
           }
-          // ---- the final row: broker ids in list order, digest
-          digest += relax_retire3(raw, oc_prev < 0 ? 4 : oc_prev, g_node_id, out, (uint32_t)k, p, cnt2);
-          continue;
         }
-      }
-      // ---- any other tile: per-lane list lengths
-      n_slow += 1;
+        // ---- the step's global accesses: wait for what was asked for a step ago ...
+        tile += step;
+        kasw::wait_loads();
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const uint32_t n = pp.slot[64 * t];
-        padr[t] = cnt + (n < (uint32_t)nmax ? n : (uint32_t)nmax);   // no holder: the padding node, and + 0
-      }
-      uint32_t x[3];
+        for (int b = 0; b < NB; ++b) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) x[q] = cnt[c[q] < (uint32_t)nmax ? c[q] : (uint32_t)nmax];
-      kasw::lockstep();
-      bool valid[3];
-      int32_t rank[3], Lp = 0;
+          for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { valid[q] = active && (c[q] & 0x8000u) == 0u; Lp += valid[q] ? 1 : 0; }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        rank[q] = 0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) rank[q] += (j != q && valid[j] && c[j] < c[q]) ? 1 : 0;
-      }
-      int32_t oc_prev = -1;
-      for (int32_t it = 0;; ++it) {
-        n_evals += 1;
-        if (it > 66) { stuck = true; break; }
-        const int32_t oc = relax_eval_generic(x, valid, rank, Lp, rt);
-        if (kasw::ballot(oc != oc_prev) == 0ull) break;
-        const uint32_t w0 = (uint32_t)oc & 3u, w1 = ((uint32_t)oc >> 2) & 3u;
-        rbuf[lane] = (Lp >= 1 ? KAS_RELAX_F0_ONE << w0 : 0u) | (Lp >= 2 ? KAS_RELAX_F1_ONE << w1 : 0u);
-        relax_pairs<3>(pp, padr, padd, it > 0);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) x[q] = mine[q];
-        oc_prev = oc;
-      }
-      if (active && oc_prev >= 0) {
-        const int32_t w0 = oc_prev & 3, w1 = (oc_prev >> 2) & 3, w2 = 3 - w0 - w1;
-        const int32_t w[3] = {w0, w1, w2};
-#pragma unroll
-        for (int r = 0; r < W; ++r) {
-          if (r < ow) {
-            const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
-            const int32_t id = r < Lp ? g_node_id[cell] : -1;
-            if constexpr (CTX) { if (r == 2 && r < Lp) kasw::lds_add_u32(cnt2 + cell, 1u); }
-            out[(int64_t)p * ow + r] = id;
-            if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
+          for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
+        }
+        // ... the next rows move up (their orphan rows from the records that came with them),
+        if constexpr (NB == 1) {
+          raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile));
+          if constexpr (RECS_OK) {
+            kasw::arrived(rec_nx[0]); kasw::arrived(rec_nx[1]); kasw::arrived(info_nx);
+            if (use_recs) merge_recs(raw[0], info_1);
+            info_1 = (use_recs && tile + 1 < nt) ? (uint32_t)kasw::uniform((int)info_nx) : 0u;   // (of tile + 1: arrived just now)
+          }
+        } else {
+          if (step == 2) {
+            raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile)); raw[1] = mid_take<W, FULLW>(nx[1], ow, row_exists(tile + 1));
+          } else {
+            raw[0] = raw[1]; raw[1] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile + 1));
           }
         }
+        // the previous step's final rows go out,
+        digest += relax_flush<NB>(pend, out, (uint32_t)k);
+        // and the requests are made: the broker ids of this step's final rows, the mid rows two steps on
+        // (every in-flight register has ONE requesting statement, executed on every path: a step without final rows of
+        // its own asks for node 0's id, a single-tile step of the double-tile instance asks for a tile it had already)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) kasw::gload_u32_async<0>(pend.id[b][q], uid, req_l[b][q] << 2);
+        pend.p = p; pend.n = req_n;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) request_tile(nx[b], tile + NB + b);
+        if constexpr (RECS_OK) { request_recs(info_1); request_info(tile + 2); }
       }
-    }
+      // the topic's last rows (and no request is left outstanding: its register would be written behind our back)
+      kasw::wait_loads();
+      if constexpr (RECS_OK) { kasw::arrived(rec_nx[0]); kasw::arrived(rec_nx[1]); kasw::arrived(info_nx); }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
+      }
+      digest += relax_flush<NB>(pend, out, (uint32_t)k);
+    };
+    if (ow == W) topic_rows(std::true_type{});
+    else topic_rows(std::false_type{});
   }
   if constexpr (CTX) {
     // the Context goes back (KAS:360-369): every row has retired, the words hold every commit

@@ -42,6 +42,15 @@ KAS_DEV int read_lane(int v, int uniform_lane) {
 // a value every lane of the wavefront holds alike, moved to a scalar register (branches on it are scalar branches)
 KAS_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// a pointer every lane holds alike, moved to scalar registers (the base of a global_load with a per-lane offset)
+template <class T>
+KAS_DEV T* uniform_ptr(T* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
+
 KAS_DEV void sync() { __syncthreads(); }
 
 // Ordering point for a section that only ONE wave of the workgroup executes: this wave's
@@ -148,6 +157,35 @@ KAS_DEV void lds_add_u32(uint32_t* p, uint32_t v) {
 KAS_DEV void lds_sub_u32(uint32_t* p, uint32_t v) {
   (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
+// Global loads the COMPILER DOES NOT SEE (inline assembly): gload_*_async asks for a value, wait_loads() is the one
+// s_waitcnt vmcnt(0) that makes everything asked for so far usable, arrived(x) ties a use of x behind it.  Why not plain
+// loads: the compiler's wait insertion is exact inside a basic block only.  A loaded value that lives across a loop's back
+// edge in a loop with several paths gets "vmcnt(0)" at the latch (a register copy of the value is a use), i.e. behind the
+// requests the iteration has just made — the order kernel's one wavefront then waits out an L2 or HBM round trip per tile
+// on its dependency chain.  With these the kernel decides where it waits: once per step, where every outstanding request
+// is a whole step old (kas_order_relax.h).  The value lands in `dst` itself ("+v": the register of the loop-carried
+// variable), so there is no copy to wait for.  base: wave-uniform (scalar registers), voff: byte offset per lane.
+template <int IMM = 0>
+KAS_DEV void gload_u32_async(uint32_t& dst, const void* base, uint32_t voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+template <int IMM = 0>
+KAS_DEV void gload_u16_async(uint32_t& dst, const void* base, uint32_t voff) {
+  asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+// ... for the lanes with `on` only: the instruction is issued under a narrowed EXEC (restored behind it), so a lane that does
+// not ask keeps what its register holds and nothing is requested for it — the statement itself is unconditional, which is
+// what keeps the compiler from merging two definitions of `dst` with a copy (kas_order_relax.h, mid_request)
+template <int IMM = 0>
+KAS_DEV void gload_u32_async_if(uint32_t& dst, const void* base, uint32_t voff, bool on) {
+  const uint64_t m = (uint64_t)__builtin_amdgcn_ballot_w64(on);
+  uint64_t saved;
+  asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %2\n\tglobal_load_dword %0, %3, %4 offset:%5\n\ts_mov_b64 exec, %1"
+               : "+v"(dst), "=&s"(saved) : "s"(m), "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+KAS_DEV void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+KAS_DEV void arrived(uint32_t& x) { asm volatile("" : "+v"(x)); }
 
 // 64-bit word written earlier by this wave (accept-mask scratch): force a vector load so the
 // value never comes from the scalar cache, which is not coherent with the wave's own stores.

@@ -1,7 +1,11 @@
 #!/bin/bash
-# scripts/trip_ab.sh NAME LIB [LIB ...]: configs[2] mix (1000 scenarios, alone and eight plans in flight) and configs[1]
-# through the given builds of the library (tools/ab_harness): kernel durations, in-flight rate, record checksums
+# scripts/trip_ab.sh NAME LIB...: tuning builds (variants/libkas_hip_LIB.so) through tools/ab_harness on one box, every slot its
+# own tables: kernel durations alone, the in-flight rate at 8 x 40 and 8 x 20 steps, record checksums (must be equal).
 O=gpurun_out/$1; shift; mkdir -p $O
-run() { local name=$1; shift; timeout 60 "$@" > $O/$name.log 2>&1; echo "exit $?" >> $O/$name.log; grep -v "^   kas_\|^exit 0\|generated in" $O/$name.log | cut -c1-250; }
-AB_INFLIGHT=8:20:3 run c3mix tools/ab_harness c3mix 1000 5 "$@"
-run c2 tools/ab_harness shape:10000:100:10:3 1 50 "$@"
+export GPU_MAX_HW_QUEUES=16 AB_DISTINCT=1
+LIBS=""; for v in "$@"; do LIBS="$LIBS variants/libkas_hip_$v.so"; done
+for round in 1 2; do
+  AB_INFLIGHT=8:40:3 timeout 300 tools/ab_harness c3mix 1000 3 $LIBS > $O/ab40_$round.log 2>&1; echo "exit $?" >> $O/ab40_$round.log
+  grep -E "fill .* us|in flight|records|exit" $O/ab40_$round.log | cut -c1-200
+done
+AB_INFLIGHT=8:20:5 timeout 300 tools/ab_harness c3mix 1000 3 $LIBS > $O/ab20.log 2>&1; grep -E "in flight" $O/ab20.log | cut -c1-200

@@ -1,0 +1,21 @@
+// tests/asm/relax_instances.hip — every instance of the relaxation-form order kernel and nothing else, for
+// tests/test_async_loads_asm.py: hipcc -S of this file (seconds; the whole library takes minutes), then
+// tools/check_async_loads.py over the assembly.  TEST INFRASTRUCTURE: the product builds csrc/kas_hip.hip.
+#define KAS_ABI_FN __host__ __device__ static inline
+#include <hip/hip_runtime.h>
+
+#include "kas_abi.h"
+#include "kas_plan_math.h"
+#include "kas_solver_body.h"
+
+template <int W, bool DUAL, bool CTX>
+__global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::order_relax<W, DUAL, CTX>(a, (int32_t)blockIdx.x, kas_lds);
+}
+template __global__ void kas_order_relax_kernel<2, false, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, true>(KasLaunch);

@@ -91,6 +91,8 @@ KAS_DEV int read_lane(int v, int uniform_lane) { return shfl(v, uniform_lane); }
 
 KAS_DEV int uniform(int v) { return v; }                  // (hardware: v_readfirstlane)
 
+template <class T>
+KAS_DEV T* uniform_ptr(T* p) { return p; }                  // (hardware: both halves through v_readfirstlane)
 KAS_DEV void sync() { rendezvous(K_SYNC); }
 KAS_DEV void lockstep() { rendezvous(K_LOCKSTEP); }
 KAS_DEV void wave_sync() { rendezvous(K_WAVESYNC); }
@@ -132,6 +134,22 @@ KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }
 KAS_DEV uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 KAS_DEV void lds_add_u32(uint32_t* p, uint32_t v) { *p += v; }
 KAS_DEV void lds_sub_u32(uint32_t* p, uint32_t v) { *p -= v; }
+
+// (hardware: global loads issued as inline assembly and waited for once per step, csrc/kas_wave.h; here they are loads)
+template <int IMM = 0>
+KAS_DEV void gload_u32_async(uint32_t& dst, const void* base, uint32_t voff) {
+  dst = *(const uint32_t*)((const char*)base + voff + IMM);
+}
+template <int IMM = 0>
+KAS_DEV void gload_u16_async(uint32_t& dst, const void* base, uint32_t voff) {
+  dst = (uint32_t)*(const uint16_t*)((const char*)base + voff + IMM);
+}
+template <int IMM = 0>
+KAS_DEV void gload_u32_async_if(uint32_t& dst, const void* base, uint32_t voff, bool on) {
+  if (on) dst = *(const uint32_t*)((const char*)base + voff + IMM);
+}
+KAS_DEV void wait_loads() {}
+KAS_DEV void arrived(uint32_t&) {}
 
 KAS_DEV uint32_t load_shared_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 KAS_DEV void store_shared_u32(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }

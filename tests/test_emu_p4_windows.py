@@ -43,7 +43,7 @@ def build_case():
     live = np.array([0, 1, 2, 3, 4, 5], dtype=np.int32)
     n_orph = 3 * 64
     P = n_orph
-    mid = np.full((P, 4), NONE, dtype=np.uint16)
+    mid = np.full((P, 3), NONE, dtype=np.uint16)
     mid[:, 0] = 6; mid[:, 1] = 7                       # two holders on racks 4, 5: any listed node is fine
     for p in (5, 2 * 64 + 9):                          # one orphan of window 0 and one of window 2: holders on racks 0, 1
         mid[p, 0] = 8; mid[p, 1] = 9
@@ -93,7 +93,7 @@ def random_case(rng):
     n = n_live + len(hold_racks)
     rack = np.concatenate([rng.integers(0, 3, size=n_live), hold_racks]).astype(np.int32)
     n_orph = int(rng.integers(300, 700))
-    mid = np.full((n_orph, 4), NONE, dtype=np.uint16)
+    mid = np.full((n_orph, 3), NONE, dtype=np.uint16)
     need_total = 0
     for p in range(n_orph):
         if rng.random() < 0.015:

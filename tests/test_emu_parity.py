@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows
+from emu_lib import NO_ORPHAN_RECS, NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows, last_recs
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_oracle_vs_literal import scenarios
@@ -83,6 +83,12 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu relaxation form, tiles of 64 rows")
+    assert last_recs() == (1 if RF == 3 else 0)             # lists 3 wide over tiles of 64 rows: orphan rows travel as records ...
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64 | NO_ORPHAN_RECS), "emu relaxation form, orphans through the mid rows")
+    assert last_recs() == 0                                 # ... unless the plan says no
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64 | NO_RTN_QUOTA), "emu tiles of 64 rows, quota drawn without the atomic-with-return")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64 | (1 << 8)), "emu tiles of 64 rows, one fill wavefront per scenario")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64 | 8), "emu tiles of 64 rows, chunk-count pass")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_128), "emu relaxation form, double tiles")
     assert_same_outputs(fb, want, emu_solve(fb, flags=NO_RTN_QUOTA), "emu fill, quota drawn without the atomic-with-return")
     assert_same_outputs(fb, want, emu_solve(fb, flags=1), "emu generic fill")
@@ -150,6 +156,7 @@ def test_emu_multi_topic_scenarios_without_context_io_use_cross_topic_tickets():
     assert_same_outputs(fb, want, emu_solve(fb), "emu multi-topic, relaxation form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu multi-topic tickets")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu multi-topic, relaxation form over tiles of 64 rows")
+    assert last_recs() == 1                                 # (every topic its own stretch of the record scratch, failed topics skipped)
     assert_same_outputs(fb, want, emu_solve(fb, flags=2), "emu multi-topic rounds")
     assert_same_outputs(fb, want, emu_solve(fb, flags=(2 << 12) | (2 << 8)), "emu multi-topic, 2 scenarios per wave")
 
@@ -569,3 +576,43 @@ def test_emu_many_rows_per_broker_keep_the_relaxation_form_up_to_16_bit_counts()
     assert rc == 0 and sh["relax_ok"] == 0 and sh["tickets_ok"] == 0
     assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu 70k rows per broker: round form")
     assert last_order_form() == 0
+
+
+def test_emu_orphan_records_next_to_everything_that_does_not_take_them():
+    """Round 5: lists 3 wide through the relaxation form over tiles of 64 rows move their orphan rows as 8-byte records
+    (pass B writes them, P4 completes them, the order kernel reads them: tests/.. KasLaunch::recs).  In ONE batch with the
+    records switched on: a scenario whose rows are not rack-diverse (the general fill completes its mid rows itself and
+    says "no records" in the info words), scenarios with three topics of which one fails (the topics behind it are
+    skipped, every topic has its own stretch of the record scratch), a topic 2 wide beside topics 3 wide (narrower rows
+    keep the mid-row path), rf raised so that EVERY row is an orphan, and a ragged last tile."""
+    rng = np.random.default_rng(5)
+    scs = []
+    N, R = 48, 8
+    racks = {b: "r%d" % (b % R) for b in range(N + 4)}
+    def topic(name, seed, P, rf, cyc=False):
+        cur = G.cyclic_assignment(P, N, rf, seed) if cyc else G.random_assignment(seed, P, N, R, rf)
+        return Topic(name, {p: cur[p].tolist() for p in range(P)}, rf)
+    scs.append(Scenario(brokers=[b for b in range(N) if b != 7], racks=racks,
+                        topics=[topic("t-a", 1, 1500, 3), topic("t-b", 2, 333, 2), topic("t-c", 3, 700, 3)]))
+    scs.append(Scenario(brokers=[b for b in range(N) if b != 13], racks=racks, topics=[topic("u-a", 7, 2100, 3), topic("u-b", 5, 90, 3)]))
+    # rows made for racks b mod 8 on a cluster whose racks are b mod 7: co-racked replicas -> the general fill, inside a launch
+    # that writes records for the others
+    scs.append(Scenario(brokers=list(range(N)), racks={b: "q%d" % (b % 7) for b in range(N)}, topics=[topic("v-a", 6, 800, 3)]))
+    # rf 2 -> 3 at lists 3 wide: every row needs one more replica (KTA:57, Q6)
+    cur2 = G.random_assignment(9, 900, N, R, 2)
+    scs.append(Scenario(brokers=list(range(N)), racks=racks, topics=[Topic("w-a", {p: cur2[p].tolist() for p in range(900)}, 3)]))
+    # a decommission that cannot be absorbed: the first topic fails in P4, the next one is skipped
+    few = list(range(6))
+    cur3 = G.cyclic_assignment(400, 6, 3, 0)
+    scs.append(Scenario(brokers=few[:5], racks={b: "abc"[b % 3] for b in few},
+                        topics=[Topic("x-a", {p: cur3[p].tolist() for p in range(400)}, 3), topic("x-b", 11, 200, 3)]))
+    fb = flatten(scs)
+    want = oracle_solve(fb)
+    st = want.topic_results["status"]
+    assert st.tolist() == [0, 0, 0, 0, 0, 0, 0, 1, 6], st.tolist()
+    assert want.topic_results["moved_replicas"][6] == 900      # (w-a: every row an orphan)
+    assert want.topic_results["moved_replicas"][5] > 0         # (v-a: the general fill moved something)
+    for flags, recs in ((RELAX_TILES_64, 1), (RELAX_TILES_64 | NO_ORPHAN_RECS, 0), (RELAX_TILES_64 | NO_RTN_QUOTA, 1),
+                        (RELAX_TILES_64 | (2 << 8), 1), (0, 0), (TICKET_ORDER, 0), (2, 0)):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), "emu, flags %#x" % flags)
+        assert last_recs() == recs, hex(flags)

@@ -14,6 +14,7 @@
 //   AB_INFLIGHT=K:STEPS:REPEATS  in addition: K plans on K streams (own out tables, the same cur), STEPS solves round-robin
 //                                between two synchronisations, REPEATS times: scenarios/s by the host clock (bench.py's regime)
 //   AB_FLAGS=n                   kas_plan_set_flags(n) on every plan (KAS_PLAN_* of include/kas_abi.h)
+//   AB_DISTINCT=1                in flight: every slot its own copy of the cur table (as bench.py's slots have)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -223,6 +224,11 @@ int main(int argc, char** argv) {
         if (api.plan_create(ctx, &bd, &plans[k]) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
         if (flags) api.set_flags(plans[k], flags);
         HIP_OK(hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking));
+        if (getenv("AB_DISTINCT") && k > 0) {                    // every slot its own copy of the cur table (bench.py's regime: no slot
+          int32_t* c = nullptr;                                  // finds another slot's rows in a cache)
+          HIP_OK(hipMalloc(&c, 4 * cells)); HIP_OK(hipMemcpy(c, d_cur, 4 * cells, hipMemcpyDeviceToDevice));
+          tabs[k].cur = c;
+        }
         int32_t* o = nullptr; kas_topic_result* tr = nullptr; kas_scenario_result* srk = nullptr;
         HIP_OK(hipMalloc(&o, 4 * cells)); HIP_OK(hipMalloc(&tr, sizeof(kas_topic_result) * S * T)); HIP_OK(hipMalloc(&srk, sizeof(kas_scenario_result) * S));
         tabs[k].out = o; tabs[k].topic_results = tr; tabs[k].scenario_results = srk;
@@ -249,6 +255,7 @@ int main(int argc, char** argv) {
         slots_ok = slots_ok && sk == sum;
         api.plan_destroy(plans[k]);
         HIP_OK(hipStreamDestroy(streams[k]));
+        if (tabs[k].cur != d_cur) HIP_OK(hipFree((void*)tabs[k].cur));
         HIP_OK(hipFree(tabs[k].out)); HIP_OK(hipFree(tabs[k].topic_results)); HIP_OK(hipFree(tabs[k].scenario_results));
       }
       printf("  (every slot's records %s)\n", slots_ok ? "equal the batch's" : "DIFFER");
