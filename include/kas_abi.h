@@ -320,9 +320,6 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_NO_RTN_QUOTA  rack-diverse fill with per-chunk histograms: draw a node's quota with separate LDS atomics,
  *                          reads and a ranking of the tiles in which it runs out, instead of one atomic-with-return
  *                          per list position
- *   KAS_PLAN_NO_ORPHAN_RECS lists 3 wide through the relaxation form: first fit gathers its orphan rows from the
- *                          intermediate rows and scatters its placements into them, as rounds 2-4 did, instead of
- *                          moving them as 8-byte records the order kernel reads (testing / comparison)
  *   KAS_PLAN_WAVES(n)      wavefronts per scenario workgroup of the fill kernel: 1, 2 or 4
  *   KAS_PLAN_GROUPS(n)     scenarios per wavefront of the ticket-form order kernel: 1, 2 or 4
  *                          (0 = the plan's choice for either) */
@@ -334,7 +331,6 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_RELAX_TILES(n) (((uint32_t)(n) & 3u) << 17)
 #define KAS_PLAN_NO_RTN_QUOTA 0x200000u
-#define KAS_PLAN_NO_ORPHAN_RECS 0x800000u
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
 #define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)
 int kas_plan_set_flags(kas_plan* plan, uint32_t flags);

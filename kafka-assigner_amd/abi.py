@@ -36,7 +36,6 @@ KAS_PLAN_TICKET_ORDER = 0x10000
 KAS_PLAN_RELAX_TILES_64 = 0x20000     # KAS_PLAN_RELAX_TILES(1)
 KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)
 KAS_PLAN_NO_RTN_QUOTA = 0x200000
-KAS_PLAN_NO_ORPHAN_RECS = 0x800000    # orphan rows through the mid rows (rounds 2-4) instead of as 8-byte records
 
 STATUS_NAMES = {
     KAS_OK: "OK",

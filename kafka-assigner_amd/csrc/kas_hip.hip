@@ -320,7 +320,7 @@ struct kas_plan {
   int32_t n_scenarios, n_topics;
   // device copies and scratch owned by the plan (grow-only: a plan can be rebuilt for another batch)
   KasBuf b_scen, b_topics, b_node_id, b_node_rack, b_accmask_off, b_accmask, b_orph_off, b_orph, b_perm, b_stats,
-         b_ord_flag, b_sp_hist, b_sp_quota, b_sp_node, b_sp_flag, b_sp_oc, b_recs, b_rec_off;
+         b_ord_flag, b_sp_hist, b_sp_quota, b_sp_node, b_sp_flag, b_sp_oc;
   uint64_t* allocs;             // allocation counter to report to (the context's, or NULL)
   int single_topic;             // every scenario has exactly one topic
   int32_t sp_alloc_chunks;      // chunks per scenario the spread-fill scratch is sized for
@@ -467,7 +467,7 @@ void kas_plan_destroy(kas_plan* p) {
   if (p->last_slot >= 0) (void)hipEventSynchronize(p->ev_stop[p->last_slot]);
   for (KasBuf* b : {&p->b_scen, &p->b_topics, &p->b_node_id, &p->b_node_rack, &p->b_accmask_off, &p->b_accmask,
                     &p->b_orph_off, &p->b_orph, &p->b_perm, &p->b_stats, &p->b_ord_flag, &p->b_sp_hist, &p->b_sp_quota,
-                    &p->b_sp_node, &p->b_sp_flag, &p->b_sp_oc, &p->b_recs, &p->b_rec_off})
+                    &p->b_sp_node, &p->b_sp_flag, &p->b_sp_oc})
     kas_buf_free(b);
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
@@ -578,7 +578,6 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
       {&p->b_node_rack, batch->node_rack, sizeof(int32_t) * NP, "node racks"},
       {&p->b_accmask_off, sh.accmask_off.data(), sizeof(int64_t) * sh.accmask_off.size(), "accept-mask offsets"},
       {&p->b_orph_off, sh.orph_off.data(), sizeof(int64_t) * sh.orph_off.size(), "orphan-list offsets"},
-      {&p->b_rec_off, sh.rec_off.data(), sizeof(int64_t) * sh.rec_off.size(), "orphan-record offsets"},
   };
   for (const Up& u : ups) {
     if ((rc = kas_buf_reserve(u.b, u.bytes, p->allocs, u.what)) != KAS_E_OK) return rc;
@@ -590,10 +589,6 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
       (rc = kas_buf_reserve(&p->b_perm, sizeof(int32_t) * (S + 1), p->allocs, "scenario-order scratch")) != KAS_E_OK ||
       (rc = kas_buf_reserve(&p->b_ord_flag, sizeof(int32_t) * (S + 1), p->allocs, "order-form flags")) != KAS_E_OK ||
       (rc = kas_buf_reserve(&p->b_stats, stats_bytes, p->allocs, "stats buffer")) != KAS_E_OK)
-    return rc;
-  // orphan records: for batches that may take them (kas_orphan_recs; the flags of a later kas_plan_set_flags only switch them off)
-  if (kas_orphan_recs(sh, sh.relax_ok != 0, 0u, 0) &&
-      (rc = kas_buf_reserve(&p->b_recs, sizeof(int32_t) * (size_t)(sh.rec_ints + 64), p->allocs, "orphan-record scratch")) != KAS_E_OK)
     return rc;
   KAS_HIP_TRY(hipMemsetAsync(p->b_stats.p, 0, stats_bytes, st));
   if ((rc = kas_plan_spread_scratch(p)) != KAS_E_OK) return rc;
@@ -663,13 +658,6 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   return lp;
 }
 
-// orphan rows as records in this plan's next solve (kas_orphan_recs)
-static bool kas_plan_orphan_recs(const kas_plan* p, const KasLaunchPlan& lp) {
-  const uint32_t f = (p->flags & (KAS_FLAG_GENERIC_FILL | KAS_FLAG_NO_ORPHAN_RECS)) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
-                     (kas_relax_double_tiles(p->flags, p->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u);
-  return p->b_recs.p != nullptr && kas_orphan_recs(p->shape, lp.relax, f, kas_plan_spread_chunks(p));
-}
-
 int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (!p || !buf || n <= 0) return set_error(KAS_E_INVALID_ARG, "NULL argument");
   const KasLaunchPlan lp = kas_launch_plan(p);
@@ -679,9 +667,8 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
                              ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
                              : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax)
-    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s] grid=%ux%u lds=%zu%s", p->Wc,
-             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
-             kas_plan_orphan_recs(p, lp) ? ", orphan rows as records" : "", lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
+    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows] grid=%ux%u lds=%zu%s", p->Wc,
+             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
   else if (lp.tickets)
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
@@ -738,8 +725,6 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
             ((p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA)) ? KAS_FLAG_LANE_ORDER : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
-  a.recs = (int32_t*)p->b_recs.p; a.rec_off = (const int64_t*)p->b_rec_off.p;
-  if (kas_plan_orphan_recs(p, lp)) a.flags |= KAS_FLAG_ORPHAN_RECS;
   const int slot = p->timer_next;
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
   const int32_t chunks = kas_plan_spread_chunks(p);
@@ -893,7 +878,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   if (rc != KAS_E_OK) return rc;
   if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_RELAX_TILES: 0 (by batch size), 1 (64 rows) or 2 (double tiles)");
-  p->flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_NO_ORPHAN_RECS) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
+  p->flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
   // plan may still be in flight on the old scratch

@@ -315,13 +315,10 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   uint64_t digest = 0;
   int32_t n_tiles = 0, n_evals = 0, n_slow = 0;             // (wave-uniform)
   bool stuck = false;
-  const int32_t* rec_next = (a.flags & KAS_FLAG_ORPHAN_RECS) ? a.recs + a.rec_off[s] : nullptr;   // the next topic's orphan records
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
-    const kas_topic_desc td = a.topics[ti];
-    const int32_t* const rec_topic = rec_next;
-    if (rec_next) rec_next += kas_rec_topic_ints(td.n_partitions);
     if (a.topic_results[ti].status != KAS_OK) continue;     // (a failed or skipped topic emits nothing)
+    const kas_topic_desc td = a.topics[ti];
     const int32_t P = td.n_partitions, ow = td.out_width;
     if (P <= 0) continue;
     int32_t* out = a.out + td.out_off;
@@ -370,64 +367,17 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
         for (int q = 0; q < 3; ++q) pend.id[b][q] = 0u;
       }
-      // Orphan records (KasLaunch::recs; rows of the batch's width, tiles of 64 rows, no Context).  The fill kernel left a
-      // KAS_MID_ORPHAN cell in every orphan row and per tile an info word — first record | records << 25 —, P4 completed
-      // the records: the orphan rows of a tile take their cells from them (in row order = record order).  The info word
-      // is asked for three tiles ahead, the tile's records two tiles ahead — when its info has arrived —, both beside
-      // the mid rows at the step's one wait; the rows are put right where they arrive, so nothing else lives across a step.
-      constexpr bool RECS_OK = FULLW && W == 3 && !DUAL && !CTX;
-      const bool use_recs = RECS_OK && rec_topic != nullptr;   // (wave-uniform)
-      const int32_t* uinfo = kasw::uniform_ptr(rec_topic);
-      const int32_t* urec = uinfo + ((nt + 1) & ~1);
-      uint32_t info_nx = 0u, rec_nx[2] = {0u, 0u};
-      uint32_t info_1 = 0u;                                   // info word of the tile whose rows arrive at the next wait
-      auto request_info = [&](int32_t t) {
-        kasw::gload_u32_async_if<0>(info_nx, uinfo, (uint32_t)(t < nt ? t : nt - 1) << 2, use_recs);
-      };
-      auto request_recs = [&](uint32_t info) {
-        const uint32_t off = ((info & (KAS_REC_ROWS_LIMIT - 1)) + (uint32_t)lane) << 3;
-        const bool on = use_recs && (uint32_t)lane < (info >> 25);
-        kasw::gload_u32_async_if<0>(rec_nx[0], urec, off, on);
-        kasw::gload_u32_async_if<4>(rec_nx[1], urec, off, on);
-      };
-      // the rows of a tile as they arrived -> with its orphan rows taken from the records that arrived with them
-      auto merge_recs = [&](MidRaw<W>& r, uint32_t info) {
-        const uint32_t c0 = r.w[0] & 0xffffu, c1 = r.w[0] >> 16, c2 = r.w[1] & 0xffffu;
-        const bool orphan = c0 == KAS_MID_ORPHAN || c1 == KAS_MID_ORPHAN || c2 == KAS_MID_ORPHAN;
-        const uint64_t om = kasw::ballot(orphan);
-        if ((uint32_t)kasw::popc(om) != (info >> 25)) stuck = true;   // (the fill kernel's count and its marks disagree: never)
-        if (om != 0ull) {                                     // (wave-uniform)
-          const int32_t rank = kasw::count_below(om);
-          const uint32_t s0 = (uint32_t)kasw::shfl((int)rec_nx[0], rank), s1 = (uint32_t)kasw::shfl((int)rec_nx[1], rank);
-          r.w[0] = orphan ? s0 : r.w[0];
-          r.w[1] = orphan ? (s1 & 0xffffu) : r.w[1];
-        }
-      };
 #pragma unroll
       for (int b = 0; b < NB; ++b) request_tile(nx[b], b);
-      if constexpr (RECS_OK) request_info(0);
       kasw::wait_loads();
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+      for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
-      if constexpr (RECS_OK) {
-        kasw::arrived(info_nx);
-        const uint32_t info_0 = use_recs ? (uint32_t)kasw::uniform((int)info_nx) : 0u;
-        request_recs(info_0);
-        request_info(1);
-        kasw::wait_loads();
-        kasw::arrived(rec_nx[0]); kasw::arrived(rec_nx[1]); kasw::arrived(info_nx);
-        raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(0));
-        if (use_recs) merge_recs(raw[0], info_0);
-        info_1 = (use_recs && 1 < nt) ? (uint32_t)kasw::uniform((int)info_nx) : 0u;
-      } else {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) raw[b] = mid_take<W, FULLW>(nx[b], ow, row_exists(b));
+        raw[b] = mid_take<W, FULLW>(nx[b], ow, row_exists(b));
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) request_tile(nx[b], NB + b);
-      if constexpr (RECS_OK) { request_recs(info_1); request_info(2); }
       for (int32_t tile = 0; tile < nt;) {
         const int32_t p = (tile << 6) + lane;
         const bool active = p < P;
@@ -584,14 +534,9 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
           for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
         }
-        // ... the next rows move up (their orphan rows from the records that came with them),
+        // ... the next rows move up,
         if constexpr (NB == 1) {
           raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile));
-          if constexpr (RECS_OK) {
-            kasw::arrived(rec_nx[0]); kasw::arrived(rec_nx[1]); kasw::arrived(info_nx);
-            if (use_recs) merge_recs(raw[0], info_1);
-            info_1 = (use_recs && tile + 1 < nt) ? (uint32_t)kasw::uniform((int)info_nx) : 0u;   // (of tile + 1: arrived just now)
-          }
         } else {
           if (step == 2) {
             raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile)); raw[1] = mid_take<W, FULLW>(nx[1], ow, row_exists(tile + 1));
@@ -611,11 +556,9 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
         pend.p = p; pend.n = req_n;
 #pragma unroll
         for (int b = 0; b < NB; ++b) request_tile(nx[b], tile + NB + b);
-        if constexpr (RECS_OK) { request_recs(info_1); request_info(tile + 2); }
       }
       // the topic's last rows (and no request is left outstanding: its register would be written behind our back)
       kasw::wait_loads();
-      if constexpr (RECS_OK) { kasw::arrived(rec_nx[0]); kasw::arrived(rec_nx[1]); kasw::arrived(info_nx); }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll

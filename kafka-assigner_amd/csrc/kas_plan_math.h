@@ -44,11 +44,6 @@ struct KasLaunch {
   int32_t* sp_flag;             // [S]                   != 0: the scenario takes the one-workgroup kernel instead
   int32_t* sp_oc;               // [S][chunks + 2]       orphans per chunk, then moved replicas / partitions
   int32_t sp_chunks;            // chunks per scenario (0: no spread fill in this launch)
-  // orphan records (KAS_FLAG_ORPHAN_RECS, round 5): what pass B knows about an orphan row — its holders so far — goes into an
-  // 8-byte record, P4 completes the record, and the relaxation-form order kernel takes the row from there: P4 neither
-  // gathers orphan rows from the mid rows nor scatters its placements into them
-  int32_t* recs;                // scratch: per scenario, per topic: info[tiles] then records[2 x rows]  (kas_rec_topic_ints)
-  const int64_t* rec_off;       // [n_scenarios] offset of the scenario's region in int32 elements
   int32_t n_scenarios;
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
   int32_t idmap_entries;        // entries of the direct broker-id -> node-index table
@@ -71,7 +66,6 @@ struct KasLaunch {
 #define KAS_FLAG_RELAX_TILES_128 0x40000u // relaxation form: double tiles whatever the batch size (KAS_PLAN_RELAX_TILES(2))
 #define KAS_FLAG_RELAX_DUAL      0x80000u // set by the launcher (kas_relax_double_tiles): double tiles in this launch
 #define KAS_FLAG_LANE_ORDER      0x100000u // set by the launcher: the LDS hands the lanes of one atomic instruction out in lane order here (self-test)
-#define KAS_FLAG_ORPHAN_RECS     0x400000u // set by the launcher (kas_orphan_recs): orphan rows travel as records, see KasLaunch::recs
 #define KAS_FLAG_NO_RTN_QUOTA    0x200000u // KAS_PLAN_NO_RTN_QUOTA: the fill draws its quota without the atomic-with-return (testing / comparison)
 #define KAS_RELAX_DUAL_BELOW 512         // batches of fewer scenarios than this take double tiles unless told otherwise
 
@@ -293,15 +287,6 @@ KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {
   return kas_align16(kas_align16(4 * n * kas_cnt_stride(W)) + 8 * n + 64);
 }
 
-// Orphan records: ints of a topic's part of the record scratch — one info word per 64-row tile (first record of the tile's
-// orphans | their number << 25), then two words per row slot (a record: cells 0, 1 | cell 2, meta << 16).
-#define KAS_REC_ROWS_LIMIT (1 << 25)
-#define KAS_MID_ORPHAN 0xfffeu      // mid-row cell: "this row is an orphan, its cells are in its record"
-KAS_ABI_FN int64_t kas_rec_topic_ints(int32_t n_partitions) {
-  const int64_t tiles = ((int64_t)(n_partitions > 0 ? n_partitions : 0) + 63) / 64;
-  return ((tiles + 1) & ~1ll) + 2 * 64 * tiles;               // (info padded to an even count: records stay 8-byte aligned)
-}
-
 // widths the kernels are instantiated for; a batch uses the smallest one >= its widest list
 KAS_ABI_FN int32_t kas_width_class(int32_t W) { return W <= 2 ? 2 : W <= 5 ? W : 8; }
 
@@ -329,8 +314,6 @@ struct KasShape {
   int64_t accmask_words = 0;
   std::vector<int64_t> orph_off;      // per scenario, in int32 elements
   int64_t orph_ints = 0;
-  std::vector<int64_t> rec_off;       // per scenario, in int32 elements (orphan records, kas_rec_topic_ints per topic)
-  int64_t rec_ints = 0;
   int32_t NW = 1;                     // wavefronts per scenario workgroup of the fill kernel
   int32_t G = 1;                      // lane groups (= scenarios) per wavefront, ticket form
   int64_t algorithmic_bytes = 0;
@@ -340,15 +323,6 @@ struct KasShape {
   int64_t cur_lo = 0, out_lo = 0, aux_lo = 0, ctx_lo = 0;
   KasLds lds{};
 };
-
-// Orphan records for this launch?  Lists 3 wide through the relaxation form with tiles of 64 rows and no Context (the
-// round form behind a Context does not read records), the one-workgroup fill kernel (the spread fill moves its chunk
-// lists together), topics whose rows an info word can index.  `launch_flags`: KasLaunch::flags of the solve.
-#define KAS_FLAG_NO_ORPHAN_RECS 0x800000u   // KAS_PLAN_NO_ORPHAN_RECS: P4 gathers and scatters mid rows as in rounds 2-4 (testing / comparison)
-static inline bool kas_orphan_recs(const KasShape& s, bool relax, uint32_t launch_flags, int32_t spread_chunks) {
-  return relax && s.Wc == 3 && !s.any_ctx && !(launch_flags & (KAS_FLAG_RELAX_DUAL | KAS_FLAG_GENERIC_FILL | KAS_FLAG_NO_ORPHAN_RECS)) &&
-         spread_chunks == 0 && s.max_partitions < KAS_REC_ROWS_LIMIT;
-}
 
 // Fused histogram layout of the rack-diverse fill (kas_fill_lds_layout with_x = 2): lists up to 3 wide
 // (the instantiated variants), more than one chunk, a chunk's rows countable in uint16, and the larger
@@ -407,7 +381,6 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   s.cur_lo = s.out_lo = s.aux_lo = s.ctx_lo = kNone;
   s.accmask_off.assign((size_t)b->n_scenarios, 0);
   s.orph_off.assign((size_t)b->n_scenarios, 0);
-  s.rec_off.assign((size_t)b->n_scenarios, 0);
   int64_t max_range_fit = 0;
   for (int32_t i = 0; i < b->n_scenarios; ++i) {
     const kas_scenario_desc& sd = b->scenarios[i];
@@ -487,8 +460,6 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     s.accmask_words += words > 0 ? words : 1;
     s.orph_off[(size_t)i] = s.orph_ints;
     s.orph_ints += rows > 0 ? rows : 64;
-    s.rec_off[(size_t)i] = s.rec_ints;
-    for (int32_t k = 0; k < sd.topic_count; ++k) s.rec_ints += kas_rec_topic_ints(b->topics[sd.topic_begin + k].n_partitions);
   }
   if (s.cur_lo == kNone || s.cur_lo > s.cur_need) s.cur_lo = s.cur_need;
   if (s.out_lo == kNone || s.out_lo > s.out_need) s.out_lo = s.out_need;

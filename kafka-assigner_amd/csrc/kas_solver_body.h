@@ -357,7 +357,7 @@ KAS_DEV void store_u32_a2(uint16_t* p, uint32_t v) { reinterpret_cast<U32a2*>(p)
 KAS_DEV uint16_t* mid_base(int32_t* out, int32_t P, int32_t ow) {
   return (uint16_t*)(out + (int64_t)P * ow) - (int64_t)P * mid_width(ow);
 }
-KAS_DEV int32_t mid_to_index(uint32_t v) { return (v & 0x8000u) ? -1 : (int32_t)v; }   // (KAS_MID_NONE, KAS_MID_ORPHAN: no holder)
+KAS_DEV int32_t mid_to_index(uint32_t v) { return (v & 0x8000u) ? -1 : (int32_t)v; }   // (bit 15: KAS_MID_NONE — a node index is below 32768)
 
 // One mid row, as loaded: nothing is computed from the loaded values here, so a row read ahead of its
 // use (every consumer prefetches) does not make the wave wait for the load where it is issued.
@@ -400,8 +400,6 @@ struct TopicView {
   const int32_t* cur;
   uint16_t* mid;        // mid rows of the topic (at the end of its out region); mid_width(ow) uint16 each
   int32_t* orph;        // orphan row lists of this scenario (HBM scratch)
-  int32_t* rec;         // orphan records of this topic (KasLaunch::recs: info words, then the records), or nullptr: P4 works on the mid rows
-  int32_t rec_info;     // ints the info words take (tiles, padded to an even count)
   const int32_t* len_arr;
   const int32_t* inp_arr;
   const int32_t* pid_arr;
@@ -511,14 +509,11 @@ KAS_DEV void for_tile_batches(const TopicView& T, int32_t tile0, int32_t stride,
 // P3 for one row per lane (KAS:133-160): holders of the row from its accepted replicas, orphan
 // count, movement bookkeeping and the out row (node indices for now).
 // ---------------------------------------------------------------------------------------------
-// (mark: an orphan row's first empty cell becomes KAS_MID_ORPHAN — orphan records, KasLaunch::recs; cells01 / cell2: the row's
-// cells as they were stored, for its record)
 template <int W>
 KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t len,
                      const int32_t (&ids)[W], const int32_t (&idx)[W], uint32_t accbits,
                      int32_t& need, int32_t& hc, int32_t (&hrack)[W], int32_t& moved_r,
-                     int32_t& moved_p, const int32_t* racks = nullptr, bool mark = false,
-                     uint32_t* cells01 = nullptr, uint32_t* cell2 = nullptr) {
+                     int32_t& moved_p, const int32_t* racks = nullptr) {
   const bool active = p < T.P;
   int32_t hold[W];
 #pragma unroll
@@ -539,14 +534,6 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
   }
   const bool in_parts = active && (T.inp_arr ? T.inp_arr[p] != 0 : true);
   need = in_parts ? (T.rf - hc > 0 ? T.rf - hc : 0) : 0;   // KAS:151-157
-  if (mark) {
-#pragma unroll
-    for (int k = 0; k < W; ++k) hold[k] = (need > 0 && hc == k) ? (int32_t)KAS_MID_ORPHAN : hold[k];
-  }
-  if (cells01) {
-    *cells01 = ((uint32_t)hold[0] & 0xffffu) | ((W > 1 ? ((uint32_t)hold[W > 1 ? 1 : 0] & 0xffffu) : KAS_MID_NONE) << 16);
-    *cell2 = W > 2 ? ((uint32_t)hold[W > 2 ? 2 : 0] & 0xffffu) : KAS_MID_NONE;
-  }
 #if defined(KAS_TUNE_NO_MID_STORES)                          // (tuning builds: how much of the fill's time is its 8-byte row stores)
   if (false) {
 #else
@@ -924,9 +911,6 @@ KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const No
   const int lane = kasw::lane();
   int32_t* olist = T.orph + ((int64_t)t0 << 6);
   int32_t ocount = 0;
-  const bool recs = W == 3 && T.rec != nullptr;              // orphan records (wave-uniform)
-  uint32_t* recw = recs ? (uint32_t*)(T.rec + T.rec_info) : nullptr;
-  const int32_t rec0 = t0 << 6;                             // the chunk's first record: its list's place, as in olist
   for_tiles<W>(T, t0, 1, t1, [&](int32_t tile, const int32_t (&ids)[W], int32_t len) {
     const int32_t p = (tile << 6) + lane;
     int32_t idx[W], nn[W], before[W];
@@ -998,20 +982,9 @@ KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const No
       }
     }
     int32_t need, hc, hrack[W];
-    uint32_t cells01 = 0u, cell2 = 0u;
-    p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p, nullptr, recs, &cells01, &cell2);
+    p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p);
     const uint64_t om = kasw::ballot(need > 0);
-    const int32_t slot = ocount + kasw::count_below(om);
-    if (need > 0) olist[slot] = p;
-    if (recs) {                                             // (wave-uniform)
-      // the orphan's record: its cells as stored (KAS_MID_ORPHAN where the first placement goes), holders so far, replicas missing
-      if (need > 0) {
-        RowWords<2> q;
-        q.v[0] = cells01; q.v[1] = cell2 | ((uint32_t)(hc | (need << 4)) << 16);
-        *reinterpret_cast<RowWords<2>*>(recw + 2 * (int64_t)(rec0 + slot)) = q;
-      }
-      if (lane == 0) T.rec[tile] = (rec0 + ocount) | (kasw::popc(om) << 25);   // the tile's info word: first record | records << 25
-    }
+    if (need > 0) olist[ocount + kasw::count_below(om)] = p;
     ocount += kasw::popc(om);
   });
   return ocount;
@@ -1062,8 +1035,8 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
 #pragma unroll
   for (int w = 0; w < NW; ++w) { oc[w] = L.ctl[KAS_CTL_OC + w]; total += oc[w]; }
   // row index of the g-th orphan of the topic (chunk lists concatenated), or -1 past the end
-  // place of the g-th orphan of the topic in the chunk lists (= in the records), or -1 past the end
-  auto orphan_slot = [&](int32_t g) -> int32_t {
+  // row index of the g-th orphan of the topic (chunk lists concatenated), or -1 past the end
+  auto orphan_row = [&](int32_t g) -> int32_t {
     int32_t w = 0, base = 0;
 #pragma unroll
     for (int k = 0; k < NW - 1; ++k) {
@@ -1071,28 +1044,9 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
       base += next ? oc[k] : 0;
       w += next ? 1 : 0;
     }
-    return g < total ? (chunk_begin<NW>(T.nt, w) << 6) + (g - base) : -1;
-  };
-  // Orphan records (round 5): the window's rows come as 8-byte records pass B wrote (coalesced: 64 consecutive records) and
-  // go back into them completed — no gather from the mid rows, no 2-byte scatter into them; the order kernel takes these
-  // rows from the records.  Without records `p` is the row, with them it is the record's place.
-  const bool recs = W == 3 && T.rec != nullptr;              // (wave-uniform)
-  uint32_t* recw = recs ? (uint32_t*)(T.rec + T.rec_info) : nullptr;
-  auto orphan_row = [&](int32_t g) -> int32_t {
-    const int32_t slot = orphan_slot(g);
-    return (slot >= 0 && !recs) ? T.orph[slot] : slot;
+    return g < total ? T.orph[((int64_t)chunk_begin<NW>(T.nt, w) << 6) + (g - base)] : -1;
   };
   auto row_cells = [&](int32_t p) -> MidRaw<W> {
-    if (recs) {
-      MidRaw<W> raw;
-#pragma unroll
-      for (int k = 0; k < W; ++k) raw.w[k] = 0xffffffffu;
-      if (p >= 0) {
-        const RowWords<2> q = *reinterpret_cast<const RowWords<2>*>(recw + 2 * (int64_t)p);
-        raw.w[0] = q.v[0]; raw.w[1] = q.v[1] | 0xffff0000u;
-      }
-      return raw;
-    }
     return mid_load_raw<W>(T.mid, T.ow, p >= 0 ? p : 0, p >= 0);
   };
   const int32_t n_win = (total + 63) >> 6;
@@ -1179,8 +1133,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
             if (wm != 0) {
               const int32_t rank = kasw::count_below(wm);
               if (want && rank < slots[u]) {               // accept (KAS:178-181)
-                if (recs) put<W>(c_cur, hc, n[u]);
-                else T.mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
+                T.mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
                 put<W>(hr, hc, rk[u]);
                 hc += 1;
                 need -= 1;
@@ -1207,16 +1160,9 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
         const uint64_t left = kasw::ballot(need > 0);
         fail_win = w;
         fail_row = kasw::shfl(p, left != 0 ? kasw::first_lane(left) : 0);
-        if (recs && fail_row >= 0) fail_row = T.orph[fail_row];   // (the record's place -> the row)
       }
       if (lane == 0) prog[wave] = (uint64_t)(uint32_t)(w + 1) << 32;
       break;
-    }
-    if (recs && p >= 0) {                                  // the completed row goes back into its record
-      RowWords<2> q;
-      q.v[0] = ((uint32_t)c_cur[0] & 0xffffu) | (((uint32_t)c_cur[1] & 0xffffu) << 16);
-      q.v[1] = ((uint32_t)c_cur[W > 2 ? 2 : 0] & 0xffffu) | 0xffff0000u;
-      *reinterpret_cast<RowWords<2>*>(recw + 2 * (int64_t)p) = q;
     }
     // done: full nodes at the front of the live list need not be looked at again
     if (lane == 0) {
@@ -1290,11 +1236,10 @@ KAS_DEV void sort_holders(const int32_t (&cells)[W], int32_t (&h)[W], int32_t& L
 // the whole workgroup.  Leaves the out rows holding node indices (holders in acceptance order,
 // -1 padded); the order kernel turns them into the final preference lists.
 // ---------------------------------------------------------------------------------------------
-// (rec_topic: the topic's part of the orphan-record scratch when the launch uses records, else nullptr)
 template <int W, int NW>
 KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, const LdsView& L,
                                 const NodeMap& nm, const int32_t* g_node_id, const int32_t* g_node_rack,
-                                uint64_t* accmask, int32_t* orph, int32_t* rec_topic, int64_t (&st)[8]) {
+                                uint64_t* accmask, int32_t* orph, int64_t (&st)[8]) {
   constexpr int NT = 64 * NW;
   const int lane = kasw::lane();
   const int tid = kasw::tid();
@@ -1304,7 +1249,6 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   TopicView T;
   T.cur = a.cur + td.cur_off;
   T.orph = orph;
-  T.rec = nullptr; T.rec_info = 0;
   T.len_arr = td.cur_len_off >= 0 ? a.aux + td.cur_len_off : nullptr;
   T.inp_arr = td.in_partitions_off >= 0 ? a.aux + td.in_partitions_off : nullptr;
   T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
@@ -1381,12 +1325,6 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
       for (int32_t i = tid; i < N; i += NT) lds_load(L, i) = 0;
       kasw::sync();
     }
-  }
-  // orphan records: rows 3 wide through the rack-diverse form; every other topic says "no records" in its info words
-  // (the general form's P3 / P4 complete the mid rows themselves)
-  if (rec_topic != nullptr) {                                // (workgroup-uniform)
-    if (fast && W == 3 && T.ow == W) { T.rec = rec_topic; T.rec_info = (T.nt + 1) & ~1; }
-    else for (int32_t i = tid; i < T.nt; i += NT) rec_topic[i] = 0;
   }
   int32_t moved_r = 0, moved_p = 0;
   if (fast) {
@@ -1555,21 +1493,18 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
   st[0] += kasw::clock_ticks() - t_begin;
   uint64_t* accmask = a.accmask + a.accmask_off[s];
   int32_t* orph = a.orph + a.orph_off[s];
-  int32_t* rec_next = (a.flags & KAS_FLAG_ORPHAN_RECS) ? a.recs + a.rec_off[s] : nullptr;   // the next topic's records
   int32_t scen_status = KAS_OK, fail_topic = -1, fail_part = -1;
   int32_t moved_r = 0, moved_p = 0;
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
     const kas_topic_desc td = a.topics[ti];
-    int32_t* const rec_topic = rec_next;
-    if (rec_next) rec_next += kas_rec_topic_ints(td.n_partitions);
     TopicOutcome o;
     o.status = KAS_OK; o.fail_partition = -1; o.moved_replicas = 0; o.moved_partitions = 0;
     if (scen_status != KAS_OK) o.status = KAS_SKIPPED;                 // KAG:173-184 aborted
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = fill_topic<W, NW>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph, rec_topic, st);
+    else o = fill_topic<W, NW>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph, st);
     kasw::sync();
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding
@@ -1637,7 +1572,6 @@ KAS_DEV SpreadTopic spread_topic(const KasLaunch& a, int32_t s) {
   TopicView& T = S.T;
   T.cur = a.cur + td.cur_off;
   T.orph = a.orph + a.orph_off[s];
-  T.rec = nullptr; T.rec_info = 0;                          // (the spread fill moves its chunk lists together: no orphan records)
   T.len_arr = nullptr; T.inp_arr = nullptr;
   T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
   T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;

@@ -264,7 +264,6 @@ static long g_last_queue_rows = 0;
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
 static int g_last_order_form = 0;   // 1: ticket form (lists <= 3 wide), 2: wide ticket form, 3: relaxation form, 0: round form (the last solve's plan)
-static int g_last_recs = 0;         // the last solve's fill wrote orphan records (KAS_FLAG_ORPHAN_RECS)
 static long g_last_relax_tiles = 0, g_last_relax_evals = 0, g_last_relax_slow = 0;   // relaxation form: tiles, evaluations, tiles off the straight-line path
 static int g_last_flagged = 0; // scenarios a ticket form left to the round form (Context counters too large for its fields)
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
@@ -330,15 +329,6 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   g_last_spread = 0;
   const int32_t CH = (sh.NW == 4 && sh.Wc >= 3 && sh.Wc <= 5 && !(flags & KAS_FLAG_GENERIC_FILL))
                          ? kas_spread_chunks(sh, b->n_scenarios, kas_batch_single_topic(b), (flags & KAS_FLAG_SPREAD_FILL) != 0) : 0;
-  // orphan records (same decision as kas_solve_device)
-  std::vector<int32_t> recs;
-  a.recs = nullptr; a.rec_off = sh.rec_off.data();
-  if (kas_orphan_recs(sh, relax, a.flags | (flags & KAS_FLAG_NO_ORPHAN_RECS), CH)) {
-    recs.assign((size_t)sh.rec_ints + 64, (int32_t)0xDEADBEEF);
-    a.recs = recs.data();
-    a.flags |= KAS_FLAG_ORPHAN_RECS;
-  }
-  g_last_recs = a.recs != nullptr ? 1 : 0;
   std::vector<int32_t> sp_hist, sp_quota, sp_node, sp_flag, sp_oc;
   if (CH > 0) {
     const size_t S = (size_t)b->n_scenarios, NM = (size_t)sh.n_max;
@@ -547,9 +537,7 @@ int kas_emu_last_flagged(void) { return g_last_flagged; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_order_form(void) { return g_last_order_form; }
-// 1: the last solve's fill kernel wrote orphan records and the order kernel took the orphan rows from them
-extern "C" __attribute__((visibility("default")))
-int kas_emu_last_recs(void) { return g_last_recs; }
+
 
 // relaxation form of the last kas_emu_solve_batch: out[0..2] = tiles, evaluations, tiles off the straight-line path
 extern "C" __attribute__((visibility("default")))
@@ -598,7 +586,7 @@ int kas_emu_p4_unit(int32_t n_nodes, const int32_t* load, const int32_t* rack, i
   r.L.ctl[KAS_CTL_OC] = n_orphans;                               // one list: chunk 0 holds every orphan
   r.L.ctl[KAS_CTL_LIVE] = live_count;
   memset(&r.T, 0, sizeof(r.T));
-  r.T.orph = orphan_rows; r.T.mid = mid; r.T.rec = nullptr; r.T.rec_info = 0;
+  r.T.orph = orphan_rows; r.T.mid = mid;
   r.T.P = P; r.T.cw = 3; r.T.rf = 3; r.T.ow = 3; r.T.nt = (P + 63) >> 6; r.T.N = n_nodes; r.T.cap = cap;
   r.live_count = live_count; r.fail_row = -1;
   if (kasw::run_block(run_p4_unit, &r, 4) != 0) return -100;

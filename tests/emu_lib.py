@@ -221,18 +221,10 @@ def last_order_form() -> int:
     return int(L.kas_emu_last_order_form())
 
 
-def last_recs() -> int:
-    """1: the last solve moved its orphan rows as records (KAS_FLAG_ORPHAN_RECS)"""
-    L = lib()
-    L.kas_emu_last_recs.restype = C.c_int
-    return int(L.kas_emu_last_recs())
-
-
 TICKET_ORDER = 0x10000     # KAS_PLAN_TICKET_ORDER: the ticket form where the relaxation form would run
 RELAX_TILES_64 = 0x20000   # KAS_PLAN_RELAX_TILES(1): relaxation form over tiles of 64 rows whatever the batch size
 RELAX_TILES_128 = 0x40000  # KAS_PLAN_RELAX_TILES(2): double tiles whatever the batch size
 NO_RTN_QUOTA = 0x200000    # KAS_PLAN_NO_RTN_QUOTA: the fill draws its quota without the atomic-with-return
-NO_ORPHAN_RECS = 0x800000  # KAS_PLAN_NO_ORPHAN_RECS: P4 gathers / scatters the mid rows instead of moving orphan rows as records
 
 
 def last_relax_stats():
