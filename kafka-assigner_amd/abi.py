@@ -37,6 +37,11 @@ KAS_PLAN_RELAX_TILES_64 = 0x20000     # KAS_PLAN_RELAX_TILES(1)
 KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)
 KAS_PLAN_NO_RTN_QUOTA = 0x200000
 
+
+def KAS_PLAN_VERIFY_SAMPLE(k: int) -> int:
+    """relaxation form: k tiles per topic evaluated a second time row by row (include/kas_abi.h)"""
+    return (k & 0xff) << 24
+
 STATUS_NAMES = {
     KAS_OK: "OK",
     KAS_FAIL_UNASSIGNABLE: "FAIL_UNASSIGNABLE",

@@ -71,16 +71,19 @@ __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
   kas::order_scenario_rounds<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
-// Self-test of the one hardware property the relaxation form of P5 relies on and the ISA documents do not state:
-// the LDS serves the lanes of ONE ds_add_rtn instruction that name the same word in ascending lane order, so that
-// the value returned to lane i is the word before the instruction plus the addends of the lanes below i
-// (kas_wave.h, lds_add_rtn_u32).  Pseudo-random words of tables of 1 .. 1024 entries, a second wavefront keeping the
-// LDS busy; *bad counts the lane-operations that came back with anything else.  Run once per context.
-__global__ __launch_bounds__(128) void kas_lds_order_selftest_kernel(unsigned int* bad, int iters) {
+// Self-test of the one hardware property the relaxation form of P5 and the fill's quota draw rely on and the ISA documents do
+// not state: the LDS serves the lanes of ONE ds_add_rtn instruction that name the same word in ascending lane order, so
+// that the value returned to lane i is the word before the instruction plus the addends of the ACTIVE lanes below i
+// (kas_wave.h, lds_add_rtn_u32).  Round 5: in the regime the kernels live in — four wavefronts per workgroup of which
+// three hammer the same CU's LDS with atomics (with and without return, as the fill kernel's histogram and quota draws do),
+// enough workgroups to put several on every CU at once, and every other round under a random EXEC mask (the fill draws
+// its quota from inside a branch; round 4's test ran all 64 lanes always).  Pseudo-random words of tables of 1 .. 1024
+// entries; *bad counts the lane-operations that came back with anything else.
+__global__ __launch_bounds__(256) void kas_lds_order_selftest_kernel(unsigned int* bad, int iters) {
   __shared__ uint32_t tab[1024];
-  __shared__ uint32_t noise[1024];
+  __shared__ uint32_t noise[2048];
   const int lane = (int)(threadIdx.x & 63u);
-  for (int i = (int)threadIdx.x; i < 1024; i += (int)blockDim.x) { tab[i] = 0u; noise[i] = 0u; }
+  for (int i = (int)threadIdx.x; i < 1024; i += (int)blockDim.x) { tab[i] = 0u; noise[i] = 0u; noise[1024 + i] = 0u; }
   __syncthreads();
   uint32_t rng = 0x9E3779B9u * (blockIdx.x * 1024u + threadIdx.x + 1u);
   unsigned int nbad = 0;
@@ -89,21 +92,26 @@ __global__ __launch_bounds__(128) void kas_lds_order_selftest_kernel(unsigned in
     for (int it = 0; it < iters; ++it) {
       rng = rng * 1664525u + 1013904223u;
       const uint32_t w = (rng >> 11) & mask, add = 1u + ((rng >> 5) & 15u);
+      const bool on = (it & 1) == 0 || ((rng >> 24) & 3u) != 0u;      // odd rounds: a random three quarters of the lanes draw
       const uint32_t before = tab[w];                               // (only this wavefront writes tab)
       kasw::lockstep();
-      const uint32_t got = kasw::lds_add_rtn_u32(&tab[w], add);
+      uint32_t got = 0u;
+      if (on) got = kasw::lds_add_rtn_u32(&tab[w], add);
       kasw::lockstep();
+      const uint64_t onm = kasw::ballot(on);
       uint32_t lower = 0u;
       for (int l = 0; l < 64; ++l) {
         const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l), al = (uint32_t)__builtin_amdgcn_readlane((int)add, l);
-        lower += (l < lane && wl == w) ? al : 0u;
+        lower += (l < lane && wl == w && ((onm >> l) & 1ull)) ? al : 0u;
       }
-      nbad += got != before + lower ? 1u : 0u;
+      nbad += (on && got != before + lower) ? 1u : 0u;
     }
   } else {
     for (int it = 0; it < 2 * iters; ++it) {
       rng = rng * 1664525u + 1013904223u;
-      atomicAdd(&noise[(rng >> 9) & 1023u], 1u);
+      const uint32_t w = (rng >> 9) & 2047u;
+      if (it & 1) atomicAdd(&noise[w], 1u << (16u * ((rng >> 3) & 1u)));       // (the fill's uint16 histogram cells)
+      else if ((rng >> 28) & 1u) (void)kasw::lds_add_rtn_u32(&noise[w], 0xffffffffu);   // (its quota draw, under a mask)
     }
   }
   if (nbad) atomicAdd(bad, nbad);
@@ -302,7 +310,10 @@ struct kas_ctx {
   KasCachedPlan plans[KAS_HOST_PLAN_CACHE];
   uint64_t use_clock = 0;
   uint64_t host_calls = 0, host_plan_hits = 0, host_allocs = 0;
-  int lds_lane_order_ok = 0;            // kas_ctx_create's self-test passed: the relaxation form of P5 may run here
+  int lds_lane_order_ok = 0;            // the self-test passed: the relaxation form of P5 and the fill's quota draw by ds_add_rtn may run here
+  int lds_lane_order_state = -1;        // 1 passed, 0 FAILED (some lane-operation came back out of lane order), -1 could not run
+                                        // (allocation / launch error), -2 switched off (environment: KAS_NO_LANE_ORDER=1)
+  long lds_lane_order_checked = 0;      // lane-operations checked so far (context creation + every plan creation)
 };
 
 #define KAS_TIMER_SLOTS 64
@@ -382,6 +393,31 @@ int kas_device_count(void) {
   return n;
 }
 
+// Runs the self-test (grid workgroups x iters rounds x 64 lanes) on the context's stream, blocking; folds the outcome into
+// the context: a failure is final, a run that could not happen leaves an earlier pass standing.
+static void kas_lds_order_selftest(kas_ctx* c, int grid, int iters) {
+  if (c->lds_lane_order_state == 0 || c->lds_lane_order_state == -2) return;
+  if (const char* off = getenv("KAS_NO_LANE_ORDER")) {
+    if (off[0] != 0 && off[0] != '0') { c->lds_lane_order_state = -2; c->lds_lane_order_ok = 0; return; }
+  }
+  unsigned int* d_bad = nullptr;
+  unsigned int h_bad = 1u;
+  bool ran = false;
+  if (hipMalloc((void**)&d_bad, sizeof(unsigned int)) == hipSuccess) {
+    if (hipMemsetAsync(d_bad, 0, sizeof(unsigned int), c->stream) == hipSuccess) {
+      hipLaunchKernelGGL(kas_lds_order_selftest_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, d_bad, iters);
+      ran = hipGetLastError() == hipSuccess &&
+            hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+            hipStreamSynchronize(c->stream) == hipSuccess;
+    }
+    (void)hipFree(d_bad);
+  }
+  if (!ran) { (void)hipGetLastError(); return; }             // (state stays: -1 if it never ran, 1 if an earlier run passed)
+  c->lds_lane_order_checked += (long)grid * iters * 64;
+  c->lds_lane_order_state = h_bad == 0u ? 1 : 0;
+  c->lds_lane_order_ok = h_bad == 0u ? 1 : 0;
+}
+
 int kas_ctx_create(int device, kas_ctx** out_ctx) {
   if (!out_ctx) return set_error(KAS_E_INVALID_ARG, "out_ctx == NULL");
   *out_ctx = nullptr;
@@ -415,20 +451,7 @@ int kas_ctx_create(int device, kas_ctx** out_ctx) {
     return set_error(KAS_E_HIP, hipGetErrorString(e));
   }
   // the relaxation form of P5 runs only where the LDS hands out the lanes' additions in lane order (see the kernel)
-  {
-    unsigned int* d_bad = nullptr;
-    unsigned int h_bad = 1u;
-    if (hipMalloc((void**)&d_bad, sizeof(unsigned int)) == hipSuccess) {
-      if (hipMemsetAsync(d_bad, 0, sizeof(unsigned int), c->stream) == hipSuccess) {
-        hipLaunchKernelGGL(kas_lds_order_selftest_kernel, dim3(96), dim3(128), 0, c->stream, d_bad, 400);
-        if (hipGetLastError() == hipSuccess &&
-            hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-            hipStreamSynchronize(c->stream) == hipSuccess)
-          c->lds_lane_order_ok = h_bad == 0u ? 1 : 0;
-      }
-      (void)hipFree(d_bad);
-    }
-  }
+  kas_lds_order_selftest(c, 2048, 200);
   *out_ctx = c;
   return KAS_E_OK;
 }
@@ -451,6 +474,12 @@ void kas_ctx_destroy(kas_ctx* ctx) {
   for (hipStream_t h : ctx->hstream) if (h) (void)hipStreamDestroy(h);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+int kas_ctx_lds_lane_order(const kas_ctx* ctx, int64_t* lane_ops_checked) {
+  if (!ctx) return set_error(KAS_E_INVALID_ARG, "ctx == NULL");
+  if (lane_ops_checked) *lane_ops_checked = (int64_t)ctx->lds_lane_order_checked;
+  return ctx->lds_lane_order_state;
 }
 
 int kas_ctx_synchronize(kas_ctx* ctx) {
@@ -568,6 +597,18 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
     return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at the instantiated width");
   if (!kas_minimal_ok(p->Wc, p->NW, p->G))
     return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only lists 3 wide, 4 fill waves");
+  // some order kernel must be able to take the batch HERE: beyond 8,191 brokers at lists <= 3 wide that is the relaxation
+  // form alone, which needs the LDS lane order the context's self-test looks for (such a plan used to fail at its
+  // first solve with a launch error)
+  {
+    const bool relax_here = sh.relax_ok && ctx->lds_lane_order_ok && kas_order_relax_for(sh.Wc, 0, 0) != nullptr;
+    if (!sh.round_fits && !sh.tickets_ok && !sh.wide_ok && !relax_here)
+      return set_error(KAS_E_UNSUPPORTED,
+                       sh.relax_ok ? (ctx->lds_lane_order_state == -1
+                                          ? "this broker count x list width is served by the relaxation form only, and the context's LDS lane-order self-test could not run"
+                                          : "this broker count x list width is served by the relaxation form only, and the context does not use it (LDS lane-order self-test failed or KAS_NO_LANE_ORDER)")
+                                   : "no order kernel fits this broker count x list width (INTEGRATION.md, limits)");
+  }
   hipStream_t st = ctx->stream;
   const size_t S = (size_t)batch->n_scenarios, T = (size_t)batch->n_topics, NP = (size_t)batch->node_pool_len;
   struct Up { KasBuf* b; const void* src; size_t bytes; const char* what; };
@@ -612,6 +653,12 @@ static int kas_plan_new(kas_ctx* ctx, const kas_batch_desc* batch, uint64_t* all
       kas_plan_destroy(p);
       return set_error(KAS_E_HIP, "hipEventCreate failed");
     }
+  }
+  // (a short run of the LDS lane-order self-test again: the property is checked where and when the form is about to be used)
+  if (ctx->lds_lane_order_ok) {
+    KasShape pre;
+    std::string err;
+    if (kas_shape_batch(batch, &pre, &err, 0, 0) == KAS_E_OK && pre.relax_ok) kas_lds_order_selftest(ctx, 1024, 40);
   }
   const int rc = kas_plan_build(p, batch);
   if (rc != KAS_E_OK) { kas_plan_destroy(p); return rc; }
@@ -685,6 +732,12 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (chunks > 0)
     snprintf(spread, sizeof(spread), "kas_spread_{a,q,b,p4}_kernel<%d> %d chunks x %d scenarios (rows not rack-diverse: ", p->Wc,
              chunks, p->n_scenarios);
+  if (p->shape.relax_ok && !lp.relax && !(p->flags & KAS_FLAG_ROUND_ORDER) && !kas_flags_want_tickets(p->flags)) {
+    const int stt = p->ctx->lds_lane_order_state;              // the form the shape allows is not the one launched: say why
+    const size_t ol = strlen(order);
+    snprintf(order + ol, sizeof(order) - ol, " [relaxation form off: LDS lane-order self-test %s]",
+             stt == 0 ? "FAILED" : (stt == -2 ? "switched off (KAS_NO_LANE_ORDER)" : "could not run"));
+  }
   const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s + %s", spread, p->Wc, p->NW,
                            generic ? "sweeps" : (kas_plan_fused(p) ? "quota, chunk histograms" : "quota"), lp.fill_grid,
                            lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", order);
@@ -853,32 +906,34 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
   if ((flags & KAS_FLAG_ROUND_ORDER) && !p->shape.round_fits)
     return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_ROUND_ORDER: the round form's LDS exceeds 160 KiB at this broker count x width");
+  if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))   // (every check before anything is changed)
+    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_RELAX_TILES: 0 (by batch size), 1 (64 rows) or 2 (double tiles)");
   if (!kas_minimal_ok(p->Wc, nw ? nw : p->NW, g ? g : p->G))
     return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only 4 fill waves, 1 or 2 groups");
   const KasShape& sh = p->shape;
+  // (every refusal before the plan is touched: a call that returns an error leaves the plan as it was — ADVICE r4)
+  KasLds l_nw = p->lds;
   if (nw != 0 && nw != p->NW) {
-    KasLds l = kas_fill_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch, sh.with_x);
-    if (l.total > KAS_LDS_LIMIT)
+    l_nw = kas_fill_lds_layout(sh.n_max, sh.Wc, nw, sh.idmap_entries, sh.need_bsearch, sh.with_x);
+    if (l_nw.total > KAS_LDS_LIMIT)
       return set_error(KAS_E_UNSUPPORTED, "LDS carve-up exceeds 160 KiB at that many waves");
-    p->lds = l;
+  }
+  if (g != 0 && g != p->G &&
+      (kas_order_ticket_lds(sh.n_max, g, 0) > KAS_LDS_LIMIT || (int64_t)g * kas_order_ticket_group_bytes(sh.n_max, g, 0) > 65536))
+    return set_error(KAS_E_UNSUPPORTED, "LDS of the order kernel exceeds 160 KiB at that many groups");
+  if (nw != 0 && nw != p->NW) {
+    p->lds = l_nw;
     p->NW = nw;
     KasShape tmp = sh;                                       // per-chunk histograms at the new workgroup width?
-    tmp.NW = nw; tmp.lds = l;
+    tmp.NW = nw; tmp.lds = l_nw;
     kas_choose_fused(&tmp);
     p->fused = tmp.fused_ok; p->lds_fused = tmp.lds_fused;
   }
-  if (g != 0 && g != p->G) {
-    if (kas_order_ticket_lds(sh.n_max, g, 0) > KAS_LDS_LIMIT ||
-        (int64_t)g * kas_order_ticket_group_bytes(sh.n_max, g, 0) > 65536)
-      return set_error(KAS_E_UNSUPPORTED, "LDS of the order kernel exceeds 160 KiB at that many groups");
-    p->G = g;
-  }
+  if (g != 0 && g != p->G) p->G = g;
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))
-    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_RELAX_TILES: 0 (by batch size), 1 (64 rows) or 2 (double tiles)");
-  p->flags = (flags & (0xffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
+  p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
   // plan may still be in flight on the old scratch

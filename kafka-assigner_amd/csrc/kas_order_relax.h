@@ -250,6 +250,28 @@ KAS_DEV uint64_t relax_flush(RelaxPend<NB>& pend, int32_t* out, uint32_t k) {
   return d;
 }
 
+// Sampled verification (KAS_PLAN_VERIFY_SAMPLE): a tile the relaxation has settled, evaluated AGAIN one row at a time —
+// row i reads the counter words as rows 0 .. i - 1 left them, picks, adds its own counts with plain LDS adds — so that
+// nothing depends on the order in which the LDS serves the lanes of one instruction.  Called with the tile's additions
+// taken back; leaves the words as the sequential evaluation makes them (== what the relaxation had, if it was right).
+// Returns the lanes whose row came out differently.  64 one-lane steps: ~3 us a tile.
+KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, const uint32_t (&c)[3], const RelaxTags& g, int32_t oc) {
+  const int lane = kasw::lane();
+  bool differs = false;
+  for (int32_t i = 0; i < 64; ++i) {
+    if (lane == i) {
+      const uint32_t x[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
+      const int32_t os = relax_eval3(x, g);
+      differs = os != oc;
+      const uint32_t w0 = (uint32_t)os & 3u, w1 = ((uint32_t)os >> 2) & 3u;
+      kasw::lds_add_u32(cnt + (w0 == 0u ? c[0] : (w0 == 1u ? c[1] : c[2])), KAS_RELAX_F0_ONE);
+      kasw::lds_add_u32(cnt + (w1 == 0u ? c[0] : (w1 == 1u ? c[1] : c[2])), KAS_RELAX_F1_ONE);
+    }
+    kasw::lockstep();
+  }
+  return kasw::ballot(differs);
+}
+
 // DUAL: the instance that takes double tiles (a kernel of its own: it needs 91 vector registers, the instance without
 // them 56 — two of its wavefronts fit where one wavefront of the fill kernel does)
 // CTX: the instance for batches in which some scenario hands a Context in or wants it back (KAS:360-369): the counter
@@ -258,7 +280,7 @@ KAS_DEV uint64_t relax_flush(RelaxPend<NB>& pend, int32_t* out, uint32_t k) {
 // issue priority of the relaxation form's wavefront among the waves of its SIMD (s_setprio 0..3): its loop is ONE dependency
 // chain, the fill kernel's wavefronts beside it have four tiles of independent work in flight each
 #ifndef KAS_RELAX_PRIO
-#define KAS_RELAX_PRIO 0
+#define KAS_RELAX_PRIO 3
 #endif
 template <int W, bool DUAL, bool CTX>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
@@ -291,6 +313,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       }
     }
   }
+  uint32_t seed0 = 0u, seed1 = 0u;                           // (per lane) what the Context brings to the [0] / [1] fields
   for (int32_t n = lane; n < N; n += 64) {
     uint32_t w = 0u;
     if constexpr (CTX) {
@@ -299,6 +322,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       cnt2[n] = 0u;
     }
     cnt[n] = w;
+    seed0 += w & 0xffffu; seed1 += w >> 16;
   }
   if (lane == 0) cnt[nmax] = KAS_RELAX_PAD_WORD;
   RelaxPairs pp;
@@ -313,8 +337,15 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   kasw::lockstep();
 
   uint64_t digest = 0;
-  int32_t n_tiles = 0, n_evals = 0, n_slow = 0;             // (wave-uniform)
+  int32_t n_tiles = 0, n_evals = 0, n_slow = 0, n_verified = 0;   // (wave-uniform)
   bool stuck = false;
+  // Two checks on the form's one assumption (kas_wave.h, lds_add_rtn_u32).  Conservation, always on: every row with a first
+  // (second) pick adds exactly one to some node's count[.][0] (count[.][1]) field, so when the last row has retired the
+  // fields sum to what the Context brought plus the rows counted here — a lost or doubled addition cannot go unnoticed.
+  // Sampled verification, on request (KAS_PLAN_VERIFY_SAMPLE(k): k tiles per topic): relax_verify_rows.
+  uint32_t rows1 = 0u, rows2 = 0u;                           // rows that added to a [0] / [1] field (wave-uniform)
+  bool unsound = false;
+  const int32_t verify_k = (int32_t)(a.flags >> 24);
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
     if (a.topic_results[ti].status != KAS_OK) continue;     // (a failed or skipped topic emits nothing)
@@ -352,6 +383,8 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       // the same point of the next step looks at them.  The requests are loads the compiler does not see
       // (kasw::gload_*_async: its own wait insertion put a vmcnt(0) behind the requests of the same iteration).
       constexpr int NB = DUAL ? 2 : 1;
+      const int32_t vstride = verify_k > 0 ? (nt / verify_k > 0 ? nt / verify_k : 1) : 0;   // every vstride-th tile is verified,
+      const int32_t voff = vstride > 0 ? s % vstride : 0;                                    // starting at a tile of the scenario's own
       auto row_exists = [&](int32_t t) -> bool { return ((t << 6) + lane) < P; };
       auto request_tile = [&](MidRaw<W>& r, int32_t t) {
         const int32_t pn = (t << 6) + lane;
@@ -432,6 +465,15 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
                 for (int q = 0; q < 3; ++q) { xa[q] = mine[q]; xb[q] = mine[192 + q]; }
                 pa = oa; pb = ob;
               }
+              rows1 += 128u; rows2 += 128u;
+              if (vstride > 0 && ((tile % vstride) == voff || ((tile + 1) % vstride) == voff)) {   // (wave-uniform)
+                n_verified += 2;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
+                kasw::lockstep();
+                if (relax_verify_rows(cnt, c, ga, pa) != 0ull) unsound = true;
+                if (relax_verify_rows(cnt, cb, gb, pb) != 0ull) unsound = true;
+              }
               relax_list3(raw[0], pa < 0 ? 4 : pa, req_l[0], cnt2);
               relax_list3(raw[NB - 1], pb < 0 ? 4 : pb, req_l[NB - 1], cnt2);
               req_n = 2;
@@ -469,6 +511,14 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
                 x[0] = mine[0]; x[1] = mine[1]; x[2] = mine[2];
                 oc_prev = oc;
               }
+              rows1 += 64u; rows2 += 64u;
+              if (vstride > 0 && (tile % vstride) == voff) {     // (wave-uniform)
+                n_verified += 1;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
+                kasw::lockstep();
+                if (relax_verify_rows(cnt, c, g, oc_prev) != 0ull) unsound = true;
+              }
               // ---- the final row: its list as node indices now, broker ids and the store one step later
               relax_list3(raw[0], oc_prev < 0 ? 4 : oc_prev, req_l[0], cnt2);
               req_n = 1;
@@ -495,6 +545,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
               for (int j = 0; j < 3; ++j) rank[q] += (j != q && valid[j] && c[j] < c[q]) ? 1 : 0;
             }
+            rows1 += (uint32_t)kasw::popc(kasw::ballot(Lp >= 1)); rows2 += (uint32_t)kasw::popc(kasw::ballot(Lp >= 2));
             int32_t oc_prev = -1;
             for (int32_t it = 0;; ++it) {
               n_evals += 1;
@@ -571,6 +622,14 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     if (ow == W) topic_rows(std::true_type{});
     else topic_rows(std::false_type{});
   }
+  {
+    // conservation: the fields of every node's word against the rows that added to them (and the padding node's word untouched)
+    kasw::lockstep();
+    uint32_t f0 = 0u, f1 = 0u;
+    for (int32_t n = lane; n < N; n += 64) { const uint32_t w = cnt[n]; f0 += w & 0xffffu; f1 += w >> 16; }
+    const uint32_t d0 = (uint32_t)kasw::wave_sum((int)(f0 - seed0)), d1 = (uint32_t)kasw::wave_sum((int)(f1 - seed1));
+    if (!stuck && (d0 != rows1 || d1 != rows2 || kasw::ballot(cnt[nmax] != KAS_RELAX_PAD_WORD) != 0ull)) unsound = true;
+  }
   if constexpr (CTX) {
     // the Context goes back (KAS:360-369): every row has retired, the words hold every commit
     kasw::lockstep();
@@ -585,13 +644,13 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   const uint64_t dsum = kasw::wave_sum_u64(digest);
   if (lane == 0) {
     a.scenario_results[s].digest = dsum;
-    if (stuck) {
+    if (stuck || unsound) {
       a.scenario_results[s].status = KAS_FAIL_WATCHDOG;
       a.scenario_results[s].fail_topic = -1; a.scenario_results[s].fail_partition = -1;
     }
     if (a.stats) {
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
-      st[8] = kasw::clock_ticks() - t_begin; st[9] = n_evals; st[12] = n_tiles; st[13] = n_slow;
+      st[8] = kasw::clock_ticks() - t_begin; st[9] = n_evals; st[12] = n_tiles; st[13] = n_slow; st[10] = n_verified; st[11] = unsound ? 1 : 0;
     }
   }
 }

@@ -24,7 +24,7 @@ SYMBOLS = [
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
     "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
     "kas_plan_describe", "kas_ctx_host_stats", "kas_solve_host_select", "kas_host_alloc", "kas_host_free",
-    "kas_shard_range", "kas_batch_slice", "kas_solve_host_sharded",
+    "kas_shard_range", "kas_batch_slice", "kas_solve_host_sharded", "kas_ctx_lds_lane_order",
 ]
 
 _LIB = None
@@ -120,6 +120,14 @@ class DeviceContext:
 
     def synchronize(self):
         _check(self._lib.kas_ctx_synchronize(self._h))
+
+    def lds_lane_order(self):
+        """(state, lane-operations checked): kas_ctx_lds_lane_order — 1 the LDS served every checked atomic-with-return in
+        lane order, 0 violated, -1 the self-test could not run, -2 switched off (KAS_NO_LANE_ORDER=1)."""
+        n = C.c_int64()
+        self._lib.kas_ctx_lds_lane_order.restype = C.c_int
+        self._lib.kas_ctx_lds_lane_order.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        return int(self._lib.kas_ctx_lds_lane_order(self._h, C.byref(n))), n.value
 
     def host_stats(self):
         """(kas_solve_host calls, calls served by a cached plan, device allocations made)."""

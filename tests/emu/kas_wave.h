@@ -51,6 +51,7 @@ struct Emu {
   int n_lanes;
   int cur;               // fiber being run
   uint64_t slot[KAS_EMU_MAX_LANES];
+  uint64_t slot2[KAS_EMU_MAX_LANES];
   long collectives;
 };
 
@@ -131,7 +132,24 @@ KAS_DEV void lds_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }
 // (hardware: the lanes of one LDS atomic instruction are served in ascending lane order; here the fibers of a
 // wave run one after the other, in lane order, between two rendezvous — the callers put a lockstep() around
 // every group of these that must look like one instruction)
+#ifdef KAS_EMU_RTN_DESCENDING
+// Test build: an LDS that serves the lanes of one atomic-with-return instruction in DESCENDING lane order — the hardware
+// the relaxation form of P5 would NOT survive (tests/test_emu_lane_order.py: its lists come out wrong with status OK, and
+// KAS_PLAN_VERIFY_SAMPLE turns them into KAS_FAIL_WATCHDOG).  Every lane of the wave must execute the instruction.
+KAS_DEV uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) {
+  Emu& e = g_emu;
+  const int base = e.cur & ~63, me = e.cur & 63;
+  e.slot[e.cur] = (uint64_t)(uintptr_t)p; e.slot2[e.cur] = v;
+  rendezvous(K_LOCKSTEP);
+  uint32_t ret = *p;                                         // the word as the instruction found it + the HIGHER lanes' addends
+  for (int l = me + 1; l < 64; ++l) if (e.slot[base + l] == (uint64_t)(uintptr_t)p) ret += (uint32_t)e.slot2[base + l];
+  rendezvous(K_LOCKSTEP);
+  *p += v;
+  return ret;
+}
+#else
 KAS_DEV uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+#endif
 KAS_DEV void lds_add_u32(uint32_t* p, uint32_t v) { *p += v; }
 KAS_DEV void lds_sub_u32(uint32_t* p, uint32_t v) { *p -= v; }
 

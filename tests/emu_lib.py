@@ -26,6 +26,7 @@ TEST_VARIANTS = {
     "bounded": ["-DKAS_SPIN_BOUND=200000"],
     "stalled": ["-DKAS_SPIN_BOUND=1500", "-DKAS_TEST_STALL_AFTER=2"],
     "stalled_sparse": ["-DKAS_SPIN_BOUND=65536", "-DKAS_SPIN_CHECK=4096", "-DKAS_TEST_STALL_AFTER=2"],
+    "rtn_descending": ["-DKAS_EMU_RTN_DESCENDING"],
 }
 
 
@@ -225,6 +226,11 @@ TICKET_ORDER = 0x10000     # KAS_PLAN_TICKET_ORDER: the ticket form where the re
 RELAX_TILES_64 = 0x20000   # KAS_PLAN_RELAX_TILES(1): relaxation form over tiles of 64 rows whatever the batch size
 RELAX_TILES_128 = 0x40000  # KAS_PLAN_RELAX_TILES(2): double tiles whatever the batch size
 NO_RTN_QUOTA = 0x200000    # KAS_PLAN_NO_RTN_QUOTA: the fill draws its quota without the atomic-with-return
+
+
+def VERIFY_SAMPLE(k: int) -> int:
+    """KAS_PLAN_VERIFY_SAMPLE(k): the relaxation form evaluates k tiles per topic again, one row at a time"""
+    return (k & 0xff) << 24
 
 
 def last_relax_stats():

@@ -655,3 +655,24 @@ def test_many_rows_per_broker_keep_the_relaxation_form_up_to_16_bit_counts():
     assert_same_outputs(fb, want, native.solve_host(fb), "hip 4,286 rows per broker, relaxation form")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip 4,286 rows per broker, tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "hip 4,286 rows per broker, ticket form")
+
+
+def test_lds_lane_order_is_checked_and_the_sampled_verification_stays_silent():
+    """Round 5: the context's self-test runs under LDS load on every CU and under partial EXEC masks, again at
+    plan creation; KAS_PLAN_VERIFY_SAMPLE(k) evaluates k tiles per topic a second time row by row (no dependence on the
+    LDS's lane order) — on this hardware it must agree with the relaxation everywhere; the conservation check is always on.
+    tests/test_emu_lane_order.py shows what both catch when the order does NOT hold."""
+    ctx = native.default_context()
+    state, checked = ctx.lds_lane_order()
+    assert state == 1 and checked >= 2048 * 200 * 64, (state, checked)
+    fb = _batch(515, 6, 20000, 200, 10, 3, ("remove1", "add_k", "mixed"))
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).sum() >= 3
+    plan = native.Plan(ctx, fb)                               # (a plan that may take the relaxation form: the self-test again)
+    assert "kas_order_relax_kernel" in plan.describe()
+    plan.close()
+    assert ctx.lds_lane_order()[1] > checked
+    for flags in (abi.KAS_PLAN_VERIFY_SAMPLE(255), TILES_64 | abi.KAS_PLAN_VERIFY_SAMPLE(16), TILES_128 | abi.KAS_PLAN_VERIFY_SAMPLE(255)):
+        got = native.solve_host_with_flags(fb, flags)
+        assert_same_outputs(fb, want, got, "hip, verification sample, flags %#x" % flags)
+        assert not (got.scenario_results["status"] == abi.KAS_FAIL_WATCHDOG).any()
