@@ -384,6 +384,28 @@ def run_rank(args) -> int:
     S = run.S
     for sl in run.slots:
         sl["all"] = run.new_gather_buffer(total) if world > 1 else run.records_tensor(sl)
+    if world > 1:
+        # Pre-flight of the one data-path collective, before anything is timed: every slot's all-gather once, on the slot's
+        # OWN stream (where the timed steps put it: a non-default HIP stream with a hardware queue of its own, which is where
+        # an RCCL / IPC problem would first show), synchronised, the records of my own shard checked.  A failure ends the
+        # run here with the collective's error text and no JSON line.  Environment the run needs:
+        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC between the ranks' devices), GPU_MAX_HW_QUEUES >= slots + 2.
+        try:
+            for i, sl in enumerate(run.slots):
+                with run.stream_ctx(sl):
+                    sl["all"] = sharding.gather_records(run.records_tensor(sl), total, out=sl["all"])
+            run.synchronize()
+            dist.barrier()
+            mine = run.records_tensor(run.slots[0])
+            got = run.slots[0]["all"][lo * sharding.RECORD_BYTES:hi * sharding.RECORD_BYTES]
+            if not bool((got == mine).all()):
+                raise RuntimeError("the all-gather returned other bytes than this rank's own records for its shard")
+        except Exception as e:
+            print(f"bench.py: rank {rank}: pre-flight all-gather of the result records failed: {e!r}\n"
+                  f"  (HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
+                  f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}, world {world}, device {run.device_index})",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(3)
 
     def step():
         sl = run.slots[run.step_no % run.n_slots]
@@ -604,10 +626,18 @@ def run_rank(args) -> int:
             try:
                 import csv
                 pipes = {}
-                with open(os.path.join(ROOT, "profiles", "r04_pipe_utilisation.csv")) as f:
+                side = json.load(open(os.path.join(ROOT, "profiles", "pipe_utilisation.json")))
+                if side.get("kernel") != describe or side.get("kernel_sources_sha16") != roof["kernel_sources_sha16"]:
+                    roof["pipes_note"] = ("profiles/pipe_utilisation.json was taken from other kernels or sources "
+                                          f"({side.get('kernel_sources_sha16')}): not quoted")
+                    raise LookupError("stale pipe table")
+                with open(os.path.join(ROOT, side["csv"])) as f:
+                    vals = {}
                     for row in csv.DictReader(f):
-                        if row["batches_in_flight"] == "8" and row["kernel"] == "fill+order" and row["fraction_of_capacity"]:
-                            pipes[row["quantity"]] = float(row["fraction_of_capacity"])
+                        if row["batches_in_flight"] == "8" and row["kernel"] == "fill+order":
+                            vals[row["quantity"]] = float(row["value"])
+                            if row["fraction_of_capacity"]:
+                                pipes[row["quantity"]] = float(row["fraction_of_capacity"])
                 table = {"valu_pipe_busy": pipes.get("VALU pipe busy, counter"),
                          "salu_issue_busy": pipes.get("SALU issue busy"),
                          "lds_array_busy": pipes.get("LDS array busy"),
@@ -617,10 +647,10 @@ def run_rank(args) -> int:
                 near = max(((k, v) for k, v in table.items() if v is not None and k != "lds_array_busy_without_bank_conflicts"),
                            key=lambda kv: kv[1])
                 roof["pipes"] = dict(table, nearest_ceiling={"pipe": near[0], "frac": near[1]},
-                                     source="profiles/r04_pipe_utilisation.csv (rocprofv3 SQ counter passes of bench.py, eight "
-                                            "batches in flight, fill + order kernels over the ms_per_step window; units in the file)",
-                                     note="no pipe is saturated: the job is bound by how many wavefronts stay resident "
-                                          "(3 of 8 per SIMD, parked half of their time), DESIGN.md section 4.7")
+                                     waves_resident_per_simd=vals.get("waves resident per SIMD (average)"),
+                                     source=side["csv"] + " (rocprofv3 SQ counter passes of bench.py, eight batches in flight, "
+                                            "fill + order kernels over the ms_per_step window; units in the file; same kernel "
+                                            "sources as this run)")
             except Exception:
                 pass
         if not args.stub and not args.no_extras and world == 1:

@@ -36,13 +36,13 @@ with open(f"profiles/{tag}_pmc_hbm_traffic.csv", "w") as out:
 KB = 1024
 ff, fo = res[("FETCH_SIZE", "fill")] * KB, res[("FETCH_SIZE", "order")] * KB
 wf, wo = res[("WRITE_SIZE", "fill")] * KB, res[("WRITE_SIZE", "order")] * KB
-known = 1000 * 100000 * 8           # the order kernel reads every 8-byte mid row exactly once
+known = 1000 * 100000 * 6           # the order kernel reads every 6-byte mid row exactly once (round 5: packed rows; 8 bytes before)
 corr = known / fo
 j = {"scenarios": 1000, "partitions": 100000,
      "hbm_bytes_per_launch": 2 * (ff + fo) + wf + wo,
      "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, profiles/{tag}_pmc_hbm_traffic.csv), "
                "kB -> bytes; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE tallies 128-B requests at 64 B) - "
-               "check: the order kernel reads each 8-byte mid row exactly once, known/measured = %.3f" % corr,
+               "check: the order kernel reads each 6-byte mid row exactly once, known/measured = %.3f" % corr,
      "fetch_kb": {"fill": res[("FETCH_SIZE", "fill")], "order": res[("FETCH_SIZE", "order")]},
      "write_kb": {"fill": res[("WRITE_SIZE", "fill")], "order": res[("WRITE_SIZE", "order")]},
      "read_correction_measured": corr}

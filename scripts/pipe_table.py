@@ -74,6 +74,10 @@ for mode in (1, 8):
             "a wave issues at most one instruction per ~4.3-5 cycles (probe), so this / (waves resident x (1 - parked) / 4.5) is how full the waves' own issue is")
 with open(f"profiles/{tag}_pipe_utilisation.csv", "w") as f:
     csv.writer(f).writerows(out)
+# which kernels and sources the table belongs to: bench.py quotes it (roofline.pipes) only for the same ones
+json.dump({"csv": f"profiles/{tag}_pipe_utilisation.csv", "kernel": line["roofline"]["kernel"],
+           "kernel_sources_sha16": line["roofline"]["kernel_sources_sha16"], "ms_per_step_of_the_window": line["ms_per_step"]},
+          open("profiles/pipe_utilisation.json", "w"), indent=1)
 for r in out:
     if r[0] == 8 or r[0] == "batches_in_flight" or (r[0] == 1 and "busy" in r[4]):
         print(" | ".join(str(x) for x in r[:8]))

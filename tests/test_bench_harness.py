@@ -62,6 +62,22 @@ def test_bench_world_of_eight_over_gloo(scaling, scenarios, expect_sizes):
     assert cfg["gathered_records_ok"] is True and cfg["allgather_alone_us"] > 0
 
 
+@pytest.mark.parametrize("world,scenarios,expect_sizes", [
+    (3, 10, [4, 3, 3]),
+    (5, 12, [3, 3, 2, 2, 2]),
+])
+def test_bench_odd_world_sizes_strong_scaling_ragged_shards(world, scenarios, expect_sizes):
+    """World sizes the driver's 1 / 2 / 4 / 8 sweep does not have: the padded all-gather of ragged
+    shards, the pre-flight gather on every slot's stream, every rank's records in global order."""
+    r = _run(["--stub", "--gpus", str(world), "--steps", "4", "--warmup", "1", "--scenarios", str(scenarios),
+              "--scaling", "strong", "--in-flight", "3"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    cfg = line["config"]
+    assert line["n_gpus"] == world and cfg["world_size"] == world and cfg["scenarios_per_gpu"] == expect_sizes
+    assert cfg["scenarios_total"] == scenarios and cfg["gathered_records_ok"] is True
+
+
 def test_bench_single_rank_stub_line():
     r = _run(["--stub", "--steps", "3", "--warmup", "1", "--scenarios", "5"])
     assert r.returncode == 0, r.stderr[-3000:]
