@@ -120,10 +120,20 @@ __global__ __launch_bounds__(256) void kas_lds_order_selftest_kernel(unsigned in
 // lists up to 3 wide: the relaxation form, one wavefront (= one workgroup) per scenario (kas_order_relax.h)
 // (DUAL: the instance with double tiles, kas_relax_double_tiles)
 // (CTX: the instance for batches in which some scenario hands a Context in or wants it back)
-template <int W, bool DUAL, bool CTX>
+// (VERIFY: the instances for plans with KAS_PLAN_VERIFY_SAMPLE)
+template <int W, bool DUAL, bool CTX, bool VERIFY = false>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY>(a, (int32_t)blockIdx.x, kas_lds);
+}
+template <bool VERIFY>
+static void (*kas_order_relax_pick(int Wc, int dual, int ctx))(KasLaunch) {
+  if (Wc <= 2) return ctx ? kas_order_relax_kernel<2, false, true, VERIFY> : kas_order_relax_kernel<2, false, false, VERIFY>;   // (double tiles are rows of three holders)
+  if (Wc == 3) {
+    if (ctx) return dual ? kas_order_relax_kernel<3, true, true, VERIFY> : kas_order_relax_kernel<3, false, true, VERIFY>;
+    return dual ? kas_order_relax_kernel<3, true, false, VERIFY> : kas_order_relax_kernel<3, false, false, VERIFY>;
+  }
+  return nullptr;
 }
 
 // lists 4 and 5 wide: one scenario per workgroup (stager, retirer, three solver wavefronts: kas_order_wide.h)
@@ -175,7 +185,7 @@ static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<5, 4>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
-static kas_kernel_fn kas_order_relax_for(int, int, int) { return nullptr; }
+static kas_kernel_fn kas_order_relax_for(int, int, int, int = 0) { return nullptr; }
 static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_kernels_w<5>() : KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #elif defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES != 0
 // tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
@@ -189,9 +199,8 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
 }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
 static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
-static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx) {
-  if (ctx) return dual ? kas_order_relax_kernel<3, true, true> : kas_order_relax_kernel<3, false, true>;
-  return dual ? kas_order_relax_kernel<3, true, false> : kas_order_relax_kernel<3, false, false>;
+static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx, int verify = 0) {
+  return verify ? kas_order_relax_pick<true>(3, dual, ctx) : kas_order_relax_pick<false>(3, dual, ctx);
 }
 static KasSpreadKernels kas_spread_for(int) { return KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #else
@@ -239,13 +248,8 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
 static kas_kernel_fn kas_order_wide_for(int Wc) {
   return Wc == 4 ? kas_order_wide_kernel<4> : kas_order_wide_kernel<5>;
 }
-static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx) {
-  if (Wc <= 2) return ctx ? kas_order_relax_kernel<2, false, true> : kas_order_relax_kernel<2, false, false>;   // (double tiles are rows of three holders)
-  if (Wc == 3) {
-    if (ctx) return dual ? kas_order_relax_kernel<3, true, true> : kas_order_relax_kernel<3, false, true>;
-    return dual ? kas_order_relax_kernel<3, true, false> : kas_order_relax_kernel<3, false, false>;
-  }
-  return nullptr;
+static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx, int verify = 0) {
+  return verify ? kas_order_relax_pick<true>(Wc, dual, ctx) : kas_order_relax_pick<false>(Wc, dual, ctx);
 }
 static KasSpreadKernels kas_spread_for(int Wc) {
   switch (Wc) {
@@ -516,10 +520,11 @@ static int kas_plan_set_kernels(kas_plan* p) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kas_order_ticket_lds(p->shape.n_max, p->G, pk) + KAS_TUNE_ORDER_LDS_PAD));
   for (int dual = 0; dual < 2; ++dual)
-    if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx))
-      KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx)));
+    for (int verify = 0; verify < 2; ++verify)
+      if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify))
+        KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx)));
   if (p->shape.round_fits)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -714,8 +719,9 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
                              ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
                              : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax)
-    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows] grid=%ux%u lds=%zu%s", p->Wc,
-             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
+    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s] grid=%ux%u lds=%zu%s", p->Wc,
+             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
+             (p->flags >> 24) ? ", sampled verification" : "", lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
   else if (lp.tickets)
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
@@ -833,7 +839,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   else
 #endif
   if (lp.relax)
-    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
                        lp.order_lds, st, a);

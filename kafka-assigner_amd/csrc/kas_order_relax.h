@@ -211,7 +211,7 @@ struct RelaxPend {
 template <int W, bool FULLW>
 KAS_DEV void mid_request(MidRaw<W>& r, const uint16_t* mid, int32_t ow, int32_t p) {
   if constexpr (FULLW) {                                    // (packed rows: the dword of a 6-byte row is 2-byte aligned)
-    const uint32_t off = (uint32_t)p * (uint32_t)(2 * W);
+    const uint32_t off = (uint32_t)p * (uint32_t)(2 * mid_width_of<W>());
     kasw::gload_u32_async<0>(r.w[0], mid, off);
     if constexpr (W == 3) kasw::gload_u16_async<4>(r.w[1], mid, off);
   } else {
@@ -255,8 +255,12 @@ KAS_DEV uint64_t relax_flush(RelaxPend<NB>& pend, int32_t* out, uint32_t k) {
 // nothing depends on the order in which the LDS serves the lanes of one instruction.  Called with the tile's additions
 // taken back; leaves the words as the sequential evaluation makes them (== what the relaxation had, if it was right).
 // Returns the lanes whose row came out differently.  64 one-lane steps: ~3 us a tile.
-KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, const uint32_t (&c)[3], const RelaxTags& g, int32_t oc) {
+// (the cells and their tags are made again from the mid row: nothing of the tile's evaluation has to stay in registers for
+// this rarely taken path — with them passed in, the instance with tiles of 64 rows needed 66 instead of 60 registers)
+KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, uint32_t w0_cells, uint32_t w1_cells, const uint32_t* tagtab, int32_t oc) {
   const int lane = kasw::lane();
+  const uint32_t c[3] = {w0_cells & 0xffffu, w0_cells >> 16, w1_cells & 0xffffu};
+  const RelaxTags g = relax_tags(c, tagtab);
   bool differs = false;
   for (int32_t i = 0; i < 64; ++i) {
     if (lane == i) {
@@ -282,7 +286,10 @@ KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, const uint32_t (&c)[3], const 
 #ifndef KAS_RELAX_PRIO
 #define KAS_RELAX_PRIO 3
 #endif
-template <int W, bool DUAL, bool CTX>
+// VERIFY: the instances for plans that ask for the sampled verification (KAS_PLAN_VERIFY_SAMPLE) — kernels of their own because
+// the second evaluation keeps a tile's addresses and addends alive behind its loop: 67 instead of 60 vector registers for
+// the instance with tiles of 64 rows, one register-file slot more than two of its wavefronts may take beside a fill wavefront
+template <int W, bool DUAL, bool CTX, bool VERIFY = false>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
   if constexpr (KAS_RELAX_PRIO > 0) kasw::set_priority<KAS_RELAX_PRIO>();
@@ -313,7 +320,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       }
     }
   }
-  uint32_t seed0 = 0u, seed1 = 0u;                           // (per lane) what the Context brings to the [0] / [1] fields
+  uint32_t seed0 = 0u, seed1 = 0u;                           // what the Context brings to the [0] / [1] fields
   for (int32_t n = lane; n < N; n += 64) {
     uint32_t w = 0u;
     if constexpr (CTX) {
@@ -323,6 +330,11 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     }
     cnt[n] = w;
     seed0 += w & 0xffffu; seed1 += w >> 16;
+  }
+  if constexpr (CTX) {                                       // (wave-uniform from here on: scalar registers)
+    seed0 = (uint32_t)kasw::uniform(kasw::wave_sum((int)seed0)); seed1 = (uint32_t)kasw::uniform(kasw::wave_sum((int)seed1));
+  } else {
+    seed0 = 0u; seed1 = 0u;
   }
   if (lane == 0) cnt[nmax] = KAS_RELAX_PAD_WORD;
   RelaxPairs pp;
@@ -345,7 +357,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   // Sampled verification, on request (KAS_PLAN_VERIFY_SAMPLE(k): k tiles per topic): relax_verify_rows.
   uint32_t rows1 = 0u, rows2 = 0u;                           // rows that added to a [0] / [1] field (wave-uniform)
   bool unsound = false;
-  const int32_t verify_k = (int32_t)(a.flags >> 24);
+  const int32_t verify_k = VERIFY ? (int32_t)(a.flags >> 24) : 0;
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
     if (a.topic_results[ti].status != KAS_OK) continue;     // (a failed or skipped topic emits nothing)
@@ -466,13 +478,13 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
                 pa = oa; pb = ob;
               }
               rows1 += 128u; rows2 += 128u;
-              if (vstride > 0 && ((tile % vstride) == voff || ((tile + 1) % vstride) == voff)) {   // (wave-uniform)
+              if (VERIFY && vstride > 0 && ((tile % vstride) == voff || ((tile + 1) % vstride) == voff)) {   // (wave-uniform)
                 n_verified += 2;
 #pragma unroll
                 for (int t = 0; t < 6; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
                 kasw::lockstep();
-                if (relax_verify_rows(cnt, c, ga, pa) != 0ull) unsound = true;
-                if (relax_verify_rows(cnt, cb, gb, pb) != 0ull) unsound = true;
+                if (relax_verify_rows(cnt, raw[0].w[0], raw[0].w[1], tagtab, pa) != 0ull) unsound = true;
+                if (relax_verify_rows(cnt, raw[NB - 1].w[0], raw[NB - 1].w[1], tagtab, pb) != 0ull) unsound = true;
               }
               relax_list3(raw[0], pa < 0 ? 4 : pa, req_l[0], cnt2);
               relax_list3(raw[NB - 1], pb < 0 ? 4 : pb, req_l[NB - 1], cnt2);
@@ -512,12 +524,12 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
                 oc_prev = oc;
               }
               rows1 += 64u; rows2 += 64u;
-              if (vstride > 0 && (tile % vstride) == voff) {     // (wave-uniform)
+              if (VERIFY && vstride > 0 && (tile % vstride) == voff) {     // (wave-uniform)
                 n_verified += 1;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
                 kasw::lockstep();
-                if (relax_verify_rows(cnt, c, g, oc_prev) != 0ull) unsound = true;
+                if (relax_verify_rows(cnt, raw[0].w[0], raw[0].w[1], tagtab, oc_prev) != 0ull) unsound = true;
               }
               // ---- the final row: its list as node indices now, broker ids and the store one step later
               relax_list3(raw[0], oc_prev < 0 ? 4 : oc_prev, req_l[0], cnt2);
@@ -605,6 +617,19 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
           for (int q = 0; q < 3; ++q) kasw::gload_u32_async<0>(pend.id[b][q], uid, req_l[b][q] << 2);
         pend.p = p; pend.n = req_n;
+        // The instance with tiles of 64 rows — launches that fill the GPU with wavefronts — sends the final rows out in the
+        // step that decided them: it waits for the broker ids here, where the other wavefronts of the SIMD have work to
+        // issue.  Measured (experiments/README.md, round 5): with the GPU full the deferred rows cost 5 % (2000 x 4 in
+        // flight 588k -> 620k scenarios/s, 4000 x 3 590k -> 630k, 1000 x 8 605k -> 614k), while a batch alone gains 15 %
+        // from them (order kernel 1.79 -> 1.51 ms) — and a batch alone is what the double-tile instance is launched for.
+        if constexpr (!DUAL) {
+          kasw::wait_loads();
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
+          digest += relax_flush<NB>(pend, out, (uint32_t)k);
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) request_tile(nx[b], tile + NB + b);
       }
@@ -627,7 +652,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     kasw::lockstep();
     uint32_t f0 = 0u, f1 = 0u;
     for (int32_t n = lane; n < N; n += 64) { const uint32_t w = cnt[n]; f0 += w & 0xffffu; f1 += w >> 16; }
-    const uint32_t d0 = (uint32_t)kasw::wave_sum((int)(f0 - seed0)), d1 = (uint32_t)kasw::wave_sum((int)(f1 - seed1));
+    const uint32_t d0 = (uint32_t)kasw::wave_sum((int)f0) - seed0, d1 = (uint32_t)kasw::wave_sum((int)f1) - seed1;
     if (!stuck && (d0 != rows1 || d1 != rows2 || kasw::ballot(cnt[nmax] != KAS_RELAX_PAD_WORD) != 0ull)) unsound = true;
   }
   if constexpr (CTX) {

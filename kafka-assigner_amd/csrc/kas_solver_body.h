@@ -348,9 +348,12 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
 // one trailing halfword through 2-byte-aligned accesses (U32a2: one global_load_dword / global_store_dword each — the
 // hardware's unaligned access mode, which the HSA ABI turns on).
 #define KAS_MID_NONE 0xffffu
-KAS_DEV int32_t mid_width(int32_t ow) { return ow; }
+#ifndef KAS_MID_PAD
+#define KAS_MID_PAD 0                    // tuning builds: 1 = rows padded to an even number of cells (rounds 2-4), same accesses
+#endif
+KAS_DEV int32_t mid_width(int32_t ow) { return KAS_MID_PAD ? ((ow + 1) & ~1) : ow; }
 template <int W>
-constexpr int mid_width_of() { return W; }
+constexpr int mid_width_of() { return KAS_MID_PAD ? ((W + 1) & ~1) : W; }
 struct __attribute__((packed, aligned(2))) U32a2 { uint32_t v; };
 KAS_DEV uint32_t load_u32_a2(const uint16_t* p) { return reinterpret_cast<const U32a2*>(p)->v; }
 KAS_DEV void store_u32_a2(uint16_t* p, uint32_t v) { reinterpret_cast<U32a2*>(p)->v = v; }
@@ -372,7 +375,7 @@ KAS_DEV MidRaw<W> mid_load_raw(const uint16_t* mid, int32_t ow, int64_t p, bool 
   for (int k = 0; k < W; ++k) raw.w[k] = 0xffffffffu;
   if (ow == W) {
     if (active) {
-      const uint16_t* row = mid + p * W;
+      const uint16_t* row = mid + p * mid_width_of<W>();
 #pragma unroll
       for (int k = 0; k < W / 2; ++k) raw.w[k] = load_u32_a2(row + 2 * k);
       if constexpr (W & 1) raw.w[W / 2] = (uint32_t)row[W - 1] | 0xffff0000u;
@@ -540,7 +543,7 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
   if (active) {
 #endif
     if (T.ow == W) {                                        // wave-uniform: the mid row as W / 2 dwords (+ a halfword)
-      uint16_t* row = T.mid + (int64_t)p * W;
+      uint16_t* row = T.mid + (int64_t)p * mid_width_of<W>();
 #pragma unroll
       for (int k = 0; k < W / 2; ++k)
         store_u32_a2(row + 2 * k, ((uint32_t)hold[2 * k] & 0xffffu) | (((uint32_t)hold[2 * k + 1] & 0xffffu) << 16));

@@ -8,14 +8,20 @@
 #include "kas_plan_math.h"
 #include "kas_solver_body.h"
 
-template <int W, bool DUAL, bool CTX>
+template <int W, bool DUAL, bool CTX, bool VERIFY>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY>(a, (int32_t)blockIdx.x, kas_lds);
 }
-template __global__ void kas_order_relax_kernel<2, false, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<2, false, true>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, false, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, false, true>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, true, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, true, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, false, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, true, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, true, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, false, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, true, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, true, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, false, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, true, false>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, true, true>(KasLaunch);

@@ -212,9 +212,9 @@ template <int W> void run_order_wide(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
 }
-template <int W, bool DUAL, bool CTX> void run_order_relax(void* p) {
+template <int W, bool DUAL, bool CTX, bool VERIFY = false> void run_order_relax(void* p) {
   RunArgs* r = (RunArgs*)p;
-  if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX>(*r->a, r->s, r->lds);
+  if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY>(*r->a, r->s, r->lds);
 }
 template <int W> void run_order_rounds(void* p) {
   RunArgs* r = (RunArgs*)p;
@@ -383,6 +383,9 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     const bool rdual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
     run_fn f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true> : (rdual ? run_order_relax<3, true, true> : run_order_relax<3, false, true>))
                           : (sh.Wc <= 2 ? run_order_relax<2, false, false> : (rdual ? run_order_relax<3, true, false> : run_order_relax<3, false, false>));
+    if ((a.flags >> 24) != 0u)                                // KAS_PLAN_VERIFY_SAMPLE: the instances with the second evaluation
+      f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true, true> : (rdual ? run_order_relax<3, true, true, true> : run_order_relax<3, false, true, true>))
+                     : (sh.Wc <= 2 ? run_order_relax<2, false, false, true> : (rdual ? run_order_relax<3, true, false, true> : run_order_relax<3, false, false, true>));
     // exactly the LDS the product launches the kernel with, and a guard behind it: the hardware drops what a
     // workgroup writes beyond its allocation and reads zeros there — here that must not pass unnoticed
     const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx);
