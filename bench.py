@@ -96,9 +96,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the one-batch-alone, literal-mix, end-to-end and other-config legs")
-    ap.add_argument("--in-flight", type=int, default=8,
+    ap.add_argument("--in-flight", type=int, default=12,
                     help="batches in flight: steps are issued round-robin on this many HIP streams, "
-                         "each slot with its own tables, broker sets, plan scratch and outputs")
+                         "each slot with its own tables, broker sets, plan scratch and outputs (round 5: 12 — with every "
+                         "slot's stream on a hardware queue of its own 10-12 slots read 2-5 %% above 8 in the driver's "
+                         "20-step region, whose slots start in phase; rounds 3-4: 8, when two pairs of slots shared a queue)")
     ap.add_argument("--same-batch", action="store_true",
                     help="every slot solves slot 0's tables and broker sets (the consistency stress of "
                          "scripts/stress_inflight.py; not a measurement mode)")
@@ -622,19 +624,20 @@ def run_rank(args) -> int:
         # which pipe is nearest its ceiling: the per-pipe utilisation of the committed SQ-counter passes of this very
         # command line (scripts/pipe_table.py; eight batches in flight, whole job), HBM from the traffic above at this
         # run's rate.  Counters cannot be collected inside a timed run: the table is a committed measurement.
-        if not args.stub and (S, P, N, R, RF) == C3_SHAPE and run.n_slots == 8:
+        if not args.stub and (S, P, N, R, RF) == C3_SHAPE:
             try:
                 import csv
                 pipes = {}
                 side = json.load(open(os.path.join(ROOT, "profiles", "pipe_utilisation.json")))
-                if side.get("kernel") != describe or side.get("kernel_sources_sha16") != roof["kernel_sources_sha16"]:
+                if (side.get("kernel") != describe or side.get("kernel_sources_sha16") != roof["kernel_sources_sha16"] or
+                        side.get("batches_in_flight") != run.n_slots):
                     roof["pipes_note"] = ("profiles/pipe_utilisation.json was taken from other kernels or sources "
                                           f"({side.get('kernel_sources_sha16')}): not quoted")
                     raise LookupError("stale pipe table")
                 with open(os.path.join(ROOT, side["csv"])) as f:
                     vals = {}
                     for row in csv.DictReader(f):
-                        if row["batches_in_flight"] == "8" and row["kernel"] == "fill+order":
+                        if row["batches_in_flight"] not in ("1", "batches_in_flight") and row["kernel"] == "fill+order":
                             vals[row["quantity"]] = float(row["value"])
                             if row["fraction_of_capacity"]:
                                 pipes[row["quantity"]] = float(row["fraction_of_capacity"])
@@ -648,7 +651,7 @@ def run_rank(args) -> int:
                            key=lambda kv: kv[1])
                 roof["pipes"] = dict(table, nearest_ceiling={"pipe": near[0], "frac": near[1]},
                                      waves_resident_per_simd=vals.get("waves resident per SIMD (average)"),
-                                     source=side["csv"] + " (rocprofv3 SQ counter passes of bench.py, eight batches in flight, "
+                                     source=side["csv"] + f" (rocprofv3 SQ counter passes of bench.py, {run.n_slots} batches in flight, "
                                             "fill + order kernels over the ms_per_step window; units in the file; same kernel "
                                             "sources as this run)")
             except Exception:

@@ -39,7 +39,8 @@ def add(mode, k, window, clock, name, value, unit, frac, how):
     out.append([mode, k, f"{window * 1e6:.1f}", f"{clock / 1e9:.2f}", name, f"{value:.4g}", unit, "" if frac is None else f"{frac:.3f}", how])
 
 
-for mode in (1, 8):
+modes = sorted({m for (m, _k) in c})                        # 1 and the bench's default number of batches in flight
+for mode in modes:
     kernels = ["fill", "order"] if mode == 1 else ["fill", "order", "fill+order"]
     for k in kernels:
         if k == "fill+order":
@@ -76,8 +77,9 @@ with open(f"profiles/{tag}_pipe_utilisation.csv", "w") as f:
     csv.writer(f).writerows(out)
 # which kernels and sources the table belongs to: bench.py quotes it (roofline.pipes) only for the same ones
 json.dump({"csv": f"profiles/{tag}_pipe_utilisation.csv", "kernel": line["roofline"]["kernel"],
-           "kernel_sources_sha16": line["roofline"]["kernel_sources_sha16"], "ms_per_step_of_the_window": line["ms_per_step"]},
+           "kernel_sources_sha16": line["roofline"]["kernel_sources_sha16"], "ms_per_step_of_the_window": line["ms_per_step"],
+           "batches_in_flight": max(modes)},
           open("profiles/pipe_utilisation.json", "w"), indent=1)
 for r in out:
-    if r[0] == 8 or r[0] == "batches_in_flight" or (r[0] == 1 and "busy" in r[4]):
+    if r[0] != 1 or (r[0] == 1 and "busy" in r[4]):
         print(" | ".join(str(x) for x in r[:8]))
