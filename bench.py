@@ -891,6 +891,30 @@ def end_to_end_leg(args, run):
         "end_to_end plain: lists differ from the CPU solver"
     for f in fields:
         assert (ho_pin.scenario_results[f][:m] == want.scenario_results[f][:m]).all()
+    # the same call with 16-bit cells (kas_solve_host16, ABI v5): node indices, half the bytes over the link
+    from kafka_assigner_amd.flatten import cells16_to_ids, host_tables16, to_cells16
+    c16 = to_cells16(fbp)
+    pin_cur16, pin_out16 = native.PinnedArray(c16.size, np.uint16), native.PinnedArray(fbp.out_len, np.uint16)
+    pin_cur16.array[:] = c16
+    pin_out16.array[:] = 0
+    t16, ho16 = host_tables16(fbp, pin_cur16.array)
+    t16.out = pin_out16.array.ctypes.data
+    bdp16 = batch_desc(fbp)
+    bdp16.node_id = None
+    for _ in range(2):
+        native._check(L.kas_solve_host16(ctx._h, C.byref(bdp16), C.byref(t16), None, -1))
+    t0 = time.perf_counter()
+    for _ in range(4):
+        native._check(L.kas_solve_host16(ctx._h, C.byref(bdp16), C.byref(t16), None, -1))
+    dt = (time.perf_counter() - t0) / 4
+    plain["pinned_16_bit_cells"] = {"value": m / dt, "unit": "scenarios/s", "ms_per_call": 1e3 * dt,
+                                    "pcie_gb_per_s": 2 * (c16.size + fbp.out_len) / dt / 1e9,
+                                    "what": "kas_solve_host16: cur / out as uint16 node indices, widened / narrowed on the device"}
+    assert (cells16_to_ids(fbp, pin_out16.array) == want.out[:fbp.out_len]).all(), "end_to_end plain, 16-bit cells: lists differ from the CPU solver"
+    for f in fields:
+        if f != "digest":                                               # (the digest covers the cells as emitted: node indices)
+            assert (ho16.scenario_results[f][:m] == want.scenario_results[f][:m]).all()
+    pin_cur16.close(); pin_out16.close()
     plain["what"] = (f"kas_solve_host: {m} scenarios with their own {P} x {RF} tables per call ({4 * fbp.cur.size / 1e6:.0f} MB up, "
                      f"{4 * fbp.out_len / 1e6:.0f} MB down), cut into scenario ranges whose upload / solve / download overlap; "
                      f"pinned = caller buffers from kas_host_alloc (DMA without staging)")
@@ -924,7 +948,20 @@ def end_to_end_leg(args, run):
     to = []
     for _ in range(5):
         t0 = time.perf_counter(); oracle_solve(fb1); to.append(time.perf_counter() - t0)
+    c1 = to_cells16(fb1)
+    t1h, ho1h = host_tables16(fb1, c1)
+    bd1h = batch_desc(fb1)
+    bd1h.node_id = None
+    native._check(L.kas_solve_host16(ctx._h, C.byref(bd1h), C.byref(t1h), None, -1))
+    assert (cells16_to_ids(fb1, ho1h.out)[:fb1.out_len] == want1.out[:fb1.out_len]).all() and (ho1h.ctx == want1.ctx).all(), \
+        "end_to_end per-topic call, 16-bit cells: differs from the CPU solver"
+    t0 = time.perf_counter()
+    for _ in range(n1):
+        ho1h.ctx[:] = ctx_in
+        native._check(L.kas_solve_host16(ctx._h, C.byref(bd1h), C.byref(t1h), None, -1))
+    per_call16 = (time.perf_counter() - t0) / n1
     res["per_topic_call_with_context"] = {
+        "gpu_ms_per_call_16_bit_cells": 1e3 * per_call16,
         "what": "kas_solve_host, one 10k x 100 x RF 3 topic with the adapter's Context in and out (120 KB up, 120 KB down), "
                 "blocking: the drop-in for one getRackAwareAssignment call",
         "gpu_ms_per_call": 1e3 * per_call,

@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define KAS_ABI_VERSION 4
+#define KAS_ABI_VERSION 5
 
 /* Longest replica list the kernels keep in registers: max(cur_width, rf) <= KAS_MAX_WIDTH. */
 #define KAS_MAX_WIDTH 8
@@ -258,6 +258,36 @@ int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* 
 int kas_solve_host_select(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables,
                           const int32_t* select, int32_t n_select);
 
+/* ---- ABI v5: the same host call with 16-bit cells -------------------------------------------------------
+ * The host boundary of the per-topic call (KafkaTopicAssigner.java:70-71) and of the CLI's loop over topics
+ * (KafkaAssignmentGenerator.java:173-184) is bound by the host link, not by the solve; kas_solve_host16 moves half the
+ * bytes.  cur / out cells are uint16 NODE INDICES: cell value i names node i of the scenario's node table — the i-th
+ * smallest broker id of its broker set; every caller sorts the ids anyway to lay out node_rack[] (the reference's own
+ * TreeSet at KafkaAssignmentStrategy.java:73-99), and maps cells back with one table lookup.  KAS_CELL16_NONE in cur =
+ * a broker that is not in the scenario's broker set (its replica is dropped whichever broker it was, KAS:108-110), in
+ * out = the pad value (-1 of the int32 layout).  Everything the algorithm derives from broker ids is their ORDER
+ * (KAS:73-99 sorted nodes, KAS:188-200 processing order by position, KAS:263-278 ties by position), which the indices
+ * keep: rows, statuses, fail_partition and movement counts are those of kas_solve_host on the int32 form of the same
+ * batch, cell for cell after the lookup (tests/test_cells16.py).  The digest of a scenario record covers the cells as
+ * emitted, i.e. kas_digest_cell over node indices.
+ *   batch->node_id is not read and may be NULL (node i has id i); node_rack[], descriptors, aux, ctx, the result
+ *   records and select / n_select (n_select < 0: every row in place) are exactly kas_solve_host_select's; descriptor
+ *   offsets and cur_len / out_len count cells.  More than 65,535 brokers in a scenario: KAS_E_UNSUPPORTED.
+ * On the device the cells are widened before and narrowed behind the solve (two streaming kernels on the range's
+ * solve stream, 6 bytes of HBM traffic per cell against 2 bytes on the link); kas_solve_device keeps int32 cells. */
+#define KAS_CELL16_NONE 0xFFFFu
+typedef struct kas_tables16 {
+  const uint16_t* cur;                  /* cur pool, node indices                            */
+  uint16_t*       out;                  /* out pool, node indices                            */
+  const int32_t* aux;
+  int32_t*       ctx;
+  kas_topic_result*    topic_results;
+  kas_scenario_result* scenario_results;
+  int64_t cur_len, out_len, aux_len, ctx_len;
+} kas_tables16;
+int kas_solve_host16(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables16* host_tables,
+                     const int32_t* select, int32_t n_select);
+
 /* Pinned host memory for table pools (DMA without staging: see kas_solve_host).  A JNI caller wraps
  * it with NewDirectByteBuffer, a Python caller with numpy.frombuffer. */
 int  kas_host_alloc(int64_t bytes, void** out_ptr);
@@ -303,8 +333,9 @@ int kas_ctx_host_stats(kas_ctx* ctx, int64_t* calls, int64_t* plan_hits, int64_t
  * error, and *launches = 0 when nothing was recorded. */
 int kas_plan_kernel_time_us(kas_plan* plan, double* avg_us, int* launches);
 
-/* The same accumulator split by kernel: a solve is the fill kernel (P0-P4) followed by the order
- * kernel (P5) on one stream.  Either call resets the accumulator. */
+/* The same accumulator split in two: a solve is the fill kernel (P0-P3), first fit (P4: kas_p4_kernel behind the fill
+ * where kas_plan_describe names it, inside the fill workgroup elsewhere) — together *fill_us — followed by the order
+ * kernel (P5, *order_us) on one stream.  Either call resets the accumulator. */
 int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, int* launches);
 
 /* Behaviour switches of a plan (default 0); every combination produces identical results, they
@@ -329,6 +360,8 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_NO_RTN_QUOTA  rack-diverse fill with per-chunk histograms: draw a node's quota with separate LDS atomics,
  *                          reads and a ranking of the tiles in which it runs out, instead of one atomic-with-return
  *                          per list position
+ *   KAS_PLAN_FILL_WITH_P4  first fit (KAS:162-186) inside the fill kernel's workgroup, as in rounds 1-4, instead of in
+ *                          kas_p4_kernel behind it (testing / comparison)
  *   KAS_PLAN_VERIFY_SAMPLE(k) relaxation form: k tiles of 64 rows per topic (evenly spaced, 1..255) are evaluated a second
  *                          time one row at a time — independent of how the LDS orders the lanes of an instruction —
  *                          and a scenario in which a row comes out differently reports KAS_FAIL_WATCHDOG instead of a
@@ -345,6 +378,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_RELAX_TILES(n) (((uint32_t)(n) & 3u) << 17)
 #define KAS_PLAN_NO_RTN_QUOTA 0x200000u
+#define KAS_PLAN_FILL_WITH_P4 0x800000u
 #define KAS_PLAN_VERIFY_SAMPLE(k) (((uint32_t)(k) & 0xffu) << 24)
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)
 #define KAS_PLAN_GROUPS(n)    (((uint32_t)(n) & 0xfu) << 12)

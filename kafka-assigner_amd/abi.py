@@ -7,8 +7,9 @@ from __future__ import annotations
 
 import ctypes as C
 
-KAS_ABI_VERSION = 4
+KAS_ABI_VERSION = 5
 KAS_MAX_WIDTH = 8
+KAS_CELL16_NONE = 0xFFFF      # 16-bit cells (kas_solve_host16): no such broker in cur, pad in out
 
 KAS_E_OK = 0
 KAS_E_INVALID_ARG = -1
@@ -36,6 +37,7 @@ KAS_PLAN_TICKET_ORDER = 0x10000
 KAS_PLAN_RELAX_TILES_64 = 0x20000     # KAS_PLAN_RELAX_TILES(1)
 KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)
 KAS_PLAN_NO_RTN_QUOTA = 0x200000
+KAS_PLAN_FILL_WITH_P4 = 0x800000      # first fit inside the fill workgroup (rounds 1-4) instead of in kas_p4_kernel
 
 
 def KAS_PLAN_VERIFY_SAMPLE(k: int) -> int:

@@ -71,6 +71,25 @@ __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
   kas::order_scenario_rounds<W>(a, (int32_t)blockIdx.x, kas_lds);
 }
 
+// first fit (P4) of the topics the fill kernel handed over: one workgroup of four wavefronts per scenario on a slim LDS layout
+// (kas_solver_body.h, p4_scenario; KAS_FLAG_SPLIT_P4)
+// ONE wavefront per scenario: its windows follow each other without a hand-over between wavefronts, so nothing in the kernel
+// polls — alone that is slower (fill + first fit 1.39 ms per 1000 scenarios against 1.07 ms inside the fill workgroup, 1.09 with
+// four wavefronts here), with eight batches in flight it is the fastest (672k scenarios/s in a 20-step region against 617k
+// inside the fill workgroup, 620k with four wavefronts, 646k with two: experiments/README.md)
+#ifndef KAS_P4_KERNEL_WAVES
+#define KAS_P4_KERNEL_WAVES 1
+#endif
+#ifndef KAS_P4_PRIO
+#define KAS_P4_PRIO 2
+#endif
+template <int W>
+__global__ __launch_bounds__(64 * KAS_P4_KERNEL_WAVES) void kas_p4_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  if constexpr (KAS_P4_PRIO > 0) kasw::set_priority<KAS_P4_PRIO>();
+  kas::p4_scenario<W, KAS_P4_KERNEL_WAVES>(a, (int32_t)blockIdx.x, kas_lds);
+}
+
 // Self-test of the one hardware property the relaxation form of P5 and the fill's quota draw rely on and the ISA documents do
 // not state: the LDS serves the lanes of ONE ds_add_rtn instruction that name the same word in ascending lane order, so
 // that the value returned to lane i is the word before the instruction plus the addends of the ACTIVE lanes below i
@@ -182,6 +201,7 @@ typedef void (*kas_kernel_fn)(KasLaunch);
 // tuning build for BASELINE.json configs[4] (lists 5 wide, 4 fill waves): seconds to compile
 static bool kas_minimal_ok(int Wc, int NW, int) { return Wc == 5 && NW == 4; }
 static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<5, 4>; }
+static kas_kernel_fn kas_p4_for(int) { return kas_p4_kernel<5>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
@@ -193,6 +213,7 @@ static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_ker
 // seconds.  Other shapes are refused by kas_plan_create in such a build.
 static bool kas_minimal_ok(int Wc, int NW, int G) { return Wc == 3 && NW == 4 && (G == 2 || G == 1); }
 static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<3, 4>; }
+static kas_kernel_fn kas_p4_for(int) { return kas_p4_kernel<3>; }
 static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
   if (G == 1) return packed ? kas_order_ticket_kernel<3, 1, true> : kas_order_ticket_kernel<3, 1, false>;
   return packed ? kas_order_ticket_kernel<3, 2, true> : kas_order_ticket_kernel<3, 2, false>;
@@ -220,6 +241,15 @@ static kas_kernel_fn kas_fill_for(int Wc, int NW) {
     case 1: return kas_fill_for_w<1>(Wc);   // instantiated width costs a minute of build time and 8 was
     case 2: return kas_fill_for_w<2>(Wc);   // never the faster choice on the GPU)
     default: return kas_fill_for_w<4>(Wc);
+  }
+}
+static kas_kernel_fn kas_p4_for(int Wc) {
+  switch (Wc) {
+    case 2: return kas_p4_kernel<2>;
+    case 3: return kas_p4_kernel<3>;
+    case 4: return kas_p4_kernel<4>;
+    case 5: return kas_p4_kernel<5>;
+    default: return kas_p4_kernel<8>;
   }
 }
 template <int G, bool PK>
@@ -310,6 +340,8 @@ struct kas_ctx {
   hipEvent_t hev_up[KAS_HOST_STREAMS], hev_done[KAS_HOST_STREAMS];
   std::mutex host_mu;                   // kas_solve_host calls on one context are serialised
   KasBuf h_cur, h_out, h_aux, h_ctx, h_tr, h_sr;
+  KasBuf h_cur16, h_out16;              // the 16-bit cells of kas_solve_host16 as they travel (widened / narrowed on the device)
+  std::vector<int32_t> ident_ids;       // node_id pool of a 16-bit call: node i of every scenario has id i
   KasBuf h_tr_pin, h_sr_pin;            // pinned HOST staging of the result records (see kas_solve_host_locked)
   KasCachedPlan plans[KAS_HOST_PLAN_CACHE];
   uint64_t use_clock = 0;
@@ -335,7 +367,7 @@ struct kas_plan {
   int32_t n_scenarios, n_topics;
   // device copies and scratch owned by the plan (grow-only: a plan can be rebuilt for another batch)
   KasBuf b_scen, b_topics, b_node_id, b_node_rack, b_accmask_off, b_accmask, b_orph_off, b_orph, b_perm, b_stats,
-         b_ord_flag, b_sp_hist, b_sp_quota, b_sp_node, b_sp_flag, b_sp_oc;
+         b_ord_flag, b_sp_hist, b_sp_quota, b_sp_node, b_sp_flag, b_sp_oc, b_p4s;
   uint64_t* allocs;             // allocation counter to report to (the context's, or NULL)
   int single_topic;             // every scenario has exactly one topic
   int32_t sp_alloc_chunks;      // chunks per scenario the spread-fill scratch is sized for
@@ -468,7 +500,7 @@ void kas_ctx_destroy(kas_ctx* ctx) {
   if (ctx->hup) (void)hipStreamSynchronize(ctx->hup);
   if (ctx->hdown) (void)hipStreamSynchronize(ctx->hdown);
   for (KasCachedPlan& c : ctx->plans) if (c.plan) kas_plan_destroy(c.plan);
-  for (KasBuf* b : {&ctx->h_cur, &ctx->h_out, &ctx->h_aux, &ctx->h_ctx, &ctx->h_tr, &ctx->h_sr}) kas_buf_free(b);
+  for (KasBuf* b : {&ctx->h_cur, &ctx->h_out, &ctx->h_aux, &ctx->h_ctx, &ctx->h_tr, &ctx->h_sr, &ctx->h_cur16, &ctx->h_out16}) kas_buf_free(b);
   for (KasBuf* b : {&ctx->h_tr_pin, &ctx->h_sr_pin}) { if (b->p) (void)hipHostFree(b->p); b->p = nullptr; b->cap = 0; }
   if (ctx->hevent) (void)hipEventDestroy(ctx->hevent);
   for (hipEvent_t ev : ctx->hev_up) if (ev) (void)hipEventDestroy(ev);
@@ -500,7 +532,7 @@ void kas_plan_destroy(kas_plan* p) {
   if (p->last_slot >= 0) (void)hipEventSynchronize(p->ev_stop[p->last_slot]);
   for (KasBuf* b : {&p->b_scen, &p->b_topics, &p->b_node_id, &p->b_node_rack, &p->b_accmask_off, &p->b_accmask,
                     &p->b_orph_off, &p->b_orph, &p->b_perm, &p->b_stats, &p->b_ord_flag, &p->b_sp_hist, &p->b_sp_quota,
-                    &p->b_sp_node, &p->b_sp_flag, &p->b_sp_oc})
+                    &p->b_sp_node, &p->b_sp_flag, &p->b_sp_oc, &p->b_p4s})
     kas_buf_free(b);
   for (int i = 0; i < KAS_TIMER_SLOTS; ++i) {
     if (p->ev_start[i]) (void)hipEventDestroy(p->ev_start[i]);
@@ -525,6 +557,9 @@ static int kas_plan_set_kernels(kas_plan* p) {
         KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx)));
+  if (p->shape.with_x && kas_p4_lds_layout(p->shape.n_max).total <= KAS_LDS_LIMIT)
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_p4_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kas_p4_lds_layout(p->shape.n_max).total));
   if (p->shape.round_fits)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -637,6 +672,10 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
       (rc = kas_buf_reserve(&p->b_stats, stats_bytes, p->allocs, "stats buffer")) != KAS_E_OK)
     return rc;
   KAS_HIP_TRY(hipMemsetAsync(p->b_stats.p, 0, stats_bytes, st));
+  // hand-over of the first fit to kas_p4_kernel: head words + the brokers' loads, per topic
+  if (sh.with_x && (rc = kas_buf_reserve(&p->b_p4s, sizeof(int32_t) * T * (size_t)(KAS_P4S_HEAD + (sh.n_max > 0 ? sh.n_max : 1)),
+                                         p->allocs, "first-fit hand-over scratch")) != KAS_E_OK)
+    return rc;
   if ((rc = kas_plan_spread_scratch(p)) != KAS_E_OK) return rc;
   if ((rc = kas_plan_set_kernels(p)) != KAS_E_OK) return rc;
   // descriptors are resident before the caller may free its copies
@@ -710,6 +749,12 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   return lp;
 }
 
+// first fit in kas_p4_kernel in this plan's next solve (kas_split_p4)
+static bool kas_plan_split_p4(const kas_plan* p) {
+  return p->b_p4s.p != nullptr &&
+         kas_split_p4(p->shape, p->NW, p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL), kas_plan_spread_chunks(p));
+}
+
 int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (!p || !buf || n <= 0) return set_error(KAS_E_INVALID_ARG, "NULL argument");
   const KasLaunchPlan lp = kas_launch_plan(p);
@@ -744,9 +789,14 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
     snprintf(order + ol, sizeof(order) - ol, " [relaxation form off: LDS lane-order self-test %s]",
              stt == 0 ? "FAILED" : (stt == -2 ? "switched off (KAS_NO_LANE_ORDER)" : "could not run"));
   }
-  const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s + %s", spread, p->Wc, p->NW,
+  char p4[96];
+  p4[0] = 0;
+  if (kas_plan_split_p4(p))                                    // first fit (P4) is a launch of its own between the two
+    snprintf(p4, sizeof(p4), " + kas_p4_kernel<%d> grid=%ux%u lds=%zu", p->Wc, (unsigned)p->n_scenarios, 64u * KAS_P4_KERNEL_WAVES,
+             (size_t)kas_p4_lds_layout(p->shape.n_max).total);
+  const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s%s + %s", spread, p->Wc, p->NW,
                            generic ? "sweeps" : (kas_plan_fused(p) ? "quota, chunk histograms" : "quota"), lp.fill_grid,
-                           lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", order);
+                           lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", p4, order);
   return len < n ? len : n - 1;
 }
 
@@ -784,6 +834,9 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
             ((p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA)) ? KAS_FLAG_LANE_ORDER : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
+  const bool split_p4 = kas_plan_split_p4(p);
+  a.p4s = (int32_t*)p->b_p4s.p;
+  if (split_p4) a.flags |= KAS_FLAG_SPLIT_P4;
   const int slot = p->timer_next;
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
   const int32_t chunks = kas_plan_spread_chunks(p);
@@ -815,6 +868,11 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
+  if (split_p4) {
+    hipLaunchKernelGGL(kas_p4_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64 * KAS_P4_KERNEL_WAVES),
+                       (size_t)kas_p4_lds_layout(p->shape.n_max).total, st, a);
+    KAS_HIP_TRY(hipGetLastError());
+  }
   KAS_HIP_TRY(hipEventRecord(p->ev_mid[slot], st));
   const int packed = lp.packed;
   // a Context handed in: the ticket forms flag the scenarios whose counters do not fit their count
@@ -850,7 +908,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   KAS_HIP_TRY(hipGetLastError());
   if (wide_recheck) {
     KasLaunch af = a;
-    af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~KAS_FLAG_WIDE_CHECK;
+    af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~(KAS_FLAG_WIDE_CHECK | KAS_FLAG_SPLIT_P4);   // (this fill does its own first fit)
     af.sp_flag = a.ord_flag;                                 // (same meaning: != 0, this kernel takes the scenario)
     hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, af);
     KAS_HIP_TRY(hipGetLastError());
@@ -939,7 +997,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
+  p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_FILL_WITH_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
   // plan may still be in flight on the old scratch
@@ -1189,15 +1247,104 @@ static int kas_host_copy_streams(kas_ctx* c) {
   return KAS_E_OK;
 }
 
+// ---- 16-bit cells at the host boundary (kas_solve_host16, include/kas_abi.h) --------------------------------------
+// The solver kernels read and write int32 cells; a 16-bit call moves half the bytes over PCIe and converts on the device,
+// where a cell costs 6 bytes of HBM traffic against the link's 2: KAS_CELL16_NONE <-> -1, every other value as it is.
+// A thread takes 8 cells, the 16-byte side of its accesses aligned (the pools start at whatever cell the descriptors
+// say; the cells before the first aligned group and behind the last go one by one).
+__global__ __launch_bounds__(256) void kas_cells_widen_kernel(const uint16_t* __restrict__ in, int32_t* __restrict__ out, int64_t n) {
+  const int64_t head0 = (int64_t)((16u - (uint32_t)((uintptr_t)in & 15u)) & 15u) >> 1;
+  const int64_t head = head0 < n ? head0 : n;
+  const int64_t groups = (n - head) >> 3;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  auto one = [&](int64_t i) { const uint32_t v = in[i]; out[i] = v == 0xffffu ? -1 : (int32_t)v; };
+  for (int64_t g = tid; g < groups; g += nth) {
+    const int64_t at = head + (g << 3);
+    const uint4 v = *reinterpret_cast<const uint4*>(in + at);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t lo = w[k] & 0xffffu, hi = w[k] >> 16;
+      out[at + 2 * k] = lo == 0xffffu ? -1 : (int32_t)lo;
+      out[at + 2 * k + 1] = hi == 0xffffu ? -1 : (int32_t)hi;
+    }
+  }
+  for (int64_t i = tid; i < head; i += nth) one(i);
+  for (int64_t i = head + (groups << 3) + tid; i < n; i += nth) one(i);
+}
+
+__global__ __launch_bounds__(256) void kas_cells_narrow_kernel(const int32_t* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
+  const int64_t head0 = (int64_t)((16u - (uint32_t)((uintptr_t)out & 15u)) & 15u) >> 1;
+  const int64_t head = head0 < n ? head0 : n;
+  const int64_t groups = (n - head) >> 3;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  // (a node index is below 32,768 and the pad value is -1: the low half of the cell is the 16-bit cell)
+  for (int64_t g = tid; g < groups; g += nth) {
+    const int64_t at = head + (g << 3);
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      w[k] = ((uint32_t)in[at + 2 * k] & 0xffffu) | ((uint32_t)in[at + 2 * k + 1] << 16);
+    *reinterpret_cast<uint4*>(out + at) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  for (int64_t i = tid; i < head; i += nth) out[i] = (uint16_t)in[i];
+  for (int64_t i = head + (groups << 3) + tid; i < n; i += nth) out[i] = (uint16_t)in[i];
+}
+
+static unsigned kas_cells_grid(int64_t n) {
+  const int64_t g = (n / 8 + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+// the 16-bit side of a host call (nullptr members: the int32 call)
+struct KasCells16 {
+  const uint16_t* cur = nullptr;
+  uint16_t* out = nullptr;
+};
+
 #define KAS_HOST_SPLIT_MIN_BYTES (48ll << 20)   // tables smaller than this are moved and solved as one range
 #define KAS_HOST_SPLIT_MAX 8
 
 static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h, const int32_t* select,
-                                 int32_t n_select) {
+                                 int32_t n_select, const KasCells16* c16 = nullptr) {
   KAS_HIP_TRY(hipSetDevice(ctx->device));
   ctx->host_calls += 1;
   const bool all_rows = n_select < 0;
   if (!all_rows && n_select > 0 && !select) return set_error(KAS_E_INVALID_ARG, "select == NULL");
+  // 16-bit cells are node indices: the node table the kernels see gives node i the id i (h->cur / h->out are unused)
+  kas_batch_desc ident_batch;
+  if (c16) {
+    if (batch->n_scenarios < 0 || batch->node_pool_len < 0 || (batch->n_scenarios > 0 && !batch->scenarios))
+      return set_error(KAS_E_INVALID_ARG, "negative size / scenarios == NULL");
+    ctx->ident_ids.assign((size_t)batch->node_pool_len, 0);
+    for (int32_t s = 0; s < batch->n_scenarios; ++s) {
+      const kas_scenario_desc& sd = batch->scenarios[s];
+      if (sd.n_nodes < 0 || sd.node_off < 0 || sd.node_off + sd.n_nodes > batch->node_pool_len)
+        return set_error(KAS_E_INVALID_ARG, "scenario " + std::to_string(s) + ": node table outside the node pool");
+      if (sd.n_nodes > 65535)
+        return set_error(KAS_E_UNSUPPORTED, "scenario " + std::to_string(s) + ": more than 65,535 brokers do not fit 16-bit cells");
+      for (int32_t i = 0; i < sd.n_nodes; ++i) ctx->ident_ids[(size_t)(sd.node_off + i)] = i;
+    }
+    ident_batch = *batch;
+    ident_batch.node_id = ctx->ident_ids.data();
+    batch = &ident_batch;
+  }
+  const size_t cell = c16 ? sizeof(uint16_t) : sizeof(int32_t);     // bytes of a cur / out cell as it travels
+  // A 16-bit call whose out pool lies in pinned memory gets its rows by the narrowing kernel's own stores, straight into
+  // the caller's buffer: the copy engine then only carries the uploads, and the two directions of the link really run
+  // at once (copies of both directions issued from several streams shared the engine: 54-63 GB/s for the sum of both
+  // against 97 GB/s probed, profiles/r04_pcie_*.log).  KAS_NO_ZERO_COPY_OUT=1: through the staging buffer and a copy.
+  uint16_t* zc_out = nullptr;
+  if (c16 && c16->out && all_rows && !(getenv("KAS_NO_ZERO_COPY_OUT") && getenv("KAS_NO_ZERO_COPY_OUT")[0] == '1')) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, c16->out) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
+      zc_out = (uint16_t*)at.devicePointer;
+    else
+      (void)hipGetLastError();                                 // (ordinary memory: not an error)
+  }
+  const bool have_cur = c16 ? c16->cur != nullptr : h->cur != nullptr;
+  const bool have_out = c16 ? c16->out != nullptr : h->out != nullptr;
   // the whole batch: validation and the extents of every pool
   KasShape full;
   {
@@ -1209,7 +1356,7 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   if (h->cur_len < full.cur_need || (all_rows && h->out_len < full.out_need) || h->aux_len < full.aux_need ||
       h->ctx_len < full.ctx_need)
     return set_error(KAS_E_INVALID_ARG, "a descriptor offset reaches beyond the pool length given in kas_tables");
-  if ((full.cur_need > full.cur_lo && !h->cur) || (all_rows && full.out_need > full.out_lo && !h->out) ||
+  if ((full.cur_need > full.cur_lo && !have_cur) || (all_rows && full.out_need > full.out_lo && !have_out) ||
       (full.aux_need > full.aux_lo && !h->aux) || (full.ctx_need > full.ctx_lo && !h->ctx) || (T && !h->topic_results) ||
       (S && !h->scenario_results))
     return set_error(KAS_E_INVALID_ARG, "a table the descriptors refer to is NULL");
@@ -1228,7 +1375,7 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
       }
     }
     sel_off[(size_t)n_select] = at;
-    if (h->out_len < at || (at > 0 && !h->out))
+    if (h->out_len < at || (at > 0 && !have_out))
       return set_error(KAS_E_INVALID_ARG, "select: out / out_len too small for the selected scenarios' rows");
   }
   // device pools: only [lo, need) of each is ever touched, the pointers are rebased so that the
@@ -1239,6 +1386,9 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   if ((rc = kas_host_buf(ctx, &ctx->h_out, sizeof(int32_t) * (size_t)(full.out_need - full.out_lo + 8))) != KAS_E_OK) return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_aux, sizeof(int32_t) * (size_t)(full.aux_need - full.aux_lo + 8))) != KAS_E_OK) return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_ctx, sizeof(int32_t) * (size_t)(full.ctx_need - full.ctx_lo + 8))) != KAS_E_OK) return rc;
+  if (c16 && ((rc = kas_host_buf(ctx, &ctx->h_cur16, sizeof(uint16_t) * (size_t)(full.cur_need - full.cur_lo + 8))) != KAS_E_OK ||
+              (rc = kas_host_buf(ctx, &ctx->h_out16, sizeof(uint16_t) * (size_t)(full.out_need - full.out_lo + 8))) != KAS_E_OK))
+    return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_tr, sizeof(kas_topic_result) * (size_t)(T + 1))) != KAS_E_OK) return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_sr, sizeof(kas_scenario_result) * (size_t)(S + 1))) != KAS_E_OK) return rc;
   // The result records come back through pinned staging of the context's own: the caller's record arrays are ordinary
@@ -1251,6 +1401,8 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   kas_scenario_result* p_sr = (kas_scenario_result*)ctx->h_sr_pin.p;
   int32_t* d_cur = (int32_t*)ctx->h_cur.p - full.cur_lo;
   int32_t* d_out = (int32_t*)ctx->h_out.p - full.out_lo;
+  uint16_t* d_cur16 = c16 ? (uint16_t*)ctx->h_cur16.p - full.cur_lo : nullptr;
+  uint16_t* d_out16 = c16 ? (uint16_t*)ctx->h_out16.p - full.out_lo : nullptr;
   int32_t* d_aux = (int32_t*)ctx->h_aux.p - full.aux_lo;
   int32_t* d_ctx = (int32_t*)ctx->h_ctx.p - full.ctx_lo;
   kas_topic_result* d_tr = (kas_topic_result*)ctx->h_tr.p;
@@ -1258,8 +1410,8 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
 
   // ---- scenario ranges (chains).  Large tables laid out scenario by scenario are cut so that the upload
   // of one range, the solve of the previous one and the download of the one before overlap.
-  const int64_t bytes_in = 4 * (full.cur_need - full.cur_lo);
-  const int64_t bytes_out = all_rows ? 4 * (full.out_need - full.out_lo) : 0;
+  const int64_t bytes_in = (int64_t)cell * (full.cur_need - full.cur_lo);
+  const int64_t bytes_out = all_rows ? (int64_t)cell * (full.out_need - full.out_lo) : 0;
   int K = 1;
   if (bytes_in + bytes_out >= KAS_HOST_SPLIT_MIN_BYTES && S >= 2) {
     K = (int)((bytes_in + bytes_out) / (KAS_HOST_SPLIT_MIN_BYTES / 2));
@@ -1325,8 +1477,11 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   auto download = [&](int i) {
     const KasChain& c = chains[(size_t)i];
     if (K > 1) hip_ok(hipStreamWaitEvent(s_down, ctx->hev_done[i], 0), "wait");
-    if (all_rows && c.out_hi > c.out_lo)
-      hip_ok(hipMemcpyAsync(h->out + c.out_lo, d_out + c.out_lo, 4 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, s_down), "download out");
+    if (all_rows && c.out_hi > c.out_lo) {
+      if (c16 && zc_out) {}                                    // (the narrowing kernel has stored them where they belong)
+      else if (c16) hip_ok(hipMemcpyAsync(c16->out + c.out_lo, d_out16 + c.out_lo, 2 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, s_down), "download out");
+      else hip_ok(hipMemcpyAsync(h->out + c.out_lo, d_out + c.out_lo, 4 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, s_down), "download out");
+    }
     if (c.thi > c.tlo)
       hip_ok(hipMemcpyAsync(p_tr + c.tlo, d_tr + c.tlo, sizeof(kas_topic_result) * (size_t)(c.thi - c.tlo), hipMemcpyDeviceToHost, s_down), "download topic results");
     if (c.hi > c.lo)
@@ -1340,19 +1495,32 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   for (int i = 0; i < K && he == hipSuccess && fail_rc == KAS_E_OK; ++i) {
     KasChain& c = chains[(size_t)i];
     hipStream_t st = K > 1 ? ctx->hstream[i % KAS_HOST_STREAMS] : s0;
-    if (c.cur_hi > c.cur_lo)
-      hip_ok(hipMemcpyAsync(d_cur + c.cur_lo, h->cur + c.cur_lo, 4 * (size_t)(c.cur_hi - c.cur_lo), hipMemcpyHostToDevice, s_up), "upload cur");
+    if (c.cur_hi > c.cur_lo) {
+      if (c16) hip_ok(hipMemcpyAsync(d_cur16 + c.cur_lo, c16->cur + c.cur_lo, 2 * (size_t)(c.cur_hi - c.cur_lo), hipMemcpyHostToDevice, s_up), "upload cur");
+      else hip_ok(hipMemcpyAsync(d_cur + c.cur_lo, h->cur + c.cur_lo, 4 * (size_t)(c.cur_hi - c.cur_lo), hipMemcpyHostToDevice, s_up), "upload cur");
+    }
     if (K > 1) {
       hip_ok(hipEventRecord(ctx->hev_up[i], s_up), "record");
       hip_ok(hipStreamWaitEvent(st, ctx->hev_up[i], 0), "wait");
     }
     if (he != hipSuccess) break;
+    if (c16 && c.cur_hi > c.cur_lo) {                          // (on the range's solve stream: the copy streams only copy)
+      const int64_t n = c.cur_hi - c.cur_lo;
+      hipLaunchKernelGGL(kas_cells_widen_kernel, dim3(kas_cells_grid(n)), dim3(256), 0, st, d_cur16 + c.cur_lo, d_cur + c.cur_lo, n);
+      if (!hip_ok(hipGetLastError(), "kas_cells_widen_kernel")) break;
+    }
     kas_tables d;
     memset(&d, 0, sizeof(d));
     d.cur = d_cur; d.out = d_out; d.aux = d_aux; d.ctx = d_ctx;
     d.topic_results = d_tr + c.tlo; d.scenario_results = d_sr + c.lo;
     const int src = kas_solve_device(c.plan, &d, st);
     if (src != KAS_E_OK) { fail_rc = src; break; }
+    if (c16 && all_rows && c.out_hi > c.out_lo) {
+      const int64_t n = c.out_hi - c.out_lo;
+      hipLaunchKernelGGL(kas_cells_narrow_kernel, dim3(kas_cells_grid(n)), dim3(256), 0, st, d_out + c.out_lo,
+                         (zc_out ? zc_out : d_out16) + c.out_lo, n);
+      if (!hip_ok(hipGetLastError(), "kas_cells_narrow_kernel")) break;
+    }
     if (K > 1) hip_ok(hipEventRecord(ctx->hev_done[i], st), "record");
     if (i >= lag) download(i - lag);
   }
@@ -1373,7 +1541,11 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
       for (int32_t t = 0; t < sd.topic_count && he == hipSuccess; ++t) {
         const kas_topic_desc& td = batch->topics[sd.topic_begin + t];
         const int64_t cells = (int64_t)td.n_partitions * td.out_width;
-        if (cells > 0)
+        if (cells > 0 && c16) {
+          hipLaunchKernelGGL(kas_cells_narrow_kernel, dim3(kas_cells_grid(cells)), dim3(256), 0, s0, d_out + td.out_off, d_out16 + td.out_off, cells);
+          hip_ok(hipGetLastError(), "kas_cells_narrow_kernel");
+          hip_ok(hipMemcpyAsync(c16->out + at, d_out16 + td.out_off, 2 * (size_t)cells, hipMemcpyDeviceToHost, s0), "download selected rows");
+        } else if (cells > 0)
           hip_ok(hipMemcpyAsync(h->out + at, d_out + td.out_off, 4 * (size_t)cells, hipMemcpyDeviceToHost, s0), "download selected rows");
         at += cells;
       }
@@ -1391,6 +1563,18 @@ int kas_solve_host_select(kas_ctx* ctx, const kas_batch_desc* batch, const kas_t
 
 int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h) {
   return kas_solve_host_select(ctx, batch, h, nullptr, -1);
+}
+
+int kas_solve_host16(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables16* h16, const int32_t* select, int32_t n_select) {
+  if (!ctx || !batch || !h16) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  kas_tables h;                                                // everything but the cells is the int32 call's
+  memset(&h, 0, sizeof(h));
+  h.aux = h16->aux; h.ctx = h16->ctx; h.topic_results = h16->topic_results; h.scenario_results = h16->scenario_results;
+  h.cur_len = h16->cur_len; h.out_len = h16->out_len; h.aux_len = h16->aux_len; h.ctx_len = h16->ctx_len;
+  KasCells16 c16;
+  c16.cur = h16->cur; c16.out = h16->out;
+  std::lock_guard<std::mutex> lock(ctx->host_mu);
+  return kas_solve_host_locked(ctx, batch, &h, select, n_select < 0 ? -1 : n_select, &c16);
 }
 
 int kas_solve_host_sharded(kas_ctx* const* ctxs, int32_t n_ctx, const kas_batch_desc* batch, const kas_tables* h) {

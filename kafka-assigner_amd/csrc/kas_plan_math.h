@@ -44,6 +44,10 @@ struct KasLaunch {
   int32_t* sp_flag;             // [S]                   != 0: the scenario takes the one-workgroup kernel instead
   int32_t* sp_oc;               // [S][chunks + 2]       orphans per chunk, then moved replicas / partitions
   int32_t sp_chunks;            // chunks per scenario (0: no spread fill in this launch)
+  // split first fit (KAS_FLAG_SPLIT_P4, round 5): the fill kernel ends a rack-diverse topic behind pass B and leaves P4 to
+  // kas_p4_kernel — four wavefronts on 9 KB of LDS instead of the fill workgroup's 128 VGPRs x 4 and 35 KB for the
+  // 0.3 ms in which first fit touches no table
+  int32_t* p4s;                 // [n_topics][KAS_P4S_HEAD + n_max]: head words (kas_plan_math.h), then the brokers' loads after P2
   int32_t n_scenarios;
   int32_t n_max;                // largest broker count in the batch (LDS array extent)
   int32_t idmap_entries;        // entries of the direct broker-id -> node-index table
@@ -66,6 +70,8 @@ struct KasLaunch {
 #define KAS_FLAG_RELAX_TILES_128 0x40000u // relaxation form: double tiles whatever the batch size (KAS_PLAN_RELAX_TILES(2))
 #define KAS_FLAG_RELAX_DUAL      0x80000u // set by the launcher (kas_relax_double_tiles): double tiles in this launch
 #define KAS_FLAG_LANE_ORDER      0x100000u // set by the launcher: the LDS hands the lanes of one atomic instruction out in lane order here (self-test)
+#define KAS_FLAG_SPLIT_P4        0x400000u // set by the launcher (kas_split_p4): first fit of rack-diverse topics runs in kas_p4_kernel
+#define KAS_FLAG_FILL_WITH_P4    0x800000u // KAS_PLAN_FILL_WITH_P4: first fit inside the fill workgroup as in rounds 1-4 (testing / comparison)
 #define KAS_FLAG_NO_RTN_QUOTA    0x200000u // KAS_PLAN_NO_RTN_QUOTA: the fill draws its quota without the atomic-with-return (testing / comparison)
 #define KAS_RELAX_DUAL_BELOW 512         // batches of fewer scenarios than this take double tiles unless told otherwise
 
@@ -287,6 +293,24 @@ KAS_ABI_FN int32_t kas_order_round_lds(int32_t n_max, int32_t W) {
   return kas_align16(kas_align16(4 * n * kas_cnt_stride(W)) + 8 * n + 64);
 }
 
+// Hand-over words of a topic whose first fit is left to kas_p4_kernel (KasLaunch::p4s): [0] 1 = first fit pending (0: the
+// fill kernel did it itself — the general fill — or the topic is not OK), [1] cap, [2 .. 2 + NW) orphans per chunk
+#define KAS_P4S_HEAD 16
+#define KAS_P4_WAVES 4
+// LDS of kas_p4_kernel: load[n] int32, rack[n] int16, live[n] int16, control words
+struct KasP4Lds { int32_t off_load, off_rack, off_live, off_ctl, total; };
+KAS_ABI_FN KasP4Lds kas_p4_lds_layout(int32_t n_max) {
+  KasP4Lds L;
+  const int64_t n = n_max > 0 ? n_max : 1;
+  int64_t o = 0;
+  L.off_load = (int32_t)o; o = kas_align16(o + 4 * n);
+  L.off_rack = (int32_t)o; o = kas_align16(o + 2 * n);
+  L.off_live = (int32_t)o; o = kas_align16(o + 2 * n);
+  L.off_ctl = (int32_t)o;  o = kas_align16(o + 4 * KAS_CTL_INTS);
+  L.total = (int32_t)o;
+  return L;
+}
+
 // widths the kernels are instantiated for; a batch uses the smallest one >= its widest list
 KAS_ABI_FN int32_t kas_width_class(int32_t W) { return W <= 2 ? 2 : W <= 5 ? W : 8; }
 
@@ -323,6 +347,13 @@ struct KasShape {
   int64_t cur_lo = 0, out_lo = 0, aux_lo = 0, ctx_lo = 0;
   KasLds lds{};
 };
+
+// First fit in a kernel of its own for this launch?  The rack-diverse fill with four wavefronts per scenario, the
+// one-workgroup fill kernel (the spread fill has its own P4 kernel).  `launch_flags`: KasLaunch::flags of the solve.
+static inline bool kas_split_p4(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks) {
+  return s.with_x && nw == KAS_P4_WAVES && !(launch_flags & (KAS_FLAG_GENERIC_FILL | KAS_FLAG_FILL_WITH_P4)) && spread_chunks == 0 &&
+         kas_p4_lds_layout(s.n_max).total <= KAS_LDS_LIMIT;
+}
 
 // Fused histogram layout of the rack-diverse fill (kas_fill_lds_layout with_x = 2): lists up to 3 wide
 // (the instantiated variants), more than one chunk, a chunk's rows countable in uint16, and the larger
@@ -413,7 +444,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     }
     if (sd.n_nodes > s.n_max) s.n_max = sd.n_nodes;
     s.algorithmic_bytes += 8ll * sd.n_nodes;
-    int64_t words = 0, rows = 0, ticket_bound = 0;
+    int64_t words = 0, rows = 0, rows_sum = 0, ticket_bound = 0;
     for (int32_t k = 0; k < sd.topic_count; ++k) {
       const kas_topic_desc& td = b->topics[sd.topic_begin + k];
       std::string where = "scenario " + std::to_string(i) + " topic " + std::to_string(k) + ": ";
@@ -442,6 +473,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       int64_t w = (int64_t)td.cur_width * ((P + 63) / 64);
       if (w > words) words = w;
       if (((P + 63) / 64) * 64 > rows) rows = ((P + 63) / 64) * 64;
+      rows_sum += ((P + 63) / 64) * 64;
       s.algorithmic_bytes += 4ll * P * (td.cur_width + td.out_width);
       // a node never holds more than cap rows of a topic (KAS:65-71, cap over <= P partitions), and
       // a ticket on node n counts the rows that hold n so far in the scenario
@@ -458,8 +490,10 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
     if (ticket_bound >= KAS_WIDE_COMMIT_LIMIT) s.bound_mid = 0;
     s.accmask_off[(size_t)i] = s.accmask_words;
     s.accmask_words += words > 0 ? words : 1;
+    // (every topic its own stretch of the scenario's orphan scratch: with the first fit in a kernel of its own a topic's list
+    // is read after the fill kernel has gone on to the next topic)
     s.orph_off[(size_t)i] = s.orph_ints;
-    s.orph_ints += rows > 0 ? rows : 64;
+    s.orph_ints += rows_sum > 0 ? rows_sum : 64;
   }
   if (s.cur_lo == kNone || s.cur_lo > s.cur_need) s.cur_lo = s.cur_need;
   if (s.out_lo == kNone || s.out_lo > s.out_need) s.out_lo = s.out_need;

@@ -537,6 +537,13 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
   }
   const bool in_parts = active && (T.inp_arr ? T.inp_arr[p] != 0 : true);
   need = in_parts ? (T.rf - hc > 0 ? T.rf - hc : 0) : 0;   // KAS:151-157
+#if defined(KAS_TUNE_NO_ORPHANS)                            // (tuning builds, WRONG results: what would the job run at if P4 cost the fill nothing?
+  {                                                         //  missing holders are filled with other brokers on the spot, no row is an orphan)
+#pragma unroll
+    for (int k = 0; k < W; ++k) hold[k] = (k >= hc && k < T.rf) ? (int32_t)((uint32_t)(p * 7 + k * 131) % (uint32_t)T.N) : hold[k];
+    need = 0;
+  }
+#endif
 #if defined(KAS_TUNE_NO_MID_STORES)                          // (tuning builds: how much of the fill's time is its 8-byte row stores)
   if (false) {
 #else
@@ -1029,25 +1036,27 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
 #ifndef KAS_P4_U_WIDE
 #define KAS_P4_U_WIDE 1
 #endif
-template <int W, int NW>
+// (NC: chunk lists the orphans come in — the fill's wavefronts — where that is not the number of wavefronts running the
+// windows: kas_p4_kernel)
+template <int W, int NW, int NC = NW>
 KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t live_count, int32_t wave,
                                int64_t (&st)[8], int32_t& fail_win, int32_t& fail_row) {
   const int lane = kasw::lane();
   uint64_t* prog = (uint64_t*)&L.ctl[KAS_CTL_PROG];
-  int32_t oc[NW], total = 0;
+  int32_t oc[NC], total = 0;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) { oc[w] = L.ctl[KAS_CTL_OC + w]; total += oc[w]; }
+  for (int w = 0; w < NC; ++w) { oc[w] = L.ctl[KAS_CTL_OC + w]; total += oc[w]; }
   // row index of the g-th orphan of the topic (chunk lists concatenated), or -1 past the end
   // row index of the g-th orphan of the topic (chunk lists concatenated), or -1 past the end
   auto orphan_row = [&](int32_t g) -> int32_t {
     int32_t w = 0, base = 0;
 #pragma unroll
-    for (int k = 0; k < NW - 1; ++k) {
+    for (int k = 0; k < NC - 1; ++k) {
       const bool next = w == k && g >= base + oc[k];
       base += next ? oc[k] : 0;
       w += next ? 1 : 0;
     }
-    return g < total ? T.orph[((int64_t)chunk_begin<NW>(T.nt, w) << 6) + (g - base)] : -1;
+    return g < total ? T.orph[((int64_t)chunk_begin<NC>(T.nt, w) << 6) + (g - base)] : -1;
   };
   auto row_cells = [&](int32_t p) -> MidRaw<W> {
     return mid_load_raw<W>(T.mid, T.ow, p >= 0 ? p : 0, p >= 0);
@@ -1243,7 +1252,7 @@ KAS_DEV void sort_holders(const int32_t (&cells)[W], int32_t (&h)[W], int32_t& L
 template <int W, int NW>
 KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, const LdsView& L,
                                 const NodeMap& nm, const int32_t* g_node_id, const int32_t* g_node_rack,
-                                uint64_t* accmask, int32_t* orph, int64_t (&st)[8]) {
+                                uint64_t* accmask, int32_t* orph, int32_t* p4s, int64_t (&st)[8]) {
   constexpr int NT = 64 * NW;
   const int lane = kasw::lane();
   const int tid = kasw::tid();
@@ -1384,6 +1393,27 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   // ---- KAS:168: getNodeProcessingOrder(topic, all nodes); runs even with zero orphans -------
   const int32_t idxN = java_abs_mod(hash, N);
   if (idxN < 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }      // workgroup-uniform
+  // ---- split first fit (KAS_FLAG_SPLIT_P4): a rack-diverse topic ends here — the brokers' loads, the orphan counts of the
+  // chunks and cap go to kas_p4_kernel, which runs P4 (KAS:56, 162-186) on a quarter of this workgroup's LDS and registers
+  // and reports a partition that cannot be placed; the topic's result says OK until then
+  if (p4s != nullptr) {                                      // (workgroup-uniform)
+    if (fast) {
+      for (int32_t i = tid; i < N; i += NT) p4s[KAS_P4S_HEAD + i] = lds_load(L, i);
+      if (tid == 0) { p4s[0] = 1; p4s[1] = cap; }
+      if (tid < NW) p4s[2 + tid] = L.ctl[KAS_CTL_OC + tid];
+      const int32_t mr = kasw::wave_sum(moved_r), mp = kasw::wave_sum(moved_p);
+      if (lane == 0 && (mr | mp) != 0) {
+        kasw::lds_atomic_add(&L.ctl[KAS_CTL_MOVED_R], mr);
+        kasw::lds_atomic_add(&L.ctl[KAS_CTL_MOVED_P], mp);
+      }
+      kasw::sync();
+      { const int64_t now = kasw::clock_ticks(); st[3] += now - tmark; tmark = now; }
+      res.moved_replicas = L.ctl[KAS_CTL_MOVED_R];
+      res.moved_partitions = L.ctl[KAS_CTL_MOVED_P];
+      return res;
+    }
+    if (tid == 0) p4s[0] = 0;                                // (the general fill: first fit below, in this workgroup)
+  }
   if (wave == 0) {
     const int32_t start = (N - idxN) % N;        // order[j] = sorted[(j + start) % N]
     // non-full nodes in processing order (full nodes can never accept again)
@@ -1496,19 +1526,23 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 
   st[0] += kasw::clock_ticks() - t_begin;
   uint64_t* accmask = a.accmask + a.accmask_off[s];
-  int32_t* orph = a.orph + a.orph_off[s];
+  int32_t* orph = a.orph + a.orph_off[s];                   // (the next topic's stretch)
   int32_t scen_status = KAS_OK, fail_topic = -1, fail_part = -1;
   int32_t moved_r = 0, moved_p = 0;
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
     const kas_topic_desc td = a.topics[ti];
+    int32_t* const orph_topic = orph;                                  // (every topic its own stretch of the orphan scratch)
+    orph += (int64_t)((td.n_partitions > 0 ? td.n_partitions : 0) + 63) / 64 * 64;
+    int32_t* const p4s = (a.flags & KAS_FLAG_SPLIT_P4) ? a.p4s + (int64_t)ti * (KAS_P4S_HEAD + a.n_max) : nullptr;
+    if (p4s != nullptr && tid == 0) p4s[0] = 0;                        // (until a rack-diverse topic says otherwise)
     TopicOutcome o;
     o.status = KAS_OK; o.fail_partition = -1; o.moved_replicas = 0; o.moved_partitions = 0;
     if (scen_status != KAS_OK) o.status = KAS_SKIPPED;                 // KAG:173-184 aborted
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = fill_topic<W, NW>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph, st);
+    else o = fill_topic<W, NW>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph_topic, p4s, st);
     kasw::sync();
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding
@@ -1538,6 +1572,113 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
       for (int i = 0; i < 8; ++i) a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + i] = st[i];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kas_p4_kernel, one scenario (KAS_FLAG_SPLIT_P4): first fit (P4, KAS:56, 162-186) of the topics the fill kernel handed
+// over, in order, on four wavefronts — p4_lists_parallel exactly as the fill workgroup ran it, on the loads the sticky
+// fill left (KasLaunch::p4s), the topic's orphan lists and its mid rows.  A partition that cannot be placed fails its
+// topic (KAS:183-184), the topics behind it are skipped (KAG:173-184 aborted) and emit nothing, and the scenario's
+// record says so — what fill_scenario does when first fit runs inside it.
+// ---------------------------------------------------------------------------------------------
+template <int W, int PW>
+KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+  constexpr int NW = PW, NT = 64 * NW, NC = KAS_P4_WAVES;    // PW wavefronts run the windows over the fill's NC chunk lists
+  const int tid = kasw::tid(), lane = kasw::lane();
+  const int32_t wave = kasw::wave_id();
+  const kas_scenario_desc sd = a.scen[s];
+  const int32_t N = sd.n_nodes;
+  // (a scenario the fill kernel failed at topic k2 still has its rack-diverse topics before k2 waiting for their first fit)
+  const KasP4Lds lay = kas_p4_lds_layout(a.n_max);
+  LdsView L;
+  L.x = nullptr; L.qrs = nullptr; L.idmap = nullptr; L.ids = nullptr; L.ring_p = nullptr; L.ring_meta = nullptr; L.ring_rack = nullptr;
+  L.load = (int32_t*)(lds_raw + lay.off_load);
+  L.rack = (int16_t*)(lds_raw + lay.off_rack);
+  L.live = (int16_t*)(lds_raw + lay.off_live);
+  L.ctl = (int32_t*)(lds_raw + lay.off_ctl);
+  L.ns = 1; L.rs = 1;
+  const int32_t* g_node_rack = a.node_rack + sd.node_off;
+  const int64_t t_begin = kasw::clock_ticks();
+  int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t* orph = a.orph + a.orph_off[s];
+  bool failed = false;
+  int32_t fail_topic = -1, fail_part = -1, moved_r = 0, moved_p = 0;   // (moved: over the topics before a failure)
+  for (int32_t k = 0; k < sd.topic_count; ++k) {
+    const int32_t ti = sd.topic_begin + k;
+    const kas_topic_desc td = a.topics[ti];
+    int32_t* const orph_topic = orph;
+    orph += (int64_t)((td.n_partitions > 0 ? td.n_partitions : 0) + 63) / 64 * 64;
+    if (failed) {                                            // KAG:173-184 aborted: nothing is returned for this topic
+      int32_t* out = a.out + td.out_off;
+      const int64_t cells = (int64_t)td.n_partitions * td.out_width;
+      for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
+      if (tid == 0) {
+        kas_topic_result tr;
+        tr.status = KAS_SKIPPED; tr.fail_partition = -1; tr.moved_replicas = 0; tr.moved_partitions = 0;
+        a.topic_results[ti] = tr;
+      }
+      continue;
+    }
+    const kas_topic_result tr0 = a.topic_results[ti];
+    moved_r += tr0.moved_replicas; moved_p += tr0.moved_partitions;
+    const int32_t* p4s = a.p4s + (int64_t)ti * (KAS_P4S_HEAD + a.n_max);
+    if (tr0.status != KAS_OK || p4s[0] == 0) continue;       // (workgroup-uniform: nothing handed over)
+    TopicView T;
+    T.cur = nullptr; T.orph = orph_topic; T.len_arr = nullptr; T.inp_arr = nullptr;
+    T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
+    T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
+    T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
+    T.mid = mid_base(a.out + td.out_off, T.P, T.ow);
+    T.cap = p4s[1];
+    const int32_t cap = T.cap;
+    kasw::sync();                                            // (the previous topic's node state has been read)
+    for (int32_t i = tid; i < N; i += NT) { L.load[i] = p4s[KAS_P4S_HEAD + i]; L.rack[i] = (int16_t)g_node_rack[i]; }
+    if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : (tid == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
+    kasw::sync();
+    if (tid < NC) L.ctl[KAS_CTL_OC + tid] = p4s[2 + tid];
+    if (wave == 0) {                                         // non-full nodes in processing order (KAS:168, 188-200), as fill_topic
+      const int32_t idxN = java_abs_mod(T.hash, N);          // (>= 0: the fill kernel checked)
+      const int32_t start = (N - idxN) % N;
+      int32_t live_count = 0;
+      for (int32_t base = 0; base < N; base += 64) {
+        const int32_t j = base + lane;
+        int32_t n = j + start; if (n >= N) n -= N;
+        const bool is_live = j < N && lds_load(L, n) < cap;
+        const uint64_t m = kasw::ballot(is_live);
+        if (is_live) L.live[live_count + kasw::count_below(m)] = (int16_t)n;
+        live_count += kasw::popc(m);
+      }
+      kasw::lockstep();
+      if (lane == 0) L.ctl[KAS_CTL_LIVE] = live_count;
+    }
+    kasw::sync();
+    int32_t fail_win = -1, fail_row = -1;
+    p4_lists_parallel<W, NW, NC>(L, T, L.ctl[KAS_CTL_LIVE], wave, st, fail_win, fail_row);
+    kasw::sync();                                            // KAS_CTL_FAILWIN is final: its wave reports the row
+    if (fail_win >= 0 && fail_win == L.ctl[KAS_CTL_FAILWIN] && lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
+    kasw::sync();
+    const bool hung = KAS_SPIN_BOUND > 0 && L.ctl[KAS_CTL_WATCHDOG] != 0;
+    const int32_t frow = L.ctl[KAS_CTL_FAILROW];
+    if (hung || frow >= 0) {                                 // (workgroup-uniform)
+      failed = true; fail_topic = k;
+      fail_part = hung ? -1 : (T.pid_arr ? T.pid_arr[frow] : frow);
+      moved_r -= tr0.moved_replicas; moved_p -= tr0.moved_partitions;
+      int32_t* out = a.out + td.out_off;                     // nothing is returned for a failed topic: its rows are all padding
+      const int64_t cells = (int64_t)td.n_partitions * td.out_width;
+      for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
+      if (tid == 0) {
+        kas_topic_result tr;
+        tr.status = hung ? KAS_FAIL_WATCHDOG : KAS_FAIL_UNASSIGNABLE; tr.fail_partition = fail_part;
+        tr.moved_replicas = 0; tr.moved_partitions = 0;
+        a.topic_results[ti] = tr;
+        kas_scenario_result sr;
+        sr.status = tr.status; sr.fail_topic = fail_topic; sr.fail_partition = fail_part;
+        sr.moved_replicas = moved_r; sr.moved_partitions = moved_p; sr.reserved = 0; sr.digest = 0;
+        a.scenario_results[s] = sr;
+      }
+    }
+  }
+  if (tid == 0 && a.stats) a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 3] += kasw::clock_ticks() - t_begin;
 }
 
 // ---------------------------------------------------------------------------------------------

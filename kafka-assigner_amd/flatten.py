@@ -331,3 +331,87 @@ def unflatten_context(fb: FlatBatch, ctx: np.ndarray, scenario_index: int) -> Di
     ids = fb.node_id[int(sd["node_off"]): int(sd["node_off"]) + N]
     return {int(ids[n]): {r: int(tab[n, r]) for r in range(cw) if tab[n, r]}
             for n in range(N) if tab[n].any()}
+
+
+# ---- 16-bit cells (kas_solve_host16, include/kas_abi.h): cur / out as node indices ---------------------------------
+def _topic_scenarios(fb: FlatBatch) -> np.ndarray:
+    """scenario index per topic"""
+    owner = np.full(fb.n_topics, -1, dtype=np.int64)
+    for s in range(fb.n_scenarios):
+        b, c = int(fb.scen["topic_begin"][s]), int(fb.scen["topic_count"][s])
+        owner[b:b + c] = s
+    return owner
+
+
+def to_cells16(fb: FlatBatch) -> np.ndarray:
+    """The cur pool as uint16 node indices: cell i = position of the broker id in its scenario's (ascending) node table,
+    KAS_CELL16_NONE for a broker that is not in the scenario's broker set (and for the cells behind a short row).
+    A cur table shared by scenarios with different broker sets (the what-if layout) has no such form: ValueError."""
+    cur16 = np.full(fb.cur.shape[0], abi.KAS_CELL16_NONE, dtype=np.uint16)
+    owner = _topic_scenarios(fb)
+    done: Dict[int, int] = {}
+    for t in range(fb.n_topics):
+        td, s = fb.topics[t], int(owner[t])
+        if s < 0:
+            continue
+        n, off = int(fb.scen["n_nodes"][s]), int(fb.scen["node_off"][s])
+        if n > 65535:
+            raise ValueError("more than 65,535 brokers do not fit 16-bit cells")
+        ids = fb.node_id[off:off + n]
+        lo, cells = int(td["cur_off"]), int(td["n_partitions"]) * int(td["cur_width"])
+        if cells <= 0:
+            continue
+        if lo in done:
+            o = done[lo]
+            po, pn = int(fb.scen["node_off"][o]), int(fb.scen["n_nodes"][o])
+            if pn != n or not np.array_equal(fb.node_id[po:po + pn], ids):
+                raise ValueError("a cur table shared by scenarios with different broker sets has no node-index form")
+            continue
+        done[lo] = s
+        c = fb.cur[lo:lo + cells]
+        pos = np.searchsorted(ids, c)
+        hit = (pos < n) & (ids[np.minimum(pos, max(n - 1, 0))] == c) if n else np.zeros(cells, bool)
+        cur16[lo:lo + cells] = np.where(hit, pos, abi.KAS_CELL16_NONE).astype(np.uint16)
+    return cur16
+
+
+def cells16_to_ids(fb: FlatBatch, out16: np.ndarray) -> np.ndarray:
+    """An out pool of node indices back as int32 broker ids (KAS_CELL16_NONE -> -1, cells no topic owns -> -2 as
+    host_tables leaves them)."""
+    out = np.full(out16.shape[0], -2, dtype=np.int32)
+    owner = _topic_scenarios(fb)
+    for t in range(fb.n_topics):
+        td, s = fb.topics[t], int(owner[t])
+        if s < 0:
+            continue
+        n, off = int(fb.scen["n_nodes"][s]), int(fb.scen["node_off"][s])
+        ids = np.concatenate([fb.node_id[off:off + n], np.zeros(1, np.int32)])
+        lo, cells = int(td["out_off"]), int(td["n_partitions"]) * int(td["out_width"])
+        c = out16[lo:lo + cells].astype(np.int64)
+        pad = c == abi.KAS_CELL16_NONE
+        out[lo:lo + cells] = np.where(pad, -1, ids[np.where(pad, n, np.minimum(c, n))])
+    return out
+
+
+def index_form(fb: FlatBatch) -> FlatBatch:
+    """The batch a 16-bit call solves, in int32: node i of every scenario has id i and cur holds node indices (-1 for a
+    broker that is not in the broker set).  kas_solve_host on it returns the cells and the digests kas_solve_host16
+    returns for `fb` (tests/test_cells16.py holds both to the oracle)."""
+    c16 = to_cells16(fb)
+    ident = np.zeros_like(fb.node_id)
+    for s in range(fb.n_scenarios):
+        n, off = int(fb.scen["n_nodes"][s]), int(fb.scen["node_off"][s])
+        ident[off:off + n] = np.arange(n, dtype=np.int32)
+    cur = np.where(c16 == abi.KAS_CELL16_NONE, -1, c16.astype(np.int32)).astype(np.int32)
+    return FlatBatch(scen=fb.scen, topics=fb.topics, node_id=ident, node_rack=fb.node_rack, cur=cur, aux=fb.aux,
+                     ctx=fb.ctx, out_len=fb.out_len, row_ids=fb.row_ids)
+
+
+def host_tables16(fb: FlatBatch, cur16: np.ndarray, out_len: Optional[int] = None) -> "tuple[abi.Tables, HostOutputs]":
+    """host_tables for kas_solve_host16: HostOutputs.out is a uint16 pool of node indices."""
+    t, ho = host_tables(fb, out_len=out_len)
+    ho.out = np.full(max(int(t.out_len), 1), 0xFFFE, dtype=np.uint16)
+    t.cur = cur16.ctypes.data
+    t.out = ho.out.ctypes.data
+    t.cur_len = int(cur16.shape[0])
+    return t, ho

@@ -17,9 +17,14 @@ import java.util.TreeSet;
 final class NativeAssignmentStrategy {
     static { System.loadLibrary("kas_jni"); }
 
-    static final int LAYOUT = 3;         // KAS_JNI_LAYOUT of kas_jni.cpp
+    static final int LAYOUT = 4;         // KAS_JNI_LAYOUT of kas_jni.cpp
     static final int WIDTH = 8;          // KAS_MAX_WIDTH
-    static final int HEADER_INTS = 12;   // {LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen, device, nSelect, 0, 0}
+    static final int HEADER_INTS = 12;   // {LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen, device, nSelect, cellBits, 0}
+    /** 16-bit cells (kas_solve_host16, ABI v5): cur[] and out[] travel as positions in the scenario's ascending broker
+     *  list, two bytes a cell — half the bytes over the host link.  Used whenever no cur table is shared by several
+     *  scenarios (a what-if batch shares ONE table among different broker sets, which has no such form) and every
+     *  broker set has at most 65,535 members; false = int32 broker ids always. */
+    static volatile boolean cells16 = true;
     /** HIP device the calls of this JVM run on (one native context per device). */
     static volatile int device = 0;
 
@@ -30,7 +35,9 @@ final class NativeAssignmentStrategy {
      *  long curOff, outOff, curLenOff, inPartitionsOff, partIdOff), nodeId[], nodeRack[], cur[],
      *  aux[], ctx[], select[].  Layout of `out`: T topic results (status, failPartition, movedReplicas,
      *  movedPartitions), S scenario results (32 bytes), out[], ctx[].  nSelect = -1: out[] holds every
-     *  row; nSelect >= 0 (what-if): only the rows of the scenarios select[] names, packed in that order. */
+     *  row; nSelect >= 0 (what-if): only the rows of the scenarios select[] names, packed in that order.
+     *  cellBits = 16: cur[] / out[] hold unsigned 16-bit node indices (0xFFFF: not in the broker set / pad), two to an
+     *  int, (len + 1) / 2 ints each; lengths and offsets count cells. */
     static native int solveBatch(ByteBuffer in, ByteBuffer out);
 
     /** One topic of a scenario, in the reference's own argument types (KAS:40-43). */
@@ -125,7 +132,9 @@ final class NativeAssignmentStrategy {
             new java.util.IdentityHashMap<Object, java.util.IdentityHashMap<Object, TreeMap<Integer, List<Integer>>>>();
         java.util.IdentityHashMap<Object, long[]> placed = new java.util.IdentityHashMap<Object, long[]>();   // rows -> {curOff, auxOff}
         final Object NO_PARTITIONS = new Object();
+        boolean anyShared = false, small = true;
         for (ScenarioRequest sc : batch) {
+            small = small && sc.nodes.size() <= 65535;
             List<TreeMap<Integer, List<Integer>>> perTopic = new ArrayList<TreeMap<Integer, List<Integer>>>();
             for (TopicRequest t : sc.topics) {
                 java.util.IdentityHashMap<Object, TreeMap<Integer, List<Integer>>> byParts = seen.get(t.currentAssignment);
@@ -136,6 +145,7 @@ final class NativeAssignmentStrategy {
                 final Object partsKey = t.partitions != null ? t.partitions : NO_PARTITIONS;
                 TreeMap<Integer, List<Integer>> rows = byParts.get(partsKey);
                 final boolean shared = rows != null;
+                anyShared = anyShared || shared;
                 if (!shared) {
                     rows = new TreeMap<Integer, List<Integer>>(t.currentAssignment);
                     byParts.put(partsKey, rows);
@@ -180,15 +190,17 @@ final class NativeAssignmentStrategy {
             }
         }
         final int nSelect = select == null ? -1 : select.length;
-        final long retLen = select == null ? outLen : selLen;       // ints of out[] that come back
-        long inInts = HEADER_INTS + 8L * S + 16L * T + 2 * nodePool + curLen + auxLen + ctxLen + Math.max(nSelect, 0);
-        long outInts = 4L * T + 8L * S + retLen + ctxLen;
+        final long retLen = select == null ? outLen : selLen;       // cells of out[] that come back
+        final boolean c16 = cells16 && !anyShared && small;
+        final long curInts = c16 ? (curLen + 1) / 2 : curLen, retInts = c16 ? (retLen + 1) / 2 : retLen;
+        long inInts = HEADER_INTS + 8L * S + 16L * T + 2 * nodePool + curInts + auxLen + ctxLen + Math.max(nSelect, 0);
+        long outInts = 4L * T + 8L * S + retInts + ctxLen;
         // (a direct ByteBuffer holds < 2 GiB: a larger batch must be split by the caller, not truncated)
         ByteBuffer in = ByteBuffer.allocateDirect(Math.toIntExact(4 * inInts)).order(ByteOrder.nativeOrder());
         ByteBuffer out = ByteBuffer.allocateDirect(Math.toIntExact(4 * outInts)).order(ByteOrder.nativeOrder());
         in.putInt(LAYOUT).putInt(S).putInt(T).putInt(Math.toIntExact(nodePool)).putInt(Math.toIntExact(curLen))
           .putInt(Math.toIntExact(auxLen)).putInt(Math.toIntExact(ctxLen)).putInt(Math.toIntExact(retLen))
-          .putInt(device).putInt(nSelect).putInt(0).putInt(0);
+          .putInt(device).putInt(nSelect).putInt(c16 ? 16 : 32).putInt(0);
         // ---- descriptors
         long nodeOff = 0, ctxOff = 0;
         int topicBegin = 0;
@@ -242,14 +254,30 @@ final class NativeAssignmentStrategy {
         // ---- cur pool, then aux pool (per topic: partId[P], curLen[P], inPartitions[P]); a shared table is
         // written where it was first placed and nowhere else
         java.util.IdentityHashMap<Object, Boolean> written = new java.util.IdentityHashMap<Object, Boolean>();
-        for (int s = 0; s < S; ++s)
+        // (16-bit cells: the position of a broker in its scenario's ascending list; no table is shared then)
+        List<int[]> idOf = new ArrayList<int[]>();
+        for (int s = 0; s < S; ++s) {
+            Map<Integer, Integer> indexOf = null;
+            if (c16) {
+                indexOf = new HashMap<Integer, Integer>();
+                int[] ids = new int[nodeSets.get(s).size()];
+                int n = 0;
+                for (int id : nodeSets.get(s)) { indexOf.put(id, n); ids[n++] = id; }
+                idOf.add(ids);
+            }
             for (TreeMap<Integer, List<Integer>> rows : rowsOf.get(s)) {
                 if (written.put(rows, Boolean.TRUE) != null) continue;
                 int cw = 0;
                 for (List<Integer> l : rows.values()) cw = Math.max(cw, l.size());
                 for (List<Integer> l : rows.values())
-                    for (int k = 0; k < cw; ++k) in.putInt(k < l.size() ? l.get(k) : -1);
+                    for (int k = 0; k < cw; ++k) {
+                        if (!c16) { in.putInt(k < l.size() ? l.get(k) : -1); continue; }
+                        Integer at = k < l.size() ? indexOf.get(l.get(k)) : null;
+                        in.putShort((short) (at != null ? at : 0xFFFF));
+                    }
             }
+        }
+        if (c16 && (curLen & 1) != 0) in.putShort((short) 0);
         written.clear();
         for (int s = 0; s < S; ++s)
             for (int k = 0; k < batch.get(s).topics.size(); ++k) {
@@ -277,8 +305,9 @@ final class NativeAssignmentStrategy {
         // ---- results
         List<List<TopicOutcome>> result = new ArrayList<List<TopicOutcome>>();
         int ti = 0;
-        long rowBase = 4L * T + 8L * S;      // int index of out[] inside `out`
-        long ctxBase = rowBase + retLen;
+        long rowBase = 0;                    // cell index inside out[], which starts at byte 4 * (4T + 8S) of `out`
+        final long rowBytes = 4 * (4L * T + 8L * S);
+        long ctxBase = 4L * T + 8L * S + retInts;
         for (int s = 0; s < S; ++s) {
             ScenarioRequest sc = batch.get(s);
             List<TopicOutcome> outcomes = new ArrayList<TopicOutcome>();
@@ -298,8 +327,14 @@ final class NativeAssignmentStrategy {
                     for (int part : rows.keySet()) {
                         List<Integer> l = new ArrayList<Integer>();
                         for (int c = 0; c < ow; ++c) {
-                            int b = out.getInt((int) (4 * (rowBase + row * ow + c)));
-                            if (b >= 0) l.add(b);
+                            final long cellAt = rowBase + row * ow + c;
+                            if (c16) {
+                                int v = out.getShort((int) (rowBytes + 2 * cellAt)) & 0xFFFF;
+                                if (v != 0xFFFF) l.add(idOf.get(s)[v]);
+                            } else {
+                                int b = out.getInt((int) (rowBytes + 4 * cellAt));
+                                if (b >= 0) l.add(b);
+                            }
                         }
                         if (!l.isEmpty()) o.assignment.put(part, l);   // a row nobody holds is not a key (KAS:205-214)
                         ++row;

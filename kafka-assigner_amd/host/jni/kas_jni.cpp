@@ -11,7 +11,7 @@
 //
 // Payload (int32 units, native byte order; written by NativeAssignmentStrategy.java):
 //   in :  header[12] = {KAS_JNI_LAYOUT, S, T, nodePoolLen, curLen, auxLen, ctxLen, outLen,
-//                       device, nSelect, 0, 0}
+//                       device, nSelect, cellBits, 0}
 //         scenario descriptors  S x 8 ints   (kas_scenario_desc, 32 bytes each)
 //         topic descriptors     T x 16 ints  (kas_topic_desc, 64 bytes each)
 //         nodeId[nodePoolLen] nodeRack[nodePoolLen] cur[curLen] aux[auxLen] ctx[ctxLen] select[max(nSelect, 0)]
@@ -21,6 +21,10 @@
 // place (kas_solve_host); nSelect >= 0: the what-if form (kas_solve_host_select) — every scenario
 // reports its records, out[] holds only the rows of the scenarios select[] names, packed in that order
 // (KAG:177-186 prints ONE assignment however many broker sets were tried).
+// Layout 4 (ABI v5): cellBits = 16 -> cur[] and out[] hold uint16 node indices (kas_solve_host16: position of the broker
+// in the scenario's ascending node table, 0xFFFF = not in the broker set / pad), two to an int, (curLen + 1) / 2 and
+// (outLen + 1) / 2 ints; curLen / outLen and the descriptors' offsets count cells; nodeId[] is carried and not read.
+// cellBits = 0 or 32: int32 cells as in layout 3, whose payloads are still accepted.
 #if defined(__has_include)
 #if __has_include(<jni.h>)
 #define KAS_HAVE_JNI 1
@@ -37,7 +41,7 @@
 
 #include "kas_abi.h"
 
-#define KAS_JNI_LAYOUT 3
+#define KAS_JNI_LAYOUT 4
 
 namespace {
 std::mutex g_mu;          // guards the lazily created contexts; kas_solve_host serialises its own callers
@@ -51,13 +55,16 @@ Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jc
   int32_t* out = static_cast<int32_t*>(env->GetDirectBufferAddress(jout));
   if (!in || !out) return KAS_E_INVALID_ARG;
   const int64_t in_ints = env->GetDirectBufferCapacity(jin) / 4, out_ints = env->GetDirectBufferCapacity(jout) / 4;
-  if (in_ints < kHeaderInts || in[0] != KAS_JNI_LAYOUT) return KAS_E_INVALID_ARG;
+  if (in_ints < kHeaderInts || (in[0] != KAS_JNI_LAYOUT && in[0] != 3)) return KAS_E_INVALID_ARG;
   const int64_t S = in[1], T = in[2], npool = in[3], cur_len = in[4], aux_len = in[5], ctx_len = in[6], out_len = in[7];
   const int32_t device = in[8], n_select = in[9];
+  const bool cells16 = in[0] >= 4 && in[10] == 16;
+  if (in[0] >= 4 && in[10] != 0 && in[10] != 16 && in[10] != 32) return KAS_E_INVALID_ARG;
+  const int64_t cur_ints = cells16 ? (cur_len + 1) / 2 : cur_len, out_ints_rows = cells16 ? (out_len + 1) / 2 : out_len;
   if (S < 0 || T < 0 || npool < 0 || cur_len < 0 || aux_len < 0 || ctx_len < 0 || out_len < 0 || device < 0 || n_select < -1)
     return KAS_E_INVALID_ARG;
-  const int64_t need_in = kHeaderInts + 8 * S + 16 * T + 2 * npool + cur_len + aux_len + ctx_len + (n_select > 0 ? n_select : 0);
-  const int64_t need_out = 4 * T + 8 * S + out_len + ctx_len;
+  const int64_t need_in = kHeaderInts + 8 * S + 16 * T + 2 * npool + cur_ints + aux_len + ctx_len + (n_select > 0 ? n_select : 0);
+  const int64_t need_out = 4 * T + 8 * S + out_ints_rows + ctx_len;
   if (in_ints < need_in || out_ints < need_out) return KAS_E_INVALID_ARG;
 
   // descriptors are copied out of the buffer: no alignment assumption on the ByteBuffer
@@ -71,7 +78,7 @@ Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jc
   p += 16 * T;
   const int32_t* node_id = p; p += npool;
   const int32_t* node_rack = p; p += npool;
-  const int32_t* cur = p; p += cur_len;
+  const int32_t* cur = p; p += cur_ints;
   const int32_t* aux = p; p += aux_len;
   const int32_t* ctx_in = p; p += ctx_len;
   const int32_t* select = p;
@@ -82,7 +89,7 @@ Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jc
   int32_t* out_tr = out;
   int32_t* out_sr = out_tr + 4 * T;
   int32_t* out_rows = out_sr + 8 * S;
-  int32_t* ctx_out = out_rows + out_len;
+  int32_t* ctx_out = out_rows + out_ints_rows;
   if (ctx_len) memcpy(ctx_out, ctx_in, sizeof(int32_t) * (size_t)ctx_len);     // Context counters are in/out
 
   kas_batch_desc bd;
@@ -109,7 +116,18 @@ Java_siftscience_kafka_tools_NativeAssignmentStrategy_solveBatch(JNIEnv* env, jc
   }
   // the context keeps its device buffers and the plans of recent batch shapes: a JVM that calls
   // once per topic or per what-if round pays no allocation after the first call
-  int rc = n_select < 0 ? kas_solve_host(ctx, &bd, &t) : kas_solve_host_select(ctx, &bd, &t, select, n_select);
+  int rc;
+  if (cells16) {
+    kas_tables16 t16;
+    memset(&t16, 0, sizeof(t16));
+    t16.cur = reinterpret_cast<const uint16_t*>(cur); t16.out = reinterpret_cast<uint16_t*>(out_rows);
+    t16.aux = t.aux; t16.ctx = t.ctx; t16.topic_results = t.topic_results; t16.scenario_results = t.scenario_results;
+    t16.cur_len = cur_len; t16.out_len = out_len; t16.aux_len = aux_len; t16.ctx_len = ctx_len;
+    bd.node_id = nullptr;                                      // (node i has id i: the Java side maps the cells back)
+    rc = kas_solve_host16(ctx, &bd, &t16, n_select < 0 ? nullptr : select, n_select);
+  } else {
+    rc = n_select < 0 ? kas_solve_host(ctx, &bd, &t) : kas_solve_host_select(ctx, &bd, &t, select, n_select);
+  }
   if (rc != KAS_E_OK) return rc;
   if (T) memcpy(out_tr, tr.data(), sizeof(kas_topic_result) * (size_t)T);
   if (S) memcpy(out_sr, sr.data(), sizeof(kas_scenario_result) * (size_t)S);

@@ -9,6 +9,7 @@
 // itself runs on the GPU; there is no CPU path behind this header.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <map>
@@ -100,7 +101,11 @@ class KafkaAssignmentStrategy {
     for (auto& e : currentAssignment) cw = std::max(cw, (int32_t)e.second.size());
     const int32_t ow = std::max(std::max(cw, replicationFactor), 1);
     if (ow > KAS_MAX_WIDTH) throw SolverError("replica lists longer than KAS_MAX_WIDTH");
-    std::vector<int32_t> aux(3 * (size_t)P), cur((size_t)P * std::max(cw, 1), -1);
+    // 16-bit cells (kas_solve_host16, ABI v5): a replica travels as the position of its broker in node_id[] — half the bytes
+    // of the per-topic call (KTA:70-71) over the host link; KAS_CELLS32=1 in the environment keeps int32 broker ids
+    const bool cells16 = N <= 65535 && !(getenv("KAS_CELLS32") && getenv("KAS_CELLS32")[0] == '1');
+    std::vector<int32_t> aux(3 * (size_t)P), cur(cells16 ? 0 : (size_t)P * std::max(cw, 1), -1);
+    std::vector<uint16_t> cur16(cells16 ? (size_t)P * std::max(cw, 1) : 0, (uint16_t)KAS_CELL16_NONE);
     {
       int32_t row = 0;
       for (int p : row_ids) {
@@ -109,7 +114,11 @@ class KafkaAssignmentStrategy {
         aux[row] = p;                                                   // part_id
         aux[(size_t)P + row] = len;                                     // cur_len
         aux[2 * (size_t)P + row] = partitions.count(p) ? 1 : 0;         // in_partitions
-        for (int32_t k = 0; k < len; ++k) cur[(size_t)row * cw + k] = it->second[k];
+        for (int32_t k = 0; k < len; ++k) {
+          if (!cells16) { cur[(size_t)row * cw + k] = it->second[k]; continue; }
+          auto at = std::lower_bound(node_id.begin(), node_id.end(), (int32_t)it->second[k]);
+          if (at != node_id.end() && *at == it->second[k]) cur16[(size_t)row * cw + k] = (uint16_t)(at - node_id.begin());
+        }
         ++row;
       }
     }
@@ -122,7 +131,8 @@ class KafkaAssignmentStrategy {
           if (c.first >= 0 && c.first < KAS_MAX_WIDTH) ctx[(size_t)i * KAS_MAX_WIDTH + c.first] = c.second;
       }
     }
-    std::vector<int32_t> out((size_t)P * ow + 1, -1);
+    std::vector<int32_t> out(cells16 ? 0 : (size_t)P * ow + 1, -1);
+    std::vector<uint16_t> out16(cells16 ? (size_t)P * ow + 1 : 0, (uint16_t)KAS_CELL16_NONE);
 
     kas_topic_desc td{};
     td.name_hash = javaStringHashCode(topicName);
@@ -142,7 +152,16 @@ class KafkaAssignmentStrategy {
     t.topic_results = &tr; t.scenario_results = &sr;
     t.cur_len = (int64_t)P * cw; t.out_len = (int64_t)P * ow; t.aux_len = 3 * (int64_t)P;
     t.ctx_len = context ? (int64_t)N * KAS_MAX_WIDTH : 0;
-    int rc = kas_solve_host(deviceContext(), &bd, &t);
+    int rc;
+    if (cells16) {
+      kas_tables16 t16{};
+      t16.cur = cur16.data(); t16.out = out16.data(); t16.aux = t.aux; t16.ctx = t.ctx;
+      t16.topic_results = &tr; t16.scenario_results = &sr;
+      t16.cur_len = t.cur_len; t16.out_len = t.out_len; t16.aux_len = t.aux_len; t16.ctx_len = t.ctx_len;
+      rc = kas_solve_host16(deviceContext(), &bd, &t16, nullptr, -1);
+    } else {
+      rc = kas_solve_host(deviceContext(), &bd, &t);
+    }
     if (rc != KAS_E_OK) throw SolverError(std::string(kas_strerror(rc)) + ": " + kas_last_error());
 
     switch (tr.status) {
@@ -166,8 +185,13 @@ class KafkaAssignmentStrategy {
       for (int p : row_ids) {
         std::vector<int> l;
         for (int32_t k = 0; k < ow; ++k) {
-          const int32_t b = out[(size_t)row * ow + k];
-          if (b >= 0) l.push_back(b);
+          if (cells16) {
+            const uint16_t c = out16[(size_t)row * ow + k];
+            if (c != KAS_CELL16_NONE) l.push_back(node_id[c]);
+          } else {
+            const int32_t b = out[(size_t)row * ow + k];
+            if (b >= 0) l.push_back(b);
+          }
         }
         if (!l.empty()) result[p] = l;                                  // KAS:205-214 lists held rows only
         ++row;

@@ -24,7 +24,7 @@ SYMBOLS = [
     "kas_plan_destroy", "kas_plan_algorithmic_bytes", "kas_solve_device", "kas_solve_host",
     "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
     "kas_plan_describe", "kas_ctx_host_stats", "kas_solve_host_select", "kas_host_alloc", "kas_host_free",
-    "kas_shard_range", "kas_batch_slice", "kas_solve_host_sharded", "kas_ctx_lds_lane_order",
+    "kas_shard_range", "kas_batch_slice", "kas_solve_host_sharded", "kas_ctx_lds_lane_order", "kas_solve_host16",
 ]
 
 _LIB = None
@@ -75,6 +75,9 @@ def load():
     L.kas_solve_host_select.restype = C.c_int
     L.kas_solve_host_select.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
                                         C.POINTER(C.c_int32), C.c_int32]
+    L.kas_solve_host16.restype = C.c_int         # (kas_tables16 has kas_tables' layout: abi.Tables holds untyped pointers)
+    L.kas_solve_host16.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
+                                   C.POINTER(C.c_int32), C.c_int32]
     L.kas_solve_host_sharded.restype = C.c_int
     L.kas_solve_host_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
     L.kas_host_alloc.restype = C.c_int; L.kas_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
@@ -261,6 +264,25 @@ def solve_host_select(fb: FlatBatch, select, ctx: Optional[DeviceContext] = None
     return ho
 
 
+def solve_host16(fb: FlatBatch, ctx: Optional[DeviceContext] = None, select=None, cur16=None, tables=None,
+                 ho: Optional[HostOutputs] = None) -> HostOutputs:
+    """kas_solve_host16: the host call with 16-bit cells (node indices; flatten.to_cells16 / cells16_to_ids).
+    HostOutputs.out is the uint16 out pool; select = scenario indices whose rows come back packed (None: every row)."""
+    from .flatten import host_tables16, to_cells16
+    L = load()
+    ctx = ctx or default_context()
+    bd = batch_desc(fb)
+    bd.node_id = None                      # (not read: node i has id i)
+    sel = None if select is None else np.ascontiguousarray(select, dtype=np.int32)
+    if tables is None:
+        cur16 = to_cells16(fb) if cur16 is None else cur16
+        tables, ho = host_tables16(fb, cur16, out_len=None if sel is None else selected_out_len(fb, sel))
+    _check(L.kas_solve_host16(ctx._h, C.byref(bd), C.byref(tables),
+                              None if sel is None else sel.ctypes.data_as(C.POINTER(C.c_int32)),
+                              -1 if sel is None else int(sel.size)))
+    return ho
+
+
 def solve_host_sharded(fb: FlatBatch, ctxs) -> HostOutputs:
     """kas_solve_host_sharded: contiguous scenario ranges over several contexts (devices), one host
     thread each; the caller's host arrays are the gather."""
@@ -273,14 +295,16 @@ def solve_host_sharded(fb: FlatBatch, ctxs) -> HostOutputs:
 
 
 class PinnedArray:
-    """int32 numpy array over kas_host_alloc memory (pinned: kas_solve_host moves it by DMA without staging)."""
+    """int32 (or uint16: 16-bit cells) numpy array over kas_host_alloc memory (pinned: kas_solve_host moves it by DMA
+    without staging)."""
 
-    def __init__(self, n: int):
+    def __init__(self, n: int, dtype=np.int32):
         self._lib = load()
         self._p = C.c_void_p()
-        _check(self._lib.kas_host_alloc(4 * max(int(n), 1), C.byref(self._p)))
-        buf = (C.c_int32 * max(int(n), 1)).from_address(self._p.value)
-        self.array = np.frombuffer(buf, dtype=np.int32)[:int(n)]
+        item = np.dtype(dtype).itemsize
+        _check(self._lib.kas_host_alloc(item * max(int(n), 1), C.byref(self._p)))
+        buf = (C.c_uint8 * (item * max(int(n), 1))).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dtype)[:int(n)]
 
     def close(self):
         if self._p:

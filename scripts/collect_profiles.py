@@ -34,19 +34,20 @@ with open(f"profiles/{tag}_pmc_hbm_traffic.csv", "w") as out:
         for k, v in agg.items():
             out.write(f'{name},"{k}",{len(v)},{ctr},{sum(v) / len(v):.1f}\n')
             if "permutation" not in k:
-                res[(ctr, "fill" if "fill" in k else "order")] = sum(v) / len(v)
+                res[(ctr, "fill" if "fill" in k else ("p4" if "kas_p4" in k else "order"))] = sum(v) / len(v)
 KB = 1024
 ff, fo = res[("FETCH_SIZE", "fill")] * KB, res[("FETCH_SIZE", "order")] * KB
 wf, wo = res[("WRITE_SIZE", "fill")] * KB, res[("WRITE_SIZE", "order")] * KB
+fp, wp = res.get(("FETCH_SIZE", "p4"), 0.0) * KB, res.get(("WRITE_SIZE", "p4"), 0.0) * KB     # first fit in its own kernel (round 5)
 known = 1000 * 100000 * 6           # the order kernel reads every 6-byte mid row exactly once (round 5: packed rows; 8 bytes before)
 corr = known / fo
 j = {"scenarios": 1000, "partitions": 100000,
-     "hbm_bytes_per_launch": 2 * (ff + fo) + wf + wo,
+     "hbm_bytes_per_launch": 2 * (ff + fp + fo) + wf + wp + wo,
      "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, profiles/{tag}_pmc_hbm_traffic.csv), "
                "kB -> bytes; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE tallies 128-B requests at 64 B) - "
                "check: the order kernel reads each 6-byte mid row exactly once, known/measured = %.3f" % corr,
-     "fetch_kb": {"fill": res[("FETCH_SIZE", "fill")], "order": res[("FETCH_SIZE", "order")]},
-     "write_kb": {"fill": res[("WRITE_SIZE", "fill")], "order": res[("WRITE_SIZE", "order")]},
+     "fetch_kb": {"fill": res[("FETCH_SIZE", "fill")], "p4": fp / KB, "order": res[("FETCH_SIZE", "order")]},
+     "write_kb": {"fill": res[("WRITE_SIZE", "fill")], "p4": wp / KB, "order": res[("WRITE_SIZE", "order")]},
      "read_correction_measured": corr}
 # which kernels and sources the numbers belong to: bench.py quotes them only for the same ones
 for log in (os.path.join(d, "prof_fetch.log"), os.path.join(d, "prof_write.log")):

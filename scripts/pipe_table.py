@@ -1,12 +1,12 @@
 #!/usr/bin/env python
-"""Per-pipe utilisation of the two kernels of a solve (profiles/<tag>_pipe_utilisation.csv) from the SQ counter passes
+"""Per-pipe utilisation of the kernels of a solve (fill, first fit, order) (profiles/<tag>_pipe_utilisation.csv) from the SQ counter passes
 of gpu_trip.sh `sq` (profiles/<tag>_pmc_sq_counters.csv), the kernel trace (one batch alone) and the bench line.
 MEASUREMENT TOOLING.  usage: pipe_table.py TAG BENCH_LOG ISSUE_PROBE_LOG
 
 Units (MI355X_MICROARCH.md, rocprofv3 PMC): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over
 waves; SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT count LDS-array cycles summed over CUs; SQ_INSTS_* count wave-instructions;
 GRBM_GUI_ACTIVE counts cycles summed over the 8 XCDs.  Windows: one batch alone = the kernel's own duration (kernel
-trace); eight batches in flight = ms_per_step of the bench line (one fill + one order launch per step, the kernels of
+trace); eight batches in flight = ms_per_step of the bench line (one launch of each kernel per step, the kernels of
 different steps overlap), so the in-flight rows give the utilisation of the whole job.
 Capacities: 1024 SIMDs x window cycles for the issue pipes; 256 CUs x window cycles for the LDS array.  Issue cost per
 wave-instruction from tools/issue_probe (same device): VALU 2.1 cycles (add/and/xor/sub/mov/lshr/bitop3) or 4.2 (the
@@ -20,13 +20,15 @@ tag, bench_log = sys.argv[1], sys.argv[2]
 rows = list(csv.DictReader(open(f"profiles/{tag}_pmc_sq_counters.csv")))
 c = collections.defaultdict(dict)
 for r in rows:
-    k = "fill" if "fill" in r["kernel"] else ("order" if "order_relax" in r["kernel"] or "order_ticket" in r["kernel"] else None)
+    k = "fill" if "fill" in r["kernel"] else ("p4" if "kas_p4" in r["kernel"] else ("order" if "order_relax" in r["kernel"] or "order_ticket" in r["kernel"] else None))
     if k:
         c[(int(r["batches_in_flight"]), k)][r["counter"]] = float(r["avg_value_per_dispatch"])
 dur = {}
 for r in csv.DictReader(open(f"profiles/{tag}_kernel_trace_stats_one_batch_in_flight.csv")):
     if "kas_fill" in r["Name"]:
         dur["fill"] = float(r["AverageNs"]) * 1e-9
+    if "kas_p4" in r["Name"]:
+        dur["p4"] = float(r["AverageNs"]) * 1e-9
     if "kas_order_relax" in r["Name"] or "kas_order_ticket" in r["Name"]:
         dur["order"] = float(r["AverageNs"]) * 1e-9
 line = json.loads([l for l in open(bench_log) if l.startswith("{")][-1])
@@ -41,11 +43,12 @@ def add(mode, k, window, clock, name, value, unit, frac, how):
 
 modes = sorted({m for (m, _k) in c})                        # 1 and the bench's default number of batches in flight
 for mode in modes:
-    kernels = ["fill", "order"] if mode == 1 else ["fill", "order", "fill+order"]
+    each = [kk for kk in ("fill", "p4", "order") if (mode, kk) in c]     # (p4: first fit in its own kernel, round 5)
+    kernels = each if mode == 1 else each + ["fill+order"]               # "fill+order": every kernel of a solve
     for k in kernels:
         if k == "fill+order":
             d = collections.Counter()
-            for kk in ("fill", "order"):
+            for kk in each:
                 d.update(c[(mode, kk)])
             window = step
             # (the clock of the one-batch-alone passes: in flight a kernel's duration differs from run to run, and the

@@ -29,7 +29,7 @@ def main(argv):
         n = r["Kernel_Name"]
         if "kas_" not in n or "selftest" in n:
             continue
-        kind = "fill" if ("kas_fill" in n or "kas_spread" in n) else ("order" if "kas_order" in n else "other")
+        kind = ("p4" if "kas_p4" in n else "fill") if ("kas_fill" in n or "kas_spread" in n or "kas_p4" in n) else ("order" if "kas_order" in n else "other")
         rows.append({"stream": r["Stream_Id"], "queue": r["Queue_Id"], "kind": kind, "name": n.split("(")[0],
                      "s": int(r["Start_Timestamp"]), "e": int(r["End_Timestamp"])})
     by_stream = defaultdict(list)
@@ -61,16 +61,18 @@ def main(argv):
             continue
         busy = sum(r["e"] - r["s"] for r in v)
         gaps = [v[i + 1]["s"] - v[i]["e"] for i in range(len(v) - 1)]
-        fo_gaps = [v[i + 1]["s"] - v[i]["e"] for i in range(len(v) - 1) if v[i]["kind"] == "fill" and v[i + 1]["kind"] == "order"]
-        of_gaps = [v[i + 1]["s"] - v[i]["e"] for i in range(len(v) - 1) if v[i]["kind"] == "order" and v[i + 1]["kind"] == "fill"]
+        def gaps_of(a, b):
+            g = sorted(v[i + 1]["s"] - v[i]["e"] for i in range(len(v) - 1) if v[i]["kind"] == a and v[i + 1]["kind"] == b)
+            return g[len(g) // 2] / 1e3 if g else float("nan")
+        has_p4 = any(r["kind"] == "p4" for r in v)
         q = sorted({r["queue"] for r in v})
         for qq in q:
             queues[qq].add(st)
         lines.append(["stream", st, "%.3f" % (busy / span), "busy fraction",
-                      "queue %s; %d kernels; median gap fill->order %.1f us, order->next fill %.1f us" % (
+                      "queue %s; %d kernels; median gap %s, order->next fill %.1f us" % (
                           "/".join(q), len(v),
-                          sorted(fo_gaps)[len(fo_gaps) // 2] / 1e3 if fo_gaps else float("nan"),
-                          sorted(of_gaps)[len(of_gaps) // 2] / 1e3 if of_gaps else float("nan"))])
+                          ("fill->first fit %.1f us, first fit->order %.1f us" % (gaps_of("fill", "p4"), gaps_of("p4", "order"))) if has_p4
+                          else "fill->order %.1f us" % gaps_of("fill", "order"), gaps_of("order", "fill"))])
     for q, sts in sorted(queues.items(), key=lambda kv: int(kv[0])):
         lines.append(["queue", q, str(len(sts)), "streams", "streams " + " ".join(sorted(sts, key=int))])
     # time-weighted concurrency
@@ -79,26 +81,31 @@ def main(argv):
         ev.append((r["s"], 1, r["kind"]))
         ev.append((r["e"], -1, r["kind"]))
     ev.sort()
-    cur = {"fill": 0, "order": 0, "other": 0}
+    cur = {"fill": 0, "p4": 0, "order": 0, "other": 0}
     hist = defaultdict(int)
     last = ev[0][0]
     for t, d, kind in ev:
         if t > last:
-            hist[(cur["fill"], cur["order"])] += t - last
+            hist[(cur["fill"], cur["p4"], cur["order"])] += t - last
             last = t
         cur[kind] += d
     tot = sum(hist.values())
-    avg_f = sum(f * w for (f, o), w in hist.items()) / tot
-    avg_o = sum(o * w for (f, o), w in hist.items()) / tot
-    lines.append(["concurrency", "fill kernels executing (average)", "%.2f" % avg_f, "kernels", ""])
-    lines.append(["concurrency", "order kernels executing (average)", "%.2f" % avg_o, "kernels", ""])
-    lines.append(["concurrency", "both kinds executing", "%.3f" % (sum(w for (f, o), w in hist.items() if f > 0 and o > 0) / tot), "fraction of time", ""])
-    lines.append(["concurrency", "only fill kernels executing", "%.3f" % (sum(w for (f, o), w in hist.items() if f > 0 and o == 0) / tot), "fraction of time", ""])
-    lines.append(["concurrency", "only order kernels executing", "%.3f" % (sum(w for (f, o), w in hist.items() if f == 0 and o > 0) / tot), "fraction of time", ""])
-    lines.append(["concurrency", "nothing executing", "%.3f" % (sum(w for (f, o), w in hist.items() if f == 0 and o == 0) / tot), "fraction of time", ""])
-    for (f, o), w in sorted(hist.items(), key=lambda kv: -kv[1])[:12]:
-        lines.append(["concurrency", "%d fill + %d order" % (f, o), "%.3f" % (w / tot), "fraction of time", ""])
-    for kind in ("fill", "order"):
+    share = lambda pred: "%.3f" % (sum(w for k, w in hist.items() if pred(*k)) / tot)
+    with_p4 = any(k[1] for k in hist)
+    lines.append(["concurrency", "fill kernels executing (average)", "%.2f" % (sum(k[0] * w for k, w in hist.items()) / tot), "kernels", ""])
+    if with_p4:
+        lines.append(["concurrency", "first-fit kernels executing (average)", "%.2f" % (sum(k[1] * w for k, w in hist.items()) / tot), "kernels", ""])
+    lines.append(["concurrency", "order kernels executing (average)", "%.2f" % (sum(k[2] * w for k, w in hist.items()) / tot), "kernels", ""])
+    lines.append(["concurrency", "fill and order kernels executing", share(lambda f, p, o: f > 0 and o > 0), "fraction of time", ""])
+    lines.append(["concurrency", "fill but no order kernel executing", share(lambda f, p, o: f > 0 and o == 0), "fraction of time", ""])
+    lines.append(["concurrency", "order but no fill kernel executing", share(lambda f, p, o: f == 0 and o > 0), "fraction of time", ""])
+    if with_p4:
+        lines.append(["concurrency", "only first-fit kernels executing", share(lambda f, p, o: f == 0 and o == 0 and p > 0), "fraction of time", ""])
+    lines.append(["concurrency", "nothing executing", share(lambda f, p, o: f == 0 and o == 0 and p == 0), "fraction of time", ""])
+    for (f, p4, o), w in sorted(hist.items(), key=lambda kv: -kv[1])[:12]:
+        lines.append(["concurrency", ("%d fill + %d first fit + %d order" % (f, p4, o)) if with_p4 else "%d fill + %d order" % (f, o),
+                      "%.3f" % (w / tot), "fraction of time", ""])
+    for kind in ("fill", "p4", "order"):
         d = sorted(r["e"] - r["s"] for r in kept if r["kind"] == kind)
         if d:
             lines.append(["duration", kind, "%.3f" % (sum(d) / len(d) / 1e6), "ms average",

@@ -200,6 +200,10 @@ template <int W, int NW> void run_fill(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::fill_scenario<W, NW>(*r->a, r->s, r->lds);
 }
+template <int W> void run_p4(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  kas::p4_scenario<W, 1>(*r->a, r->s, r->lds);            // (one wavefront, as kas_p4_kernel is launched)
+}
 template <int W, int G, bool PK> void run_order_tickets(void* p) {
   RunArgs* r = (RunArgs*)p;
   if constexpr (W <= 3) kas::order_tickets<W, G, PK>(*r->a, r->s, r->lds);
@@ -264,6 +268,7 @@ static long g_last_queue_rows = 0;
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
 static int g_last_order_form = 0;   // 1: ticket form (lists <= 3 wide), 2: wide ticket form, 3: relaxation form, 0: round form (the last solve's plan)
+static int g_last_split_p4 = 0;     // the last solve ran its first fit in kas_p4_kernel (KAS_FLAG_SPLIT_P4)
 static long g_last_relax_tiles = 0, g_last_relax_evals = 0, g_last_relax_slow = 0;   // relaxation form: tiles, evaluations, tiles off the straight-line path
 static int g_last_flagged = 0; // scenarios a ticket form left to the round form (Context counters too large for its fields)
 // flags: low byte = KAS_FLAG_*, bits 8..11 = wavefronts per scenario of the fill kernel, bits
@@ -316,7 +321,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   g_last_flagged = 0;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch;
-  a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128) & ~KAS_FLAG_FUSED_HIST) |
+  a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4) & ~KAS_FLAG_FUSED_HIST) |
             (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u) |
             (kas_relax_double_tiles(flags, b->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
             ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER);
@@ -372,12 +377,36 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     case 8: fill = fill_for_w<8>(sh.Wc); break;
     default: fill = fill_for_w<4>(sh.Wc); break;
   }
+  // first fit in a kernel of its own (same decision as kas_solve_device)
+  std::vector<int32_t> p4s;
+  a.p4s = nullptr;
+  const bool split_p4 = kas_split_p4(sh, sh.NW, a.flags | (flags & KAS_FLAG_FILL_WITH_P4), CH);
+  if (split_p4) {
+    p4s.assign((size_t)b->n_topics * (size_t)(KAS_P4S_HEAD + (sh.n_max > 0 ? sh.n_max : 1)) + 64, (int32_t)0xDEADBEEF);
+    a.p4s = p4s.data();
+    a.flags |= KAS_FLAG_SPLIT_P4;
+  }
+  g_last_split_p4 = split_p4 ? 1 : 0;
   for (int32_t s = 0; s < b->n_scenarios; ++s) {
     memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
     RunArgs ra{&a, s, lds.data()};
     if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill", s);
   }
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
+  if (split_p4) {
+    // exactly the LDS the product launches kas_p4_kernel with, and a guard behind it
+    const size_t p4_bytes = (size_t)kas_p4_lds_layout(sh.n_max).total;
+    std::vector<unsigned char> pl(p4_bytes + 4096);
+    run_fn fp4 = sh.Wc <= 2 ? run_p4<2> : sh.Wc == 3 ? run_p4<3> : sh.Wc == 4 ? run_p4<4> : sh.Wc == 5 ? run_p4<5> : run_p4<8>;
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(pl.data(), 0xCD, p4_bytes);
+      memset(pl.data() + p4_bytes, 0xA5, 4096);
+      RunArgs ra{&a, s, pl.data()};
+      if (kasw::run_block(fp4, &ra, 1) != 0) return bad("first fit (kas_p4_kernel)", s);
+      for (size_t i = 0; i < 4096; ++i)
+        if (pl[p4_bytes + i] != 0xA5) return bad("first fit: LDS written beyond kas_p4_lds_layout()", s);
+    }
+  }
   // order kernel: one wavefront per scenario (relaxation form, round form), three per G scenarios (ticket form)
   if (relax) {
     const bool rdual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
@@ -467,7 +496,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   if (wide_recheck) {
     // as kas_solve_device: a scenario whose counts outgrew the wide form's fields is filled again ...
     KasLaunch af = a;
-    af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~KAS_FLAG_WIDE_CHECK;
+    af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~(KAS_FLAG_WIDE_CHECK | KAS_FLAG_SPLIT_P4);
     af.sp_flag = ord_flag.data();
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(lds.data(), 0xCD, lds.size());
@@ -540,6 +569,9 @@ int kas_emu_last_flagged(void) { return g_last_flagged; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_order_form(void) { return g_last_order_form; }
+// 1: the last solve's first fit ran in kas_p4_kernel
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_split_p4(void) { return g_last_split_p4; }
 
 
 // relaxation form of the last kas_emu_solve_batch: out[0..2] = tiles, evaluations, tiles off the straight-line path

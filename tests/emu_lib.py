@@ -222,6 +222,14 @@ def last_order_form() -> int:
     return int(L.kas_emu_last_order_form())
 
 
+def last_split_p4() -> int:
+    """1: the last emu_solve ran its first fit (P4) in kas_p4_kernel behind the fill kernel (KAS_FLAG_SPLIT_P4)"""
+    L = lib()
+    L.kas_emu_last_split_p4.restype = C.c_int
+    return int(L.kas_emu_last_split_p4())
+
+
+FILL_WITH_P4 = 0x800000    # KAS_PLAN_FILL_WITH_P4: first fit inside the fill workgroup, as in rounds 1-4
 TICKET_ORDER = 0x10000     # KAS_PLAN_TICKET_ORDER: the ticket form where the relaxation form would run
 RELAX_TILES_64 = 0x20000   # KAS_PLAN_RELAX_TILES(1): relaxation form over tiles of 64 rows whatever the batch size
 RELAX_TILES_128 = 0x40000  # KAS_PLAN_RELAX_TILES(2): double tiles whatever the batch size

@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows
+from emu_lib import FILL_WITH_P4, NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows, last_split_p4
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_oracle_vs_literal import scenarios
@@ -81,6 +81,10 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
+    assert last_split_p4() == 1                             # round 5: first fit in kas_p4_kernel behind the fill kernel ...
+    assert_same_outputs(fb, want, emu_solve(fb, flags=FILL_WITH_P4), "emu, first fit inside the fill workgroup")
+    assert last_split_p4() == 0                             # ... unless the plan says otherwise
+    assert_same_outputs(fb, want, emu_solve(fb, flags=FILL_WITH_P4 | RELAX_TILES_64), "emu, first fit inside the fill workgroup, tiles of 64 rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu relaxation form, tiles of 64 rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64 | NO_RTN_QUOTA), "emu tiles of 64 rows, quota drawn without the atomic-with-return")
@@ -606,5 +610,7 @@ def test_emu_mixed_batch_over_tiles_of_64_rows():
     assert st.tolist() == [0, 0, 0, 0, 0, 0, 0, 1, 6], st.tolist()
     assert want.topic_results["moved_replicas"][6] == 900      # (w-a: every row an orphan)
     assert want.topic_results["moved_replicas"][5] > 0         # (v-a: the general fill moved something)
-    for flags in (RELAX_TILES_64, RELAX_TILES_64 | NO_RTN_QUOTA, RELAX_TILES_64 | (2 << 8), 1 << 8, 8, 0, TICKET_ORDER, 2, 1):
+    for flags, split in ((RELAX_TILES_64, 1), (RELAX_TILES_64 | NO_RTN_QUOTA, 1), (RELAX_TILES_64 | (2 << 8), 0), (1 << 8, 0), (8, 1), (0, 1),
+                         (FILL_WITH_P4, 0), (FILL_WITH_P4 | RELAX_TILES_64, 0), (TICKET_ORDER, 1), (2, 1), (1, 0)):
         assert_same_outputs(fb, want, emu_solve(fb, flags=flags), "emu, flags %#x" % flags)
+        assert last_split_p4() == split, hex(flags)         # (first fit in kas_p4_kernel: four fill wavefronts, rack-diverse form)

@@ -67,6 +67,7 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip relaxation form, tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_128), "hip relaxation form, double tiles")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "hip fill, quota drawn without the atomic-with-return")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FILL_WITH_P4), "hip first fit inside the fill workgroup (no kas_p4_kernel)")
     # the general multi-sweep sticky fill must agree with the rack-diverse histogram/quota form,
     # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
@@ -170,6 +171,7 @@ def test_one_plan_orders_its_solves_across_streams():
     ctx = native.default_context()
     plan = native.Plan(ctx, fb)
     assert "kas_fill_kernel<3,4>[quota, chunk histograms]" in plan.describe() and "kas_order_relax_kernel<3>" in plan.describe()
+    assert "+ kas_p4_kernel<3> grid=24x64" in plan.describe()                       # first fit: a launch of its own, one wavefront per scenario
     dev = torch.device("cuda", ctx.device)
     d_cur = torch.from_numpy(fb.cur).to(dev)
     streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
@@ -195,6 +197,8 @@ def test_one_plan_orders_its_solves_across_streams():
     assert "kas_order_relax_kernel<3>[tiles of 128 rows]" in plan.describe()      # 24 scenarios: a latency-bound launch
     plan.set_flags(TILES_64)
     assert "kas_order_relax_kernel<3>[tiles of 64 rows]" in plan.describe()
+    plan.set_flags(abi.KAS_PLAN_FILL_WITH_P4)
+    assert "kas_p4_kernel" not in plan.describe()
     plan.close()
 
 
@@ -593,7 +597,7 @@ def test_solves_in_flight_leave_identical_records_for_every_kernel_family():
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
     import re
     m = re.search(r"suite: (\d+) of (\d+) kernel families clean", r.stdout)
-    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 11, r.stdout[-3000:]
+    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 13, r.stdout[-3000:]
     assert r.stdout.count(": 0 scenario records differ from the reference") == int(m.group(2))
 
 

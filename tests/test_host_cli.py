@@ -36,8 +36,10 @@ def _snapshot(tmp_path, brokers, racks, extra_brokers=()):
     return str(path), snap
 
 
-def _run(cli, *args):
-    return subprocess.run([cli, *args], capture_output=True, text=True, timeout=120)
+def _run(cli, *args, cells32=False):
+    """cells32: KAS_CELLS32=1 — the mirror hands kas_solve_host int32 broker ids instead of kas_solve_host16 node indices"""
+    env = dict(os.environ, KAS_CELLS32="1") if cells32 else None
+    return subprocess.run([cli, *args], capture_output=True, text=True, timeout=120, env=env)
 
 
 def _sections(stdout):
@@ -86,8 +88,9 @@ def _expected_new(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cells32", [False, True], ids=["cells16", "cells32"])
 @pytest.mark.parametrize("case", [c for c in C1["cases"] if "fails" not in c], ids=lambda c: c["name"])
-def test_print_reassignment_matches_appendix_b(cli, tmp_path, case):
+def test_print_reassignment_matches_appendix_b(cli, tmp_path, case, cells32):
     all_brokers = set(range(9))
     racks = {str(b): "abc"[b % 3] for b in range(6)}
     racks.update({"6": "c", "7": "a", "8": "b"})             # extra brokers
@@ -96,7 +99,7 @@ def test_print_reassignment_matches_appendix_b(cli, tmp_path, case):
             "--integer_broker_ids", ",".join(str(b) for b in case["brokers"])]
     if not case["racks"]:
         args.append("--disable_rack_awareness")
-    r = _run(cli, *args)
+    r = _run(cli, *args, cells32=cells32)
     assert r.returncode == 0, r.stderr
     sec = _sections(r.stdout)
     assert sec["CURRENT ASSIGNMENT"]["partitions"] == snap["partitions"]     # rollback aid, KAG:159-160
@@ -163,7 +166,7 @@ def test_exported_scenarios_through_the_cli_equal_the_oracle(cli, tmp_path):
                                topics=[Topic("t0", cur, 3, None)])])
         want = oracle_solve(fb)
         r = _run(cli, "--snapshot", path, "--mode", "PRINT_REASSIGNMENT",
-                 "--integer_broker_ids", ",".join(str(b) for b in snap["solve_brokers"]))
+                 "--integer_broker_ids", ",".join(str(b) for b in snap["solve_brokers"]), cells32=(s == 3))
         if want.scenario_results["status"][0] == abi.KAS_OK:
             assert r.returncode == 0, r.stderr
             new = _sections(r.stdout)["NEW ASSIGNMENT"]["partitions"]

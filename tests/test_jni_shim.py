@@ -56,6 +56,27 @@ def _payload(fb, select=None, device=0):
     return inp, out
 
 
+def _payload16(fb, select=None, device=0):
+    """Layout 4 with cellBits = 16 (ABI v5): cur[] / out[] as uint16 node indices, two to an int; everything else as
+    layout 3.  Returns (in, out, ints of out[] that hold the rows)."""
+    from kafka_assigner_amd.flatten import to_cells16
+    from kafka_assigner_amd.native import selected_out_len
+    S, T = fb.n_scenarios, fb.n_topics
+    c16 = to_cells16(fb) if fb.cur.size else np.zeros(0, np.uint16)
+    if c16.size % 2:
+        c16 = np.concatenate([c16, np.zeros(1, np.uint16)])
+    sel = np.zeros(0, np.int32) if select is None else np.asarray(select, dtype=np.int32)
+    ret_len = fb.out_len if select is None else selected_out_len(fb, sel)
+    hdr = np.asarray([4, S, T, fb.node_id.size, fb.cur.size if fb.cur.size else 0, fb.aux.size, fb.ctx.size, ret_len,
+                      device, -1 if select is None else sel.size, 16, 0], dtype=np.int32)
+    parts = [hdr, fb.scen[:S].view(np.int32).reshape(-1), fb.topics[:T].view(np.int32).reshape(-1),
+             fb.node_id, fb.node_rack, c16.view(np.int32), fb.aux, fb.ctx, sel]
+    inp = np.concatenate([np.ascontiguousarray(x, dtype=np.int32).reshape(-1) for x in parts])
+    ret_ints = (ret_len + 1) // 2
+    out = np.full(4 * T + 8 * S + ret_ints + fb.ctx.size, -7, dtype=np.int32)
+    return inp, out, ret_ints
+
+
 def _call(shim, inp, out):
     bi, bo = StubBuffer(inp.ctypes.data, inp.nbytes), StubBuffer(out.ctypes.data, out.nbytes)
     return shim(None, None, C.byref(bi), C.byref(bo))
@@ -81,6 +102,12 @@ def test_shim_rejects_short_buffers_and_unknown_layouts_without_a_gpu(shim):
     assert _call(shim, neg, out) == -1
     bad_dev = np.asarray([3, 0, 0, 0, 0, 0, 0, 0, -2, -1, 0, 0], dtype=np.int32)
     assert _call(shim, bad_dev, out) == -1
+    bad_cells = np.asarray([4, 0, 0, 0, 0, 0, 0, 0, 0, -1, 8, 0], dtype=np.int32)    # layout 4: cellBits must be 0, 16 or 32
+    assert _call(shim, bad_cells, out) == -1
+    short16 = np.asarray([4, 1, 1, 5, 9, 0, 0, 9, 0, -1, 16, 0], dtype=np.int32)     # 16-bit cells: tables missing
+    assert _call(shim, short16, out) == -1
+    future = np.asarray([5, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0, 0], dtype=np.int32)
+    assert _call(shim, future, out) == -1
 
 
 @pytest.mark.gpu
@@ -164,3 +191,61 @@ def test_shim_what_if_payload_returns_records_for_all_and_rows_for_the_selected(
         np.testing.assert_array_equal(rows[k * cells:(k + 1) * cells], want.out[s_ * cells:(s_ + 1) * cells])
     inp, out = _payload(fb, select=select, device=63)
     assert _call(shim, inp, out) == -1
+
+
+@pytest.mark.gpu
+def test_shim_layout_4_with_16_bit_cells_batch_and_selected_rows(shim):
+    """Layout 4, cellBits = 16 (kas_solve_host16 behind the shim): the batch payload of several scenarios and topics with
+    Contexts, and the form that returns only selected scenarios' rows — cells are node indices (0xFFFF pad), records and
+    Context counters as in layout 3; mapped through the node tables the rows are the oracle's lists of the int32 batch.
+    cellBits = 32 in a layout-4 header is the int32 payload."""
+    from kafka_assigner_amd import generator as G
+    from kafka_assigner_amd.flatten import cells16_to_ids, index_form
+    from kafka_assigner_amd.native import selected_out_len
+    scs = []
+    for s in range(4):
+        act, bs = G.scenario_action(21, s, 60, 12, actions=("add_k", "remove1", "replace1"), max_add=6)
+        racks = {int(b) * 5 + 3: "r%d" % int(r) for b, r in zip(bs.node_id, bs.node_rack)}
+        topics = []
+        for t in range(3):
+            cur = G.random_assignment(5 + 7 * s + t, 701 + 12 * t, 60, 12, 3)
+            topics.append(Topic("topic-%d" % t, {p: [int(x) * 5 + 3 for x in cur[p]] for p in range(cur.shape[0])}, 3))
+        scs.append(Scenario(brokers=[int(b) * 5 + 3 for b in bs.node_id], racks=racks, topics=topics, want_context=(s % 2 == 0)))
+    fb = flatten(scs)
+    want_ids = oracle_solve(fb)
+    want = oracle_solve(index_form(fb))
+    inp, out, ret_ints = _payload16(fb)
+    assert _call(shim, inp, out) == 0
+    S, T = fb.n_scenarios, fb.n_topics
+    tr = out[:4 * T].view(abi.TOPIC_RESULT_DTYPE)
+    sr = out[4 * T:4 * T + 8 * S].view(abi.SCENARIO_RESULT_DTYPE)
+    rows16 = out[4 * T + 8 * S:4 * T + 8 * S + ret_ints].view(np.uint16)[:fb.out_len]
+    ctx = out[4 * T + 8 * S + ret_ints:]
+    for f in ("status", "fail_partition", "moved_replicas", "moved_partitions"):
+        np.testing.assert_array_equal(tr[f], want.topic_results[f][:T])
+    for f in ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest"):
+        np.testing.assert_array_equal(sr[f], want.scenario_results[f][:S])
+    np.testing.assert_array_equal(rows16, np.where(want.out[:fb.out_len] < 0, 0xFFFF, want.out[:fb.out_len]).astype(np.uint16))
+    np.testing.assert_array_equal(cells16_to_ids(fb, rows16), want_ids.out[:fb.out_len])
+    np.testing.assert_array_equal(ctx, want_ids.ctx[:fb.ctx.size])
+    # selected rows only
+    select = [2, 1]
+    inp, out, ret_ints = _payload16(fb, select=select)
+    assert _call(shim, inp, out) == 0
+    n_sel = selected_out_len(fb, select)
+    sr = out[4 * T:4 * T + 8 * S].view(abi.SCENARIO_RESULT_DTYPE)
+    np.testing.assert_array_equal(sr["digest"], want.scenario_results["digest"][:S])
+    rows16 = out[4 * T + 8 * S:4 * T + 8 * S + ret_ints].view(np.uint16)[:n_sel]
+    at = 0
+    for s_ in select:
+        for t in range(int(fb.scen["topic_begin"][s_]), int(fb.scen["topic_begin"][s_]) + int(fb.scen["topic_count"][s_])):
+            td = fb.topics[t]
+            lo, n = int(td["out_off"]), int(td["n_partitions"]) * int(td["out_width"])
+            np.testing.assert_array_equal(rows16[at:at + n], np.where(want.out[lo:lo + n] < 0, 0xFFFF, want.out[lo:lo + n]).astype(np.uint16))
+            at += n
+    assert at == n_sel
+    # a layout-4 header with int32 cells
+    inp, out = _payload(fb)
+    inp[0], inp[10] = 4, 32
+    assert _call(shim, inp, out) == 0
+    np.testing.assert_array_equal(_unpack(fb, out)[2], want_ids.out[:fb.out_len])
