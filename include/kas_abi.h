@@ -241,9 +241,9 @@ int kas_ctx_synchronize(kas_ctx* ctx);
  * Copies: a pool in memory HIP knows as pinned (kas_host_alloc, hipHostMalloc, hipHostRegister) is
  * moved by DMA straight from / to the caller's buffer; pageable memory goes through the runtime's
  * staging.  Only [first, last] element a descriptor refers to is moved in either direction.  Batches
- * whose tables are large and laid out scenario by scenario are cut into scenario ranges, and the
+ * whose tables are large and laid out scenario by scenario are cut into (up to three) scenario ranges, and the
  * upload of one range, the solve of the previous one and the download of the one before run
- * concurrently on eight streams.  On an error after work was enqueued the call drains its streams
+ * concurrently, on streams of their own.  On an error after work was enqueued the call drains its streams
  * before it returns (no kernel or copy is left touching the caller's memory). */
 int kas_solve_host(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* host_tables);
 
@@ -360,8 +360,12 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_NO_RTN_QUOTA  rack-diverse fill with per-chunk histograms: draw a node's quota with separate LDS atomics,
  *                          reads and a ranking of the tiles in which it runs out, instead of one atomic-with-return
  *                          per list position
- *   KAS_PLAN_FILL_WITH_P4  first fit (KAS:162-186) inside the fill kernel's workgroup, as in rounds 1-4, instead of in
- *                          kas_p4_kernel behind it (testing / comparison)
+ *   KAS_PLAN_FILL_WITH_P4 / KAS_PLAN_SPLIT_P4  first fit (KAS:162-186) inside the fill kernel's workgroup (four wavefronts
+ *                          hand the windows over through LDS) / in kas_p4_kernel behind it (one wavefront per scenario),
+ *                          whatever the batch size.  Default: kas_p4_kernel for batches of >= 512 scenarios — it
+ *                          frees the fill workgroup's registers and LDS early, which is what counts when several
+ *                          batches share the GPU — and inside the fill workgroup below that and in kas_solve_host's
+ *                          plans (a batch alone on the GPU: the shorter critical path counts)
  *   KAS_PLAN_VERIFY_SAMPLE(k) relaxation form: k tiles of 64 rows per topic (evenly spaced, 1..255) are evaluated a second
  *                          time one row at a time — independent of how the LDS orders the lanes of an instruction —
  *                          and a scenario in which a row comes out differently reports KAS_FAIL_WATCHDOG instead of a
@@ -378,6 +382,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_RELAX_TILES(n) (((uint32_t)(n) & 3u) << 17)
 #define KAS_PLAN_NO_RTN_QUOTA 0x200000u
+#define KAS_PLAN_SPLIT_P4     0x400000u
 #define KAS_PLAN_FILL_WITH_P4 0x800000u
 #define KAS_PLAN_VERIFY_SAMPLE(k) (((uint32_t)(k) & 0xffu) << 24)
 #define KAS_PLAN_WAVES(n)     (((uint32_t)(n) & 0xfu) << 8)

@@ -37,7 +37,8 @@ KAS_PLAN_TICKET_ORDER = 0x10000
 KAS_PLAN_RELAX_TILES_64 = 0x20000     # KAS_PLAN_RELAX_TILES(1)
 KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)
 KAS_PLAN_NO_RTN_QUOTA = 0x200000
-KAS_PLAN_FILL_WITH_P4 = 0x800000      # first fit inside the fill workgroup (rounds 1-4) instead of in kas_p4_kernel
+KAS_PLAN_SPLIT_P4 = 0x400000          # first fit in kas_p4_kernel whatever the batch size (default: from 512 scenarios on)
+KAS_PLAN_FILL_WITH_P4 = 0x800000      # first fit inside the fill workgroup whatever the batch size
 
 
 def KAS_PLAN_VERIFY_SAMPLE(k: int) -> int:

@@ -752,7 +752,7 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
 // first fit in kas_p4_kernel in this plan's next solve (kas_split_p4)
 static bool kas_plan_split_p4(const kas_plan* p) {
   return p->b_p4s.p != nullptr &&
-         kas_split_p4(p->shape, p->NW, p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL), kas_plan_spread_chunks(p));
+         kas_split_p4(p->shape, p->NW, p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL), kas_plan_spread_chunks(p), p->n_scenarios);
 }
 
 int kas_plan_describe(const kas_plan* p, char* buf, int n) {
@@ -836,7 +836,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   const bool tickets = lp.tickets;
   const bool split_p4 = kas_plan_split_p4(p);
   a.p4s = (int32_t*)p->b_p4s.p;
-  if (split_p4) a.flags |= KAS_FLAG_SPLIT_P4;
+  a.flags = split_p4 ? (a.flags | KAS_FLAG_SPLIT_P4) : (a.flags & ~KAS_FLAG_SPLIT_P4);   // (the kernels' bit: this launch's form)
   const int slot = p->timer_next;
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
   const int32_t chunks = kas_plan_spread_chunks(p);
@@ -997,7 +997,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_FILL_WITH_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
+  p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
   // plan may still be in flight on the old scratch
@@ -1181,7 +1181,9 @@ static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_p
   // a host call blocks until its results are back: its solve has the GPU to itself (or shares it with the few other
   // scenario ranges of the same call), so the relaxation form takes double tiles whatever the batch size — the order
   // kernel of a 1000-variant what-if call 2.0 -> 1.7 ms
-  victim->plan->flags |= KAS_FLAG_RELAX_TILES_128;
+  // ... and its first fit stays on the fill workgroup's four wavefronts (kas_split_p4: 1000 variants alone, fill + first fit
+  // 1.07 ms against 1.39 ms with kas_p4_kernel)
+  victim->plan->flags |= KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4;
   *out_plan = victim->plan;
   return KAS_E_OK;
 }
@@ -1303,7 +1305,14 @@ struct KasCells16 {
 };
 
 #define KAS_HOST_SPLIT_MIN_BYTES (48ll << 20)   // tables smaller than this are moved and solved as one range
-#define KAS_HOST_SPLIT_MAX 8
+// Scenario ranges of one call.  A range's solve is a chain of ~2.5-3 ms however few scenarios it holds (one workgroup per
+// scenario walks its 100,000 rows), so a call lasts upload + that chain + the last range's download, and more ranges only
+// shorten the last download — while the runtime maps the ranges' solve streams onto GPU_MAX_HW_QUEUES (default 4) hardware
+// queues shared with everything else, where ranges on one queue run one after the other (a kernel + copy trace of eight
+// ranges: the last one solved alone, 3.4 ms after the others).  240 scenarios x 100,000 x 3 cells, 16-bit cells, pinned:
+// 2 ranges 6.4 ms, 3: 6.0, 4: 7.1 (5.9 with eight hardware queues), 8: 7.8; int32 cells 9.3-10.0 ms whatever the count
+// (scripts/e2e_host_path.py; KAS_HOST_RANGES overrides for such measurements).
+#define KAS_HOST_SPLIT_MAX 3
 
 static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables* h, const int32_t* select,
                                  int32_t n_select, const KasCells16* c16 = nullptr) {
@@ -1330,19 +1339,6 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     batch = &ident_batch;
   }
   const size_t cell = c16 ? sizeof(uint16_t) : sizeof(int32_t);     // bytes of a cur / out cell as it travels
-  // A 16-bit call whose out pool lies in pinned memory gets its rows by the narrowing kernel's own stores, straight into
-  // the caller's buffer: the copy engine then only carries the uploads, and the two directions of the link really run
-  // at once (copies of both directions issued from several streams shared the engine: 54-63 GB/s for the sum of both
-  // against 97 GB/s probed, profiles/r04_pcie_*.log).  KAS_NO_ZERO_COPY_OUT=1: through the staging buffer and a copy.
-  uint16_t* zc_out = nullptr;
-  if (c16 && c16->out && all_rows && !(getenv("KAS_NO_ZERO_COPY_OUT") && getenv("KAS_NO_ZERO_COPY_OUT")[0] == '1')) {
-    hipPointerAttribute_t at;
-    memset(&at, 0, sizeof(at));
-    if (hipPointerGetAttributes(&at, c16->out) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
-      zc_out = (uint16_t*)at.devicePointer;
-    else
-      (void)hipGetLastError();                                 // (ordinary memory: not an error)
-  }
   const bool have_cur = c16 ? c16->cur != nullptr : h->cur != nullptr;
   const bool have_out = c16 ? c16->out != nullptr : h->out != nullptr;
   // the whole batch: validation and the extents of every pool
@@ -1416,6 +1412,7 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   if (bytes_in + bytes_out >= KAS_HOST_SPLIT_MIN_BYTES && S >= 2) {
     K = (int)((bytes_in + bytes_out) / (KAS_HOST_SPLIT_MIN_BYTES / 2));
     if (K > KAS_HOST_SPLIT_MAX) K = KAS_HOST_SPLIT_MAX;
+    if (const char* e = getenv("KAS_HOST_RANGES")) { const int k = atoi(e); if (k >= 1 && k <= KAS_HOST_STREAMS) K = k; }
     if (K > S) K = (int)S;
   }
   std::vector<KasChain> chains;
@@ -1478,8 +1475,7 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     const KasChain& c = chains[(size_t)i];
     if (K > 1) hip_ok(hipStreamWaitEvent(s_down, ctx->hev_done[i], 0), "wait");
     if (all_rows && c.out_hi > c.out_lo) {
-      if (c16 && zc_out) {}                                    // (the narrowing kernel has stored them where they belong)
-      else if (c16) hip_ok(hipMemcpyAsync(c16->out + c.out_lo, d_out16 + c.out_lo, 2 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, s_down), "download out");
+      if (c16) hip_ok(hipMemcpyAsync(c16->out + c.out_lo, d_out16 + c.out_lo, 2 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, s_down), "download out");
       else hip_ok(hipMemcpyAsync(h->out + c.out_lo, d_out + c.out_lo, 4 * (size_t)(c.out_hi - c.out_lo), hipMemcpyDeviceToHost, s_down), "download out");
     }
     if (c.thi > c.tlo)
@@ -1517,8 +1513,9 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     if (src != KAS_E_OK) { fail_rc = src; break; }
     if (c16 && all_rows && c.out_hi > c.out_lo) {
       const int64_t n = c.out_hi - c.out_lo;
-      hipLaunchKernelGGL(kas_cells_narrow_kernel, dim3(kas_cells_grid(n)), dim3(256), 0, st, d_out + c.out_lo,
-                         (zc_out ? zc_out : d_out16) + c.out_lo, n);
+      // (into the staging buffer, not into the caller's pinned pool: the kernel's stores over the link ran at 20 GB/s —
+      // a call of 240 scenarios 10.5 ms against 8.4 ms with the copy engine, experiments/README.md)
+      hipLaunchKernelGGL(kas_cells_narrow_kernel, dim3(kas_cells_grid(n)), dim3(256), 0, st, d_out + c.out_lo, d_out16 + c.out_lo, n);
       if (!hip_ok(hipGetLastError(), "kas_cells_narrow_kernel")) break;
     }
     if (K > 1) hip_ok(hipEventRecord(ctx->hev_done[i], st), "record");

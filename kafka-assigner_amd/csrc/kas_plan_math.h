@@ -70,8 +70,9 @@ struct KasLaunch {
 #define KAS_FLAG_RELAX_TILES_128 0x40000u // relaxation form: double tiles whatever the batch size (KAS_PLAN_RELAX_TILES(2))
 #define KAS_FLAG_RELAX_DUAL      0x80000u // set by the launcher (kas_relax_double_tiles): double tiles in this launch
 #define KAS_FLAG_LANE_ORDER      0x100000u // set by the launcher: the LDS hands the lanes of one atomic instruction out in lane order here (self-test)
-#define KAS_FLAG_SPLIT_P4        0x400000u // set by the launcher (kas_split_p4): first fit of rack-diverse topics runs in kas_p4_kernel
-#define KAS_FLAG_FILL_WITH_P4    0x800000u // KAS_PLAN_FILL_WITH_P4: first fit inside the fill workgroup as in rounds 1-4 (testing / comparison)
+#define KAS_FLAG_SPLIT_P4        0x400000u // KAS_PLAN_SPLIT_P4 / set by the launcher (kas_split_p4): first fit of rack-diverse topics runs in kas_p4_kernel
+#define KAS_FLAG_FILL_WITH_P4    0x800000u // KAS_PLAN_FILL_WITH_P4: first fit inside the fill workgroup whatever the batch size
+#define KAS_SPLIT_P4_FROM 512            // batches of at least this many scenarios take kas_p4_kernel unless told otherwise
 #define KAS_FLAG_NO_RTN_QUOTA    0x200000u // KAS_PLAN_NO_RTN_QUOTA: the fill draws its quota without the atomic-with-return (testing / comparison)
 #define KAS_RELAX_DUAL_BELOW 512         // batches of fewer scenarios than this take double tiles unless told otherwise
 
@@ -350,9 +351,15 @@ struct KasShape {
 
 // First fit in a kernel of its own for this launch?  The rack-diverse fill with four wavefronts per scenario, the
 // one-workgroup fill kernel (the spread fill has its own P4 kernel).  `launch_flags`: KasLaunch::flags of the solve.
-static inline bool kas_split_p4(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks) {
-  return s.with_x && nw == KAS_P4_WAVES && !(launch_flags & (KAS_FLAG_GENERIC_FILL | KAS_FLAG_FILL_WITH_P4)) && spread_chunks == 0 &&
-         kas_p4_lds_layout(s.n_max).total <= KAS_LDS_LIMIT;
+// By batch size unless the flags say (KAS_FLAG_SPLIT_P4 / KAS_FLAG_FILL_WITH_P4): one first-fit wavefront per scenario in a
+// kernel of its own is what fills a GPU that has thousands of wavefronts to run (twelve batches of 1000 in flight: 672k
+// against 617k scenarios/s); a batch that has the GPU to itself waits for that wavefront's windows one after the other
+// (1000 scenarios alone: fill + first fit 1.39 ms against 1.07 ms on the fill's four wavefronts).
+static inline bool kas_split_p4(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks, int32_t n_scenarios) {
+  if (!(s.with_x && nw == KAS_P4_WAVES && !(launch_flags & (KAS_FLAG_GENERIC_FILL | KAS_FLAG_FILL_WITH_P4)) && spread_chunks == 0 &&
+        kas_p4_lds_layout(s.n_max).total <= KAS_LDS_LIMIT))
+    return false;
+  return (launch_flags & KAS_FLAG_SPLIT_P4) != 0u || n_scenarios >= KAS_SPLIT_P4_FROM;
 }
 
 // Fused histogram layout of the rack-diverse fill (kas_fill_lds_layout with_x = 2): lists up to 3 wide

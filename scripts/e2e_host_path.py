@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """The plain host path in seconds (MEASUREMENT TOOLING; bench.py's end_to_end leg holds the figures that are quoted):
 S scenarios with their own 100,000 x 3 tables through kas_solve_host (int32 broker ids) and kas_solve_host16 (16-bit
-node indices), caller buffers from kas_host_alloc; 16-bit rows stored by the narrowing kernel straight into the caller's
-buffer or (KAS_NO_ZERO_COPY_OUT=1) copied from a staging buffer.  usage: e2e_host_path.py [S] [calls]"""
+node indices), caller buffers from kas_host_alloc; and the number of scenario ranges a call is cut into
+(KAS_HOST_RANGES, a tuning override of kas_solve_host's own choice).  usage: e2e_host_path.py [S] [calls]"""
 import ctypes as C
 import os
 import sys
@@ -50,13 +50,15 @@ def run(name, fn, cell):
     print(f"{name:58s} {1e3 * dt:7.2f} ms per call  {S / dt / 1e3:6.1f}k scenarios/s  {cell * (fb.cur.size + fb.out_len) / dt / 1e9:5.1f} GB/s over the link (sum)", flush=True)
 
 
-run("int32 broker ids, pinned", lambda: native._check(L.kas_solve_host(ctx._h, C.byref(bd), C.byref(t))), 4)
+f32 = lambda: native._check(L.kas_solve_host(ctx._h, C.byref(bd), C.byref(t)))
+f16 = lambda: native._check(L.kas_solve_host16(ctx._h, C.byref(bd16), C.byref(t16), None, -1))
+run("int32 broker ids, pinned", f32, 4)
 ids32 = po.array.copy()
-run("16-bit cells, pinned, rows stored by the narrowing kernel", lambda: native._check(L.kas_solve_host16(ctx._h, C.byref(bd16), C.byref(t16), None, -1)), 2)
+run("16-bit cells, pinned", f16, 2)
 assert (cells16_to_ids(fb, po16.array) == ids32).all(), "16-bit rows differ from the int32 call's"
-po16.array[:] = 0
-os.environ["KAS_NO_ZERO_COPY_OUT"] = "1"
-run("16-bit cells, pinned, rows copied from the staging buffer", lambda: native._check(L.kas_solve_host16(ctx._h, C.byref(bd16), C.byref(t16), None, -1)), 2)
-assert (cells16_to_ids(fb, po16.array) == ids32).all()
-del os.environ["KAS_NO_ZERO_COPY_OUT"]
-print("rows of the three forms identical")
+for k in (os.environ.get("E2E_RANGES", "2,3,4,6,8").split(",")):          # scenario ranges per call (KAS_HOST_RANGES: tuning)
+    os.environ["KAS_HOST_RANGES"] = k
+    run(f"int32, {k} scenario ranges", f32, 4)
+    run(f"16-bit cells, {k} scenario ranges", f16, 2)
+del os.environ["KAS_HOST_RANGES"]
+print("rows identical")

@@ -321,7 +321,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   g_last_flagged = 0;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch;
-  a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4) & ~KAS_FLAG_FUSED_HIST) |
+  a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~KAS_FLAG_FUSED_HIST) |
             (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u) |
             (kas_relax_double_tiles(flags, b->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
             ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER);
@@ -380,11 +380,13 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   // first fit in a kernel of its own (same decision as kas_solve_device)
   std::vector<int32_t> p4s;
   a.p4s = nullptr;
-  const bool split_p4 = kas_split_p4(sh, sh.NW, a.flags | (flags & KAS_FLAG_FILL_WITH_P4), CH);
+  const bool split_p4 = kas_split_p4(sh, sh.NW, a.flags, CH, b->n_scenarios);
   if (split_p4) {
     p4s.assign((size_t)b->n_topics * (size_t)(KAS_P4S_HEAD + (sh.n_max > 0 ? sh.n_max : 1)) + 64, (int32_t)0xDEADBEEF);
     a.p4s = p4s.data();
     a.flags |= KAS_FLAG_SPLIT_P4;
+  } else {
+    a.flags &= ~KAS_FLAG_SPLIT_P4;
   }
   g_last_split_p4 = split_p4 ? 1 : 0;
   for (int32_t s = 0; s < b->n_scenarios; ++s) {

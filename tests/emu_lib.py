@@ -140,11 +140,11 @@ def variant_solver(name: str, flags):
     L.kas_emu_solve_batch.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
                                       C.c_uint, C.c_char_p, C.c_int]
 
-    def solve(fb: FlatBatch, flags: int = 0) -> HostOutputs:
+    def solve(fb: FlatBatch, flags: int = 0, p4_by_batch_size: bool = False) -> HostOutputs:
         bd = batch_desc(fb)
         t, ho = host_tables(fb)
         err = C.create_string_buffer(512)
-        rc = L.kas_emu_solve_batch(C.byref(bd), C.byref(t), flags, err, 512)
+        rc = L.kas_emu_solve_batch(C.byref(bd), C.byref(t), _p4_form(flags, p4_by_batch_size), err, 512)
         if rc != 0:
             raise RuntimeError(f"kas_emu_solve_batch rc={rc}: {err.value.decode()}")
         return ho
@@ -175,11 +175,21 @@ def last_queue_rows() -> int:
     return int(lib().kas_emu_last_queue_rows())
 
 
-def emu_solve(fb: FlatBatch, flags: int = 0) -> HostOutputs:
+def _p4_form(flags: int, by_batch_size: bool) -> int:
+    """The product runs first fit in kas_p4_kernel from 512 scenarios a batch on (kas_split_p4) — the headline's form, and
+    the emulator's batches are small: unless a test names a form (FILL_WITH_P4 / SPLIT_P4) or asks for the product's own
+    choice (p4_by_batch_size=True), the emulator runs kas_p4_kernel; the form inside the fill workgroup is covered where
+    FILL_WITH_P4 is passed (test_emu_parity.py)."""
+    if by_batch_size or (flags & (FILL_WITH_P4 | SPLIT_P4)):
+        return flags
+    return flags | SPLIT_P4
+
+
+def emu_solve(fb: FlatBatch, flags: int = 0, p4_by_batch_size: bool = False) -> HostOutputs:
     bd = batch_desc(fb)
     t, ho = host_tables(fb)
     err = C.create_string_buffer(512)
-    rc = lib().kas_emu_solve_batch(C.byref(bd), C.byref(t), flags, err, 512)
+    rc = lib().kas_emu_solve_batch(C.byref(bd), C.byref(t), _p4_form(flags, p4_by_batch_size), err, 512)
     if rc != 0:
         raise RuntimeError(f"kas_emu_solve_batch rc={rc}: {err.value.decode()}")
     return ho
@@ -229,7 +239,8 @@ def last_split_p4() -> int:
     return int(L.kas_emu_last_split_p4())
 
 
-FILL_WITH_P4 = 0x800000    # KAS_PLAN_FILL_WITH_P4: first fit inside the fill workgroup, as in rounds 1-4
+FILL_WITH_P4 = 0x800000    # KAS_PLAN_FILL_WITH_P4: first fit inside the fill workgroup whatever the batch size
+SPLIT_P4 = 0x400000        # KAS_PLAN_SPLIT_P4: first fit in kas_p4_kernel whatever the batch size
 TICKET_ORDER = 0x10000     # KAS_PLAN_TICKET_ORDER: the ticket form where the relaxation form would run
 RELAX_TILES_64 = 0x20000   # KAS_PLAN_RELAX_TILES(1): relaxation form over tiles of 64 rows whatever the batch size
 RELAX_TILES_128 = 0x40000  # KAS_PLAN_RELAX_TILES(2): double tiles whatever the batch size

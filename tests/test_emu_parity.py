@@ -83,7 +83,9 @@ def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert last_split_p4() == 1                             # round 5: first fit in kas_p4_kernel behind the fill kernel ...
     assert_same_outputs(fb, want, emu_solve(fb, flags=FILL_WITH_P4), "emu, first fit inside the fill workgroup")
-    assert last_split_p4() == 0                             # ... unless the plan says otherwise
+    assert last_split_p4() == 0                             # ... unless the plan says otherwise ...
+    assert_same_outputs(fb, want, emu_solve(fb, p4_by_batch_size=True), "emu, first fit where the product runs it for six scenarios")
+    assert last_split_p4() == 0                             # ... or the batch is small (kas_split_p4: from 512 scenarios on)
     assert_same_outputs(fb, want, emu_solve(fb, flags=FILL_WITH_P4 | RELAX_TILES_64), "emu, first fit inside the fill workgroup, tiles of 64 rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu ticket form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu relaxation form, tiles of 64 rows")
@@ -614,3 +616,14 @@ def test_emu_mixed_batch_over_tiles_of_64_rows():
                          (FILL_WITH_P4, 0), (FILL_WITH_P4 | RELAX_TILES_64, 0), (TICKET_ORDER, 1), (2, 1), (1, 0)):
         assert_same_outputs(fb, want, emu_solve(fb, flags=flags), "emu, flags %#x" % flags)
         assert last_split_p4() == split, hex(flags)         # (first fit in kas_p4_kernel: four fill wavefronts, rack-diverse form)
+
+
+def test_first_fit_takes_its_own_kernel_from_512_scenarios_on():
+    """kas_split_p4: by batch size unless the plan flags name a form."""
+    for S, split in ((511, 0), (512, 1)):
+        fb = _batch(808, S, 130, 12, 4, 3, ("remove1", "add_k"))
+        want = oracle_solve(fb, threads=0)
+        assert_same_outputs(fb, want, emu_solve(fb, p4_by_batch_size=True), "emu, %d scenarios" % S)
+        assert last_split_p4() == split, S
+    assert_same_outputs(fb, want, emu_solve(fb, flags=FILL_WITH_P4), "emu, 512 scenarios, first fit inside the fill workgroup")
+    assert last_split_p4() == 0

@@ -68,6 +68,8 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_128), "hip relaxation form, double tiles")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "hip fill, quota drawn without the atomic-with-return")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FILL_WITH_P4), "hip first fit inside the fill workgroup (no kas_p4_kernel)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4), "hip first fit in kas_p4_kernel (what batches of >= 512 scenarios take)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip kas_p4_kernel + tiles of 64 rows: the headline's kernels")
     # the general multi-sweep sticky fill must agree with the rack-diverse histogram/quota form,
     # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
@@ -171,7 +173,7 @@ def test_one_plan_orders_its_solves_across_streams():
     ctx = native.default_context()
     plan = native.Plan(ctx, fb)
     assert "kas_fill_kernel<3,4>[quota, chunk histograms]" in plan.describe() and "kas_order_relax_kernel<3>" in plan.describe()
-    assert "+ kas_p4_kernel<3> grid=24x64" in plan.describe()                       # first fit: a launch of its own, one wavefront per scenario
+    assert "kas_p4_kernel" not in plan.describe()                                   # 24 scenarios: first fit inside the fill workgroup
     dev = torch.device("cuda", ctx.device)
     d_cur = torch.from_numpy(fb.cur).to(dev)
     streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
@@ -197,6 +199,8 @@ def test_one_plan_orders_its_solves_across_streams():
     assert "kas_order_relax_kernel<3>[tiles of 128 rows]" in plan.describe()      # 24 scenarios: a latency-bound launch
     plan.set_flags(TILES_64)
     assert "kas_order_relax_kernel<3>[tiles of 64 rows]" in plan.describe()
+    plan.set_flags(abi.KAS_PLAN_SPLIT_P4)
+    assert "+ kas_p4_kernel<3> grid=24x64" in plan.describe()                       # a launch of its own, one wavefront per scenario
     plan.set_flags(abi.KAS_PLAN_FILL_WITH_P4)
     assert "kas_p4_kernel" not in plan.describe()
     plan.close()
@@ -259,8 +263,8 @@ def test_host_path_what_if_select_returns_every_record_and_the_selected_rows():
 
 
 def test_host_path_cuts_large_tables_into_overlapping_scenario_ranges_and_takes_pinned_memory():
-    """Tables of 48 MB and more laid out scenario by scenario are moved and solved as up to eight
-    scenario ranges on three streams (upload / solve / download overlapping); the result must not depend
+    """Tables of 48 MB and more laid out scenario by scenario are moved and solved as up to three
+    scenario ranges (upload / solve / download overlapping, each on streams of its own); the result must not depend
     on it, nor on whether the caller's pools are pageable or pinned (kas_host_alloc)."""
     from kafka_assigner_amd.flatten import host_tables
     import ctypes as C
@@ -270,7 +274,7 @@ def test_host_path_cuts_large_tables_into_overlapping_scenario_ranges_and_takes_
     assert_same_outputs(fb, want, native.solve_host(fb, ctx), "host path, split into ranges (pageable)")
     calls, hits, allocs = ctx.host_stats()
     assert_same_outputs(fb, want, native.solve_host(fb, ctx), "host path, split into ranges, again")
-    assert ctx.host_stats() == (calls + 1, hits + 4, allocs)             # four ranges, four cached plans, nothing grown
+    assert ctx.host_stats() == (calls + 1, hits + 3, allocs)             # three ranges, three cached plans, nothing grown
     pin_cur, pin_out = native.PinnedArray(fb.cur.size), native.PinnedArray(fb.out_len)
     pin_cur.array[:] = fb.cur
     pin_out.array[:] = -9
