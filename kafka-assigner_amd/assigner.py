@@ -115,8 +115,19 @@ class KafkaAssignmentStrategy:
                                   node_rack_assignment: Dict[int, str], nodes: Set[int],
                                   partitions: Set[int], replication_factor: int,
                                   context: Optional[Context]) -> Dict[int, List[int]]:
+        import os
         from . import native
-        result, _ = _solve_one(native.solve_host, topic_name, current_assignment,
+        from .flatten import cells16_to_ids
+
+        def solve16(fb):
+            """kas_solve_host16 (ABI v5): replicas travel as positions in the sorted broker list, half the bytes of the
+            per-topic call; mapped back here.  KAS_CELLS32=1: kas_solve_host with int32 broker ids."""
+            ho = native.solve_host16(fb)
+            ho.out = cells16_to_ids(fb, ho.out)
+            return ho
+
+        cells32 = os.environ.get("KAS_CELLS32", "") == "1" or len(set(nodes)) > 65535
+        result, _ = _solve_one(native.solve_host if cells32 else solve16, topic_name, current_assignment,
                                node_rack_assignment, nodes, partitions, replication_factor,
                                context)
         return result

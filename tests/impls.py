@@ -5,7 +5,8 @@
   emu     : the product's kernel SOURCE (csrc/kas_solver_body.h, kas_order_wide.h) stepped on the CPU fiber
             emulator (tests/emu) behind the product's host mirror — test infrastructure, no GPU
   hip     : the product — kafka_assigner_amd.KafkaTopicAssigner over the C ABI and HIP kernels
-            (GPU only; tests using it are marked @pytest.mark.gpu)
+            (GPU only; tests using it are marked @pytest.mark.gpu); it calls kas_solve_host16 (16-bit node-index cells),
+            hip32 the same mirror through kas_solve_host (int32 broker ids)
 
 Each is exposed behind the reference's own interface: an object with
 generate_assignment(topic, current_assignment, brokers, rack_assignment, desired_rf)
@@ -84,11 +85,27 @@ class HipAssigner:
         return self._impl.generate_assignment(topic, cur, set(brokers), dict(racks), desired_rf)
 
 
+class HipAssignerInt32Cells(HipAssigner):
+    """the same mirror with KAS_CELLS32=1: kas_solve_host (int32 broker ids) instead of kas_solve_host16 (node indices)"""
+
+    def generate_assignment(self, topic, cur, brokers, racks, desired_rf):
+        old = os.environ.get("KAS_CELLS32")
+        os.environ["KAS_CELLS32"] = "1"
+        try:
+            return super().generate_assignment(topic, cur, brokers, racks, desired_rf)
+        finally:
+            if old is None:
+                del os.environ["KAS_CELLS32"]
+            else:
+                os.environ["KAS_CELLS32"] = old
+
+
 IMPLS = {
     "literal": LiteralAssigner,
     "oracle": OracleAssigner,
     "emu": EmuAssigner,
     "hip": HipAssigner,
+    "hip32": HipAssignerInt32Cells,
 }
 
 # parametrisation helper: CPU implementations always, the product only on the GPU box
@@ -97,4 +114,5 @@ ALL_IMPLS = [
     pytest.param("oracle", id="oracle"),
     pytest.param("emu", id="emu"),
     pytest.param("hip", id="hip", marks=pytest.mark.gpu),
+    pytest.param("hip32", id="hip-int32-cells", marks=pytest.mark.gpu),
 ]
