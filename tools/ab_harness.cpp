@@ -15,6 +15,7 @@
 //                                between two synchronisations, REPEATS times: scenarios/s by the host clock (bench.py's regime)
 //   AB_FLAGS=n                   kas_plan_set_flags(n) on every plan (KAS_PLAN_* of include/kas_abi.h)
 //   AB_DISTINCT=1                in flight: every slot its own copy of the cur table (as bench.py's slots have)
+//   AB_CELLS16=1                 timing experiment: cur as packed uint16 node indices, identity node ids (for -DKAS_TUNE_CELLS16 builds)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -125,6 +126,23 @@ int main(int argc, char** argv) {
   kas_batch_desc bd;
   bd.n_scenarios = S; bd.n_topics = S * T; bd.scenarios = scen.data(); bd.topics = topics.data();
   bd.node_id = node_id.data(); bd.node_rack = node_rack.data(); bd.node_pool_len = (int64_t)node_id.size();
+  if (getenv("AB_CELLS16")) {
+    // timing experiment (libraries built with -DKAS_TUNE_CELLS16 only): every topic's rows as uint16 node indices, packed
+    // at the start of the topic's own int32 region (same offsets); node i has id i
+    for (int s = 0; s < S; ++s) {
+      const kas_scenario_desc& sd = scen[s];
+      std::vector<int32_t> index_of((size_t)N0 + 64, -1);
+      for (int32_t i = 0; i < sd.n_nodes; ++i) index_of[(size_t)node_id[(size_t)(sd.node_off + i)]] = i;
+      for (int k = 0; k < T; ++k) {
+        const kas_topic_desc& td = topics[(size_t)s * T + k];
+        const int32_t* src = cur.data() + td.cur_off;
+        uint16_t* dst = reinterpret_cast<uint16_t*>(cur.data() + td.cur_off);
+        const int64_t n = (int64_t)td.n_partitions * td.cur_width;
+        for (int64_t i = 0; i < n; ++i) { const int32_t ix = index_of[(size_t)src[i]]; dst[i] = ix < 0 ? (uint16_t)0xffffu : (uint16_t)ix; }
+      }
+      for (int32_t i = 0; i < sd.n_nodes; ++i) node_id[(size_t)(sd.node_off + i)] = i;
+    }
+  }
   const auto t_gen = std::chrono::steady_clock::now();
   if (const char* dump = getenv("AB_DUMP")) {
     // the batch as raw int32 arrays for a checker outside this tool (tests/test_ab_harness.py: the oracle on the same tables):
