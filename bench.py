@@ -110,6 +110,9 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=int(os.environ.get("KAS_BENCH_GROUPS", "0")),
                     help="scenarios per wavefront of the ticket-form order kernel (0 = the plan's choice)")
     ap.add_argument("--plan-flags", type=int, default=0, help="KAS_PLAN_* switches (testing)")
+    ap.add_argument("--cells", type=int, choices=(16, 32), default=16,
+                    help="cells of the tables resident in HBM: 16 = uint16 node indices (kas_plan_create16, ABI v5; lists up to "
+                         "3 wide, else 32 is taken), 32 = int32 broker ids (kas_plan_create)")
     ap.add_argument("--stub", action="store_true",
                     help="harness self-test on CPU (gloo, synthetic records): NOT a measurement")
     return ap.parse_args(argv)
@@ -176,6 +179,7 @@ class HipRun:
         S, P, N, R, RF = hi - lo, args.partitions, args.brokers, args.racks, args.rf
         self.S, self.lo = S, lo
         self.ctx = native.DeviceContext(local_rank)
+        self.cells16 = getattr(args, "cells", 16) == 16 and RF <= 3
         self.n_slots = max(1, min(args.in_flight, args.steps))
         self.distinct = 1 if args.same_batch else self.n_slots
         # every slot its own current assignments (slot 0's are the ones rounds 1 and 2 measured)
@@ -207,7 +211,7 @@ class HipRun:
                 act, bs = G.scenario_action(self.slot_seed(i), self.lo + s, args.brokers, args.racks, actions=action_mix)
                 actions.append(act); ids.append(bs.node_id); racks.append(bs.node_rack)
             fb = node_set_batch(ids, racks, args.partitions, args.rf, args.rf)
-            plan_ = native.Plan(self.ctx, fb)
+            plan_ = native.Plan(self.ctx, fb, cells16=self.cells16)
             if args.waves or args.groups or args.plan_flags:
                 plan_.set_flags((args.waves << 8) | (args.groups << 12) | args.plan_flags)
             if old:
@@ -215,13 +219,14 @@ class HipRun:
             else:
                 # a dedicated HIP stream per slot, shared by its solver launches and its RCCL
                 # all-gather (handle 0, torch's default stream, would select the library's own)
-                sl = {"out": torch.empty(fb.out_len, dtype=torch.int32, device=self.dev),
+                sl = {"out": torch.empty(fb.out_len, dtype=torch.int16 if self.cells16 else torch.int32, device=self.dev),
                       "tr": torch.zeros(S * 16, dtype=torch.uint8, device=self.dev),
                       "sr": torch.zeros(S * 32, dtype=torch.uint8, device=self.dev),
                       "stream": torch.cuda.Stream(self.dev)}
                 sl["stream"].wait_stream(torch.cuda.current_stream(self.dev))
-            sl.update(plan=plan_, fb=fb, ids=ids, racks=racks, actions=actions,
-                      cur=self.d_cur[i if self.distinct > 1 else 0])
+            cur_ids = self.d_cur[i if self.distinct > 1 else 0]
+            sl.update(plan=plan_, fb=fb, ids=ids, racks=racks, actions=actions, cur_ids=cur_ids,
+                      cur=self.cells_of(cur_ids, ids) if self.cells16 else cur_ids)
             self.slots.append(sl)
         self.actions = self.slots[0]["actions"]
         # set-up, not warm-up: every slot's plan runs once so that no slot meets its first launch
@@ -230,6 +235,86 @@ class HipRun:
             self.solve(sl)
         self.synchronize()
         self.step_no = 0
+
+    def cells_of(self, cur_ids, ids):
+        """The resident form of a slot's tables with 16-bit cells: every replica as the position of its broker in the
+        scenario's ascending broker list (0xFFFF: the broker left the set) — int16 [S, P * RF], made on the device from the
+        int32 table by one table lookup per scenario (set-up, not timed)."""
+        torch = self.torch
+        S = len(ids)
+        width = int(max(int(x.max()) for x in ids)) + 2
+        width = max(width, self.args.brokers + 2)
+        lut = np.full((S, width), 0xFFFF, dtype=np.uint16)
+        for s, x in enumerate(ids):
+            lut[s, x] = np.arange(len(x), dtype=np.uint16)
+        d_lut = torch.from_numpy(lut.view(np.int16)).to(self.dev)
+        out = torch.empty((S, cur_ids.shape[1] * cur_ids.shape[2]), dtype=torch.int16, device=self.dev)
+        step = 64
+        for lo in range(0, S, step):
+            hi = min(S, lo + step)
+            idx = cur_ids[lo:hi].reshape(hi - lo, -1).to(torch.int64)
+            out[lo:hi] = torch.gather(d_lut[lo:hi], 1, idx)
+        return out
+
+    def check_ids(self, sl):
+        """broker ids of the slot's scenarios as the CHECKERS see them: with 16-bit cells node i has id i"""
+        return [np.arange(len(x), dtype=np.int32) for x in sl["ids"]] if self.cells16 else sl["ids"]
+
+    def check_cur(self, slot, idx=None):
+        """the slot's cur tables as the checkers see them (int32 [n, P, RF]): broker ids, or node indices with -1 for 0xFFFF"""
+        if not self.cells16:
+            return self.host_cur(slot, idx)
+        c = self.slots[slot]["cur"]
+        if idx is not None and len(idx) != self.S:
+            c = self.torch.stack([c[s] for s in idx])
+        h = c.cpu().numpy().view(np.uint16).astype(np.int32)
+        h[h == 0xFFFF] = -1
+        return h.reshape(h.shape[0], self.args.partitions, self.args.rf)
+
+    def check_out(self, sl, lo=None, hi=None):
+        """out cells [lo, hi) as int32 (-1 = pad): broker ids, or node indices"""
+        o = sl["out"] if lo is None else sl["out"][lo:hi]
+        h = o.cpu().numpy()
+        if not self.cells16:
+            return h
+        h = h.view(np.uint16).astype(np.int32)
+        h[h == 0xFFFF] = -1
+        return h
+
+    def int32_cells_rate(self, n_steps):
+        """The same slots through kas_plan_create / kas_solve_device (int32 broker ids in HBM): scenarios per second over
+        n_steps steps round-robin, for the line's comparison figure.  Builds and drops its own plans and out tables."""
+        torch = self.torch
+        from kafka_assigner_amd import native
+        args = self.args
+        extra = []
+        for sl in self.slots:
+            plan_ = native.Plan(self.ctx, sl["fb"])
+            if args.waves or args.groups or args.plan_flags:
+                plan_.set_flags((args.waves << 8) | (args.groups << 12) | args.plan_flags)
+            extra.append((plan_, torch.empty(sl["fb"].out_len, dtype=torch.int32, device=self.dev)))
+
+        def go(k):
+            sl, (plan_, out) = self.slots[k % self.n_slots], extra[k % self.n_slots]
+            plan_.solve_device(sl["cur_ids"].data_ptr(), out.data_ptr(), sl["tr"].data_ptr(), sl["sr"].data_ptr(),
+                               stream=sl["stream"].cuda_stream)
+        for k in range(self.n_slots):
+            go(k)
+        self.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            go(k)
+        self.synchronize()
+        el = time.perf_counter() - t0
+        what = extra[0][0].describe()
+        for plan_, _ in extra:
+            plan_.close()
+        del extra
+        # (the slots' records were overwritten by these solves: one solve each puts the product's back)
+        for sl in self.slots:
+            self.solve(sl)
+        self.synchronize()
+        return self.S * n_steps / el, 1e3 * el / n_steps, what
 
     def solve(self, sl):
         sl["plan"].solve_device(sl["cur"].data_ptr(), sl["out"].data_ptr(), sl["tr"].data_ptr(),
@@ -265,7 +350,8 @@ class HipRun:
         return self.slots[0]["plan"].algorithmic_bytes
 
     def host_cur(self, slot, idx=None):
-        cur = self.slots[slot]["cur"]
+        """the slot's tables as int32 broker ids (what the generator made: the host-boundary legs start from these)"""
+        cur = self.slots[slot]["cur_ids"]
         if idx is None or len(idx) == self.S:
             return cur.cpu().numpy()
         return self.torch.stack([cur[s] for s in idx]).cpu().numpy()
@@ -456,6 +542,13 @@ def run_rank(args) -> int:
     long_steps = 2 * args.steps
     long_reps = [] if args.stub or args.no_extras else [timed(long_steps, 0) for _ in range(3)]
     run.phase_times()
+    # the same slots with int32 broker ids resident in HBM (kas_plan_create / kas_solve_device), for comparison
+    int32_cells = None
+    if not args.stub and not args.no_extras and world == 1 and getattr(run, "cells16", False):
+        v32, ms32, what32 = run.int32_cells_rate(args.steps)
+        int32_cells = {"value": v32, "unit": "scenarios/s", "ms_per_step": ms32, "steps": args.steps, "kernel": what32,
+                       "note": "one region of the same steps, tables as int32 broker ids (12 + 12 bytes per row of three replicas "
+                               "read and written instead of 6 + 6)"}
 
     if args.stats and rank == 0 and not args.stub:
         st = run.slots[0]["plan"].stats().astype(np.float64)
@@ -591,6 +684,10 @@ def run_rank(args) -> int:
                 "collective": "all_gather of 32-byte result records per step" if world > 1 else "none (1 GPU)",
                 "allgather_alone_us": allgather_us,
                 "batches_in_flight": run.n_slots, "distinct_batches_in_flight": run.distinct,
+                "cells": ("uint16 node indices resident in HBM (kas_plan_create16 / kas_solve_device16, ABI v5): a replica is the "
+                          "position of its broker in the scenario's ascending broker list; parity: the CPU solvers on the index "
+                          "form of every batch" if getattr(run, "cells16", False) else "int32 broker ids resident in HBM"),
+                "int32_cells": int32_cells,
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "setup_solves_per_slot": 0 if args.stub else 1,
                 "literal_c3_mix": literal,
@@ -690,8 +787,11 @@ def parity_and_cpu_baselines(args, run, slot_records, world):
     if len(bad) and int(bad[0]) not in pick:            # keep a failing scenario in a bounded sample
         pick[-1] = int(bad[0])
     sl0 = run.slots[0]
-    h_cur = run.host_cur(0, pick)
-    sub = node_set_batch([sl0["ids"][s] for s in pick], [sl0["racks"][s] for s in pick], P, RF, RF, cur=h_cur)
+    # (with 16-bit cells resident in HBM the checkers solve the index form of the batch — node i has id i, cur holds node
+    # indices — whose lists and digests are the device's cell for cell: run.check_*)
+    h_cur = run.check_cur(0, pick)
+    ids0 = run.check_ids(sl0)
+    sub = node_set_batch([ids0[s] for s in pick], [sl0["racks"][s] for s in pick], P, RF, RF, cur=h_cur)
     cores = host_threads()
     fields = ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest")
 
@@ -712,12 +812,12 @@ def parity_and_cpu_baselines(args, run, slot_records, world):
     b1_all, want = median_wall(oracle_solve, sub, 3 if timed_cpu else 0)      # B1 (and the checker's answers)
     b1_threads = want.threads_used
     ow = RF
-    got_out = sl0["out"].cpu().numpy() if n_check == S else None
+    got_out = run.check_out(sl0) if n_check == S else None
     for i, s in enumerate(pick):
         for f in fields:
             assert sr[f][s] == want.scenario_results[f][i], f"slot 0 scenario {s}: {f} differs from the oracle"
         rows = got_out[s * P * ow:(s + 1) * P * ow] if got_out is not None else \
-            sl0["out"][s * P * ow:(s + 1) * P * ow].cpu().numpy()
+            run.check_out(sl0, s * P * ow, (s + 1) * P * ow)
         assert (rows == want.out[i * P * ow:(i + 1) * P * ow]).all(), f"slot 0 scenario {s}: lists differ from the oracle"
     parity = {"records": len(pick), "lists": len(pick), "slots": 1}
 
@@ -730,7 +830,7 @@ def parity_and_cpu_baselines(args, run, slot_records, world):
                 assert (slot_records[k] == sr).all(), f"slot {k} (same inputs as slot 0) left different records"
                 parity["records"] += S; parity["slots"] += 1
                 continue
-            batch = sub if k == 0 else node_set_batch(sl["ids"], sl["racks"], P, RF, RF, cur=run.host_cur(k))
+            batch = sub if k == 0 else node_set_batch(run.check_ids(sl), sl["racks"], P, RF, RF, cur=run.check_cur(k))
             fast = cpu_fast_solve(batch, threads=0)
             if k == 0:
                 fast0 = fast
@@ -753,7 +853,7 @@ def parity_and_cpu_baselines(args, run, slot_records, world):
             t_c0 = time.perf_counter()
             while True:
                 idx = [(done + i) % len(pick) for i in range(m)]
-                part = node_set_batch([sl0["ids"][pick[j]] for j in idx], [sl0["racks"][pick[j]] for j in idx], P, RF, RF,
+                part = node_set_batch([ids0[pick[j]] for j in idx], [sl0["racks"][pick[j]] for j in idx], P, RF, RF,
                                       cur=h_cur[idx])
                 t2 = time.perf_counter()
                 solve(part, threads=1)
@@ -1110,7 +1210,7 @@ def other_configs_leg(args, run):
         # records of a sample against the flat-array CPU solver (all host threads), which is also the CPU figure
         n_cpu = 128
         from kafka_assigner_amd.flatten import node_set_batch
-        sub = node_set_batch(sl0["ids"][:n_cpu], sl0["racks"][:n_cpu], a3.partitions, a3.rf, a3.rf, cur=run3.host_cur(0, list(range(n_cpu))))
+        sub = node_set_batch(run3.check_ids(sl0)[:n_cpu], sl0["racks"][:n_cpu], a3.partitions, a3.rf, a3.rf, cur=run3.check_cur(0, list(range(n_cpu))))
         t0 = time.perf_counter()
         want3 = cpu_fast_solve(sub, threads=0)
         c3 = time.perf_counter() - t0

@@ -273,8 +273,9 @@ int kas_solve_host_select(kas_ctx* ctx, const kas_batch_desc* batch, const kas_t
  *   batch->node_id is not read and may be NULL (node i has id i); node_rack[], descriptors, aux, ctx, the result
  *   records and select / n_select (n_select < 0: every row in place) are exactly kas_solve_host_select's; descriptor
  *   offsets and cur_len / out_len count cells.  More than 65,535 brokers in a scenario: KAS_E_UNSUPPORTED.
- * On the device the cells are widened before and narrowed behind the solve (two streaming kernels on the range's
- * solve stream, 6 bytes of HBM traffic per cell against 2 bytes on the link); kas_solve_device keeps int32 cells. */
+ * On the device the batch is solved on the 16-bit cells themselves where the kernels with that I/O take it
+ * (kas_plan_create16 below); any other batch is widened before and narrowed behind an int32 solve (two streaming kernels on
+ * the range's solve stream). */
 #define KAS_CELL16_NONE 0xFFFFu
 typedef struct kas_tables16 {
   const uint16_t* cur;                  /* cur pool, node indices                            */
@@ -287,6 +288,16 @@ typedef struct kas_tables16 {
 } kas_tables16;
 int kas_solve_host16(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables16* host_tables,
                      const int32_t* select, int32_t n_select);
+
+/* The device-resident form of the same layout: a plan whose solves read and write 16-bit cells in HBM.  The fill kernel
+ * then streams 2 bytes a cell instead of 4, the order kernel stores a final row's node indices as they are (no gather of
+ * broker ids) over the mid row the row was made from, so a topic's out region is all the scratch its rows need:
+ * 6 + 6 instead of 12 + 12 bytes of table traffic per row of three replicas.  Served by the kernels of lists up to 3 wide
+ * (fill kernel, kas_p4_kernel, relaxation and round forms of the order kernel): any other batch — lists 4 and more wide —
+ * is KAS_E_UNSUPPORTED here, and kas_solve_host16 widens such a batch on the device instead.  batch->node_id is not read; tables as kas_solve_device's, cells as kas_solve_host16's;
+ * kas_plan_set_flags: no ticket form (KAS_PLAN_TICKET_ORDER takes the round form) and no KAS_PLAN_VERIFY_SAMPLE. */
+int kas_plan_create16(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan);
+int kas_solve_device16(kas_plan* plan, const kas_tables16* device_tables, void* hip_stream);
 
 /* Pinned host memory for table pools (DMA without staging: see kas_solve_host).  A JNI caller wraps
  * it with NewDirectByteBuffer, a Python caller with numpy.frombuffer. */

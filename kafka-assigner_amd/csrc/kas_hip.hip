@@ -140,17 +140,18 @@ __global__ __launch_bounds__(256) void kas_lds_order_selftest_kernel(unsigned in
 // (DUAL: the instance with double tiles, kas_relax_double_tiles)
 // (CTX: the instance for batches in which some scenario hands a Context in or wants it back)
 // (VERIFY: the instances for plans with KAS_PLAN_VERIFY_SAMPLE)
-template <int W, bool DUAL, bool CTX, bool VERIFY = false>
+// (C16: the instances for plans with 16-bit cells, kas_plan_create16)
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX, VERIFY>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY, C16>(a, (int32_t)blockIdx.x, kas_lds);
 }
-template <bool VERIFY>
+template <bool VERIFY, bool C16 = false>
 static void (*kas_order_relax_pick(int Wc, int dual, int ctx))(KasLaunch) {
-  if (Wc <= 2) return ctx ? kas_order_relax_kernel<2, false, true, VERIFY> : kas_order_relax_kernel<2, false, false, VERIFY>;   // (double tiles are rows of three holders)
+  if (Wc <= 2) return ctx ? kas_order_relax_kernel<2, false, true, VERIFY, C16> : kas_order_relax_kernel<2, false, false, VERIFY, C16>;   // (double tiles are rows of three holders)
   if (Wc == 3) {
-    if (ctx) return dual ? kas_order_relax_kernel<3, true, true, VERIFY> : kas_order_relax_kernel<3, false, true, VERIFY>;
-    return dual ? kas_order_relax_kernel<3, true, false, VERIFY> : kas_order_relax_kernel<3, false, false, VERIFY>;
+    if (ctx) return dual ? kas_order_relax_kernel<3, true, true, VERIFY, C16> : kas_order_relax_kernel<3, false, true, VERIFY, C16>;
+    return dual ? kas_order_relax_kernel<3, true, false, VERIFY, C16> : kas_order_relax_kernel<3, false, false, VERIFY, C16>;
   }
   return nullptr;
 }
@@ -220,7 +221,8 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
 }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
 static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
-static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx, int verify = 0) {
+static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx, int verify = 0, int c16 = 0) {
+  if (c16) return verify ? nullptr : kas_order_relax_pick<false, true>(3, dual, ctx);
   return verify ? kas_order_relax_pick<true>(3, dual, ctx) : kas_order_relax_pick<false>(3, dual, ctx);
 }
 static KasSpreadKernels kas_spread_for(int) { return KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
@@ -278,7 +280,8 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
 static kas_kernel_fn kas_order_wide_for(int Wc) {
   return Wc == 4 ? kas_order_wide_kernel<4> : kas_order_wide_kernel<5>;
 }
-static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx, int verify = 0) {
+static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx, int verify = 0, int c16 = 0) {
+  if (c16) return verify ? nullptr : kas_order_relax_pick<false, true>(Wc, dual, ctx);
   return verify ? kas_order_relax_pick<true>(Wc, dual, ctx) : kas_order_relax_pick<false>(Wc, dual, ctx);
 }
 static KasSpreadKernels kas_spread_for(int Wc) {
@@ -370,6 +373,7 @@ struct kas_plan {
          b_ord_flag, b_sp_hist, b_sp_quota, b_sp_node, b_sp_flag, b_sp_oc, b_p4s;
   uint64_t* allocs;             // allocation counter to report to (the context's, or NULL)
   int single_topic;             // every scenario has exactly one topic
+  int cells16;                  // kas_plan_create16: cur / out cells are uint16 node indices (KAS_FLAG_CELLS16 in every launch)
   int32_t sp_alloc_chunks;      // chunks per scenario the spread-fill scratch is sized for
   hipStream_t last_stream;
   int last_slot;                // timer slot of the most recent solve (-1: none yet)
@@ -553,8 +557,8 @@ static int kas_plan_set_kernels(kas_plan* p) {
                                       kas_order_ticket_lds(p->shape.n_max, p->G, pk) + KAS_TUNE_ORDER_LDS_PAD));
   for (int dual = 0; dual < 2; ++dual)
     for (int verify = 0; verify < 2; ++verify)
-      if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify))
-        KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify),
+      if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16))
+        KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx)));
   if (p->shape.with_x && kas_p4_lds_layout(p->shape.n_max).total <= KAS_LDS_LIMIT)
@@ -588,6 +592,7 @@ static bool kas_plan_fused(const kas_plan* p) {
 
 // chunks per scenario of the spread fill for this plan's next solve, or 0 (one-workgroup fill kernel)
 static int32_t kas_plan_spread_chunks(const kas_plan* p) {
+  if (p->cells16) return 0;                                  // (the spread fill's kernels read int32 cells)
   if (p->NW != 4 || !kas_spread_for(p->Wc).a || (p->flags & KAS_FLAG_GENERIC_FILL)) return 0;
   // (the quota kernel puts scenarios on grid.y and nodes on grid.x)
   if (p->shape.n_max <= 0 || p->n_scenarios > 65535) return 0;
@@ -640,6 +645,13 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   // some order kernel must be able to take the batch HERE: beyond 8,191 brokers at lists <= 3 wide that is the relaxation
   // form alone, which needs the LDS lane order the context's self-test looks for (such a plan used to fail at its
   // first solve with a launch error)
+  if (p->cells16) {
+    // 16-bit cells (kas_plan_create16): the kernels with that I/O are the fill kernel (+ kas_p4_kernel), the relaxation form
+    // and the round form — lists up to 3 wide; anything else is the caller's to widen (kas_solve_host16 does)
+    const bool relax16 = sh.relax_ok && ctx->lds_lane_order_ok && kas_order_relax_for(sh.Wc, 0, 0, 0, 1) != nullptr;
+    if (sh.Wc > 3 || !(relax16 || sh.round_fits))
+      return set_error(KAS_E_UNSUPPORTED, "16-bit cells: lists up to 3 wide, and a batch the relaxation form (LDS lane-order self-test passed) or the round form of the order kernel takes");
+  }
   {
     const bool relax_here = sh.relax_ok && ctx->lds_lane_order_ok && kas_order_relax_for(sh.Wc, 0, 0) != nullptr;
     if (!sh.round_fits && !sh.tickets_ok && !sh.wide_ok && !relax_here)
@@ -683,9 +695,10 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   return KAS_E_OK;
 }
 
-static int kas_plan_new(kas_ctx* ctx, const kas_batch_desc* batch, uint64_t* allocs, kas_plan** out_plan) {
+static int kas_plan_new(kas_ctx* ctx, const kas_batch_desc* batch, uint64_t* allocs, kas_plan** out_plan, int cells16 = 0) {
   *out_plan = nullptr;
   kas_plan* p = new kas_plan();
+  p->cells16 = cells16;
   memset((void*)p->ev_start, 0, sizeof(p->ev_start));
   memset((void*)p->ev_stop, 0, sizeof(p->ev_stop));
   memset((void*)p->ev_mid, 0, sizeof(p->ev_mid));
@@ -715,6 +728,33 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   return kas_plan_new(ctx, batch, nullptr, out_plan);
 }
 
+// 16-bit cells are node indices: the node table the kernels see gives node i the id i (`ids` holds it, `out` = *b with it)
+static int kas_ident_batch(const kas_batch_desc* b, std::vector<int32_t>* ids, kas_batch_desc* out) {
+  if (b->n_scenarios < 0 || b->node_pool_len < 0 || (b->n_scenarios > 0 && !b->scenarios))
+    return set_error(KAS_E_INVALID_ARG, "negative size / scenarios == NULL");
+  ids->assign((size_t)b->node_pool_len, 0);
+  for (int32_t s = 0; s < b->n_scenarios; ++s) {
+    const kas_scenario_desc& sd = b->scenarios[s];
+    if (sd.n_nodes < 0 || sd.node_off < 0 || sd.node_off + sd.n_nodes > b->node_pool_len)
+      return set_error(KAS_E_INVALID_ARG, "scenario " + std::to_string(s) + ": node table outside the node pool");
+    if (sd.n_nodes > 65535)
+      return set_error(KAS_E_UNSUPPORTED, "scenario " + std::to_string(s) + ": more than 65,535 brokers do not fit 16-bit cells");
+    for (int32_t i = 0; i < sd.n_nodes; ++i) (*ids)[(size_t)(sd.node_off + i)] = i;
+  }
+  *out = *b;
+  out->node_id = ids->data();
+  return KAS_E_OK;
+}
+
+int kas_plan_create16(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan) {
+  if (!ctx || !batch || !out_plan) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  std::vector<int32_t> ids;
+  kas_batch_desc ib;
+  const int rc = kas_ident_batch(batch, &ids, &ib);
+  if (rc != KAS_E_OK) return rc;
+  return kas_plan_new(ctx, &ib, nullptr, out_plan, 1);
+}
+
 // the launch decisions of kas_solve_device, in one place
 struct KasLaunchPlan {
   bool relax;                   // relaxation form of P5 (then neither tickets nor wide)
@@ -727,10 +767,10 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   KasLaunchPlan lp;
   lp.relax = p->shape.relax_ok && p->ctx->lds_lane_order_ok && kas_order_relax_for(p->Wc, 0, 0) != nullptr &&
              !(p->flags & KAS_FLAG_ROUND_ORDER) && !(kas_flags_want_tickets(p->flags) && p->tickets);
-  lp.tickets = !lp.relax && p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER);
+  lp.tickets = !lp.relax && p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER) && !p->cells16;   // (no ticket form with 16-bit cells: the round form)
   lp.packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
   lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G;
-  lp.wide = !lp.tickets && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
+  lp.wide = !lp.tickets && !p->cells16 && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
   lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD;
   if (lp.relax) {
@@ -794,9 +834,9 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (kas_plan_split_p4(p))                                    // first fit (P4) is a launch of its own between the two
     snprintf(p4, sizeof(p4), " + kas_p4_kernel<%d> grid=%ux%u lds=%zu", p->Wc, (unsigned)p->n_scenarios, 64u * KAS_P4_KERNEL_WAVES,
              (size_t)kas_p4_lds_layout(p->shape.n_max).total);
-  const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s%s + %s", spread, p->Wc, p->NW,
+  const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s%s + %s%s", spread, p->Wc, p->NW,
                            generic ? "sweeps" : (kas_plan_fused(p) ? "quota, chunk histograms" : "quota"), lp.fill_grid,
-                           lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", p4, order);
+                           lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", p4, order, p->cells16 ? " [16-bit cells]" : "");
   return len < n ? len : n - 1;
 }
 
@@ -804,8 +844,26 @@ int64_t kas_plan_algorithmic_bytes(const kas_plan* plan) {
   return plan ? plan->shape.algorithmic_bytes : -1;
 }
 
+static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_stream);
+
 int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   if (!p || !t) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  if (p->cells16) return set_error(KAS_E_INVALID_ARG, "a plan of kas_plan_create16 is solved by kas_solve_device16");
+  return kas_solve_device_impl(p, t, hip_stream);
+}
+
+int kas_solve_device16(kas_plan* p, const kas_tables16* t16, void* hip_stream) {
+  if (!p || !t16) return set_error(KAS_E_INVALID_ARG, "NULL argument");
+  if (!p->cells16) return set_error(KAS_E_INVALID_ARG, "kas_solve_device16 needs a plan of kas_plan_create16");
+  kas_tables t;                                              // (the kernels take the cell width from KAS_FLAG_CELLS16)
+  memset(&t, 0, sizeof(t));
+  t.cur = reinterpret_cast<const int32_t*>(t16->cur); t.out = reinterpret_cast<int32_t*>(t16->out);
+  t.aux = t16->aux; t.ctx = t16->ctx; t.topic_results = t16->topic_results; t.scenario_results = t16->scenario_results;
+  t.cur_len = t16->cur_len; t.out_len = t16->out_len; t.aux_len = t16->aux_len; t.ctx_len = t16->ctx_len;
+  return kas_solve_device_impl(p, &t, hip_stream);
+}
+
+static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_stream) {
   if (p->n_scenarios == 0) return KAS_E_OK;
   if (!t->out || !t->topic_results || !t->scenario_results || (p->shape.cur_need > 0 && !t->cur) ||
       (p->shape.aux_need > 0 && !t->aux) || (p->shape.ctx_need > 0 && !t->ctx))
@@ -831,7 +889,8 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   a.flags = (p->flags & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ORDER_FLAGGED | KAS_FLAG_WIDE_CHECK)) | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL) |
             (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u) |
             (kas_relax_double_tiles(p->flags, p->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
-            ((p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA)) ? KAS_FLAG_LANE_ORDER : 0u);
+            ((p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA)) ? KAS_FLAG_LANE_ORDER : 0u) |
+            (p->cells16 ? KAS_FLAG_CELLS16 : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
   const bool split_p4 = kas_plan_split_p4(p);
@@ -897,7 +956,7 @@ int kas_solve_device(kas_plan* p, const kas_tables* t, void* hip_stream) {
   else
 #endif
   if (lp.relax)
-    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u, p->cells16), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
                        lp.order_lds, st, a);
@@ -970,6 +1029,10 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
   if ((flags & KAS_FLAG_ROUND_ORDER) && !p->shape.round_fits)
     return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_ROUND_ORDER: the round form's LDS exceeds 160 KiB at this broker count x width");
+  if (p->cells16 && (flags >> 24) != 0u)
+    return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_VERIFY_SAMPLE: not instantiated for plans with 16-bit cells");
+  if (p->cells16 && kas_flags_want_tickets(flags) && !p->shape.round_fits)
+    return set_error(KAS_E_UNSUPPORTED, "16-bit cells: no ticket form; the round form it would take does not fit at this broker count");
   if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))   // (every check before anything is changed)
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_RELAX_TILES: 0 (by batch size), 1 (64 rows) or 2 (double tiles)");
   if (!kas_minimal_ok(p->Wc, nw ? nw : p->NW, g ? g : p->G))
@@ -1116,7 +1179,7 @@ static uint64_t kas_hash64(uint64_t h, const void* data, size_t n) {
 
 // The plan of this batch from the context's cache: the one whose descriptors and node tables are the
 // same byte for byte, else the least recently used entry rebuilt in place (or a new one into a free entry).
-static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_plan) {
+static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_plan, int cells16 = 0) {
   *out_plan = nullptr;
   if (b->n_scenarios < 0 || b->n_topics < 0 || b->node_pool_len < 0 ||
       (b->n_scenarios > 0 && !b->scenarios) || (b->n_topics > 0 && !b->topics) ||
@@ -1126,7 +1189,7 @@ static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_p
                nb = sizeof(int32_t) * (size_t)b->node_pool_len;
   // what identifies the batch: (S, T, node pool length), scenario and topic descriptors, node tables — hashed and
   // compared where they lie; a copy is made only when a plan is built for them
-  int64_t hdr[2] = {((int64_t)b->n_scenarios << 32) | (uint32_t)b->n_topics, b->node_pool_len};
+  int64_t hdr[2] = {((int64_t)b->n_scenarios << 32) | (uint32_t)b->n_topics, b->node_pool_len | ((int64_t)(cells16 ? 1 : 0) << 62)};   // (a plan for 16-bit cells is another plan)
   const void* seg[5] = {hdr, b->scenarios, b->topics, b->node_id, b->node_rack};
   const size_t seg_bytes[5] = {16, sb, tb, nb, nb};
   const size_t desc_bytes = 16 + sb + tb + 2 * nb;
@@ -1164,11 +1227,12 @@ static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_p
   if (!victim) return set_error(KAS_E_NOMEM, "host-path plan cache exhausted by one call");
   int rc;
   if (victim->plan) {
+    victim->plan->cells16 = cells16;
     rc = kas_plan_build(victim->plan, b);                      // in place: its buffers are reused where they are large enough
     if (rc != KAS_E_OK) { kas_plan_destroy(victim->plan); victim->plan = nullptr; victim->desc.clear(); victim->sig = 0; return rc; }
   } else {
     kas_plan* plan = nullptr;
-    rc = kas_plan_new(ctx, b, &ctx->host_allocs, &plan);
+    rc = kas_plan_new(ctx, b, &ctx->host_allocs, &plan, cells16);
     if (rc != KAS_E_OK) return rc;
     victim->plan = plan;
   }
@@ -1323,19 +1387,8 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   // 16-bit cells are node indices: the node table the kernels see gives node i the id i (h->cur / h->out are unused)
   kas_batch_desc ident_batch;
   if (c16) {
-    if (batch->n_scenarios < 0 || batch->node_pool_len < 0 || (batch->n_scenarios > 0 && !batch->scenarios))
-      return set_error(KAS_E_INVALID_ARG, "negative size / scenarios == NULL");
-    ctx->ident_ids.assign((size_t)batch->node_pool_len, 0);
-    for (int32_t s = 0; s < batch->n_scenarios; ++s) {
-      const kas_scenario_desc& sd = batch->scenarios[s];
-      if (sd.n_nodes < 0 || sd.node_off < 0 || sd.node_off + sd.n_nodes > batch->node_pool_len)
-        return set_error(KAS_E_INVALID_ARG, "scenario " + std::to_string(s) + ": node table outside the node pool");
-      if (sd.n_nodes > 65535)
-        return set_error(KAS_E_UNSUPPORTED, "scenario " + std::to_string(s) + ": more than 65,535 brokers do not fit 16-bit cells");
-      for (int32_t i = 0; i < sd.n_nodes; ++i) ctx->ident_ids[(size_t)(sd.node_off + i)] = i;
-    }
-    ident_batch = *batch;
-    ident_batch.node_id = ctx->ident_ids.data();
+    const int irc = kas_ident_batch(batch, &ctx->ident_ids, &ident_batch);
+    if (irc != KAS_E_OK) return irc;
     batch = &ident_batch;
   }
   const size_t cell = c16 ? sizeof(uint16_t) : sizeof(int32_t);     // bytes of a cur / out cell as it travels
@@ -1443,8 +1496,17 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     if (ok) break;
     K = 1;                                                     // shared or interleaved tables: one range
   }
-  for (KasChain& c : chains)
-    if ((rc = kas_host_plan(ctx, &c.bd, &c.plan)) != KAS_E_OK) return rc;
+  // A 16-bit call is solved on its 16-bit cells where the kernels with that I/O take the batch (kas_plan_create16's
+  // plans: lists up to 3 wide, relaxation form); any other batch is widened before and narrowed behind an int32 solve.
+  bool native16 = c16 != nullptr;
+  for (KasChain& c : chains) {
+    rc = kas_host_plan(ctx, &c.bd, &c.plan, native16 ? 1 : 0);
+    if (rc == KAS_E_UNSUPPORTED && native16) { native16 = false; break; }
+    if (rc != KAS_E_OK) return rc;
+  }
+  if (c16 && !native16)
+    for (KasChain& c : chains)
+      if ((rc = kas_host_plan(ctx, &c.bd, &c.plan, 0)) != KAS_E_OK) return rc;
 
   // ---- enqueue.  From here on every exit drains the streams first.
   if ((rc = kas_host_solve_streams(ctx, K > 1 ? K : 1)) != KAS_E_OK) return rc;
@@ -1500,7 +1562,7 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
       hip_ok(hipStreamWaitEvent(st, ctx->hev_up[i], 0), "wait");
     }
     if (he != hipSuccess) break;
-    if (c16 && c.cur_hi > c.cur_lo) {                          // (on the range's solve stream: the copy streams only copy)
+    if (c16 && !native16 && c.cur_hi > c.cur_lo) {             // (on the range's solve stream: the copy streams only copy)
       const int64_t n = c.cur_hi - c.cur_lo;
       hipLaunchKernelGGL(kas_cells_widen_kernel, dim3(kas_cells_grid(n)), dim3(256), 0, st, d_cur16 + c.cur_lo, d_cur + c.cur_lo, n);
       if (!hip_ok(hipGetLastError(), "kas_cells_widen_kernel")) break;
@@ -1509,9 +1571,10 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     memset(&d, 0, sizeof(d));
     d.cur = d_cur; d.out = d_out; d.aux = d_aux; d.ctx = d_ctx;
     d.topic_results = d_tr + c.tlo; d.scenario_results = d_sr + c.lo;
-    const int src = kas_solve_device(c.plan, &d, st);
+    if (native16) { d.cur = reinterpret_cast<const int32_t*>(d_cur16); d.out = reinterpret_cast<int32_t*>(d_out16); }
+    const int src = kas_solve_device_impl(c.plan, &d, st);
     if (src != KAS_E_OK) { fail_rc = src; break; }
-    if (c16 && all_rows && c.out_hi > c.out_lo) {
+    if (c16 && !native16 && all_rows && c.out_hi > c.out_lo) {
       const int64_t n = c.out_hi - c.out_lo;
       // (into the staging buffer, not into the caller's pinned pool: the kernel's stores over the link ran at 20 GB/s —
       // a call of 240 scenarios 10.5 ms against 8.4 ms with the copy engine, experiments/README.md)
@@ -1539,8 +1602,10 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
         const kas_topic_desc& td = batch->topics[sd.topic_begin + t];
         const int64_t cells = (int64_t)td.n_partitions * td.out_width;
         if (cells > 0 && c16) {
-          hipLaunchKernelGGL(kas_cells_narrow_kernel, dim3(kas_cells_grid(cells)), dim3(256), 0, s0, d_out + td.out_off, d_out16 + td.out_off, cells);
-          hip_ok(hipGetLastError(), "kas_cells_narrow_kernel");
+          if (!native16) {
+            hipLaunchKernelGGL(kas_cells_narrow_kernel, dim3(kas_cells_grid(cells)), dim3(256), 0, s0, d_out + td.out_off, d_out16 + td.out_off, cells);
+            hip_ok(hipGetLastError(), "kas_cells_narrow_kernel");
+          }
           hip_ok(hipMemcpyAsync(c16->out + at, d_out16 + td.out_off, 2 * (size_t)cells, hipMemcpyDeviceToHost, s0), "download selected rows");
         } else if (cells > 0)
           hip_ok(hipMemcpyAsync(h->out + at, d_out + td.out_off, 4 * (size_t)cells, hipMemcpyDeviceToHost, s0), "download selected rows");

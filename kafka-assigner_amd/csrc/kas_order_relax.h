@@ -228,9 +228,10 @@ KAS_DEV MidRaw<W> mid_take(const MidRaw<W>& r, int32_t ow, bool active) {
   return o;
 }
 
-// the pending rows go out (one 12-byte store each); returns their digest
-template <int NB>
-KAS_DEV uint64_t relax_flush(RelaxPend<NB>& pend, int32_t* out, uint32_t k) {
+// the pending rows go out (one 12-byte store each; C16, 16-bit cells: 6 bytes, in the place of the mid row they were made
+// from); returns their digest
+template <int NB, bool C16 = false>
+KAS_DEV uint64_t relax_flush(RelaxPend<NB>& pend, int32_t* out, uint16_t* out16, uint32_t k) {
   uint64_t d = 0;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -242,7 +243,13 @@ KAS_DEV uint64_t relax_flush(RelaxPend<NB>& pend, int32_t* out, uint32_t k) {
         d += kas_digest_cell(k, (uint32_t)(pend.p + 64 * b), (uint32_t)q, o.v[q]);
       }
 #if !defined(KAS_TUNE_NO_ROW_STORES)                          // (tuning builds: the mid rows stay, the kernel can run again)
-      *reinterpret_cast<RowW<3>*>(out + (int64_t)(pend.p + 64 * b) * 3) = o;
+      if constexpr (C16) {
+        uint16_t* row = out16 + (int64_t)(pend.p + 64 * b) * 3;
+        store_u32_a2(row, (uint32_t)o.v[0] | ((uint32_t)o.v[1] << 16));
+        row[2] = (uint16_t)o.v[2];
+      } else {
+        *reinterpret_cast<RowW<3>*>(out + (int64_t)(pend.p + 64 * b) * 3) = o;
+      }
 #endif
     }
   }
@@ -289,9 +296,12 @@ KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, uint32_t w0_cells, uint32_t w1
 // VERIFY: the instances for plans that ask for the sampled verification (KAS_PLAN_VERIFY_SAMPLE) — kernels of their own because
 // the second evaluation keeps a tile's addresses and addends alive behind its loop: 67 instead of 60 vector registers for
 // the instance with tiles of 64 rows, one register-file slot more than two of its wavefronts may take beside a fill wavefront
-template <int W, bool DUAL, bool CTX, bool VERIFY = false>
+// C16: the instances for plans with 16-bit cells (KAS_FLAG_CELLS16): a final row is its node indices — no broker ids to ask
+// for, nothing to wait for before the row goes out — stored over the mid row it was made from
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
+  static_assert(!(VERIFY && C16), "the sampled verification is not instantiated for 16-bit cells");
   if constexpr (KAS_RELAX_PRIO > 0) kasw::set_priority<KAS_RELAX_PRIO>();
   const int lane = kasw::lane();
   const kas_scenario_desc sd = a.scen[s];
@@ -364,8 +374,9 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     const kas_topic_desc td = a.topics[ti];
     const int32_t P = td.n_partitions, ow = td.out_width;
     if (P <= 0) continue;
-    int32_t* out = a.out + td.out_off;
-    const uint16_t* mid = mid_base(out, P, ow);
+    int32_t* out = C16 ? nullptr : a.out + td.out_off;
+    uint16_t* out16 = C16 ? reinterpret_cast<uint16_t*>(a.out) + td.out_off : nullptr;
+    const uint16_t* mid = C16 ? out16 : mid_base(out, P, ow);
     const RelaxTopic rt = relax_topic(td.name_hash);
     const int32_t nt = (P + 63) >> 6;
     // the topic's tags by the order of a row's cells: bit 0 = cell 0 < cell 1, bit 1 = cell 0 < cell 2, bit 2 = cell 1 <
@@ -578,9 +589,10 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
               for (int r = 0; r < W; ++r) {
                 if (r < ow) {
                   const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
-                  const int32_t id = r < Lp ? g_node_id[cell] : -1;
+                  const int32_t id = r < Lp ? (C16 ? (int32_t)cell : g_node_id[cell]) : -1;
                   if constexpr (CTX) { if (r == 2 && r < Lp) kasw::lds_add_u32(cnt2 + cell, 1u); }
-                  out[(int64_t)p * ow + r] = id;
+                  if constexpr (C16) out16[(int64_t)p * ow + r] = (uint16_t)id;
+                  else out[(int64_t)p * ow + r] = id;
                   if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
                 }
               }
@@ -608,14 +620,17 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
           }
         }
         // the previous step's final rows go out,
-        digest += relax_flush<NB>(pend, out, (uint32_t)k);
+        digest += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
         // and the requests are made: the broker ids of this step's final rows, the mid rows two steps on
         // (every in-flight register has ONE requesting statement, executed on every path: a step without final rows of
         // its own asks for node 0's id, a single-tile step of the double-tile instance asks for a tile it had already)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) kasw::gload_u32_async<0>(pend.id[b][q], uid, req_l[b][q] << 2);
+          for (int q = 0; q < 3; ++q) {
+            if constexpr (C16) pend.id[b][q] = req_l[b][q];           // (the cell IS the node index)
+            else kasw::gload_u32_async<0>(pend.id[b][q], uid, req_l[b][q] << 2);
+          }
         pend.p = p; pend.n = req_n;
         // The instance with tiles of 64 rows — launches that fill the GPU with wavefronts — sends the final rows out in the
         // step that decided them: it waits for the broker ids here, where the other wavefronts of the SIMD have work to
@@ -623,12 +638,14 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
         // flight 588k -> 620k scenarios/s, 4000 x 3 590k -> 630k, 1000 x 8 605k -> 614k), while a batch alone gains 15 %
         // from them (order kernel 1.79 -> 1.51 ms) — and a batch alone is what the double-tile instance is launched for.
         if constexpr (!DUAL) {
-          kasw::wait_loads();
+          if constexpr (!C16) {
+            kasw::wait_loads();
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
-          digest += relax_flush<NB>(pend, out, (uint32_t)k);
+              for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
+          }
+          digest += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) request_tile(nx[b], tile + NB + b);
@@ -642,7 +659,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
         for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
       }
-      digest += relax_flush<NB>(pend, out, (uint32_t)k);
+      digest += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
     };
     if (ow == W) topic_rows(std::true_type{});
     else topic_rows(std::false_type{});

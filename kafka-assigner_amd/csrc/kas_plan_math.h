@@ -63,6 +63,8 @@ struct KasLaunch {
 #define KAS_FLAG_SPREAD_FILL  32u  // spread fill also for small scenarios, with few chunks (testing / comparison)
 #define KAS_FLAG_ONLY_FLAGGED 64u  // set by the launcher: the fill kernel takes only the scenarios the spread fill handed back
 #define KAS_FLAG_ORDER_FLAGGED 128u // set by the launcher: the round-form order kernel takes only scenarios with ord_flag set
+#define KAS_FLAG_CELLS16      512u  // set by the launcher (plans of kas_plan_create16, ABI v5): cur / out cells are uint16 node indices (node i has id i),
+                                   // out rows take the place of the mid rows they are made from
 #define KAS_FLAG_WIDE_CHECK   256u  // set by the launcher (KasShape::wide_checked): the wide ticket form checks its count fields at the end
 #define KAS_FLAG_TICKET_ORDER 0x10000u // lists <= 3 wide: the ticket form of P5 where the relaxation form would run (testing / comparison);
                                        // KAS_PLAN_GROUPS(n) and KAS_PLAN_WIDE_COUNTERS, which only mean something to the ticket form, imply it

@@ -362,6 +362,39 @@ KAS_DEV uint16_t* mid_base(int32_t* out, int32_t P, int32_t ow) {
 }
 KAS_DEV int32_t mid_to_index(uint32_t v) { return (v & 0x8000u) ? -1 : (int32_t)v; }   // (bit 15: KAS_MID_NONE — a node index is below 32768)
 
+// ---- cells of the cur / out tables: int32 broker ids, or — KAS_FLAG_CELLS16, the plans of kas_plan_create16 (ABI v5) —
+// uint16 node indices (0xFFFF: no such broker / pad; node i has id i).  With 16-bit cells a topic's out region is exactly
+// its mid rows' size (ow cells of 2 bytes a row): final row p takes the place of mid row p, which every order kernel has
+// read before it writes the row.
+KAS_DEV bool cells16(const KasLaunch& a) { return (a.flags & KAS_FLAG_CELLS16) != 0u; }
+struct OutRef {
+  int32_t* o32;          // int32 cells (nullptr with 16-bit cells)
+  uint16_t* o16;         // uint16 cells
+};
+KAS_DEV OutRef topic_out(const KasLaunch& a, const kas_topic_desc& td) {
+  OutRef o;
+  o.o32 = cells16(a) ? nullptr : a.out + td.out_off;
+  o.o16 = cells16(a) ? reinterpret_cast<uint16_t*>(a.out) + td.out_off : nullptr;
+  return o;
+}
+KAS_DEV void out_store(const OutRef& o, int64_t cell, int32_t v) {   // v: broker id / node index, or -1 = pad
+  if (o.o16) o.o16[cell] = (uint16_t)v;                               // (-1 -> 0xFFFF)
+  else o.o32[cell] = v;
+}
+KAS_DEV void out_pad(const OutRef& o, int64_t cells, int32_t first, int32_t step) {   // a topic that returns nothing: all padding
+  if (o.o16) { for (int64_t i = first; i < cells; i += step) o.o16[i] = (uint16_t)0xffffu; }
+  else { for (int64_t i = first; i < cells; i += step) o.o32[i] = -1; }
+}
+KAS_DEV uint16_t* topic_mid(const KasLaunch& a, const kas_topic_desc& td) {
+  if (cells16(a)) return reinterpret_cast<uint16_t*>(a.out) + td.out_off;
+  return mid_base(a.out + td.out_off, td.n_partitions, td.out_width);
+}
+// the topic's cur rows: for 16-bit cells the pointer is only a byte address (2-byte aligned), read through load_row / cur_cell
+KAS_DEV const int32_t* topic_cur(const KasLaunch& a, const kas_topic_desc& td) {
+  if (cells16(a)) return reinterpret_cast<const int32_t*>(reinterpret_cast<const uint16_t*>(a.cur) + td.cur_off);
+  return a.cur + td.cur_off;
+}
+
 // One mid row, as loaded: nothing is computed from the loaded values here, so a row read ahead of its
 // use (every consumer prefetches) does not make the wave wait for the load where it is issued.
 // Rows of the template width (ow == W) come as W / 2 dwords and, W odd, one halfword (w[k] = cells 2 k, 2 k + 1; the
@@ -400,6 +433,7 @@ KAS_DEV void mid_unpack(const MidRaw<W>& raw, int32_t ow, int32_t (&c)[W]) {
 
 // Everything a phase needs to know about the topic being solved.
 struct TopicView {
+  bool c16;             // cells of cur are uint16 node indices (KAS_FLAG_CELLS16)
   const int32_t* cur;
   uint16_t* mid;        // mid rows of the topic (at the end of its out region); mid_width(ow) uint16 each
   int32_t* orph;        // orphan row lists of this scenario (HBM scratch)
@@ -416,18 +450,35 @@ struct TopicView {
 template <int W>
 struct RowW { int32_t v[W]; };
 
-template <int W, bool FULL = false>
+// C16: the cells are uint16 node indices (a full row: the packed 2 W bytes of a mid row, read the same way)
+KAS_DEV int32_t cur_cell(const TopicView& T, int64_t cell) {
+  if (T.c16) return mid_to_index((uint32_t)reinterpret_cast<const uint16_t*>(T.cur)[cell]);
+  return T.cur[cell];
+}
+template <int W, bool FULL = false, bool C16 = false>
 KAS_DEV void load_row(const TopicView& T, int32_t p, int32_t (&ids)[W], int32_t& len) {
   const bool active = p < T.P;
   if constexpr (FULL) {
     const int32_t pc = active ? p : (T.P > 0 ? T.P - 1 : 0);
-    const RowW<W> q = *reinterpret_cast<const RowW<W>*>(T.cur + (int64_t)pc * W);
+    if constexpr (C16) {
+      static_assert(!KAS_MID_PAD, "16-bit cells: rows are packed");
+      const MidRaw<W> q = mid_load_raw<W>(reinterpret_cast<const uint16_t*>(T.cur), W, pc, true);
+      mid_unpack<W>(q, W, ids);
+    } else {
+      const RowW<W> q = *reinterpret_cast<const RowW<W>*>(T.cur + (int64_t)pc * W);
 #pragma unroll
-    for (int r = 0; r < W; ++r) ids[r] = q.v[r];
+      for (int r = 0; r < W; ++r) ids[r] = q.v[r];
+    }
     len = active ? W : 0;
   } else {
+    if constexpr (C16) {
+      const uint16_t* c = reinterpret_cast<const uint16_t*>(T.cur);
 #pragma unroll
-    for (int r = 0; r < W; ++r) ids[r] = (active && r < T.cw) ? T.cur[(int64_t)p * T.cw + r] : -1;
+      for (int r = 0; r < W; ++r) ids[r] = (active && r < T.cw) ? mid_to_index((uint32_t)c[(int64_t)p * T.cw + r]) : -1;
+    } else {
+#pragma unroll
+      for (int r = 0; r < W; ++r) ids[r] = (active && r < T.cw) ? T.cur[(int64_t)p * T.cw + r] : -1;
+    }
     len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
   }
 }
@@ -442,13 +493,13 @@ KAS_DEV bool full_rows_of(const TopicView& T) { return T.cw == W && T.ow == W &&
 #ifndef KAS_TILES_AHEAD
 #define KAS_TILES_AHEAD 4
 #endif
-template <int W, bool FULL, typename Body>
+template <int W, bool FULL, bool C16, typename Body>
 KAS_DEV void for_tiles_impl(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
   constexpr int D = KAS_TILES_AHEAD;
   const int lane = kasw::lane();
   int32_t nx[D][W], nlen[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) load_row<W, FULL>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
+  for (int d = 0; d < D; ++d) load_row<W, FULL, C16>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
   for (int32_t tile = tile0; tile < t_end; tile += stride * D) {
     int32_t ids[D][W], len[D];
 #pragma unroll
@@ -459,7 +510,7 @@ KAS_DEV void for_tiles_impl(const TopicView& T, int32_t tile0, int32_t stride, i
     }
 #pragma unroll
     for (int d = 0; d < D; ++d)                              // request the next batch
-      load_row<W, FULL>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
+      load_row<W, FULL, C16>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int32_t t = tile + d * stride;
@@ -471,13 +522,13 @@ KAS_DEV void for_tiles_impl(const TopicView& T, int32_t tile0, int32_t stride, i
 // Same stream, but `body(ids[D][W], len[D])` gets KAS_TILES_AHEAD tiles at once (len = 0 for
 // rows / tiles past the end): for passes whose tiles do not depend on each other, so that the
 // LDS lookups of the four tiles overlap instead of forming four serial chains.
-template <int W, bool FULL, typename Body>
+template <int W, bool FULL, bool C16, typename Body>
 KAS_DEV void for_tile_batches_impl(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
   constexpr int D = KAS_TILES_AHEAD;
   const int lane = kasw::lane();
   int32_t nx[D][W], nlen[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) load_row<W, FULL>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
+  for (int d = 0; d < D; ++d) load_row<W, FULL, C16>(T, ((tile0 + d * stride) << 6) + lane, nx[d], nlen[d]);
   for (int32_t tile = tile0; tile < t_end; tile += stride * D) {
     int32_t ids[D][W], len[D];
 #pragma unroll
@@ -488,7 +539,7 @@ KAS_DEV void for_tile_batches_impl(const TopicView& T, int32_t tile0, int32_t st
     }
 #pragma unroll
     for (int d = 0; d < D; ++d)
-      load_row<W, FULL>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
+      load_row<W, FULL, C16>(T, ((tile + (D + d) * stride) << 6) + lane, nx[d], nlen[d]);
     body(ids, len);
   }
 }
@@ -498,14 +549,24 @@ KAS_DEV bool full_rows(const TopicView& T) { return full_rows_of<W>(T); }
 
 template <int W, typename Body>
 KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
-  if (full_rows<W>(T)) for_tiles_impl<W, true>(T, tile0, stride, t_end, body);
-  else for_tiles_impl<W, false>(T, tile0, stride, t_end, body);
+  if (T.c16) {                                              // (wave-uniform: one of the four row streams runs)
+    if (full_rows<W>(T)) for_tiles_impl<W, true, true>(T, tile0, stride, t_end, body);
+    else for_tiles_impl<W, false, true>(T, tile0, stride, t_end, body);
+  } else {
+    if (full_rows<W>(T)) for_tiles_impl<W, true, false>(T, tile0, stride, t_end, body);
+    else for_tiles_impl<W, false, false>(T, tile0, stride, t_end, body);
+  }
 }
 
 template <int W, typename Body>
 KAS_DEV void for_tile_batches(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
-  if (full_rows<W>(T)) for_tile_batches_impl<W, true>(T, tile0, stride, t_end, body);
-  else for_tile_batches_impl<W, false>(T, tile0, stride, t_end, body);
+  if (T.c16) {
+    if (full_rows<W>(T)) for_tile_batches_impl<W, true, true>(T, tile0, stride, t_end, body);
+    else for_tile_batches_impl<W, false, true>(T, tile0, stride, t_end, body);
+  } else {
+    if (full_rows<W>(T)) for_tile_batches_impl<W, true, false>(T, tile0, stride, t_end, body);
+    else for_tile_batches_impl<W, false, false>(T, tile0, stride, t_end, body);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -636,9 +697,9 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
       const int32_t p = (tile << 6) + lane;
       const bool active = p < T.P;
       const int32_t len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
-      const int32_t* row = T.cur + (int64_t)p * T.cw;
+      const int64_t row = (int64_t)p * T.cw;                // (cells: cur_cell reads either width)
       int32_t n = -1;
-      if (r < len) n = node_lookup(L, nm, row[r]);         // node != null (KAS:119-120)
+      if (r < len) n = node_lookup(L, nm, cur_cell(T, row + r));   // node != null (KAS:119-120)
       bool elig = n >= 0;
       const int32_t rk = elig ? (int32_t)lds_rack(L, n) : -1;
 #pragma unroll
@@ -646,7 +707,7 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
         if (r2 < r) {                                       // wave-uniform
           const uint64_t aw = kasw::load_shared_u64(accmask + (int64_t)r2 * nt + tile);
           if (elig && ((aw >> lane) & 1ull)) {
-            const int32_t n2 = node_lookup(L, nm, row[r2]);
+            const int32_t n2 = node_lookup(L, nm, cur_cell(T, row + r2));
             if ((int32_t)lds_rack(L, n2) == rk) elig = false;    // rack.canAccept (KAS:346-348)
           }
         }
@@ -690,7 +751,8 @@ KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const No
   for (int32_t tile = 0; tile < T.nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
     int32_t ids[W], idx[W], len;
-    load_row<W>(T, p, ids, len);
+    if (T.c16) load_row<W, false, true>(T, p, ids, len);
+    else load_row<W>(T, p, ids, len);
     uint32_t accbits = 0;
 #pragma unroll
     for (int r = 0; r < W; ++r) {
@@ -1260,14 +1322,15 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   const uint64_t lt = kasw::lanemask_lt();
   const int32_t N = nm.n;
   TopicView T;
-  T.cur = a.cur + td.cur_off;
+  T.c16 = cells16(a);
+  T.cur = topic_cur(a, td);
   T.orph = orph;
   T.len_arr = td.cur_len_off >= 0 ? a.aux + td.cur_len_off : nullptr;
   T.inp_arr = td.in_partitions_off >= 0 ? a.aux + td.in_partitions_off : nullptr;
   T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
   T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
   T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
-  T.mid = mid_base(a.out + td.out_off, T.P, T.ow);
+  T.mid = topic_mid(a, td);
   const int32_t P = T.P, hash = T.hash;
 
   TopicOutcome res;
@@ -1546,9 +1609,7 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
     kasw::sync();
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding
-      int32_t* out = a.out + td.out_off;
-      const int64_t cells = (int64_t)td.n_partitions * td.out_width;
-      for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
+      out_pad(topic_out(a, td), (int64_t)td.n_partitions * td.out_width, tid, NT);
       o.moved_replicas = 0; o.moved_partitions = 0;
       if (scen_status == KAS_OK) { scen_status = o.status; fail_topic = k; fail_part = o.fail_partition; }
     }
@@ -1609,9 +1670,7 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     int32_t* const orph_topic = orph;
     orph += (int64_t)((td.n_partitions > 0 ? td.n_partitions : 0) + 63) / 64 * 64;
     if (failed) {                                            // KAG:173-184 aborted: nothing is returned for this topic
-      int32_t* out = a.out + td.out_off;
-      const int64_t cells = (int64_t)td.n_partitions * td.out_width;
-      for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
+      out_pad(topic_out(a, td), (int64_t)td.n_partitions * td.out_width, tid, NT);
       if (tid == 0) {
         kas_topic_result tr;
         tr.status = KAS_SKIPPED; tr.fail_partition = -1; tr.moved_replicas = 0; tr.moved_partitions = 0;
@@ -1624,11 +1683,11 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     const int32_t* p4s = a.p4s + (int64_t)ti * (KAS_P4S_HEAD + a.n_max);
     if (tr0.status != KAS_OK || p4s[0] == 0) continue;       // (workgroup-uniform: nothing handed over)
     TopicView T;
-    T.cur = nullptr; T.orph = orph_topic; T.len_arr = nullptr; T.inp_arr = nullptr;
+    T.c16 = cells16(a); T.cur = nullptr; T.orph = orph_topic; T.len_arr = nullptr; T.inp_arr = nullptr;
     T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
     T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
     T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
-    T.mid = mid_base(a.out + td.out_off, T.P, T.ow);
+    T.mid = topic_mid(a, td);
     T.cap = p4s[1];
     const int32_t cap = T.cap;
     kasw::sync();                                            // (the previous topic's node state has been read)
@@ -1663,9 +1722,7 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       failed = true; fail_topic = k;
       fail_part = hung ? -1 : (T.pid_arr ? T.pid_arr[frow] : frow);
       moved_r -= tr0.moved_replicas; moved_p -= tr0.moved_partitions;
-      int32_t* out = a.out + td.out_off;                     // nothing is returned for a failed topic: its rows are all padding
-      const int64_t cells = (int64_t)td.n_partitions * td.out_width;
-      for (int64_t i = tid; i < cells; i += NT) out[i] = -1;
+      out_pad(topic_out(a, td), (int64_t)td.n_partitions * td.out_width, tid, NT);   // nothing is returned for a failed topic
       if (tid == 0) {
         kas_topic_result tr;
         tr.status = hung ? KAS_FAIL_WATCHDOG : KAS_FAIL_UNASSIGNABLE; tr.fail_partition = fail_part;
@@ -1715,6 +1772,7 @@ KAS_DEV SpreadTopic spread_topic(const KasLaunch& a, int32_t s) {
   S.td = a.topics[S.ok ? sd.topic_begin : 0];
   const kas_topic_desc& td = S.td;
   TopicView& T = S.T;
+  T.c16 = false;                                          // (the spread fill is not launched for 16-bit cells)
   T.cur = a.cur + td.cur_off;
   T.orph = a.orph + a.orph_off[s];
   T.len_arr = nullptr; T.inp_arr = nullptr;
@@ -2794,7 +2852,7 @@ KAS_DEV void order_tickets(const KasLaunch& a, int32_t first_scenario, unsigned 
 // row order, so the result is the sequential one.  Returns true on the KAS:190 index error.
 // ---------------------------------------------------------------------------------------------
 template <int W>
-KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td, int32_t* out,
+KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td, const OutRef& out, const uint16_t* mid,
                           const int32_t* g_node_id, uint32_t topic_k, uint64_t& digest,
                           int64_t& rounds) {
   constexpr int CS = cnt_stride<W>();
@@ -2811,7 +2869,7 @@ KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td,
   idxm[0] = 0;
   // rows come in as mid rows at the end of the topic's out region and leave as final rows from its
   // start: the tile after the current one is read before the current tile's final rows are written
-  const uint16_t* mid = mid_base(out, P, ow);
+  // (16-bit cells: final row p takes mid row p's place — read a tile ago)
   MidRaw<W> nxr = mid_load_raw<W>(mid, ow, lane < P ? lane : 0, lane < P);   // next tile's mid row (software prefetch)
   for (int32_t tile = 0; tile < nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
@@ -2882,8 +2940,8 @@ KAS_DEV bool order_rounds(int32_t* cnt, uint64_t* dep, const kas_topic_desc& td,
       for (int k = 0; k < W; ++k) {
         if (k < ow) {
           const int32_t node = lst[k];
-          const int32_t id = node >= 0 ? g_node_id[node] : -1;
-          out[(int64_t)p * ow + k] = id;
+          const int32_t id = node >= 0 ? (out.o16 ? node : g_node_id[node]) : -1;
+          out_store(out, (int64_t)p * ow + k, id);
           if (node >= 0) digest += kas_digest_cell(topic_k, (uint32_t)p, (uint32_t)k, id);
         }
       }
@@ -2922,14 +2980,13 @@ KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char*
     const int32_t ti = sd.topic_begin + k;
     kas_topic_result tr = a.topic_results[ti];
     const kas_topic_desc td = a.topics[ti];
-    int32_t* out = a.out + td.out_off;
+    const OutRef out = topic_out(a, td);
     kasw::lockstep();                                      // every lane has read tr before lane 0 rewrites it
     if (failed_here && tr.status != KAS_SKIPPED) {
       // an earlier topic failed in this kernel: the CLI run would have aborted (KAG:173-184)
       if (tr.status == KAS_OK) {
         sr.moved_replicas -= tr.moved_replicas; sr.moved_partitions -= tr.moved_partitions;
-        const int64_t cells = (int64_t)td.n_partitions * td.out_width;
-        for (int64_t i = lane; i < cells; i += 64) out[i] = -1;
+        out_pad(out, (int64_t)td.n_partitions * td.out_width, lane, 64);
       }
       tr.status = KAS_SKIPPED; tr.fail_partition = -1; tr.moved_replicas = 0; tr.moved_partitions = 0;
       if (lane == 0) a.topic_results[ti] = tr;
@@ -2937,11 +2994,10 @@ KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char*
     }
     if (tr.status != KAS_OK) continue;
     uint64_t dg = 0;
-    const bool hash_fail = order_rounds<W>(cnt, dep, td, out, g_node_id, (uint32_t)k, dg, rounds);
+    const bool hash_fail = order_rounds<W>(cnt, dep, td, out, topic_mid(a, td), g_node_id, (uint32_t)k, dg, rounds);
     if (hash_fail) {
       kasw::wave_sync();
-      const int64_t cells = (int64_t)td.n_partitions * td.out_width;
-      for (int64_t i = lane; i < cells; i += 64) out[i] = -1;
+      out_pad(out, (int64_t)td.n_partitions * td.out_width, lane, 64);
       sr.moved_replicas -= tr.moved_replicas; sr.moved_partitions -= tr.moved_partitions;
       tr.status = KAS_FAIL_HASH_INDEX; tr.fail_partition = -1; tr.moved_replicas = 0; tr.moved_partitions = 0;
       if (lane == 0) a.topic_results[ti] = tr;

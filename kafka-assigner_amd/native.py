@@ -25,6 +25,7 @@ SYMBOLS = [
     "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
     "kas_plan_describe", "kas_ctx_host_stats", "kas_solve_host_select", "kas_host_alloc", "kas_host_free",
     "kas_shard_range", "kas_batch_slice", "kas_solve_host_sharded", "kas_ctx_lds_lane_order", "kas_solve_host16",
+    "kas_plan_create16", "kas_solve_device16",
 ]
 
 _LIB = None
@@ -78,6 +79,10 @@ def load():
     L.kas_solve_host16.restype = C.c_int         # (kas_tables16 has kas_tables' layout: abi.Tables holds untyped pointers)
     L.kas_solve_host16.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables),
                                    C.POINTER(C.c_int32), C.c_int32]
+    L.kas_plan_create16.restype = C.c_int
+    L.kas_plan_create16.argtypes = [C.c_void_p, C.POINTER(abi.BatchDesc), C.POINTER(C.c_void_p)]
+    L.kas_solve_device16.restype = C.c_int
+    L.kas_solve_device16.argtypes = [C.c_void_p, C.POINTER(abi.Tables), C.c_void_p]
     L.kas_solve_host_sharded.restype = C.c_int
     L.kas_solve_host_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables)]
     L.kas_host_alloc.restype = C.c_int; L.kas_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
@@ -153,13 +158,20 @@ class DeviceContext:
 class Plan:
     """kas_plan: validated batch shape with descriptors and node tables resident in HBM."""
 
-    def __init__(self, ctx: DeviceContext, fb: FlatBatch):
+    def __init__(self, ctx: DeviceContext, fb: FlatBatch, cells16: bool = False):
+        """cells16: kas_plan_create16 — the plan's solves read and write uint16 node-index cells (solve_device with
+        pointers to uint16 pools; fb.node_id is not read)."""
         self._lib = load()
         self._ctx = ctx
         self._fb = fb                      # keeps the host descriptor arrays alive
+        self.cells16 = bool(cells16)
         bd = batch_desc(fb)
         self._h = C.c_void_p()
-        _check(self._lib.kas_plan_create(ctx._h, C.byref(bd), C.byref(self._h)))
+        if cells16:
+            bd.node_id = None
+            _check(self._lib.kas_plan_create16(ctx._h, C.byref(bd), C.byref(self._h)))
+        else:
+            _check(self._lib.kas_plan_create(ctx._h, C.byref(bd), C.byref(self._h)))
 
     @property
     def algorithmic_bytes(self) -> int:
@@ -171,7 +183,8 @@ class Plan:
         t = abi.Tables()
         t.cur = cur or None; t.out = out or None; t.aux = aux or None; t.ctx = ctx or None
         t.topic_results = topic_results or None; t.scenario_results = scenario_results or None
-        _check(self._lib.kas_solve_device(self._h, C.byref(t), C.c_void_p(stream) if stream else None))
+        fn = self._lib.kas_solve_device16 if self.cells16 else self._lib.kas_solve_device
+        _check(fn(self._h, C.byref(t), C.c_void_p(stream) if stream else None))
 
     def set_flags(self, flags: int):
         _check(self._lib.kas_plan_set_flags(self._h, flags))
@@ -352,4 +365,40 @@ def solve_host_with_flags(fb: FlatBatch, flags: int, ctx: Optional[DeviceContext
     if d_ctx is not None:
         ho.ctx = d_ctx.cpu().numpy()
     plan.close()
+    return ho
+
+
+def solve_device16_with_flags(fb: FlatBatch, flags: int = 0, ctx: Optional[DeviceContext] = None, cur16=None) -> HostOutputs:
+    """kas_plan_create16 + kas_solve_device16: the batch solved on uint16 node-index cells resident in HBM (HostOutputs.out is
+    the uint16 out pool).  Raises KasError(KAS_E_UNSUPPORTED) for batches the 16-bit kernels do not take."""
+    import torch
+    from .flatten import to_cells16
+    ctx = ctx or default_context()
+    dev = torch.device("cuda", ctx.device)
+    plan = Plan(ctx, fb, cells16=True)
+    try:
+        if flags:
+            plan.set_flags(flags)
+        _, ho = host_tables(fb)
+        c16 = to_cells16(fb) if cur16 is None else cur16
+        d_cur = torch.from_numpy(c16.view(np.int16)).to(dev)
+        d_aux = torch.from_numpy(fb.aux).to(dev) if fb.aux.size else None
+        d_ctx = torch.from_numpy(ho.ctx).to(dev) if ho.ctx.size else None
+        d_out = torch.full((max(fb.out_len, 1),), -2, dtype=torch.int16, device=dev)
+        d_tr = torch.zeros(max(fb.n_topics, 1) * 16, dtype=torch.uint8, device=dev)
+        d_sr = torch.zeros(max(fb.n_scenarios, 1) * 32, dtype=torch.uint8, device=dev)
+        st = torch.cuda.Stream(dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(),
+                          aux=d_aux.data_ptr() if d_aux is not None else 0,
+                          ctx=d_ctx.data_ptr() if d_ctx is not None else 0, stream=st.cuda_stream)
+        st.synchronize()
+        ho.out = d_out.cpu().numpy().view(np.uint16)
+        ho.topic_results = d_tr.cpu().numpy().view(abi.TOPIC_RESULT_DTYPE)
+        ho.scenario_results = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
+        if d_ctx is not None:
+            ho.ctx = d_ctx.cpu().numpy()
+        ho.describe = plan.describe()
+    finally:
+        plan.close()
     return ho

@@ -31,17 +31,23 @@ from oracle_lib import oracle_solve  # noqa: E402
 # The kernel families and plan variants a solve can launch, each at a shape that takes it (name, must appear
 # in the plan's description — "!x": x must NOT appear —, bench.py flags).  The first is the headline shape (BASELINE.json configs[2]).
 SUITE = [
-    ("headline: fill<3,4> per-chunk histograms + first fit in kas_p4_kernel + relaxation form of the order kernel",
-     "+ kas_p4_kernel<3> grid=1000x64", ["--in-flight", "12"]),
+    ("headline: 16-bit cells in HBM — fill<3,4> per-chunk histograms + first fit in kas_p4_kernel + relaxation form of the order kernel",
+     "[16-bit cells]", ["--in-flight", "12"]),
+    ("the same kernels on int32 broker ids (kas_plan_create)",
+     "+ kas_p4_kernel<3> grid=1000x64", ["--in-flight", "12", "--cells", "32"]),
     ("first fit inside the fill workgroup (KAS_PLAN_FILL_WITH_P4: four wavefronts hand windows over through LDS, no kas_p4_kernel)",
-     "!kas_p4_kernel", ["--plan-flags", "8388608", "--in-flight", "12"]),
+     "!kas_p4_kernel", ["--plan-flags", "8388608", "--in-flight", "12", "--cells", "32"]),
+    ("16-bit cells, first fit inside the fill workgroup + double tiles (what small batches and host calls take)",
+     "[16-bit cells]", ["--plan-flags", str(8388608 | 262144), "--in-flight", "12"]),
+    ("16-bit cells, round form of the order kernel (what a ticket-form request takes there)",
+     "kas_order_round_kernel<3>", ["--plan-flags", "65536", "--in-flight", "12", "--scenarios", "200"]),
     ("relaxation form over double tiles (KAS_PLAN_RELAX_TILES(2): what batches of fewer than 512 scenarios take)",
-     "kas_order_relax_kernel<3>[tiles of 128 rows]", ["--plan-flags", "262144", "--in-flight", "12"]),
+     "kas_order_relax_kernel<3>[tiles of 128 rows]", ["--plan-flags", "262144", "--in-flight", "12", "--cells", "32"]),
     ("packed ticket form, 2 scenarios per wavefront (KAS_PLAN_TICKET_ORDER)",
-     "kas_order_ticket_kernel<3,2,true>", ["--plan-flags", "65536", "--in-flight", "12"]),
-    ("one scenario per solver wavefront (G = 1)", "kas_order_ticket_kernel<3,1,true>", ["--groups", "1", "--in-flight", "12"]),
-    ("4 x uint16 counter rows", "kas_order_ticket_kernel<3,2,false>", ["--plan-flags", "4", "--in-flight", "12"]),
-    ("histogram for the whole topic + chunk-count pass", "kas_fill_kernel<3,4>[quota]", ["--plan-flags", "8", "--in-flight", "12"]),
+     "kas_order_ticket_kernel<3,2,true>", ["--plan-flags", "65536", "--in-flight", "12", "--cells", "32"]),
+    ("one scenario per solver wavefront (G = 1)", "kas_order_ticket_kernel<3,1,true>", ["--groups", "1", "--in-flight", "12", "--cells", "32"]),
+    ("4 x uint16 counter rows", "kas_order_ticket_kernel<3,2,false>", ["--plan-flags", "4", "--in-flight", "12", "--cells", "32"]),
+    ("histogram for the whole topic + chunk-count pass", "kas_fill_kernel<3,4>[quota]", ["--plan-flags", "8", "--in-flight", "12", "--cells", "32"]),
     ("lists 5 wide: wide ticket form (five wavefronts, class lists, joint solve)", "kas_order_wide_kernel<5>",
      ["--scenarios", "96", "--partitions", "40000", "--brokers", "600", "--racks", "40", "--rf", "5",
       "--actions", "add_k,mixed", "--in-flight", "6"]),
@@ -56,10 +62,10 @@ SUITE = [
       "--actions", "add_k,mixed", "--in-flight", "3"]),
     ("spread fill, lists 3 wide + relaxation form", "kas_spread_",
      ["--scenarios", "24", "--partitions", "140000", "--brokers", "1000", "--racks", "20", "--rf", "3",
-      "--actions", "add_k,mixed", "--in-flight", "4"]),
+      "--actions", "add_k,mixed", "--in-flight", "4", "--cells", "32"]),
     ("spread fill, lists 3 wide + ticket form", "kas_order_ticket_kernel<3,",
      ["--scenarios", "24", "--partitions", "140000", "--brokers", "1000", "--racks", "20", "--rf", "3",
-      "--actions", "add_k,mixed", "--in-flight", "4", "--plan-flags", "65536"]),
+      "--actions", "add_k,mixed", "--in-flight", "4", "--plan-flags", "65536", "--cells", "32"]),
 ]
 
 
@@ -81,7 +87,7 @@ def run_case(argv, rounds=None, min_solves=None):
     run.synchronize()                      # (the copy runs on torch's stream, the next solves on the slots' own)
     # the reference itself against the oracle (records of every scenario)
     sl0 = run.slots[0]
-    sub = node_set_batch(sl0["ids"], sl0["racks"], P, RF, RF, cur=run.host_cur(0))
+    sub = node_set_batch(run.check_ids(sl0), sl0["racks"], P, RF, RF, cur=run.check_cur(0))   # (16-bit cells: the index form)
     want = oracle_solve(sub, threads=0)
     got = ref_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
     for f in ("status", "fail_partition", "moved_replicas", "moved_partitions", "digest"):

@@ -8,10 +8,10 @@
 #include "kas_plan_math.h"
 #include "kas_solver_body.h"
 
-template <int W, bool DUAL, bool CTX, bool VERIFY>
+template <int W, bool DUAL, bool CTX, bool VERIFY, bool C16 = false>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX, VERIFY>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY, C16>(a, (int32_t)blockIdx.x, kas_lds);
 }
 template __global__ void kas_order_relax_kernel<2, false, false, false>(KasLaunch);
 template __global__ void kas_order_relax_kernel<2, false, false, true>(KasLaunch);
@@ -25,3 +25,10 @@ template __global__ void kas_order_relax_kernel<3, true, false, false>(KasLaunch
 template __global__ void kas_order_relax_kernel<3, true, false, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, true, false>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, true, true>(KasLaunch);
+// the instances for 16-bit cells (kas_plan_create16): mid rows still come in by async loads
+template __global__ void kas_order_relax_kernel<2, false, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, true, false, true>(KasLaunch);

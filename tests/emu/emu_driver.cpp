@@ -216,9 +216,9 @@ template <int W> void run_order_wide(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
 }
-template <int W, bool DUAL, bool CTX, bool VERIFY = false> void run_order_relax(void* p) {
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false> void run_order_relax(void* p) {
   RunArgs* r = (RunArgs*)p;
-  if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY>(*r->a, r->s, r->lds);
+  if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY, C16>(*r->a, r->s, r->lds);
 }
 template <int W> void run_order_rounds(void* p) {
   RunArgs* r = (RunArgs*)p;
@@ -275,8 +275,25 @@ static int g_last_flagged = 0; // scenarios a ticket form left to the round form
 // 12..15 = scenarios per wavefront of the ticket-form order kernel (0 = the planner's choice),
 // bit 16 = KAS_FLAG_TICKET_ORDER (the ticket form where the relaxation form would run), bits 17 / 18 = tiles of 64 rows /
 // double tiles in the relaxation form whatever the batch size, bit 21 = KAS_FLAG_NO_RTN_QUOTA
+static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen, bool c16);
+
 extern "C" __attribute__((visibility("default")))
 int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen) {
+  return emu_solve(b, t, flags, errbuf, errlen, false);
+}
+
+// kas_plan_create16 + kas_solve_device16 (ABI v5): t->cur / t->out point at uint16 node-index cells, b->node_id is not read
+extern "C" __attribute__((visibility("default")))
+int kas_emu_solve_batch16(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen) {
+  std::vector<int32_t> ids((size_t)(b->node_pool_len > 0 ? b->node_pool_len : 0), 0);
+  for (int32_t s = 0; s < b->n_scenarios; ++s)
+    for (int32_t i = 0; i < b->scenarios[s].n_nodes; ++i) ids[(size_t)(b->scenarios[s].node_off + i)] = i;
+  kas_batch_desc ib = *b;
+  ib.node_id = ids.data();
+  return emu_solve(&ib, t, flags, errbuf, errlen, true);
+}
+
+static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flags, char* errbuf, int errlen, bool c16) {
   KasShape sh;
   std::string err;
   int rc = kas_shape_batch(b, &sh, &err, (int)((flags >> 8) & 0xfu), (int)((flags >> 12) & 0xfu));
@@ -284,10 +301,18 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if (errbuf && errlen > 0) { strncpy(errbuf, err.c_str(), (size_t)errlen - 1); errbuf[errlen - 1] = 0; }
     return rc;
   }
+  if (c16 && (sh.Wc > 3 || !(sh.relax_ok || sh.round_fits))) {   // (kas_plan_build's refusal for plans with 16-bit cells)
+    if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "16-bit cells: lists up to 3 wide, relaxation or round form");
+    return KAS_E_UNSUPPORTED;
+  }
+  if (c16 && (((flags >> 24) != 0u) || (kas_flags_want_tickets(flags) && !sh.round_fits))) {   // (kas_plan_set_flags' refusals)
+    if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "16-bit cells: no sampled verification / no ticket form");
+    return KAS_E_UNSUPPORTED;
+  }
   // (the launch decisions of kas_launch_plan in kas_hip.hip)
   const bool relax = sh.relax_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !(kas_flags_want_tickets(flags) && sh.tickets_ok);
-  const bool tickets = !relax && sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER);
-  const bool wide = sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER);
+  const bool tickets = !relax && sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !c16;
+  const bool wide = sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !c16;
   g_last_order_form = relax ? 3 : (tickets ? 1 : (wide ? 2 : 0));
   g_last_relax_tiles = 0; g_last_relax_evals = 0; g_last_relax_slow = 0;
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
@@ -324,7 +349,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~KAS_FLAG_FUSED_HIST) |
             (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u) |
             (kas_relax_double_tiles(flags, b->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
-            ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER);
+            ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER) | (c16 ? KAS_FLAG_CELLS16 : 0u);
   auto bad = [&](const char* what, int32_t s) {
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;
@@ -332,7 +357,7 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
   // spread fill (same decision as kas_solve_device): passes A and B over one-wavefront workgroups
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
   g_last_spread = 0;
-  const int32_t CH = (sh.NW == 4 && sh.Wc >= 3 && sh.Wc <= 5 && !(flags & KAS_FLAG_GENERIC_FILL))
+  const int32_t CH = (!c16 && sh.NW == 4 && sh.Wc >= 3 && sh.Wc <= 5 && !(flags & KAS_FLAG_GENERIC_FILL))
                          ? kas_spread_chunks(sh, b->n_scenarios, kas_batch_single_topic(b), (flags & KAS_FLAG_SPREAD_FILL) != 0) : 0;
   std::vector<int32_t> sp_hist, sp_quota, sp_node, sp_flag, sp_oc;
   if (CH > 0) {
@@ -417,6 +442,9 @@ int kas_emu_solve_batch(const kas_batch_desc* b, const kas_tables* t, unsigned f
     if ((a.flags >> 24) != 0u)                                // KAS_PLAN_VERIFY_SAMPLE: the instances with the second evaluation
       f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true, true> : (rdual ? run_order_relax<3, true, true, true> : run_order_relax<3, false, true, true>))
                      : (sh.Wc <= 2 ? run_order_relax<2, false, false, true> : (rdual ? run_order_relax<3, true, false, true> : run_order_relax<3, false, false, true>));
+    if (c16)                                                  // the instances for 16-bit cells
+      f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true, false, true> : (rdual ? run_order_relax<3, true, true, false, true> : run_order_relax<3, false, true, false, true>))
+                     : (sh.Wc <= 2 ? run_order_relax<2, false, false, false, true> : (rdual ? run_order_relax<3, true, false, false, true> : run_order_relax<3, false, false, false, true>));
     // exactly the LDS the product launches the kernel with, and a guard behind it: the hardware drops what a
     // workgroup writes beyond its allocation and reads zeros there — here that must not pass unnoticed
     const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx);

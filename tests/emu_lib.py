@@ -195,6 +195,24 @@ def emu_solve(fb: FlatBatch, flags: int = 0, p4_by_batch_size: bool = False) -> 
     return ho
 
 
+def emu_solve16(fb: FlatBatch, flags: int = 0, p4_by_batch_size: bool = False, cur16=None) -> HostOutputs:
+    """kas_plan_create16 + kas_solve_device16 on the emulator: cur / out as uint16 node-index pools (HostOutputs.out is the
+    uint16 out pool).  Raises RuntimeError with the library's code for batches the 16-bit kernels do not take."""
+    from kafka_assigner_amd.flatten import host_tables16, to_cells16
+    L = lib()
+    L.kas_emu_solve_batch16.restype = C.c_int
+    L.kas_emu_solve_batch16.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables), C.c_uint, C.c_char_p, C.c_int]
+    bd = batch_desc(fb)
+    bd.node_id = None
+    c16 = to_cells16(fb) if cur16 is None else cur16
+    t, ho = host_tables16(fb, c16)
+    err = C.create_string_buffer(512)
+    rc = L.kas_emu_solve_batch16(C.byref(bd), C.byref(t), _p4_form(flags, p4_by_batch_size), err, 512)
+    if rc != 0:
+        raise RuntimeError(f"kas_emu_solve_batch16 rc={rc}: {err.value.decode()}")
+    return ho
+
+
 def last_spread() -> int:
     """Scenarios the spread fill solved itself (not handed back to the one-workgroup kernel) in the last emu_solve."""
     L = lib()

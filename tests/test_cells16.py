@@ -90,6 +90,91 @@ def test_index_form_multi_topic_scenarios_and_round_trip_of_the_cells():
         to_cells16(shared)
 
 
+# ---- the kernels' own 16-bit I/O (kas_plan_create16 / kas_solve_device16) on the CPU emulator -------------------------
+def _want16(fb):
+    want = oracle_solve(index_form(fb))
+    want.out = _as_cells16(fb, want.out)
+    return want
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(scenarios())
+def test_emu16_equals_oracle_small_odd_inputs(sc):
+    """Ragged rows, duplicate brokers, brokers that left, partitions != keys(cur), empty topics, failures — with and without
+    a Context; batches with lists more than 3 wide are refused (KAS_E_UNSUPPORTED: the caller widens)."""
+    from emu_lib import emu_solve16
+    brokers, racks, topics = sc
+    for want_ctx in (True, False):
+        fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=want_ctx,
+                               topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
+        wide = bool((fb.topics["out_width"] > 3).any())
+        try:
+            got = emu_solve16(fb)
+        except RuntimeError as e:
+            assert "rc=-3" in str(e) and wide, str(e)
+            continue
+        assert not wide
+        assert_same_outputs(fb, _want16(fb), got, "emu, 16-bit cells, odd inputs")
+        assert_same_outputs(fb, _want16(fb), emu_solve16(fb, flags=2), "emu, 16-bit cells, round form")
+
+
+@pytest.mark.parametrize("P,N,R,RF,actions", [
+    (1000, 40, 8, 3, G.ACTIONS), (3000, 100, 10, 3, ("remove1",)), (2048, 64, 8, 2, ("add_k",)),
+    (8000, 80, 8, 3, ("replace1", "add_k")),
+])
+def test_emu16_equals_oracle_seeded_batches_every_plan_variant(P, N, R, RF, actions):
+    from emu_lib import (FILL_WITH_P4, NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve16,
+                         last_split_p4)
+    fb = _batch(1234, 6, P, N, R, RF, actions)
+    want = _want16(fb)
+    assert_same_outputs(fb, want, emu_solve16(fb), "emu 16-bit cells")
+    assert last_split_p4() == 1
+    for flags, what in ((FILL_WITH_P4, "first fit inside the fill workgroup"), (RELAX_TILES_64, "tiles of 64 rows"),
+                        (RELAX_TILES_128, "double tiles"), (RELAX_TILES_64 | NO_RTN_QUOTA, "quota without the atomic-with-return"),
+                        (1, "general fill"), (2, "round form"), (TICKET_ORDER, "ticket form asked for: round form"),
+                        (RELAX_TILES_64 | (1 << 8), "one fill wavefront"), (RELAX_TILES_64 | (2 << 8), "two fill wavefronts"),
+                        (8, "chunk-count pass"), (3 | (1 << 8), "general fill + round form, one wavefront")):
+        assert_same_outputs(fb, want, emu_solve16(fb, flags=flags), "emu 16-bit cells, " + what)
+    # sparse, non-contiguous broker ids: the cells do not care
+    fb2 = _batch(77, 3, P, N, R, RF, actions, rack_aware=False)
+    fb2.node_id[:] = fb2.node_id * 7 + 1000
+    fb2.cur[:] = np.where(fb2.cur >= 0, fb2.cur * 7 + 1000, fb2.cur)
+    assert_same_outputs(fb2, _want16(fb2), emu_solve16(fb2), "emu 16-bit cells, sparse ids, rack awareness off")
+    # rows that are not rack-diverse: the general fill inside the fill kernel
+    fb3 = _batch(78, 3, P, N, 2, RF, ("remove1", "add_k"), cyclic=True) if RF <= 2 else _batch(78, 3, P, N, R, RF, ("remove1", "add_k"), cyclic=True)
+    assert_same_outputs(fb3, _want16(fb3), emu_solve16(fb3), "emu 16-bit cells, cyclic rows")
+
+
+def test_emu16_multi_topic_scenarios_with_and_without_a_context_and_refusals():
+    from emu_lib import RELAX_TILES_64, VERIFY_SAMPLE, emu_solve16
+    fb = _multi_topic_scenarios(77, 3, 3, 700, 40, 8, 3)
+    want = _want16(fb)
+    assert (want.topic_results["status"] != abi.KAS_OK).any()          # failing and skipped topics: rows of padding
+    for flags in (0, RELAX_TILES_64, 2):
+        assert_same_outputs(fb, want, emu_solve16(fb, flags=flags), "emu 16-bit cells, multi-topic, flags %#x" % flags)
+    scs = []
+    for s in range(3):
+        cur = G.random_assignment(300 + s, 2500, 40, 8, 3)
+        _, bs = G.scenario_action(300, s, 40, 8, actions=("remove1", "add_k"), max_add=4)
+        racks = {int(b) * 3 + 7: "r%d" % int(r) for b, r in zip(bs.node_id, bs.node_rack)}
+        scs.append(Scenario(brokers=[int(b) * 3 + 7 for b in bs.node_id], racks=racks, want_context=True,
+                            topics=[Topic("topic-%d" % t, {p: [int(x) * 3 + 7 for x in cur[p]] for p in range(2500 - 100 * t)}, 3) for t in range(3)]))
+    fbc = flatten(scs)
+    for flags in (0, RELAX_TILES_64, 2):
+        assert_same_outputs(fbc, _want16(fbc), emu_solve16(fbc, flags=flags), "emu 16-bit cells, Context in and out, flags %#x" % flags)
+    # a Context whose counters leave the relaxation form's 16-bit fields: the scenario is left to the round form
+    big = flatten([Scenario(brokers=list(range(40)), racks={b: "r%d" % (b % 8) for b in range(40)}, want_context=True,
+                            context={b: {0: 65000, 1: 3} for b in range(40)},
+                            topics=[Topic("t", {p: [(p + k) % 40 for k in range(3)] for p in range(900)}, 3)])])
+    assert_same_outputs(big, _want16(big), emu_solve16(big), "emu 16-bit cells, Context beyond 16 bits: round form")
+    # lists 5 wide, and the sampled verification: refused
+    wide = _batch(5, 2, 600, 40, 10, 5, G.ACTIONS)
+    with pytest.raises(RuntimeError, match="rc=-3"):
+        emu_solve16(wide)
+    with pytest.raises(RuntimeError, match="rc=-3"):
+        emu_solve16(fb, flags=VERIFY_SAMPLE(8))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _check_hip16(fb, what, ctx=None, pinned=False):
     from kafka_assigner_amd import native
@@ -205,3 +290,95 @@ def test_hip16_select_returns_every_record_and_the_selected_rows_and_the_refusal
     with pytest.raises(native.KasError) as e:
         native.solve_host16(fb, tables=t, ho=ho)
     assert e.value.code == abi.KAS_E_INVALID_ARG
+
+
+# ---- the kernels' own 16-bit I/O on the GPU: kas_plan_create16 + kas_solve_device16 ----------------------------------
+@pytest.mark.gpu
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(scenarios())
+def test_hip_device16_equals_oracle_small_odd_inputs(sc):
+    from kafka_assigner_amd import native
+    brokers, racks, topics = sc
+    for want_ctx in (True, False):
+        fb = flatten([Scenario(brokers=brokers, racks=racks, want_context=want_ctx,
+                               topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
+        wide = bool((fb.topics["out_width"] > 3).any())
+        try:
+            got = native.solve_device16_with_flags(fb)
+        except native.KasError as e:
+            assert e.code == abi.KAS_E_UNSUPPORTED and wide, str(e)
+            continue
+        assert not wide
+        assert_same_outputs(fb, _want16(fb), got, "hip, 16-bit cells in HBM, odd inputs")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,N,R,RF,actions", [
+    (1000, 40, 8, 3, G.ACTIONS), (3000, 100, 10, 3, ("remove1",)), (2048, 64, 8, 2, ("add_k",)),
+    (8000, 80, 8, 3, ("replace1", "add_k")),
+])
+def test_hip_device16_equals_oracle_seeded_batches_every_plan_variant(P, N, R, RF, actions):
+    from kafka_assigner_amd import native
+    fb = _batch(1234, 6, P, N, R, RF, actions)
+    want = _want16(fb)
+    got = native.solve_device16_with_flags(fb)
+    assert "[16-bit cells]" in got.describe and "kas_order_relax_kernel" in got.describe
+    assert_same_outputs(fb, want, got, "hip 16-bit cells")
+    T64, T128 = abi.KAS_PLAN_RELAX_TILES_64, abi.KAS_PLAN_RELAX_TILES_128
+    for flags, what in ((abi.KAS_PLAN_SPLIT_P4 | T64, "kas_p4_kernel + tiles of 64 rows: the headline's kernels"),
+                        (abi.KAS_PLAN_FILL_WITH_P4, "first fit inside the fill workgroup"), (T128, "double tiles"),
+                        (T64 | abi.KAS_PLAN_NO_RTN_QUOTA, "quota without the atomic-with-return"), (1, "general fill"),
+                        (2, "round form"), (abi.KAS_PLAN_TICKET_ORDER, "ticket form asked for: round form"),
+                        (T64 | (1 << 8), "one fill wavefront"), (8, "chunk-count pass")):
+        assert_same_outputs(fb, want, native.solve_device16_with_flags(fb, flags), "hip 16-bit cells, " + what)
+    with pytest.raises(native.KasError) as e:
+        native.solve_device16_with_flags(fb, abi.KAS_PLAN_VERIFY_SAMPLE(8))
+    assert e.value.code == abi.KAS_E_UNSUPPORTED
+    fb3 = _batch(78, 3, P, N, R, RF, ("remove1", "add_k"), cyclic=True)
+    assert_same_outputs(fb3, _want16(fb3), native.solve_device16_with_flags(fb3), "hip 16-bit cells, cyclic rows")
+
+
+@pytest.mark.gpu
+def test_hip_device16_multi_topic_context_full_size_and_refusals():
+    from kafka_assigner_amd import native
+    from kafka_assigner_amd.flatten import node_set_batch
+    fb = _multi_topic_scenarios(77, 3, 3, 700, 40, 8, 3)
+    assert_same_outputs(fb, _want16(fb), native.solve_device16_with_flags(fb), "hip 16-bit cells, multi-topic")
+    scs = []
+    for s in range(3):
+        cur = G.random_assignment(300 + s, 2500, 40, 8, 3)
+        _, bs = G.scenario_action(300, s, 40, 8, actions=("remove1", "add_k"), max_add=4)
+        racks = {int(b) * 3 + 7: "r%d" % int(r) for b, r in zip(bs.node_id, bs.node_rack)}
+        scs.append(Scenario(brokers=[int(b) * 3 + 7 for b in bs.node_id], racks=racks, want_context=True,
+                            topics=[Topic("topic-%d" % t, {p: [int(x) * 3 + 7 for x in cur[p]] for p in range(2500 - 100 * t)}, 3) for t in range(3)]))
+    fbc = flatten(scs)
+    assert_same_outputs(fbc, _want16(fbc), native.solve_device16_with_flags(fbc), "hip 16-bit cells, Context in and out")
+    big = flatten([Scenario(brokers=list(range(40)), racks={b: "r%d" % (b % 8) for b in range(40)}, want_context=True,
+                            context={b: {0: 65000, 1: 3} for b in range(40)},
+                            topics=[Topic("t", {p: [(p + k) % 40 for k in range(3)] for p in range(900)}, 3)])])
+    assert_same_outputs(big, _want16(big), native.solve_device16_with_flags(big), "hip 16-bit cells, Context beyond 16 bits: round form")
+    # BASELINE configs[2]'s shape, 24 scenarios, every action of the bench mix; and 600 scenarios (first fit in kas_p4_kernel by size)
+    S, P, N, R = 24, 100000, 1000, 10
+    cur = np.stack([G.random_assignment(50 + s % 3, P, N, R, 3) for s in range(S)])
+    sets = [G.scenario_action(9, s, N, R, actions=G.BENCH_ACTIONS, max_add=50)[1] for s in range(S)]
+    full = node_set_batch([b.node_id for b in sets], [b.node_rack for b in sets], P, 3, 3, cur=cur)
+    got = native.solve_device16_with_flags(full, abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64)
+    assert "kas_p4_kernel<3>" in got.describe and "tiles of 64 rows" in got.describe
+    assert_same_outputs(full, oracle_16 := _want16(full), got, "hip 16-bit cells, 100k x 1k x RF 3")
+    assert (oracle_16.scenario_results["status"] == abi.KAS_OK).sum() >= 20
+    many = _batch(31, 600, 900, 60, 6, 3, G.BENCH_ACTIONS)
+    gm = native.solve_device16_with_flags(many)
+    assert "kas_p4_kernel<3> grid=600x64" in gm.describe
+    assert_same_outputs(many, _want16(many), gm, "hip 16-bit cells, 600 scenarios")
+    # refusals: lists 5 wide; an int32 plan through kas_solve_device16 and the other way round
+    with pytest.raises(native.KasError) as e:
+        native.solve_device16_with_flags(_batch(5, 2, 600, 40, 10, 5, G.ACTIONS))
+    assert e.value.code == abi.KAS_E_UNSUPPORTED
+    ctx = native.default_context()
+    p32, p16 = native.Plan(ctx, fb), native.Plan(ctx, fb, cells16=True)
+    p32.cells16, p16.cells16 = True, False                                # (call the wrong entry point on purpose)
+    for pl in (p32, p16):
+        with pytest.raises(native.KasError) as e:
+            pl.solve_device(1, 1, 1, 1)
+        assert e.value.code == abi.KAS_E_INVALID_ARG
+        pl.close()

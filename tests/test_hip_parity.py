@@ -601,7 +601,7 @@ def test_solves_in_flight_leave_identical_records_for_every_kernel_family():
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
     import re
     m = re.search(r"suite: (\d+) of (\d+) kernel families clean", r.stdout)
-    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 13, r.stdout[-3000:]
+    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 16, r.stdout[-3000:]
     assert r.stdout.count(": 0 scenario records differ from the reference") == int(m.group(2))
 
 
