@@ -231,6 +231,7 @@ class HipRun:
         self.actions = self.slots[0]["actions"]
         # set-up, not warm-up: every slot's plan runs once so that no slot meets its first launch
         # (scratch first touched, kernels resident) inside the timed region when K is small
+        self.synchronize()                  # (the tables' conversion above ran on torch's stream: not beside the first solves)
         for sl in self.slots:
             self.solve(sl)
         self.synchronize()

@@ -828,7 +828,12 @@ constexpr int fused_block_words() {                                     // == ka
 // kas_fused_block_words() dwords per node holding uint16 hist[n][w][r] (a chunk has < 65536 rows: the
 // plan checks), so that the quota pass below also knows every chunk's share and no second counting
 // pass over cur is needed.  Returns this lane's "not rack-diverse" verdict.
-template <int W, int NW, bool DIRECT>
+// IDENT: 16-bit cells (KAS_FLAG_CELLS16) — a cell IS its node index (node i has id i), no table to look into
+KAS_DEV int32_t node_lookup_ident(const NodeMap& m, int32_t id) {
+  const uint32_t d = (uint32_t)id - (uint32_t)m.min_id;
+  return d < m.range ? (int32_t)d : -1;
+}
+template <int W, int NW, bool DIRECT, bool IDENT = false>
 KAS_DEV bool fill_pass_a_fused(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
   constexpr int D = KAS_TILES_AHEAD;
   constexpr int BW = fused_block_words<W, NW>();
@@ -839,7 +844,7 @@ KAS_DEV bool fill_pass_a_fused(const LdsView& L, const TopicView& T, const NodeM
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? node_lookup_as<DIRECT>(L, nm, ids[d][r]) : -1;
+      for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? (IDENT ? node_lookup_ident(nm, ids[d][r]) : node_lookup_as<DIRECT>(L, nm, ids[d][r])) : -1;
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -1388,7 +1393,8 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   if (try_fast) {
     bool viol;
     if constexpr (W <= 3 && NW > 1) {
-      if (fused) viol = nm.range != 0u ? fill_pass_a_fused<W, NW, true>(L, T, nm, wave) : fill_pass_a_fused<W, NW, false>(L, T, nm, wave);
+      if (fused) viol = (T.c16 && nm.range != 0u && nm.min_id == 0) ? fill_pass_a_fused<W, NW, true, true>(L, T, nm, wave)
+                        : (nm.range != 0u ? fill_pass_a_fused<W, NW, true>(L, T, nm, wave) : fill_pass_a_fused<W, NW, false>(L, T, nm, wave));
       else viol = nm.range != 0u ? fill_pass_a<W, NW, true>(L, T, nm, wave) : fill_pass_a<W, NW, false>(L, T, nm, wave);
     } else {
       viol = nm.range != 0u ? fill_pass_a<W, NW, true>(L, T, nm, wave) : fill_pass_a<W, NW, false>(L, T, nm, wave);
