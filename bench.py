@@ -1156,6 +1156,7 @@ def other_configs_leg(args, run):
     out["configs[1]"] = {
         "workload": "one scenario, 10k partitions x 100 brokers x 10 racks, RF 3, decommission 1 broker",
         "gpu_ms_per_solve": ms, "gpu_fill_kernel_us": f_us, "gpu_order_kernel_us": o_us, "kernel": desc,
+        "roofline_frac": fb.algorithmic_bytes() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "with_the_adapters_context_in_and_out": with_ctx,
         "cpu_fast_one_core_ms": c1, "cpu_fast_all_cores_ms": c1,
         "note": "a single scenario has no scenario-level parallelism for the host (all-core = one core) and little for "
@@ -1173,6 +1174,7 @@ def other_configs_leg(args, run):
     out["configs[4]"] = {
         "workload": "1M partitions x 5k brokers x 40 racks, RF 5, remove every 50th broker + add 200 (N = 5100, cap 981)",
         "one_scenario": {"gpu_ms_per_solve": ms1, "gpu_fill_us": f1, "gpu_order_kernel_us": o1, "kernel": desc1,
+                         "roofline_frac": fb1.algorithmic_bytes() / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "cpu_fast_one_core_ms": c5_1, "moved_replicas": int(sr1["moved_replicas"][0])},
         "host_hardware_threads": host_threads(),
     }
@@ -1186,6 +1188,7 @@ def other_configs_leg(args, run):
             "what": f"{nb} broker-set variants of the same snapshot (rack map on / off alternating) in one batch",
             "gpu_ms_per_batch": msn, "gpu_scenarios_per_s": 1e3 * nb / msn, "gpu_fill_us": fn_,
             "gpu_order_kernel_us": on_, "kernel": descn,
+            "roofline_frac": fbn.algorithmic_bytes() / (msn * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "cpu_fast_all_cores_ms": c5_n, "cpu_fast_all_cores_scenarios_per_s": 1e3 * nb / c5_n,
             "cpu_threads": wantn.threads_used}
         del fbn, srn, rowsn, wantn
@@ -1221,6 +1224,7 @@ def other_configs_leg(args, run):
             "workload": "one GPU's share of 64k scenarios: 8000 scenarios of 100k partitions x 1k brokers x 20 racks, RF 3, "
                         "action add brokers 1000-1049 (N = 1050, cap 286), one batch of 8000, 2 batches in flight",
             "gpu_scenarios_per_s": a3.scenarios * a3.steps / w3, "gpu_ms_per_batch": 1e3 * w3 / a3.steps,
+            "roofline_frac": run3.algorithmic_bytes() / (w3 / a3.steps) / 1e9 / HBM_PEAK_GBPS,
             "kernel": run3.describe(), "ok_scenarios": int((sr3["status"] == abi.KAS_OK).sum()),
             "parity_checked_scenarios": n_cpu,
             "cpu_fast_all_cores_scenarios_per_s": n_cpu / c3, "cpu_threads": want3.threads_used,

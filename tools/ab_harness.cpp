@@ -15,7 +15,7 @@
 //                                between two synchronisations, REPEATS times: scenarios/s by the host clock (bench.py's regime)
 //   AB_FLAGS=n                   kas_plan_set_flags(n) on every plan (KAS_PLAN_* of include/kas_abi.h)
 //   AB_DISTINCT=1                in flight: every slot its own copy of the cur table (as bench.py's slots have)
-//   AB_CELLS16=1                 timing experiment: cur as packed uint16 node indices, identity node ids (for -DKAS_TUNE_CELLS16 builds)
+//   AB_CELLS16=1                 the batch as uint16 node-index cells through kas_plan_create16 / kas_solve_device16 (ABI v5)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -49,6 +49,13 @@ struct Api {
   int (*phase_times)(kas_plan*, double*, double*, int*);
   const char* (*last_error)(void);
   int (*set_flags)(kas_plan*, unsigned);
+  int (*plan_create16)(kas_ctx*, const kas_batch_desc*, kas_plan**) = nullptr;      // (ABI v5; absent from older builds)
+  int (*solve_device16)(kas_plan*, const kas_tables16*, void*) = nullptr;
+  bool cells16 = false;                                     // AB_CELLS16: plans and solves on 16-bit cells
+  int make_plan(kas_ctx* c, const kas_batch_desc* b, kas_plan** p) { return cells16 ? plan_create16(c, b, p) : plan_create(c, b, p); }
+  int solve(kas_plan* p, const kas_tables* t, void* st) {   // (kas_tables16 has kas_tables' layout: pointer types apart)
+    return cells16 ? solve_device16(p, reinterpret_cast<const kas_tables16*>(t), st) : solve_device(p, t, st);
+  }
   bool load(const char* path) {
     h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", path, dlerror()); return false; }
@@ -58,6 +65,10 @@ struct Api {
     SYM(ctx_synchronize, "kas_ctx_synchronize") SYM(phase_times, "kas_plan_phase_times_us") SYM(last_error, "kas_last_error")
     SYM(set_flags, "kas_plan_set_flags")
 #undef SYM
+    plan_create16 = (decltype(plan_create16))dlsym(h, "kas_plan_create16");
+    solve_device16 = (decltype(solve_device16))dlsym(h, "kas_solve_device16");
+    cells16 = getenv("AB_CELLS16") != nullptr;
+    if (cells16 && (!plan_create16 || !solve_device16)) { fprintf(stderr, "%s: no kas_plan_create16 / kas_solve_device16\n", path); return false; }
     return true;
   }
 };
@@ -127,8 +138,8 @@ int main(int argc, char** argv) {
   bd.n_scenarios = S; bd.n_topics = S * T; bd.scenarios = scen.data(); bd.topics = topics.data();
   bd.node_id = node_id.data(); bd.node_rack = node_rack.data(); bd.node_pool_len = (int64_t)node_id.size();
   if (getenv("AB_CELLS16")) {
-    // timing experiment (libraries built with -DKAS_TUNE_CELLS16 only): every topic's rows as uint16 node indices, packed
-    // at the start of the topic's own int32 region (same offsets); node i has id i
+    // 16-bit cells (kas_plan_create16 / kas_solve_device16): every topic's rows as uint16 node indices — packed at the start
+    // of the pools, the descriptors' offsets count cells either way; node i has id i
     for (int s = 0; s < S; ++s) {
       const kas_scenario_desc& sd = scen[s];
       std::vector<int32_t> index_of((size_t)N0 + 64, -1);
@@ -136,7 +147,7 @@ int main(int argc, char** argv) {
       for (int k = 0; k < T; ++k) {
         const kas_topic_desc& td = topics[(size_t)s * T + k];
         const int32_t* src = cur.data() + td.cur_off;
-        uint16_t* dst = reinterpret_cast<uint16_t*>(cur.data() + td.cur_off);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(cur.data()) + td.cur_off;   // (in place, ascending: byte 2 i <= byte 4 i)
         const int64_t n = (int64_t)td.n_partitions * td.cur_width;
         for (int64_t i = 0; i < n; ++i) { const int32_t ix = index_of[(size_t)src[i]]; dst[i] = ix < 0 ? (uint16_t)0xffffu : (uint16_t)ix; }
       }
@@ -204,19 +215,19 @@ int main(int argc, char** argv) {
     kas_ctx* ctx = nullptr;
     kas_plan* plan = nullptr;
     if (api.ctx_create(0, &ctx) != 0) { fprintf(stderr, "%s: kas_ctx_create: %s\n", argv[li], api.last_error()); return 4; }
-    if (api.plan_create(ctx, &bd, &plan) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
+    if (api.make_plan(ctx, &bd, &plan) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
     const unsigned flags = getenv("AB_FLAGS") ? (unsigned)strtoul(getenv("AB_FLAGS"), nullptr, 0) : 0u;
     if (flags && api.set_flags(plan, flags) != 0) { fprintf(stderr, "%s: kas_plan_set_flags: %s\n", argv[li], api.last_error()); return 4; }
     char what[1024];
     api.plan_describe(plan, what, sizeof what);
     HIP_OK(hipMemset(d_out, 0xff, 4 * cells)); HIP_OK(hipMemset(d_sr, 0, sizeof(kas_scenario_result) * S));
-    if (api.solve_device(plan, &t, nullptr) != 0 || api.ctx_synchronize(ctx) != 0) { fprintf(stderr, "%s: solve: %s\n", argv[li], api.last_error()); return 5; }
+    if (api.solve(plan, &t, nullptr) != 0 || api.ctx_synchronize(ctx) != 0) { fprintf(stderr, "%s: solve: %s\n", argv[li], api.last_error()); return 5; }
     double f = 0, o = 0;
     int n = 0;
     api.phase_times(plan, &f, &o, &n);                       // (resets the accumulator: the first solve is warm-up)
     const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < reps; ++r)
-      if (api.solve_device(plan, &t, nullptr) != 0) { fprintf(stderr, "%s: solve: %s\n", argv[li], api.last_error()); return 5; }
+      if (api.solve(plan, &t, nullptr) != 0) { fprintf(stderr, "%s: solve: %s\n", argv[li], api.last_error()); return 5; }
     if (api.ctx_synchronize(ctx) != 0) { fprintf(stderr, "%s: sync: %s\n", argv[li], api.last_error()); return 5; }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
     api.phase_times(plan, &f, &o, &n);
@@ -239,7 +250,7 @@ int main(int argc, char** argv) {
       std::vector<hipStream_t> streams((size_t)K);
       std::vector<kas_tables> tabs((size_t)K, t);
       for (int k = 0; k < K; ++k) {
-        if (api.plan_create(ctx, &bd, &plans[k]) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
+        if (api.make_plan(ctx, &bd, &plans[k]) != 0) { fprintf(stderr, "%s: kas_plan_create: %s\n", argv[li], api.last_error()); return 4; }
         if (flags) api.set_flags(plans[k], flags);
         HIP_OK(hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking));
         if (getenv("AB_DISTINCT") && k > 0) {                    // every slot its own copy of the cur table (bench.py's regime: no slot
@@ -250,14 +261,14 @@ int main(int argc, char** argv) {
         int32_t* o = nullptr; kas_topic_result* tr = nullptr; kas_scenario_result* srk = nullptr;
         HIP_OK(hipMalloc(&o, 4 * cells)); HIP_OK(hipMalloc(&tr, sizeof(kas_topic_result) * S * T)); HIP_OK(hipMalloc(&srk, sizeof(kas_scenario_result) * S));
         tabs[k].out = o; tabs[k].topic_results = tr; tabs[k].scenario_results = srk;
-        if (api.solve_device(plans[k], &tabs[k], streams[k]) != 0) { fprintf(stderr, "solve: %s\n", api.last_error()); return 5; }   // set-up solve
+        if (api.solve(plans[k], &tabs[k], streams[k]) != 0) { fprintf(stderr, "solve: %s\n", api.last_error()); return 5; }   // set-up solve
       }
       HIP_OK(hipDeviceSynchronize());
       printf("   in flight, %d plans x %d steps:", K, steps);
       for (int rep = 0; rep < repeats; ++rep) {
         const auto a0 = std::chrono::steady_clock::now();
         for (int i = 0; i < steps; ++i)
-          if (api.solve_device(plans[i % K], &tabs[i % K], streams[i % K]) != 0) { fprintf(stderr, "solve: %s\n", api.last_error()); return 5; }
+          if (api.solve(plans[i % K], &tabs[i % K], streams[i % K]) != 0) { fprintf(stderr, "solve: %s\n", api.last_error()); return 5; }
         HIP_OK(hipDeviceSynchronize());
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count();
         printf(" %.1fk scenarios/s", (double)S * steps / sec / 1e3);
