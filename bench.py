@@ -54,7 +54,7 @@ import time
 
 # The HIP runtime multiplexes streams onto 4 hardware queues by default; steps in flight on more
 # streams than that would serialise in pairs.  Must be set before the runtime is loaded.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -96,11 +96,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the one-batch-alone, literal-mix, end-to-end and other-config legs")
-    ap.add_argument("--in-flight", type=int, default=20,
+    ap.add_argument("--in-flight", type=int, default=12,
                     help="batches in flight: steps are issued round-robin on this many HIP streams, "
-                         "each slot with its own tables, broker sets, plan scratch and outputs (round 5, 16-bit cells: 20 — "
-                         "every step of the driver's 20-step region on a slot of its own, 855-872k scenarios/s against 830-838k at "
-                         "12 on one box, scripts/trip_slots.sh; before that 12 — with every "
+                         "each slot with its own tables, broker sets, plan scratch and outputs (round 5: 12 — with every "
                          "slot's stream on a hardware queue of its own 10-12 slots read 2-5 %% above 8 in the driver's "
                          "20-step region, whose slots start in phase; rounds 3-4: 8, when two pairs of slots shared a queue)")
     ap.add_argument("--same-batch", action="store_true",

@@ -76,7 +76,7 @@ for step in "$@"; do
       cd $R ;;
     sq)
       cd /tmp
-      for mode in 1 ${KAS_BENCH_SLOTS:-20}; do
+      for mode in 1 ${KAS_BENCH_SLOTS:-12}; do
         timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $R/$O/prof_sq1_f$mode -o sq1 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq1_f$mode.log 2>&1; echo "sq1 f$mode exit $?"
         timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_sq2_f$mode -o sq2 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq2_f$mode.log 2>&1; echo "sq2 f$mode exit $?"
         # per-pipe: cycles a pipe spends on instructions (quad-cycle units, summed over waves), round 4
