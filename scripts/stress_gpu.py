@@ -22,11 +22,33 @@ if EMU:
 
     def solve(fb, flags=0):
         return emu_solve(fb, flags=flags)
+
+    def solve16(fb, flags=0):
+        from emu_lib import emu_solve16
+        return emu_solve16(fb, flags=flags)
 else:
     from kafka_assigner_amd import native
 
     def solve(fb, flags=0):
         return native.solve_host_with_flags(fb, flags) if flags else native.solve_host(fb)
+
+    def solve16(fb, flags=0):
+        return native.solve_device16_with_flags(fb, flags)
+
+
+n16 = 0
+
+
+def check16(fb, what, flag_sets=(0, 0x20000, 0x40000, 2)):
+    """the same batch on 16-bit node-index cells (kas_plan_create16 / kas_solve_device16) against the oracle on its index
+    form — lists up to 3 wide"""
+    global n16
+    from kafka_assigner_amd.flatten import index_form
+    want = oracle_solve(index_form(fb))
+    want.out = np.where(want.out < 0, 0xFFFF, want.out).astype(np.uint16)
+    for flags in flag_sets:
+        assert_same_outputs(fb, want, solve16(fb, flags), f"{what} 16-bit cells flags {flags}")
+    n16 += 1
 
 
 def with_context(fb, rng):
@@ -92,6 +114,7 @@ while time.time() - t0 < float(argv[1]):
         for flags in ((0, 4, 0x20000) if N <= 8191 else (0, 0x20000)):
             got = solve(fb, flags)
             assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} big-N flags {flags}")
+        check16(fb, f"seed {seed} S{S} P{P} N{N} big-N", (0, 0x20000))
         n += 1; n_big += 1
         continue
     N = int(rng.choice([8, 12, 20, 33, 64, 100, 150, 300, 500]))
@@ -108,6 +131,8 @@ while time.time() - t0 < float(argv[1]):
         for flags in ((0, 1 << 16, 2, 0x20000, 0x40000) if RF <= 3 else (0, 2)):
             got = solve(fb, flags)
             assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} Context width {int(fb.scen['ctx_width'][0])} flags {flags}")
+        if RF <= 3:
+            check16(fb, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} Context width {int(fb.scen['ctx_width'][0])}")
         n += 1; n_ctx += 1
         continue
     want = oracle_solve(fb)
@@ -116,5 +141,7 @@ while time.time() - t0 < float(argv[1]):
     for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000, 0x200000) if RF <= 3 else (0, 2, 1, 32)):
         got = solve(fb, flags)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
+    if RF <= 3:
+        check16(fb, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts}", (0, 0x20000, 0x40000, 2, 1, 0x200000, 0x400000, 0x800000))
     n += 1
-print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 1-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-12,000 brokers,", n_ctx, "with a Context in and out; seed", int(argv[2]) if len(argv) > 2 else 2026)
+print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 1-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-12,000 brokers,", n_ctx, "with a Context in and out,", n16, "also on 16-bit cells (kas_solve_device16); seed", int(argv[2]) if len(argv) > 2 else 2026)
