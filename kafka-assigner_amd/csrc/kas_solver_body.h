@@ -549,10 +549,12 @@ KAS_DEV bool full_rows(const TopicView& T) { return full_rows_of<W>(T); }
 
 template <int W, typename Body>
 KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
-  if (T.c16) {                                              // (wave-uniform: one of the four row streams runs)
+  if constexpr (W <= 3) if (T.c16) {                         // (16-bit cells: lists up to 3 wide; wave-uniform: one row stream runs)
     if (full_rows<W>(T)) for_tiles_impl<W, true, true>(T, tile0, stride, t_end, body);
     else for_tiles_impl<W, false, true>(T, tile0, stride, t_end, body);
-  } else {
+    return;
+  }
+  {
     if (full_rows<W>(T)) for_tiles_impl<W, true, false>(T, tile0, stride, t_end, body);
     else for_tiles_impl<W, false, false>(T, tile0, stride, t_end, body);
   }
@@ -560,10 +562,12 @@ KAS_DEV void for_tiles(const TopicView& T, int32_t tile0, int32_t stride, int32_
 
 template <int W, typename Body>
 KAS_DEV void for_tile_batches(const TopicView& T, int32_t tile0, int32_t stride, int32_t t_end, Body body) {
-  if (T.c16) {
+  if constexpr (W <= 3) if (T.c16) {
     if (full_rows<W>(T)) for_tile_batches_impl<W, true, true>(T, tile0, stride, t_end, body);
     else for_tile_batches_impl<W, false, true>(T, tile0, stride, t_end, body);
-  } else {
+    return;
+  }
+  {
     if (full_rows<W>(T)) for_tile_batches_impl<W, true, false>(T, tile0, stride, t_end, body);
     else for_tile_batches_impl<W, false, false>(T, tile0, stride, t_end, body);
   }
@@ -751,7 +755,7 @@ KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const No
   for (int32_t tile = 0; tile < T.nt; ++tile) {
     const int32_t p = (tile << 6) + lane;
     int32_t ids[W], idx[W], len;
-    if (T.c16) load_row<W, false, true>(T, p, ids, len);
+    if (W <= 3 && T.c16) load_row<W, false, true>(T, p, ids, len);
     else load_row<W>(T, p, ids, len);
     uint32_t accbits = 0;
 #pragma unroll
