@@ -302,7 +302,9 @@ template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
   static_assert(!(VERIFY && C16), "the sampled verification is not instantiated for 16-bit cells");
-  if constexpr (KAS_RELAX_PRIO > 0) kasw::set_priority<KAS_RELAX_PRIO>();
+  // (16-bit cells: with no broker ids to wait for the raised priority stops paying — 8 x 20 steps 815-834k scenarios/s at
+  // priority 0 against 803-815k at 3, 8 x 40 steps 833-865k against 824-853k, same box, gpurun_out/r5pr2)
+  if constexpr (KAS_RELAX_PRIO > 0 && !C16) kasw::set_priority<KAS_RELAX_PRIO>();
   const int lane = kasw::lane();
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
