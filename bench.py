@@ -155,6 +155,25 @@ def sources_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def cells16_table(torch, cur_ids, ids, n_brokers, dev):
+    """int32 broker ids [S, P, RF] -> int16 [S, P * RF] of node indices: every replica as the position of its broker in the
+    scenario's ascending broker list `ids[s]` (0xFFFF: the broker left the set), by one table lookup per scenario on `dev`
+    (what flatten.to_cells16 does on the host: tests/test_bench_harness.py holds the two to each other)."""
+    S = len(ids)
+    width = max(int(max(int(x.max()) for x in ids)) + 2, n_brokers + 2, int(cur_ids.max().item()) + 2)
+    lut = np.full((S, width), 0xFFFF, dtype=np.uint16)
+    for s, x in enumerate(ids):
+        lut[s, x] = np.arange(len(x), dtype=np.uint16)
+    d_lut = torch.from_numpy(lut.view(np.int16)).to(dev)
+    out = torch.empty((S, cur_ids.shape[1] * cur_ids.shape[2]), dtype=torch.int16, device=dev)
+    step = 64
+    for lo in range(0, S, step):
+        hi = min(S, lo + step)
+        idx = cur_ids[lo:hi].reshape(hi - lo, -1).to(torch.int64)
+        out[lo:hi] = torch.gather(d_lut[lo:hi], 1, idx)
+    return out
+
+
 # -------------------------------------------------------------------------------------------------
 # the two runs behind one interface: HIP (the product) and the CPU stub (harness self-test)
 # -------------------------------------------------------------------------------------------------
@@ -238,24 +257,8 @@ class HipRun:
         self.step_no = 0
 
     def cells_of(self, cur_ids, ids):
-        """The resident form of a slot's tables with 16-bit cells: every replica as the position of its broker in the
-        scenario's ascending broker list (0xFFFF: the broker left the set) — int16 [S, P * RF], made on the device from the
-        int32 table by one table lookup per scenario (set-up, not timed)."""
-        torch = self.torch
-        S = len(ids)
-        width = int(max(int(x.max()) for x in ids)) + 2
-        width = max(width, self.args.brokers + 2)
-        lut = np.full((S, width), 0xFFFF, dtype=np.uint16)
-        for s, x in enumerate(ids):
-            lut[s, x] = np.arange(len(x), dtype=np.uint16)
-        d_lut = torch.from_numpy(lut.view(np.int16)).to(self.dev)
-        out = torch.empty((S, cur_ids.shape[1] * cur_ids.shape[2]), dtype=torch.int16, device=self.dev)
-        step = 64
-        for lo in range(0, S, step):
-            hi = min(S, lo + step)
-            idx = cur_ids[lo:hi].reshape(hi - lo, -1).to(torch.int64)
-            out[lo:hi] = torch.gather(d_lut[lo:hi], 1, idx)
-        return out
+        """The resident form of a slot's tables with 16-bit cells (cells16_table; set-up, not timed)."""
+        return cells16_table(self.torch, cur_ids, ids, self.args.brokers, self.dev)
 
     def check_ids(self, sl):
         """broker ids of the slot's scenarios as the CHECKERS see them: with 16-bit cells node i has id i"""

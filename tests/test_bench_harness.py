@@ -105,3 +105,23 @@ def test_bench_refuses_more_gpus_than_devices():
     assert r.returncode != 0
     assert "refusing" in r.stderr and "device" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_tables_with_16_bit_cells_are_the_index_form_of_flatten():
+    """bench.py keeps its tables resident as 16-bit node-index cells, converted on the device by cells16_table; the library's
+    tests convert on the host with flatten.to_cells16.  Same cells."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from kafka_assigner_amd import generator as G
+    from kafka_assigner_amd.flatten import node_set_batch, to_cells16
+    S, P, N, R, RF = 70, 300, 40, 8, 3                       # (more scenarios than one conversion chunk)
+    cur = np.stack([G.random_assignment(11 + s, P, N, R, RF) for s in range(S)])
+    sets = [G.scenario_action(5, s, N, R, actions=G.BENCH_ACTIONS, max_add=6)[1] for s in range(S)]
+    ids = [b.node_id for b in sets]
+    fb = node_set_batch(ids, [b.node_rack for b in sets], P, RF, RF, cur=cur)
+    got = bench.cells16_table(torch, torch.from_numpy(cur), ids, N, torch.device("cpu")).numpy().view(np.uint16).reshape(-1)
+    want = to_cells16(fb)
+    np.testing.assert_array_equal(got, want)
+    assert (want == 0xFFFF).any() and (want != 0xFFFF).any()
