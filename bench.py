@@ -110,9 +110,11 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=int(os.environ.get("KAS_BENCH_GROUPS", "0")),
                     help="scenarios per wavefront of the ticket-form order kernel (0 = the plan's choice)")
     ap.add_argument("--plan-flags", type=int, default=0, help="KAS_PLAN_* switches (testing)")
-    ap.add_argument("--cells", type=int, choices=(16, 32), default=16,
-                    help="cells of the tables resident in HBM: 16 = uint16 node indices (kas_plan_create16, ABI v5; lists up to "
-                         "3 wide, else 32 is taken), 32 = int32 broker ids (kas_plan_create)")
+    ap.add_argument("--cells", type=int, choices=(16, 32), default=32,
+                    help="cells of the tables resident in HBM in the TIMED REGION: 32 = int32 broker ids in, broker ids out "
+                         "(kas_plan_create; SURVEY 8(b)/(d)'s contract — the headline), 16 = uint16 node indices "
+                         "(kas_plan_create16, ABI v5; lists up to 3 wide, else 32 is taken).  The other layout is measured "
+                         "beside it on the same slots and reported as value_cells16 / value_int32_cells")
     ap.add_argument("--stub", action="store_true",
                     help="harness self-test on CPU (gloo, synthetic records): NOT a measurement")
     return ap.parse_args(argv)
@@ -198,7 +200,7 @@ class HipRun:
         S, P, N, R, RF = hi - lo, args.partitions, args.brokers, args.racks, args.rf
         self.S, self.lo = S, lo
         self.ctx = native.DeviceContext(local_rank)
-        self.cells16 = getattr(args, "cells", 16) == 16 and RF <= 3
+        self.cells16 = getattr(args, "cells", 32) == 16 and RF <= 3
         self.n_slots = max(1, min(args.in_flight, args.steps))
         self.distinct = 1 if args.same_batch else self.n_slots
         # every slot its own current assignments (slot 0's are the ones rounds 1 and 2 measured)
@@ -285,40 +287,60 @@ class HipRun:
         h[h == 0xFFFF] = -1
         return h
 
-    def int32_cells_rate(self, n_steps):
-        """The same slots through kas_plan_create / kas_solve_device (int32 broker ids in HBM): scenarios per second over
-        n_steps steps round-robin, for the line's comparison figure.  Builds and drops its own plans and out tables."""
+    def other_cells_rate(self, n_steps, n_regions=3):
+        """The same slots (same scenarios, same broker sets, same streams) with the OTHER cell layout resident in HBM, for the
+        line's second figure: with int32 broker ids timed as the headline, uint16 node-index cells (kas_plan_create16 /
+        kas_solve_device16; the id -> index conversion of the tables is set-up here, outside the region: what a caller that
+        keeps its tables in that form has done already); with --cells 16, int32 broker ids (kas_plan_create /
+        kas_solve_device).  n_regions regions of n_steps steps round-robin, median.  Builds and drops its own plans and
+        tables; returns (dict, records of slot 0's last solve)."""
         torch = self.torch
-        from kafka_assigner_amd import native
+        from kafka_assigner_amd import abi, native
         args = self.args
+        to16 = not self.cells16
+        if to16 and args.rf > 3:
+            return None, None
         extra = []
         for sl in self.slots:
-            plan_ = native.Plan(self.ctx, sl["fb"])
+            plan_ = native.Plan(self.ctx, sl["fb"], cells16=to16)
             if args.waves or args.groups or args.plan_flags:
                 plan_.set_flags((args.waves << 8) | (args.groups << 12) | args.plan_flags)
-            extra.append((plan_, torch.empty(sl["fb"].out_len, dtype=torch.int32, device=self.dev)))
+            cur = self.cells_of(sl["cur_ids"], sl["ids"]) if to16 else sl["cur_ids"]
+            extra.append((plan_, cur, torch.empty(sl["fb"].out_len, dtype=torch.int16 if to16 else torch.int32, device=self.dev)))
+        self.synchronize()
 
         def go(k):
-            sl, (plan_, out) = self.slots[k % self.n_slots], extra[k % self.n_slots]
-            plan_.solve_device(sl["cur_ids"].data_ptr(), out.data_ptr(), sl["tr"].data_ptr(), sl["sr"].data_ptr(),
+            sl, (plan_, cur, out) = self.slots[k % self.n_slots], extra[k % self.n_slots]
+            plan_.solve_device(cur.data_ptr(), out.data_ptr(), sl["tr"].data_ptr(), sl["sr"].data_ptr(),
                                stream=sl["stream"].cuda_stream)
         for k in range(self.n_slots):
             go(k)
         self.synchronize()
-        t0 = time.perf_counter()
-        for k in range(n_steps):
-            go(k)
-        self.synchronize()
-        el = time.perf_counter() - t0
+        walls = []
+        for _ in range(max(1, n_regions)):
+            t0 = time.perf_counter()
+            for k in range(n_steps):
+                go(k)
+            self.synchronize()
+            walls.append(time.perf_counter() - t0)
+        el = sorted(walls)[(len(walls) - 1) // 2]
+        rec0 = self.slots[0]["sr"].cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE).copy()
         what = extra[0][0].describe()
-        for plan_, _ in extra:
+        alg = extra[0][0].algorithmic_bytes
+        for plan_, _, _ in extra:
             plan_.close()
         del extra
-        # (the slots' records were overwritten by these solves: one solve each puts the product's back)
+        # (the slots' records were overwritten by these solves: one solve each puts the headline layout's back)
         for sl in self.slots:
             self.solve(sl)
         self.synchronize()
-        return self.S * n_steps / el, 1e3 * el / n_steps, what
+        ms = 1e3 * el / n_steps
+        res = {"value": self.S * n_steps / el, "unit": "scenarios/s", "ms_per_step": ms, "steps": n_steps,
+               "regions": [self.S * n_steps / w for w in walls], "kernel": what,
+               "dtype": "uint16 node index" if to16 else "int32",
+               "algorithmic_bytes_per_launch": alg,
+               "achieved": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        return res, rec0
 
     def solve(self, sl):
         sl["plan"].solve_device(sl["cur"].data_ptr(), sl["out"].data_ptr(), sl["tr"].data_ptr(),
@@ -546,13 +568,10 @@ def run_rank(args) -> int:
     long_steps = 2 * args.steps
     long_reps = [] if args.stub or args.no_extras else [timed(long_steps, 0) for _ in range(3)]
     run.phase_times()
-    # the same slots with int32 broker ids resident in HBM (kas_plan_create / kas_solve_device), for comparison
-    int32_cells = None
-    if not args.stub and not args.no_extras and world == 1 and getattr(run, "cells16", False):
-        v32, ms32, what32 = run.int32_cells_rate(args.steps)
-        int32_cells = {"value": v32, "unit": "scenarios/s", "ms_per_step": ms32, "steps": args.steps, "kernel": what32,
-                       "note": "one region of the same steps, tables as int32 broker ids (12 + 12 bytes per row of three replicas "
-                               "read and written instead of 6 + 6)"}
+    # the same slots with the OTHER cell layout resident in HBM (HipRun.other_cells_rate), reported beside the headline
+    other_cells, other_rec0 = None, None
+    if not args.stub and not args.no_extras and world == 1:
+        other_cells, other_rec0 = run.other_cells_rate(args.steps)
 
     if args.stats and rank == 0 and not args.stub:
         st = run.slots[0]["plan"].stats().astype(np.float64)
@@ -662,7 +681,8 @@ def run_rank(args) -> int:
             "metric": "assignment scenarios/sec at 100k partitions x 1k brokers RF=3",
             "value": value, "unit": "scenarios/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "uint16 node index" if getattr(run, "cells16", False) else "int32",
             "data": "synthetic",
             "repeats": {"n": n_rep, "value_is": "median repeat", "values": rates, "min": min(rates), "max": max(rates),
                         "spread_pct": 100.0 * (max(rates) - min(rates)) / value if value > 0 else None,
@@ -690,8 +710,9 @@ def run_rank(args) -> int:
                 "batches_in_flight": run.n_slots, "distinct_batches_in_flight": run.distinct,
                 "cells": ("uint16 node indices resident in HBM (kas_plan_create16 / kas_solve_device16, ABI v5): a replica is the "
                           "position of its broker in the scenario's ascending broker list; parity: the CPU solvers on the index "
-                          "form of every batch" if getattr(run, "cells16", False) else "int32 broker ids resident in HBM"),
-                "int32_cells": int32_cells,
+                          "form of every batch" if getattr(run, "cells16", False) else
+                          "int32 broker ids resident in HBM in, broker ids out (SURVEY 8(b)/(d): the id -> node lookup of KAS:118-119 "
+                          "and the ids of KAS:231-236 are inside the timed solve)"),
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "setup_solves_per_slot": 0 if args.stub else 1,
                 "literal_c3_mix": literal,
@@ -699,6 +720,28 @@ def run_rank(args) -> int:
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        # the other cell layout on the same slots: flat scalars (a record parser that drops nested objects keeps them) and the
+        # whole leg under config; every frac is the layout's OWN bytes over its OWN time
+        out_line["frac"] = roof["frac"]
+        out_line["algorithmic_bytes_per_launch"] = alg_bytes
+        if other_cells is not None:
+            tag = "int32_cells" if getattr(run, "cells16", False) else "cells16"
+            for f in ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions"):
+                assert (other_rec0[f] == slot_records[0][f]).all(), f"{tag}: {f} of slot 0 differs between the two cell layouts"
+            other_cells["records_checked"] = (f"status, failing topic / partition and movement counts of slot 0's {S} scenarios equal "
+                                              "the headline layout's (whose records and lists are checked against the CPU solvers)")
+            if tag == "cells16":
+                other_cells["note"] = ("the same scenarios with the tables resident as uint16 node indices (ABI v5): the id -> index "
+                                       "map of cur and the index -> id map of out are the CALLER's here (set-up, outside the region), "
+                                       "which is why this is not the headline; frac = this layout's own bytes (2 P (cw + ow) + 4 N per "
+                                       "scenario) over its own time")
+            else:
+                other_cells["note"] = "the same scenarios with int32 broker ids in and out (SURVEY 8(d)'s contract)"
+            out_line["config"][tag] = other_cells
+            out_line["value_" + tag] = other_cells["value"]
+            out_line["ms_per_step_" + tag] = other_cells["ms_per_step"]
+            out_line["frac_" + tag] = other_cells["frac"]
+            out_line["dtype_" + tag] = other_cells["dtype"]
         if long_reps:
             lr = sorted(long_reps)[1]
             out_line["value_long_region"] = {"steps": long_steps, "value": total * long_steps / lr,

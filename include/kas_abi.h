@@ -215,8 +215,11 @@ void kas_plan_destroy(kas_plan* plan);
  * terminating NUL; truncated to n-1), or a negative KAS_E_* code. */
 int kas_plan_describe(const kas_plan* plan, char* buf, int n);
 
-/* Bytes of HBM the path must move per solve of this plan:
- * sum over topics 4*P*(cur_width + out_width) + sum over scenarios 8*N (+ ctx in/out). */
+/* Bytes of HBM the path must move per solve of this plan, in the plan's own cell width:
+ * kas_plan_create (int32 broker ids in and out — SURVEY 8(d)'s yardstick):
+ *   sum over topics 4*P*(cur_width + out_width) + sum over scenarios 8*N (+ ctx in/out);
+ * kas_plan_create16 (uint16 node indices; no id table is read):
+ *   sum over topics 2*P*(cur_width + out_width) + sum over scenarios 4*N (+ ctx in/out). */
 int64_t kas_plan_algorithmic_bytes(const kas_plan* plan);
 
 /* Solve with every bulk table already resident in HBM.  `hip_stream` is a hipStream_t
@@ -272,7 +275,7 @@ int kas_solve_host_select(kas_ctx* ctx, const kas_batch_desc* batch, const kas_t
  * emitted, i.e. kas_digest_cell over node indices.
  *   batch->node_id is not read and may be NULL (node i has id i); node_rack[], descriptors, aux, ctx, the result
  *   records and select / n_select (n_select < 0: every row in place) are exactly kas_solve_host_select's; descriptor
- *   offsets and cur_len / out_len count cells.  More than 65,535 brokers in a scenario: KAS_E_UNSUPPORTED.
+ *   offsets and cur_len / out_len count cells.  More than 32,767 brokers in a scenario (KAS_N_LIMIT, the limit of every plan: bit 15 of a cell means "no holder" inside the kernels): KAS_E_UNSUPPORTED.
  * On the device the batch is solved on the 16-bit cells themselves where the kernels with that I/O take it
  * (kas_plan_create16 below); any other batch is widened before and narrowed behind an int32 solve (two streaming kernels on
  * the range's solve stream). */
@@ -368,6 +371,10 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_RELAX_TILES(n) relaxation form: 1 = tiles of 64 rows, 2 = double tiles (128 rows, two rows per lane: fewer
  *                          LDS round trips per scenario, more LDS operations per row), 0 = by batch size (double
  *                          tiles for batches of fewer than 512 scenarios, where the GPU is not full of wavefronts)
+ *   KAS_PLAN_NO_INDEX_ROWS rack-diverse fill with per-chunk histograms on int32 cells: read `cur` in both row scans.  (Default,
+ *                          round 6: the first scan — which looks every broker id up, KAS:118-119's nodeMap.get — leaves the row's
+ *                          node indices where its mid row goes, the second scan streams those 2-byte cells and stores only the rows
+ *                          that do not keep all their replicas: `cur` is read ONCE, and the lookup is done once.)
  *   KAS_PLAN_NO_RTN_QUOTA  rack-diverse fill with per-chunk histograms: draw a node's quota with separate LDS atomics,
  *                          reads and a ranking of the tiles in which it runs out, instead of one atomic-with-return
  *                          per list position
@@ -390,6 +397,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_WIDE_COUNTERS 4u
 #define KAS_PLAN_TWO_PASS_HIST 8u
 #define KAS_PLAN_SPREAD_FILL  32u
+#define KAS_PLAN_NO_INDEX_ROWS 64u
 #define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_RELAX_TILES(n) (((uint32_t)(n) & 3u) << 17)
 #define KAS_PLAN_NO_RTN_QUOTA 0x200000u

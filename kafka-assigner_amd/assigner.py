@@ -126,7 +126,7 @@ class KafkaAssignmentStrategy:
             ho.out = cells16_to_ids(fb, ho.out)
             return ho
 
-        cells32 = os.environ.get("KAS_CELLS32", "") == "1" or len(set(nodes)) > 65535
+        cells32 = os.environ.get("KAS_CELLS32", "") == "1" or len(set(nodes)) > 32767
         result, _ = _solve_one(native.solve_host if cells32 else solve16, topic_name, current_assignment,
                                node_rack_assignment, nodes, partitions, replication_factor,
                                context)

@@ -345,6 +345,7 @@ struct kas_ctx {
   KasBuf h_cur, h_out, h_aux, h_ctx, h_tr, h_sr;
   KasBuf h_cur16, h_out16;              // the 16-bit cells of kas_solve_host16 as they travel (widened / narrowed on the device)
   std::vector<int32_t> ident_ids;       // node_id pool of a 16-bit call: node i of every scenario has id i
+  uint64_t ident_stamp = 0;             // ... and which node ranges it was filled for (kas_ident_batch)
   KasBuf h_tr_pin, h_sr_pin;            // pinned HOST staging of the result records (see kas_solve_host_locked)
   KasCachedPlan plans[KAS_HOST_PLAN_CACHE];
   uint64_t use_clock = 0;
@@ -358,6 +359,7 @@ struct kas_ctx {
 #define KAS_TIMER_SLOTS 64
 
 struct kas_plan {
+  int no_index_rows = 0;                // KAS_PLAN_NO_INDEX_ROWS (kas_plan_set_flags): the fill reads `cur` in both of its row scans
   kas_ctx* ctx;
   KasShape shape;
   int Wc;                       // instantiated width class
@@ -560,7 +562,7 @@ static int kas_plan_set_kernels(kas_plan* p) {
       if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16))
         KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx)));
+                                      kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx, KAS_RELAX_LDS_IDS && !p->cells16)));
   if (p->shape.with_x && kas_p4_lds_layout(p->shape.n_max).total <= KAS_LDS_LIMIT)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_p4_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_p4_lds_layout(p->shape.n_max).total));
@@ -588,6 +590,13 @@ static int kas_plan_set_kernels(kas_plan* p) {
 // per-chunk histograms: what the shape allows unless switched off (or the general fill is forced)
 static bool kas_plan_fused(const kas_plan* p) {
   return p->fused && !(p->flags & (KAS_FLAG_TWO_PASS_HIST | KAS_FLAG_GENERIC_FILL));
+}
+
+// index rows in this plan's next solve (KAS_FLAG_INDEX_ROWS; the kernel still decides per topic: rows of the batch's width, a
+// direct id table): int32 cells, lists up to 3 wide, per-chunk histograms, the quota drawn with the atomic-with-return
+static bool kas_plan_index_rows(const kas_plan* p) {
+  return !p->cells16 && !p->no_index_rows && p->Wc <= 3 && kas_plan_fused(p) && p->ctx->lds_lane_order_ok &&
+         !(p->flags & KAS_FLAG_NO_RTN_QUOTA) && p->shape.n_max < 0x3fff && p->shape.idmap_entries > 0;
 }
 
 // chunks per scenario of the spread fill for this plan's next solve, or 0 (one-workgroup fill kernel)
@@ -632,7 +641,7 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   p->Wc = sh.Wc; p->NW = sh.NW; p->G = sh.G;
   p->tickets = sh.tickets_ok; p->fused = sh.fused_ok;
   p->lds = sh.lds; p->lds_fused = sh.lds_fused;
-  p->flags = 0;
+  p->flags = 0; p->no_index_rows = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
   p->sp_alloc_chunks = 0;
@@ -728,18 +737,32 @@ int kas_plan_create(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_pl
   return kas_plan_new(ctx, batch, nullptr, out_plan);
 }
 
-// 16-bit cells are node indices: the node table the kernels see gives node i the id i (`ids` holds it, `out` = *b with it)
-static int kas_ident_batch(const kas_batch_desc* b, std::vector<int32_t>* ids, kas_batch_desc* out) {
+// 16-bit cells are node indices: the node table the kernels see gives node i the id i (`ids` holds it, `out` = *b with it).
+// `ids` may be a table an earlier call filled (the context's): it is rewritten only where the scenarios' node ranges
+// differ from the ones it was filled for (`stamp`: a hash of them) — a what-if caller's 1000 x 1000 table stays.
+static int kas_ident_batch(const kas_batch_desc* b, std::vector<int32_t>* ids, kas_batch_desc* out, uint64_t* stamp = nullptr) {
   if (b->n_scenarios < 0 || b->node_pool_len < 0 || (b->n_scenarios > 0 && !b->scenarios))
     return set_error(KAS_E_INVALID_ARG, "negative size / scenarios == NULL");
-  ids->assign((size_t)b->node_pool_len, 0);
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)b->node_pool_len;
   for (int32_t s = 0; s < b->n_scenarios; ++s) {
     const kas_scenario_desc& sd = b->scenarios[s];
     if (sd.n_nodes < 0 || sd.node_off < 0 || sd.node_off + sd.n_nodes > b->node_pool_len)
       return set_error(KAS_E_INVALID_ARG, "scenario " + std::to_string(s) + ": node table outside the node pool");
-    if (sd.n_nodes > 65535)
-      return set_error(KAS_E_UNSUPPORTED, "scenario " + std::to_string(s) + ": more than 65,535 brokers do not fit 16-bit cells");
-    for (int32_t i = 0; i < sd.n_nodes; ++i) (*ids)[(size_t)(sd.node_off + i)] = i;
+    // (a cell's bit 15 says "no holder" inside the kernels, mid_to_index: an index is below 32,768 — KAS_N_LIMIT, the
+    // limit of every plan; 0xFFFF is the only cell value above it that means anything)
+    if (sd.n_nodes > KAS_N_LIMIT)
+      return set_error(KAS_E_UNSUPPORTED, "scenario " + std::to_string(s) + ": more than 32,767 brokers do not fit 16-bit cells");
+    h = (h ^ (((uint64_t)(uint32_t)sd.node_off << 32) | (uint32_t)sd.n_nodes)) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  h |= 1ull;
+  if (!(stamp && *stamp == h && ids->size() == (size_t)b->node_pool_len)) {
+    ids->assign((size_t)b->node_pool_len, 0);
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      const kas_scenario_desc& sd = b->scenarios[s];
+      for (int32_t i = 0; i < sd.n_nodes; ++i) (*ids)[(size_t)(sd.node_off + i)] = i;
+    }
+    if (stamp) *stamp = h;
   }
   *out = *b;
   out->node_id = ids->data();
@@ -775,7 +798,8 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD;
   if (lp.relax) {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
-    lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios), p->shape.any_ctx);
+    lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios), p->shape.any_ctx,
+                                               KAS_RELAX_LDS_IDS && !p->cells16);
   } else if (lp.tickets) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
     lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed) + KAS_TUNE_ORDER_LDS_PAD;
@@ -835,13 +859,14 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
     snprintf(p4, sizeof(p4), " + kas_p4_kernel<%d> grid=%ux%u lds=%zu", p->Wc, (unsigned)p->n_scenarios, 64u * KAS_P4_KERNEL_WAVES,
              (size_t)kas_p4_lds_layout(p->shape.n_max).total);
   const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s%s + %s%s", spread, p->Wc, p->NW,
-                           generic ? "sweeps" : (kas_plan_fused(p) ? "quota, chunk histograms" : "quota"), lp.fill_grid,
+                           generic ? "sweeps" : (kas_plan_fused(p) ? (kas_plan_index_rows(p) && chunks == 0 ? "quota, chunk histograms, index rows" : "quota, chunk histograms") : "quota"), lp.fill_grid,
                            lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", p4, order, p->cells16 ? " [16-bit cells]" : "");
   return len < n ? len : n - 1;
 }
 
 int64_t kas_plan_algorithmic_bytes(const kas_plan* plan) {
-  return plan ? plan->shape.algorithmic_bytes : -1;
+  if (!plan) return -1;
+  return plan->cells16 ? plan->shape.algorithmic_bytes16 : plan->shape.algorithmic_bytes;   // (the plan's own cell width)
 }
 
 static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_stream);
@@ -890,7 +915,7 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
             (kas_plan_fused(p) ? KAS_FLAG_FUSED_HIST : 0u) |
             (kas_relax_double_tiles(p->flags, p->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
             ((p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA)) ? KAS_FLAG_LANE_ORDER : 0u) |
-            (p->cells16 ? KAS_FLAG_CELLS16 : 0u);
+            (p->cells16 ? KAS_FLAG_CELLS16 : 0u) | (kas_plan_index_rows(p) ? KAS_FLAG_INDEX_ROWS : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
   const bool split_p4 = kas_plan_split_p4(p);
@@ -1060,6 +1085,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
+  p->no_index_rows = (flags & KAS_PLAN_NO_INDEX_ROWS_BIT) != 0u;
   p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this
@@ -1195,7 +1221,8 @@ static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_p
   const size_t desc_bytes = 16 + sb + tb + 2 * nb;
   uint64_t key = 0xcbf29ce484222325ull;
   for (int i = 0; i < 5; ++i) if (seg_bytes[i]) key = kas_hash64(key, seg[i], seg_bytes[i]);
-  const uint64_t sig = kas_hash64(0x84222325cbf29ce4ull, hdr, 8) ^ kas_hash64(0, b->topics, tb);   // (S, T) + topic descriptors
+  // (S, T) + topic descriptors + the cell width: a plan for the other cell width is never the one rebuilt in place
+  const uint64_t sig = kas_hash64(0x84222325cbf29ce4ull, hdr, 8) ^ kas_hash64(0, b->topics, tb) ^ (cells16 ? 0x5bd1e995c16c16c1ull : 0ull);
   auto same_bytes = [&](const std::vector<unsigned char>& have) {
     if (have.size() != desc_bytes) return false;
     size_t off = 0;
@@ -1387,7 +1414,7 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   // 16-bit cells are node indices: the node table the kernels see gives node i the id i (h->cur / h->out are unused)
   kas_batch_desc ident_batch;
   if (c16) {
-    const int irc = kas_ident_batch(batch, &ctx->ident_ids, &ident_batch);
+    const int irc = kas_ident_batch(batch, &ctx->ident_ids, &ident_batch, &ctx->ident_stamp);
     if (irc != KAS_E_OK) return irc;
     batch = &ident_batch;
   }
@@ -1402,6 +1429,13 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     if (rc != KAS_E_OK) return set_error(rc, err);
   }
   const int64_t S = batch->n_scenarios, T = batch->n_topics;
+  // A 16-bit call is solved on its 16-bit cells where the kernels with that I/O take the batch (what kas_plan_create16
+  // accepts: lists up to 3 wide, relaxation or round form — kas_plan_build's test, made HERE on the shape: a batch the
+  // 16-bit kernels refuse never reaches the plan cache with the 16-bit bit set); any other batch is widened
+  // before and narrowed behind an int32 solve.
+  bool native16 = c16 != nullptr && full.Wc <= 3 &&
+                  ((full.relax_ok && ctx->lds_lane_order_ok && kas_order_relax_for(full.Wc, 0, 0, 0, 1) != nullptr) || full.round_fits);
+  const bool need32 = c16 == nullptr || !native16;             // int32 cell pools on the device
   if (h->cur_len < full.cur_need || (all_rows && h->out_len < full.out_need) || h->aux_len < full.aux_need ||
       h->ctx_len < full.ctx_need)
     return set_error(KAS_E_INVALID_ARG, "a descriptor offset reaches beyond the pool length given in kas_tables");
@@ -1431,8 +1465,9 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   // descriptors' absolute offsets apply (+ 8 ints: the fill kernel's full-row loads re-read the last
   // row for lanes past the end)
   int rc;
-  if ((rc = kas_host_buf(ctx, &ctx->h_cur, sizeof(int32_t) * (size_t)(full.cur_need - full.cur_lo + 8))) != KAS_E_OK) return rc;
-  if ((rc = kas_host_buf(ctx, &ctx->h_out, sizeof(int32_t) * (size_t)(full.out_need - full.out_lo + 8))) != KAS_E_OK) return rc;
+  // (a 16-bit call solved on its own cells never touches the int32 pools: not reserved for it)
+  if (need32 && (rc = kas_host_buf(ctx, &ctx->h_cur, sizeof(int32_t) * (size_t)(full.cur_need - full.cur_lo + 8))) != KAS_E_OK) return rc;
+  if (need32 && (rc = kas_host_buf(ctx, &ctx->h_out, sizeof(int32_t) * (size_t)(full.out_need - full.out_lo + 8))) != KAS_E_OK) return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_aux, sizeof(int32_t) * (size_t)(full.aux_need - full.aux_lo + 8))) != KAS_E_OK) return rc;
   if ((rc = kas_host_buf(ctx, &ctx->h_ctx, sizeof(int32_t) * (size_t)(full.ctx_need - full.ctx_lo + 8))) != KAS_E_OK) return rc;
   if (c16 && ((rc = kas_host_buf(ctx, &ctx->h_cur16, sizeof(uint16_t) * (size_t)(full.cur_need - full.cur_lo + 8))) != KAS_E_OK ||
@@ -1448,8 +1483,8 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
   if ((rc = kas_host_pinned(ctx, &ctx->h_sr_pin, sizeof(kas_scenario_result) * (size_t)(S + 1))) != KAS_E_OK) return rc;
   kas_topic_result* p_tr = (kas_topic_result*)ctx->h_tr_pin.p;
   kas_scenario_result* p_sr = (kas_scenario_result*)ctx->h_sr_pin.p;
-  int32_t* d_cur = (int32_t*)ctx->h_cur.p - full.cur_lo;
-  int32_t* d_out = (int32_t*)ctx->h_out.p - full.out_lo;
+  int32_t* d_cur = need32 ? (int32_t*)ctx->h_cur.p - full.cur_lo : nullptr;
+  int32_t* d_out = need32 ? (int32_t*)ctx->h_out.p - full.out_lo : nullptr;
   uint16_t* d_cur16 = c16 ? (uint16_t*)ctx->h_cur16.p - full.cur_lo : nullptr;
   uint16_t* d_out16 = c16 ? (uint16_t*)ctx->h_out16.p - full.out_lo : nullptr;
   int32_t* d_aux = (int32_t*)ctx->h_aux.p - full.aux_lo;
@@ -1496,17 +1531,12 @@ static int kas_solve_host_locked(kas_ctx* ctx, const kas_batch_desc* batch, cons
     if (ok) break;
     K = 1;                                                     // shared or interleaved tables: one range
   }
-  // A 16-bit call is solved on its 16-bit cells where the kernels with that I/O take the batch (kas_plan_create16's
-  // plans: lists up to 3 wide, relaxation form); any other batch is widened before and narrowed behind an int32 solve.
-  bool native16 = c16 != nullptr;
   for (KasChain& c : chains) {
     rc = kas_host_plan(ctx, &c.bd, &c.plan, native16 ? 1 : 0);
-    if (rc == KAS_E_UNSUPPORTED && native16) { native16 = false; break; }
+    if (rc == KAS_E_UNSUPPORTED && native16)                   // (cannot happen: a range's shape is a part of the batch's)
+      return set_error(KAS_E_UNSUPPORTED, "internal: a scenario range of a batch the 16-bit kernels take was refused by them: " + g_last_error);
     if (rc != KAS_E_OK) return rc;
   }
-  if (c16 && !native16)
-    for (KasChain& c : chains)
-      if ((rc = kas_host_plan(ctx, &c.bd, &c.plan, 0)) != KAS_E_OK) return rc;
 
   // ---- enqueue.  From here on every exit drains the streams first.
   if ((rc = kas_host_solve_streams(ctx, K > 1 ? K : 1)) != KAS_E_OK) return rc;

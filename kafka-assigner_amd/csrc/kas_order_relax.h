@@ -314,6 +314,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   uint32_t* rbuf = tagtab + 8;                              // [64 | 128] row words of the (double) tile
   uint32_t* stage = rbuf + (DUAL ? 128 : 64);               // [192 | 384] by pair of the (double) tile
   uint32_t* cnt2 = nullptr;                                 // (CTX) [nmax] what the rows add to count[n][2]
+  uint32_t* idt = nullptr;                                  // (KAS_RELAX_LDS_IDS, int32 cells) [nmax] the scenario's broker ids
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int64_t t_begin = kasw::clock_ticks();
   int32_t* g_ctx = nullptr;
@@ -342,6 +343,13 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     }
     cnt[n] = w;
     seed0 += w & 0xffffu; seed1 += w >> 16;
+  }
+  // the broker ids of the final rows come from the LDS, not from the L2-resident node table: a final row then waits for an
+  // LDS read (~100 cycles) where it waited for an L2 round trip (~700) on the kernel's one dependency chain
+  constexpr bool LDSIDS = KAS_RELAX_LDS_IDS && !C16;
+  if constexpr (LDSIDS) {
+    idt = stage + (DUAL ? 384 : 192) + (CTX ? nmax : 0);
+    for (int32_t n = lane; n < N; n += 64) idt[n] = (uint32_t)g_node_id[n];
   }
   if constexpr (CTX) {                                       // (wave-uniform from here on: scalar registers)
     seed0 = (uint32_t)kasw::uniform(kasw::wave_sum((int)seed0)); seed1 = (uint32_t)kasw::uniform(kasw::wave_sum((int)seed1));
@@ -591,7 +599,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
               for (int r = 0; r < W; ++r) {
                 if (r < ow) {
                   const uint32_t cell = w[r] == 0 ? c[0] : (w[r] == 1 ? c[1] : c[2]);
-                  const int32_t id = r < Lp ? (C16 ? (int32_t)cell : g_node_id[cell]) : -1;
+                  const int32_t id = r < Lp ? (C16 ? (int32_t)cell : (LDSIDS ? (int32_t)idt[cell] : g_node_id[cell])) : -1;
                   if constexpr (CTX) { if (r == 2 && r < Lp) kasw::lds_add_u32(cnt2 + cell, 1u); }
                   if constexpr (C16) out16[(int64_t)p * ow + r] = (uint16_t)id;
                   else out[(int64_t)p * ow + r] = id;
@@ -631,6 +639,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
             if constexpr (C16) pend.id[b][q] = req_l[b][q];           // (the cell IS the node index)
+            else if constexpr (LDSIDS) pend.id[b][q] = idt[req_l[b][q]];
             else kasw::gload_u32_async<0>(pend.id[b][q], uid, req_l[b][q] << 2);
           }
         pend.p = p; pend.n = req_n;
@@ -640,7 +649,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
         // flight 588k -> 620k scenarios/s, 4000 x 3 590k -> 630k, 1000 x 8 605k -> 614k), while a batch alone gains 15 %
         // from them (order kernel 1.79 -> 1.51 ms) — and a batch alone is what the double-tile instance is launched for.
         if constexpr (!DUAL) {
-          if constexpr (!C16) {
+          if constexpr (!C16 && !LDSIDS) {
             kasw::wait_loads();
 #pragma unroll
             for (int b = 0; b < NB; ++b)

@@ -65,6 +65,10 @@ struct KasLaunch {
 #define KAS_FLAG_ORDER_FLAGGED 128u // set by the launcher: the round-form order kernel takes only scenarios with ord_flag set
 #define KAS_FLAG_CELLS16      512u  // set by the launcher (plans of kas_plan_create16, ABI v5): cur / out cells are uint16 node indices (node i has id i),
                                    // out rows take the place of the mid rows they are made from
+#define KAS_FLAG_INDEX_ROWS   0x400u // set by the launcher (int32 cells, per-chunk histograms, LDS lane order; not with KAS_PLAN_NO_INDEX_ROWS): the fill's
+                                   // first row scan leaves every row's node indices where its mid row goes and the second scan streams those
+                                   // (kas_solver_body.h, fill_pass_a_fused<EMIT>): `cur` is read once, 6 instead of 12 bytes a row the second time
+#define KAS_PLAN_NO_INDEX_ROWS_BIT 64u // the user's switch (kas_plan_set_flags; its bit is KAS_FLAG_ONLY_FLAGGED's in a launch word, so it is kept beside the plan's flags)
 #define KAS_FLAG_WIDE_CHECK   256u  // set by the launcher (KasShape::wide_checked): the wide ticket form checks its count fields at the end
 #define KAS_FLAG_TICKET_ORDER 0x10000u // lists <= 3 wide: the ticket form of P5 where the relaxation form would run (testing / comparison);
                                        // KAS_PLAN_GROUPS(n) and KAS_PLAN_WIDE_COUNTERS, which only mean something to the ticket form, imply it
@@ -273,10 +277,14 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 // instance with double tiles: 128).  5,072 bytes at 1,000 brokers: four of these workgroups fit in the LDS that four
 // workgroups of the fill kernel leave free on a CU.
 // (with_ctx: the instance for batches with a Context keeps a second uint32 per node: what the rows add to count[n][2])
-KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles, int32_t with_ctx) {
+// (with_ids: the instances for int32 cells keep the scenario's broker ids in the LDS too — KAS_RELAX_LDS_IDS)
+#ifndef KAS_RELAX_LDS_IDS
+#define KAS_RELAX_LDS_IDS 0
+#endif
+KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles, int32_t with_ctx, int32_t with_ids = 0) {
   int64_t n = n_max > 0 ? n_max : 1;
   const int64_t rows = double_tiles ? 128 : 64;
-  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4 + (with_ctx ? 4 * n : 0));
+  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4 + (with_ctx ? 4 * n : 0) + (with_ids ? 4 * n : 0));
 }
 // Relaxation form: double tiles (128 rows, two rows per lane) in this launch?  A double tile halves the LDS round
 // trips a scenario waits for (one batch of 1000 alone: order kernel 2.0 -> 1.7 ms) at ~1.2 x the LDS operations per row
@@ -343,7 +351,8 @@ struct KasShape {
   int64_t orph_ints = 0;
   int32_t NW = 1;                     // wavefronts per scenario workgroup of the fill kernel
   int32_t G = 1;                      // lane groups (= scenarios) per wavefront, ticket form
-  int64_t algorithmic_bytes = 0;
+  int64_t algorithmic_bytes = 0;     // int32 broker ids in and out, 4 P (cw + ow) per topic + 8 N per scenario (+ ctx)
+  int64_t algorithmic_bytes16 = 0;   // the same for 16-bit cells (kas_plan_create16): 2 P (cw + ow) + 4 N (racks; no id table is read) (+ ctx)
   int64_t cur_need = 0, out_need = 0, aux_need = 0, ctx_need = 0;  // minimum pool lengths
   // first element of each pool a descriptor refers to (== *_need when none does): a batch that is a
   // slice of a larger one (kas_batch_slice) touches [lo, need) only, and the host path moves only that
@@ -450,9 +459,11 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (e > s.ctx_need) s.ctx_need = e;
       if (sd.n_nodes > 0 && sd.ctx_off < s.ctx_lo) s.ctx_lo = sd.ctx_off;
       s.algorithmic_bytes += 8ll * sd.n_nodes * sd.ctx_width;
+      s.algorithmic_bytes16 += 8ll * sd.n_nodes * sd.ctx_width;
     }
     if (sd.n_nodes > s.n_max) s.n_max = sd.n_nodes;
     s.algorithmic_bytes += 8ll * sd.n_nodes;
+    s.algorithmic_bytes16 += 4ll * sd.n_nodes;
     int64_t words = 0, rows = 0, rows_sum = 0, ticket_bound = 0;
     for (int32_t k = 0; k < sd.topic_count; ++k) {
       const kas_topic_desc& td = b->topics[sd.topic_begin + k];
@@ -484,6 +495,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
       if (((P + 63) / 64) * 64 > rows) rows = ((P + 63) / 64) * 64;
       rows_sum += ((P + 63) / 64) * 64;
       s.algorithmic_bytes += 4ll * P * (td.cur_width + td.out_width);
+      s.algorithmic_bytes16 += 2ll * P * (td.cur_width + td.out_width);
       // a node never holds more than cap rows of a topic (KAS:65-71, cap over <= P partitions), and
       // a ticket on node n counts the rows that hold n so far in the scenario
       if (td.rf >= 1 && td.rf <= sd.n_nodes && sd.n_nodes > 0) {
@@ -518,7 +530,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // the broker count is limited by the fill kernel's LDS only.  A Context handed in is checked per scenario by the
   // kernel (its counters + the rows to come must fit the fields; else the round form, which fits whenever a batch
   // with a Context is accepted at all)
-  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && kas_order_relax_lds(s.n_max, 1, s.any_ctx) <= KAS_LDS_LIMIT;
+  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && kas_order_relax_lds(s.n_max, 1, s.any_ctx, KAS_RELAX_LDS_IDS) <= KAS_LDS_LIMIT;
   // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
   // to the round form — which must then fit)
   s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&

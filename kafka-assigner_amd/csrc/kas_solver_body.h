@@ -348,6 +348,9 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
 // one trailing halfword through 2-byte-aligned accesses (U32a2: one global_load_dword / global_store_dword each — the
 // hardware's unaligned access mode, which the HSA ABI turns on).
 #define KAS_MID_NONE 0xffffu
+#ifndef KAS_IXROWS_SKIP_SAME
+#define KAS_IXROWS_SKIP_SAME 1
+#endif
 #ifndef KAS_MID_PAD
 #define KAS_MID_PAD 0                    // tuning builds: 1 = rows padded to an even number of cells (rounds 2-4), same accesses
 #endif
@@ -581,7 +584,7 @@ template <int W>
 KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t len,
                      const int32_t (&ids)[W], const int32_t (&idx)[W], uint32_t accbits,
                      int32_t& need, int32_t& hc, int32_t (&hrack)[W], int32_t& moved_r,
-                     int32_t& moved_p, const int32_t* racks = nullptr) {
+                     int32_t& moved_p, const int32_t* racks = nullptr, bool inplace = false) {
   const bool active = p < T.P;
   int32_t hold[W];
 #pragma unroll
@@ -609,10 +612,15 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
     need = 0;
   }
 #endif
+  // inplace (index rows, fill_pass_a_fused<EMIT>): the row's cells already lie where its mid row goes — a row that keeps every
+  // one of them, in order, is not stored again (KAS_IXROWS_SKIP_SAME=0: tuning builds store every row)
+  bool same = inplace && KAS_IXROWS_SKIP_SAME;
+#pragma unroll
+  for (int k = 0; k < W; ++k) same = same && hold[k] == idx[k];
 #if defined(KAS_TUNE_NO_MID_STORES)                          // (tuning builds: how much of the fill's time is its 8-byte row stores)
   if (false) {
 #else
-  if (active) {
+  if (active && !same) {
 #endif
     if (T.ow == W) {                                        // wave-uniform: the mid row as W / 2 dwords (+ a halfword)
       uint16_t* row = T.mid + (int64_t)p * mid_width_of<W>();
@@ -837,18 +845,36 @@ KAS_DEV int32_t node_lookup_ident(const NodeMap& m, int32_t id) {
   const uint32_t d = (uint32_t)id - (uint32_t)m.min_id;
   return d < m.range ? (int32_t)d : -1;
 }
-template <int W, int NW, bool DIRECT, bool IDENT = false>
+// EMIT (KAS_FLAG_INDEX_ROWS; int32 cells, rows exactly W wide): the pass also leaves every row's node indices — the 2 W packed
+// bytes of a mid row, 0xffff for a broker that is not in the set — where the topic's mid rows go (the end of its out region,
+// scratch until pass B writes there).  Pass B then streams THOSE rows (6 bytes instead of 12 at lists 3 wide, no id lookups,
+// and a row whose holders are its own cells — most rows — is already in place): `cur` is read once.
+template <int W, int NW, bool DIRECT, bool IDENT = false, bool EMIT = false>
 KAS_DEV bool fill_pass_a_fused(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave) {
   constexpr int D = KAS_TILES_AHEAD;
   constexpr int BW = fused_block_words<W, NW>();
   const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
   bool viol = false;
+  int32_t tb = t0;                                             // first tile of the batch the body is handed (EMIT)
+  const int lane = kasw::lane();
   for_tile_batches<W>(T, t0, 1, t1, [&](const int32_t (&ids)[D][W], const int32_t (&len)[D]) {
     int32_t idx[D][W], rk[D][W];
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
       for (int r = 0; r < W; ++r) idx[d][r] = r < len[d] ? (IDENT ? node_lookup_ident(nm, ids[d][r]) : node_lookup_as<DIRECT>(L, nm, ids[d][r])) : -1;
+    if constexpr (EMIT) {
+      static_assert(W == 2 || W == 3, "index rows: lists 2 and 3 wide");
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (len[d] != 0) {                                     // (the row exists; full rows: len == W)
+          uint16_t* row = T.mid + (int64_t)(((tb + d) << 6) + lane) * W;
+          store_u32_a2(row, ((uint32_t)idx[d][0] & 0xffffu) | ((uint32_t)idx[d][1] << 16));
+          if constexpr (W == 3) row[2] = (uint16_t)idx[d][2];
+        }
+      }
+      tb += D;
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -986,7 +1012,7 @@ KAS_DEV void fill_chunk_prefix(const LdsView& L, const TopicView& T, int32_t tid
 // (kas_wave.h, lds_add_rtn_u32; the launcher sets KAS_FLAG_LANE_ORDER where kas_ctx_create's self-test saw that order):
 // what comes back is the quota left for exactly this row, no read before, no read after, no ranking of a tile in
 // which a quota runs out.
-template <int W, bool DIRECT, int QS, bool RTN = false>
+template <int W, bool DIRECT, int QS, bool RTN = false, bool INPLACE = false>
 KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t t0, int32_t t1,
                                   int32_t* qc, int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();
@@ -1063,20 +1089,20 @@ KAS_DEV int32_t fill_pass_b_range(const LdsView& L, const TopicView& T, const No
       }
     }
     int32_t need, hc, hrack[W];
-    p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p);
+    p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p, nullptr, INPLACE);
     const uint64_t om = kasw::ballot(need > 0);
     if (need > 0) olist[ocount + kasw::count_below(om)] = p;
     ocount += kasw::popc(om);
   });
   return ocount;
 }
-template <int W, int NW, bool DIRECT, bool FUSED = false, bool RTN = false>
+template <int W, int NW, bool DIRECT, bool FUSED = false, bool RTN = false, bool INPLACE = false>
 KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap& nm, int32_t wave,
                             int32_t& moved_r, int32_t& moved_p, int64_t (&st)[8]) {
   const int32_t t0 = chunk_begin<NW>(T.nt, wave), t1 = chunk_begin<NW>(T.nt, wave + 1);
   constexpr int QS = FUSED ? fused_block_words<W, NW>() : 1;     // stride of a node's quota word
   int32_t* qc = FUSED ? L.x + wave : L.x + wave * T.N;
-  return fill_pass_b_range<W, DIRECT, QS, RTN>(L, T, nm, t0, t1, qc, moved_r, moved_p, st);
+  return fill_pass_b_range<W, DIRECT, QS, RTN, INPLACE>(L, T, nm, t0, t1, qc, moved_r, moved_p, st);
 }
 
 
@@ -1394,10 +1420,16 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
 
   // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
   bool fast = false;
+  // index rows (KAS_FLAG_INDEX_ROWS): int32 cells, per-chunk histograms, the quota drawn with the atomic-with-return, a direct
+  // id table and rows exactly W wide — pass A leaves the rows' node indices where the mid rows go and pass B streams those
+  // (workgroup-uniform; 14-bit node indices in the rewritten table below)
+  const bool ixrows = W <= 3 && NW > 1 && try_fast && fused && !T.c16 && (a.flags & KAS_FLAG_INDEX_ROWS) != 0u &&
+                      (a.flags & KAS_FLAG_LANE_ORDER) != 0u && nm.range != 0u && full_rows_of<W>(T) && N < 0x3fff;
   if (try_fast) {
     bool viol;
     if constexpr (W <= 3 && NW > 1) {
-      if (fused) viol = (T.c16 && nm.range != 0u && nm.min_id == 0) ? fill_pass_a_fused<W, NW, true, true>(L, T, nm, wave)
+      if (fused) viol = ixrows ? fill_pass_a_fused<W, NW, true, false, true>(L, T, nm, wave)
+                        : (T.c16 && nm.range != 0u && nm.min_id == 0) ? fill_pass_a_fused<W, NW, true, true>(L, T, nm, wave)
                         : (nm.range != 0u ? fill_pass_a_fused<W, NW, true>(L, T, nm, wave) : fill_pass_a_fused<W, NW, false>(L, T, nm, wave));
       else viol = nm.range != 0u ? fill_pass_a<W, NW, true>(L, T, nm, wave) : fill_pass_a<W, NW, false>(L, T, nm, wave);
     } else {
@@ -1421,7 +1453,21 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
         fill_quota_fused<W, NW>(L, T, tid);
         kasw::sync();
         { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
-        if (a.flags & KAS_FLAG_LANE_ORDER) {                   // (workgroup-uniform)
+        if (ixrows) {                                          // (workgroup-uniform)
+          st[6] += 1;                                            // (kas_plan_stats()[6] of a fill launch: topics that took index rows)
+          // pass B over the index rows pass A left in the mid region, as a topic of 16-bit cells whose node i has id i: the
+          // table it looks into is node index -> node index | r* << 14 (the broker ids are not needed again for this topic)
+          for (int32_t i = tid; i < N; i += NT)
+            L.idmap[i] = (int16_t)(uint16_t)((uint32_t)i | (((uint32_t)lds_qrs(L, i) >> 28) << 14));
+          kasw::sync();
+          TopicView T2 = T;
+          T2.c16 = true;
+          T2.cur = reinterpret_cast<const int32_t*>(T.mid);
+          NodeMap nm2;
+          nm2.n = N; nm2.min_id = 0; nm2.range = (uint32_t)N;
+          oc = fill_pass_b<W, NW, true, true, true, true>(L, T2, nm2, wave, moved_r, moved_p, st);
+        }
+        else if (a.flags & KAS_FLAG_LANE_ORDER) {              // (workgroup-uniform)
           if (nm.range != 0u) {
             // pass B reads ONE 16-bit word per cell: node index | r* << 14 (no node has index 0x3fff: the LDS ends
             // at 13,492 brokers; an id that is no broker keeps 0xffff) — the id table is not looked up again for

@@ -355,8 +355,8 @@ def to_cells16(fb: FlatBatch) -> np.ndarray:
         if s < 0:
             continue
         n, off = int(fb.scen["n_nodes"][s]), int(fb.scen["node_off"][s])
-        if n > 65535:
-            raise ValueError("more than 65,535 brokers do not fit 16-bit cells")
+        if n > 32767:
+            raise ValueError("more than 32,767 brokers do not fit 16-bit cells (KAS_N_LIMIT)")
         ids = fb.node_id[off:off + n]
         lo, cells = int(td["cur_off"]), int(td["n_partitions"]) * int(td["cur_width"])
         if cells <= 0:

@@ -23,7 +23,7 @@ final class NativeAssignmentStrategy {
     /** 16-bit cells (kas_solve_host16, ABI v5): cur[] and out[] travel as positions in the scenario's ascending broker
      *  list, two bytes a cell — half the bytes over the host link.  Used whenever no cur table is shared by several
      *  scenarios (a what-if batch shares ONE table among different broker sets, which has no such form) and every
-     *  broker set has at most 65,535 members; false = int32 broker ids always. */
+     *  broker set has at most 32,767 members; false = int32 broker ids always. */
     static volatile boolean cells16 = true;
     /** HIP device the calls of this JVM run on (one native context per device). */
     static volatile int device = 0;
@@ -134,7 +134,7 @@ final class NativeAssignmentStrategy {
         final Object NO_PARTITIONS = new Object();
         boolean anyShared = false, small = true;
         for (ScenarioRequest sc : batch) {
-            small = small && sc.nodes.size() <= 65535;
+            small = small && sc.nodes.size() <= 32767;
             List<TreeMap<Integer, List<Integer>>> perTopic = new ArrayList<TreeMap<Integer, List<Integer>>>();
             for (TopicRequest t : sc.topics) {
                 java.util.IdentityHashMap<Object, TreeMap<Integer, List<Integer>>> byParts = seen.get(t.currentAssignment);

@@ -103,7 +103,7 @@ class KafkaAssignmentStrategy {
     if (ow > KAS_MAX_WIDTH) throw SolverError("replica lists longer than KAS_MAX_WIDTH");
     // 16-bit cells (kas_solve_host16, ABI v5): a replica travels as the position of its broker in node_id[] — half the bytes
     // of the per-topic call (KTA:70-71) over the host link; KAS_CELLS32=1 in the environment keeps int32 broker ids
-    const bool cells16 = N <= 65535 && !(getenv("KAS_CELLS32") && getenv("KAS_CELLS32")[0] == '1');
+    const bool cells16 = N <= 32767 && !(getenv("KAS_CELLS32") && getenv("KAS_CELLS32")[0] == '1');
     std::vector<int32_t> aux(3 * (size_t)P), cur(cells16 ? 0 : (size_t)P * std::max(cw, 1), -1);
     std::vector<uint16_t> cur16(cells16 ? (size_t)P * std::max(cw, 1) : 0, (uint16_t)KAS_CELL16_NONE);
     {

@@ -84,6 +84,20 @@ for step in "$@"; do
         timeout 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LDS_ATOMIC_RETURN SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/$O/prof_sq4_f$mode -o sq4 -- python $R/bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps $((2 * mode)) --warmup 1 --in-flight $mode > $R/$O/prof_sq4_f$mode.log 2>&1; echo "sq4 f$mode exit $?"
       done
       cd $R ;;
+    sqc5)   # SQ counter passes of configs[4] x1 (1M x 5k x RF 5, one scenario): where kas_order_wide_kernel<5>'s time goes
+      cd /tmp
+      C5="--no-cpu --no-extras --repeats 1 --check 0 --scenarios 1 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 3 --warmup 1"
+      timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $R/$O/prof_c5sq1 -o sq1 -- python $R/bench.py $C5 > $R/$O/prof_c5sq1.log 2>&1; echo "c5 sq1 exit $?"
+      timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/prof_c5sq2 -o sq2 -- python $R/bench.py $C5 > $R/$O/prof_c5sq2.log 2>&1; echo "c5 sq2 exit $?"
+      timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES --output-format csv -d $R/$O/prof_c5sq3 -o sq3 -- python $R/bench.py $C5 > $R/$O/prof_c5sq3.log 2>&1; echo "c5 sq3 exit $?"
+      timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LDS_ATOMIC_RETURN SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/$O/prof_c5sq4 -o sq4 -- python $R/bench.py $C5 > $R/$O/prof_c5sq4.log 2>&1; echo "c5 sq4 exit $?"
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_trace_config5 -o trace -- python $R/bench.py $C5 > $R/$O/prof_trace_c5.log 2>&1; echo "c5 trace exit $?"
+      cd $R ;;
+    ab32:*)   # benchq with that tuning build and extra plan flags: ab32:LIB:FLAGS (e.g. ab32:base:64 = no index rows)
+      rest=${step#ab32:}; lib=${rest%%:*}; pf=${rest#*:}; [ "$pf" == "$rest" ] && pf=0
+      KAS_HIP_LIB=variants/libkas_hip_$lib.so timeout 400 python bench.py --no-cpu --check 0 --no-extras --repeats 3 --plan-flags $pf > $O/bench_v_${lib}_pf$pf.log 2>&1
+      echo "ab32 $lib flags $pf: value $(val value $O/bench_v_${lib}_pf$pf.log) $(grep -o '"values": \[[^]]*' $O/bench_v_${lib}_pf$pf.log | cut -c1-120)"
+      grep -v '^{' $O/bench_v_${lib}_pf$pf.log | tail -2 | cut -c1-200 ;;
     abh:*)
       bash scripts/gpu_ab_quick.sh variants/libkas_hip_${step#abh:}.so | grep -v "^   kas_" ;;
     ab:*)

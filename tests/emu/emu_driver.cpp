@@ -265,6 +265,7 @@ run_fn rounds_for(int Wc) {
 // rows the ticket-form solver decided inside queues during the last kas_emu_solve_batch (summed
 // over scenarios): lets a CPU test assert that the queue path ran, not only the one-row path
 static long g_last_queue_rows = 0;
+static long g_last_index_rows = 0;   // topics whose fill took the index rows (fill_pass_a_fused<EMIT>) in the last kas_emu_solve_batch
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
 static int g_last_order_form = 0;   // 1: ticket form (lists <= 3 wide), 2: wide ticket form, 3: relaxation form, 0: round form (the last solve's plan)
@@ -325,7 +326,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     return KAS_E_UNSUPPORTED;
   }
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
-  if ((size_t)kas_order_relax_lds(sh.n_max, 1, 1) > lds_bytes) lds_bytes = (size_t)kas_order_relax_lds(sh.n_max, 1, 1);
+  if ((size_t)kas_order_relax_lds(sh.n_max, 1, 1, 1) > lds_bytes) lds_bytes = (size_t)kas_order_relax_lds(sh.n_max, 1, 1, 1);
   if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
   if (lds_bytes < sizeof(int32_t) * (KAS_PERM_BINS + 8)) lds_bytes = sizeof(int32_t) * (KAS_PERM_BINS + 8);
   std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
@@ -346,10 +347,15 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   g_last_flagged = 0;
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch;
-  a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~KAS_FLAG_FUSED_HIST) |
+  // (bit 64 of the caller's word is KAS_PLAN_NO_INDEX_ROWS, of a launch word KAS_FLAG_ONLY_FLAGGED: as kas_plan_set_flags / kas_plan_index_rows)
+  const bool index_rows = !c16 && !(flags & KAS_PLAN_NO_INDEX_ROWS_BIT) && sh.Wc <= 3 && fused && !(flags & KAS_FLAG_NO_RTN_QUOTA) &&
+                          sh.n_max < 0x3fff && sh.idmap_entries > 0;
+  a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
             (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u) |
             (kas_relax_double_tiles(flags, b->n_scenarios) ? KAS_FLAG_RELAX_DUAL : 0u) |
-            ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER) | (c16 ? KAS_FLAG_CELLS16 : 0u);
+            ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER) | (c16 ? KAS_FLAG_CELLS16 : 0u) |
+            (index_rows ? KAS_FLAG_INDEX_ROWS : 0u);
+  g_last_index_rows = 0;
   auto bad = [&](const char* what, int32_t s) {
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;
@@ -418,6 +424,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
     RunArgs ra{&a, s, lds.data()};
     if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill", s);
+    g_last_index_rows += (long)a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 6];   // (the fill's own tally, before an order kernel writes there)
   }
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
   if (split_p4) {
@@ -447,7 +454,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
                      : (sh.Wc <= 2 ? run_order_relax<2, false, false, false, true> : (rdual ? run_order_relax<3, true, false, false, true> : run_order_relax<3, false, false, false, true>));
     // exactly the LDS the product launches the kernel with, and a guard behind it: the hardware drops what a
     // workgroup writes beyond its allocation and reads zeros there — here that must not pass unnoticed
-    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx);
+    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx, KAS_RELAX_LDS_IDS && !c16);
     std::vector<unsigned char> rl(relax_bytes + 4096);
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(rl.data(), 0xCD, relax_bytes);
@@ -590,6 +597,9 @@ long kas_emu_last_queue_rows(void) { return g_last_queue_rows; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_fused(void) { return g_last_fused; }
+
+extern "C" __attribute__((visibility("default")))
+long kas_emu_last_index_rows(void) { return g_last_index_rows; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_spread(void) { return g_last_spread; }

@@ -213,6 +213,17 @@ def emu_solve16(fb: FlatBatch, flags: int = 0, p4_by_batch_size: bool = False, c
     return ho
 
 
+def last_index_rows() -> int:
+    """Topics whose fill took the index rows in the last emu_solve (KAS_FLAG_INDEX_ROWS: pass A leaves the rows' node indices
+    where the mid rows go, pass B streams those)."""
+    L = lib()
+    L.kas_emu_last_index_rows.restype = C.c_long
+    return int(L.kas_emu_last_index_rows())
+
+
+NO_INDEX_ROWS = 64         # KAS_PLAN_NO_INDEX_ROWS: the fill reads `cur` in both of its row scans
+
+
 def last_spread() -> int:
     """Scenarios the spread fill solved itself (not handed back to the one-workgroup kernel) in the last emu_solve."""
     L = lib()

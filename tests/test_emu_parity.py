@@ -10,7 +10,8 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import FILL_WITH_P4, NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_queue_rows, last_split_p4
+from emu_lib import (FILL_WITH_P4, NO_INDEX_ROWS, NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_index_rows,
+                     last_queue_rows, last_split_p4)
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
 from test_oracle_vs_literal import scenarios
@@ -80,6 +81,12 @@ def _batch(seed, S, P, N, R, RF, actions, rack_aware=True, cyclic=False, name_ha
 def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
     want = oracle_solve(fb)
+    assert_same_outputs(fb, want, emu_solve(fb), "emu")
+    # round 6: lists up to 3 wide — the fill's first scan leaves every row's node indices where the mid rows go, the second streams those
+    assert last_index_rows() == (6 if RF <= 3 else 0)
+    assert_same_outputs(fb, want, emu_solve(fb, flags=NO_INDEX_ROWS), "emu, cur read by both row scans of the fill (no index rows)")
+    assert last_index_rows() == 0
+    assert_same_outputs(fb, want, emu_solve(fb, flags=NO_INDEX_ROWS | FILL_WITH_P4 | RELAX_TILES_64), "emu, no index rows, first fit inside the fill workgroup, tiles of 64 rows")
     assert_same_outputs(fb, want, emu_solve(fb), "emu")
     assert last_split_p4() == 1                             # round 5: first fit in kas_p4_kernel behind the fill kernel ...
     assert_same_outputs(fb, want, emu_solve(fb, flags=FILL_WITH_P4), "emu, first fit inside the fill workgroup")
@@ -282,6 +289,51 @@ def test_emu_fill_with_per_chunk_histograms_and_with_the_chunk_count_pass():
     fb = uniform_batch(cur.astype(np.int32)[None], ids[:, :19], racks[:, :19], 3)
     assert_same_outputs(fb, oracle_solve(fb), emu_solve(fb), "emu per-chunk histograms, sparse ids")
     assert last_fused()
+
+
+def test_emu_index_rows_where_they_apply_and_where_they_do_not():
+    """KAS_FLAG_INDEX_ROWS (round 6): int32 cells, per-chunk histograms, the quota drawn with the atomic-with-return, a direct id
+    table and rows of the batch's width — the fill's first scan stores every row's node indices (0xffff: the broker left the set)
+    where its mid row goes and the second scan streams those, storing only the rows that do not keep all their replicas.  Anything
+    else reads `cur` twice as before; both against the oracle."""
+    # duplicates in a row, brokers that are not in the set, ids far from zero (min_id != 0), ragged last tile
+    rng = np.random.default_rng(61)
+    P, N = 1333, 37
+    ids = (np.arange(N, dtype=np.int32) * 3 + 1000)[None, :]
+    racks = (np.arange(N) % 7).astype(np.int32)[None, :]
+    cur = (rng.integers(0, N + 6, size=(P, 3)).astype(np.int32) * 3 + 1000)      # (some ids beyond the set, some rows with one broker twice)
+    cur[::17, 1] = cur[::17, 0]
+    fb = uniform_batch(cur[None], ids, racks, 3)
+    want = oracle_solve(fb)
+    assert_same_outputs(fb, want, emu_solve(fb), "emu index rows: duplicates, absent brokers (rows not rack-diverse: the general fill over the scratch)")
+    cur2 = G.random_assignment(8, P, N, 7, 3) * 3 + 1000
+    cur2[5::11, 2] = 1000 + 3 * (N + 2)                                          # a broker that left the set, in rack-diverse rows
+    fb2 = uniform_batch(cur2.astype(np.int32)[None], ids[:, :N - 2], racks[:, :N - 2], 3)
+    want2 = oracle_solve(fb2)
+    assert (want2.scenario_results["status"] == abi.KAS_OK).all()
+    assert_same_outputs(fb2, want2, emu_solve(fb2), "emu index rows: absent brokers, ids from 1000")
+    assert last_index_rows() == 1
+    assert_same_outputs(fb2, want2, emu_solve(fb2, flags=NO_INDEX_ROWS), "emu without index rows")
+    for flags, n in ((NO_RTN_QUOTA, 0), (8, 0), (1 << 8, 0), (1, 0), (2 << 8, 1), (8 << 8, 1), (FILL_WITH_P4, 1), (2, 1), (TICKET_ORDER, 1)):
+        assert_same_outputs(fb2, want2, emu_solve(fb2, flags=flags), f"emu index rows, plan flags {flags:#x}")
+        assert last_index_rows() == n, (flags, last_index_rows())
+    # topics of a scenario decide one by one: a topic narrower than the batch, a topic growing its lists (cur 2 wide, out 3 wide),
+    # a topic with a partition subset (in_partitions) — rows of the batch's width take the index rows, the others do not
+    scs = [Scenario(brokers=list(range(30)), racks={b: "r%d" % (b % 6) for b in range(30)}, want_context=False,
+                    topics=[Topic("a", {p: G.random_assignment(1, 700, 30, 6, 3)[p].tolist() for p in range(700)}, 3),
+                            Topic("b", {p: G.random_assignment(2, 500, 30, 6, 2)[p].tolist() for p in range(500)}, 3),
+                            Topic("c", {p: G.random_assignment(3, 300, 30, 6, 2)[p].tolist() for p in range(300)}, 2),
+                            Topic("d", {p: G.random_assignment(4, 900, 30, 6, 3)[p].tolist() for p in range(900)}, 3)])]
+    fbm = flatten(scs)
+    wantm = oracle_solve(fbm)
+    assert_same_outputs(fbm, wantm, emu_solve(fbm), "emu index rows, topics of several widths")
+    assert last_index_rows() == 2                                                # topics a and d
+    # sparse ids (binary search): no direct table, no index rows
+    curs = G.random_assignment(5, 2500, 20, 5, 3).astype(np.int64) * 100003 + 7
+    sid = (np.arange(20, dtype=np.int64) * 100003 + 7).astype(np.int32)[None, :]
+    fbs = uniform_batch(curs.astype(np.int32)[None], sid[:, :19], (np.arange(20) % 5).astype(np.int32)[None, :19], 3)
+    assert_same_outputs(fbs, oracle_solve(fbs), emu_solve(fbs), "emu sparse ids")
+    assert last_index_rows() == 0
 
 
 def test_emu_wide_lists_more_brokers_than_the_side_table_has_room_for():

@@ -1,0 +1,128 @@
+"""-m gpu: the headline's EXACT launch.
+
+bench.py's default step is one solve of 1000 scenarios x 100,000 partitions x 1,000 brokers x 20 racks, RF 3, the bench
+action mix, batches of >= 512 scenarios: kas_fill_kernel<3,4> + kas_p4_kernel<3> + kas_order_relax_kernel<3> over tiles of 64
+rows.  This test builds slot 0 of that very run (same seeds, same generator on the device, same broker sets), solves it
+through
+
+  * kas_plan_create / kas_solve_device   int32 broker ids in, broker ids out — SURVEY 8(b)/(d)'s contract, the headline —
+                                          once as the plan chooses and once with KAS_PLAN_SPLIT_P4 | RELAX_TILES(1) spelled out,
+  * kas_plan_create16 / kas_solve_device16   the same scenarios as uint16 node-index cells (ABI v5),
+
+and holds every one of the 1000 scenario records (status, failing partition, movement counts, digest of every emitted
+cell) to the flat-array CPU solver and every list of the first 64 scenarios (+ every failing one) to the oracle.  The
+kas_plan_describe strings asserted here are the ones bench.py prints as roofline.kernel / config.cells16.kernel.
+"""
+import numpy as np
+import pytest
+
+from kafka_assigner_amd import abi
+from kafka_assigner_amd import generator as G
+from kafka_assigner_amd.flatten import node_set_batch
+
+S, P, N, R, RF = 1000, 100000, 1000, 20, 3
+SEED = 2026                      # bench.py's --seed default; slot 0, rank 0
+N_LISTS = 64
+
+# what bench.py's line names (the plan's own description of its launch); n_max = 1050 (up to 50 brokers added)
+HEADLINE_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms, index rows] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "
+                    "lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows] grid=1000x64 lds=5264")
+CELLS16_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "
+                   "lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows] grid=1000x64 lds=5264 [16-bit cells]")
+
+
+def _records(t):
+    return t.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE).copy()
+
+
+@pytest.mark.gpu
+def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
+    import torch
+    import bench
+    from kafka_assigner_amd import native
+    from oracle_lib import cpu_fast_solve, oracle_solve
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED)
+    d_cur = G.torch_random_assignment(gen, S, P, N, R, RF, dev)              # int32 [S, P, RF]: slot 0's tables
+    ids, racks = [], []
+    for s in range(S):
+        _, bs = G.scenario_action(SEED, s, N, R, actions=G.BENCH_ACTIONS)
+        ids.append(bs.node_id); racks.append(bs.node_rack)
+    fb = node_set_batch(ids, racks, P, RF, RF)
+    ctx = native.default_context()
+    d_tr = torch.zeros(S * 16, dtype=torch.uint8, device=dev)
+    d_sr = torch.zeros(S * 32, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    fields = ("status", "fail_topic", "fail_partition", "moved_replicas", "moved_partitions", "digest")
+
+    # ---- the CPU answers: every record from the flat-array solver, lists of a sample from the oracle
+    h_cur = d_cur.cpu().numpy()
+    full = node_set_batch(ids, racks, P, RF, RF, cur=h_cur)
+    fast = cpu_fast_solve(full, threads=0)
+    bad = [int(s) for s in np.nonzero(fast.scenario_results["status"][:S] != abi.KAS_OK)[0]]
+    pick = sorted(set(range(N_LISTS)) | set(bad[:8]))
+    sub = node_set_batch([ids[s] for s in pick], [racks[s] for s in pick], P, RF, RF, cur=h_cur[pick])
+    want = oracle_solve(sub, threads=0)
+    for i, s in enumerate(pick):
+        for f in fields:
+            assert fast.scenario_results[f][s] == want.scenario_results[f][i], f"cpu_fast vs oracle, scenario {s}: {f}"
+    assert len(bad) >= 1, "the bench mix holds scenarios the reference strands (KAS:183-184): a failure path in the launch"
+
+    # ---- int32 broker ids in HBM in, broker ids out: the headline
+    for flags, what in ((0, "as the plan chooses"),
+                        (abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64, "SPLIT_P4 | RELAX_TILES(1)"),
+                        (abi.KAS_PLAN_NO_INDEX_ROWS, "cur read twice (no index rows)")):
+        plan = native.Plan(ctx, fb)
+        if flags:
+            plan.set_flags(flags)
+        desc = plan.describe()
+        if flags != abi.KAS_PLAN_NO_INDEX_ROWS:
+            assert desc == HEADLINE_KERNELS, desc
+        else:
+            assert desc == HEADLINE_KERNELS.replace(", index rows", ""), desc
+        d_out = torch.full((fb.out_len,), -2, dtype=torch.int32, device=dev)
+        d_sr.zero_()
+        plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        sr = _records(d_sr)
+        for f in fields:
+            diff = np.nonzero(sr[f] != fast.scenario_results[f][:S])[0]
+            assert diff.size == 0, f"int32 cells ({what}), scenario {int(diff[0])}: {f} differs from the CPU solver"
+        for i, s in enumerate(pick):
+            rows = d_out[s * P * RF:(s + 1) * P * RF].cpu().numpy()
+            assert (rows == want.out[i * P * RF:(i + 1) * P * RF]).all(), f"int32 cells ({what}), scenario {s}: lists differ from the oracle"
+        plan.close()
+        del d_out
+
+    # ---- the same scenarios as uint16 node-index cells (kas_plan_create16 / kas_solve_device16)
+    ident = [np.arange(len(x), dtype=np.int32) for x in ids]
+    d_c16 = bench.cells16_table(torch, d_cur, ids, N, dev)
+    h16 = d_c16.cpu().numpy().view(np.uint16).astype(np.int32)
+    h16[h16 == 0xFFFF] = -1
+    full16 = node_set_batch(ident, racks, P, RF, RF, cur=h16.reshape(S, P, RF))
+    fast16 = cpu_fast_solve(full16, threads=0)
+    for f in fields[:-1]:                                                   # (the digest covers the cells as emitted: indices)
+        assert (fast16.scenario_results[f][:S] == fast.scenario_results[f][:S]).all(), f"index form vs id form: {f}"
+    sub16 = node_set_batch([ident[s] for s in pick], [racks[s] for s in pick], P, RF, RF, cur=h16.reshape(S, P, RF)[pick])
+    want16 = oracle_solve(sub16, threads=0)
+    plan = native.Plan(ctx, fb, cells16=True)
+    assert plan.describe() == CELLS16_KERNELS, plan.describe()
+    d_out16 = torch.full((fb.out_len,), -2, dtype=torch.int16, device=dev)
+    d_sr.zero_()
+    plan.solve_device(d_c16.data_ptr(), d_out16.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
+    st.synchronize()
+    sr = _records(d_sr)
+    for f in fields:
+        diff = np.nonzero(sr[f] != fast16.scenario_results[f][:S])[0]
+        assert diff.size == 0, f"16-bit cells, scenario {int(diff[0])}: {f} differs from the CPU solver on the index form"
+    for i, s in enumerate(pick):
+        rows = d_out16[s * P * RF:(s + 1) * P * RF].cpu().numpy().view(np.uint16).astype(np.int32)
+        rows[rows == 0xFFFF] = -1
+        assert (rows == want16.out[i * P * RF:(i + 1) * P * RF]).all(), f"16-bit cells, scenario {s}: lists differ from the oracle"
+        # ... and they ARE the id form's lists after the index -> id lookup the caller does
+        w32 = want.out[i * P * RF:(i + 1) * P * RF]
+        back = np.where(rows >= 0, ids[s][np.clip(rows, 0, len(ids[s]) - 1)], -1)
+        assert (back == w32).all(), f"16-bit cells, scenario {s}: index -> id lookup does not give the id form's lists"
+    plan.close()

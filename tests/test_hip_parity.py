@@ -67,6 +67,8 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "hip relaxation form, tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_128), "hip relaxation form, double tiles")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "hip fill, quota drawn without the atomic-with-return")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_INDEX_ROWS), "hip fill, cur read by both row scans (no index rows)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_INDEX_ROWS | abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip no index rows, kas_p4_kernel, tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FILL_WITH_P4), "hip first fit inside the fill workgroup (no kas_p4_kernel)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4), "hip first fit in kas_p4_kernel (what batches of >= 512 scenarios take)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip kas_p4_kernel + tiles of 64 rows: the headline's kernels")
@@ -113,6 +115,8 @@ def test_config3_shape_full_size_scenarios():
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TILES_64), "C3 relaxation form over tiles of 64 rows (what a batch of 1000 takes)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "C3 ticket form")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "C3 quota drawn without the atomic-with-return")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_INDEX_ROWS), "C3 cur read by both row scans (no index rows)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "C3 kas_p4_kernel + tiles of 64 rows (the headline's kernels)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 4), "C3 4 x uint16 counter rows")
