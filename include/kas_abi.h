@@ -298,7 +298,7 @@ int kas_solve_host16(kas_ctx* ctx, const kas_batch_desc* batch, const kas_tables
  * 6 + 6 instead of 12 + 12 bytes of table traffic per row of three replicas.  Served by the kernels of lists up to 3 wide
  * (fill kernel, kas_p4_kernel, relaxation and round forms of the order kernel): any other batch — lists 4 and more wide —
  * is KAS_E_UNSUPPORTED here, and kas_solve_host16 widens such a batch on the device instead.  batch->node_id is not read; tables as kas_solve_device's, cells as kas_solve_host16's;
- * kas_plan_set_flags: no ticket form (KAS_PLAN_TICKET_ORDER takes the round form) and no KAS_PLAN_VERIFY_SAMPLE. */
+ * kas_plan_set_flags: no ticket form (KAS_PLAN_TICKET_ORDER takes the round form); KAS_PLAN_VERIFY_SAMPLE works as on int32 cells (round 6). */
 int kas_plan_create16(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_plan);
 int kas_solve_device16(kas_plan* plan, const kas_tables16* device_tables, void* hip_stream);
 
@@ -371,10 +371,11 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *   KAS_PLAN_RELAX_TILES(n) relaxation form: 1 = tiles of 64 rows, 2 = double tiles (128 rows, two rows per lane: fewer
  *                          LDS round trips per scenario, more LDS operations per row), 0 = by batch size (double
  *                          tiles for batches of fewer than 512 scenarios, where the GPU is not full of wavefronts)
- *   KAS_PLAN_NO_INDEX_ROWS rack-diverse fill with per-chunk histograms on int32 cells: read `cur` in both row scans.  (Default,
- *                          round 6: the first scan — which looks every broker id up, KAS:118-119's nodeMap.get — leaves the row's
+ *   KAS_PLAN_INDEX_ROWS / KAS_PLAN_NO_INDEX_ROWS  rack-diverse fill with per-chunk histograms on int32 cells (round 6): with index
+ *                          rows the first row scan — which looks every broker id up, KAS:118-119's nodeMap.get — leaves the row's
  *                          node indices where its mid row goes, the second scan streams those 2-byte cells and stores only the rows
- *                          that do not keep all their replicas: `cur` is read ONCE, and the lookup is done once.)
+ *                          that do not keep all their replicas: `cur` is read ONCE and every id is looked up once; without, `cur` is
+ *                          read by both scans.  Neither flag: the library's default (DESIGN.md section 4.1 has the measurement).
  *   KAS_PLAN_NO_RTN_QUOTA  rack-diverse fill with per-chunk histograms: draw a node's quota with separate LDS atomics,
  *                          reads and a ranking of the tiles in which it runs out, instead of one atomic-with-return
  *                          per list position
@@ -398,6 +399,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_TWO_PASS_HIST 8u
 #define KAS_PLAN_SPREAD_FILL  32u
 #define KAS_PLAN_NO_INDEX_ROWS 64u
+#define KAS_PLAN_INDEX_ROWS  128u
 #define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_RELAX_TILES(n) (((uint32_t)(n) & 3u) << 17)
 #define KAS_PLAN_NO_RTN_QUOTA 0x200000u

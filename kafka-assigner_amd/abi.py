@@ -34,6 +34,7 @@ KAS_PLAN_WIDE_COUNTERS = 4
 KAS_PLAN_TWO_PASS_HIST = 8
 KAS_PLAN_SPREAD_FILL = 32
 KAS_PLAN_NO_INDEX_ROWS = 64
+KAS_PLAN_INDEX_ROWS = 128
 KAS_PLAN_TICKET_ORDER = 0x10000
 KAS_PLAN_RELAX_TILES_64 = 0x20000     # KAS_PLAN_RELAX_TILES(1)
 KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)

@@ -141,19 +141,27 @@ __global__ __launch_bounds__(256) void kas_lds_order_selftest_kernel(unsigned in
 // (CTX: the instance for batches in which some scenario hands a Context in or wants it back)
 // (VERIFY: the instances for plans with KAS_PLAN_VERIFY_SAMPLE)
 // (C16: the instances for plans with 16-bit cells, kas_plan_create16)
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false>
+// (IDL: the instances for int32 cells with the scenario's broker ids in the LDS — kas_relax_lds_ids; the gather instances,
+//  IDL = false on int32 cells, exist without the sampled verification only)
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX, VERIFY, C16>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL>(a, (int32_t)blockIdx.x, kas_lds);
 }
-template <bool VERIFY, bool C16 = false>
+template <bool VERIFY, bool C16 = false, bool IDL = false>
 static void (*kas_order_relax_pick(int Wc, int dual, int ctx))(KasLaunch) {
-  if (Wc <= 2) return ctx ? kas_order_relax_kernel<2, false, true, VERIFY, C16> : kas_order_relax_kernel<2, false, false, VERIFY, C16>;   // (double tiles are rows of three holders)
+  if (Wc <= 2) return ctx ? kas_order_relax_kernel<2, false, true, VERIFY, C16, IDL> : kas_order_relax_kernel<2, false, false, VERIFY, C16, IDL>;   // (double tiles are rows of three holders)
   if (Wc == 3) {
-    if (ctx) return dual ? kas_order_relax_kernel<3, true, true, VERIFY, C16> : kas_order_relax_kernel<3, false, true, VERIFY, C16>;
-    return dual ? kas_order_relax_kernel<3, true, false, VERIFY, C16> : kas_order_relax_kernel<3, false, false, VERIFY, C16>;
+    if (ctx) return dual ? kas_order_relax_kernel<3, true, true, VERIFY, C16, IDL> : kas_order_relax_kernel<3, false, true, VERIFY, C16, IDL>;
+    return dual ? kas_order_relax_kernel<3, true, false, VERIFY, C16, IDL> : kas_order_relax_kernel<3, false, false, VERIFY, C16, IDL>;
   }
   return nullptr;
+}
+// the instance for (verify, 16-bit cells, ids in the LDS)
+static void (*kas_order_relax_any(int Wc, int dual, int ctx, int verify, int c16, int idl))(KasLaunch) {
+  if (c16) return verify ? kas_order_relax_pick<true, true>(Wc, dual, ctx) : kas_order_relax_pick<false, true>(Wc, dual, ctx);
+  if (idl) return verify ? kas_order_relax_pick<true, false, true>(Wc, dual, ctx) : kas_order_relax_pick<false, false, true>(Wc, dual, ctx);
+  return verify ? nullptr : kas_order_relax_pick<false>(Wc, dual, ctx);
 }
 
 // lists 4 and 5 wide: one scenario per workgroup (stager, retirer, three solver wavefronts: kas_order_wide.h)
@@ -206,7 +214,7 @@ static kas_kernel_fn kas_p4_for(int) { return kas_p4_kernel<5>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
-static kas_kernel_fn kas_order_relax_for(int, int, int, int = 0) { return nullptr; }
+static kas_kernel_fn kas_order_relax_for(int, int, int, int = 0, int = 0, int = 0) { return nullptr; }
 static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_kernels_w<5>() : KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #elif defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES != 0
 // tuning builds (scripts/build_variant.sh): only the kernels BASELINE.json configs[2] launches —
@@ -221,9 +229,8 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
 }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
 static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
-static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx, int verify = 0, int c16 = 0) {
-  if (c16) return verify ? nullptr : kas_order_relax_pick<false, true>(3, dual, ctx);
-  return verify ? kas_order_relax_pick<true>(3, dual, ctx) : kas_order_relax_pick<false>(3, dual, ctx);
+static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx, int verify = 0, int c16 = 0, int idl = 0) {
+  return kas_order_relax_any(3, dual, ctx, verify, c16, idl);
 }
 static KasSpreadKernels kas_spread_for(int) { return KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #else
@@ -280,9 +287,8 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
 static kas_kernel_fn kas_order_wide_for(int Wc) {
   return Wc == 4 ? kas_order_wide_kernel<4> : kas_order_wide_kernel<5>;
 }
-static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx, int verify = 0, int c16 = 0) {
-  if (c16) return verify ? nullptr : kas_order_relax_pick<false, true>(Wc, dual, ctx);
-  return verify ? kas_order_relax_pick<true>(Wc, dual, ctx) : kas_order_relax_pick<false>(Wc, dual, ctx);
+static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx, int verify = 0, int c16 = 0, int idl = 0) {
+  return kas_order_relax_any(Wc, dual, ctx, verify, c16, idl);
 }
 static KasSpreadKernels kas_spread_for(int Wc) {
   switch (Wc) {
@@ -359,7 +365,7 @@ struct kas_ctx {
 #define KAS_TIMER_SLOTS 64
 
 struct kas_plan {
-  int no_index_rows = 0;                // KAS_PLAN_NO_INDEX_ROWS (kas_plan_set_flags): the fill reads `cur` in both of its row scans
+  uint32_t index_rows_bits = 0;         // KAS_PLAN_NO_INDEX_ROWS / KAS_PLAN_INDEX_ROWS of the last kas_plan_set_flags (kas_index_rows_wanted)
   kas_ctx* ctx;
   KasShape shape;
   int Wc;                       // instantiated width class
@@ -548,6 +554,11 @@ void kas_plan_destroy(kas_plan* p) {
   delete p;
 }
 
+// the relaxation form's instances for this plan keep the broker ids in the LDS (int32 cells; kas_relax_lds_ids)
+static int kas_plan_relax_idl(const kas_plan* p) {
+  return !p->cells16 && kas_relax_lds_ids(p->shape.n_max, p->shape.any_ctx) ? 1 : 0;
+}
+
 // opt every kernel this plan may launch into its dynamic LDS size
 static int kas_plan_set_kernels(kas_plan* p) {
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -559,10 +570,10 @@ static int kas_plan_set_kernels(kas_plan* p) {
                                       kas_order_ticket_lds(p->shape.n_max, p->G, pk) + KAS_TUNE_ORDER_LDS_PAD));
   for (int dual = 0; dual < 2; ++dual)
     for (int verify = 0; verify < 2; ++verify)
-      if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16))
-        KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16),
+      if (p->shape.relax_ok && kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16, kas_plan_relax_idl(p)))
+        KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_for(p->Wc, dual, p->shape.any_ctx, verify, p->cells16, kas_plan_relax_idl(p)),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx, KAS_RELAX_LDS_IDS && !p->cells16)));
+                                      kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx, kas_plan_relax_idl(p))));
   if (p->shape.with_x && kas_p4_lds_layout(p->shape.n_max).total <= KAS_LDS_LIMIT)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_p4_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_p4_lds_layout(p->shape.n_max).total));
@@ -595,7 +606,7 @@ static bool kas_plan_fused(const kas_plan* p) {
 // index rows in this plan's next solve (KAS_FLAG_INDEX_ROWS; the kernel still decides per topic: rows of the batch's width, a
 // direct id table): int32 cells, lists up to 3 wide, per-chunk histograms, the quota drawn with the atomic-with-return
 static bool kas_plan_index_rows(const kas_plan* p) {
-  return !p->cells16 && !p->no_index_rows && p->Wc <= 3 && kas_plan_fused(p) && p->ctx->lds_lane_order_ok &&
+  return !p->cells16 && kas_index_rows_wanted(p->index_rows_bits) && p->Wc <= 3 && kas_plan_fused(p) && p->ctx->lds_lane_order_ok &&
          !(p->flags & KAS_FLAG_NO_RTN_QUOTA) && p->shape.n_max < 0x3fff && p->shape.idmap_entries > 0;
 }
 
@@ -641,7 +652,7 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   p->Wc = sh.Wc; p->NW = sh.NW; p->G = sh.G;
   p->tickets = sh.tickets_ok; p->fused = sh.fused_ok;
   p->lds = sh.lds; p->lds_fused = sh.lds_fused;
-  p->flags = 0; p->no_index_rows = 0;
+  p->flags = 0; p->index_rows_bits = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
   p->sp_alloc_chunks = 0;
@@ -799,7 +810,7 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   if (lp.relax) {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
     lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios), p->shape.any_ctx,
-                                               KAS_RELAX_LDS_IDS && !p->cells16);
+                                               kas_plan_relax_idl(p));
   } else if (lp.tickets) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
     lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed) + KAS_TUNE_ORDER_LDS_PAD;
@@ -828,8 +839,9 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
                              ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
                              : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax)
-    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s] grid=%ux%u lds=%zu%s", p->Wc,
+    snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s%s] grid=%ux%u lds=%zu%s", p->Wc,
              (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
+             kas_plan_relax_idl(p) ? ", ids in LDS" : "",
              (p->flags >> 24) ? ", sampled verification" : "", lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
   else if (lp.tickets)
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
@@ -981,7 +993,8 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   else
 #endif
   if (lp.relax)
-    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u, p->cells16), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+    hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u, p->cells16, kas_plan_relax_idl(p)),
+                       dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
                        lp.order_lds, st, a);
@@ -1054,8 +1067,8 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_GROUPS: scenarios per wavefront must be 1, 2 or 4");
   if ((flags & KAS_FLAG_ROUND_ORDER) && !p->shape.round_fits)
     return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_ROUND_ORDER: the round form's LDS exceeds 160 KiB at this broker count x width");
-  if (p->cells16 && (flags >> 24) != 0u)
-    return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_VERIFY_SAMPLE: not instantiated for plans with 16-bit cells");
+  if ((flags >> 24) != 0u && p->shape.relax_ok && kas_order_relax_for(p->Wc, 0, p->shape.any_ctx, 1, p->cells16, kas_plan_relax_idl(p)) == nullptr)
+    return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_VERIFY_SAMPLE: not instantiated for the instances that gather the broker ids from the node table (this many brokers)");
   if (p->cells16 && kas_flags_want_tickets(flags) && !p->shape.round_fits)
     return set_error(KAS_E_UNSUPPORTED, "16-bit cells: no ticket form; the round form it would take does not fit at this broker count");
   if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))   // (every check before anything is changed)
@@ -1085,7 +1098,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   KAS_HIP_TRY(hipSetDevice(p->ctx->device));
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
-  p->no_index_rows = (flags & KAS_PLAN_NO_INDEX_ROWS_BIT) != 0u;
+  p->index_rows_bits = flags & (KAS_PLAN_NO_INDEX_ROWS_BIT | KAS_PLAN_INDEX_ROWS_BIT);
   p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this

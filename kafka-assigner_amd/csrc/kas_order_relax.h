@@ -297,11 +297,16 @@ KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, uint32_t w0_cells, uint32_t w1
 // the second evaluation keeps a tile's addresses and addends alive behind its loop: 67 instead of 60 vector registers for
 // the instance with tiles of 64 rows, one register-file slot more than two of its wavefronts may take beside a fill wavefront
 // C16: the instances for plans with 16-bit cells (KAS_FLAG_CELLS16): a final row is its node indices — no broker ids to ask
-// for, nothing to wait for before the row goes out — stored over the mid row it was made from
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false>
+// for, nothing to wait for before the row goes out — stored over the mid row it was made from (round 6: VERIFY instances of
+// these too — the second evaluation reads the tile's cells from registers, before the final rows take the mid rows' place)
+// IDL (int32 cells; round 6): the scenario's broker ids are kept in the LDS (kas_relax_lds_ids: where 4 bytes a broker more fit
+// comfortably) and a final row's ids are read from there — an LDS read (~100 cycles) on the kernel's one dependency chain where
+// the L2-resident node table cost a round trip of ~700: order kernel alone 1.79 -> 1.46 ms per 1000 scenarios, twelve batches in
+// flight 643k -> 726k scenarios/s (profiles/r06a_*).  IDL = false keeps the gather from the node table (asked for through
+// kasw::gload_u32_async, waited for at the step's one s_waitcnt): broker counts whose ids do not fit.
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
-  static_assert(!(VERIFY && C16), "the sampled verification is not instantiated for 16-bit cells");
   // (16-bit cells: with no broker ids to wait for the raised priority stops paying — 8 x 20 steps 815-834k scenarios/s at
   // priority 0 against 803-815k at 3, 8 x 40 steps 833-865k against 824-853k, same box, gpurun_out/r5pr2)
   if constexpr (KAS_RELAX_PRIO > 0 && !C16) kasw::set_priority<KAS_RELAX_PRIO>();
@@ -314,7 +319,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   uint32_t* rbuf = tagtab + 8;                              // [64 | 128] row words of the (double) tile
   uint32_t* stage = rbuf + (DUAL ? 128 : 64);               // [192 | 384] by pair of the (double) tile
   uint32_t* cnt2 = nullptr;                                 // (CTX) [nmax] what the rows add to count[n][2]
-  uint32_t* idt = nullptr;                                  // (KAS_RELAX_LDS_IDS, int32 cells) [nmax] the scenario's broker ids
+  uint32_t* idt = nullptr;                                  // (IDL, int32 cells) [nmax] the scenario's broker ids
   const int32_t* g_node_id = a.node_id + sd.node_off;
   const int64_t t_begin = kasw::clock_ticks();
   int32_t* g_ctx = nullptr;
@@ -346,7 +351,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   }
   // the broker ids of the final rows come from the LDS, not from the L2-resident node table: a final row then waits for an
   // LDS read (~100 cycles) where it waited for an L2 round trip (~700) on the kernel's one dependency chain
-  constexpr bool LDSIDS = KAS_RELAX_LDS_IDS && !C16;
+  constexpr bool LDSIDS = IDL && !C16;
   if constexpr (LDSIDS) {
     idt = stage + (DUAL ? 384 : 192) + (CTX ? nmax : 0);
     for (int32_t n = lane; n < N; n += 64) idt[n] = (uint32_t)g_node_id[n];

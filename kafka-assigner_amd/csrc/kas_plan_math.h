@@ -68,7 +68,17 @@ struct KasLaunch {
 #define KAS_FLAG_INDEX_ROWS   0x400u // set by the launcher (int32 cells, per-chunk histograms, LDS lane order; not with KAS_PLAN_NO_INDEX_ROWS): the fill's
                                    // first row scan leaves every row's node indices where its mid row goes and the second scan streams those
                                    // (kas_solver_body.h, fill_pass_a_fused<EMIT>): `cur` is read once, 6 instead of 12 bytes a row the second time
-#define KAS_PLAN_NO_INDEX_ROWS_BIT 64u // the user's switch (kas_plan_set_flags; its bit is KAS_FLAG_ONLY_FLAGGED's in a launch word, so it is kept beside the plan's flags)
+#define KAS_PLAN_NO_INDEX_ROWS_BIT 64u // the user's switches (kas_plan_set_flags; their bits are KAS_FLAG_ONLY_FLAGGED's / KAS_FLAG_ORDER_FLAGGED's in a launch
+#define KAS_PLAN_INDEX_ROWS_BIT 128u   // word, so they are kept beside the plan's flags): off / on whatever KAS_INDEX_ROWS_DEFAULT says
+#ifndef KAS_INDEX_ROWS_DEFAULT
+#define KAS_INDEX_ROWS_DEFAULT 0   // (round 6, measured at the headline shape with twelve batches in flight: 643k scenarios/s with, 661k without — the stores of pass A cost more than the second read of cur)
+#endif
+// index rows for a plan / emulator flag word that names neither switch?
+KAS_ABI_FN int32_t kas_index_rows_wanted(uint32_t user_flags) {
+  if (user_flags & KAS_PLAN_NO_INDEX_ROWS_BIT) return 0;
+  if (user_flags & KAS_PLAN_INDEX_ROWS_BIT) return 1;
+  return KAS_INDEX_ROWS_DEFAULT;
+}
 #define KAS_FLAG_WIDE_CHECK   256u  // set by the launcher (KasShape::wide_checked): the wide ticket form checks its count fields at the end
 #define KAS_FLAG_TICKET_ORDER 0x10000u // lists <= 3 wide: the ticket form of P5 where the relaxation form would run (testing / comparison);
                                        // KAS_PLAN_GROUPS(n) and KAS_PLAN_WIDE_COUNTERS, which only mean something to the ticket form, imply it
@@ -277,14 +287,25 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 // instance with double tiles: 128).  5,072 bytes at 1,000 brokers: four of these workgroups fit in the LDS that four
 // workgroups of the fill kernel leave free on a CU.
 // (with_ctx: the instance for batches with a Context keeps a second uint32 per node: what the rows add to count[n][2])
-// (with_ids: the instances for int32 cells keep the scenario's broker ids in the LDS too — KAS_RELAX_LDS_IDS)
-#ifndef KAS_RELAX_LDS_IDS
-#define KAS_RELAX_LDS_IDS 0
+// (with_ids: the instances for int32 cells that keep the scenario's broker ids in the LDS too — kas_relax_lds_ids)
+#ifndef KAS_RELAX_IDS_LDS_MAX
+#define KAS_RELAX_IDS_LDS_MAX (64 * 1024)   // ... where the whole carve-up stays below this (about 7,900 brokers; 5,400 with a Context)
 #endif
 KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles, int32_t with_ctx, int32_t with_ids = 0) {
   int64_t n = n_max > 0 ? n_max : 1;
   const int64_t rows = double_tiles ? 128 : 64;
   return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4 + (with_ctx ? 4 * n : 0) + (with_ids ? 4 * n : 0));
+}
+// Relaxation form on int32 cells: broker ids in the LDS (the IDL instances) for this broker count?  (KAS_TUNE_RELAX_GATHER_IDS:
+// tuning builds that keep the gather from the L2-resident node table, for A/B)
+KAS_ABI_FN int32_t kas_relax_lds_ids(int32_t n_max, int32_t with_ctx) {
+#if defined(KAS_TUNE_RELAX_GATHER_IDS)
+  (void)n_max; (void)with_ctx;
+  return 0;
+#else
+  int64_t n = n_max > 0 ? n_max : 1;
+  return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + 128 * 4 + 3 * 128 * 4 + (with_ctx ? 4 * n : 0) + 4 * n) <= KAS_RELAX_IDS_LDS_MAX ? 1 : 0;
+#endif
 }
 // Relaxation form: double tiles (128 rows, two rows per lane) in this launch?  A double tile halves the LDS round
 // trips a scenario waits for (one batch of 1000 alone: order kernel 2.0 -> 1.7 ms) at ~1.2 x the LDS operations per row
@@ -530,7 +551,7 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // the broker count is limited by the fill kernel's LDS only.  A Context handed in is checked per scenario by the
   // kernel (its counters + the rows to come must fit the fields; else the round form, which fits whenever a batch
   // with a Context is accepted at all)
-  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && kas_order_relax_lds(s.n_max, 1, s.any_ctx, KAS_RELAX_LDS_IDS) <= KAS_LDS_LIMIT;
+  s.relax_ok = s.Wc <= 3 && relax_inputs_ok && kas_order_relax_lds(s.n_max, 1, s.any_ctx, kas_relax_lds_ids(s.n_max, s.any_ctx)) <= KAS_LDS_LIMIT;
   // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
   // to the round form — which must then fit)
   s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&

@@ -98,6 +98,10 @@ for step in "$@"; do
       KAS_HIP_LIB=variants/libkas_hip_$lib.so timeout 400 python bench.py --no-cpu --check 0 --no-extras --repeats 3 --plan-flags $pf > $O/bench_v_${lib}_pf$pf.log 2>&1
       echo "ab32 $lib flags $pf: value $(val value $O/bench_v_${lib}_pf$pf.log) $(grep -o '"values": \[[^]]*' $O/bench_v_${lib}_pf$pf.log | cut -c1-120)"
       grep -v '^{' $O/bench_v_${lib}_pf$pf.log | tail -2 | cut -c1-200 ;;
+    ab1f:*)   # one batch alone with that tuning build and plan flags: ab1f:LIB:FLAGS
+      rest=${step#ab1f:}; lib=${rest%%:*}; pf=${rest#*:}; [ "$pf" == "$rest" ] && pf=0
+      KAS_HIP_LIB=variants/libkas_hip_$lib.so timeout 400 python bench.py --no-cpu --check 0 --no-extras --repeats 1 --steps 10 --in-flight 1 --plan-flags $pf > $O/bench_v1_${lib}_pf$pf.log 2>&1
+      echo "ab1f $lib flags $pf: ms_per_step $(val ms_per_step $O/bench_v1_${lib}_pf$pf.log) $(grep -o '"in_flight_launch": {[^}]*' $O/bench_v1_${lib}_pf$pf.log | cut -c1-110)" ;;
     abh:*)
       bash scripts/gpu_ab_quick.sh variants/libkas_hip_${step#abh:}.so | grep -v "^   kas_" ;;
     ab:*)

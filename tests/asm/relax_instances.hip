@@ -8,27 +8,41 @@
 #include "kas_plan_math.h"
 #include "kas_solver_body.h"
 
-template <int W, bool DUAL, bool CTX, bool VERIFY, bool C16 = false>
+template <int W, bool DUAL, bool CTX, bool VERIFY, bool C16 = false, bool IDL = false>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX, VERIFY, C16>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL>(a, (int32_t)blockIdx.x, kas_lds);
 }
+// int32 cells, broker ids gathered from the node table (broker counts whose ids do not fit the LDS; no sampled verification)
 template __global__ void kas_order_relax_kernel<2, false, false, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<2, false, false, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<2, false, true, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<2, false, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, false, false, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, false, false, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, false, true, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, false, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, false, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, true, false, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, true, false>(KasLaunch);
-template __global__ void kas_order_relax_kernel<3, true, true, true>(KasLaunch);
-// the instances for 16-bit cells (kas_plan_create16): mid rows still come in by async loads
+// int32 cells, broker ids in the LDS (round 6: what every BASELINE config at RF 3 launches): mid rows still come in by async loads
+template __global__ void kas_order_relax_kernel<2, false, false, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, false, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, true, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, true, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, false, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, false, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, true, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, true, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, false, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, false, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, true, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, true, true, false, true>(KasLaunch);
+// the instances for 16-bit cells (kas_plan_create16), with and without the sampled verification
 template __global__ void kas_order_relax_kernel<2, false, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, false, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<2, false, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<2, false, true, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, false, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, false, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, false, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, false, true, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, false, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, false, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, true, false, true>(KasLaunch);
+template __global__ void kas_order_relax_kernel<3, true, true, true, true>(KasLaunch);

@@ -216,9 +216,15 @@ template <int W> void run_order_wide(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
 }
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false> void run_order_relax(void* p) {
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false> void run_order_relax(void* p) {
   RunArgs* r = (RunArgs*)p;
-  if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY, C16>(*r->a, r->s, r->lds);
+  if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL>(*r->a, r->s, r->lds);
+}
+typedef void (*relax_fn)(void*);
+template <bool VERIFY, bool C16, bool IDL> relax_fn relax_pick(int Wc, bool dual, bool ctx) {   // as kas_order_relax_pick (kas_hip.hip)
+  if (Wc <= 2) return ctx ? run_order_relax<2, false, true, VERIFY, C16, IDL> : run_order_relax<2, false, false, VERIFY, C16, IDL>;
+  if (ctx) return dual ? run_order_relax<3, true, true, VERIFY, C16, IDL> : run_order_relax<3, false, true, VERIFY, C16, IDL>;
+  return dual ? run_order_relax<3, true, false, VERIFY, C16, IDL> : run_order_relax<3, false, false, VERIFY, C16, IDL>;
 }
 template <int W> void run_order_rounds(void* p) {
   RunArgs* r = (RunArgs*)p;
@@ -265,6 +271,7 @@ run_fn rounds_for(int Wc) {
 // rows the ticket-form solver decided inside queues during the last kas_emu_solve_batch (summed
 // over scenarios): lets a CPU test assert that the queue path ran, not only the one-row path
 static long g_last_queue_rows = 0;
+static int g_last_relax_idl = 0;      // the last relaxation-form launch read its broker ids from the LDS
 static long g_last_index_rows = 0;   // topics whose fill took the index rows (fill_pass_a_fused<EMIT>) in the last kas_emu_solve_batch
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
@@ -306,8 +313,8 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "16-bit cells: lists up to 3 wide, relaxation or round form");
     return KAS_E_UNSUPPORTED;
   }
-  if (c16 && (((flags >> 24) != 0u) || (kas_flags_want_tickets(flags) && !sh.round_fits))) {   // (kas_plan_set_flags' refusals)
-    if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "16-bit cells: no sampled verification / no ticket form");
+  if (c16 && kas_flags_want_tickets(flags) && !sh.round_fits) {   // (kas_plan_set_flags' refusal)
+    if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "16-bit cells: no ticket form");
     return KAS_E_UNSUPPORTED;
   }
   // (the launch decisions of kas_launch_plan in kas_hip.hip)
@@ -326,7 +333,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     return KAS_E_UNSUPPORTED;
   }
   if ((size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0) > lds_bytes) lds_bytes = (size_t)kas_order_ticket_lds(sh.n_max, sh.G, 0);
-  if ((size_t)kas_order_relax_lds(sh.n_max, 1, 1, 1) > lds_bytes) lds_bytes = (size_t)kas_order_relax_lds(sh.n_max, 1, 1, 1);
+  if ((size_t)kas_order_relax_lds(sh.n_max, 1, 1, 1) > lds_bytes) lds_bytes = (size_t)kas_order_relax_lds(sh.n_max, 1, 1, 1);   // (an upper bound)
   if (wide && (size_t)kas_order_wide_lds(sh.n_max) > lds_bytes) lds_bytes = (size_t)kas_order_wide_lds(sh.n_max);
   if (lds_bytes < sizeof(int32_t) * (KAS_PERM_BINS + 8)) lds_bytes = sizeof(int32_t) * (KAS_PERM_BINS + 8);
   std::vector<unsigned char> lds(lds_bytes + 64, 0xCD);
@@ -348,7 +355,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   a.n_scenarios = b->n_scenarios; a.n_max = sh.n_max; a.idmap_entries = sh.idmap_entries;
   a.need_bsearch = sh.need_bsearch;
   // (bit 64 of the caller's word is KAS_PLAN_NO_INDEX_ROWS, of a launch word KAS_FLAG_ONLY_FLAGGED: as kas_plan_set_flags / kas_plan_index_rows)
-  const bool index_rows = !c16 && !(flags & KAS_PLAN_NO_INDEX_ROWS_BIT) && sh.Wc <= 3 && fused && !(flags & KAS_FLAG_NO_RTN_QUOTA) &&
+  const bool index_rows = !c16 && kas_index_rows_wanted(flags) && sh.Wc <= 3 && fused && !(flags & KAS_FLAG_NO_RTN_QUOTA) &&
                           sh.n_max < 0x3fff && sh.idmap_entries > 0;
   a.flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
             (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL) | (fused ? KAS_FLAG_FUSED_HIST : 0u) |
@@ -444,17 +451,22 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   // order kernel: one wavefront per scenario (relaxation form, round form), three per G scenarios (ticket form)
   if (relax) {
     const bool rdual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
-    run_fn f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true> : (rdual ? run_order_relax<3, true, true> : run_order_relax<3, false, true>))
-                          : (sh.Wc <= 2 ? run_order_relax<2, false, false> : (rdual ? run_order_relax<3, true, false> : run_order_relax<3, false, false>));
-    if ((a.flags >> 24) != 0u)                                // KAS_PLAN_VERIFY_SAMPLE: the instances with the second evaluation
-      f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true, true> : (rdual ? run_order_relax<3, true, true, true> : run_order_relax<3, false, true, true>))
-                     : (sh.Wc <= 2 ? run_order_relax<2, false, false, true> : (rdual ? run_order_relax<3, true, false, true> : run_order_relax<3, false, false, true>));
-    if (c16)                                                  // the instances for 16-bit cells
-      f = sh.any_ctx ? (sh.Wc <= 2 ? run_order_relax<2, false, true, false, true> : (rdual ? run_order_relax<3, true, true, false, true> : run_order_relax<3, false, true, false, true>))
-                     : (sh.Wc <= 2 ? run_order_relax<2, false, false, false, true> : (rdual ? run_order_relax<3, true, false, false, true> : run_order_relax<3, false, false, false, true>));
+    // the instance kas_order_relax_any (kas_hip.hip) picks: 16-bit cells; int32 cells with the broker ids in the LDS
+    // (kas_relax_lds_ids; KAS_EMU_RELAX_GATHER=1 in the environment: the instances that gather them from the node table, which
+    // exist without the sampled verification only — as in the product, which refuses the flag there)
+    const bool verify = (a.flags >> 24) != 0u;
+    const bool idl = !c16 && kas_relax_lds_ids(sh.n_max, sh.any_ctx) && !(getenv("KAS_EMU_RELAX_GATHER") && getenv("KAS_EMU_RELAX_GATHER")[0] == '1');
+    if (verify && !c16 && !idl) {
+      if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "KAS_PLAN_VERIFY_SAMPLE: not instantiated for the gather instances");
+      return KAS_E_UNSUPPORTED;
+    }
+    run_fn f = c16 ? (verify ? relax_pick<true, true, false>(sh.Wc, rdual, sh.any_ctx) : relax_pick<false, true, false>(sh.Wc, rdual, sh.any_ctx))
+               : idl ? (verify ? relax_pick<true, false, true>(sh.Wc, rdual, sh.any_ctx) : relax_pick<false, false, true>(sh.Wc, rdual, sh.any_ctx))
+                     : relax_pick<false, false, false>(sh.Wc, rdual, sh.any_ctx);
+    g_last_relax_idl = idl ? 1 : 0;
     // exactly the LDS the product launches the kernel with, and a guard behind it: the hardware drops what a
     // workgroup writes beyond its allocation and reads zeros there — here that must not pass unnoticed
-    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx, KAS_RELAX_LDS_IDS && !c16);
+    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx, idl);
     std::vector<unsigned char> rl(relax_bytes + 4096);
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(rl.data(), 0xCD, relax_bytes);
@@ -600,6 +612,9 @@ int kas_emu_last_fused(void) { return g_last_fused; }
 
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_index_rows(void) { return g_last_index_rows; }
+
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_relax_idl(void) { return g_last_relax_idl; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_spread(void) { return g_last_spread; }

@@ -151,6 +151,27 @@ def variant_solver(name: str, flags):
     return solve
 
 
+def variant_solver16(name: str, flags):
+    """emu_solve16 bound to an emulator variant: (fb, plan flags) -> HostOutputs with the uint16 out pool"""
+    from kafka_assigner_amd.flatten import host_tables16, to_cells16
+    L = C.CDLL(build_emu_variant(name, flags))
+    L.kas_emu_solve_batch16.restype = C.c_int
+    L.kas_emu_solve_batch16.argtypes = [C.POINTER(abi.BatchDesc), C.POINTER(abi.Tables), C.c_uint, C.c_char_p, C.c_int]
+
+    def solve(fb: FlatBatch, flags: int = 0) -> HostOutputs:
+        bd = batch_desc(fb)
+        bd.node_id = None
+        c16 = to_cells16(fb)                                # (kept alive: t.cur is its raw address)
+        t, ho = host_tables16(fb, c16)
+        err = C.create_string_buffer(512)
+        rc = L.kas_emu_solve_batch16(C.byref(bd), C.byref(t), _p4_form(flags, False), err, 512)
+        del c16
+        if rc != 0:
+            raise RuntimeError(f"kas_emu_solve_batch16 rc={rc}: {err.value.decode()}")
+        return ho
+    return solve
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -221,7 +242,15 @@ def last_index_rows() -> int:
     return int(L.kas_emu_last_index_rows())
 
 
+def last_relax_idl() -> int:
+    """1: the relaxation form of the last emu_solve read the final rows' broker ids from the LDS (the IDL instances)"""
+    L = lib()
+    L.kas_emu_last_relax_idl.restype = C.c_int
+    return int(L.kas_emu_last_relax_idl())
+
+
 NO_INDEX_ROWS = 64         # KAS_PLAN_NO_INDEX_ROWS: the fill reads `cur` in both of its row scans
+INDEX_ROWS = 128           # KAS_PLAN_INDEX_ROWS: the fill's first scan leaves node indices where the mid rows go, the second streams those
 
 
 def last_spread() -> int:

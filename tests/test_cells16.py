@@ -167,12 +167,37 @@ def test_emu16_multi_topic_scenarios_with_and_without_a_context_and_refusals():
                             context={b: {0: 65000, 1: 3} for b in range(40)},
                             topics=[Topic("t", {p: [(p + k) % 40 for k in range(3)] for p in range(900)}, 3)])])
     assert_same_outputs(big, _want16(big), emu_solve16(big), "emu 16-bit cells, Context beyond 16 bits: round form")
-    # lists 5 wide, and the sampled verification: refused
+    # lists 5 wide: refused
     wide = _batch(5, 2, 600, 40, 10, 5, G.ACTIONS)
     with pytest.raises(RuntimeError, match="rc=-3"):
         emu_solve16(wide)
-    with pytest.raises(RuntimeError, match="rc=-3"):
-        emu_solve16(fb, flags=VERIFY_SAMPLE(8))
+    # the sampled verification (round 6: instantiated for 16-bit cells too): same lists, never fires on an ascending LDS
+    for flags in (VERIFY_SAMPLE(8), RELAX_TILES_64 | VERIFY_SAMPLE(255)):
+        got = emu_solve16(fb, flags=flags)
+        assert_same_outputs(fb, want, got, "emu 16-bit cells, sampled verification, flags %#x" % flags)
+        assert_same_outputs(fbc, _want16(fbc), emu_solve16(fbc, flags=flags), "emu 16-bit cells, Context, sampled verification")
+
+
+def test_emu16_descending_lane_order_is_caught_by_the_sampled_verification():
+    """The 16-bit instances are what bench.py's cells16 leg and kas_solve_host16 launch: on an emulator whose LDS serves the lanes
+    of one atomic in DESCENDING order they produce wrong lists with status OK, and with every tile verified none gets out."""
+    from emu_lib import NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, VERIFY_SAMPLE, variant_solver16
+    solve16 = variant_solver16("rtn_descending", ["-DKAS_EMU_RTN_DESCENDING"])
+    fb = _batch(4321, 6, 6000, 80, 8, 3, ("remove1",))
+    want = _want16(fb)
+    ok = want.scenario_results["status"] == abi.KAS_OK
+    assert ok.sum() >= 3
+    P3 = 6000 * 3
+    for tiles in (RELAX_TILES_64, RELAX_TILES_128):
+        got = solve16(fb, NO_RTN_QUOTA | tiles)
+        wrong = np.array([bool((want.out[s * P3:(s + 1) * P3] != got.out[s * P3:(s + 1) * P3]).any()) for s in range(6)]) & ok
+        assert wrong.any(), "the descending LDS should have changed some list"
+        assert (got.scenario_results["status"][wrong] == abi.KAS_OK).any()
+        chk = solve16(fb, NO_RTN_QUOTA | tiles | VERIFY_SAMPLE(255))
+        caught = chk.scenario_results["status"] == abi.KAS_FAIL_WATCHDOG
+        assert caught[wrong].all(), "a scenario with a wrong list was not flagged"
+        for s in np.nonzero(ok & ~caught)[0]:
+            assert (want.out[s * P3:(s + 1) * P3] == chk.out[s * P3:(s + 1) * P3]).all()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -331,9 +356,11 @@ def test_hip_device16_equals_oracle_seeded_batches_every_plan_variant(P, N, R, R
                         (2, "round form"), (abi.KAS_PLAN_TICKET_ORDER, "ticket form asked for: round form"),
                         (T64 | (1 << 8), "one fill wavefront"), (8, "chunk-count pass")):
         assert_same_outputs(fb, want, native.solve_device16_with_flags(fb, flags), "hip 16-bit cells, " + what)
-    with pytest.raises(native.KasError) as e:
-        native.solve_device16_with_flags(fb, abi.KAS_PLAN_VERIFY_SAMPLE(8))
-    assert e.value.code == abi.KAS_E_UNSUPPORTED
+    # the sampled verification on the 16-bit instances (round 6): same lists, and it never fires on this hardware
+    for flags in (abi.KAS_PLAN_VERIFY_SAMPLE(8), T64 | abi.KAS_PLAN_VERIFY_SAMPLE(255), T128 | abi.KAS_PLAN_VERIFY_SAMPLE(40)):
+        gv = native.solve_device16_with_flags(fb, flags)
+        assert "sampled verification" in gv.describe
+        assert_same_outputs(fb, want, gv, "hip 16-bit cells, sampled verification, flags %#x" % flags)
     fb3 = _batch(78, 3, P, N, R, RF, ("remove1", "add_k"), cyclic=True)
     assert_same_outputs(fb3, _want16(fb3), native.solve_device16_with_flags(fb3), "hip 16-bit cells, cyclic rows")
 
@@ -382,3 +409,30 @@ def test_hip_device16_multi_topic_context_full_size_and_refusals():
             pl.solve_device(1, 1, 1, 1)
         assert e.value.code == abi.KAS_E_INVALID_ARG
         pl.close()
+
+
+@pytest.mark.gpu
+def test_hip16_wide_lists_do_not_thrash_the_plan_cache():
+    """kas_solve_host16 on a batch the 16-bit kernels refuse (lists 5 wide: widened before and narrowed behind an
+    int32 solve) used to ask the plan cache for a 16-bit plan first — rebuilding the int32 plan of the previous call in place,
+    failing, destroying it — so that EVERY call rebuilt its plan.  The cell width of the solve is now decided from the shape
+    before the cache is touched: the second call of the same batch finds its plan byte for byte and allocates nothing."""
+    from kafka_assigner_amd import native
+    ctx = native.DeviceContext(0)
+    fb = _batch(5, 3, 900, 40, 10, 5, G.ACTIONS)
+    want = oracle_solve(index_form(fb), threads=0)
+    want.out = np.where(want.out < 0, 0xFFFF, want.out).astype(np.uint16)
+    got = native.solve_host16(fb, ctx)
+    np.testing.assert_array_equal(got.out[:fb.out_len], want.out[:fb.out_len])
+    calls, hits, allocs = ctx.host_stats()
+    for k in range(3):
+        got = native.solve_host16(fb, ctx)
+        np.testing.assert_array_equal(got.out[:fb.out_len], want.out[:fb.out_len])
+        assert ctx.host_stats() == (calls + k + 1, hits + k + 1, allocs), ctx.host_stats()
+    # ... and a batch the 16-bit kernels DO take, between two such calls, evicts nothing it needs
+    fb3 = _batch(6, 3, 900, 40, 10, 3, G.ACTIONS)
+    native.solve_host16(fb3, ctx)
+    c2, h2, a2 = ctx.host_stats()
+    native.solve_host16(fb, ctx); native.solve_host16(fb3, ctx)
+    assert ctx.host_stats()[1] == h2 + 2 and ctx.host_stats()[2] == a2, ctx.host_stats()
+    ctx.close()

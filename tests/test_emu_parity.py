@@ -10,7 +10,7 @@ from hypothesis import HealthCheck, given, settings
 from kafka_assigner_amd import abi
 from kafka_assigner_amd.flatten import Scenario, Topic, flatten, uniform_batch
 from kafka_assigner_amd import generator as G
-from emu_lib import (FILL_WITH_P4, NO_INDEX_ROWS, NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_index_rows,
+from emu_lib import (FILL_WITH_P4, INDEX_ROWS, NO_INDEX_ROWS, NO_RTN_QUOTA, RELAX_TILES_64, RELAX_TILES_128, TICKET_ORDER, emu_solve, last_index_rows,
                      last_queue_rows, last_split_p4)
 from oracle_lib import oracle_solve
 from parity_util import assert_same_outputs
@@ -81,9 +81,10 @@ def _batch(seed, S, P, N, R, RF, actions, rack_aware=True, cyclic=False, name_ha
 def test_emu_equals_oracle_seeded_batches(P, N, R, RF, actions):
     fb = _batch(1234, 6, P, N, R, RF, actions)
     want = oracle_solve(fb)
-    assert_same_outputs(fb, want, emu_solve(fb), "emu")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=INDEX_ROWS), "emu, index rows")
     # round 6: lists up to 3 wide — the fill's first scan leaves every row's node indices where the mid rows go, the second streams those
     assert last_index_rows() == (6 if RF <= 3 else 0)
+    assert_same_outputs(fb, want, emu_solve(fb, flags=INDEX_ROWS | FILL_WITH_P4 | RELAX_TILES_64), "emu, index rows, first fit inside the fill workgroup, tiles of 64 rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=NO_INDEX_ROWS), "emu, cur read by both row scans of the fill (no index rows)")
     assert last_index_rows() == 0
     assert_same_outputs(fb, want, emu_solve(fb, flags=NO_INDEX_ROWS | FILL_WITH_P4 | RELAX_TILES_64), "emu, no index rows, first fit inside the fill workgroup, tiles of 64 rows")
@@ -305,17 +306,17 @@ def test_emu_index_rows_where_they_apply_and_where_they_do_not():
     cur[::17, 1] = cur[::17, 0]
     fb = uniform_batch(cur[None], ids, racks, 3)
     want = oracle_solve(fb)
-    assert_same_outputs(fb, want, emu_solve(fb), "emu index rows: duplicates, absent brokers (rows not rack-diverse: the general fill over the scratch)")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=INDEX_ROWS), "emu index rows: duplicates, absent brokers (rows not rack-diverse: the general fill over the scratch)")
     cur2 = G.random_assignment(8, P, N, 7, 3) * 3 + 1000
     cur2[5::11, 2] = 1000 + 3 * (N + 2)                                          # a broker that left the set, in rack-diverse rows
     fb2 = uniform_batch(cur2.astype(np.int32)[None], ids[:, :N - 2], racks[:, :N - 2], 3)
     want2 = oracle_solve(fb2)
     assert (want2.scenario_results["status"] == abi.KAS_OK).all()
-    assert_same_outputs(fb2, want2, emu_solve(fb2), "emu index rows: absent brokers, ids from 1000")
+    assert_same_outputs(fb2, want2, emu_solve(fb2, flags=INDEX_ROWS), "emu index rows: absent brokers, ids from 1000")
     assert last_index_rows() == 1
     assert_same_outputs(fb2, want2, emu_solve(fb2, flags=NO_INDEX_ROWS), "emu without index rows")
     for flags, n in ((NO_RTN_QUOTA, 0), (8, 0), (1 << 8, 0), (1, 0), (2 << 8, 1), (8 << 8, 1), (FILL_WITH_P4, 1), (2, 1), (TICKET_ORDER, 1)):
-        assert_same_outputs(fb2, want2, emu_solve(fb2, flags=flags), f"emu index rows, plan flags {flags:#x}")
+        assert_same_outputs(fb2, want2, emu_solve(fb2, flags=flags | INDEX_ROWS), f"emu index rows, plan flags {flags:#x}")
         assert last_index_rows() == n, (flags, last_index_rows())
     # topics of a scenario decide one by one: a topic narrower than the batch, a topic growing its lists (cur 2 wide, out 3 wide),
     # a topic with a partition subset (in_partitions) — rows of the batch's width take the index rows, the others do not
@@ -326,14 +327,38 @@ def test_emu_index_rows_where_they_apply_and_where_they_do_not():
                             Topic("d", {p: G.random_assignment(4, 900, 30, 6, 3)[p].tolist() for p in range(900)}, 3)])]
     fbm = flatten(scs)
     wantm = oracle_solve(fbm)
-    assert_same_outputs(fbm, wantm, emu_solve(fbm), "emu index rows, topics of several widths")
+    assert_same_outputs(fbm, wantm, emu_solve(fbm, flags=INDEX_ROWS), "emu index rows, topics of several widths")
     assert last_index_rows() == 2                                                # topics a and d
     # sparse ids (binary search): no direct table, no index rows
     curs = G.random_assignment(5, 2500, 20, 5, 3).astype(np.int64) * 100003 + 7
     sid = (np.arange(20, dtype=np.int64) * 100003 + 7).astype(np.int32)[None, :]
     fbs = uniform_batch(curs.astype(np.int32)[None], sid[:, :19], (np.arange(20) % 5).astype(np.int32)[None, :19], 3)
-    assert_same_outputs(fbs, oracle_solve(fbs), emu_solve(fbs), "emu sparse ids")
+    assert_same_outputs(fbs, oracle_solve(fbs), emu_solve(fbs, flags=INDEX_ROWS), "emu sparse ids")
     assert last_index_rows() == 0
+
+
+def test_emu_relaxation_form_broker_ids_from_the_lds_and_from_the_node_table(monkeypatch):
+    """Round 6: the relaxation form's instances for int32 cells keep the scenario's broker ids in the LDS (kas_relax_lds_ids) and read a
+    final row's ids there; broker counts whose ids do not fit keep the gather from the node table (asked for with the asynchronous
+    loads, waited for at the step's one s_waitcnt).  Both against the oracle, with and without a Context, both tile sizes."""
+    from emu_lib import last_relax_idl
+    fb = _batch(606, 5, 5000, 90, 9, 3, G.ACTIONS)
+    fb.node_id[:] = fb.node_id * 5 + 77                                      # ids that are not their own index
+    fb.cur[:] = np.where(fb.cur >= 0, fb.cur * 5 + 77, fb.cur)
+    want = oracle_solve(fb)
+    fbm = _multi_topic_scenarios(78, 3, 3, 900, 40, 8, 3)
+    wantm = oracle_solve(fbm)
+    for gather in ("0", "1"):
+        monkeypatch.setenv("KAS_EMU_RELAX_GATHER", gather)
+        for flags in (RELAX_TILES_64, RELAX_TILES_128):
+            assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu relaxation form, gather={gather}, flags {flags:#x}")
+            assert last_relax_idl() == (0 if gather == "1" else 1)
+            assert_same_outputs(fbm, wantm, emu_solve(fbm, flags=flags), f"emu relaxation form, topics + Context, gather={gather}, flags {flags:#x}")
+    monkeypatch.setenv("KAS_EMU_RELAX_GATHER", "0")
+    # 9,000 brokers: the ids no longer fit beside the counter words (KAS_RELAX_IDS_LDS_MAX) — the gather instances by themselves
+    big = _batch(17, 1, 30000, 9000, 10, 3, ("remove1",))
+    assert_same_outputs(big, oracle_solve(big), emu_solve(big), "emu relaxation form, 9,000 brokers")
+    assert last_relax_idl() == 0
 
 
 def test_emu_wide_lists_more_brokers_than_the_side_table_has_room_for():

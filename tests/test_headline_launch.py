@@ -25,8 +25,9 @@ SEED = 2026                      # bench.py's --seed default; slot 0, rank 0
 N_LISTS = 64
 
 # what bench.py's line names (the plan's own description of its launch); n_max = 1050 (up to 50 brokers added)
-HEADLINE_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms, index rows] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "
-                    "lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows] grid=1000x64 lds=5264")
+HEADLINE_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms%s] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "
+                    "lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] grid=1000x64 lds=9472")
+INDEX_ROWS_BY_DEFAULT = False    # the library's KAS_INDEX_ROWS_DEFAULT (measured both ways)
 CELLS16_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "
                    "lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows] grid=1000x64 lds=5264 [16-bit cells]")
 
@@ -71,17 +72,16 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
     assert len(bad) >= 1, "the bench mix holds scenarios the reference strands (KAS:183-184): a failure path in the launch"
 
     # ---- int32 broker ids in HBM in, broker ids out: the headline
-    for flags, what in ((0, "as the plan chooses"),
-                        (abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64, "SPLIT_P4 | RELAX_TILES(1)"),
-                        (abi.KAS_PLAN_NO_INDEX_ROWS, "cur read twice (no index rows)")):
+    dflt = ", index rows" if INDEX_ROWS_BY_DEFAULT else ""
+    for flags, what, ixr in ((0, "as the plan chooses", dflt),
+                             (abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64, "SPLIT_P4 | RELAX_TILES(1)", dflt),
+                             (abi.KAS_PLAN_NO_INDEX_ROWS, "cur read by both row scans of the fill", ""),
+                             (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", ", index rows")):
         plan = native.Plan(ctx, fb)
         if flags:
             plan.set_flags(flags)
         desc = plan.describe()
-        if flags != abi.KAS_PLAN_NO_INDEX_ROWS:
-            assert desc == HEADLINE_KERNELS, desc
-        else:
-            assert desc == HEADLINE_KERNELS.replace(", index rows", ""), desc
+        assert desc == HEADLINE_KERNELS % ixr, desc
         d_out = torch.full((fb.out_len,), -2, dtype=torch.int32, device=dev)
         d_sr.zero_()
         plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)

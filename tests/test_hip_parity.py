@@ -69,6 +69,9 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "hip fill, quota drawn without the atomic-with-return")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_INDEX_ROWS), "hip fill, cur read by both row scans (no index rows)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_INDEX_ROWS | abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip no index rows, kas_p4_kernel, tiles of 64 rows")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_INDEX_ROWS), "hip fill, index rows (cur read once)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_INDEX_ROWS | abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip index rows, kas_p4_kernel, tiles of 64 rows")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_INDEX_ROWS | abi.KAS_PLAN_FILL_WITH_P4), "hip index rows, first fit inside the fill workgroup")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FILL_WITH_P4), "hip first fit inside the fill workgroup (no kas_p4_kernel)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4), "hip first fit in kas_p4_kernel (what batches of >= 512 scenarios take)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip kas_p4_kernel + tiles of 64 rows: the headline's kernels")
@@ -116,6 +119,7 @@ def test_config3_shape_full_size_scenarios():
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, TICKET_ORDER), "C3 ticket form")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "C3 quota drawn without the atomic-with-return")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_INDEX_ROWS), "C3 cur read by both row scans (no index rows)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_INDEX_ROWS), "C3 index rows (cur read once)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "C3 kas_p4_kernel + tiles of 64 rows (the headline's kernels)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
@@ -176,7 +180,7 @@ def test_one_plan_orders_its_solves_across_streams():
     want = oracle_solve(fb, threads=0)
     ctx = native.default_context()
     plan = native.Plan(ctx, fb)
-    assert "kas_fill_kernel<3,4>[quota, chunk histograms]" in plan.describe() and "kas_order_relax_kernel<3>" in plan.describe()
+    assert "kas_fill_kernel<3,4>[quota, chunk histograms" in plan.describe() and "kas_order_relax_kernel<3>" in plan.describe()
     assert "kas_p4_kernel" not in plan.describe()                                   # 24 scenarios: first fit inside the fill workgroup
     dev = torch.device("cuda", ctx.device)
     d_cur = torch.from_numpy(fb.cur).to(dev)
