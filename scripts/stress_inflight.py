@@ -42,7 +42,7 @@ SUITE = [
     ("16-bit cells, round form of the order kernel (what a ticket-form request takes there)",
      "kas_order_round_kernel<3>", ["--plan-flags", "65536", "--in-flight", "12", "--scenarios", "200"]),
     ("relaxation form over double tiles (KAS_PLAN_RELAX_TILES(2): what batches of fewer than 512 scenarios take)",
-     "kas_order_relax_kernel<3>[tiles of 128 rows]", ["--plan-flags", "262144", "--in-flight", "12", "--cells", "32"]),
+     "kas_order_relax_kernel<3>[tiles of 128 rows", ["--plan-flags", "262144", "--in-flight", "12", "--cells", "32"]),
     ("packed ticket form, 2 scenarios per wavefront (KAS_PLAN_TICKET_ORDER)",
      "kas_order_ticket_kernel<3,2,true>", ["--plan-flags", "65536", "--in-flight", "12", "--cells", "32"]),
     ("one scenario per solver wavefront (G = 1)", "kas_order_ticket_kernel<3,1,true>", ["--groups", "1", "--in-flight", "12", "--cells", "32"]),
