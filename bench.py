@@ -117,7 +117,36 @@ def parse_args(argv=None):
                          "beside it on the same slots and reported as value_cells16 / value_int32_cells")
     ap.add_argument("--stub", action="store_true",
                     help="harness self-test on CPU (gloo, synthetic records): NOT a measurement")
-    return ap.parse_args(argv)
+    ap.add_argument("--config", type=int, choices=(2, 3, 4), default=0,
+                    help="BASELINE.json configs[N] as a preset of the flags above (an explicit flag still wins): 2 = the headline "
+                         "(1000 scenarios x 100k x 1k x 20 racks, RF 3, per GPU); 3 = 64k scenarios of that shape with brokers "
+                         "1000-1049 added, cut over the GPUs (--scaling strong; 8000 per GPU at --gpus 8); 4 = 1M partitions x 5k "
+                         "brokers x 40 racks, RF 5, remove every 50th broker + add 200, rack map on / off alternating, 8 variants "
+                         "per GPU as replicas (--scaling weak)")
+    args = ap.parse_args(argv)
+    apply_config_preset(args, ap, argv if argv is not None else sys.argv[1:])
+    return args
+
+
+# BASELINE.json configs[2..4] as flag presets (DESIGN.md section 8 lists the command lines)
+CONFIG_PRESETS = {
+    2: dict(scenarios=1000, partitions=100000, brokers=1000, racks=20, rf=3, scaling="weak"),
+    3: dict(scenarios=64000, partitions=100000, brokers=1000, racks=20, rf=3, scaling="strong", actions="add50", in_flight=2),
+    4: dict(scenarios=8, partitions=1000000, brokers=5000, racks=40, rf=5, scaling="weak", actions="c5,c5_norack", in_flight=1,
+            check=2),
+}
+
+
+def apply_config_preset(args, ap, argv):
+    """--config N: the preset's values for every flag the command line does not name itself."""
+    if not args.config:
+        return
+    named = {a.split("=")[0] for a in argv if a.startswith("--")}
+    for key, val in CONFIG_PRESETS[args.config].items():
+        if "--" + key.replace("_", "-") not in named:
+            setattr(args, key, val)
+    if args.config == 3 and "--in-flight" not in named and args.gpus < 2:
+        args.in_flight = 1                          # (64k scenarios on ONE GPU: 154 GB of tables per batch in flight)
 
 
 # -------------------------------------------------------------------------------------------------
@@ -625,6 +654,24 @@ def run_rank(args) -> int:
         run.slots, run.n_slots = keep, keep_n
         alone = {"steps": n_alone, "ms_per_step": 1e3 * el1 / n_alone, "fill_kernel_us": f1, "order_kernel_us": o1,
                  "launches_timed": n1}
+        # ... and as a caller that KNOWS its batch has the GPU to itself would ask for it (what kas_solve_host's plans take by
+        # themselves): first fit inside the fill workgroup, double tiles in the order kernel
+        try:
+            from kafka_assigner_amd import abi as _abi
+            base_flags = (args.waves << 8) | (args.groups << 12) | args.plan_flags
+            run.slots, run.n_slots = keep[:1], 1
+            keep[0]["plan"].set_flags(base_flags | _abi.KAS_PLAN_FILL_WITH_P4 | _abi.KAS_PLAN_RELAX_TILES_128)
+            what_l = keep[0]["plan"].describe()
+            el1l = timed(n_alone, 1)
+            f1l, o1l, _ = run.phase_times()
+            keep[0]["plan"].set_flags(base_flags)
+            run.solve(keep[0]); run.synchronize()                  # (slot 0's records and rows: the headline plan's again)
+            alone["with_latency_flags"] = {"ms_per_step": 1e3 * el1l / n_alone, "fill_kernel_us": f1l, "order_kernel_us": o1l,
+                                           "plan_flags": "KAS_PLAN_FILL_WITH_P4 | KAS_PLAN_RELAX_TILES(2)", "kernel": what_l}
+        except Exception as e:                                     # (a leg of its own: never costs the headline line)
+            alone["with_latency_flags"] = {"error": repr(e)}
+        finally:
+            run.slots, run.n_slots = keep, keep_n
 
     # ---- the literal SURVEY 8(d) C3 action mix (with 'replace 1'), same cur tables ---------------
     literal = None
@@ -690,10 +737,11 @@ def run_rank(args) -> int:
                         "note": f"each repeat = exactly {args.steps} steps between barrier + synchronize; "
                                 f"{args.warmup} warm-up steps before the first"},
             "config": {
-                "workload": f"{'BASELINE.json configs[2]' if shape_c3 else 'custom shape'}: "
+                "workload": f"{('BASELINE.json configs[%d]' % args.config) if args.config else ('BASELINE.json configs[2]' if shape_c3 else 'custom shape')}: "
                             f"batch of {S} independent scenarios per GPU, "
                             f"{P} partitions x {N} brokers x {R} racks, RF {RF}; per-scenario G(seed+s) "
                             f"current assignment + action in {{{', '.join(action_mix)}}} (remove <= 5, add <= 50)",
+                "preset": args.config or None,
                 "scenarios_per_gpu": sizes, "scenarios_total": total,
                 "partitions": P, "brokers": N, "racks": R, "rf": RF,
                 "world_size": world, "rank_devices": rank_devices, "device": run.device_name,

@@ -370,7 +370,10 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *                          of >= 131,072 partitions) for any single-topic batch, with few chunks
  *   KAS_PLAN_RELAX_TILES(n) relaxation form: 1 = tiles of 64 rows, 2 = double tiles (128 rows, two rows per lane: fewer
  *                          LDS round trips per scenario, more LDS operations per row), 0 = by batch size (double
- *                          tiles for batches of fewer than 512 scenarios, where the GPU is not full of wavefronts)
+ *                          tiles for batches of fewer than 512 scenarios, where the GPU is not full of wavefronts).
+ *                          Lists 4 and 5 wide (round 6): 1 = the relaxation form for these widths (kas_order_relax_wide.h: one
+ *                          wavefront per scenario, uint64 counter words; batches without a Context) instead of the wide ticket
+ *                          form — exact, and measured slower at BASELINE configs[4], hence opt-in
  *   KAS_PLAN_INDEX_ROWS / KAS_PLAN_NO_INDEX_ROWS  rack-diverse fill with per-chunk histograms on int32 cells (round 6): with index
  *                          rows the first row scan — which looks every broker id up, KAS:118-119's nodeMap.get — leaves the row's
  *                          node indices where its mid row goes, the second scan streams those 2-byte cells and stores only the rows

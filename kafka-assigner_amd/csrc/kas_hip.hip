@@ -164,6 +164,13 @@ static void (*kas_order_relax_any(int Wc, int dual, int ctx, int verify, int c16
   return verify ? nullptr : kas_order_relax_pick<false>(Wc, dual, ctx);
 }
 
+// lists 4 and 5 wide, relaxation form: one wavefront (= one workgroup) per scenario (kas_order_relax_wide.h)
+template <int W>
+__global__ __launch_bounds__(64) void kas_order_relax_wide_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::order_relax_wide<W>(a, (int32_t)blockIdx.x, kas_lds);
+}
+
 // lists 4 and 5 wide: one scenario per workgroup (stager, retirer, three solver wavefronts: kas_order_wide.h)
 template <int W>
 __global__ __launch_bounds__(KAS_ORDER_WIDE_BLOCK) void kas_order_wide_kernel(KasLaunch a) {
@@ -214,6 +221,7 @@ static kas_kernel_fn kas_p4_for(int) { return kas_p4_kernel<5>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
+static kas_kernel_fn kas_order_relaxw_for(int) { return kas_order_relax_wide_kernel<5>; }
 static kas_kernel_fn kas_order_relax_for(int, int, int, int = 0, int = 0, int = 0) { return nullptr; }
 static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_kernels_w<5>() : KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #elif defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES != 0
@@ -229,6 +237,7 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
 }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
 static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
+static kas_kernel_fn kas_order_relaxw_for(int) { return nullptr; }
 static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx, int verify = 0, int c16 = 0, int idl = 0) {
   return kas_order_relax_any(3, dual, ctx, verify, c16, idl);
 }
@@ -286,6 +295,9 @@ static kas_kernel_fn kas_order_round_for(int Wc) {
 }
 static kas_kernel_fn kas_order_wide_for(int Wc) {
   return Wc == 4 ? kas_order_wide_kernel<4> : kas_order_wide_kernel<5>;
+}
+static kas_kernel_fn kas_order_relaxw_for(int Wc) {
+  return Wc == 4 ? kas_order_relax_wide_kernel<4> : (Wc == 5 ? kas_order_relax_wide_kernel<5> : nullptr);
 }
 static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx, int verify = 0, int c16 = 0, int idl = 0) {
   return kas_order_relax_any(Wc, dual, ctx, verify, c16, idl);
@@ -581,6 +593,9 @@ static int kas_plan_set_kernels(kas_plan* p) {
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_order_round_lds(p->shape.n_max, p->Wc)));
+  if (p->shape.relaxw_ok && kas_order_relaxw_for(p->Wc))
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relaxw_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kas_order_relaxw_lds(p->shape.n_max, p->Wc)));
   if (p->shape.wide_ok && kas_order_wide_for(p->Wc))
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_wide_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -791,6 +806,7 @@ int kas_plan_create16(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_
 
 // the launch decisions of kas_solve_device, in one place
 struct KasLaunchPlan {
+  bool relaxw;                  // relaxation form of P5 for lists 4 and 5 wide (then neither tickets nor wide)
   bool relax;                   // relaxation form of P5 (then neither tickets nor wide)
   bool tickets, pairing, wide;
   int packed;
@@ -804,13 +820,18 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   lp.tickets = !lp.relax && p->tickets && !(p->flags & KAS_FLAG_ROUND_ORDER) && !p->cells16;   // (no ticket form with 16-bit cells: the round form)
   lp.packed = p->shape.packed_ok && !(p->flags & KAS_FLAG_WIDE_COUNTERS);
   lp.pairing = lp.tickets && p->G > 1 && p->n_scenarios > p->G;
-  lp.wide = !lp.tickets && !p->cells16 && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
+  lp.relaxw = !lp.relax && !p->cells16 && p->shape.relaxw_ok && p->ctx->lds_lane_order_ok && kas_order_relaxw_for(p->Wc) != nullptr &&
+              kas_relaxw_wanted(p->flags);
+  lp.wide = !lp.tickets && !lp.relaxw && !p->cells16 && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
   lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD;
   if (lp.relax) {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
     lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios), p->shape.any_ctx,
                                                kas_plan_relax_idl(p));
+  } else if (lp.relaxw) {
+    lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
+    lp.order_lds = (size_t)kas_order_relaxw_lds(p->shape.n_max, p->Wc);
   } else if (lp.tickets) {
     lp.order_grid = (unsigned)((p->n_scenarios + p->G - 1) / p->G); lp.order_block = 192u;
     lp.order_lds = (size_t)kas_order_ticket_lds(p->shape.n_max, p->G, lp.packed) + KAS_TUNE_ORDER_LDS_PAD;
@@ -843,6 +864,9 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
              (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
              kas_plan_relax_idl(p) ? ", ids in LDS" : "",
              (p->flags >> 24) ? ", sampled verification" : "", lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
+  else if (lp.relaxw)
+    snprintf(order, sizeof(order), "kas_order_relax_wide_kernel<%d>[tiles of 64 rows, ids in LDS] grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
+             lp.order_block, lp.order_lds);
   else if (lp.tickets)
     snprintf(order, sizeof(order), "%skas_order_ticket_kernel<%d,%d,%s> grid=%ux%u lds=%zu%s",
              lp.pairing ? "kas_order_permutation_kernel + " : "", p->Wc, p->G, lp.packed ? "true" : "false",
@@ -995,6 +1019,8 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   if (lp.relax)
     hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u, p->cells16, kas_plan_relax_idl(p)),
                        dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+  else if (lp.relaxw)
+    hipLaunchKernelGGL(kas_order_relaxw_for(p->Wc), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (tickets)
     hipLaunchKernelGGL(kas_order_ticket_for(p->Wc, p->G, packed), dim3(lp.order_grid), dim3(lp.order_block),
                        lp.order_lds, st, a);

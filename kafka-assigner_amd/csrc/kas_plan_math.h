@@ -296,6 +296,21 @@ KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles, int3
   const int64_t rows = double_tiles ? 128 : 64;
   return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4 + (with_ctx ? 4 * n : 0) + (with_ids ? 4 * n : 0));
 }
+// relaxation form for lists 4 and 5 wide (kas_order_relax_wide.h), one wavefront per scenario: a uint64 counter word per node + the
+// padding node's, a row word per row and an 8-byte staging word per (row, cell) pair of a tile of 64 rows, the scenario's broker ids
+KAS_ABI_FN int32_t kas_order_relaxw_lds(int32_t n_max, int32_t W) {
+  int64_t n = n_max > 0 ? n_max : 1;
+  return kas_align16(kas_align16(8 * (n + 1)) + 64 * 4 + 64 * (int64_t)W * 8 + 4 * n);
+}
+// ... launched where the plan says: KAS_PLAN_RELAX_TILES(1) at these widths, or — KAS_RELAXW_DEFAULT — whenever it applies
+// (KAS_PLAN_TICKET_ORDER then names the wide ticket form)
+#ifndef KAS_RELAXW_DEFAULT
+#define KAS_RELAXW_DEFAULT 0
+#endif
+KAS_ABI_FN int32_t kas_relaxw_wanted(uint32_t flags) {
+  if (flags & (KAS_FLAG_ROUND_ORDER | KAS_FLAG_TICKET_ORDER)) return 0;
+  return (flags & KAS_FLAG_RELAX_TILES_64) != 0u || KAS_RELAXW_DEFAULT;
+}
 // Relaxation form on int32 cells: broker ids in the LDS (the IDL instances) for this broker count?  (KAS_TUNE_RELAX_GATHER_IDS:
 // tuning builds that keep the gather from the L2-resident node table, for A/B)
 KAS_ABI_FN int32_t kas_relax_lds_ids(int32_t n_max, int32_t with_ctx) {
@@ -359,6 +374,7 @@ struct KasShape {
   int32_t any_ctx = 0;                // some scenario hands a Context in / wants it back
   int32_t wide_ok = 0;                // lists 4 or 5 wide and the wide ticket form is applicable
   int32_t relax_ok = 0;               // lists <= 3 wide and the relaxation form (kas_order_relax.h) is applicable to every scenario
+  int32_t relaxw_ok = 0;              // lists 4 or 5 wide and the relaxation form for them (kas_order_relax_wide.h) is applicable
   int32_t bound_mid = 1;              // every scenario's ticket bound is below KAS_WIDE_COMMIT_LIMIT
   int32_t wide_checked = 0;           // wide_ok with a ticket bound of 1023 or more somewhere: the kernel checks its count
                                       // fields at the end and a scenario that outgrew them is solved again (fill + round form)
@@ -552,6 +568,8 @@ static inline int kas_shape_batch(const kas_batch_desc* b, KasShape* sh, std::st
   // kernel (its counters + the rows to come must fit the fields; else the round form, which fits whenever a batch
   // with a Context is accepted at all)
   s.relax_ok = s.Wc <= 3 && relax_inputs_ok && kas_order_relax_lds(s.n_max, 1, s.any_ctx, kas_relax_lds_ids(s.n_max, s.any_ctx)) <= KAS_LDS_LIMIT;
+  // ... and at lists 4 and 5 wide: no Context handed in, the broker ids in the LDS beside the 8-byte counter words
+  s.relaxw_ok = (s.Wc == 4 || s.Wc == 5) && relax_inputs_ok && !s.any_ctx && kas_order_relaxw_lds(s.n_max, s.Wc) <= 96 * 1024;
   // (a node that may hold 1023 .. 2039 rows: the count fields are checked after the fact, and what outgrew them goes
   // to the round form — which must then fit)
   s.wide_ok = (s.Wc == 4 || s.Wc == 5) && s.tickets_ok && s.bound_mid && 8 * ((int64_t)s.n_max + 1) <= 65536 &&

@@ -3086,3 +3086,4 @@ KAS_DEV void order_scenario_rounds(const KasLaunch& a, int32_t s, unsigned char*
 
 #include "kas_order_wide.h"
 #include "kas_order_relax.h"
+#include "kas_order_relax_wide.h"

@@ -157,6 +157,14 @@ KAS_DEV void lds_add_u32(uint32_t* p, uint32_t v) {
 KAS_DEV void lds_sub_u32(uint32_t* p, uint32_t v) {
   (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// ... and on 64-bit words (ds_add_rtn_u64, ds_sub_u64): the relaxation form for lists 4 and 5 wide (kas_order_relax_wide.h), same
+// property (the probes measured both widths)
+KAS_DEV uint64_t lds_add_rtn_u64(uint64_t* p, uint64_t v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+KAS_DEV void lds_sub_u64(uint64_t* p, uint64_t v) {
+  (void)__hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // Global loads the COMPILER DOES NOT SEE (inline assembly): gload_*_async asks for a value, wait_loads() is the one
 // s_waitcnt vmcnt(0) that makes everything asked for so far usable, arrived(x) ties a use of x behind it.  Why not plain

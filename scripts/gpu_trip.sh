@@ -139,6 +139,21 @@ PY
       # lists 3 wide at 5,000 brokers: one group of the ticket form (round 2: the round form from 4,680 brokers on)
       c5 bench_1m_5k_rf3_ticket_form --actions c5 --rf 3
       c5 bench_1m_5k_rf3_round_form --actions c5 --rf 3 --plan-flags 2 --steps 1 --warmup 1 ;;
+    c5f:*)    # configs[4] x1 (and the batch of 8) with that tuning build and plan flags: c5f:LIB:FLAGS (131072 = the relaxation form for wide lists)
+      rest=${step#c5f:}; lib=${rest%%:*}; pf=${rest#*:}; [ "$pf" == "$rest" ] && pf=0
+      KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5_v_${lib}_pf$pf --actions c5 --plan-flags $pf --stats $O/stats_c5_${lib}_pf$pf.json
+      KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5norack_v_${lib}_pf$pf --actions c5_norack --plan-flags $pf
+      KAS_HIP_LIB=variants/libkas_hip_$lib.so timeout 300 python bench.py --no-cpu --no-extras --repeats 1 --check 2 --scenarios 64 --partitions 1000000 --brokers 5000 --racks 40 --rf 5 --actions c5 --in-flight 1 --steps 3 --warmup 1 --plan-flags $pf > $O/bench_c5x64_v_${lib}_pf$pf.log 2>&1
+      echo "configs[4] x64 $lib flags $pf: ms_per_step $(val ms_per_step $O/bench_c5x64_v_${lib}_pf$pf.log) $(grep -o '"in_flight_launch": {[^}]*' $O/bench_c5x64_v_${lib}_pf$pf.log | cut -c1-110)"
+      python - $O/stats_c5_${lib}_pf$pf.json <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print("   stats:", " ".join("%s %.0f" % (k, d[k]["mean"]) for k in ("solver_iterations", "stager_iterations", "order_us") if k in d))
+except Exception as e:
+    print("   no stats:", e)
+PY
+      ;;
     c5:*)
       lib=${step#c5:}
       if [ "$lib" == "-" ]; then c5 bench_c5_product --actions c5; else KAS_HIP_LIB=variants/libkas_hip_$lib.so c5 bench_c5_v_$lib --actions c5 --stats $O/stats_c5_$lib.json; fi ;;

@@ -31,16 +31,18 @@ from oracle_lib import oracle_solve  # noqa: E402
 # The kernel families and plan variants a solve can launch, each at a shape that takes it (name, must appear
 # in the plan's description — "!x": x must NOT appear —, bench.py flags).  The first is the headline shape (BASELINE.json configs[2]).
 SUITE = [
-    ("headline: 16-bit cells in HBM — fill<3,4> per-chunk histograms + first fit in kas_p4_kernel + relaxation form of the order kernel",
-     "[16-bit cells]", ["--in-flight", "12"]),
-    ("the same kernels on int32 broker ids (kas_plan_create)",
-     "+ kas_p4_kernel<3> grid=1000x64", ["--in-flight", "12", "--cells", "32"]),
+    ("headline: int32 broker ids in HBM in, ids out — fill<3,4> per-chunk histograms + first fit in kas_p4_kernel + relaxation form of the order kernel with the ids in the LDS",
+     "rows, ids in LDS] grid=1000x64", ["--in-flight", "12", "--cells", "32"]),
+    ("the same kernels on 16-bit cells in HBM (kas_plan_create16)",
+     "[16-bit cells]", ["--in-flight", "12", "--cells", "16"]),
+    ("index rows (KAS_PLAN_INDEX_ROWS: the fill's first scan leaves node indices where the mid rows go, the second streams those)",
+     "index rows]", ["--plan-flags", "128", "--in-flight", "12", "--cells", "32"]),
     ("first fit inside the fill workgroup (KAS_PLAN_FILL_WITH_P4: four wavefronts hand windows over through LDS, no kas_p4_kernel)",
      "!kas_p4_kernel", ["--plan-flags", "8388608", "--in-flight", "12", "--cells", "32"]),
     ("16-bit cells, first fit inside the fill workgroup + double tiles (what small batches and host calls take)",
-     "[16-bit cells]", ["--plan-flags", str(8388608 | 262144), "--in-flight", "12"]),
+     "[16-bit cells]", ["--plan-flags", str(8388608 | 262144), "--in-flight", "12", "--cells", "16"]),
     ("16-bit cells, round form of the order kernel (what a ticket-form request takes there)",
-     "kas_order_round_kernel<3>", ["--plan-flags", "65536", "--in-flight", "12", "--scenarios", "200"]),
+     "kas_order_round_kernel<3>", ["--plan-flags", "65536", "--in-flight", "12", "--scenarios", "200", "--cells", "16"]),
     ("relaxation form over double tiles (KAS_PLAN_RELAX_TILES(2): what batches of fewer than 512 scenarios take)",
      "kas_order_relax_kernel<3>[tiles of 128 rows", ["--plan-flags", "262144", "--in-flight", "12", "--cells", "32"]),
     ("packed ticket form, 2 scenarios per wavefront (KAS_PLAN_TICKET_ORDER)",

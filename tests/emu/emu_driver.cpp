@@ -212,6 +212,10 @@ void run_permutation(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_permutation(*r->a, r->lds);
 }
+template <int W> void run_order_relax_wide(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  if constexpr (W == 4 || W == 5) kas::order_relax_wide<W>(*r->a, r->s, r->lds);
+}
 template <int W> void run_order_wide(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::order_tickets_wide<W>(*r->a, r->s, r->lds);
@@ -320,8 +324,9 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   // (the launch decisions of kas_launch_plan in kas_hip.hip)
   const bool relax = sh.relax_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !(kas_flags_want_tickets(flags) && sh.tickets_ok);
   const bool tickets = !relax && sh.tickets_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !c16;
-  const bool wide = sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !c16;
-  g_last_order_form = relax ? 3 : (tickets ? 1 : (wide ? 2 : 0));
+  const bool relaxw = !relax && !c16 && sh.relaxw_ok && kas_relaxw_wanted(flags);   // relaxation form for lists 4 and 5 wide
+  const bool wide = !relaxw && sh.wide_ok && !(flags & KAS_FLAG_ROUND_ORDER) && !c16;
+  g_last_order_form = relax ? 3 : (relaxw ? 4 : (tickets ? 1 : (wide ? 2 : 0)));
   g_last_relax_tiles = 0; g_last_relax_evals = 0; g_last_relax_slow = 0;
   std::vector<uint64_t> accmask((size_t)sh.accmask_words + 1, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> orph((size_t)sh.orph_ints + 64, (int32_t)0xDEADBEEF);
@@ -477,6 +482,20 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
         if (rl[relax_bytes + i] != 0xA5) return bad("order (relaxation): LDS written beyond kas_order_relax_lds()", s);
       const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
       g_last_relax_evals += (long)st[9]; g_last_relax_tiles += (long)st[12]; g_last_relax_slow += (long)st[13];
+    }
+  } else if (relaxw) {
+    run_fn f = sh.Wc == 4 ? run_order_relax_wide<4> : run_order_relax_wide<5>;
+    const size_t rw_bytes = (size_t)kas_order_relaxw_lds(sh.n_max, sh.Wc);      // exactly the product's LDS, and a guard behind it
+    std::vector<unsigned char> rl(rw_bytes + 4096);
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(rl.data(), 0xCD, rw_bytes);
+      memset(rl.data() + rw_bytes, 0xA5, 4096);
+      RunArgs ra{&a, s, rl.data()};
+      if (kasw::run_block(f, &ra, 1) != 0) return bad("order (relaxation, wide lists)", s);
+      for (size_t i = 0; i < 4096; ++i)
+        if (rl[rw_bytes + i] != 0xA5) return bad("order (relaxation, wide lists): LDS written beyond kas_order_relaxw_lds()", s);
+      const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      g_last_relax_evals += (long)st[9]; g_last_relax_tiles += (long)st[12];
     }
   } else if (tickets) {
     if (sh.G > 1 && b->n_scenarios > sh.G) {

@@ -152,6 +152,22 @@ KAS_DEV uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p 
 #endif
 KAS_DEV void lds_add_u32(uint32_t* p, uint32_t v) { *p += v; }
 KAS_DEV void lds_sub_u32(uint32_t* p, uint32_t v) { *p -= v; }
+#ifdef KAS_EMU_RTN_DESCENDING
+KAS_DEV uint64_t lds_add_rtn_u64(uint64_t* p, uint64_t v) {   // (as lds_add_rtn_u32 of this build: the lanes served in DESCENDING order)
+  Emu& e = g_emu;
+  const int base = e.cur & ~63, me = e.cur & 63;
+  e.slot[e.cur] = (uint64_t)(uintptr_t)p; e.slot2[e.cur] = v;
+  rendezvous(K_LOCKSTEP);
+  uint64_t ret = *p;
+  for (int l = me + 1; l < 64; ++l) if (e.slot[base + l] == (uint64_t)(uintptr_t)p) ret += e.slot2[base + l];
+  rendezvous(K_LOCKSTEP);
+  *p += v;
+  return ret;
+}
+#else
+KAS_DEV uint64_t lds_add_rtn_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = o + v; return o; }
+#endif
+KAS_DEV void lds_sub_u64(uint64_t* p, uint64_t v) { *p -= v; }
 
 // (hardware: global loads issued as inline assembly and waited for once per step, csrc/kas_wave.h; here they are loads)
 template <int IMM = 0>

@@ -78,6 +78,41 @@ def test_bench_odd_world_sizes_strong_scaling_ragged_shards(world, scenarios, ex
     assert cfg["scenarios_total"] == scenarios and cfg["gathered_records_ok"] is True
 
 
+@pytest.mark.parametrize("config,expect_sizes,scaling", [
+    (3, [8000] * 8, "strong"),     # configs[3]: 64k scenarios cut over 8 GPUs, add brokers 1000-1049
+    (4, [8] * 8, "weak"),          # configs[4]: 8 variants of the 1M x 5k x RF 5 cluster per GPU, as replicas
+    (2, [1000] * 8, "weak"),       # configs[2]: the headline's batch per GPU
+])
+def test_bench_config_presets_at_world_8(config, expect_sizes, scaling):
+    """`bench.py --gpus 8 --config N`: the BASELINE configs beyond the headline as one flag, so that a driver
+    run on an 8-GPU node needs no hand-assembled command line.  Over gloo with the stub: shards, gather, the line's labels."""
+    r = _run(["--stub", "--gpus", "8", "--steps", "2", "--warmup", "1", "--config", str(config)], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and line["scaling"] == scaling and cfg["scenarios_per_gpu"] == expect_sizes
+    assert cfg["preset"] == config and f"configs[{config}]" in cfg["workload"]
+    assert cfg["gathered_records_ok"] is True
+    if config == 3:
+        assert "add50" in cfg["workload"] and cfg["batches_in_flight"] == 2
+    if config == 4:
+        assert cfg["partitions"] == 1000000 and cfg["brokers"] == 5000 and cfg["rf"] == 5 and "c5_norack" in cfg["workload"]
+
+
+def test_bench_config_preset_yields_to_explicit_flags():
+    import bench
+    a = bench.parse_args(["--config", "3", "--scenarios", "128", "--in-flight", "4"])
+    assert (a.scenarios, a.in_flight, a.actions, a.scaling) == (128, 4, "add50", "strong")
+    a = bench.parse_args(["--config", "3"])
+    assert (a.scenarios, a.in_flight) == (64000, 1)                # one GPU: one batch in flight (154 GB of tables)
+    a = bench.parse_args(["--config", "3", "--gpus", "8"])
+    assert a.in_flight == 2
+    a = bench.parse_args(["--config", "4"])
+    assert (a.partitions, a.brokers, a.racks, a.rf, a.scenarios, a.actions) == (1000000, 5000, 40, 5, 8, "c5,c5_norack")
+    a = bench.parse_args([])
+    assert (a.config, a.scenarios, a.cells) == (0, 1000, 32)
+
+
 def test_bench_single_rank_stub_line():
     r = _run(["--stub", "--steps", "3", "--warmup", "1", "--scenarios", "5"])
     assert r.returncode == 0, r.stderr[-3000:]

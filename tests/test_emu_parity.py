@@ -361,6 +361,58 @@ def test_emu_relaxation_form_broker_ids_from_the_lds_and_from_the_node_table(mon
     assert last_relax_idl() == 0
 
 
+@pytest.mark.parametrize("S,P,N,R,RF,actions,rack_aware", [
+    (6, 777, 40, 10, 5, G.ACTIONS, True),              # ragged last tile, every action kind
+    (6, 640, 24, 8, 4, ("replace1", "remove1"), True),
+    (4, 3000, 120, 24, 5, ("add_k",), True),
+    (3, 5000, 100, 10, 4, G.ACTIONS, False),           # rack awareness off: every broker its own rack
+])
+def test_emu_wide_lists_relaxation_form(S, P, N, R, RF, actions, rack_aware):
+    """Round 6: the relaxation form for lists 4 and 5 wide (kas_order_relax_wide.h; KAS_PLAN_RELAX_TILES(1) at these widths) —
+    uint64 counter words of four 16-bit fields, sorted holders, the general pick over the holders that are left — against the
+    oracle; without the flag the wide ticket form runs."""
+    from emu_lib import last_order_form, last_relax_stats
+    fb = _batch(1234, S, P, N, R, RF, actions, rack_aware=rack_aware)
+    want = oracle_solve(fb)
+    assert (want.scenario_results["status"] == abi.KAS_OK).any()
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu relaxation form, wide lists")
+    assert last_order_form() == 4
+    tiles, evals, _ = last_relax_stats()
+    assert tiles > 0 and evals >= 2 * tiles                 # (every tile: one evaluation to decide, one to see nothing moved)
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64 | FILL_WITH_P4), "emu relaxation form, wide lists, first fit inside the fill workgroup")
+    assert_same_outputs(fb, want, emu_solve(fb), "emu wide ticket form")
+    assert last_order_form() == 2
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64 | TICKET_ORDER), "emu: the ticket form asked for by name")
+    assert last_order_form() == 2
+
+
+def test_emu_wide_lists_relaxation_form_topics_of_several_widths_share_the_counters():
+    """A topic 5 wide, one 4 wide, one 3 wide and one 5 wide again in ONE scenario: every list position r <= 3 adds to its field
+    whatever the list's length (KAS:236), and a later, wider topic reads what the narrower one left (KAS:263-278)."""
+    from emu_lib import last_order_form
+    scs = []
+    for s in range(3):
+        brokers = list(range(50)) if s == 0 else [b for b in range(53) if b != 7 * s]
+        tps = []
+        for t, (w, P) in enumerate(((5, 900), (4, 700), (3, 500), (5, 300), (2, 200))):
+            cur = G.random_assignment(50 + s * 7 + t, P, 50, 10, w)
+            tps.append(Topic("topic-%d" % t, {p: cur[p].tolist() for p in range(P)}, w))
+        # (no rack map — every broker its own rack, KAS:82-86: with racks of equal size a load cap of ceil(mean) leaves the rack-aware
+        # first fit no slack at these widths, and a failed topic would end the scenario before the widths have met)
+        scs.append(Scenario(brokers=brokers, racks={}, want_context=False, topics=tps))
+    fb = flatten(scs)
+    want = oracle_solve(fb)
+    assert (want.topic_results["status"] == abi.KAS_OK).sum() >= 10, want.topic_results["status"]
+    assert_same_outputs(fb, want, emu_solve(fb, flags=RELAX_TILES_64), "emu relaxation form, wide lists, topics of several widths")
+    assert last_order_form() == 4
+    # with a Context handed in the form does not apply: the wide ticket form + round form as before
+    for sc in scs:
+        sc.want_context = True
+    fbc = flatten(scs)
+    assert_same_outputs(fbc, oracle_solve(fbc), emu_solve(fbc, flags=RELAX_TILES_64), "emu wide lists with a Context: ticket form")
+    assert last_order_form() == 2
+
+
 def test_emu_wide_lists_more_brokers_than_the_side_table_has_room_for():
     """Beyond ~6,500 brokers the wide ticket form's LDS has no room for the joint solve's front[] words
     (one per node): the kernel then runs without side dependencies — same results."""

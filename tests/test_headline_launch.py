@@ -84,6 +84,7 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
         assert desc == HEADLINE_KERNELS % ixr, desc
         d_out = torch.full((fb.out_len,), -2, dtype=torch.int32, device=dev)
         d_sr.zero_()
+        st.wait_stream(torch.cuda.current_stream(dev))        # (the two fills above run on torch's stream: not beside the solve)
         plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
         st.synchronize()
         sr = _records(d_sr)
@@ -111,6 +112,7 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
     assert plan.describe() == CELLS16_KERNELS, plan.describe()
     d_out16 = torch.full((fb.out_len,), -2, dtype=torch.int16, device=dev)
     d_sr.zero_()
+    st.wait_stream(torch.cuda.current_stream(dev))
     plan.solve_device(d_c16.data_ptr(), d_out16.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
     st.synchronize()
     sr = _records(d_sr)
