@@ -387,7 +387,12 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *                          whatever the batch size.  Default: kas_p4_kernel for batches of >= 512 scenarios — it
  *                          frees the fill workgroup's registers and LDS early, which is what counts when several
  *                          batches share the GPU — and inside the fill workgroup below that and in kas_solve_host's
- *                          plans (a batch alone on the GPU: the shorter critical path counts)
+ *                          plans (a batch alone on the GPU: the shorter critical path counts).
+ *   KAS_PLAN_P4_WITH_ORDER (= both of the above; round 6)  first fit as a second wavefront of the ORDER kernel's workgroup
+ *                          (kas_p4_order_kernel; lists up to 3 wide on the relaxation form, no Context, no sampled verification —
+ *                          otherwise kas_p4_kernel): the order wavefront follows first fit's progress row by row instead of
+ *                          waiting behind a kernel boundary, so a batch that has the GPU to itself lasts
+ *                          fill + max(first fit, order) instead of fill + first fit + order
  *   KAS_PLAN_VERIFY_SAMPLE(k) relaxation form: k tiles of 64 rows per topic (evenly spaced, 1..255) are evaluated a second
  *                          time one row at a time — independent of how the LDS orders the lanes of an instruction —
  *                          and a scenario in which a row comes out differently reports KAS_FAIL_WATCHDOG instead of a

@@ -41,6 +41,7 @@ KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)
 KAS_PLAN_NO_RTN_QUOTA = 0x200000
 KAS_PLAN_SPLIT_P4 = 0x400000          # first fit in kas_p4_kernel whatever the batch size (default: from 512 scenarios on)
 KAS_PLAN_FILL_WITH_P4 = 0x800000      # first fit inside the fill workgroup whatever the batch size
+KAS_PLAN_P4_WITH_ORDER = 0xC00000     # both: first fit as a second wavefront of the order kernel's workgroup (kas_p4_order_kernel)
 
 
 def KAS_PLAN_VERIFY_SAMPLE(k: int) -> int:

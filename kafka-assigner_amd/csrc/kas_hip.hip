@@ -80,9 +80,6 @@ __global__ __launch_bounds__(64) void kas_order_round_kernel(KasLaunch a) {
 #ifndef KAS_P4_KERNEL_WAVES
 #define KAS_P4_KERNEL_WAVES 1
 #endif
-#ifndef KAS_P4_PRIO
-#define KAS_P4_PRIO 2
-#endif
 template <int W>
 __global__ __launch_bounds__(64 * KAS_P4_KERNEL_WAVES) void kas_p4_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
@@ -164,6 +161,23 @@ static void (*kas_order_relax_any(int Wc, int dual, int ctx, int verify, int c16
   return verify ? nullptr : kas_order_relax_pick<false>(Wc, dual, ctx);
 }
 
+// first fit (P4) and the relaxation form of P5 in one workgroup of two wavefronts (kas_order_relax.h, p4_order_scenario): the order
+// wavefront follows first fit's progress instead of waiting behind a kernel boundary — for launches whose latency is a scenario's
+template <int W, bool DUAL, bool C16, bool IDL>
+__global__ __launch_bounds__(128) void kas_p4_order_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::p4_order_scenario<W, DUAL, C16, IDL>(a, (int32_t)blockIdx.x, kas_lds);
+}
+// (int32 cells with the broker ids in the LDS, or 16-bit cells: the instances that wait for no gather)
+static void (*kas_p4_order_pick(int Wc, int dual, int c16))(KasLaunch) {
+  if (Wc <= 2) return c16 ? kas_p4_order_kernel<2, false, true, false> : kas_p4_order_kernel<2, false, false, true>;
+  if (Wc == 3) {
+    if (c16) return dual ? kas_p4_order_kernel<3, true, true, false> : kas_p4_order_kernel<3, false, true, false>;
+    return dual ? kas_p4_order_kernel<3, true, false, true> : kas_p4_order_kernel<3, false, false, true>;
+  }
+  return nullptr;
+}
+
 // lists 4 and 5 wide, relaxation form: one wavefront (= one workgroup) per scenario (kas_order_relax_wide.h)
 template <int W>
 __global__ __launch_bounds__(64) void kas_order_relax_wide_kernel(KasLaunch a) {
@@ -222,6 +236,7 @@ static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
 static kas_kernel_fn kas_order_wide_for(int) { return kas_order_wide_kernel<5>; }
 static kas_kernel_fn kas_order_relaxw_for(int) { return kas_order_relax_wide_kernel<5>; }
+static kas_kernel_fn kas_p4_order_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_relax_for(int, int, int, int = 0, int = 0, int = 0) { return nullptr; }
 static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_kernels_w<5>() : KasSpreadKernels{nullptr, nullptr, nullptr, nullptr}; }
 #elif defined(KAS_MINIMAL_INSTANCES) && KAS_MINIMAL_INSTANCES != 0
@@ -238,6 +253,7 @@ static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<3>; }
 static kas_kernel_fn kas_order_wide_for(int) { return nullptr; }
 static kas_kernel_fn kas_order_relaxw_for(int) { return nullptr; }
+static kas_kernel_fn kas_p4_order_for(int, int dual, int c16) { return kas_p4_order_pick(3, dual, c16); }
 static kas_kernel_fn kas_order_relax_for(int, int dual, int ctx, int verify = 0, int c16 = 0, int idl = 0) {
   return kas_order_relax_any(3, dual, ctx, verify, c16, idl);
 }
@@ -299,6 +315,7 @@ static kas_kernel_fn kas_order_wide_for(int Wc) {
 static kas_kernel_fn kas_order_relaxw_for(int Wc) {
   return Wc == 4 ? kas_order_relax_wide_kernel<4> : (Wc == 5 ? kas_order_relax_wide_kernel<5> : nullptr);
 }
+static kas_kernel_fn kas_p4_order_for(int Wc, int dual, int c16) { return kas_p4_order_pick(Wc, dual, c16); }
 static kas_kernel_fn kas_order_relax_for(int Wc, int dual, int ctx, int verify = 0, int c16 = 0, int idl = 0) {
   return kas_order_relax_any(Wc, dual, ctx, verify, c16, idl);
 }
@@ -593,6 +610,11 @@ static int kas_plan_set_kernels(kas_plan* p) {
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_round_for(p->Wc),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_order_round_lds(p->shape.n_max, p->Wc)));
+  for (int dual = 0; dual < 2; ++dual)
+    if (p->shape.relax_ok && !p->shape.any_ctx && (p->cells16 || kas_plan_relax_idl(p)) && kas_p4_order_for(p->Wc, dual, p->cells16) &&
+        kas_p4_order_lds(p->shape.n_max, dual, kas_plan_relax_idl(p)) <= KAS_LDS_LIMIT)
+      KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_p4_order_for(p->Wc, dual, p->cells16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kas_p4_order_lds(p->shape.n_max, dual, kas_plan_relax_idl(p))));
   if (p->shape.relaxw_ok && kas_order_relaxw_for(p->Wc))
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relaxw_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_order_relaxw_lds(p->shape.n_max, p->Wc)));
@@ -806,6 +828,7 @@ int kas_plan_create16(kas_ctx* ctx, const kas_batch_desc* batch, kas_plan** out_
 
 // the launch decisions of kas_solve_device, in one place
 struct KasLaunchPlan {
+  bool p4_order;                // first fit inside the order kernel's workgroup (kas_p4_order_kernel; then `relax`, and no kas_p4_kernel)
   bool relaxw;                  // relaxation form of P5 for lists 4 and 5 wide (then neither tickets nor wide)
   bool relax;                   // relaxation form of P5 (then neither tickets nor wide)
   bool tickets, pairing, wide;
@@ -823,12 +846,22 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
   lp.relaxw = !lp.relax && !p->cells16 && p->shape.relaxw_ok && p->ctx->lds_lane_order_ok && kas_order_relaxw_for(p->Wc) != nullptr &&
               kas_relaxw_wanted(p->flags);
   lp.wide = !lp.tickets && !lp.relaxw && !p->cells16 && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
+  lp.p4_order = false;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
   lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD;
   if (lp.relax) {
+    const int dual = p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios);
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
-    lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios), p->shape.any_ctx,
-                                               kas_plan_relax_idl(p));
+    lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx, kas_plan_relax_idl(p));
+    // first fit as a second wavefront of the order kernel's workgroup?
+    const bool relax_plain = !p->shape.any_ctx && (p->flags >> 24) == 0u && (p->cells16 || kas_plan_relax_idl(p)) &&
+                             kas_p4_order_for(p->Wc, dual, p->cells16) != nullptr && p->b_p4s.p != nullptr;
+    if (kas_p4_with_order(p->shape, p->NW, p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL), kas_plan_spread_chunks(p), p->n_scenarios,
+                          relax_plain, dual, kas_plan_relax_idl(p))) {
+      lp.p4_order = true;
+      lp.order_block = 128u;
+      lp.order_lds = (size_t)kas_p4_order_lds(p->shape.n_max, dual, kas_plan_relax_idl(p));
+    }
   } else if (lp.relaxw) {
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
     lp.order_lds = (size_t)kas_order_relaxw_lds(p->shape.n_max, p->Wc);
@@ -859,7 +892,11 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   const char* ctx_tail = (lp.wide && p->shape.wide_checked)
                              ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
                              : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
-  if (lp.relax)
+  if (lp.relax && lp.p4_order)
+    snprintf(order, sizeof(order), "kas_p4_order_kernel<%d>[first fit + relaxation form, tiles of %d rows%s] grid=%ux%u lds=%zu", p->Wc,
+             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, kas_plan_relax_idl(p) ? ", ids in LDS" : "",
+             lp.order_grid, lp.order_block, lp.order_lds);
+  else if (lp.relax)
     snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s%s] grid=%ux%u lds=%zu%s", p->Wc,
              (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
              kas_plan_relax_idl(p) ? ", ids in LDS" : "",
@@ -891,7 +928,7 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   }
   char p4[96];
   p4[0] = 0;
-  if (kas_plan_split_p4(p))                                    // first fit (P4) is a launch of its own between the two
+  if (kas_plan_split_p4(p) && !lp.p4_order)                    // first fit (P4) is a launch of its own between the two
     snprintf(p4, sizeof(p4), " + kas_p4_kernel<%d> grid=%ux%u lds=%zu", p->Wc, (unsigned)p->n_scenarios, 64u * KAS_P4_KERNEL_WAVES,
              (size_t)kas_p4_lds_layout(p->shape.n_max).total);
   const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s%s + %s%s", spread, p->Wc, p->NW,
@@ -988,7 +1025,7 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
-  if (split_p4) {
+  if (split_p4 && !lp.p4_order) {
     hipLaunchKernelGGL(kas_p4_for(p->Wc), dim3((unsigned)p->n_scenarios), dim3(64 * KAS_P4_KERNEL_WAVES),
                        (size_t)kas_p4_lds_layout(p->shape.n_max).total, st, a);
     KAS_HIP_TRY(hipGetLastError());
@@ -1016,7 +1053,9 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   if (true) {}
   else
 #endif
-  if (lp.relax)
+  if (lp.relax && lp.p4_order)
+    hipLaunchKernelGGL(kas_p4_order_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->cells16), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+  else if (lp.relax)
     hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u, p->cells16, kas_plan_relax_idl(p)),
                        dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (lp.relaxw)

@@ -293,6 +293,10 @@ KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, uint32_t w0_cells, uint32_t w1
 #ifndef KAS_RELAX_PRIO
 #define KAS_RELAX_PRIO 3
 #endif
+// ... and of a first-fit wavefront (kas_p4_kernel; wavefront 1 of kas_p4_order_kernel)
+#ifndef KAS_P4_PRIO
+#define KAS_P4_PRIO 2
+#endif
 // VERIFY: the instances for plans that ask for the sampled verification (KAS_PLAN_VERIFY_SAMPLE) — kernels of their own because
 // the second evaluation keeps a tile's addresses and addends alive behind its loop: 67 instead of 60 vector registers for
 // the instance with tiles of 64 rows, one register-file slot more than two of its wavefronts may take beside a fill wavefront
@@ -304,9 +308,16 @@ KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, uint32_t w0_cells, uint32_t w1
 // the L2-resident node table cost a round trip of ~700: order kernel alone 1.79 -> 1.46 ms per 1000 scenarios, twelve batches in
 // flight 643k -> 726k scenarios/s (profiles/r06a_*).  IDL = false keeps the gather from the node table (asked for through
 // kasw::gload_u32_async, waited for at the step's one s_waitcnt): broker counts whose ids do not fit.
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false>
-KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+// FS (kas_p4_order_kernel, round 6): first fit (P4) runs as a second wavefront of THIS workgroup (p4_scenario<W, 1, true>) and this
+// wavefront follows it through fs[] — it asks for a tile's mid rows only when first fit is done with them (every row below the
+// next window's first orphan is final), so that P5's chain starts while P4 is still placing orphans further down instead of
+// behind a kernel boundary: a batch that has the GPU to itself lasts fill + max(P4, P5) instead of fill + P4 + P5.  A topic first
+// fit fails (KAS:183-184) is abandoned where this wavefront stands: its rows' digest is dropped, fs[2] says that nothing more is
+// written, and the first-fit wavefront pads the topic (nothing is returned for it: KAG:173-184).
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool FS = false>
+KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, uint64_t* fs = nullptr) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
+  static_assert(!FS || (!CTX && !VERIFY), "first fit in the order kernel's workgroup: batches without a Context, no sampled verification");
   // (16-bit cells: with no broker ids to wait for the raised priority stops paying — 8 x 20 steps 815-834k scenarios/s at
   // priority 0 against 803-815k at 3, 8 x 40 steps 833-865k against 824-853k, same box, gpurun_out/r5pr2)
   if constexpr (KAS_RELAX_PRIO > 0 && !C16) kasw::set_priority<KAS_RELAX_PRIO>();
@@ -383,12 +394,32 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
   uint32_t rows1 = 0u, rows2 = 0u;                           // rows that added to a [0] / [1] field (wave-uniform)
   bool unsound = false;
   const int32_t verify_k = VERIFY ? (int32_t)(a.flags >> 24) : 0;
+  bool aborted = false;                                      // (FS) first fit failed a topic: the scenario ends there
+  // (FS) wait until first fit is done with rows [0, upto) of topic k; false: the topic (or an earlier one) has failed
+  auto rows_final = [&](int32_t k, int32_t upto) -> bool {
+    if constexpr (FS) {
+      int32_t idle = 0;
+      for (;;) {
+        kasw::repoll();
+        const uint64_t f = kasw::load_shared_u64_lds(&fs[0]), fk = kasw::load_shared_u64_lds(&fs[1]);
+        const int32_t ft = (int32_t)(f >> 32), fr = (int32_t)(uint32_t)f;
+        if (kasw::ballot(fk <= (uint64_t)(uint32_t)k) != 0ull) return false;
+        if (kasw::ballot(ft > k || (ft == k && fr >= upto)) != 0ull) return true;
+        if (watchdog_poll(reinterpret_cast<uint32_t*>(&fs[3]), false, idle)) { stuck = true; return false; }
+      }
+    }
+    return true;
+  };
   for (int32_t k = 0; k < sd.topic_count; ++k) {
     const int32_t ti = sd.topic_begin + k;
+    if constexpr (FS) {
+      if (!rows_final(k, 0)) { aborted = true; break; }      // (first fit has reached this topic; an earlier failure ends the scenario)
+    }
     if (a.topic_results[ti].status != KAS_OK) continue;     // (a failed or skipped topic emits nothing)
     const kas_topic_desc td = a.topics[ti];
     const int32_t P = td.n_partitions, ow = td.out_width;
     if (P <= 0) continue;
+    uint64_t dtop = 0;                                       // the topic's digest: counted when the topic is through
     int32_t* out = C16 ? nullptr : a.out + td.out_off;
     uint16_t* out16 = C16 ? reinterpret_cast<uint16_t*>(a.out) + td.out_off : nullptr;
     const uint16_t* mid = C16 ? out16 : mid_base(out, P, ow);
@@ -608,7 +639,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
                   if constexpr (CTX) { if (r == 2 && r < Lp) kasw::lds_add_u32(cnt2 + cell, 1u); }
                   if constexpr (C16) out16[(int64_t)p * ow + r] = (uint16_t)id;
                   else out[(int64_t)p * ow + r] = id;
-                  if (r < Lp) digest += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
+                  if (r < Lp) dtop += kas_digest_cell((uint32_t)k, (uint32_t)p, (uint32_t)r, id);
                 }
               }
             }
@@ -635,7 +666,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
           }
         }
         // the previous step's final rows go out,
-        digest += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
+        dtop += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
         // and the requests are made: the broker ids of this step's final rows, the mid rows two steps on
         // (every in-flight register has ONE requesting statement, executed on every path: a step without final rows of
         // its own asks for node 0's id, a single-tile step of the double-tile instance asks for a tile it had already)
@@ -661,10 +692,17 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
               for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
           }
-          digest += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
+          dtop += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
+        }
+        // (FS: the rows about to be asked for must be final — first fit is usually far ahead, and this is two LDS reads)
+        bool gone = false;
+        if constexpr (FS) {
+          const int32_t upto = (tile + 2 * NB) << 6;
+          gone = tile < nt && !rows_final(k, upto < P ? upto : P);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) request_tile(nx[b], tile + NB + b);
+        if (gone) { aborted = true; break; }                 // (wave-uniform; the requests above are waited for below, their rows dropped)
       }
       // the topic's last rows (and no request is left outstanding: its register would be written behind our back)
       kasw::wait_loads();
@@ -675,10 +713,32 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
 #pragma unroll
         for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
       }
-      digest += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
+      if (aborted) pend.n = 0;                               // (FS: the topic has failed, nothing more is written)
+      dtop += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
     };
+    if constexpr (FS) {
+      // the first tiles' rows must be final before they are asked for
+      const int32_t upto0 = (2 * (DUAL ? 2 : 1)) << 6;
+      if (!rows_final(k, upto0 < P ? upto0 : P)) { aborted = true; break; }
+    }
     if (ow == W) topic_rows(std::true_type{});
     else topic_rows(std::false_type{});
+    if (aborted) break;
+    digest += dtop;
+  }
+  if constexpr (FS) {
+    if (aborted) {
+      // nothing of mine is on its way to the failed topic's rows any more: say so, the first-fit wavefront pads them
+      kasw::wave_sync();
+      if (lane == 0) kasw::store_shared_u64_lds(&fs[2], 1ull);
+    }
+    // the records of this scenario are first fit's until it has passed the last topic; the digest goes in behind them
+    int32_t idle = 0;
+    for (;;) {
+      kasw::repoll();
+      if (kasw::ballot((int32_t)(kasw::load_shared_u64_lds(&fs[0]) >> 32) >= sd.topic_count) != 0ull) break;
+      if (watchdog_poll(reinterpret_cast<uint32_t*>(&fs[3]), false, idle)) { stuck = true; break; }
+    }
   }
   {
     // conservation: the fields of every node's word against the rows that added to them (and the padding node's word untouched)
@@ -686,7 +746,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     uint32_t f0 = 0u, f1 = 0u;
     for (int32_t n = lane; n < N; n += 64) { const uint32_t w = cnt[n]; f0 += w & 0xffffu; f1 += w >> 16; }
     const uint32_t d0 = (uint32_t)kasw::wave_sum((int)f0) - seed0, d1 = (uint32_t)kasw::wave_sum((int)f1) - seed1;
-    if (!stuck && (d0 != rows1 || d1 != rows2 || kasw::ballot(cnt[nmax] != KAS_RELAX_PAD_WORD) != 0ull)) unsound = true;
+    if (!stuck && !aborted && (d0 != rows1 || d1 != rows2 || kasw::ballot(cnt[nmax] != KAS_RELAX_PAD_WORD) != 0ull)) unsound = true;
   }
   if constexpr (CTX) {
     // the Context goes back (KAS:360-369): every row has retired, the words hold every commit
@@ -710,6 +770,27 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
       st[8] = kasw::clock_ticks() - t_begin; st[9] = n_evals; st[12] = n_tiles; st[13] = n_slow; st[10] = n_verified; st[11] = unsound ? 1 : 0;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kas_p4_order_kernel, one scenario: first fit (P4) and the relaxation form of P5 in ONE workgroup of two wavefronts —
+// wavefront 0 is order_relax<.., FS>, wavefront 1 is p4_scenario<W, 1, FS> on the hand-over of the fill kernel
+// (KAS_FLAG_SPLIT_P4: loads after the sticky fill, the chunks' orphan lists), and fs[] (four 8-byte words of LDS between
+// the two carve-ups) is how the first follows the second.  LDS: kas_p4_order_lds.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int W, bool DUAL, bool C16, bool IDL>
+KAS_DEV void p4_order_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+  const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
+  const int32_t off_fs = kas_align16(kas_order_relax_lds(nmax, DUAL ? 1 : 0, 0, (IDL && !C16) ? 1 : 0));
+  uint64_t* fs = reinterpret_cast<uint64_t*>(lds_raw + off_fs);
+  if (kasw::tid() < 4) fs[kasw::tid()] = kasw::tid() == 1 ? 0x7fffffffull : 0ull;   // rows final: none; failed topic: none; no answer; no watchdog
+  kasw::sync();                                              // (the one workgroup barrier: both wavefronts pass it exactly once)
+  if (kasw::wave_id() == 0) {
+    order_relax<W, DUAL, false, false, C16, IDL, true>(a, s, lds_raw, fs);
+  } else {
+    if constexpr (KAS_P4_PRIO > 0) kasw::set_priority<KAS_P4_PRIO>();
+    p4_scenario<W, 1, true>(a, s, lds_raw + off_fs + 32, fs);
   }
 }
 

@@ -358,6 +358,19 @@ KAS_ABI_FN KasP4Lds kas_p4_lds_layout(int32_t n_max) {
   return L;
 }
 
+// LDS of kas_p4_order_kernel (first fit as a second wavefront of the relaxation form's workgroup, kas_order_relax.h): the order
+// wavefront's carve-up, four 8-byte words between the two, first fit's carve-up
+KAS_ABI_FN int32_t kas_p4_order_lds(int32_t n_max, int32_t double_tiles, int32_t with_ids) {
+  return kas_align16(kas_order_relax_lds(n_max, double_tiles, 0, with_ids)) + 32 + kas_p4_lds_layout(n_max).total;
+}
+// First fit inside the order kernel's workgroup for this launch?  Lists up to 3 wide on the relaxation form without a Context and
+// without the sampled verification, the fill kernel handing first fit over (what kas_split_p4 needs).  Asked for by naming BOTH
+// first-fit switches (KAS_PLAN_SPLIT_P4 | KAS_PLAN_FILL_WITH_P4 = KAS_PLAN_P4_WITH_ORDER); by itself — KAS_P4_WITH_ORDER_BELOW —
+// for batches too small to fill the GPU, where a scenario's latency is the batch's.
+#ifndef KAS_P4_WITH_ORDER_BELOW
+#define KAS_P4_WITH_ORDER_BELOW 0          // batches of fewer scenarios than this take it unless told otherwise (0: only on request)
+#endif
+#define KAS_FLAG_P4_WITH_ORDER (KAS_FLAG_SPLIT_P4 | KAS_FLAG_FILL_WITH_P4)
 // widths the kernels are instantiated for; a batch uses the smallest one >= its widest list
 KAS_ABI_FN int32_t kas_width_class(int32_t W) { return W <= 2 ? 2 : W <= 5 ? W : 8; }
 
@@ -404,10 +417,21 @@ struct KasShape {
 // against 617k scenarios/s); a batch that has the GPU to itself waits for that wavefront's windows one after the other
 // (1000 scenarios alone: fill + first fit 1.39 ms against 1.07 ms on the fill's four wavefronts).
 static inline bool kas_split_p4(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks, int32_t n_scenarios) {
-  if (!(s.with_x && nw == KAS_P4_WAVES && !(launch_flags & (KAS_FLAG_GENERIC_FILL | KAS_FLAG_FILL_WITH_P4)) && spread_chunks == 0 &&
-        kas_p4_lds_layout(s.n_max).total <= KAS_LDS_LIMIT))
+  const bool both = (launch_flags & KAS_FLAG_P4_WITH_ORDER) == KAS_FLAG_P4_WITH_ORDER;   // (first fit in the order kernel's workgroup: handed over too)
+  if (!(s.with_x && nw == KAS_P4_WAVES && !(launch_flags & KAS_FLAG_GENERIC_FILL) && (both || !(launch_flags & KAS_FLAG_FILL_WITH_P4)) &&
+        spread_chunks == 0 && kas_p4_lds_layout(s.n_max).total <= KAS_LDS_LIMIT))
     return false;
-  return (launch_flags & KAS_FLAG_SPLIT_P4) != 0u || n_scenarios >= KAS_SPLIT_P4_FROM;
+  return (launch_flags & KAS_FLAG_SPLIT_P4) != 0u || n_scenarios >= KAS_SPLIT_P4_FROM || n_scenarios < KAS_P4_WITH_ORDER_BELOW;
+}
+// ... and then: inside the order kernel's workgroup (true) or in kas_p4_kernel (false)?  `relax_plain`: the launch takes the relaxation
+// form without a Context and without the sampled verification; `with_ids`: its instance keeps the broker ids in the LDS
+static inline bool kas_p4_with_order(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks, int32_t n_scenarios,
+                                     bool relax_plain, int32_t double_tiles, int32_t with_ids) {
+  if (!relax_plain || !kas_split_p4(s, nw, launch_flags, spread_chunks, n_scenarios)) return false;
+  if (kas_p4_order_lds(s.n_max, double_tiles, with_ids) > KAS_LDS_LIMIT) return false;
+  if ((launch_flags & KAS_FLAG_P4_WITH_ORDER) == KAS_FLAG_P4_WITH_ORDER) return true;
+  if (launch_flags & (KAS_FLAG_SPLIT_P4 | KAS_FLAG_FILL_WITH_P4)) return false;
+  return n_scenarios < KAS_P4_WITH_ORDER_BELOW;
 }
 
 // Fused histogram layout of the rack-diverse fill (kas_fill_lds_layout with_x = 2): lists up to 3 wide

@@ -1135,9 +1135,12 @@ KAS_DEV int32_t fill_pass_b(const LdsView& L, const TopicView& T, const NodeMap&
 #endif
 // (NC: chunk lists the orphans come in — the fill's wavefronts — where that is not the number of wavefronts running the
 // windows: kas_p4_kernel)
+// (fin != nullptr — first fit in the order kernel's workgroup, kas_p4_order_kernel, NW == 1: behind every finished window the word
+//  gets fin_hi | rows of the topic that are FINAL — every row below the next window's first orphan; the order wavefront of the
+//  same workgroup follows it)
 template <int W, int NW, int NC = NW>
 KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t live_count, int32_t wave,
-                               int64_t (&st)[8], int32_t& fail_win, int32_t& fail_row) {
+                               int64_t (&st)[8], int32_t& fail_win, int32_t& fail_row, uint64_t* fin = nullptr, uint64_t fin_hi = 0ull) {
   const int lane = kasw::lane();
   uint64_t* prog = (uint64_t*)&L.ctl[KAS_CTL_PROG];
   int32_t oc[NC], total = 0;
@@ -1280,6 +1283,11 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
       while (head < live_count && lds_load(L, (int32_t)L.live[head]) >= cap) ++head;
       kasw::lds_atomic_max(&L.ctl[KAS_CTL_HEAD], head);
       prog[wave] = (uint64_t)(uint32_t)(w + 1) << 32;
+    }
+    if (fin != nullptr) {                                    // (wave-uniform) this window's mid-row cells are out: publish
+      const int32_t nxt0 = kasw::shfl(p_nxt, 0);             // the next window's first orphan (ascending rows), or none
+      kasw::wave_sync();                                     // (release: the stores above before the word)
+      if (lane == 0) kasw::store_shared_u64_lds(fin, fin_hi | (uint64_t)(uint32_t)(nxt0 >= 0 ? nxt0 : T.P));
     }
   }
 }
@@ -1698,11 +1706,19 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 // topic (KAS:183-184), the topics behind it are skipped (KAG:173-184 aborted) and emit nothing, and the scenario's
 // record says so — what fill_scenario does when first fit runs inside it.
 // ---------------------------------------------------------------------------------------------
-template <int W, int PW>
-KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
+// FS (kas_p4_order_kernel: first fit as ONE wavefront of the order kernel's workgroup, whatever its index there): the workgroup
+// barriers become wavefront barriers, and fs[] carries what the order wavefront follows —
+//   fs[0]  topic << 32 | rows of that topic that are final (first fit done with them; a topic that needs none: all its rows)
+//   fs[1]  the topic first fit failed at (KAS:183-184), or 0x7fffffff;  fs[2]  the order wavefront's answer: it has stopped writing
+// — and a failed topic's padding waits for that answer (the order wavefront may have emitted rows of it already).
+template <int W, int PW, bool FS = false>
+KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw, uint64_t* fs = nullptr) {
   constexpr int NW = PW, NT = 64 * NW, NC = KAS_P4_WAVES;    // PW wavefronts run the windows over the fill's NC chunk lists
-  const int tid = kasw::tid(), lane = kasw::lane();
-  const int32_t wave = kasw::wave_id();
+  static_assert(!FS || PW == 1, "first fit inside the order kernel's workgroup is one wavefront");
+  const int lane = kasw::lane();
+  const int tid = FS ? lane : kasw::tid();
+  const int32_t wave = FS ? 0 : kasw::wave_id();
+  auto barrier = [&]() { if constexpr (FS) kasw::wave_sync(); else kasw::sync(); };
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
   // (a scenario the fill kernel failed at topic k2 still has its rack-diverse topics before k2 waiting for their first fit)
@@ -1726,6 +1742,7 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     int32_t* const orph_topic = orph;
     orph += (int64_t)((td.n_partitions > 0 ? td.n_partitions : 0) + 63) / 64 * 64;
     if (failed) {                                            // KAG:173-184 aborted: nothing is returned for this topic
+      // (FS: the order wavefront skips every topic behind fs[1] and never writes there)
       out_pad(topic_out(a, td), (int64_t)td.n_partitions * td.out_width, tid, NT);
       if (tid == 0) {
         kas_topic_result tr;
@@ -1737,7 +1754,12 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     const kas_topic_result tr0 = a.topic_results[ti];
     moved_r += tr0.moved_replicas; moved_p += tr0.moved_partitions;
     const int32_t* p4s = a.p4s + (int64_t)ti * (KAS_P4S_HEAD + a.n_max);
-    if (tr0.status != KAS_OK || p4s[0] == 0) continue;       // (workgroup-uniform: nothing handed over)
+    if (tr0.status != KAS_OK || p4s[0] == 0) {               // (workgroup-uniform: nothing handed over)
+      if constexpr (FS) {                                    // every row of the topic is final as the fill kernel left it
+        if (lane == 0) kasw::store_shared_u64_lds(&fs[0], ((uint64_t)(uint32_t)k << 32) | (uint64_t)(uint32_t)(td.n_partitions > 0 ? td.n_partitions : 0));
+      }
+      continue;
+    }
     TopicView T;
     T.c16 = cells16(a); T.cur = nullptr; T.orph = orph_topic; T.len_arr = nullptr; T.inp_arr = nullptr;
     T.pid_arr = td.part_id_off >= 0 ? a.aux + td.part_id_off : nullptr;
@@ -1746,10 +1768,10 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
     T.mid = topic_mid(a, td);
     T.cap = p4s[1];
     const int32_t cap = T.cap;
-    kasw::sync();                                            // (the previous topic's node state has been read)
+    barrier();                                            // (the previous topic's node state has been read)
     for (int32_t i = tid; i < N; i += NT) { L.load[i] = p4s[KAS_P4S_HEAD + i]; L.rack[i] = (int16_t)g_node_rack[i]; }
     if (tid < KAS_CTL_INTS) L.ctl[tid] = tid == KAS_CTL_FAILROW ? -1 : (tid == KAS_CTL_FAILWIN ? 0x7fffffff : 0);
-    kasw::sync();
+    barrier();
     if (tid < NC) L.ctl[KAS_CTL_OC + tid] = p4s[2 + tid];
     if (wave == 0) {                                         // non-full nodes in processing order (KAS:168, 188-200), as fill_topic
       const int32_t idxN = java_abs_mod(T.hash, N);          // (>= 0: the fill kernel checked)
@@ -1766,18 +1788,42 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
       kasw::lockstep();
       if (lane == 0) L.ctl[KAS_CTL_LIVE] = live_count;
     }
-    kasw::sync();
+    barrier();
     int32_t fail_win = -1, fail_row = -1;
-    p4_lists_parallel<W, NW, NC>(L, T, L.ctl[KAS_CTL_LIVE], wave, st, fail_win, fail_row);
-    kasw::sync();                                            // KAS_CTL_FAILWIN is final: its wave reports the row
+    if constexpr (FS) {
+      // rows below the topic's first orphan are final already
+      const int32_t total_o = L.ctl[KAS_CTL_OC] + L.ctl[KAS_CTL_OC + 1] + L.ctl[KAS_CTL_OC + 2] + L.ctl[KAS_CTL_OC + 3];
+      int32_t first = T.P;
+      if (total_o > 0) {
+        int32_t w0 = 0;
+        while (w0 < NC - 1 && L.ctl[KAS_CTL_OC + w0] == 0) ++w0;
+        first = T.orph[(int64_t)chunk_begin<NC>(T.nt, w0) << 6];
+      }
+      if (lane == 0) kasw::store_shared_u64_lds(&fs[0], ((uint64_t)(uint32_t)k << 32) | (uint64_t)(uint32_t)first);
+      p4_lists_parallel<W, NW, NC>(L, T, L.ctl[KAS_CTL_LIVE], wave, st, fail_win, fail_row, &fs[0], (uint64_t)(uint32_t)k << 32);
+    } else {
+      p4_lists_parallel<W, NW, NC>(L, T, L.ctl[KAS_CTL_LIVE], wave, st, fail_win, fail_row);
+    }
+    barrier();                                            // KAS_CTL_FAILWIN is final: its wave reports the row
     if (fail_win >= 0 && fail_win == L.ctl[KAS_CTL_FAILWIN] && lane == 0) L.ctl[KAS_CTL_FAILROW] = fail_row;
-    kasw::sync();
+    barrier();
     const bool hung = KAS_SPIN_BOUND > 0 && L.ctl[KAS_CTL_WATCHDOG] != 0;
     const int32_t frow = L.ctl[KAS_CTL_FAILROW];
     if (hung || frow >= 0) {                                 // (workgroup-uniform)
       failed = true; fail_topic = k;
       fail_part = hung ? -1 : (T.pid_arr ? T.pid_arr[frow] : frow);
       moved_r -= tr0.moved_replicas; moved_p -= tr0.moved_partitions;
+      if constexpr (FS) {
+        // the order wavefront may have emitted rows of this topic: it stops when it sees fs[1], says so in fs[2], and only
+        // then is the topic padded (bounded like every wait between wavefronts: kas_solver_body.h, "Hang containment")
+        if (lane == 0) kasw::store_shared_u64_lds(&fs[1], (uint64_t)(uint32_t)k);
+        int32_t idle = 0;
+        for (;;) {
+          kasw::repoll();
+          if (kasw::ballot(kasw::load_shared_u64_lds(&fs[2]) != 0ull) != 0ull) break;
+          if (watchdog_poll(reinterpret_cast<uint32_t*>(&fs[3]), false, idle)) break;
+        }
+      }
       out_pad(topic_out(a, td), (int64_t)td.n_partitions * td.out_width, tid, NT);   // nothing is returned for a failed topic
       if (tid == 0) {
         kas_topic_result tr;
@@ -1790,6 +1836,10 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) 
         a.scenario_results[s] = sr;
       }
     }
+  }
+  if constexpr (FS) {
+    kasw::wave_sync();                                       // (the records above before the word)
+    if (lane == 0) kasw::store_shared_u64_lds(&fs[0], (uint64_t)(uint32_t)sd.topic_count << 32);
   }
   if (tid == 0 && a.stats) a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 3] += kasw::clock_ticks() - t_begin;
 }

@@ -203,6 +203,14 @@ KAS_DEV uint64_t load_shared_u64(const uint64_t* p) {
 KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// ... and an 8-byte word of LDS one wavefront of the workgroup writes and another polls (kas_p4_order_kernel: first fit's progress
+// for the order wavefront): one ds_write_b64 / ds_read_b64, so that the two halves are never seen apart
+KAS_DEV uint64_t load_shared_u64_lds(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+KAS_DEV void store_shared_u64_lds(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // A word of LDS another wave of the workgroup writes / reads (list counts, flags): a relaxed atomic access, NOT a volatile
 // one — `*(volatile uint32_t*)p` on a pointer the compiler holds as generic is a FLAT load (sc0 sc1) that the wave then
 // waits for with vmcnt(0); the atomic form keeps the LDS address space and becomes ds_read_b32 / ds_write_b32.  Re-read

@@ -224,6 +224,10 @@ template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, boo
   RunArgs* r = (RunArgs*)p;
   if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL>(*r->a, r->s, r->lds);
 }
+template <int W, bool DUAL, bool C16, bool IDL> void run_p4_order(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  if constexpr (W <= 3) kas::p4_order_scenario<W, DUAL, C16, IDL>(*r->a, r->s, r->lds);
+}
 typedef void (*relax_fn)(void*);
 template <bool VERIFY, bool C16, bool IDL> relax_fn relax_pick(int Wc, bool dual, bool ctx) {   // as kas_order_relax_pick (kas_hip.hip)
   if (Wc <= 2) return ctx ? run_order_relax<2, false, true, VERIFY, C16, IDL> : run_order_relax<2, false, false, VERIFY, C16, IDL>;
@@ -275,6 +279,7 @@ run_fn rounds_for(int Wc) {
 // rows the ticket-form solver decided inside queues during the last kas_emu_solve_batch (summed
 // over scenarios): lets a CPU test assert that the queue path ran, not only the one-row path
 static long g_last_queue_rows = 0;
+static int g_last_p4_order = 0;       // the last solve ran first fit inside the order kernel's workgroup (kas_p4_order_kernel)
 static int g_last_relax_idl = 0;      // the last relaxation-form launch read its broker ids from the LDS
 static long g_last_index_rows = 0;   // topics whose fill took the index rows (fill_pass_a_fused<EMIT>) in the last kas_emu_solve_batch
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
@@ -439,7 +444,13 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     g_last_index_rows += (long)a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 6];   // (the fill's own tally, before an order kernel writes there)
   }
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
-  if (split_p4) {
+  // first fit inside the order kernel's workgroup (kas_p4_order_kernel; same decision as kas_launch_plan in kas_hip.hip)
+  const bool relax_dual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
+  const bool relax_idl = !c16 && kas_relax_lds_ids(sh.n_max, sh.any_ctx) && !(getenv("KAS_EMU_RELAX_GATHER") && getenv("KAS_EMU_RELAX_GATHER")[0] == '1');
+  const bool p4_order = relax && kas_p4_with_order(sh, sh.NW, flags | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL), CH, b->n_scenarios,
+                                                   !sh.any_ctx && (a.flags >> 24) == 0u && (c16 || relax_idl), relax_dual, relax_idl);
+  g_last_p4_order = p4_order ? 1 : 0;
+  if (split_p4 && !p4_order) {
     // exactly the LDS the product launches kas_p4_kernel with, and a guard behind it
     const size_t p4_bytes = (size_t)kas_p4_lds_layout(sh.n_max).total;
     std::vector<unsigned char> pl(p4_bytes + 4096);
@@ -454,7 +465,23 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     }
   }
   // order kernel: one wavefront per scenario (relaxation form, round form), three per G scenarios (ticket form)
-  if (relax) {
+  if (relax && p4_order) {
+    run_fn f = sh.Wc <= 2 ? (c16 ? run_p4_order<2, false, true, false> : run_p4_order<2, false, false, true>)
+               : c16 ? (relax_dual ? run_p4_order<3, true, true, false> : run_p4_order<3, false, true, false>)
+                     : (relax_dual ? run_p4_order<3, true, false, true> : run_p4_order<3, false, false, true>);
+    const size_t fb_bytes = (size_t)kas_p4_order_lds(sh.n_max, relax_dual, relax_idl);   // exactly the product's LDS, and a guard behind it
+    std::vector<unsigned char> rl(fb_bytes + 4096);
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(rl.data(), 0xCD, fb_bytes);
+      memset(rl.data() + fb_bytes, 0xA5, 4096);
+      RunArgs ra{&a, s, rl.data()};
+      if (kasw::run_block(f, &ra, 2) != 0) return bad("first fit + order (kas_p4_order_kernel)", s);
+      for (size_t i = 0; i < 4096; ++i)
+        if (rl[fb_bytes + i] != 0xA5) return bad("kas_p4_order_kernel: LDS written beyond kas_p4_order_lds()", s);
+      const int64_t* st = a.stats + (int64_t)s * KAS_STATS_PER_SCENARIO;
+      g_last_relax_evals += (long)st[9]; g_last_relax_tiles += (long)st[12]; g_last_relax_slow += (long)st[13];
+    }
+  } else if (relax) {
     const bool rdual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
     // the instance kas_order_relax_any (kas_hip.hip) picks: 16-bit cells; int32 cells with the broker ids in the LDS
     // (kas_relax_lds_ids; KAS_EMU_RELAX_GATHER=1 in the environment: the instances that gather them from the node table, which
@@ -634,6 +661,9 @@ long kas_emu_last_index_rows(void) { return g_last_index_rows; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_relax_idl(void) { return g_last_relax_idl; }
+
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_p4_order(void) { return g_last_p4_order; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_spread(void) { return g_last_spread; }

@@ -189,6 +189,8 @@ KAS_DEV uint32_t load_shared_u32(const uint32_t* p) { return *(const volatile ui
 KAS_DEV void store_shared_u32(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 KAS_DEV uint64_t load_shared_u64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
 KAS_DEV void store_shared_u64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
+KAS_DEV uint64_t load_shared_u64_lds(const uint64_t* p) { return *(const volatile uint64_t*)p; }
+KAS_DEV void store_shared_u64_lds(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
 
 KAS_DEV int64_t clock_ticks() { return 0; }
 

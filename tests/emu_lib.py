@@ -242,6 +242,16 @@ def last_index_rows() -> int:
     return int(L.kas_emu_last_index_rows())
 
 
+def last_p4_order() -> int:
+    """1: the last emu_solve ran first fit inside the order kernel's workgroup (kas_p4_order_kernel: KAS_PLAN_SPLIT_P4 | KAS_PLAN_FILL_WITH_P4)"""
+    L = lib()
+    L.kas_emu_last_p4_order.restype = C.c_int
+    return int(L.kas_emu_last_p4_order())
+
+
+P4_WITH_ORDER = 0x400000 | 0x800000   # KAS_PLAN_P4_WITH_ORDER: both first-fit switches = first fit as a second wavefront of the order kernel's workgroup
+
+
 def last_relax_idl() -> int:
     """1: the relaxation form of the last emu_solve read the final rows' broker ids from the LDS (the IDL instances)"""
     L = lib()

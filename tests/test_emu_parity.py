@@ -203,7 +203,7 @@ def test_emu_protocols_survive_arbitrary_wave_speeds():
         "for acts, P, N in ((G.ACTIONS, 2000, 60), (('replace1', 'add_k'), 3500, 80)):\n"
         "    fb = _batch(99, 4, P, N, 8, 3, acts)\n"
         "    want = oracle_solve(fb)\n"
-        "    for flags in (0, 0x10000, 1 << 12, (8 << 8) | (4 << 12)):\n"
+        "    for flags in (0, 0x10000, 1 << 12, (8 << 8) | (4 << 12), 0xC00000, 0xC00000 | 0x20000):\n"   # 0xC00000: first fit as a wavefront of the order kernel's workgroup
         "        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), 'chaos')\n"
         "for rf, acts in ((5, ('add_k', 'mixed')), (4, G.ACTIONS)):\n"      # the wide ticket form: joint solve, claim lists
         "    fb = _batch(77, 2, 1500, 120, 12, rf, acts)\n"
@@ -411,6 +411,43 @@ def test_emu_wide_lists_relaxation_form_topics_of_several_widths_share_the_count
     fbc = flatten(scs)
     assert_same_outputs(fbc, oracle_solve(fbc), emu_solve(fbc, flags=RELAX_TILES_64), "emu wide lists with a Context: ticket form")
     assert last_order_form() == 2
+
+
+@pytest.mark.parametrize("P,N,R,RF,actions", [
+    (1000, 40, 8, 3, G.ACTIONS),
+    (3000, 100, 10, 3, ("remove1",)),
+    (2048, 64, 8, 2, ("add_k",)),
+    (8000, 80, 8, 3, ("replace1", "add_k")),   # most scenarios strand a partition (KAS:183-184): the abandon path
+])
+def test_emu_first_fit_as_a_wavefront_of_the_order_kernels_workgroup(P, N, R, RF, actions):
+    """Round 6, kas_p4_order_kernel (KAS_PLAN_SPLIT_P4 | KAS_PLAN_FILL_WITH_P4): first fit runs as the second wavefront of the
+    relaxation form's workgroup and the order wavefront follows its progress — it asks for a tile's mid rows only when first fit is
+    done with them, abandons a topic first fit fails (whose rows the first-fit wavefront then pads) and writes its digest behind
+    first fit's records.  Against the oracle, both tile sizes, both cell widths, with and without index rows."""
+    from emu_lib import INDEX_ROWS, P4_WITH_ORDER, emu_solve16, last_p4_order
+    from test_cells16 import _want16
+    fb = _batch(1234, 6, P, N, R, RF, actions)
+    want = oracle_solve(fb)
+    for flags in (P4_WITH_ORDER, P4_WITH_ORDER | RELAX_TILES_64, P4_WITH_ORDER | RELAX_TILES_128, P4_WITH_ORDER | INDEX_ROWS):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu first fit + order in one workgroup, flags {flags:#x}")
+        assert last_p4_order() == 1
+    assert_same_outputs(fb, _want16(fb), emu_solve16(fb, flags=P4_WITH_ORDER | RELAX_TILES_64), "emu first fit + order in one workgroup, 16-bit cells")
+    assert last_p4_order() == 1
+    # where it does not apply the two kernels run as before: the ticket form asked for, the sampled verification, the general fill
+    for flags in (P4_WITH_ORDER | TICKET_ORDER, P4_WITH_ORDER | RELAX_TILES_64 | (8 << 24), P4_WITH_ORDER | 1):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu, flags {flags:#x}")
+        assert last_p4_order() == 0
+
+
+def test_emu_first_fit_with_order_topics_failing_at_different_places():
+    from emu_lib import P4_WITH_ORDER, last_p4_order
+    fb = _multi_topic_scenarios(77, 3, 3, 700, 40, 8, 3)
+    want = oracle_solve(fb)
+    st = want.topic_results["status"]
+    assert (st == abi.KAS_FAIL_UNASSIGNABLE).any() and (st == abi.KAS_SKIPPED).any() and (st == abi.KAS_OK).sum() >= 4
+    for flags in (P4_WITH_ORDER | RELAX_TILES_64, P4_WITH_ORDER | RELAX_TILES_128):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), "emu first fit + order in one workgroup, several topics")
+        assert last_p4_order() == 1
 
 
 def test_emu_wide_lists_more_brokers_than_the_side_table_has_room_for():

@@ -76,12 +76,16 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
     for flags, what, ixr in ((0, "as the plan chooses", dflt),
                              (abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64, "SPLIT_P4 | RELAX_TILES(1)", dflt),
                              (abi.KAS_PLAN_NO_INDEX_ROWS, "cur read by both row scans of the fill", ""),
-                             (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", ", index rows")):
+                             (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", ", index rows"),
+                             (abi.KAS_PLAN_P4_WITH_ORDER, "first fit as a wavefront of the order kernel's workgroup", None)):
         plan = native.Plan(ctx, fb)
         if flags:
             plan.set_flags(flags)
         desc = plan.describe()
-        assert desc == HEADLINE_KERNELS % ixr, desc
+        if ixr is None:
+            assert "kas_p4_order_kernel<3>[first fit + relaxation form, tiles of 64 rows, ids in LDS] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
+        else:
+            assert desc == HEADLINE_KERNELS % ixr, desc
         d_out = torch.full((fb.out_len,), -2, dtype=torch.int32, device=dev)
         d_sr.zero_()
         st.wait_stream(torch.cuda.current_stream(dev))        # (the two fills above run on torch's stream: not beside the solve)

@@ -75,6 +75,9 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FILL_WITH_P4), "hip first fit inside the fill workgroup (no kas_p4_kernel)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4), "hip first fit in kas_p4_kernel (what batches of >= 512 scenarios take)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip kas_p4_kernel + tiles of 64 rows: the headline's kernels")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER), "hip first fit as a wavefront of the order kernel's workgroup (kas_p4_order_kernel where it applies)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER | TILES_64), "hip kas_p4_order_kernel, tiles of 64 rows")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER | TILES_128 | abi.KAS_PLAN_INDEX_ROWS), "hip kas_p4_order_kernel, double tiles, index rows")
     # the general multi-sweep sticky fill must agree with the rack-diverse histogram/quota form,
     # the tile-round preference ordering with the ticket form, at every workgroup width
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "hip generic fill")
@@ -120,6 +123,8 @@ def test_config3_shape_full_size_scenarios():
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_RTN_QUOTA), "C3 quota drawn without the atomic-with-return")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_NO_INDEX_ROWS), "C3 cur read by both row scans (no index rows)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_INDEX_ROWS), "C3 index rows (cur read once)")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER), "C3 first fit as a wavefront of the order kernel's workgroup")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER | TILES_64), "C3 kas_p4_order_kernel, tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "C3 kas_p4_kernel + tiles of 64 rows (the headline's kernels)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 1), "C3 generic fill")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 2), "C3 round order")
