@@ -695,14 +695,14 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
           dtop += relax_flush<NB, C16>(pend, out, out16, (uint32_t)k);
         }
         // (FS: the rows about to be asked for must be final — first fit is usually far ahead, and this is two LDS reads)
-        bool gone = false;
         if constexpr (FS) {
+          // (a topic that has failed is left through the loop's own exit: a second way out of the loop BEHIND the requests below
+          // would make the compiler copy registers whose loads are in flight — tools/check_async_loads.py)
           const int32_t upto = (tile + 2 * NB) << 6;
-          gone = tile < nt && !rows_final(k, upto < P ? upto : P);
+          if (tile < nt && !rows_final(k, upto < P ? upto : P)) { aborted = true; tile = nt; }
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) request_tile(nx[b], tile + NB + b);
-        if (gone) { aborted = true; break; }                 // (wave-uniform; the requests above are waited for below, their rows dropped)
       }
       // the topic's last rows (and no request is left outstanding: its register would be written behind our back)
       kasw::wait_loads();

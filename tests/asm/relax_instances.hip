@@ -46,3 +46,15 @@ template __global__ void kas_order_relax_kernel<3, true, false, false, true>(Kas
 template __global__ void kas_order_relax_kernel<3, true, false, true, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, true, false, true>(KasLaunch);
 template __global__ void kas_order_relax_kernel<3, true, true, true, true>(KasLaunch);
+// first fit + relaxation form in one workgroup (kas_p4_order_kernel): the order wavefront's loads are the same asynchronous ones
+template <int W, bool DUAL, bool C16, bool IDL>
+__global__ __launch_bounds__(128) void kas_p4_order_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  kas::p4_order_scenario<W, DUAL, C16, IDL>(a, (int32_t)blockIdx.x, kas_lds);
+}
+template __global__ void kas_p4_order_kernel<2, false, true, false>(KasLaunch);
+template __global__ void kas_p4_order_kernel<2, false, false, true>(KasLaunch);
+template __global__ void kas_p4_order_kernel<3, false, true, false>(KasLaunch);
+template __global__ void kas_p4_order_kernel<3, false, false, true>(KasLaunch);
+template __global__ void kas_p4_order_kernel<3, true, true, false>(KasLaunch);
+template __global__ void kas_p4_order_kernel<3, true, false, true>(KasLaunch);
