@@ -654,20 +654,20 @@ def run_rank(args) -> int:
         run.slots, run.n_slots = keep, keep_n
         alone = {"steps": n_alone, "ms_per_step": 1e3 * el1 / n_alone, "fill_kernel_us": f1, "order_kernel_us": o1,
                  "launches_timed": n1}
-        # ... and as a caller that KNOWS its batch has the GPU to itself would ask for it (what kas_solve_host's plans take by
-        # themselves): first fit inside the fill workgroup, double tiles in the order kernel
+        # ... and as a caller that KNOWS its batch has the GPU to itself would ask for it (what kas_solve_host's plans and batches of
+        # fewer than 512 scenarios take by themselves): first fit as a wavefront of the order kernel's workgroup, double tiles
         try:
             from kafka_assigner_amd import abi as _abi
             base_flags = (args.waves << 8) | (args.groups << 12) | args.plan_flags
             run.slots, run.n_slots = keep[:1], 1
-            keep[0]["plan"].set_flags(base_flags | _abi.KAS_PLAN_FILL_WITH_P4 | _abi.KAS_PLAN_RELAX_TILES_128)
+            keep[0]["plan"].set_flags(base_flags | _abi.KAS_PLAN_P4_WITH_ORDER | _abi.KAS_PLAN_RELAX_TILES_128)
             what_l = keep[0]["plan"].describe()
             el1l = timed(n_alone, 1)
             f1l, o1l, _ = run.phase_times()
             keep[0]["plan"].set_flags(base_flags)
             run.solve(keep[0]); run.synchronize()                  # (slot 0's records and rows: the headline plan's again)
             alone["with_latency_flags"] = {"ms_per_step": 1e3 * el1l / n_alone, "fill_kernel_us": f1l, "order_kernel_us": o1l,
-                                           "plan_flags": "KAS_PLAN_FILL_WITH_P4 | KAS_PLAN_RELAX_TILES(2)", "kernel": what_l}
+                                           "plan_flags": "KAS_PLAN_P4_WITH_ORDER | KAS_PLAN_RELAX_TILES(2)", "kernel": what_l}
         except Exception as e:                                     # (a leg of its own: never costs the headline line)
             alone["with_latency_flags"] = {"error": repr(e)}
         finally:

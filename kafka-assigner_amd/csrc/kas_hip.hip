@@ -893,8 +893,8 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
                              ? " [count fields checked at the end; kas_fill_kernel + kas_order_round_kernel for scenarios it flags]"
                              : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax && lp.p4_order)
-    snprintf(order, sizeof(order), "kas_p4_order_kernel<%d>[first fit + relaxation form, tiles of %d rows%s] grid=%ux%u lds=%zu", p->Wc,
-             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, kas_plan_relax_idl(p) ? ", ids in LDS" : "",
+    snprintf(order, sizeof(order), "kas_p4_order_kernel<%d>[first fit beside kas_order_relax_kernel<%d>[tiles of %d rows%s] in one workgroup] grid=%ux%u lds=%zu",
+             p->Wc, p->Wc, (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, kas_plan_relax_idl(p) ? ", ids in LDS" : "",
              lp.order_grid, lp.order_block, lp.order_lds);
   else if (lp.relax)
     snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s%s] grid=%ux%u lds=%zu%s", p->Wc,
@@ -991,7 +991,7 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
             (p->cells16 ? KAS_FLAG_CELLS16 : 0u) | (kas_plan_index_rows(p) ? KAS_FLAG_INDEX_ROWS : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
   const bool tickets = lp.tickets;
-  const bool split_p4 = kas_plan_split_p4(p);
+  const bool split_p4 = kas_plan_split_p4(p) || lp.p4_order;   // (the fill kernel hands first fit over: to kas_p4_kernel, or to kas_p4_order_kernel)
   a.p4s = (int32_t*)p->b_p4s.p;
   a.flags = split_p4 ? (a.flags | KAS_FLAG_SPLIT_P4) : (a.flags & ~KAS_FLAG_SPLIT_P4);   // (the kernels' bit: this launch's form)
   const int slot = p->timer_next;
@@ -1350,9 +1350,10 @@ static int kas_host_plan(kas_ctx* ctx, const kas_batch_desc* b, kas_plan** out_p
   // a host call blocks until its results are back: its solve has the GPU to itself (or shares it with the few other
   // scenario ranges of the same call), so the relaxation form takes double tiles whatever the batch size — the order
   // kernel of a 1000-variant what-if call 2.0 -> 1.7 ms
-  // ... and its first fit stays on the fill workgroup's four wavefronts (kas_split_p4: 1000 variants alone, fill + first fit
-  // 1.07 ms against 1.39 ms with kas_p4_kernel)
-  victim->plan->flags |= KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_FILL_WITH_P4;
+  // ... and its first fit runs as a wavefront of the order kernel's workgroup where that applies (kas_p4_with_order: round 6, a
+  // batch of 1000 alone 2.15 ms against 2.42 ms with first fit on the fill workgroup's four wavefronts, round 5's choice — which
+  // the same two bits still give every plan the new kernel does not serve: kas_split_p4 / kas_p4_with_order)
+  victim->plan->flags |= KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_P4_WITH_ORDER;
   *out_plan = victim->plan;
   return KAS_E_OK;
 }

@@ -368,7 +368,10 @@ KAS_ABI_FN int32_t kas_p4_order_lds(int32_t n_max, int32_t double_tiles, int32_t
 // first-fit switches (KAS_PLAN_SPLIT_P4 | KAS_PLAN_FILL_WITH_P4 = KAS_PLAN_P4_WITH_ORDER); by itself — KAS_P4_WITH_ORDER_BELOW —
 // for batches too small to fill the GPU, where a scenario's latency is the batch's.
 #ifndef KAS_P4_WITH_ORDER_BELOW
-#define KAS_P4_WITH_ORDER_BELOW 0          // batches of fewer scenarios than this take it unless told otherwise (0: only on request)
+#define KAS_P4_WITH_ORDER_BELOW 512        // batches of fewer scenarios than this take it unless told otherwise (0: only on request) —
+                                           // where kas_p4_kernel takes over (KAS_SPLIT_P4_FROM): 1000 scenarios alone 2.15 ms against 2.42 ms with
+                                           // first fit inside the fill workgroup and 2.77 ms with kas_p4_kernel; twelve batches in flight 629k
+                                           // scenarios/s against 753k with kas_p4_kernel (gpurun_out/r6h)
 #endif
 #define KAS_FLAG_P4_WITH_ORDER (KAS_FLAG_SPLIT_P4 | KAS_FLAG_FILL_WITH_P4)
 // widths the kernels are instantiated for; a batch uses the smallest one >= its widest list
@@ -416,22 +419,27 @@ struct KasShape {
 // kernel of its own is what fills a GPU that has thousands of wavefronts to run (twelve batches of 1000 in flight: 672k
 // against 617k scenarios/s); a batch that has the GPU to itself waits for that wavefront's windows one after the other
 // (1000 scenarios alone: fill + first fit 1.39 ms against 1.07 ms on the fill's four wavefronts).
-static inline bool kas_split_p4(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks, int32_t n_scenarios) {
-  const bool both = (launch_flags & KAS_FLAG_P4_WITH_ORDER) == KAS_FLAG_P4_WITH_ORDER;   // (first fit in the order kernel's workgroup: handed over too)
-  if (!(s.with_x && nw == KAS_P4_WAVES && !(launch_flags & KAS_FLAG_GENERIC_FILL) && (both || !(launch_flags & KAS_FLAG_FILL_WITH_P4)) &&
-        spread_chunks == 0 && kas_p4_lds_layout(s.n_max).total <= KAS_LDS_LIMIT))
-    return false;
-  return (launch_flags & KAS_FLAG_SPLIT_P4) != 0u || n_scenarios >= KAS_SPLIT_P4_FROM || n_scenarios < KAS_P4_WITH_ORDER_BELOW;
+// (what either needs: the rack-diverse fill with four wavefronts per scenario, the one-workgroup fill kernel, first fit's LDS)
+static inline bool kas_p4_handover_ok(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks) {
+  return s.with_x && nw == KAS_P4_WAVES && !(launch_flags & KAS_FLAG_GENERIC_FILL) && spread_chunks == 0 &&
+         kas_p4_lds_layout(s.n_max).total <= KAS_LDS_LIMIT;
 }
-// ... and then: inside the order kernel's workgroup (true) or in kas_p4_kernel (false)?  `relax_plain`: the launch takes the relaxation
-// form without a Context and without the sampled verification; `with_ids`: its instance keeps the broker ids in the LDS
+// first fit in kas_p4_kernel: KAS_PLAN_SPLIT_P4 by itself, or — neither switch named — batches of >= KAS_SPLIT_P4_FROM scenarios
+static inline bool kas_split_p4(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks, int32_t n_scenarios) {
+  if (!kas_p4_handover_ok(s, nw, launch_flags, spread_chunks)) return false;
+  const uint32_t sw = launch_flags & KAS_FLAG_P4_WITH_ORDER;
+  return sw == KAS_FLAG_SPLIT_P4 || (sw == 0u && n_scenarios >= KAS_SPLIT_P4_FROM);
+}
+// first fit inside the order kernel's workgroup (kas_p4_order_kernel): both switches named, or — neither — batches of fewer than
+// KAS_P4_WITH_ORDER_BELOW scenarios; where the kernel does not apply such a launch keeps first fit inside the FILL workgroup.
+// `relax_plain`: the launch takes the relaxation form without a Context and without the sampled verification, in an instance that
+// waits for no gather; `with_ids`: that instance keeps the broker ids in the LDS
 static inline bool kas_p4_with_order(const KasShape& s, int32_t nw, uint32_t launch_flags, int32_t spread_chunks, int32_t n_scenarios,
                                      bool relax_plain, int32_t double_tiles, int32_t with_ids) {
-  if (!relax_plain || !kas_split_p4(s, nw, launch_flags, spread_chunks, n_scenarios)) return false;
+  if (!relax_plain || !kas_p4_handover_ok(s, nw, launch_flags, spread_chunks)) return false;
   if (kas_p4_order_lds(s.n_max, double_tiles, with_ids) > KAS_LDS_LIMIT) return false;
-  if ((launch_flags & KAS_FLAG_P4_WITH_ORDER) == KAS_FLAG_P4_WITH_ORDER) return true;
-  if (launch_flags & (KAS_FLAG_SPLIT_P4 | KAS_FLAG_FILL_WITH_P4)) return false;
-  return n_scenarios < KAS_P4_WITH_ORDER_BELOW;
+  const uint32_t sw = launch_flags & KAS_FLAG_P4_WITH_ORDER;
+  return sw == KAS_FLAG_P4_WITH_ORDER || (sw == 0u && n_scenarios < KAS_P4_WITH_ORDER_BELOW);
 }
 
 // Fused histogram layout of the rack-diverse fill (kas_fill_lds_layout with_x = 2): lists up to 3 wide

@@ -428,7 +428,13 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   // first fit in a kernel of its own (same decision as kas_solve_device)
   std::vector<int32_t> p4s;
   a.p4s = nullptr;
-  const bool split_p4 = kas_split_p4(sh, sh.NW, a.flags, CH, b->n_scenarios);
+  // first fit inside the order kernel's workgroup (kas_p4_order_kernel; same decision as kas_launch_plan in kas_hip.hip)
+  const bool relax_dual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
+  const bool relax_idl = !c16 && kas_relax_lds_ids(sh.n_max, sh.any_ctx) && !(getenv("KAS_EMU_RELAX_GATHER") && getenv("KAS_EMU_RELAX_GATHER")[0] == '1');
+  const bool p4_order = relax && kas_p4_with_order(sh, sh.NW, a.flags, CH, b->n_scenarios,
+                                                   !sh.any_ctx && (a.flags >> 24) == 0u && (c16 || relax_idl), relax_dual, relax_idl);
+  g_last_p4_order = p4_order ? 1 : 0;
+  const bool split_p4 = p4_order || kas_split_p4(sh, sh.NW, a.flags, CH, b->n_scenarios);   // (the fill kernel hands first fit over)
   if (split_p4) {
     p4s.assign((size_t)b->n_topics * (size_t)(KAS_P4S_HEAD + (sh.n_max > 0 ? sh.n_max : 1)) + 64, (int32_t)0xDEADBEEF);
     a.p4s = p4s.data();
@@ -436,7 +442,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   } else {
     a.flags &= ~KAS_FLAG_SPLIT_P4;
   }
-  g_last_split_p4 = split_p4 ? 1 : 0;
+  g_last_split_p4 = (split_p4 && !p4_order) ? 1 : 0;
   for (int32_t s = 0; s < b->n_scenarios; ++s) {
     memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
     RunArgs ra{&a, s, lds.data()};
@@ -444,12 +450,6 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     g_last_index_rows += (long)a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 6];   // (the fill's own tally, before an order kernel writes there)
   }
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
-  // first fit inside the order kernel's workgroup (kas_p4_order_kernel; same decision as kas_launch_plan in kas_hip.hip)
-  const bool relax_dual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
-  const bool relax_idl = !c16 && kas_relax_lds_ids(sh.n_max, sh.any_ctx) && !(getenv("KAS_EMU_RELAX_GATHER") && getenv("KAS_EMU_RELAX_GATHER")[0] == '1');
-  const bool p4_order = relax && kas_p4_with_order(sh, sh.NW, flags | (sh.with_x ? 0u : KAS_FLAG_GENERIC_FILL), CH, b->n_scenarios,
-                                                   !sh.any_ctx && (a.flags >> 24) == 0u && (c16 || relax_idl), relax_dual, relax_idl);
-  g_last_p4_order = p4_order ? 1 : 0;
   if (split_p4 && !p4_order) {
     // exactly the LDS the product launches kas_p4_kernel with, and a guard behind it
     const size_t p4_bytes = (size_t)kas_p4_lds_layout(sh.n_max).total;

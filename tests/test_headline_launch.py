@@ -83,7 +83,7 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
             plan.set_flags(flags)
         desc = plan.describe()
         if ixr is None:
-            assert "kas_p4_order_kernel<3>[first fit + relaxation form, tiles of 64 rows, ids in LDS] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
+            assert "kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] in one workgroup] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
         else:
             assert desc == HEADLINE_KERNELS % ixr, desc
         d_out = torch.full((fb.out_len,), -2, dtype=torch.int32, device=dev)
