@@ -138,10 +138,14 @@ while time.time() - t0 < float(argv[1]):
     want = oracle_solve(fb)
     # (0 = the relaxation form of the order kernel for lists <= 3 wide, 1 << 12 / 4 = its ticket forms;
     # 32 = KAS_PLAN_SPREAD_FILL: the row scans over one-wavefront workgroups with their slim LDS layouts)
-    for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000, 0x200000) if RF <= 3 else (0, 2, 1, 32)):
+    # (round 6: 0x80 / 0x40 = index rows on / off, 0xC00000 = first fit beside the order kernel in one workgroup (with either tile
+    # size), 0x400000 / 0x800000 = first fit in kas_p4_kernel / inside the fill workgroup; lists 4-5 wide: 0x20000 = the relaxation
+    # form for wide lists)
+    for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000, 0x200000, 0x80, 0x40 | 0x400000, 0xC00000 | 0x20000, 0xC00000 | 0x40000 | 0x80, 0x800000)
+                  if RF <= 3 else ((0, 2, 1, 32, 0x20000, 0x20000 | 0x800000) if RF <= 5 else (0, 2, 1, 32))):
         got = solve(fb, flags)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
     if RF <= 3:
-        check16(fb, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts}", (0, 0x20000, 0x40000, 2, 1, 0x200000, 0x400000, 0x800000))
+        check16(fb, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts}", (0, 0x20000, 0x40000, 2, 1, 0x200000, 0x400000, 0x800000, 0xC00000, 0xC00000 | 0x20000, 0x20000 | (255 << 24)))
     n += 1
 print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 1-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-12,000 brokers,", n_ctx, "with a Context in and out,", n16, "also on 16-bit cells (kas_solve_device16); seed", int(argv[2]) if len(argv) > 2 else 2026)
