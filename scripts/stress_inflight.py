@@ -37,6 +37,10 @@ SUITE = [
      "[16-bit cells]", ["--in-flight", "12", "--cells", "16"]),
     ("index rows (KAS_PLAN_INDEX_ROWS: the fill's first scan leaves node indices where the mid rows go, the second streams those)",
      "index rows]", ["--plan-flags", "128", "--in-flight", "12", "--cells", "32"]),
+    ("first fit beside the order kernel in one workgroup (KAS_PLAN_P4_WITH_ORDER: the order wavefront follows first fit's progress through LDS words)",
+     "kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of 64 rows", ["--plan-flags", str(0xC00000), "--in-flight", "12", "--cells", "32"]),
+    ("... on 16-bit cells, double tiles (what small batches and host calls take)",
+     "kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of 128 rows", ["--plan-flags", str(0xC00000 | 0x40000), "--in-flight", "12", "--cells", "16"]),
     ("first fit inside the fill workgroup (KAS_PLAN_FILL_WITH_P4: four wavefronts hand windows over through LDS, no kas_p4_kernel)",
      "!kas_p4_kernel", ["--plan-flags", "8388608", "--in-flight", "12", "--cells", "32"]),
     ("16-bit cells, first fit inside the fill workgroup + double tiles (what small batches and host calls take)",
