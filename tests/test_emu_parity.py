@@ -40,6 +40,10 @@ def test_emu_equals_oracle_small_odd_inputs_without_context_io(sc):
                            topics=[Topic(n, c, rf, parts) for n, c, rf, parts in topics])])
     want = oracle_solve(fb)
     assert_same_outputs(fb, want, emu_solve(fb), "emu (no ctx): relaxation form where applicable")
+    # what the PRODUCT launches for a batch this small since round 6: first fit beside the order kernel in one workgroup where
+    # that applies (kas_p4_order_kernel), index rows on request — ragged lists, duplicate brokers, empty topics, failures
+    assert_same_outputs(fb, want, emu_solve(fb, p4_by_batch_size=True), "emu (no ctx), the product's choice for a small batch")
+    assert_same_outputs(fb, want, emu_solve(fb, flags=0xC00000 | RELAX_TILES_64 | INDEX_ROWS), "emu (no ctx), first fit beside the order kernel, tiles of 64 rows, index rows")
     assert_same_outputs(fb, want, emu_solve(fb, flags=TICKET_ORDER), "emu (no ctx), ticket form")
     assert_same_outputs(fb, want, emu_solve(fb, flags=4 | (1 << 12)), "emu (no ctx), wide counters, 1 scenario per wave")
 
