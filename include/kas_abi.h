@@ -379,6 +379,10 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *                          node indices where its mid row goes, the second scan streams those 2-byte cells and stores only the rows
  *                          that do not keep all their replicas: `cur` is read ONCE and every id is looked up once; without, `cur` is
  *                          read by both scans.  Neither flag: the library's default (DESIGN.md section 4.1 has the measurement).
+ *   KAS_PLAN_FULL_FILL     kas_fill_kernel for every scenario.  Default (round 6; int32 cells, lists up to 3 wide, per-chunk
+ *                          histograms, a direct id table, first fit handed over): kas_fill_slim_kernel first — the one path
+ *                          rack-diverse scenarios take, compiled without the others (120 VGPRs, no scratch) — and
+ *                          kas_fill_kernel behind it, on a small grid, for the scenarios it hands back (rows not rack-diverse, ...)
  *   KAS_PLAN_NO_RTN_QUOTA  rack-diverse fill with per-chunk histograms: draw a node's quota with separate LDS atomics,
  *                          reads and a ranking of the tiles in which it runs out, instead of one atomic-with-return
  *                          per list position
@@ -405,6 +409,7 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_ROUND_ORDER  2u
 #define KAS_PLAN_WIDE_COUNTERS 4u
 #define KAS_PLAN_TWO_PASS_HIST 8u
+#define KAS_PLAN_FULL_FILL    16u
 #define KAS_PLAN_SPREAD_FILL  32u
 #define KAS_PLAN_NO_INDEX_ROWS 64u
 #define KAS_PLAN_INDEX_ROWS  128u

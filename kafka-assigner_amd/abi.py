@@ -33,6 +33,7 @@ KAS_PLAN_ROUND_ORDER = 2
 KAS_PLAN_WIDE_COUNTERS = 4
 KAS_PLAN_TWO_PASS_HIST = 8
 KAS_PLAN_SPREAD_FILL = 32
+KAS_PLAN_FULL_FILL = 16
 KAS_PLAN_NO_INDEX_ROWS = 64
 KAS_PLAN_INDEX_ROWS = 128
 KAS_PLAN_TICKET_ORDER = 0x10000

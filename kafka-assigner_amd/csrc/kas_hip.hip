@@ -45,6 +45,18 @@ __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(K
     kas::fill_scenario<W, NW>(a, s, kas_lds);
 }
 
+// The slim fill (round 6): fill_scenario<W, 4, SLIM> — only the path every BASELINE config at RF <= 3 takes (kas_solver_body.h,
+// fill_topic's SLIM branch): 120 VGPRs and no scratch where kas_fill_kernel<3,4> has 128 and 368 B per lane.  A scenario that
+// needs another path is flagged (KasLaunch::sp_flag) and kas_fill_kernel, launched behind this one with KAS_FLAG_ONLY_FLAGGED on
+// a grid of at most KAS_FILL_BACK_GRID workgroups, solves it from its first topic.
+template <int W>
+__global__ __launch_bounds__(256, KAS_FILL_MIN_WAVES) void kas_fill_slim_kernel(KasLaunch a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
+  for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
+    kas::fill_scenario<W, 4, true>(a, s, kas_lds);
+}
+#define KAS_FILL_BACK_GRID 256u
+
 // min waves per SIMD of the ticket-form order kernel (0 = whatever the allocation comes to: 92 VGPRs, 5)
 #ifndef KAS_ORDER_MIN_WAVES
 #define KAS_ORDER_MIN_WAVES 0
@@ -231,6 +243,7 @@ typedef void (*kas_kernel_fn)(KasLaunch);
 // tuning build for BASELINE.json configs[4] (lists 5 wide, 4 fill waves): seconds to compile
 static bool kas_minimal_ok(int Wc, int NW, int) { return Wc == 5 && NW == 4; }
 static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<5, 4>; }
+static kas_kernel_fn kas_fill_slim_for(int) { return nullptr; }
 static kas_kernel_fn kas_p4_for(int) { return kas_p4_kernel<5>; }
 static kas_kernel_fn kas_order_ticket_for(int, int, int) { return nullptr; }
 static kas_kernel_fn kas_order_round_for(int) { return kas_order_round_kernel<5>; }
@@ -245,6 +258,7 @@ static KasSpreadKernels kas_spread_for(int Wc) { return Wc == 5 ? kas_spread_ker
 // seconds.  Other shapes are refused by kas_plan_create in such a build.
 static bool kas_minimal_ok(int Wc, int NW, int G) { return Wc == 3 && NW == 4 && (G == 2 || G == 1); }
 static kas_kernel_fn kas_fill_for(int, int) { return kas_fill_kernel<3, 4>; }
+static kas_kernel_fn kas_fill_slim_for(int) { return kas_fill_slim_kernel<3>; }
 static kas_kernel_fn kas_p4_for(int) { return kas_p4_kernel<3>; }
 static kas_kernel_fn kas_order_ticket_for(int, int G, int packed) {
   if (G == 1) return packed ? kas_order_ticket_kernel<3, 1, true> : kas_order_ticket_kernel<3, 1, false>;
@@ -276,6 +290,9 @@ static kas_kernel_fn kas_fill_for(int Wc, int NW) {
     case 2: return kas_fill_for_w<2>(Wc);   // never the faster choice on the GPU)
     default: return kas_fill_for_w<4>(Wc);
   }
+}
+static kas_kernel_fn kas_fill_slim_for(int Wc) {
+  return Wc == 2 ? kas_fill_slim_kernel<2> : (Wc == 3 ? kas_fill_slim_kernel<3> : nullptr);
 }
 static kas_kernel_fn kas_p4_for(int Wc) {
   switch (Wc) {
@@ -394,6 +411,7 @@ struct kas_ctx {
 #define KAS_TIMER_SLOTS 64
 
 struct kas_plan {
+  uint32_t full_fill = 0;               // KAS_PLAN_FULL_FILL of the last kas_plan_set_flags: no slim fill kernel
   uint32_t index_rows_bits = 0;         // KAS_PLAN_NO_INDEX_ROWS / KAS_PLAN_INDEX_ROWS of the last kas_plan_set_flags (kas_index_rows_wanted)
   kas_ctx* ctx;
   KasShape shape;
@@ -592,6 +610,9 @@ static int kas_plan_relax_idl(const kas_plan* p) {
 static int kas_plan_set_kernels(kas_plan* p) {
   KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_for(p->Wc, p->NW), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (p->fused && p->lds_fused.total > p->lds.total ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD));
+  if (p->NW == 4 && p->fused && kas_fill_slim_for(p->Wc) != nullptr)
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_slim_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    p->lds_fused.total + KAS_TUNE_FILL_LDS_PAD));
   if (p->Wc <= 3 && p->tickets && kas_order_ticket_for(p->Wc, p->G, 0))   // (beyond 8,191 brokers only the relaxation form applies)
     for (int pk = 0; pk < 2; ++pk)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
@@ -647,6 +668,16 @@ static bool kas_plan_index_rows(const kas_plan* p) {
          !(p->flags & KAS_FLAG_NO_RTN_QUOTA) && p->shape.n_max < 0x3fff && p->shape.idmap_entries > 0;
 }
 
+// the slim fill kernel in this plan's next solve (with kas_fill_kernel behind it for the scenarios it hands back): int32 cells,
+// lists up to 3 wide, per-chunk histograms on 4 wavefronts, the quota drawn with the atomic-with-return, a direct id table for
+// every scenario, no index rows, first fit handed over (split_p4: to kas_p4_kernel or to kas_p4_order_kernel), no spread fill
+static bool kas_plan_slim_fill(const kas_plan* p, bool split_p4, int32_t chunks) {
+  return KAS_SLIM_FILL_DEFAULT && !p->full_fill && !p->cells16 && p->Wc <= 3 && p->NW == 4 && kas_fill_slim_for(p->Wc) != nullptr &&
+         kas_plan_fused(p) && p->shape.with_x && p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA) &&
+         !kas_plan_index_rows(p) && split_p4 && chunks == 0 && p->shape.idmap_entries > 0 && !p->shape.need_bsearch &&
+         p->b_sp_flag.p != nullptr;
+}
+
 // chunks per scenario of the spread fill for this plan's next solve, or 0 (one-workgroup fill kernel)
 static int32_t kas_plan_spread_chunks(const kas_plan* p) {
   if (p->cells16) return 0;                                  // (the spread fill's kernels read int32 cells)
@@ -670,6 +701,10 @@ static int kas_plan_spread_scratch(kas_plan* p) {
         (rc = kas_buf_reserve(&p->b_sp_oc, 4 * S * (C + 2), p->allocs, "spread-fill scratch")) != KAS_E_OK)
       return rc;
   }
+  else {                                                         // (the slim fill kernel's hand-back flags: 4 B per scenario)
+    const int rc = kas_buf_reserve(&p->b_sp_flag, 4 * ((size_t)p->n_scenarios + 1), p->allocs, "fill hand-back flags");
+    if (rc != KAS_E_OK) return rc;
+  }
   p->sp_alloc_chunks = chunks;
   return KAS_E_OK;
 }
@@ -689,7 +724,7 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   p->Wc = sh.Wc; p->NW = sh.NW; p->G = sh.G;
   p->tickets = sh.tickets_ok; p->fused = sh.fused_ok;
   p->lds = sh.lds; p->lds_fused = sh.lds_fused;
-  p->flags = 0; p->index_rows_bits = 0;
+  p->flags = 0; p->index_rows_bits = 0; p->full_fill = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
   p->sp_alloc_chunks = 0;
@@ -931,6 +966,13 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (kas_plan_split_p4(p) && !lp.p4_order)                    // first fit (P4) is a launch of its own between the two
     snprintf(p4, sizeof(p4), " + kas_p4_kernel<%d> grid=%ux%u lds=%zu", p->Wc, (unsigned)p->n_scenarios, 64u * KAS_P4_KERNEL_WAVES,
              (size_t)kas_p4_lds_layout(p->shape.n_max).total);
+  if (kas_plan_slim_fill(p, kas_plan_split_p4(p) || lp.p4_order, chunks)) {
+    const unsigned back = lp.fill_grid < KAS_FILL_BACK_GRID ? lp.fill_grid : KAS_FILL_BACK_GRID;
+    const int len = snprintf(buf, (size_t)n, "kas_fill_slim_kernel<%d>[quota, chunk histograms] grid=%ux%u lds=%zu (+ kas_fill_kernel<%d,%d>[quota, chunk histograms] "
+                             "grid=%ux%u for scenarios it hands back)%s + %s", p->Wc, lp.fill_grid, lp.fill_block, lp.fill_lds, p->Wc, p->NW, back,
+                             lp.fill_block, p4, order);
+    return len < n ? len : n - 1;
+  }
   const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s%s + %s%s", spread, p->Wc, p->NW,
                            generic ? "sweeps" : (kas_plan_fused(p) ? (kas_plan_index_rows(p) && chunks == 0 ? "quota, chunk histograms, index rows" : "quota, chunk histograms") : "quota"), lp.fill_grid,
                            lp.fill_block, lp.fill_lds, chunks > 0 ? ")" : "", p4, order, p->cells16 ? " [16-bit cells]" : "");
@@ -1019,10 +1061,23 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   }
   // (tuning builds, scripts/build_variant.sh -- -DKAS_TUNE_...: one of the two kernels alone, to see what each saturates at.
   // ORDER_ONLY: the fill runs in the plan's first solve only, and KAS_TUNE_NO_ROW_STORES keeps its mid rows in place.)
+  unsigned fill_grid = lp.fill_grid;
+  if (kas_plan_slim_fill(p, split_p4, chunks)) {
+    // the slim kernel takes every scenario (and writes each one's hand-back flag, 0 or 1); the full kernel behind it takes the
+    // flagged ones on a small grid — its workgroups need a slot of 35 KB of LDS each before they can see that there is nothing to do
+    a.sp_flag = (int32_t*)p->b_sp_flag.p;
+#if defined(KAS_TUNE_ORDER_ONLY)
+    if (p->last_slot < 0)
+#endif
+    hipLaunchKernelGGL(kas_fill_slim_for(p->Wc), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
+    KAS_HIP_TRY(hipGetLastError());
+    a.flags |= KAS_FLAG_ONLY_FLAGGED;
+    if (fill_grid > KAS_FILL_BACK_GRID) fill_grid = KAS_FILL_BACK_GRID;
+  }
 #if defined(KAS_TUNE_ORDER_ONLY)
   if (p->last_slot < 0)
 #endif
-  hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
+  hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
   KAS_HIP_TRY(hipGetLastError());
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
   if (split_p4 && !lp.p4_order) {
@@ -1164,6 +1219,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
   p->index_rows_bits = flags & (KAS_PLAN_NO_INDEX_ROWS_BIT | KAS_PLAN_INDEX_ROWS_BIT);
+  p->full_fill = flags & KAS_PLAN_FULL_FILL_BIT;
   p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)
   // the spread fill's scratch follows the flags (allocated here, never inside a solve); a solve of this

@@ -68,6 +68,11 @@ struct KasLaunch {
 #define KAS_FLAG_INDEX_ROWS   0x400u // set by the launcher (int32 cells, per-chunk histograms, LDS lane order; not with KAS_PLAN_NO_INDEX_ROWS): the fill's
                                    // first row scan leaves every row's node indices where its mid row goes and the second scan streams those
                                    // (kas_solver_body.h, fill_pass_a_fused<EMIT>): `cur` is read once, 6 instead of 12 bytes a row the second time
+#define KAS_PLAN_FULL_FILL_BIT 16u     // the user's switch (KAS_PLAN_FULL_FILL; KAS_FLAG_FUSED_HIST's bit in a launch word, so kept beside the plan's flags):
+                                      // kas_fill_kernel for every scenario, no kas_fill_slim_kernel in front of it (testing / comparison)
+#ifndef KAS_SLIM_FILL_DEFAULT
+#define KAS_SLIM_FILL_DEFAULT 1
+#endif
 #define KAS_PLAN_NO_INDEX_ROWS_BIT 64u // the user's switches (kas_plan_set_flags; their bits are KAS_FLAG_ONLY_FLAGGED's / KAS_FLAG_ORDER_FLAGGED's in a launch
 #define KAS_PLAN_INDEX_ROWS_BIT 128u   // word, so they are kept beside the plan's flags): off / on whatever KAS_INDEX_ROWS_DEFAULT says
 #ifndef KAS_INDEX_ROWS_DEFAULT

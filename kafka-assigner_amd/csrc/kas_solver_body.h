@@ -1354,7 +1354,13 @@ KAS_DEV void sort_holders(const int32_t (&cells)[W], int32_t (&h)[W], int32_t& L
 // the whole workgroup.  Leaves the out rows holding node indices (holders in acceptance order,
 // -1 padded); the order kernel turns them into the final preference lists.
 // ---------------------------------------------------------------------------------------------
-template <int W, int NW>
+// SLIM (kas_fill_slim_kernel, round 6): the ONE path every BASELINE config at RF <= 3 takes — int32 cells, per-chunk histograms, a
+// direct id table, the quota drawn with the atomic-with-return, first fit handed over — compiled without the other ~40 (general
+// fill, binary search, chunk-count pass, 16-bit cells, index rows, first fit's windows): 120 VGPRs and NO scratch where the full
+// kernel has 128 and 368 B per lane.  A topic that needs another path returns KAS_TOPIC_NEEDS_FULL_FILL: the scenario is handed
+// back (KasLaunch::sp_flag) and the full kernel, launched behind this one for flagged scenarios only, solves it from its first topic.
+#define KAS_TOPIC_NEEDS_FULL_FILL (-1000)
+template <int W, int NW, bool SLIM = false>
 KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, const LdsView& L,
                                 const NodeMap& nm, const int32_t* g_node_id, const int32_t* g_node_rack,
                                 uint64_t* accmask, int32_t* orph, int32_t* p4s, int64_t (&st)[8]) {
@@ -1427,6 +1433,42 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   { const int64_t now = kasw::clock_ticks(); st[0] += now - tmark; tmark = now; }
 
   // ---- P2: sticky fill (KAS:49, 101-131) ----------------------------------------------------
+  if constexpr (SLIM) {
+    static_assert(W <= 3 && NW > 1, "the slim fill is the per-chunk-histogram form");
+    const bool mine = try_fast && fused && !T.c16 && (a.flags & KAS_FLAG_LANE_ORDER) != 0u && !(a.flags & KAS_FLAG_INDEX_ROWS) &&
+                      nm.range != 0u && p4s != nullptr;
+    if (!mine) { res.status = KAS_TOPIC_NEEDS_FULL_FILL; return res; }      // (workgroup-uniform)
+    const bool viol = fill_pass_a_fused<W, NW, true>(L, T, nm, wave);
+    if (kasw::ballot(viol) != 0 && lane == 0) L.ctl[KAS_CTL_VIOL] = 1;
+    kasw::sync();
+    if (L.ctl[KAS_CTL_VIOL] != 0) { res.status = KAS_TOPIC_NEEDS_FULL_FILL; return res; }   // rows not rack-diverse: the general fill's case
+    fill_quota_fused<W, NW>(L, T, tid);
+    kasw::sync();
+    { const int64_t now = kasw::clock_ticks(); st[1] += now - tmark; tmark = now; }
+    for (int32_t i = tid; i < N; i += NT)                     // (pass B's one 16-bit word per cell: node index | r* << 14, as below)
+      L.idmap[(uint32_t)g_node_id[i] - (uint32_t)nm.min_id] =
+          (int16_t)(uint16_t)((uint32_t)i | (((uint32_t)lds_qrs(L, i) >> 28) << 14));
+    kasw::sync();
+    int32_t moved_r = 0, moved_p = 0;
+    const int32_t oc = fill_pass_b<W, NW, true, true, true>(L, T, nm, wave, moved_r, moved_p, st);
+    if (lane == 0) L.ctl[KAS_CTL_OC + wave] = oc;
+    kasw::sync();
+    { const int64_t now = kasw::clock_ticks(); st[2] += now - tmark; tmark = now; }
+    if (java_abs_mod(hash, N) < 0) { res.status = KAS_FAIL_HASH_INDEX; return res; }   // KAS:168 (workgroup-uniform)
+    for (int32_t i = tid; i < N; i += NT) p4s[KAS_P4S_HEAD + i] = lds_load(L, i);     // the hand-over to first fit, as below
+    if (tid == 0) { p4s[0] = 1; p4s[1] = cap; }
+    if (tid < NW) p4s[2 + tid] = L.ctl[KAS_CTL_OC + tid];
+    const int32_t mr = kasw::wave_sum(moved_r), mp = kasw::wave_sum(moved_p);
+    if (lane == 0 && (mr | mp) != 0) {
+      kasw::lds_atomic_add(&L.ctl[KAS_CTL_MOVED_R], mr);
+      kasw::lds_atomic_add(&L.ctl[KAS_CTL_MOVED_P], mp);
+    }
+    kasw::sync();
+    { const int64_t now = kasw::clock_ticks(); st[3] += now - tmark; tmark = now; }
+    res.moved_replicas = L.ctl[KAS_CTL_MOVED_R];
+    res.moved_partitions = L.ctl[KAS_CTL_MOVED_P];
+    return res;
+  } else {
   bool fast = false;
   // index rows (KAS_FLAG_INDEX_ROWS): int32 cells, per-chunk histograms, the quota drawn with the atomic-with-return, a direct
   // id table and rows exactly W wide — pass A leaves the rows' node indices where the mid rows go and pass B streams those
@@ -1590,17 +1632,19 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   res.moved_partitions = L.ctl[KAS_CTL_MOVED_P];
 
   return res;
+  }                                                          // (!SLIM)
 }
 
 // ---------------------------------------------------------------------------------------------
 // fill kernel, one scenario: the per-topic loop of KAG:173-184 up to (not including) P5.
 // Writes the topic results and the scenario record (digest 0; the order kernel completes it).
 // ---------------------------------------------------------------------------------------------
-template <int W, int NW>
+template <int W, int NW, bool SLIM = false>
 KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   constexpr int NT = 64 * NW;
   const int tid = kasw::tid();
-  if ((a.flags & KAS_FLAG_ONLY_FLAGGED) && a.sp_flag[s] == 0) return;   // the spread fill did this one
+  if (!SLIM && (a.flags & KAS_FLAG_ONLY_FLAGGED) && a.sp_flag[s] == 0) return;   // the spread fill / the slim fill kernel did this one
+  if (SLIM && tid == 0) a.sp_flag[s] = 0;                    // (this thread alone writes the flag: 1 below if the scenario is handed back)
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
   const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch,
@@ -1669,7 +1713,13 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = fill_topic<W, NW>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph_topic, p4s, st);
+    else o = fill_topic<W, NW, SLIM>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph_topic, p4s, st);
+    if constexpr (SLIM) {
+      if (o.status == KAS_TOPIC_NEEDS_FULL_FILL) {            // (workgroup-uniform) hand the scenario back: the full kernel solves it from its first topic
+        if (tid == 0) a.sp_flag[s] = 1;
+        return;
+      }
+    }
     kasw::sync();
     if (o.status != KAS_OK) {
       // nothing is returned for a failed topic: its rows are all padding

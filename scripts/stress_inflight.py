@@ -31,8 +31,10 @@ from oracle_lib import oracle_solve  # noqa: E402
 # The kernel families and plan variants a solve can launch, each at a shape that takes it (name, must appear
 # in the plan's description — "!x": x must NOT appear —, bench.py flags).  The first is the headline shape (BASELINE.json configs[2]).
 SUITE = [
-    ("headline: int32 broker ids in HBM in, ids out — fill<3,4> per-chunk histograms + first fit in kas_p4_kernel + relaxation form of the order kernel with the ids in the LDS",
-     "rows, ids in LDS] grid=1000x64", ["--in-flight", "12", "--cells", "32"]),
+    ("headline: int32 broker ids in HBM in, ids out — slim fill kernel (per-chunk histograms) + first fit in kas_p4_kernel + relaxation form of the order kernel with the ids in the LDS",
+     "kas_fill_slim_kernel<3>[", ["--in-flight", "12", "--cells", "32"]),
+    ("the same with kas_fill_kernel<3,4> for every scenario (KAS_PLAN_FULL_FILL: no slim kernel in front)",
+     "!kas_fill_slim_kernel", ["--plan-flags", "16", "--in-flight", "12", "--cells", "32"]),
     ("the same kernels on 16-bit cells in HBM (kas_plan_create16)",
      "[16-bit cells]", ["--in-flight", "12", "--cells", "16"]),
     ("index rows (KAS_PLAN_INDEX_ROWS: the fill's first scan leaves node indices where the mid rows go, the second streams those)",

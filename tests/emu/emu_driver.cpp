@@ -196,6 +196,10 @@ namespace {
 
 struct RunArgs { const KasLaunch* a; int32_t s; unsigned char* lds; };
 
+template <int W> void run_fill_slim(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  kas::fill_scenario<W, 4, true>(*r->a, r->s, r->lds);
+}
 template <int W, int NW> void run_fill(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::fill_scenario<W, NW>(*r->a, r->s, r->lds);
@@ -281,6 +285,7 @@ run_fn rounds_for(int Wc) {
 static long g_last_queue_rows = 0;
 static int g_last_p4_order = 0;       // the last solve ran first fit inside the order kernel's workgroup (kas_p4_order_kernel)
 static int g_last_relax_idl = 0;      // the last relaxation-form launch read its broker ids from the LDS
+static long g_last_slim_fill = 0;    // scenarios the slim fill kernel solved itself (not handed back) in the last kas_emu_solve_batch
 static long g_last_index_rows = 0;   // topics whose fill took the index rows (fill_pass_a_fused<EMIT>) in the last kas_emu_solve_batch
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
@@ -443,6 +448,23 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     a.flags &= ~KAS_FLAG_SPLIT_P4;
   }
   g_last_split_p4 = (split_p4 && !p4_order) ? 1 : 0;
+  // the slim fill kernel in front (same decision as kas_plan_slim_fill in kas_hip.hip): it writes every scenario's hand-back flag
+  const bool slim = KAS_SLIM_FILL_DEFAULT && !(flags & KAS_PLAN_FULL_FILL_BIT) && !c16 && sh.Wc <= 3 && sh.NW == 4 && fused && sh.with_x &&
+                    !(flags & KAS_FLAG_NO_RTN_QUOTA) && !index_rows && split_p4 && CH == 0 && sh.idmap_entries > 0 && !sh.need_bsearch;
+  g_last_slim_fill = 0;
+  if (slim) {
+    sp_flag.assign((size_t)b->n_scenarios + 1, (int32_t)0xDEADBEEF);
+    a.sp_flag = sp_flag.data();
+    run_fn fs = sh.Wc <= 2 ? run_fill_slim<2> : run_fill_slim<3>;
+    for (int32_t s = 0; s < b->n_scenarios; ++s) {
+      memset(lds.data(), 0xCD, lds.size());
+      RunArgs ra{&a, s, lds.data()};
+      if (kasw::run_block(fs, &ra, 4) != 0) return bad("slim fill", s);
+      if (sp_flag[(size_t)s] != 0 && sp_flag[(size_t)s] != 1) return bad("slim fill (hand-back flag not written)", s);
+      g_last_slim_fill += sp_flag[(size_t)s] == 0 ? 1 : 0;
+    }
+    a.flags |= KAS_FLAG_ONLY_FLAGGED;
+  }
   for (int32_t s = 0; s < b->n_scenarios; ++s) {
     memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
     RunArgs ra{&a, s, lds.data()};
@@ -658,6 +680,8 @@ int kas_emu_last_fused(void) { return g_last_fused; }
 
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_index_rows(void) { return g_last_index_rows; }
+extern "C" __attribute__((visibility("default")))
+long kas_emu_last_slim_fill(void) { return g_last_slim_fill; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_relax_idl(void) { return g_last_relax_idl; }

@@ -242,6 +242,14 @@ def last_index_rows() -> int:
     return int(L.kas_emu_last_index_rows())
 
 
+def last_slim_fill() -> int:
+    """Scenarios the slim fill kernel (kas_fill_slim_kernel) solved itself in the last emu_solve: 0 when it was not launched,
+    fewer than the batch's scenarios when it handed some back to kas_fill_kernel."""
+    L = lib()
+    L.kas_emu_last_slim_fill.restype = C.c_long
+    return int(L.kas_emu_last_slim_fill())
+
+
 def last_p4_order() -> int:
     """1: the last emu_solve ran first fit inside the order kernel's workgroup (kas_p4_order_kernel: KAS_PLAN_SPLIT_P4 | KAS_PLAN_FILL_WITH_P4)"""
     L = lib()
@@ -259,6 +267,7 @@ def last_relax_idl() -> int:
     return int(L.kas_emu_last_relax_idl())
 
 
+FULL_FILL = 16             # KAS_PLAN_FULL_FILL: kas_fill_kernel for every scenario (no kas_fill_slim_kernel in front)
 NO_INDEX_ROWS = 64         # KAS_PLAN_NO_INDEX_ROWS: the fill reads `cur` in both of its row scans
 INDEX_ROWS = 128           # KAS_PLAN_INDEX_ROWS: the fill's first scan leaves node indices where the mid rows go, the second streams those
 

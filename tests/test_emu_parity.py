@@ -341,6 +341,51 @@ def test_emu_index_rows_where_they_apply_and_where_they_do_not():
     assert last_index_rows() == 0
 
 
+def test_emu_slim_fill_kernel_in_front_and_the_full_kernel_for_what_it_hands_back():
+    """kas_fill_slim_kernel (round 6): int32 cells, lists up to 3 wide, per-chunk histograms, a direct id table, first fit handed
+    over — the slim kernel takes every scenario, solves the rack-diverse ones on the one path it holds and flags the others
+    (rows not rack-diverse; a topic of another width; ...), which kas_fill_kernel then solves from their first topic."""
+    from emu_lib import FULL_FILL, P4_WITH_ORDER, last_slim_fill
+    # rack-diverse scenarios: all of them stay with the slim kernel, under either hand-over of first fit
+    fb = _batch(1234, 5, 1777, 45, 9, 3, G.BENCH_ACTIONS)
+    want = oracle_solve(fb)
+    for flags in (0, P4_WITH_ORDER, RELAX_TILES_128, TICKET_ORDER, 2):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu slim fill, plan flags {flags:#x}")
+        assert last_slim_fill() == 5, (flags, last_slim_fill())
+    for flags in (FULL_FILL, INDEX_ROWS, NO_RTN_QUOTA, 8, 1, FILL_WITH_P4, 2 << 8):   # switched off / forms it does not hold
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu without the slim fill, plan flags {flags:#x}")
+        assert last_slim_fill() == 0, (flags, last_slim_fill())
+    fb2 = _batch(77, 3, 900, 30, 6, 2, G.ACTIONS)
+    assert_same_outputs(fb2, oracle_solve(fb2), emu_solve(fb2), "emu slim fill, lists 2 wide")
+    assert last_slim_fill() == 3
+    # scenarios 1 and 3 start from rows that are not rack-diverse (cyclic over 6 racks that divide the broker count): handed back
+    racks = (np.arange(60) % 6).astype(np.int32)
+    ids = np.arange(60, dtype=np.int32)
+    curs = [G.random_assignment(5, 1200, 60, 6, 3), G.cyclic_assignment(1200, 60, 3, 1) * 6 % 60,
+            G.random_assignment(6, 1200, 60, 6, 3), G.cyclic_assignment(1200, 60, 3, 2) * 6 % 60]
+    fbm = uniform_batch(np.stack(curs).astype(np.int32), np.tile(ids, (4, 1))[:, :58], np.tile(racks, (4, 1))[:, :58], 3)
+    wantm = oracle_solve(fbm)
+    assert_same_outputs(fbm, wantm, emu_solve(fbm), "emu slim fill: two of four scenarios handed back")
+    assert last_slim_fill() == 2
+    assert_same_outputs(fbm, wantm, emu_solve(fbm, flags=P4_WITH_ORDER), "emu slim fill + first fit beside the order kernel: two of four handed back")
+    assert last_slim_fill() == 2
+    # a scenario whose THIRD topic is the one the slim kernel does not hold (2 wide in a batch 3 wide): the scenario is solved
+    # again from its first topic, over the records, mid rows and hand-over words the slim kernel left for topics one and two
+    scs = [Scenario(brokers=list(range(30)), racks={b: "r%d" % (b % 6) for b in range(30)}, want_context=False,
+                    topics=[Topic("a", {p: G.random_assignment(1, 700, 32, 6, 3)[p].tolist() for p in range(700)}, 3),
+                            Topic("d", {p: G.random_assignment(4, 900, 32, 6, 3)[p].tolist() for p in range(900)}, 3),
+                            Topic("c", {p: G.random_assignment(3, 300, 32, 6, 2)[p].tolist() for p in range(300)}, 2)]),
+           Scenario(brokers=list(range(31)), racks={b: "r%d" % (b % 6) for b in range(31)}, want_context=False,
+                    topics=[Topic("a", {p: G.random_assignment(9, 800, 32, 6, 3)[p].tolist() for p in range(800)}, 3)])]
+    fbt = flatten(scs)
+    wantt = oracle_solve(fbt)
+    got = emu_solve(fbt)
+    assert_same_outputs(fbt, wantt, got, "emu slim fill: a topic of another width hands the scenario back")
+    n_slim = last_slim_fill()
+    assert_same_outputs(fbt, wantt, emu_solve(fbt, flags=FULL_FILL), "emu: the same without the slim kernel")
+    assert n_slim in (1, 2)        # (2 if a narrower topic's rows are streamed at its own width: then nothing is handed back)
+
+
 def test_emu_relaxation_form_broker_ids_from_the_lds_and_from_the_node_table(monkeypatch):
     """Round 6: the relaxation form's instances for int32 cells keep the scenario's broker ids in the LDS (kas_relax_lds_ids) and read a
     final row's ids there; broker counts whose ids do not fit keep the gather from the node table (asked for with the asynchronous

@@ -1,7 +1,7 @@
 """-m gpu: the headline's EXACT launch.
 
 bench.py's default step is one solve of 1000 scenarios x 100,000 partitions x 1,000 brokers x 20 racks, RF 3, the bench
-action mix, batches of >= 512 scenarios: kas_fill_kernel<3,4> + kas_p4_kernel<3> + kas_order_relax_kernel<3> over tiles of 64
+action mix, batches of >= 512 scenarios: kas_fill_slim_kernel<3> (+ kas_fill_kernel<3,4> behind it) + kas_p4_kernel<3> + kas_order_relax_kernel<3> over tiles of 64
 rows.  This test builds slot 0 of that very run (same seeds, same generator on the device, same broker sets), solves it
 through
 
@@ -25,8 +25,11 @@ SEED = 2026                      # bench.py's --seed default; slot 0, rank 0
 N_LISTS = 64
 
 # what bench.py's line names (the plan's own description of its launch); n_max = 1050 (up to 50 brokers added)
-HEADLINE_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms%s] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "
-                    "lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] grid=1000x64 lds=9472")
+TAIL = (" + kas_p4_kernel<3> grid=1000x64 lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] grid=1000x64 lds=9472")
+# round 6: the slim fill kernel in front, the full one behind it on a small grid for scenarios handed back (none in this batch)
+HEADLINE_KERNELS = ("kas_fill_slim_kernel<3>[quota, chunk histograms] grid=1000x256 lds=35552 (+ kas_fill_kernel<3,4>[quota, chunk histograms] "
+                    "grid=256x256 for scenarios it hands back)" + TAIL)
+FULL_FILL_KERNELS = "kas_fill_kernel<3,4>[quota, chunk histograms%s] grid=1000x256 lds=35552" + TAIL
 INDEX_ROWS_BY_DEFAULT = False    # the library's KAS_INDEX_ROWS_DEFAULT (measured both ways)
 CELLS16_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "
                    "lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows] grid=1000x64 lds=5264 [16-bit cells]")
@@ -72,20 +75,21 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
     assert len(bad) >= 1, "the bench mix holds scenarios the reference strands (KAS:183-184): a failure path in the launch"
 
     # ---- int32 broker ids in HBM in, broker ids out: the headline
-    dflt = ", index rows" if INDEX_ROWS_BY_DEFAULT else ""
-    for flags, what, ixr in ((0, "as the plan chooses", dflt),
-                             (abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64, "SPLIT_P4 | RELAX_TILES(1)", dflt),
-                             (abi.KAS_PLAN_NO_INDEX_ROWS, "cur read by both row scans of the fill", ""),
-                             (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", ", index rows"),
-                             (abi.KAS_PLAN_P4_WITH_ORDER, "first fit as a wavefront of the order kernel's workgroup", None)):
+    dflt = (FULL_FILL_KERNELS % ", index rows") if INDEX_ROWS_BY_DEFAULT else HEADLINE_KERNELS
+    for flags, what, expect in ((0, "as the plan chooses", dflt),
+                                (abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64, "SPLIT_P4 | RELAX_TILES(1)", dflt),
+                                (abi.KAS_PLAN_FULL_FILL, "kas_fill_kernel for every scenario", FULL_FILL_KERNELS % ""),
+                                (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", FULL_FILL_KERNELS % ", index rows"),
+                                (abi.KAS_PLAN_P4_WITH_ORDER, "first fit as a wavefront of the order kernel's workgroup", None)):
         plan = native.Plan(ctx, fb)
         if flags:
             plan.set_flags(flags)
         desc = plan.describe()
-        if ixr is None:
+        if expect is None:
             assert "kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] in one workgroup] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
+            assert desc.startswith("kas_fill_slim_kernel<3>["), desc
         else:
-            assert desc == HEADLINE_KERNELS % ixr, desc
+            assert desc == expect, desc
         d_out = torch.full((fb.out_len,), -2, dtype=torch.int32, device=dev)
         d_sr.zero_()
         st.wait_stream(torch.cuda.current_stream(dev))        # (the two fills above run on torch's stream: not beside the solve)

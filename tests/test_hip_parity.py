@@ -75,6 +75,8 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FILL_WITH_P4), "hip first fit inside the fill workgroup (no kas_p4_kernel)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4), "hip first fit in kas_p4_kernel (what batches of >= 512 scenarios take)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip kas_p4_kernel + tiles of 64 rows: the headline's kernels")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FULL_FILL | abi.KAS_PLAN_SPLIT_P4 | TILES_64), "hip the headline's kernels without the slim fill kernel in front")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FULL_FILL), "hip no slim fill kernel, the plan's choice otherwise")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER), "hip first fit as a wavefront of the order kernel's workgroup (kas_p4_order_kernel where it applies)")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER | TILES_64), "hip kas_p4_order_kernel, tiles of 64 rows")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER | TILES_128 | abi.KAS_PLAN_INDEX_ROWS), "hip kas_p4_order_kernel, double tiles, index rows")
@@ -639,6 +641,40 @@ def test_solves_in_flight_leave_identical_records_for_every_kernel_family():
     m = re.search(r"suite: (\d+) of (\d+) kernel families clean", r.stdout)
     assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 16, r.stdout[-3000:]
     assert r.stdout.count(": 0 scenario records differ from the reference") == int(m.group(2))
+
+
+@pytest.mark.gpu
+def test_slim_fill_kernel_and_the_scenarios_it_hands_back():
+    """kas_fill_slim_kernel in front of kas_fill_kernel (round 6; the default for int32 cells, lists up to 3 wide, a direct id
+    table, first fit handed over): 530 scenarios — from 512 on the plan takes kas_p4_kernel by itself — of which every seventh
+    starts from rows that are not rack-diverse (the slim kernel flags it, the full kernel on its 256 workgroups solves it from its
+    first topic), then scenarios of three topics whose last one is narrower than the batch, and 2-wide lists."""
+    S, P, N = 530, 1500, 60
+    racks = (np.arange(N) % 6).astype(np.int32)
+    ids = np.arange(N, dtype=np.int32)
+    curs = [(G.cyclic_assignment(P, N, 3, s) * 6 % N) if s % 7 == 3 else G.random_assignment(900 + s, P, N, 6, 3) for s in range(S)]
+    fb = uniform_batch(np.stack(curs).astype(np.int32), np.tile(ids, (S, 1))[:, :58], np.tile(racks, (S, 1))[:, :58], 3)
+    want = oracle_solve(fb, threads=0)
+    plan = native.Plan(native.default_context(), fb)
+    d = plan.describe()
+    plan.close()
+    assert d.startswith("kas_fill_slim_kernel<3>[quota, chunk histograms] grid=530x256") and "kas_fill_kernel<3,4>[quota, chunk histograms] grid=256x256 for scenarios it hands back" in d and "+ kas_p4_kernel<3>" in d, d
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 0), "hip slim fill: every seventh scenario handed back")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER), "hip slim fill + first fit beside the order kernel: every seventh handed back")
+    assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FULL_FILL), "hip the same without the slim kernel")
+    scs = []
+    for s in range(6):
+        n = 30 + s
+        scs.append(Scenario(brokers=list(range(n)), racks={b: "r%d" % (b % 6) for b in range(n)}, want_context=False,
+                            topics=[Topic("a", {p: G.random_assignment(1 + s, 700, 32, 6, 3)[p].tolist() for p in range(700)}, 3),
+                                    Topic("d", {p: G.random_assignment(40 + s, 900, 32, 6, 3)[p].tolist() for p in range(900)}, 3)] +
+                                   ([Topic("c", {p: G.random_assignment(70 + s, 300, 32, 6, 2)[p].tolist() for p in range(300)}, 2)] if s % 2 else [])))
+    fbt = flatten(scs)
+    wantt = oracle_solve(fbt)
+    for flags in (abi.KAS_PLAN_SPLIT_P4, abi.KAS_PLAN_P4_WITH_ORDER, abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_FULL_FILL):
+        assert_same_outputs(fbt, wantt, native.solve_host_with_flags(fbt, flags), f"hip slim fill, scenarios of several topics and widths, plan flags {flags:#x}")
+    fb2 = _batch(77, 5, 2500, 30, 6, 2, G.ACTIONS)
+    assert_same_outputs(fb2, oracle_solve(fb2), native.solve_host_with_flags(fb2, abi.KAS_PLAN_SPLIT_P4), "hip slim fill, lists 2 wide")
 
 
 @pytest.mark.gpu
