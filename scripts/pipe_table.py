@@ -21,12 +21,13 @@ rows = list(csv.DictReader(open(f"profiles/{tag}_pmc_sq_counters.csv")))
 c = collections.defaultdict(dict)
 for r in rows:
     k = "fill" if "fill" in r["kernel"] else ("p4" if "kas_p4" in r["kernel"] else ("order" if "order_relax" in r["kernel"] or "order_ticket" in r["kernel"] else None))
-    if k:
-        c[(int(r["batches_in_flight"]), k)][r["counter"]] = float(r["avg_value_per_dispatch"])
+    if k:                                                    # (a kind's kernels add up: the slim fill kernel + the full one behind it)
+        d = c[(int(r["batches_in_flight"]), k)]
+        d[r["counter"]] = d.get(r["counter"], 0.0) + float(r["avg_value_per_dispatch"])
 dur = {}
 for r in csv.DictReader(open(f"profiles/{tag}_kernel_trace_stats_one_batch_in_flight.csv")):
     if "kas_fill" in r["Name"]:
-        dur["fill"] = float(r["AverageNs"]) * 1e-9
+        dur["fill"] = dur.get("fill", 0.0) + float(r["AverageNs"]) * 1e-9
     if "kas_p4" in r["Name"]:
         dur["p4"] = float(r["AverageNs"]) * 1e-9
     if "kas_order_relax" in r["Name"] or "kas_order_ticket" in r["Name"]:
