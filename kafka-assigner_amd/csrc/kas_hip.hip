@@ -48,9 +48,18 @@ __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(K
 // The slim fill (round 6): fill_scenario<W, 4, SLIM> — only the path every BASELINE config at RF <= 3 takes (kas_solver_body.h,
 // fill_topic's SLIM branch): 120 VGPRs and no scratch where kas_fill_kernel<3,4> has 128 and 368 B per lane.  A scenario that
 // needs another path is flagged (KasLaunch::sp_flag) and kas_fill_kernel, launched behind this one with KAS_FLAG_ONLY_FLAGGED on
-// a grid of at most KAS_FILL_BACK_GRID workgroups, solves it from its first topic.
+// a grid of at most KAS_FILL_BACK_GRID workgroups, solves it from its first topic.  Its LDS layout holds only what that path
+// touches (kas_fill_slim_lds: 31.6 KB at 1,050 brokers against 35.5).  Measured (experiments/README.md): the smaller layout +1.4 %
+// in flight; 96 VGPRs (KAS_SLIM_MIN_WAVES=5: 88 B of scratch) with five workgroups per CU -0.5 %, with four and room for two order
+// wavefronts per SIMD beside them (KAS_TUNE_SLIM_LDS_PAD=1280) -2 %.
+#ifndef KAS_SLIM_MIN_WAVES
+#define KAS_SLIM_MIN_WAVES 4
+#endif
+#ifndef KAS_TUNE_SLIM_LDS_PAD
+#define KAS_TUNE_SLIM_LDS_PAD 0
+#endif
 template <int W>
-__global__ __launch_bounds__(256, KAS_FILL_MIN_WAVES) void kas_fill_slim_kernel(KasLaunch a) {
+__global__ __launch_bounds__(256, KAS_SLIM_MIN_WAVES) void kas_fill_slim_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
     kas::fill_scenario<W, 4, true>(a, s, kas_lds);
@@ -612,7 +621,7 @@ static int kas_plan_set_kernels(kas_plan* p) {
                                   (p->fused && p->lds_fused.total > p->lds.total ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD));
   if (p->NW == 4 && p->fused && kas_fill_slim_for(p->Wc) != nullptr)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_slim_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    p->lds_fused.total + KAS_TUNE_FILL_LDS_PAD));
+                                    kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total + KAS_TUNE_SLIM_LDS_PAD));
   if (p->Wc <= 3 && p->tickets && kas_order_ticket_for(p->Wc, p->G, 0))   // (beyond 8,191 brokers only the relaxation form applies)
     for (int pk = 0; pk < 2; ++pk)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
@@ -969,8 +978,9 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (kas_plan_slim_fill(p, kas_plan_split_p4(p) || lp.p4_order, chunks)) {
     const unsigned back = lp.fill_grid < KAS_FILL_BACK_GRID ? lp.fill_grid : KAS_FILL_BACK_GRID;
     const int len = snprintf(buf, (size_t)n, "kas_fill_slim_kernel<%d>[quota, chunk histograms] grid=%ux%u lds=%zu (+ kas_fill_kernel<%d,%d>[quota, chunk histograms] "
-                             "grid=%ux%u for scenarios it hands back)%s + %s", p->Wc, lp.fill_grid, lp.fill_block, lp.fill_lds, p->Wc, p->NW, back,
-                             lp.fill_block, p4, order);
+                             "grid=%ux%u lds=%zu for scenarios it hands back)%s + %s", p->Wc, lp.fill_grid, lp.fill_block,
+                             (size_t)kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total, p->Wc, p->NW, back,
+                             lp.fill_block, lp.fill_lds, p4, order);
     return len < n ? len : n - 1;
   }
   const int len = snprintf(buf, (size_t)n, "%skas_fill_kernel<%d,%d>[%s] grid=%ux%u lds=%zu%s%s + %s%s", spread, p->Wc, p->NW,
@@ -1069,7 +1079,8 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
 #if defined(KAS_TUNE_ORDER_ONLY)
     if (p->last_slot < 0)
 #endif
-    hipLaunchKernelGGL(kas_fill_slim_for(p->Wc), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, a);
+    hipLaunchKernelGGL(kas_fill_slim_for(p->Wc), dim3(lp.fill_grid), dim3(lp.fill_block),
+                       (size_t)kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total + KAS_TUNE_SLIM_LDS_PAD, st, a);
     KAS_HIP_TRY(hipGetLastError());
     a.flags |= KAS_FLAG_ONLY_FLAGGED;
     if (fill_grid > KAS_FILL_BACK_GRID) fill_grid = KAS_FILL_BACK_GRID;

@@ -1647,8 +1647,9 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
   if (SLIM && tid == 0) a.sp_flag[s] = 0;                    // (this thread alone writes the flag: 1 below if the scenario is handed back)
   const kas_scenario_desc sd = a.scen[s];
   const int32_t N = sd.n_nodes;
-  const KasLds lay = kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch,
-                                         (a.flags & KAS_FLAG_GENERIC_FILL) ? 0 : ((a.flags & KAS_FLAG_FUSED_HIST) ? 2 : 1));
+  const KasLds lay = SLIM ? kas_fill_slim_lds(a.n_max, W, a.idmap_entries)
+                          : kas_fill_lds_layout(a.n_max, W, NW, a.idmap_entries, a.need_bsearch,
+                                                (a.flags & KAS_FLAG_GENERIC_FILL) ? 0 : ((a.flags & KAS_FLAG_FUSED_HIST) ? 2 : 1));
   LdsView L;
   L.x = (int32_t*)(lds_raw + lay.off_x);
   // (wide lists: load[] takes the place of histogram row NW of THIS scenario's node count once the

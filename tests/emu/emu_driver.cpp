@@ -456,10 +456,16 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     sp_flag.assign((size_t)b->n_scenarios + 1, (int32_t)0xDEADBEEF);
     a.sp_flag = sp_flag.data();
     run_fn fs = sh.Wc <= 2 ? run_fill_slim<2> : run_fill_slim<3>;
+    // exactly the LDS the product launches kas_fill_slim_kernel with (kas_fill_slim_lds), and a guard behind it
+    const size_t slim_bytes = (size_t)kas_fill_slim_lds(sh.n_max, sh.Wc, sh.idmap_entries).total;
+    std::vector<unsigned char> sl(slim_bytes + 4096);
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
-      memset(lds.data(), 0xCD, lds.size());
-      RunArgs ra{&a, s, lds.data()};
+      memset(sl.data(), 0xCD, slim_bytes);
+      memset(sl.data() + slim_bytes, 0xA5, 4096);
+      RunArgs ra{&a, s, sl.data()};
       if (kasw::run_block(fs, &ra, 4) != 0) return bad("slim fill", s);
+      for (size_t i = 0; i < 4096; ++i)
+        if (sl[slim_bytes + i] != 0xA5) return bad("slim fill: LDS written beyond kas_fill_slim_lds()", s);
       if (sp_flag[(size_t)s] != 0 && sp_flag[(size_t)s] != 1) return bad("slim fill (hand-back flag not written)", s);
       g_last_slim_fill += sp_flag[(size_t)s] == 0 ? 1 : 0;
     }

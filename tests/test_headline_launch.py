@@ -27,8 +27,8 @@ N_LISTS = 64
 # what bench.py's line names (the plan's own description of its launch); n_max = 1050 (up to 50 brokers added)
 TAIL = (" + kas_p4_kernel<3> grid=1000x64 lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] grid=1000x64 lds=9472")
 # round 6: the slim fill kernel in front, the full one behind it on a small grid for scenarios handed back (none in this batch)
-HEADLINE_KERNELS = ("kas_fill_slim_kernel<3>[quota, chunk histograms] grid=1000x256 lds=35552 (+ kas_fill_kernel<3,4>[quota, chunk histograms] "
-                    "grid=256x256 for scenarios it hands back)" + TAIL)
+HEADLINE_KERNELS = ("kas_fill_slim_kernel<3>[quota, chunk histograms] grid=1000x256 lds=31648 (+ kas_fill_kernel<3,4>[quota, chunk histograms] "
+                    "grid=256x256 lds=35552 for scenarios it hands back)" + TAIL)
 FULL_FILL_KERNELS = "kas_fill_kernel<3,4>[quota, chunk histograms%s] grid=1000x256 lds=35552" + TAIL
 INDEX_ROWS_BY_DEFAULT = False    # the library's KAS_INDEX_ROWS_DEFAULT (measured both ways)
 CELLS16_KERNELS = ("kas_fill_kernel<3,4>[quota, chunk histograms] grid=1000x256 lds=35552 + kas_p4_kernel<3> grid=1000x64 "

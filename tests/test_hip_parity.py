@@ -658,7 +658,7 @@ def test_slim_fill_kernel_and_the_scenarios_it_hands_back():
     plan = native.Plan(native.default_context(), fb)
     d = plan.describe()
     plan.close()
-    assert d.startswith("kas_fill_slim_kernel<3>[quota, chunk histograms] grid=530x256") and "kas_fill_kernel<3,4>[quota, chunk histograms] grid=256x256 for scenarios it hands back" in d and "+ kas_p4_kernel<3>" in d, d
+    assert d.startswith("kas_fill_slim_kernel<3>[quota, chunk histograms] grid=530x256") and "kas_fill_kernel<3,4>[quota, chunk histograms] grid=256x256 lds=" in d and "for scenarios it hands back" in d and "+ kas_p4_kernel<3>" in d, d
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 0), "hip slim fill: every seventh scenario handed back")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_P4_WITH_ORDER), "hip slim fill + first fit beside the order kernel: every seventh handed back")
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, abi.KAS_PLAN_FULL_FILL), "hip the same without the slim kernel")
