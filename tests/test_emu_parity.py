@@ -344,7 +344,8 @@ def test_emu_index_rows_where_they_apply_and_where_they_do_not():
 def test_emu_slim_fill_kernel_in_front_and_the_full_kernel_for_what_it_hands_back():
     """kas_fill_slim_kernel (round 6): int32 cells, lists up to 3 wide, per-chunk histograms, a direct id table, first fit handed
     over — the slim kernel takes every scenario, solves the rack-diverse ones on the one path it holds and flags the others
-    (rows not rack-diverse; a topic of another width; ...), which kas_fill_kernel then solves from their first topic."""
+    (rows not rack-diverse, a topic without rows, ...), which kas_fill_kernel then solves from their first topic; topics narrower
+    than the batch stay with the slim kernel (its scans take ragged rows)."""
     from emu_lib import FULL_FILL, P4_WITH_ORDER, last_slim_fill
     # rack-diverse scenarios: all of them stay with the slim kernel, under either hand-over of first fit
     fb = _batch(1234, 5, 1777, 45, 9, 3, G.BENCH_ACTIONS)
@@ -369,8 +370,8 @@ def test_emu_slim_fill_kernel_in_front_and_the_full_kernel_for_what_it_hands_bac
     assert last_slim_fill() == 2
     assert_same_outputs(fbm, wantm, emu_solve(fbm, flags=P4_WITH_ORDER), "emu slim fill + first fit beside the order kernel: two of four handed back")
     assert last_slim_fill() == 2
-    # a scenario whose THIRD topic is the one the slim kernel does not hold (2 wide in a batch 3 wide): the scenario is solved
-    # again from its first topic, over the records, mid rows and hand-over words the slim kernel left for topics one and two
+    # scenarios of several topics, the third narrower than the batch (2 wide in a batch 3 wide): the slim kernel's scans take the
+    # ragged rows themselves — nothing is handed back
     scs = [Scenario(brokers=list(range(30)), racks={b: "r%d" % (b % 6) for b in range(30)}, want_context=False,
                     topics=[Topic("a", {p: G.random_assignment(1, 700, 32, 6, 3)[p].tolist() for p in range(700)}, 3),
                             Topic("d", {p: G.random_assignment(4, 900, 32, 6, 3)[p].tolist() for p in range(900)}, 3),
@@ -380,10 +381,30 @@ def test_emu_slim_fill_kernel_in_front_and_the_full_kernel_for_what_it_hands_bac
     fbt = flatten(scs)
     wantt = oracle_solve(fbt)
     got = emu_solve(fbt)
-    assert_same_outputs(fbt, wantt, got, "emu slim fill: a topic of another width hands the scenario back")
-    n_slim = last_slim_fill()
+    assert_same_outputs(fbt, wantt, got, "emu slim fill: a topic narrower than the batch")
+    assert last_slim_fill() == 2
     assert_same_outputs(fbt, wantt, emu_solve(fbt, flags=FULL_FILL), "emu: the same without the slim kernel")
-    assert n_slim in (1, 2)        # (2 if a narrower topic's rows are streamed at its own width: then nothing is handed back)
+    # scenarios whose SECOND topic starts from rows that are not rack-diverse: the slim kernel has solved topic one by then (records,
+    # mid rows, hand-over words) — the full kernel solves the scenario again from its first topic over all of that
+    fb3 = _later_topic_hands_back()
+    want3 = oracle_solve(fb3)
+    assert sorted(set(want3.scenario_results["status"].tolist())) == [abi.KAS_OK, abi.KAS_FAIL_UNASSIGNABLE]   # (some of them strand, KAS:183-184)
+    for flags in (0, P4_WITH_ORDER):
+        assert_same_outputs(fb3, want3, emu_solve(fb3, flags=flags), f"emu slim fill: the second topic hands the scenario back, plan flags {flags:#x}")
+        assert last_slim_fill() == 4
+
+
+def _later_topic_hands_back():
+    """8 scenarios of three topics over 48-50 brokers in 10 racks; in every other one the SECOND topic's rows are not rack-diverse"""
+    scs = []
+    for s in range(8):
+        n = 50 - (s % 3)
+        cyc = G.cyclic_assignment(701, 50, 3, s) * 10 % 50
+        second = Topic("b", {p: (cyc[p] if s % 2 == 0 else G.random_assignment(20 + s, 701, 50, 10, 3)[p]).tolist() for p in range(701)}, 3)
+        scs.append(Scenario(brokers=list(range(n)), racks={b: "r%d" % (b % 10) for b in range(n)}, want_context=False,
+                            topics=[Topic("a", {p: G.random_assignment(11 + s, 901, 50, 10, 3)[p].tolist() for p in range(901)}, 3), second,
+                                    Topic("c", {p: G.random_assignment(13 + s, 503, 50, 10, 3)[p].tolist() for p in range(503)}, 3)]))
+    return flatten(scs)
 
 
 def test_emu_relaxation_form_broker_ids_from_the_lds_and_from_the_node_table(monkeypatch):

@@ -648,7 +648,7 @@ def test_slim_fill_kernel_and_the_scenarios_it_hands_back():
     """kas_fill_slim_kernel in front of kas_fill_kernel (round 6; the default for int32 cells, lists up to 3 wide, a direct id
     table, first fit handed over): 530 scenarios — from 512 on the plan takes kas_p4_kernel by itself — of which every seventh
     starts from rows that are not rack-diverse (the slim kernel flags it, the full kernel on its 256 workgroups solves it from its
-    first topic), then scenarios of three topics whose last one is narrower than the batch, and 2-wide lists."""
+    first topic), then scenarios of three topics whose last one is narrower than the batch (they stay with the slim kernel), and 2-wide lists."""
     S, P, N = 530, 1500, 60
     racks = (np.arange(N) % 6).astype(np.int32)
     ids = np.arange(N, dtype=np.int32)
@@ -673,6 +673,13 @@ def test_slim_fill_kernel_and_the_scenarios_it_hands_back():
     wantt = oracle_solve(fbt)
     for flags in (abi.KAS_PLAN_SPLIT_P4, abi.KAS_PLAN_P4_WITH_ORDER, abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_FULL_FILL):
         assert_same_outputs(fbt, wantt, native.solve_host_with_flags(fbt, flags), f"hip slim fill, scenarios of several topics and widths, plan flags {flags:#x}")
+    # scenarios whose SECOND topic starts from rows that are not rack-diverse: the slim kernel has written topic one's records, mid
+    # rows and hand-over words by then; the full kernel solves the scenario again from its first topic over all of that
+    from test_emu_parity import _later_topic_hands_back
+    fb3 = _later_topic_hands_back()
+    want3 = oracle_solve(fb3)
+    for flags in (abi.KAS_PLAN_SPLIT_P4, abi.KAS_PLAN_P4_WITH_ORDER, 0):
+        assert_same_outputs(fb3, want3, native.solve_host_with_flags(fb3, flags) if flags else native.solve_host(fb3), f"hip slim fill: a later topic hands the scenario back, plan flags {flags:#x}")
     fb2 = _batch(77, 5, 2500, 30, 6, 2, G.ACTIONS)
     assert_same_outputs(fb2, oracle_solve(fb2), native.solve_host_with_flags(fb2, abi.KAS_PLAN_SPLIT_P4), "hip slim fill, lists 2 wide")
 
