@@ -813,6 +813,21 @@ def run_rank(args) -> int:
                                         f"({prof.get('kernel_sources_sha16')}): not quoted")
         except Exception:
             pass
+        # the measured traffic against what HBM DELIVERS to a plain streaming kernel with the same mix of reads and writes
+        # (profiles/hbm_streaming.json: experiments/micro/mall_reads.hip on this GPU) — `frac` stays algorithmic bytes over the
+        # nominal 8 TB/s; this says how much of the distance is traffic and nominal-versus-delivered, how much idle time
+        if roof.get("traffic"):
+            try:
+                hs = json.load(open(os.path.join(ROOT, "profiles", "hbm_streaming.json")))
+                mix = float(hs["two_streams_in_one_out_GBps"])
+                t_stream_ms = roof["traffic"] / (mix * 1e9) * 1e3
+                roof["delivered"] = {"streaming_GBps_at_this_mix": mix, "streaming_GBps_reads": hs["reads_16_byte_loads_GBps"],
+                                     "traffic_at_streaming_rate_ms": t_stream_ms,
+                                     "frac_of_streaming_rate_for_own_traffic": t_stream_ms / ms_per_step,
+                                     "traffic_over_algorithmic": roof["traffic"] / alg_bytes,
+                                     "source": hs["source"]}
+            except Exception:
+                pass
         # which pipe is nearest its ceiling: the per-pipe utilisation of the committed SQ-counter passes of this very
         # command line (scripts/pipe_table.py; eight batches in flight, whole job), HBM from the traffic above at this
         # run's rate.  Counters cannot be collected inside a timed run: the table is a committed measurement.
