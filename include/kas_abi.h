@@ -379,6 +379,13 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *                          node indices where its mid row goes, the second scan streams those 2-byte cells and stores only the rows
  *                          that do not keep all their replicas: `cur` is read ONCE and every id is looked up once; without, `cur` is
  *                          read by both scans.  Neither flag: the library's default (DESIGN.md section 4.1 has the measurement).
+ *   KAS_PLAN_MID32 / KAS_PLAN_NO_MID32  dword mid rows (round 6): between the fill and the order kernel a row of up to three holders
+ *                          is ONE aligned dword — the holders sorted by node index, 11 bits each (nothing behind the fill depends on
+ *                          their order: first fit appends, KAS:228 sorts) — instead of three uint16 in acceptance order: 4 instead
+ *                          of 6 bytes a row written and read, one memory instruction where the packed row takes two, and the order
+ *                          kernel's tags become the topic's constants.  Applies to int32 cells, lists 3 wide, at most 2,047 brokers,
+ *                          the relaxation form without a Context or sampled verification; otherwise (and with KAS_PLAN_INDEX_ROWS) the
+ *                          16-bit rows.  Neither flag: the library's default (DESIGN.md section 4.6 has the measurement).
  *   KAS_PLAN_FULL_FILL     kas_fill_kernel for every scenario.  Default (round 6; int32 cells, lists up to 3 wide, per-chunk
  *                          histograms, a direct id table, first fit handed over): kas_fill_slim_kernel first — the one path
  *                          rack-diverse scenarios take, compiled without the others (120 VGPRs, no scratch) — and
@@ -413,6 +420,8 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
 #define KAS_PLAN_SPREAD_FILL  32u
 #define KAS_PLAN_NO_INDEX_ROWS 64u
 #define KAS_PLAN_INDEX_ROWS  128u
+#define KAS_PLAN_MID32        0x80000u
+#define KAS_PLAN_NO_MID32     0x100000u
 #define KAS_PLAN_TICKET_ORDER 0x10000u
 #define KAS_PLAN_RELAX_TILES(n) (((uint32_t)(n) & 3u) << 17)
 #define KAS_PLAN_NO_RTN_QUOTA 0x200000u

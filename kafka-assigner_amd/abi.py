@@ -36,6 +36,8 @@ KAS_PLAN_SPREAD_FILL = 32
 KAS_PLAN_FULL_FILL = 16
 KAS_PLAN_NO_INDEX_ROWS = 64
 KAS_PLAN_INDEX_ROWS = 128
+KAS_PLAN_MID32 = 0x80000
+KAS_PLAN_NO_MID32 = 0x100000
 KAS_PLAN_TICKET_ORDER = 0x10000
 KAS_PLAN_RELAX_TILES_64 = 0x20000     # KAS_PLAN_RELAX_TILES(1)
 KAS_PLAN_RELAX_TILES_128 = 0x40000    # KAS_PLAN_RELAX_TILES(2)

@@ -161,10 +161,15 @@ __global__ __launch_bounds__(256) void kas_lds_order_selftest_kernel(unsigned in
 // (C16: the instances for plans with 16-bit cells, kas_plan_create16)
 // (IDL: the instances for int32 cells with the scenario's broker ids in the LDS — kas_relax_lds_ids; the gather instances,
 //  IDL = false on int32 cells, exist without the sampled verification only)
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false>
+// (M32: the instances for launches with dword mid rows, KAS_FLAG_MID32 — lists 3 wide, IDL, no Context, no sampled verification)
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool M32 = false>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL, false, M32>(a, (int32_t)blockIdx.x, kas_lds);
+}
+static void (*kas_order_relax_m32_pick(int Wc, int dual))(KasLaunch) {
+  if (Wc != 3) return nullptr;
+  return dual ? kas_order_relax_kernel<3, true, false, false, false, true, true> : kas_order_relax_kernel<3, false, false, false, false, true, true>;
 }
 template <bool VERIFY, bool C16 = false, bool IDL = false>
 static void (*kas_order_relax_pick(int Wc, int dual, int ctx))(KasLaunch) {
@@ -184,10 +189,14 @@ static void (*kas_order_relax_any(int Wc, int dual, int ctx, int verify, int c16
 
 // first fit (P4) and the relaxation form of P5 in one workgroup of two wavefronts (kas_order_relax.h, p4_order_scenario): the order
 // wavefront follows first fit's progress instead of waiting behind a kernel boundary — for launches whose latency is a scenario's
-template <int W, bool DUAL, bool C16, bool IDL>
+template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false>
 __global__ __launch_bounds__(128) void kas_p4_order_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::p4_order_scenario<W, DUAL, C16, IDL>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::p4_order_scenario<W, DUAL, C16, IDL, M32>(a, (int32_t)blockIdx.x, kas_lds);
+}
+static void (*kas_p4_order_m32_pick(int Wc, int dual))(KasLaunch) {
+  if (Wc != 3) return nullptr;
+  return dual ? kas_p4_order_kernel<3, true, false, true, true> : kas_p4_order_kernel<3, false, false, true, true>;
 }
 // (int32 cells with the broker ids in the LDS, or 16-bit cells: the instances that wait for no gather)
 static void (*kas_p4_order_pick(int Wc, int dual, int c16))(KasLaunch) {
@@ -421,6 +430,7 @@ struct kas_ctx {
 
 struct kas_plan {
   uint32_t full_fill = 0;               // KAS_PLAN_FULL_FILL of the last kas_plan_set_flags: no slim fill kernel
+  uint32_t mid32_bits = 0;              // KAS_PLAN_NO_MID32 / KAS_PLAN_MID32 of the last kas_plan_set_flags (kas_mid32_wanted)
   uint32_t index_rows_bits = 0;         // KAS_PLAN_NO_INDEX_ROWS / KAS_PLAN_INDEX_ROWS of the last kas_plan_set_flags (kas_index_rows_wanted)
   kas_ctx* ctx;
   KasShape shape;
@@ -645,6 +655,15 @@ static int kas_plan_set_kernels(kas_plan* p) {
         kas_p4_order_lds(p->shape.n_max, dual, kas_plan_relax_idl(p)) <= KAS_LDS_LIMIT)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_p4_order_for(p->Wc, dual, p->cells16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kas_p4_order_lds(p->shape.n_max, dual, kas_plan_relax_idl(p))));
+  if (p->shape.relax_ok && !p->shape.any_ctx && kas_plan_relax_idl(p) && p->shape.n_max <= KAS_MID32_N_MAX)   // (the instances for dword mid rows)
+    for (int dual = 0; dual < 2; ++dual) {
+      if (kas_order_relax_m32_pick(p->Wc, dual))
+        KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_m32_pick(p->Wc, dual), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        kas_order_relax_lds(p->shape.n_max, dual, 0, 1)));
+      if (kas_p4_order_m32_pick(p->Wc, dual) && kas_p4_order_lds(p->shape.n_max, dual, 1) <= KAS_LDS_LIMIT)
+        KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_p4_order_m32_pick(p->Wc, dual), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        kas_p4_order_lds(p->shape.n_max, dual, 1)));
+    }
   if (p->shape.relaxw_ok && kas_order_relaxw_for(p->Wc))
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relaxw_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_order_relaxw_lds(p->shape.n_max, p->Wc)));
@@ -733,7 +752,7 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   p->Wc = sh.Wc; p->NW = sh.NW; p->G = sh.G;
   p->tickets = sh.tickets_ok; p->fused = sh.fused_ok;
   p->lds = sh.lds; p->lds_fused = sh.lds_fused;
-  p->flags = 0; p->index_rows_bits = 0; p->full_fill = 0;
+  p->flags = 0; p->index_rows_bits = 0; p->full_fill = 0; p->mid32_bits = 0;
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
   p->sp_alloc_chunks = 0;
@@ -928,6 +947,13 @@ static bool kas_plan_split_p4(const kas_plan* p) {
          kas_split_p4(p->shape, p->NW, p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL), kas_plan_spread_chunks(p), p->n_scenarios);
 }
 
+// dword mid rows in this plan's next solve (KAS_FLAG_MID32, kas_mid32_launch)
+static bool kas_plan_mid32(const kas_plan* p, const KasLaunchPlan& lp) {
+  return kas_mid32_launch(p->shape, p->cells16 != 0, p->mid32_bits, lp.relax, p->flags, kas_plan_relax_idl(p), kas_plan_index_rows(p),
+                          kas_plan_spread_chunks(p)) &&
+         kas_order_relax_m32_pick(p->Wc, 0) != nullptr;
+}
+
 int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (!p || !buf || n <= 0) return set_error(KAS_E_INVALID_ARG, "NULL argument");
   const KasLaunchPlan lp = kas_launch_plan(p);
@@ -938,12 +964,13 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
                              : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax && lp.p4_order)
     snprintf(order, sizeof(order), "kas_p4_order_kernel<%d>[first fit beside kas_order_relax_kernel<%d>[tiles of %d rows%s] in one workgroup] grid=%ux%u lds=%zu",
-             p->Wc, p->Wc, (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64, kas_plan_relax_idl(p) ? ", ids in LDS" : "",
+             p->Wc, p->Wc, (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
+             kas_plan_relax_idl(p) ? (kas_plan_mid32(p, lp) ? ", ids in LDS, dword mid rows" : ", ids in LDS") : "",
              lp.order_grid, lp.order_block, lp.order_lds);
   else if (lp.relax)
     snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s%s] grid=%ux%u lds=%zu%s", p->Wc,
              (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
-             kas_plan_relax_idl(p) ? ", ids in LDS" : "",
+             kas_plan_relax_idl(p) ? (kas_plan_mid32(p, lp) ? ", ids in LDS, dword mid rows" : ", ids in LDS") : "",
              (p->flags >> 24) ? ", sampled verification" : "", lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
   else if (lp.relaxw)
     snprintf(order, sizeof(order), "kas_order_relax_wide_kernel<%d>[tiles of 64 rows, ids in LDS] grid=%ux%u lds=%zu", p->Wc, lp.order_grid,
@@ -1042,6 +1069,8 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
             ((p->ctx->lds_lane_order_ok && !(p->flags & KAS_FLAG_NO_RTN_QUOTA)) ? KAS_FLAG_LANE_ORDER : 0u) |
             (p->cells16 ? KAS_FLAG_CELLS16 : 0u) | (kas_plan_index_rows(p) ? KAS_FLAG_INDEX_ROWS : 0u);
   const KasLaunchPlan lp = kas_launch_plan(p);
+  const bool m32 = kas_plan_mid32(p, lp);                      // every kernel of this solve moves mid rows as one dword each
+  if (m32) a.flags |= KAS_FLAG_MID32;
   const bool tickets = lp.tickets;
   const bool split_p4 = kas_plan_split_p4(p) || lp.p4_order;   // (the fill kernel hands first fit over: to kas_p4_kernel, or to kas_p4_order_kernel)
   a.p4s = (int32_t*)p->b_p4s.p;
@@ -1120,7 +1149,10 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   else
 #endif
   if (lp.relax && lp.p4_order)
-    hipLaunchKernelGGL(kas_p4_order_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->cells16), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+    hipLaunchKernelGGL(m32 ? kas_p4_order_m32_pick(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u) : kas_p4_order_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->cells16),
+                       dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+  else if (lp.relax && m32)
+    hipLaunchKernelGGL(kas_order_relax_m32_pick(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (lp.relax)
     hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u, p->cells16, kas_plan_relax_idl(p)),
                        dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
@@ -1230,6 +1262,7 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
   int rc = kas_plan_set_kernels(p);
   if (rc != KAS_E_OK) return rc;
   p->index_rows_bits = flags & (KAS_PLAN_NO_INDEX_ROWS_BIT | KAS_PLAN_INDEX_ROWS_BIT);
+  p->mid32_bits = flags & (KAS_PLAN_NO_MID32_BIT | KAS_PLAN_MID32_BIT);
   p->full_fill = flags & KAS_PLAN_FULL_FILL_BIT;
   p->flags = (flags & (0xff0000ffu | KAS_FLAG_TICKET_ORDER | KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128 | KAS_FLAG_NO_RTN_QUOTA | KAS_FLAG_FILL_WITH_P4 | KAS_FLAG_SPLIT_P4) & ~(KAS_FLAG_FUSED_HIST | KAS_FLAG_ONLY_FLAGGED | KAS_FLAG_ORDER_FLAGGED)) |
              (g != 0 ? KAS_FLAG_TICKET_ORDER : 0u);      // (scenarios per wavefront only mean something to the ticket form)

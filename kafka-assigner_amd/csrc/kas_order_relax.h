@@ -164,6 +164,21 @@ KAS_DEV RelaxTags relax_tags(const uint32_t (&c)[3], const uint32_t* tagtab) {
   return g;
 }
 
+// ... of a row whose cells are in ascending order (dword mid rows, KAS_FLAG_MID32): cell q has rank q — the topic's constants,
+// wave-uniform (scalar registers), no table read and nothing computed per tile
+KAS_DEV RelaxTags relax_tags_sorted(const RelaxTopic& t) {
+  RelaxTags g;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    g.t0[q] = ((t.vp3 >> (4 * q)) & 0xcu) | (uint32_t)q;
+    g.t1[q] = ((t.ord2 >> (4 * q)) & 0xcu) | (uint32_t)q;
+  }
+  return g;
+}
+
+#ifndef KAS_M32_SORTED_TAGS
+#define KAS_M32_SORTED_TAGS(M32) (M32)
+#endif
 // The picks of a row with three holders: first pick | second pick << 2 (cell indices).
 KAS_DEV int32_t relax_eval3(const uint32_t (&x)[3], const RelaxTags& g) {
   // first pick: count[.][0], first strictly smaller in visit order == minimum of (count, visit position)
@@ -208,9 +223,12 @@ struct RelaxPend {
 // rows past the topic's end read as KAS_MID_NONE.  Every word is asked for by exactly ONE unconditional statement (a cell
 // the row does not have re-reads its last one and is masked when taken): a request under a condition would make the
 // compiler merge two definitions of the variable with a register copy — of a register whose load is still in flight.
-template <int W, bool FULLW>
+// (M32: dword mid rows, KAS_FLAG_MID32 — the row is ONE aligned dword whatever the topic's width)
+template <int W, bool FULLW, bool M32 = false>
 KAS_DEV void mid_request(MidRaw<W>& r, const uint16_t* mid, int32_t ow, int32_t p) {
-  if constexpr (FULLW) {                                    // (packed rows: the dword of a 6-byte row is 2-byte aligned)
+  if constexpr (M32) {
+    kasw::gload_u32_async<0>(r.w[0], mid, (uint32_t)p * 4u);
+  } else if constexpr (FULLW) {                                    // (packed rows: the dword of a 6-byte row is 2-byte aligned)
     const uint32_t off = (uint32_t)p * (uint32_t)(2 * mid_width_of<W>());
     kasw::gload_u32_async<0>(r.w[0], mid, off);
     if constexpr (W == 3) kasw::gload_u16_async<4>(r.w[1], mid, off);
@@ -220,12 +238,44 @@ KAS_DEV void mid_request(MidRaw<W>& r, const uint16_t* mid, int32_t ow, int32_t 
     for (int k = 0; k < W; ++k) kasw::gload_u16_async<0>(r.w[k], mid, off + 2u * (uint32_t)(k < ow ? k : ow - 1));
   }
 }
-template <int W, bool FULLW>
+// (M32: the row's dword as it came, or the all-ones word — which reads as "no holder" three times — for a row that does not exist;
+// mid_view takes it apart where the step uses it)
+template <int W, bool FULLW, bool M32 = false>
 KAS_DEV MidRaw<W> mid_take(const MidRaw<W>& r, int32_t ow, bool active) {
   MidRaw<W> o;
+  if constexpr (M32) {
+    o.w[0] = active ? r.w[0] : 0xffffffffu;
+#pragma unroll
+    for (int k = 1; k < W; ++k) o.w[k] = 0xffffffffu;
+    return o;
+  }
 #pragma unroll
   for (int k = 0; k < W; ++k) o.w[k] = (active && (FULLW ? k < (W + 1) / 2 : k < ow)) ? r.w[k] : 0xffffffffu;
   return o;
+}
+
+// M32: a taken row in the layout of the 16-bit rows — FULLW: cells 0, 1 in w[0], cell 2 in w[1]; else a cell per word — its cells
+// in ascending order.  "No holder" stays 0x7ff where FULLW (it is last in a sorted row, so a row holds three brokers iff its cell 2
+// is below 0x7ff; the slow path turns it into KAS_MID_NONE) and is KAS_MID_NONE otherwise.
+template <int W, bool FULLW, bool M32>
+KAS_DEV MidRaw<W> mid_view(const MidRaw<W>& t, int32_t ow) {
+  if constexpr (M32) {
+    static_assert(W == 3, "dword mid rows: lists 3 wide");
+    MidRaw<W> o;
+    uint32_t f[3];
+    mid32_fields(t.w[0], f);
+    if constexpr (FULLW) {
+      o.w[0] = f[0] | (f[1] << 16);
+      o.w[1] = f[2] | 0xffff0000u;
+      o.w[2] = 0xffffffffu;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o.w[k] = (k < ow && f[k] != KAS_M32_NONE) ? f[k] : 0xffffffffu;
+    }
+    return o;
+  } else {
+    return t;
+  }
 }
 
 // the pending rows go out (one 12-byte store each; C16, 16-bit cells: 6 bytes, in the place of the mid row they were made
@@ -314,9 +364,13 @@ KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, uint32_t w0_cells, uint32_t w1
 // behind a kernel boundary: a batch that has the GPU to itself lasts fill + max(P4, P5) instead of fill + P4 + P5.  A topic first
 // fit fails (KAS:183-184) is abandoned where this wavefront stands: its rows' digest is dropped, fs[2] says that nothing more is
 // written, and the first-fit wavefront pads the topic (nothing is returned for it: KAG:173-184).
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool FS = false>
+// M32 (round 6): the instances for launches with dword mid rows (KAS_FLAG_MID32; kas_solver_body.h, mid32_pack): a row comes as
+// ONE aligned dword — its holders in ascending order — instead of a dword and a halfword at 2-byte alignment, and because the
+// cells are sorted a row's six tags are the topic's constants: no comparison of the cells, no tag table read.
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool FS = false, bool M32 = false>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, uint64_t* fs = nullptr) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
+  static_assert(!M32 || (W == 3 && !CTX && !VERIFY && !C16 && IDL), "dword mid rows: lists 3 wide, int32 cells with the ids in the LDS, no Context, no sampled verification");
   static_assert(!FS || (!CTX && !VERIFY), "first fit in the order kernel's workgroup: batches without a Context, no sampled verification");
   // (16-bit cells: with no broker ids to wait for the raised priority stops paying — 8 x 20 steps 815-834k scenarios/s at
   // priority 0 against 803-815k at 3, 8 x 40 steps 833-865k against 824-853k, same box, gpurun_out/r5pr2)
@@ -422,8 +476,10 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
     uint64_t dtop = 0;                                       // the topic's digest: counted when the topic is through
     int32_t* out = C16 ? nullptr : a.out + td.out_off;
     uint16_t* out16 = C16 ? reinterpret_cast<uint16_t*>(a.out) + td.out_off : nullptr;
-    const uint16_t* mid = C16 ? out16 : mid_base(out, P, ow);
+    const uint16_t* mid = C16 ? out16 : (M32 ? reinterpret_cast<const uint16_t*>(out + (int64_t)P * ow - P) : mid_base(out, P, ow));
     const RelaxTopic rt = relax_topic(td.name_hash);
+    const RelaxTags gsorted = relax_tags_sorted(rt);        // (M32)
+    constexpr uint32_t NONE_FROM = M32 ? KAS_M32_NONE : 0x8000u;   // a cell at or above this holds no broker (cells of a row that exists)
     const int32_t nt = (P + 63) >> 6;
     // the topic's tags by the order of a row's cells: bit 0 = cell 0 < cell 1, bit 1 = cell 0 < cell 2, bit 2 = cell 1 <
     // cell 2;  word = first-pick tags of cells 0..2 (4 bits each), then the second-pick tags
@@ -457,7 +513,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
       auto row_exists = [&](int32_t t) -> bool { return ((t << 6) + lane) < P; };
       auto request_tile = [&](MidRaw<W>& r, int32_t t) {
         const int32_t pn = (t << 6) + lane;
-        mid_request<W, FULLW>(r, umid, ow, pn < P ? pn : 0);
+        mid_request<W, FULLW, M32>(r, umid, ow, pn < P ? pn : 0);
       };
       MidRaw<W> raw[NB], nx[NB];
       RelaxPend<NB> pend;
@@ -476,7 +532,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
-        raw[b] = mid_take<W, FULLW>(nx[b], ow, row_exists(b));
+        raw[b] = mid_take<W, FULLW, M32>(nx[b], ow, row_exists(b));
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) request_tile(nx[b], NB + b);
@@ -484,12 +540,14 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
         const int32_t p = (tile << 6) + lane;
         const bool active = p < P;
         // ---- cells of my row (row lane): node index or KAS_MID_NONE (0xffff, bit 15)
+        // (M32: the rows' dwords taken apart here, into the layout of the 16-bit rows — mid_view)
+        const MidRaw<W> ra = mid_view<W, FULLW, M32>(raw[0], ow);
         uint32_t c[3];
         if constexpr (FULLW) {
-          c[0] = raw[0].w[0] & 0xffffu; c[1] = raw[0].w[0] >> 16; c[2] = W == 3 ? (raw[0].w[1] & 0xffffu) : KAS_MID_NONE;
+          c[0] = ra.w[0] & 0xffffu; c[1] = ra.w[0] >> 16; c[2] = W == 3 ? (ra.w[1] & 0xffffu) : KAS_MID_NONE;
         } else {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) c[q] = q < W ? (raw[0].w[q] & 0xffffu) : KAS_MID_NONE;
+          for (int q = 0; q < 3; ++q) c[q] = q < W ? (ra.w[q] & 0xffffu) : KAS_MID_NONE;
         }
         // the usual tile: 64 rows, three holders each, rows of the batch's width
         bool fast = false;
@@ -504,12 +562,14 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
           for (int q = 0; q < 3; ++q) req_l[b][q] = 0u;
         if constexpr (W == 3) {
           if (FULLW && ((tile + 1) << 6) <= P)
-            fast = kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
+            fast = M32 ? kasw::ballot(c[2] >= NONE_FROM) == 0ull      // (sorted: a row holds three brokers iff its last cell does)
+                       : kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
           // ---- two usual tiles in a row: one double tile of 128 rows, lane i evaluates rows i and 64 + i.  The same
           // fixed point (row-major pairs over six instructions), twice the work per LDS round trip.
           if constexpr (DUAL) if (fast && ((tile + 2) << 6) <= P) {
-            const uint32_t cb[3] = {raw[NB - 1].w[0] & 0xffffu, raw[NB - 1].w[0] >> 16, raw[NB - 1].w[1] & 0xffffu};
-            if (kasw::ballot(((cb[0] | cb[1] | cb[2]) & 0x8000u) != 0u) == 0ull) {
+            const MidRaw<W> rb = mid_view<W, FULLW, M32>(raw[NB - 1], ow);
+            const uint32_t cb[3] = {rb.w[0] & 0xffffu, rb.w[0] >> 16, rb.w[1] & 0xffffu};
+            if ((M32 ? kasw::ballot(cb[2] >= NONE_FROM) : kasw::ballot(((cb[0] | cb[1] | cb[2]) & 0x8000u) != 0u)) == 0ull) {
               n_tiles += 2;
               kasw::lockstep();                                // (the previous tile's words have been read)
 #pragma unroll
@@ -519,7 +579,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
               for (int t = 0; t < 6; ++t) padr[t] = cnt + pp.slot[64 * t];
               uint32_t xa[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
               uint32_t xb[3] = {cnt[cb[0]], cnt[cb[1]], cnt[cb[2]]};
-              const RelaxTags ga = relax_tags(c, tagtab), gb = relax_tags(cb, tagtab);
+              const RelaxTags ga = KAS_M32_SORTED_TAGS(M32) ? gsorted : relax_tags(c, tagtab), gb = KAS_M32_SORTED_TAGS(M32) ? gsorted : relax_tags(cb, tagtab);
               kasw::lockstep();
               int32_t pa = -1, pb = -1;
               for (int32_t it = 0;; ++it) {
@@ -540,11 +600,11 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
 #pragma unroll
                 for (int t = 0; t < 6; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
                 kasw::lockstep();
-                if (relax_verify_rows(cnt, raw[0].w[0], raw[0].w[1], tagtab, pa) != 0ull) unsound = true;
-                if (relax_verify_rows(cnt, raw[NB - 1].w[0], raw[NB - 1].w[1], tagtab, pb) != 0ull) unsound = true;
+                if (relax_verify_rows(cnt, ra.w[0], ra.w[1], tagtab, pa) != 0ull) unsound = true;
+                if (relax_verify_rows(cnt, rb.w[0], rb.w[1], tagtab, pb) != 0ull) unsound = true;
               }
-              relax_list3(raw[0], pa < 0 ? 4 : pa, req_l[0], cnt2);
-              relax_list3(raw[NB - 1], pb < 0 ? 4 : pb, req_l[NB - 1], cnt2);
+              relax_list3(ra, pa < 0 ? 4 : pa, req_l[0], cnt2);
+              relax_list3(rb, pb < 0 ? 4 : pb, req_l[NB - 1], cnt2);
               req_n = 2;
               step = 2;
             }
@@ -565,7 +625,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
               for (int t = 0; t < 3; ++t) padr[t] = cnt + pp.slot[64 * t];
               // counter words of my cells as the previous tile left them
               uint32_t x[3] = {cnt[c[0]], cnt[c[1]], cnt[c[2]]};
-              const RelaxTags g = relax_tags(c, tagtab);        // my row's six tags from the order of its cells
+              const RelaxTags g = KAS_M32_SORTED_TAGS(M32) ? gsorted : relax_tags(c, tagtab);   // my row's six tags from the order of its cells
               kasw::lockstep();
               int32_t oc_prev = -1;
               for (int32_t it = 0;; ++it) {
@@ -586,15 +646,19 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
 #pragma unroll
                 for (int t = 0; t < 3; ++t) kasw::lds_sub_u32(padr[t], padd[t]);
                 kasw::lockstep();
-                if (relax_verify_rows(cnt, raw[0].w[0], raw[0].w[1], tagtab, oc_prev) != 0ull) unsound = true;
+                if (relax_verify_rows(cnt, ra.w[0], ra.w[1], tagtab, oc_prev) != 0ull) unsound = true;
               }
               // ---- the final row: its list as node indices now, broker ids and the store one step later
-              relax_list3(raw[0], oc_prev < 0 ? 4 : oc_prev, req_l[0], cnt2);
+              relax_list3(ra, oc_prev < 0 ? 4 : oc_prev, req_l[0], cnt2);
               req_n = 1;
             }
           } else {
             // ---- any other tile: per-lane list lengths
             n_slow += 1;
+            if constexpr (M32) {                              // ("no holder" as the code below knows it)
+#pragma unroll
+              for (int q = 0; q < 3; ++q) c[q] = c[q] >= NONE_FROM ? KAS_MID_NONE : c[q];
+            }
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
               const uint32_t n = pp.slot[64 * t];
@@ -657,12 +721,12 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
         }
         // ... the next rows move up,
         if constexpr (NB == 1) {
-          raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile));
+          raw[0] = mid_take<W, FULLW, M32>(nx[0], ow, row_exists(tile));
         } else {
           if (step == 2) {
-            raw[0] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile)); raw[1] = mid_take<W, FULLW>(nx[1], ow, row_exists(tile + 1));
+            raw[0] = mid_take<W, FULLW, M32>(nx[0], ow, row_exists(tile)); raw[1] = mid_take<W, FULLW, M32>(nx[1], ow, row_exists(tile + 1));
           } else {
-            raw[0] = raw[1]; raw[1] = mid_take<W, FULLW>(nx[0], ow, row_exists(tile + 1));
+            raw[0] = raw[1]; raw[1] = mid_take<W, FULLW, M32>(nx[0], ow, row_exists(tile + 1));
           }
         }
         // the previous step's final rows go out,
@@ -779,7 +843,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
 // (KAS_FLAG_SPLIT_P4: loads after the sticky fill, the chunks' orphan lists), and fs[] (four 8-byte words of LDS between
 // the two carve-ups) is how the first follows the second.  LDS: kas_p4_order_lds.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int W, bool DUAL, bool C16, bool IDL>
+template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false>
 KAS_DEV void p4_order_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
   const int32_t off_fs = kas_align16(kas_order_relax_lds(nmax, DUAL ? 1 : 0, 0, (IDL && !C16) ? 1 : 0));
@@ -787,7 +851,7 @@ KAS_DEV void p4_order_scenario(const KasLaunch& a, int32_t s, unsigned char* lds
   if (kasw::tid() < 4) fs[kasw::tid()] = kasw::tid() == 1 ? 0x7fffffffull : 0ull;   // rows final: none; failed topic: none; no answer; no watchdog
   kasw::sync();                                              // (the one workgroup barrier: both wavefronts pass it exactly once)
   if (kasw::wave_id() == 0) {
-    order_relax<W, DUAL, false, false, C16, IDL, true>(a, s, lds_raw, fs);
+    order_relax<W, DUAL, false, false, C16, IDL, true, M32>(a, s, lds_raw, fs);
   } else {
     if constexpr (KAS_P4_PRIO > 0) kasw::set_priority<KAS_P4_PRIO>();
     p4_scenario<W, 1, true>(a, s, lds_raw + off_fs + 32, fs);

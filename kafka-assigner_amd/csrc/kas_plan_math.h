@@ -84,6 +84,23 @@ KAS_ABI_FN int32_t kas_index_rows_wanted(uint32_t user_flags) {
   if (user_flags & KAS_PLAN_INDEX_ROWS_BIT) return 1;
   return KAS_INDEX_ROWS_DEFAULT;
 }
+#define KAS_FLAG_MID32        0x800u // set by the launcher (kas_mid32_ok; not with KAS_PLAN_NO_MID32): every mid row of this launch is ONE dword — the row's
+                                   // holders SORTED by node index, 11 bits each (kas_solver_body.h, mid32_pack) — instead of three uint16 in acceptance
+                                   // order: 4 instead of 6 bytes a row for the fill to write and the order kernel to read, one aligned store / load
+                                   // where the packed 6-byte rows take a dword and a halfword at 2-byte alignment.  Lists exactly 3 wide at most
+                                   // (Wc == 3), at most KAS_MID32_N_MAX brokers, int32 cells, the relaxation form without a Context / sampled
+                                   // verification in the instances with the broker ids in the LDS.
+#define KAS_MID32_N_MAX 2047         // node indices 0 .. 2046 in 11 bits, 0x7ff = no holder
+#define KAS_PLAN_MID32_BIT 0x80000u     // the user's switches (kas_plan_set_flags; their bits are KAS_FLAG_RELAX_DUAL's / KAS_FLAG_LANE_ORDER's in a launch
+#define KAS_PLAN_NO_MID32_BIT 0x100000u // word — both set by the launcher — so they are kept beside the plan's flags): on / off whatever KAS_MID32_DEFAULT says
+#ifndef KAS_MID32_DEFAULT
+#define KAS_MID32_DEFAULT 1
+#endif
+KAS_ABI_FN int32_t kas_mid32_wanted(uint32_t user_flags) {
+  if (user_flags & KAS_PLAN_NO_MID32_BIT) return 0;
+  if (user_flags & KAS_PLAN_MID32_BIT) return 1;
+  return KAS_MID32_DEFAULT;
+}
 #define KAS_FLAG_WIDE_CHECK   256u  // set by the launcher (KasShape::wide_checked): the wide ticket form checks its count fields at the end
 #define KAS_FLAG_TICKET_ORDER 0x10000u // lists <= 3 wide: the ticket form of P5 where the relaxation form would run (testing / comparison);
                                        // KAS_PLAN_GROUPS(n) and KAS_PLAN_WIDE_COUNTERS, which only mean something to the ticket form, imply it
@@ -464,6 +481,16 @@ static inline bool kas_p4_with_order(const KasShape& s, int32_t nw, uint32_t lau
   if (kas_p4_order_lds(s.n_max, double_tiles, with_ids) > KAS_LDS_LIMIT) return false;
   const uint32_t sw = launch_flags & KAS_FLAG_P4_WITH_ORDER;
   return sw == KAS_FLAG_P4_WITH_ORDER || (sw == 0u && n_scenarios < KAS_P4_WITH_ORDER_BELOW);
+}
+
+// Dword mid rows (KAS_FLAG_MID32) in this launch?  int32 cells, the batch's lists 3 wide at most and that width class, at most
+// KAS_MID32_N_MAX brokers, the relaxation form in the instances with the broker ids in the LDS, no Context, no sampled verification
+// (`launch_flags` >> 24), no index rows (their layout is the 16-bit row's), no spread fill (its kernels write 16-bit rows).
+// `user_flags`: the word of kas_plan_set_flags / the emulator (KAS_PLAN_MID32 / KAS_PLAN_NO_MID32).
+static inline bool kas_mid32_launch(const KasShape& s, bool c16, uint32_t user_flags, bool relax, uint32_t launch_flags, int32_t with_ids,
+                                    bool index_rows, int32_t spread_chunks) {
+  return kas_mid32_wanted(user_flags) && !c16 && s.Wc == 3 && s.n_max <= KAS_MID32_N_MAX && relax && !s.any_ctx &&
+         (launch_flags >> 24) == 0u && with_ids && !index_rows && spread_chunks == 0;
 }
 
 // Fused histogram layout of the rack-diverse fill (kas_fill_lds_layout with_x = 2): lists up to 3 wide

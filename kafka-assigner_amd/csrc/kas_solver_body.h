@@ -268,12 +268,25 @@ KAS_DEV int32_t chunk_begin(int32_t nt, int32_t w) { return (int32_t)(((int64_t)
 // P4 window: up to 64 orphans (lane = orphan, ascending row order), position-major first fit.
 // Returns -1, or the lane index of the first orphan that cannot be fully assigned (KAS:183).
 // ---------------------------------------------------------------------------------------------
+KAS_DEV uint32_t mid32_pack(int32_t h0, int32_t h1, int32_t h2);
+KAS_DEV void mid32_fields(uint32_t w, uint32_t (&c)[3]);
+// (m32, dword mid rows — KAS_FLAG_MID32: the row's holders are kept in registers from the dword the row scan stored, and every
+// accept stores the whole row again, sorted)
 template <int W>
 KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t live_count,
-                          int32_t& head, uint16_t* mid, int32_t mw, int64_t (&st)[8]) {
+                          int32_t& head, uint16_t* mid, int32_t mw, int64_t (&st)[8], bool m32 = false) {
   const int lane = kasw::lane();
   const bool mine = lane < count;
   const int32_t p = mine ? L.ring_p[lane] : 0;
+  int32_t cells[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) cells[k] = -1;
+  if constexpr (W == 3) if (m32 && mine) {
+    uint32_t f[3];
+    mid32_fields(reinterpret_cast<const uint32_t*>(mid)[p], f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cells[k] = f[k] == 0x7ffu ? -1 : (int32_t)f[k];
+  }
   const int32_t meta = mine ? L.ring_meta[lane] : 0;
   int32_t need = meta & 0xff;
   int32_t hc = (meta >> 8) & 0xff;
@@ -311,7 +324,12 @@ KAS_DEV int32_t p4_window(const LdsView& L, int32_t count, int32_t cap, int32_t 
           if (w != 0) {
             const int32_t rank = kasw::count_below(w);
             if (want && rank < slots[u]) {                 // accept (KAS:178-181)
-              mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
+              if (W == 3 && m32) {
+                put<W>(cells, hc, n[u]);
+                if constexpr (W == 3) reinterpret_cast<uint32_t*>(mid)[p] = mid32_pack(cells[0], cells[1], cells[2]);
+              } else {
+                mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
+              }
               put<W>(hr, hc, rk[u]);
               hc += 1;
               need -= 1;
@@ -365,6 +383,44 @@ KAS_DEV uint16_t* mid_base(int32_t* out, int32_t P, int32_t ow) {
 }
 KAS_DEV int32_t mid_to_index(uint32_t v) { return (v & 0x8000u) ? -1 : (int32_t)v; }   // (bit 15: KAS_MID_NONE — a node index is below 32768)
 
+// Dword mid rows (KAS_FLAG_MID32, round 6).  Nothing downstream of the fill depends on the order of a row's holders: first fit
+// appends to them, and the preference ordering visits them in ascending node order (KAS:228's TreeSet, KAS:188-200).  A row of
+// up to three holders is therefore kept SORTED, a <= b <= c with "no holder" (0x7ff) last, and three 11-bit fields need only 32
+// bits because the top bits of a sorted triple are monotone: the middle value b is stored whole (bits 0..10); if its top bit is
+// set, so is c's (c keeps 10 bits, a all 11), if it is clear, so is a's (a keeps 10 bits, c all 11).  One aligned dword per row
+// whatever the topic's width: 4 bytes for the fill to write and the order kernel to read where the packed uint16 row is 6, and
+// one memory instruction where that one takes two.  Rows live at the END of the topic's out region like the 16-bit ones
+// (mid row q starts at 4 ow P - 4 (P - q); final row p ends at 4 ow (p + 1) <= that for every q > p).
+#define KAS_M32_NONE 0x7ffu
+KAS_DEV bool mid32(const KasLaunch& a) { return (a.flags & KAS_FLAG_MID32) != 0u; }
+// holders in any order, -1 (any value >= 0x7ff as unsigned) = none
+KAS_DEV uint32_t mid32_pack(int32_t h0, int32_t h1, int32_t h2) {
+  const uint32_t u0 = (uint32_t)h0, u1 = (uint32_t)h1, u2 = (uint32_t)h2;
+  const uint32_t mn01 = u0 < u1 ? u0 : u1, mx01 = u0 < u1 ? u1 : u0;
+  const uint32_t lo = mn01 < u2 ? mn01 : u2;
+  const uint32_t hi = mx01 < u2 ? u2 : mx01;
+  const uint32_t md0 = mn01 < u2 ? u2 : mn01;               // max(min(u0, u1), u2) ...
+  const uint32_t md = md0 < mx01 ? md0 : mx01;              // ... capped by max(u0, u1): the median
+  const uint32_t a = lo < KAS_M32_NONE ? lo : KAS_M32_NONE, b = md < KAS_M32_NONE ? md : KAS_M32_NONE, c = hi < KAS_M32_NONE ? hi : KAS_M32_NONE;
+  const bool f = (b & 0x400u) != 0u;
+  const uint32_t x = f ? a : c, y = f ? (c & 0x3ffu) : a;
+  return b | (x << 11) | (y << 22);
+}
+// ... and back: ascending node indices, KAS_M32_NONE = none (last)
+KAS_DEV void mid32_fields(uint32_t w, uint32_t (&c)[3]) {
+  const uint32_t b = w & 0x7ffu, x = (w >> 11) & 0x7ffu, y = w >> 22;
+  const bool f = (w & 0x400u) != 0u;
+  c[0] = f ? x : y; c[1] = b; c[2] = f ? (y | 0x400u) : x;
+}
+// the same row in the layout of the packed 16-bit rows (MidRaw<3>: cells 0, 1 in w[0], cell 2 in w[1]; KAS_MID_NONE = none)
+KAS_DEV void mid32_to_raw16(uint32_t w, uint32_t& w0, uint32_t& w1) {
+  uint32_t c[3];
+  mid32_fields(w, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c[k] = c[k] == KAS_M32_NONE ? KAS_MID_NONE : c[k];
+  w0 = c[0] | (c[1] << 16); w1 = c[2] | 0xffff0000u;
+}
+
 // ---- cells of the cur / out tables: int32 broker ids, or — KAS_FLAG_CELLS16, the plans of kas_plan_create16 (ABI v5) —
 // uint16 node indices (0xFFFF: no such broker / pad; node i has id i).  With 16-bit cells a topic's out region is exactly
 // its mid rows' size (ow cells of 2 bytes a row): final row p takes the place of mid row p, which every order kernel has
@@ -390,6 +446,8 @@ KAS_DEV void out_pad(const OutRef& o, int64_t cells, int32_t first, int32_t step
 }
 KAS_DEV uint16_t* topic_mid(const KasLaunch& a, const kas_topic_desc& td) {
   if (cells16(a)) return reinterpret_cast<uint16_t*>(a.out) + td.out_off;
+  if (mid32(a))                                              // one dword per row, at the end of the topic's out region
+    return reinterpret_cast<uint16_t*>(a.out + td.out_off + (int64_t)td.n_partitions * td.out_width - td.n_partitions);
   return mid_base(a.out + td.out_off, td.n_partitions, td.out_width);
 }
 // the topic's cur rows: for 16-bit cells the pointer is only a byte address (2-byte aligned), read through load_row / cur_cell
@@ -404,12 +462,15 @@ KAS_DEV const int32_t* topic_cur(const KasLaunch& a, const kas_topic_desc& td) {
 // cell a row does not have reads KAS_MID_NONE), others cell by cell.
 template <int W>
 struct MidRaw { uint32_t w[W]; };
+// (m32: dword mid rows, KAS_FLAG_MID32 — the row's one dword in w[0])
 template <int W>
-KAS_DEV MidRaw<W> mid_load_raw(const uint16_t* mid, int32_t ow, int64_t p, bool active) {
+KAS_DEV MidRaw<W> mid_load_raw(const uint16_t* mid, int32_t ow, int64_t p, bool active, bool m32 = false) {
   MidRaw<W> raw;
 #pragma unroll
   for (int k = 0; k < W; ++k) raw.w[k] = 0xffffffffu;
-  if (ow == W) {
+  if (W == 3 && m32) {
+    if (active) raw.w[0] = reinterpret_cast<const uint32_t*>(mid)[p];
+  } else if (ow == W) {
     if (active) {
       const uint16_t* row = mid + p * mid_width_of<W>();
 #pragma unroll
@@ -425,7 +486,14 @@ KAS_DEV MidRaw<W> mid_load_raw(const uint16_t* mid, int32_t ow, int64_t p, bool 
 }
 // ... and unpacked where it is used: node indices, -1 = none
 template <int W>
-KAS_DEV void mid_unpack(const MidRaw<W>& raw, int32_t ow, int32_t (&c)[W]) {
+KAS_DEV void mid_unpack(const MidRaw<W>& raw, int32_t ow, int32_t (&c)[W], bool m32 = false) {
+  if constexpr (W == 3) if (m32) {
+    uint32_t f[3];
+    mid32_fields(raw.w[0], f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = f[k] == KAS_M32_NONE ? -1 : (int32_t)f[k];
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < W; ++k) {
     const uint32_t packed = (raw.w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
@@ -437,6 +505,7 @@ KAS_DEV void mid_unpack(const MidRaw<W>& raw, int32_t ow, int32_t (&c)[W]) {
 // Everything a phase needs to know about the topic being solved.
 struct TopicView {
   bool c16;             // cells of cur are uint16 node indices (KAS_FLAG_CELLS16)
+  bool m32 = false;     // mid rows are one dword each (KAS_FLAG_MID32): `mid` points at row 0's dword
   const int32_t* cur;
   uint16_t* mid;        // mid rows of the topic (at the end of its out region); mid_width(ow) uint16 each
   int32_t* orph;        // orphan row lists of this scenario (HBM scratch)
@@ -622,7 +691,9 @@ KAS_DEV void p3_rows(const LdsView& L, const TopicView& T, int32_t p, int32_t le
 #else
   if (active && !same) {
 #endif
-    if (T.ow == W) {                                        // wave-uniform: the mid row as W / 2 dwords (+ a halfword)
+    if (W == 3 && T.m32) {                                  // wave-uniform: the row's holders sorted, in one dword
+      if constexpr (W == 3) reinterpret_cast<uint32_t*>(T.mid)[p] = mid32_pack(hold[0], hold[1], hold[2]);
+    } else if (T.ow == W) {                                 // wave-uniform: the mid row as W / 2 dwords (+ a halfword)
       uint16_t* row = T.mid + (int64_t)p * mid_width_of<W>();
 #pragma unroll
       for (int k = 0; k < W / 2; ++k)
@@ -672,7 +743,7 @@ KAS_DEV int32_t drain_ring(const LdsView& L, const TopicView& T, int32_t min_fil
   const int lane = kasw::lane();
   while (ring_count >= min_fill && ring_count > 0) {
     const int32_t n_win = ring_count < 64 ? ring_count : 64;
-    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.mid, mid_width(T.ow), st);
+    const int32_t fl = p4_window<W>(L, n_win, T.cap, live_count, head, T.mid, mid_width(T.ow), st, T.m32);
     if (fl >= 0) return L.ring_p[fl];
     const int32_t rest = ring_count - n_win;           // shift the ring down by one window
     int32_t tp = 0, tm = 0; int32_t tr[W];
@@ -1159,7 +1230,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     return g < total ? T.orph[((int64_t)chunk_begin<NC>(T.nt, w) << 6) + (g - base)] : -1;
   };
   auto row_cells = [&](int32_t p) -> MidRaw<W> {
-    return mid_load_raw<W>(T.mid, T.ow, p >= 0 ? p : 0, p >= 0);
+    return mid_load_raw<W>(T.mid, T.ow, p >= 0 ? p : 0, p >= 0, T.m32);
   };
   const int32_t n_win = (total + 63) >> 6;
   // Window w may touch live-list positions [j, j + U) once EVERY earlier window is done with them.
@@ -1178,7 +1249,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
   for (int32_t w = wave; w < n_win; w += NW) {
     const int32_t p = p_nxt;
     int32_t c_cur[W];
-    mid_unpack<W>(c_nxt, T.ow, c_cur);
+    mid_unpack<W>(c_nxt, T.ow, c_cur, T.m32);
     p_nxt = orphan_row(64 * (w + NW) + lane);              // my next window's rows: read ahead
     c_nxt = row_cells(p_nxt);
     kasw::repoll();
@@ -1246,7 +1317,12 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
             if (wm != 0) {
               const int32_t rank = kasw::count_below(wm);
               if (want && rank < slots[u]) {               // accept (KAS:178-181)
-                T.mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
+                if (W == 3 && T.m32) {                       // (dword mid rows: the whole row again, sorted)
+                  put<W>(c_cur, hc, n[u]);
+                  if constexpr (W == 3) reinterpret_cast<uint32_t*>(T.mid)[p] = mid32_pack(c_cur[0], c_cur[1], c_cur[2]);
+                } else {
+                  T.mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
+                }
                 put<W>(hr, hc, rk[u]);
                 hc += 1;
                 need -= 1;
@@ -1380,6 +1456,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
   T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
   T.mid = topic_mid(a, td);
+  T.m32 = mid32(a);
   const int32_t P = T.P, hash = T.hash;
 
   TopicOutcome res;
@@ -1817,6 +1894,7 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
     T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
     T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
     T.mid = topic_mid(a, td);
+    T.m32 = mid32(a);
     T.cap = p4s[1];
     const int32_t cap = T.cap;
     barrier();                                            // (the previous topic's node state has been read)

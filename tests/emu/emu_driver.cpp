@@ -228,9 +228,14 @@ template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, boo
   RunArgs* r = (RunArgs*)p;
   if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL>(*r->a, r->s, r->lds);
 }
-template <int W, bool DUAL, bool C16, bool IDL> void run_p4_order(void* p) {
+template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false> void run_p4_order(void* p) {
   RunArgs* r = (RunArgs*)p;
-  if constexpr (W <= 3) kas::p4_order_scenario<W, DUAL, C16, IDL>(*r->a, r->s, r->lds);
+  if constexpr (W <= 3) kas::p4_order_scenario<W, DUAL, C16, IDL, M32>(*r->a, r->s, r->lds);
+}
+// the instances for dword mid rows (KAS_FLAG_MID32; kas_order_relax_m32_pick in kas_hip.hip)
+template <bool DUAL> void run_order_relax_m32(void* p) {
+  RunArgs* r = (RunArgs*)p;
+  kas::order_relax<3, DUAL, false, false, false, true, false, true>(*r->a, r->s, r->lds);
 }
 typedef void (*relax_fn)(void*);
 template <bool VERIFY, bool C16, bool IDL> relax_fn relax_pick(int Wc, bool dual, bool ctx) {   // as kas_order_relax_pick (kas_hip.hip)
@@ -286,6 +291,7 @@ static long g_last_queue_rows = 0;
 static int g_last_p4_order = 0;       // the last solve ran first fit inside the order kernel's workgroup (kas_p4_order_kernel)
 static int g_last_relax_idl = 0;      // the last relaxation-form launch read its broker ids from the LDS
 static long g_last_slim_fill = 0;    // scenarios the slim fill kernel solved itself (not handed back) in the last kas_emu_solve_batch
+static long g_last_mid32 = 0;        // the last kas_emu_solve_batch moved its mid rows as one dword each (KAS_FLAG_MID32)
 static long g_last_index_rows = 0;   // topics whose fill took the index rows (fill_pass_a_fused<EMIT>) in the last kas_emu_solve_batch
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
 static int g_last_spread = 0;  // scenarios the spread fill solved itself (not handed back) in the last kas_emu_solve_batch
@@ -378,6 +384,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
             ((flags & KAS_FLAG_NO_RTN_QUOTA) ? 0u : KAS_FLAG_LANE_ORDER) | (c16 ? KAS_FLAG_CELLS16 : 0u) |
             (index_rows ? KAS_FLAG_INDEX_ROWS : 0u);
   g_last_index_rows = 0;
+  g_last_mid32 = 0;
   auto bad = [&](const char* what, int32_t s) {
     if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "wave divergence / deadlock in the %s kernel, scenario %d", what, s);
     return -100;
@@ -436,6 +443,10 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   // first fit inside the order kernel's workgroup (kas_p4_order_kernel; same decision as kas_launch_plan in kas_hip.hip)
   const bool relax_dual = sh.Wc == 3 && (a.flags & KAS_FLAG_RELAX_DUAL) != 0u;
   const bool relax_idl = !c16 && kas_relax_lds_ids(sh.n_max, sh.any_ctx) && !(getenv("KAS_EMU_RELAX_GATHER") && getenv("KAS_EMU_RELAX_GATHER")[0] == '1');
+  // dword mid rows (same decision as kas_plan_mid32 in kas_hip.hip)
+  const bool m32 = kas_mid32_launch(sh, c16, flags, relax, a.flags, relax_idl ? 1 : 0, index_rows, CH);
+  if (m32) a.flags |= KAS_FLAG_MID32;
+  g_last_mid32 = m32 ? 1 : 0;
   const bool p4_order = relax && kas_p4_with_order(sh, sh.NW, a.flags, CH, b->n_scenarios,
                                                    !sh.any_ctx && (a.flags >> 24) == 0u && (c16 || relax_idl), relax_dual, relax_idl);
   g_last_p4_order = p4_order ? 1 : 0;
@@ -494,7 +505,8 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   }
   // order kernel: one wavefront per scenario (relaxation form, round form), three per G scenarios (ticket form)
   if (relax && p4_order) {
-    run_fn f = sh.Wc <= 2 ? (c16 ? run_p4_order<2, false, true, false> : run_p4_order<2, false, false, true>)
+    run_fn f = m32 ? (relax_dual ? run_p4_order<3, true, false, true, true> : run_p4_order<3, false, false, true, true>)
+               : sh.Wc <= 2 ? (c16 ? run_p4_order<2, false, true, false> : run_p4_order<2, false, false, true>)
                : c16 ? (relax_dual ? run_p4_order<3, true, true, false> : run_p4_order<3, false, true, false>)
                      : (relax_dual ? run_p4_order<3, true, false, true> : run_p4_order<3, false, false, true>);
     const size_t fb_bytes = (size_t)kas_p4_order_lds(sh.n_max, relax_dual, relax_idl);   // exactly the product's LDS, and a guard behind it
@@ -520,7 +532,8 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
       if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "KAS_PLAN_VERIFY_SAMPLE: not instantiated for the gather instances");
       return KAS_E_UNSUPPORTED;
     }
-    run_fn f = c16 ? (verify ? relax_pick<true, true, false>(sh.Wc, rdual, sh.any_ctx) : relax_pick<false, true, false>(sh.Wc, rdual, sh.any_ctx))
+    run_fn f = m32 ? (rdual ? run_order_relax_m32<true> : run_order_relax_m32<false>)
+               : c16 ? (verify ? relax_pick<true, true, false>(sh.Wc, rdual, sh.any_ctx) : relax_pick<false, true, false>(sh.Wc, rdual, sh.any_ctx))
                : idl ? (verify ? relax_pick<true, false, true>(sh.Wc, rdual, sh.any_ctx) : relax_pick<false, false, true>(sh.Wc, rdual, sh.any_ctx))
                      : relax_pick<false, false, false>(sh.Wc, rdual, sh.any_ctx);
     g_last_relax_idl = idl ? 1 : 0;
@@ -686,6 +699,8 @@ int kas_emu_last_fused(void) { return g_last_fused; }
 
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_index_rows(void) { return g_last_index_rows; }
+extern "C" __attribute__((visibility("default")))
+long kas_emu_last_mid32(void) { return g_last_mid32; }
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_slim_fill(void) { return g_last_slim_fill; }
 

@@ -863,3 +863,144 @@ def test_first_fit_takes_its_own_kernel_from_512_scenarios_on():
         assert last_split_p4() == split, S
     assert_same_outputs(fb, want, emu_solve(fb, flags=FILL_WITH_P4), "emu, 512 scenarios, first fit inside the fill workgroup")
     assert last_split_p4() == 0
+
+
+def test_emu_dword_mid_rows_where_they_apply_and_where_they_do_not():
+    """KAS_FLAG_MID32 (round 6): between the fill and the order kernel a row of up to three holders is ONE dword — the holders
+    sorted by node index, 11 bits each (first fit appends, KAS:228 sorts: nothing reads their order) — where the 16-bit rows are
+    three uint16 in acceptance order.  int32 cells, lists 3 wide, at most 2,047 brokers, the relaxation form without a Context or
+    the sampled verification; every place first fit can run in, the scenarios the slim kernel hands back (general fill, first fit
+    from the ring), topics narrower than the batch, failures; both layouts against the oracle."""
+    from emu_lib import FULL_FILL, MID32, NO_MID32, P4_WITH_ORDER, SPLIT_P4, last_mid32, last_slim_fill
+    fb = _batch(4321, 5, 1777, 45, 9, 3, G.BENCH_ACTIONS)
+    want = oracle_solve(fb)
+    for flags, m in ((0, 1), (MID32, 1), (NO_MID32, 0), (P4_WITH_ORDER, 1), (P4_WITH_ORDER | RELAX_TILES_128, 1), (SPLIT_P4 | RELAX_TILES_64, 1),
+                     (FILL_WITH_P4, 1), (FILL_WITH_P4 | RELAX_TILES_128, 1), (FULL_FILL, 1), (FULL_FILL | SPLIT_P4, 1), (NO_RTN_QUOTA, 1), (8, 1), (1, 1),
+                     (2 << 8, 1), (1 << 8, 1), (INDEX_ROWS, 0), (TICKET_ORDER, 0), (2, 0), (7 << 24, 0)):
+        assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu dword mid rows, plan flags {flags:#x}")
+        assert last_mid32() == m, (hex(flags), last_mid32())
+    # a Context handed in or wanted back: the 16-bit rows
+    fbc = flatten([Scenario(brokers=list(range(30)), racks={b: "r%d" % (b % 6) for b in range(30)}, want_context=True,
+                            topics=[Topic("a", {p: G.random_assignment(1, 700, 30, 6, 3)[p].tolist() for p in range(700)}, 3)])])
+    assert_same_outputs(fbc, oracle_solve(fbc), emu_solve(fbc), "emu with a Context")
+    assert last_mid32() == 0
+    # lists 2 wide: a row is one dword already
+    fb2 = _batch(77, 3, 900, 30, 6, 2, G.ACTIONS)
+    assert_same_outputs(fb2, oracle_solve(fb2), emu_solve(fb2), "emu lists 2 wide")
+    assert last_mid32() == 0
+    # rows that are not rack-diverse (scenarios 1 and 3: handed back, general fill, first fit from the ring), brokers that left
+    racks = (np.arange(60) % 6).astype(np.int32)
+    ids = np.arange(60, dtype=np.int32)
+    curs = [G.random_assignment(5, 1200, 60, 6, 3), G.cyclic_assignment(1200, 60, 3, 1) * 6 % 60,
+            G.random_assignment(6, 1200, 60, 6, 3), G.cyclic_assignment(1200, 60, 3, 2) * 6 % 60]
+    fbm = uniform_batch(np.stack(curs).astype(np.int32), np.tile(ids, (4, 1))[:, :58], np.tile(racks, (4, 1))[:, :58], 3)
+    wantm = oracle_solve(fbm)
+    for flags in (0, P4_WITH_ORDER, FILL_WITH_P4, FULL_FILL, 1, NO_MID32):
+        assert_same_outputs(fbm, wantm, emu_solve(fbm, flags=flags), f"emu dword mid rows: two of four scenarios not rack-diverse, plan flags {flags:#x}")
+        assert last_mid32() == (0 if flags == NO_MID32 else 1)
+    # duplicates in a row, brokers that are not in the set, ids far from zero, ragged last tile
+    rng = np.random.default_rng(61)
+    P, N = 1333, 37
+    ids2 = (np.arange(N, dtype=np.int32) * 3 + 1000)[None, :]
+    racks2 = (np.arange(N) % 7).astype(np.int32)[None, :]
+    cur = (rng.integers(0, N + 6, size=(P, 3)).astype(np.int32) * 3 + 1000)
+    cur[::17, 1] = cur[::17, 0]
+    fbd = uniform_batch(cur[None], ids2, racks2, 3)
+    assert_same_outputs(fbd, oracle_solve(fbd), emu_solve(fbd), "emu dword mid rows: duplicates, absent brokers")
+    assert last_mid32() == 1
+    # topics of several widths in one scenario (narrower topics are one dword a row too), a partition subset, a reduced RF
+    scs = [Scenario(brokers=list(range(30)), racks={b: "r%d" % (b % 6) for b in range(30)}, want_context=False,
+                    topics=[Topic("a", {p: G.random_assignment(1, 700, 30, 6, 3)[p].tolist() for p in range(700)}, 3),
+                            Topic("b", {p: G.random_assignment(2, 500, 30, 6, 2)[p].tolist() for p in range(500)}, 3),
+                            Topic("c", {p: G.random_assignment(3, 300, 30, 6, 2)[p].tolist() for p in range(300)}, 2),
+                            Topic("e", {p: G.random_assignment(7, 130, 30, 6, 1)[p].tolist() for p in range(130)}, 1),
+                            Topic("f", {p: G.random_assignment(8, 400, 30, 6, 3)[p].tolist() for p in range(400)}, 2),
+                            Topic("d", {p: G.random_assignment(4, 900, 30, 6, 3)[p].tolist() for p in range(900)}, 3)])
+           for _ in range(2)]
+    scs[1].brokers = [b for b in range(30) if b not in (3, 17)]
+    scs[1].racks = {b: "r%d" % (b % 6) for b in scs[1].brokers}
+    fbw = flatten(scs)
+    wantw = oracle_solve(fbw)
+    for flags in (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4 | RELAX_TILES_64, NO_MID32):
+        assert_same_outputs(fbw, wantw, emu_solve(fbw, flags=flags), f"emu dword mid rows, topics of several widths, plan flags {flags:#x}")
+    # first fit fails a topic (KAS:183-184: replace one broker at zero slack), in every place it runs in
+    fbf = _batch(99, 6, 8000, 80, 8, 3, ("replace1",))
+    wantf = oracle_solve(fbf)
+    assert (wantf.scenario_results["status"] != abi.KAS_OK).any()
+    for flags in (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4):
+        assert_same_outputs(fbf, wantf, emu_solve(fbf, flags=flags), f"emu dword mid rows, failing scenarios, plan flags {flags:#x}")
+        assert last_mid32() == 1
+
+
+def dword_mid_row_cases():
+    """(what, batch, plan flag words) — batches in which the dword mid rows meet everything that touches a mid row; shared with the
+    GPU test (tests/test_hip_parity.py)."""
+    from emu_lib import FULL_FILL, NO_MID32, P4_WITH_ORDER, SPLIT_P4
+    yield ("bench mix", _batch(4321, 5, 1777, 45, 9, 3, G.BENCH_ACTIONS),
+           (0, NO_MID32, P4_WITH_ORDER, P4_WITH_ORDER | RELAX_TILES_128, SPLIT_P4 | RELAX_TILES_64, FILL_WITH_P4, FILL_WITH_P4 | RELAX_TILES_128, FULL_FILL,
+            FULL_FILL | SPLIT_P4, NO_RTN_QUOTA, 8, 1, 2 << 8, 1 << 8))
+    racks = (np.arange(60) % 6).astype(np.int32)
+    ids = np.arange(60, dtype=np.int32)
+    curs = [G.random_assignment(5, 1200, 60, 6, 3), G.cyclic_assignment(1200, 60, 3, 1) * 6 % 60,
+            G.random_assignment(6, 1200, 60, 6, 3), G.cyclic_assignment(1200, 60, 3, 2) * 6 % 60]
+    yield ("two of four scenarios not rack-diverse", uniform_batch(np.stack(curs).astype(np.int32), np.tile(ids, (4, 1))[:, :58], np.tile(racks, (4, 1))[:, :58], 3),
+           (0, P4_WITH_ORDER, FILL_WITH_P4, FULL_FILL, 1, NO_MID32))
+    rng = np.random.default_rng(61)
+    P, N = 1333, 37
+    cur = (rng.integers(0, N + 6, size=(P, 3)).astype(np.int32) * 3 + 1000)
+    cur[::17, 1] = cur[::17, 0]
+    yield ("duplicates, absent brokers", uniform_batch(cur[None], (np.arange(N, dtype=np.int32) * 3 + 1000)[None, :], (np.arange(N) % 7).astype(np.int32)[None, :], 3),
+           (0, P4_WITH_ORDER, SPLIT_P4))
+    scs = [Scenario(brokers=list(range(30)), racks={b: "r%d" % (b % 6) for b in range(30)}, want_context=False,
+                    topics=[Topic("a", {p: G.random_assignment(1, 700, 30, 6, 3)[p].tolist() for p in range(700)}, 3),
+                            Topic("b", {p: G.random_assignment(2, 500, 30, 6, 2)[p].tolist() for p in range(500)}, 3),
+                            Topic("c", {p: G.random_assignment(3, 300, 30, 6, 2)[p].tolist() for p in range(300)}, 2),
+                            Topic("e", {p: G.random_assignment(7, 130, 30, 6, 1)[p].tolist() for p in range(130)}, 1),
+                            Topic("f", {p: G.random_assignment(8, 400, 30, 6, 3)[p].tolist() for p in range(400)}, 2),
+                            Topic("d", {p: G.random_assignment(4, 900, 30, 6, 3)[p].tolist() for p in range(900)}, 3)])
+           for _ in range(2)]
+    scs[1].brokers = [b for b in range(30) if b not in (3, 17)]
+    scs[1].racks = {b: "r%d" % (b % 6) for b in scs[1].brokers}
+    yield ("topics of several widths", flatten(scs), (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4 | RELAX_TILES_64, NO_MID32))
+    yield ("failing scenarios (replace one broker at zero slack)", _batch(99, 6, 8000, 80, 8, 3, ("replace1",)), (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4))
+    for N, R, P in ((1023, 11, 4000), (1025, 25, 4000), (2047, 23, 5000), (2048, 32, 5000)):
+        cur = G.random_assignment(N, P, N, R, 3)
+        ids = np.arange(N + 40, dtype=np.int32)
+        keep = np.ones(N + 40, dtype=bool); keep[[5, 1000 % N, N - 2]] = False; keep[N:] = False
+        keep[N:N + 7] = True                                                         # seven brokers join, three leave
+        bs = ids[keep]
+        if N == 2047:
+            bs = bs[:2047]
+        yield (f"{bs.shape[0]} brokers", uniform_batch(cur.astype(np.int32)[None], bs[None, :], (bs % R).astype(np.int32)[None, :], 3), (0, P4_WITH_ORDER, NO_MID32))
+
+
+def test_emu_dword_mid_rows_at_the_field_limits():
+    """Node indices around 1,024 (where the packed fields change roles) and up to 2,046; 2,048 brokers: the 16-bit rows."""
+    from emu_lib import NO_MID32, P4_WITH_ORDER, last_mid32
+    for N, R, P, want_m in ((1023, 11, 4000, 1), (1025, 25, 4000, 1), (2047, 23, 5000, 1), (2048, 32, 5000, 0)):
+        cur = G.random_assignment(N, P, N, R, 3)
+        # (rows across the 1,024 boundary in every combination: low / mid / high indices)
+        cur[::3, 0] = np.minimum(cur[::3, 0], N - 1)
+        ids = np.arange(N + 40, dtype=np.int32)
+        keep = np.ones(N + 40, dtype=bool); keep[[5, 1000 % N, N - 2]] = False; keep[N:] = False
+        keep[N:N + 7] = True                                                         # seven brokers join, three leave
+        bs = ids[keep]
+        racks = (bs % R).astype(np.int32)
+        if bs.shape[0] > 2047 and want_m:
+            bs, racks = bs[:2047], racks[:2047]
+        fb = uniform_batch(cur.astype(np.int32)[None], bs[None, :], racks[None, :], 3)
+        want = oracle_solve(fb)
+        for flags in (0, P4_WITH_ORDER):
+            assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu dword mid rows, {bs.shape[0]} brokers, plan flags {flags:#x}")
+            assert last_mid32() == (1 if bs.shape[0] <= 2047 else 0), (N, bs.shape[0], last_mid32())
+        assert_same_outputs(fb, want, emu_solve(fb, flags=NO_MID32), f"emu 16-bit mid rows, {bs.shape[0]} brokers")
+
+
+def test_emu_dword_mid_row_cases_shared_with_the_gpu_test():
+    from emu_lib import NO_MID32, last_mid32
+    for what, fb, flag_words in dword_mid_row_cases():
+        want = oracle_solve(fb)
+        fits = int(fb.scen["n_nodes"].max()) <= 2047
+        for flags in flag_words:
+            assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu dword mid rows: {what}, plan flags {flags:#x}")
+            assert last_mid32() == (1 if fits and not (flags & NO_MID32) else 0), (what, hex(flags))

@@ -25,7 +25,9 @@ SEED = 2026                      # bench.py's --seed default; slot 0, rank 0
 N_LISTS = 64
 
 # what bench.py's line names (the plan's own description of its launch); n_max = 1050 (up to 50 brokers added)
-TAIL = (" + kas_p4_kernel<3> grid=1000x64 lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] grid=1000x64 lds=9472")
+TAIL = (" + kas_p4_kernel<3> grid=1000x64 lds=8560 + kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS%s] grid=1000x64 lds=9472")
+MID32_BY_DEFAULT = True          # the library's KAS_MID32_DEFAULT: mid rows as one dword each where they apply
+M32 = ", dword mid rows"
 # round 6: the slim fill kernel in front, the full one behind it on a small grid for scenarios handed back (none in this batch)
 HEADLINE_KERNELS = ("kas_fill_slim_kernel<3>[quota, chunk histograms] grid=1000x256 lds=31648 (+ kas_fill_kernel<3,4>[quota, chunk histograms] "
                     "grid=256x256 lds=35552 for scenarios it hands back)" + TAIL)
@@ -75,18 +77,23 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
     assert len(bad) >= 1, "the bench mix holds scenarios the reference strands (KAS:183-184): a failure path in the launch"
 
     # ---- int32 broker ids in HBM in, broker ids out: the headline
-    dflt = (FULL_FILL_KERNELS % ", index rows") if INDEX_ROWS_BY_DEFAULT else HEADLINE_KERNELS
+    m32 = M32 if MID32_BY_DEFAULT else ""
+    dflt = (FULL_FILL_KERNELS % (", index rows", "")) if INDEX_ROWS_BY_DEFAULT else HEADLINE_KERNELS % m32
     for flags, what, expect in ((0, "as the plan chooses", dflt),
                                 (abi.KAS_PLAN_SPLIT_P4 | abi.KAS_PLAN_RELAX_TILES_64, "SPLIT_P4 | RELAX_TILES(1)", dflt),
-                                (abi.KAS_PLAN_FULL_FILL, "kas_fill_kernel for every scenario", FULL_FILL_KERNELS % ""),
-                                (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", FULL_FILL_KERNELS % ", index rows"),
-                                (abi.KAS_PLAN_P4_WITH_ORDER, "first fit as a wavefront of the order kernel's workgroup", None)):
+                                (abi.KAS_PLAN_NO_MID32, "16-bit mid rows", HEADLINE_KERNELS % ""),
+                                (abi.KAS_PLAN_MID32, "dword mid rows", HEADLINE_KERNELS % M32),
+                                (abi.KAS_PLAN_FULL_FILL, "kas_fill_kernel for every scenario", FULL_FILL_KERNELS % ("", m32)),
+                                (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", FULL_FILL_KERNELS % (", index rows", "")),
+                                (abi.KAS_PLAN_P4_WITH_ORDER, "first fit as a wavefront of the order kernel's workgroup", None),
+                                (abi.KAS_PLAN_P4_WITH_ORDER | abi.KAS_PLAN_NO_MID32, "first fit in the order kernel's workgroup, 16-bit mid rows", None)):
         plan = native.Plan(ctx, fb)
         if flags:
             plan.set_flags(flags)
         desc = plan.describe()
         if expect is None:
-            assert "kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS] in one workgroup] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
+            mm = "" if (flags & abi.KAS_PLAN_NO_MID32) else m32
+            assert f"kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS{mm}] in one workgroup] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
             assert desc.startswith("kas_fill_slim_kernel<3>["), desc
         else:
             assert desc == expect, desc

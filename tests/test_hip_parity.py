@@ -92,6 +92,25 @@ def test_hip_equals_oracle_seeded_batches(P, N, R, RF, actions):
     assert_same_outputs(fb, want, native.solve_host_with_flags(fb, 3 | (1 << 8)), "hip generic+round, 1 wave")
 
 
+def test_hip_dword_mid_rows_where_they_apply():
+    """KAS_FLAG_MID32 (round 6; tests/test_emu_parity.py has the emulator's run of the same batches): between the fill and the order
+    kernel a row is ONE dword — its holders sorted, 11 bits each — on int32 cells, lists 3 wide, at most 2,047 brokers, the
+    relaxation form; every place first fit runs in, scenarios handed back to the full fill kernel, topics narrower than the batch,
+    failures, node indices around 1,024 and up to 2,046.  Lists equal to the oracle's on either layout."""
+    from test_emu_parity import dword_mid_row_cases
+    ctx = native.default_context()
+    for what, fb, flag_words in dword_mid_row_cases():
+        want = oracle_solve(fb)
+        for flags in flag_words:
+            assert_same_outputs(fb, want, native.solve_host_with_flags(fb, flags), f"hip dword mid rows: {what}, plan flags {flags:#x}")
+        plan = native.Plan(ctx, fb)
+        fits = int(fb.scen["n_nodes"].max()) <= 2047
+        assert ("dword mid rows" in plan.describe()) == fits, plan.describe()
+        plan.set_flags(abi.KAS_PLAN_NO_MID32)
+        assert "dword mid rows" not in plan.describe(), plan.describe()
+        plan.close()
+
+
 def test_hip_rack_awareness_disabled_cyclic_and_sparse_ids():
     fb = _batch(99, 4, 1500, 50, 10, 3, G.ACTIONS, rack_aware=False)
     assert_same_outputs(fb, oracle_solve(fb), native.solve_host(fb), "hip norack")
