@@ -141,7 +141,8 @@ while time.time() - t0 < float(argv[1]):
     # (round 6: 0x80 / 0x40 = index rows on / off, 0xC00000 = first fit beside the order kernel in one workgroup (with either tile
     # size), 0x400000 / 0x800000 = first fit in kas_p4_kernel / inside the fill workgroup, 16 = KAS_PLAN_FULL_FILL (no slim fill kernel in front); lists 4-5 wide: 0x20000 = the relaxation
     # form for wide lists)
-    for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000, 0x200000, 0x80, 0x40 | 0x400000, 0xC00000 | 0x20000, 0xC00000 | 0x40000 | 0x80, 0x800000, 0x400000, 0x400000 | 16)
+    for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000, 0x200000, 0x80, 0x40 | 0x400000, 0xC00000 | 0x20000, 0xC00000 | 0x40000 | 0x80, 0x800000, 0x400000, 0x400000 | 16,
+                   0x100000, 0x100000 | 0xC00000, 0x100000 | 0x400000 | 0x20000)   # (0x100000 = KAS_PLAN_NO_MID32: the packed 16-bit mid rows where the default takes a dword a row)
                   if RF <= 3 else ((0, 2, 1, 32, 0x20000, 0x20000 | 0x800000) if RF <= 5 else (0, 2, 1, 32))):
         got = solve(fb, flags)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")

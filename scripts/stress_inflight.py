@@ -32,7 +32,9 @@ from oracle_lib import oracle_solve  # noqa: E402
 # in the plan's description — "!x": x must NOT appear —, bench.py flags).  The first is the headline shape (BASELINE.json configs[2]).
 SUITE = [
     ("headline: int32 broker ids in HBM in, ids out — slim fill kernel (per-chunk histograms) + first fit in kas_p4_kernel + relaxation form of the order kernel with the ids in the LDS",
-     "kas_fill_slim_kernel<3>[", ["--in-flight", "12", "--cells", "32"]),
+     "kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS, dword mid rows]", ["--in-flight", "12", "--cells", "32"]),
+    ("the same with the packed 16-bit mid rows (KAS_PLAN_NO_MID32: three uint16 a row in acceptance order, where the default is one dword of sorted holders)",
+     "!dword mid rows", ["--plan-flags", "1048576", "--in-flight", "12", "--cells", "32"]),
     ("the same with kas_fill_kernel<3,4> for every scenario (KAS_PLAN_FULL_FILL: no slim kernel in front)",
      "!kas_fill_slim_kernel", ["--plan-flags", "16", "--in-flight", "12", "--cells", "32"]),
     ("the same kernels on 16-bit cells in HBM (kas_plan_create16)",
