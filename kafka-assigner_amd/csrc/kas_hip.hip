@@ -58,12 +58,14 @@ __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(K
 #ifndef KAS_TUNE_SLIM_LDS_PAD
 #define KAS_TUNE_SLIM_LDS_PAD 0
 #endif
-template <int W>
+// (M32: the instance for launches with dword mid rows, KAS_FLAG_MID32 — one store path in either instance)
+template <int W, bool M32 = false>
 __global__ __launch_bounds__(256, KAS_SLIM_MIN_WAVES) void kas_fill_slim_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
   for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
-    kas::fill_scenario<W, 4, true>(a, s, kas_lds);
+    kas::fill_scenario<W, 4, true, M32 ? 1 : 0>(a, s, kas_lds);
 }
+static void (*kas_fill_slim_m32())(KasLaunch) { return kas_fill_slim_kernel<3, true>; }
 #define KAS_FILL_BACK_GRID 256u
 
 // min waves per SIMD of the ticket-form order kernel (0 = whatever the allocation comes to: 92 VGPRs, 5)
@@ -632,6 +634,9 @@ static int kas_plan_set_kernels(kas_plan* p) {
   if (p->NW == 4 && p->fused && kas_fill_slim_for(p->Wc) != nullptr)
     KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_slim_for(p->Wc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total + KAS_TUNE_SLIM_LDS_PAD));
+  if (p->NW == 4 && p->fused && p->Wc == 3 && kas_fill_slim_for(p->Wc) != nullptr)     // (its instance for dword mid rows)
+    KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_fill_slim_m32(), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total + KAS_TUNE_SLIM_LDS_PAD));
   if (p->Wc <= 3 && p->tickets && kas_order_ticket_for(p->Wc, p->G, 0))   // (beyond 8,191 brokers only the relaxation form applies)
     for (int pk = 0; pk < 2; ++pk)
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_ticket_for(p->Wc, p->G, pk),
@@ -1108,7 +1113,7 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
 #if defined(KAS_TUNE_ORDER_ONLY)
     if (p->last_slot < 0)
 #endif
-    hipLaunchKernelGGL(kas_fill_slim_for(p->Wc), dim3(lp.fill_grid), dim3(lp.fill_block),
+    hipLaunchKernelGGL(m32 ? kas_fill_slim_m32() : kas_fill_slim_for(p->Wc), dim3(lp.fill_grid), dim3(lp.fill_block),
                        (size_t)kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total + KAS_TUNE_SLIM_LDS_PAD, st, a);
     KAS_HIP_TRY(hipGetLastError());
     a.flags |= KAS_FLAG_ONLY_FLAGGED;

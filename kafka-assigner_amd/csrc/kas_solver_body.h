@@ -1265,6 +1265,7 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
     if (lane == 0) prog[wave] = ((uint64_t)(uint32_t)w << 32) | (uint32_t)j;
     KAS_COUNT(st[4]);
     bool stop = false;
+    bool placed = false;                                    // (dword mid rows) my row took a broker in this window
     for (;;) {
       uint64_t pend = kasw::ballot(need > 0);
       if (pend == 0) break;
@@ -1317,9 +1318,9 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
             if (wm != 0) {
               const int32_t rank = kasw::count_below(wm);
               if (want && rank < slots[u]) {               // accept (KAS:178-181)
-                if (W == 3 && T.m32) {                       // (dword mid rows: the whole row again, sorted)
+                if (W == 3 && T.m32) {                       // (dword mid rows: the row is stored again, sorted, when its window is through)
                   put<W>(c_cur, hc, n[u]);
-                  if constexpr (W == 3) reinterpret_cast<uint32_t*>(T.mid)[p] = mid32_pack(c_cur[0], c_cur[1], c_cur[2]);
+                  placed = true;
                 } else {
                   T.mid[(int64_t)p * mw + hc] = (uint16_t)n[u];
                 }
@@ -1342,6 +1343,9 @@ KAS_DEV void p4_lists_parallel(const LdsView& L, const TopicView& T, int32_t liv
       kasw::lockstep();
       j += U;
       if (lane == 0) prog[wave] = ((uint64_t)(uint32_t)w << 32) | (uint32_t)(j < live_count ? j : live_count);
+    }
+    if constexpr (W == 3) {
+      if (T.m32 && placed) reinterpret_cast<uint32_t*>(T.mid)[p] = mid32_pack(c_cur[0], c_cur[1], c_cur[2]);
     }
     if (stop) {
       // failed or abandoned: whoever waits on this window must not hang
@@ -1436,7 +1440,9 @@ KAS_DEV void sort_holders(const int32_t (&cells)[W], int32_t (&h)[W], int32_t& L
 // kernel has 128 and 368 B per lane.  A topic that needs another path returns KAS_TOPIC_NEEDS_FULL_FILL: the scenario is handed
 // back (KasLaunch::sp_flag) and the full kernel, launched behind this one for flagged scenarios only, solves it from its first topic.
 #define KAS_TOPIC_NEEDS_FULL_FILL (-1000)
-template <int W, int NW, bool SLIM = false>
+// (M32C: the mid-row layout as a compile-time constant — 1: dword mid rows (KAS_FLAG_MID32), 0: 16-bit rows, -1: what the launch's flags
+//  say; the slim kernel is instantiated for each layout so that it holds one store path)
+template <int W, int NW, bool SLIM = false, int M32C = -1>
 KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, const LdsView& L,
                                 const NodeMap& nm, const int32_t* g_node_id, const int32_t* g_node_rack,
                                 uint64_t* accmask, int32_t* orph, int32_t* p4s, int64_t (&st)[8]) {
@@ -1456,7 +1462,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
   T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
   T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
   T.mid = topic_mid(a, td);
-  T.m32 = mid32(a);
+  T.m32 = M32C < 0 ? mid32(a) : (M32C != 0);
   const int32_t P = T.P, hash = T.hash;
 
   TopicOutcome res;
@@ -1716,7 +1722,7 @@ KAS_DEV TopicOutcome fill_topic(const KasLaunch& a, const kas_topic_desc& td, co
 // fill kernel, one scenario: the per-topic loop of KAG:173-184 up to (not including) P5.
 // Writes the topic results and the scenario record (digest 0; the order kernel completes it).
 // ---------------------------------------------------------------------------------------------
-template <int W, int NW, bool SLIM = false>
+template <int W, int NW, bool SLIM = false, int M32C = -1>
 KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   constexpr int NT = 64 * NW;
   const int tid = kasw::tid();
@@ -1791,7 +1797,7 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
     else if (nodes_bad) o.status = KAS_FAIL_BAD_NODES;
     else if (!(td.rf > 0)) o.status = KAS_FAIL_RF_NOT_POSITIVE;        // KTA:65-66
     else if (!(td.rf <= N)) o.status = KAS_FAIL_RF_GT_BROKERS;         // KTA:67-69
-    else o = fill_topic<W, NW, SLIM>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph_topic, p4s, st);
+    else o = fill_topic<W, NW, SLIM, M32C>(a, td, L, nm, g_node_id, g_node_rack, accmask, orph_topic, p4s, st);
     if constexpr (SLIM) {
       if (o.status == KAS_TOPIC_NEEDS_FULL_FILL) {            // (workgroup-uniform) hand the scenario back: the full kernel solves it from its first topic
         if (tid == 0) a.sp_flag[s] = 1;

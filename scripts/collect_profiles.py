@@ -41,8 +41,8 @@ KB = 1024
 ff, fo = res[("FETCH_SIZE", "fill")] * KB, res[("FETCH_SIZE", "order")] * KB
 wf, wo = res[("WRITE_SIZE", "fill")] * KB, res[("WRITE_SIZE", "order")] * KB
 fp, wp = res.get(("FETCH_SIZE", "p4"), 0.0) * KB, res.get(("WRITE_SIZE", "p4"), 0.0) * KB     # first fit in its own kernel (round 5)
-known = 1000 * 100000 * 6           # the order kernel reads every 6-byte mid row exactly once (round 5: packed rows; 8 bytes before)
-corr = known / fo
+known = 1000 * 100000 * 6           # the order kernel reads every 6-byte mid row exactly once (round 5: packed rows; 8 bytes before);
+corr = known / fo                   # dword mid rows (KAS_FLAG_MID32, round 6): 4 bytes — corrected below once the plan's kernel string is read
 j = {"scenarios": 1000, "partitions": 100000,
      "hbm_bytes_per_launch": 2 * (ff + fp + fo) + wf + wp + wo,
      "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, profiles/{tag}_pmc_hbm_traffic.csv), "
@@ -60,6 +60,12 @@ for log in (os.path.join(d, "prof_fetch.log"), os.path.join(d, "prof_write.log")
         break
     except Exception:
         pass
+if "dword mid rows" in j.get("kernel", ""):
+    known = 1000 * 100000 * 4
+    corr = known / fo
+    j["read_correction_measured"] = corr
+    j["source"] = j["source"].replace("reads each 6-byte mid row exactly once, known/measured = ", "reads each 4-byte (dword) mid row exactly once, known/measured = ")
+    j["source"] = j["source"][:j["source"].rindex("= ") + 2] + "%.3f" % corr
 if "kernel" not in j:
     # the workload was tools/ab_harness (scripts/gpu_ab_profiles.sh), not bench.py: its log carries the plan's kernel
     # string; the sources are the tree's (the in-tree library the harness ran was built from them)

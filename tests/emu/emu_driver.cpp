@@ -196,9 +196,9 @@ namespace {
 
 struct RunArgs { const KasLaunch* a; int32_t s; unsigned char* lds; };
 
-template <int W> void run_fill_slim(void* p) {
+template <int W, int M32C = 0> void run_fill_slim(void* p) {
   RunArgs* r = (RunArgs*)p;
-  kas::fill_scenario<W, 4, true>(*r->a, r->s, r->lds);
+  kas::fill_scenario<W, 4, true, M32C>(*r->a, r->s, r->lds);
 }
 template <int W, int NW> void run_fill(void* p) {
   RunArgs* r = (RunArgs*)p;
@@ -466,7 +466,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   if (slim) {
     sp_flag.assign((size_t)b->n_scenarios + 1, (int32_t)0xDEADBEEF);
     a.sp_flag = sp_flag.data();
-    run_fn fs = sh.Wc <= 2 ? run_fill_slim<2> : run_fill_slim<3>;
+    run_fn fs = sh.Wc <= 2 ? run_fill_slim<2> : (m32 ? run_fill_slim<3, 1> : run_fill_slim<3>);   // (the product's instance per mid-row layout)
     // exactly the LDS the product launches kas_fill_slim_kernel with (kas_fill_slim_lds), and a guard behind it
     const size_t slim_bytes = (size_t)kas_fill_slim_lds(sh.n_max, sh.Wc, sh.idmap_entries).total;
     std::vector<unsigned char> sl(slim_bytes + 4096);
