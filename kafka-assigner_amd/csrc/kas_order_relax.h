@@ -854,7 +854,7 @@ KAS_DEV void p4_order_scenario(const KasLaunch& a, int32_t s, unsigned char* lds
     order_relax<W, DUAL, false, false, C16, IDL, true, M32>(a, s, lds_raw, fs);
   } else {
     if constexpr (KAS_P4_PRIO > 0) kasw::set_priority<KAS_P4_PRIO>();
-    p4_scenario<W, 1, true>(a, s, lds_raw + off_fs + 32, fs);
+    p4_scenario<W, 1, true, M32 ? 1 : 0>(a, s, lds_raw + off_fs + 32, fs);
   }
 }
 

@@ -1845,7 +1845,8 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 //   fs[0]  topic << 32 | rows of that topic that are final (first fit done with them; a topic that needs none: all its rows)
 //   fs[1]  the topic first fit failed at (KAS:183-184), or 0x7fffffff;  fs[2]  the order wavefront's answer: it has stopped writing
 // — and a failed topic's padding waits for that answer (the order wavefront may have emitted rows of it already).
-template <int W, int PW, bool FS = false>
+// (M32C: the mid-row layout as a compile-time constant, as in fill_topic — 1: dword mid rows, 0: 16-bit rows, -1: the launch's flags)
+template <int W, int PW, bool FS = false, int M32C = -1>
 KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw, uint64_t* fs = nullptr) {
   constexpr int NW = PW, NT = 64 * NW, NC = KAS_P4_WAVES;    // PW wavefronts run the windows over the fill's NC chunk lists
   static_assert(!FS || PW == 1, "first fit inside the order kernel's workgroup is one wavefront");
@@ -1900,7 +1901,7 @@ KAS_DEV void p4_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
     T.P = td.n_partitions; T.cw = td.cur_width; T.rf = td.rf; T.ow = td.out_width;
     T.hash = td.name_hash; T.nt = (T.P + 63) >> 6; T.N = N;
     T.mid = topic_mid(a, td);
-    T.m32 = mid32(a);
+    T.m32 = M32C < 0 ? mid32(a) : (M32C != 0);
     T.cap = p4s[1];
     const int32_t cap = T.cap;
     barrier();                                            // (the previous topic's node state has been read)

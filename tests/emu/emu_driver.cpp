@@ -204,9 +204,9 @@ template <int W, int NW> void run_fill(void* p) {
   RunArgs* r = (RunArgs*)p;
   kas::fill_scenario<W, NW>(*r->a, r->s, r->lds);
 }
-template <int W> void run_p4(void* p) {
+template <int W, int M32C = 0> void run_p4(void* p) {
   RunArgs* r = (RunArgs*)p;
-  kas::p4_scenario<W, 1>(*r->a, r->s, r->lds);            // (one wavefront, as kas_p4_kernel is launched)
+  kas::p4_scenario<W, 1, false, M32C>(*r->a, r->s, r->lds);   // (one wavefront, as kas_p4_kernel is launched; its instance per mid-row layout)
 }
 template <int W, int G, bool PK> void run_order_tickets(void* p) {
   RunArgs* r = (RunArgs*)p;
@@ -493,7 +493,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     // exactly the LDS the product launches kas_p4_kernel with, and a guard behind it
     const size_t p4_bytes = (size_t)kas_p4_lds_layout(sh.n_max).total;
     std::vector<unsigned char> pl(p4_bytes + 4096);
-    run_fn fp4 = sh.Wc <= 2 ? run_p4<2> : sh.Wc == 3 ? run_p4<3> : sh.Wc == 4 ? run_p4<4> : sh.Wc == 5 ? run_p4<5> : run_p4<8>;
+    run_fn fp4 = sh.Wc <= 2 ? run_p4<2> : sh.Wc == 3 ? (m32 ? run_p4<3, 1> : run_p4<3>) : sh.Wc == 4 ? run_p4<4> : sh.Wc == 5 ? run_p4<5> : run_p4<8>;
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(pl.data(), 0xCD, p4_bytes);
       memset(pl.data() + p4_bytes, 0xA5, 4096);
