@@ -664,10 +664,17 @@ def run_rank(args) -> int:
             what_l = keep[0]["plan"].describe()
             el1l = timed(n_alone, 1)
             f1l, o1l, _ = run.phase_times()
-            keep[0]["plan"].set_flags(base_flags)
-            run.solve(keep[0]); run.synchronize()                  # (slot 0's records and rows: the headline plan's again)
             alone["with_latency_flags"] = {"ms_per_step": 1e3 * el1l / n_alone, "fill_kernel_us": f1l, "order_kernel_us": o1l,
                                            "plan_flags": "KAS_PLAN_P4_WITH_ORDER | KAS_PLAN_RELAX_TILES(2)", "kernel": what_l}
+            # ... and over quad tiles (256 rows a step, round 6: where the plan has dword mid rows; elsewhere this is the leg above again)
+            keep[0]["plan"].set_flags(base_flags | _abi.KAS_PLAN_P4_WITH_ORDER | _abi.KAS_PLAN_RELAX_TILES_64 | _abi.KAS_PLAN_RELAX_TILES_128)
+            what_q = keep[0]["plan"].describe()
+            el1q = timed(n_alone, 1)
+            f1q, o1q, _ = run.phase_times()
+            alone["with_latency_flags_quad_tiles"] = {"ms_per_step": 1e3 * el1q / n_alone, "fill_kernel_us": f1q, "order_kernel_us": o1q,
+                                                      "plan_flags": "KAS_PLAN_P4_WITH_ORDER | KAS_PLAN_RELAX_TILES(3)", "kernel": what_q}
+            keep[0]["plan"].set_flags(base_flags)
+            run.solve(keep[0]); run.synchronize()                  # (slot 0's records and rows: the headline plan's again)
         except Exception as e:                                     # (a leg of its own: never costs the headline line)
             alone["with_latency_flags"] = {"error": repr(e)}
         finally:

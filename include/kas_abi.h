@@ -374,6 +374,9 @@ int kas_plan_phase_times_us(kas_plan* plan, double* fill_us, double* order_us, i
  *                          Lists 4 and 5 wide (round 6): 1 = the relaxation form for these widths (kas_order_relax_wide.h: one
  *                          wavefront per scenario, uint64 counter words; batches without a Context) instead of the wide ticket
  *                          form — exact, and measured slower at BASELINE configs[4], hence opt-in
+ *                          3 (round 6) = quad tiles: 256 rows a step, four rows per lane — instances exist on dword mid rows only
+ *                          (elsewhere: double tiles); exact, and measured SLOWER than double tiles for a batch alone (order kernel
+ *                          1.54 against 1.42 ms per 1000 scenarios), hence only on request
  *   KAS_PLAN_INDEX_ROWS / KAS_PLAN_NO_INDEX_ROWS  rack-diverse fill with per-chunk histograms on int32 cells (round 6): with index
  *                          rows the first row scan — which looks every broker id up, KAS:118-119's nodeMap.get — leaves the row's
  *                          node indices where its mid row goes, the second scan streams those 2-byte cells and stores only the rows

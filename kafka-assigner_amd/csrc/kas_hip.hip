@@ -166,14 +166,17 @@ __global__ __launch_bounds__(256) void kas_lds_order_selftest_kernel(unsigned in
 // (IDL: the instances for int32 cells with the scenario's broker ids in the LDS — kas_relax_lds_ids; the gather instances,
 //  IDL = false on int32 cells, exist without the sampled verification only)
 // (M32: the instances for launches with dword mid rows, KAS_FLAG_MID32 — lists 3 wide, IDL, no Context, no sampled verification)
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool M32 = false>
+// (QUAD: the instance with quad tiles — 256 rows a step — on dword mid rows, KAS_PLAN_RELAX_TILES(3))
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool M32 = false, bool QUAD = false>
 __global__ __launch_bounds__(64) void kas_order_relax_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL, false, M32>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL, false, M32, QUAD>(a, (int32_t)blockIdx.x, kas_lds);
 }
-static void (*kas_order_relax_m32_pick(int Wc, int dual))(KasLaunch) {
+// (tiles: 0 = 64 rows a step, 1 = double tiles, 2 = quad tiles)
+static void (*kas_order_relax_m32_pick(int Wc, int tiles))(KasLaunch) {
   if (Wc != 3) return nullptr;
-  return dual ? kas_order_relax_kernel<3, true, false, false, false, true, true> : kas_order_relax_kernel<3, false, false, false, false, true, true>;
+  if (tiles >= 2) return kas_order_relax_kernel<3, true, false, false, false, true, true, true>;
+  return tiles ? kas_order_relax_kernel<3, true, false, false, false, true, true> : kas_order_relax_kernel<3, false, false, false, false, true, true>;
 }
 template <bool VERIFY, bool C16 = false, bool IDL = false>
 static void (*kas_order_relax_pick(int Wc, int dual, int ctx))(KasLaunch) {
@@ -193,14 +196,15 @@ static void (*kas_order_relax_any(int Wc, int dual, int ctx, int verify, int c16
 
 // first fit (P4) and the relaxation form of P5 in one workgroup of two wavefronts (kas_order_relax.h, p4_order_scenario): the order
 // wavefront follows first fit's progress instead of waiting behind a kernel boundary — for launches whose latency is a scenario's
-template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false>
+template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false, bool QUAD = false>
 __global__ __launch_bounds__(128) void kas_p4_order_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  kas::p4_order_scenario<W, DUAL, C16, IDL, M32>(a, (int32_t)blockIdx.x, kas_lds);
+  kas::p4_order_scenario<W, DUAL, C16, IDL, M32, QUAD>(a, (int32_t)blockIdx.x, kas_lds);
 }
-static void (*kas_p4_order_m32_pick(int Wc, int dual))(KasLaunch) {
+static void (*kas_p4_order_m32_pick(int Wc, int tiles))(KasLaunch) {
   if (Wc != 3) return nullptr;
-  return dual ? kas_p4_order_kernel<3, true, false, true, true> : kas_p4_order_kernel<3, false, false, true, true>;
+  if (tiles >= 2) return kas_p4_order_kernel<3, true, false, true, true, true>;
+  return tiles ? kas_p4_order_kernel<3, true, false, true, true> : kas_p4_order_kernel<3, false, false, true, true>;
 }
 // (int32 cells with the broker ids in the LDS, or 16-bit cells: the instances that wait for no gather)
 static void (*kas_p4_order_pick(int Wc, int dual, int c16))(KasLaunch) {
@@ -667,7 +671,8 @@ static int kas_plan_set_kernels(kas_plan* p) {
       KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_p4_order_for(p->Wc, dual, p->cells16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kas_p4_order_lds(p->shape.n_max, dual, kas_plan_relax_idl(p))));
   if (p->shape.relax_ok && !p->shape.any_ctx && kas_plan_relax_idl(p) && p->shape.n_max <= KAS_MID32_N_MAX)   // (the instances for dword mid rows)
-    for (int dual = 0; dual < 2; ++dual) {
+    for (int dual = 0; dual < 3; ++dual) {                     // (tiles of 64 rows, double tiles, quad tiles)
+      if (kas_order_relax_lds(p->shape.n_max, dual, 0, 1) > KAS_LDS_LIMIT) continue;
       if (kas_order_relax_m32_pick(p->Wc, dual))
         KAS_HIP_TRY(hipFuncSetAttribute((const void*)kas_order_relax_m32_pick(p->Wc, dual), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         kas_order_relax_lds(p->shape.n_max, dual, 0, 1)));
@@ -906,6 +911,8 @@ struct KasLaunchPlan {
   bool relaxw;                  // relaxation form of P5 for lists 4 and 5 wide (then neither tickets nor wide)
   bool relax;                   // relaxation form of P5 (then neither tickets nor wide)
   bool tickets, pairing, wide;
+  bool m32;                     // dword mid rows in this solve (KAS_FLAG_MID32)
+  int tiles;                    // relaxation form: 0 = tiles of 64 rows, 1 = double tiles, 2 = quad tiles (dword mid rows only)
   int packed;
   unsigned fill_grid, fill_block, order_grid, order_block;
   size_t fill_lds, order_lds;
@@ -921,15 +928,21 @@ static KasLaunchPlan kas_launch_plan(const kas_plan* p) {
               kas_relaxw_wanted(p->flags);
   lp.wide = !lp.tickets && !lp.relaxw && !p->cells16 && p->shape.wide_ok && !(p->flags & KAS_FLAG_ROUND_ORDER) && kas_order_wide_for(p->Wc) != nullptr;
   lp.p4_order = false;
+  lp.m32 = kas_mid32_launch(p->shape, p->cells16 != 0, p->mid32_bits, lp.relax, p->flags, kas_plan_relax_idl(p), kas_plan_index_rows(p),
+                            kas_plan_spread_chunks(p)) && kas_order_relax_m32_pick(p->Wc, 0) != nullptr;
+  lp.tiles = 0;
   lp.fill_grid = (unsigned)p->n_scenarios; lp.fill_block = 64u * (unsigned)p->NW;
   lp.fill_lds = (size_t)(kas_plan_fused(p) ? p->lds_fused.total : p->lds.total) + KAS_TUNE_FILL_LDS_PAD;
   if (lp.relax) {
-    const int dual = p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios);
+    int dual = p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios);
+    if (dual && lp.m32 && kas_relax_quad_tiles(p->flags, p->n_scenarios) && kas_order_relax_lds(p->shape.n_max, 2, 0, 1) <= KAS_LDS_LIMIT)
+      dual = 2;                                                 // (quad tiles: the instances on dword mid rows)
+    lp.tiles = dual;
     lp.order_grid = (unsigned)p->n_scenarios; lp.order_block = 64u;
     lp.order_lds = (size_t)kas_order_relax_lds(p->shape.n_max, dual, p->shape.any_ctx, kas_plan_relax_idl(p));
     // first fit as a second wavefront of the order kernel's workgroup?
     const bool relax_plain = !p->shape.any_ctx && (p->flags >> 24) == 0u && (p->cells16 || kas_plan_relax_idl(p)) &&
-                             kas_p4_order_for(p->Wc, dual, p->cells16) != nullptr && p->b_p4s.p != nullptr;
+                             kas_p4_order_for(p->Wc, dual != 0, p->cells16) != nullptr && p->b_p4s.p != nullptr;
     if (kas_p4_with_order(p->shape, p->NW, p->flags | (p->shape.with_x ? 0u : KAS_FLAG_GENERIC_FILL), kas_plan_spread_chunks(p), p->n_scenarios,
                           relax_plain, dual, kas_plan_relax_idl(p))) {
       lp.p4_order = true;
@@ -959,11 +972,7 @@ static bool kas_plan_split_p4(const kas_plan* p) {
 }
 
 // dword mid rows in this plan's next solve (KAS_FLAG_MID32, kas_mid32_launch)
-static bool kas_plan_mid32(const kas_plan* p, const KasLaunchPlan& lp) {
-  return kas_mid32_launch(p->shape, p->cells16 != 0, p->mid32_bits, lp.relax, p->flags, kas_plan_relax_idl(p), kas_plan_index_rows(p),
-                          kas_plan_spread_chunks(p)) &&
-         kas_order_relax_m32_pick(p->Wc, 0) != nullptr;
-}
+static bool kas_plan_mid32(const kas_plan*, const KasLaunchPlan& lp) { return lp.m32; }
 
 int kas_plan_describe(const kas_plan* p, char* buf, int n) {
   if (!p || !buf || n <= 0) return set_error(KAS_E_INVALID_ARG, "NULL argument");
@@ -975,12 +984,12 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
                              : (p->shape.any_ctx && (lp.tickets || lp.wide || lp.relax)) ? " [Context in/out; kas_order_round_kernel for scenarios it flags]" : "";
   if (lp.relax && lp.p4_order)
     snprintf(order, sizeof(order), "kas_p4_order_kernel<%d>[first fit beside kas_order_relax_kernel<%d>[tiles of %d rows%s] in one workgroup] grid=%ux%u lds=%zu",
-             p->Wc, p->Wc, (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
+             p->Wc, p->Wc, 64 << lp.tiles,
              kas_plan_relax_idl(p) ? (kas_plan_mid32(p, lp) ? ", ids in LDS, dword mid rows" : ", ids in LDS") : "",
              lp.order_grid, lp.order_block, lp.order_lds);
   else if (lp.relax)
     snprintf(order, sizeof(order), "kas_order_relax_kernel<%d>[tiles of %d rows%s%s] grid=%ux%u lds=%zu%s", p->Wc,
-             (p->Wc == 3 && kas_relax_double_tiles(p->flags, p->n_scenarios)) ? 128 : 64,
+             64 << lp.tiles,
              kas_plan_relax_idl(p) ? (kas_plan_mid32(p, lp) ? ", ids in LDS, dword mid rows" : ", ids in LDS") : "",
              (p->flags >> 24) ? ", sampled verification" : "", lp.order_grid, lp.order_block, lp.order_lds, ctx_tail);
   else if (lp.relaxw)
@@ -1160,10 +1169,10 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   else
 #endif
   if (lp.relax && lp.p4_order)
-    hipLaunchKernelGGL(m32 ? kas_p4_order_m32_pick(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u) : kas_p4_order_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->cells16),
+    hipLaunchKernelGGL(m32 ? kas_p4_order_m32_pick(p->Wc, lp.tiles) : kas_p4_order_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->cells16),
                        dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (lp.relax && m32)
-    hipLaunchKernelGGL(kas_order_relax_m32_pick(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
+    hipLaunchKernelGGL(kas_order_relax_m32_pick(p->Wc, lp.tiles), dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
   else if (lp.relax)
     hipLaunchKernelGGL(kas_order_relax_for(p->Wc, (a.flags & KAS_FLAG_RELAX_DUAL) != 0u, p->shape.any_ctx, (a.flags >> 24) != 0u, p->cells16, kas_plan_relax_idl(p)),
                        dim3(lp.order_grid), dim3(lp.order_block), lp.order_lds, st, a);
@@ -1245,8 +1254,6 @@ int kas_plan_set_flags(kas_plan* p, uint32_t flags) {
     return set_error(KAS_E_UNSUPPORTED, "KAS_PLAN_VERIFY_SAMPLE: not instantiated for the instances that gather the broker ids from the node table (this many brokers)");
   if (p->cells16 && kas_flags_want_tickets(flags) && !p->shape.round_fits)
     return set_error(KAS_E_UNSUPPORTED, "16-bit cells: no ticket form; the round form it would take does not fit at this broker count");
-  if ((flags & KAS_FLAG_RELAX_TILES_64) && (flags & KAS_FLAG_RELAX_TILES_128))   // (every check before anything is changed)
-    return set_error(KAS_E_INVALID_ARG, "KAS_PLAN_RELAX_TILES: 0 (by batch size), 1 (64 rows) or 2 (double tiles)");
   if (!kas_minimal_ok(p->Wc, nw ? nw : p->NW, g ? g : p->G))
     return set_error(KAS_E_UNSUPPORTED, "tuning build (KAS_MINIMAL_INSTANCES): only 4 fill waves, 1 or 2 groups");
   const KasShape& sh = p->shape;

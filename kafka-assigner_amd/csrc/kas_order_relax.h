@@ -67,12 +67,13 @@ namespace kas {
 // first pick, bit 16 + c when it is the second.  (word >> cell) & KAS_RELAX_PICK_BITS is the cell's addend.
 KAS_DEV uint32_t relax_row_word(uint32_t w0, uint32_t w1) { return (KAS_RELAX_F0_ONE << w0) | (KAS_RELAX_F1_ONE << w1); }
 
+#define KAS_RELAX_MAXP 12             // pair instructions of the largest tile (quad tiles: 256 rows x 3 cells / 64 lanes)
 // A lane's pairs: pair v = 64 t + lane is cell v mod 3 of row v div 3 of the (double) tile; its staging word is
 // stage[v] — the pair lanes touch consecutive words, the row lanes words 3 i .. 3 i + 2: both free of bank conflicts.
 struct RelaxPairs {
   uint32_t* slot;                      // stage + lane: pair t's word is slot[64 t]
-  const uint32_t* row[6];              // the row word of the pair's row
-  uint32_t cell[6];                    // the pair's cell
+  const uint32_t* row[KAS_RELAX_MAXP];  // the row word of the pair's row
+  uint32_t cell[KAS_RELAX_MAXP];        // the pair's cell
 };
 
 // per-topic constants of the picks (wave-uniform: scalar registers)
@@ -130,7 +131,7 @@ KAS_DEV int32_t relax_eval_generic(const uint32_t (&x)[3], const bool (&valid)[3
 // pair's staging word.  Afterwards every row lane finds in stage[3 i + c] the counter word of its cell c as its row
 // would see it with the current outcomes of all earlier rows of the tile committed.
 template <int NP>
-KAS_DEV void relax_pairs(const RelaxPairs& pp, uint32_t* const (&padr)[6], uint32_t (&padd)[6], bool undo) {
+KAS_DEV void relax_pairs(const RelaxPairs& pp, uint32_t* const (&padr)[KAS_RELAX_MAXP], uint32_t (&padd)[KAS_RELAX_MAXP], bool undo) {
   kasw::lockstep();                                          // the row words are written
   uint32_t nadd[NP];
 #pragma unroll
@@ -367,9 +368,13 @@ KAS_DEV uint64_t relax_verify_rows(uint32_t* cnt, uint32_t w0_cells, uint32_t w1
 // M32 (round 6): the instances for launches with dword mid rows (KAS_FLAG_MID32; kas_solver_body.h, mid32_pack): a row comes as
 // ONE aligned dword — its holders in ascending order — instead of a dword and a halfword at 2-byte alignment, and because the
 // cells are sorted a row's six tags are the topic's constants: no comparison of the cells, no tag table read.
-template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool FS = false, bool M32 = false>
+// QUAD (round 6, with DUAL and M32): FOUR usual tiles in a row as one tile of 256 rows (four rows per lane, twelve pair
+// instructions) — the same fixed point once more: fewer, longer steps for a launch whose latency is one scenario's chain.
+template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, bool IDL = false, bool FS = false, bool M32 = false, bool QUAD = false>
 KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, uint64_t* fs = nullptr) {
   static_assert(W == 2 || W == 3, "counter words hold the counts of lists up to 3 wide");
+  static_assert(!QUAD || (DUAL && M32), "quad tiles: an instance of the double-tile kind on dword mid rows");
+  constexpr int NBT = QUAD ? 4 : (DUAL ? 2 : 1);             // tiles a step may take
   static_assert(!M32 || (W == 3 && !CTX && !VERIFY && !C16 && IDL), "dword mid rows: lists 3 wide, int32 cells with the ids in the LDS, no Context, no sampled verification");
   static_assert(!FS || (!CTX && !VERIFY), "first fit in the order kernel's workgroup: batches without a Context, no sampled verification");
   // (16-bit cells: with no broker ids to wait for the raised priority stops paying — 8 x 20 steps 815-834k scenarios/s at
@@ -382,7 +387,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
   uint32_t* cnt = (uint32_t*)lds_raw;                       // [nmax + 1]: + the padding node's word
   uint32_t* tagtab = (uint32_t*)(lds_raw + kas_align16(4 * (int64_t)(nmax + 1)));   // [8] by the order of a row's three cells: its six tags
   uint32_t* rbuf = tagtab + 8;                              // [64 | 128] row words of the (double) tile
-  uint32_t* stage = rbuf + (DUAL ? 128 : 64);               // [192 | 384] by pair of the (double) tile
+  uint32_t* stage = rbuf + 64 * NBT;                        // [192 | 384 | 768] by pair of the (double, quad) tile
   uint32_t* cnt2 = nullptr;                                 // (CTX) [nmax] what the rows add to count[n][2]
   uint32_t* idt = nullptr;                                  // (IDL, int32 cells) [nmax] the scenario's broker ids
   const int32_t* g_node_id = a.node_id + sd.node_off;
@@ -390,7 +395,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
   int32_t* g_ctx = nullptr;
   int32_t ccols = 0;
   if constexpr (CTX) {
-    cnt2 = stage + (DUAL ? 384 : 192);
+    cnt2 = stage + 192 * NBT;
     if (sd.ctx_off >= 0 && sd.ctx_width > 0 && a.ctx != nullptr) {           // (wave-uniform)
       g_ctx = a.ctx + sd.ctx_off;
       ccols = sd.ctx_width < W ? sd.ctx_width : W;
@@ -418,7 +423,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
   // LDS read (~100 cycles) where it waited for an L2 round trip (~700) on the kernel's one dependency chain
   constexpr bool LDSIDS = IDL && !C16;
   if constexpr (LDSIDS) {
-    idt = stage + (DUAL ? 384 : 192) + (CTX ? nmax : 0);
+    idt = stage + 192 * NBT + (CTX ? nmax : 0);
     for (int32_t n = lane; n < N; n += 64) idt[n] = (uint32_t)g_node_id[n];
   }
   if constexpr (CTX) {                                       // (wave-uniform from here on: scalar registers)
@@ -430,7 +435,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
   RelaxPairs pp;
   pp.slot = stage + lane;
 #pragma unroll
-  for (int t = 0; t < 6; ++t) {
+  for (int t = 0; t < (QUAD ? 12 : 6); ++t) {
     const int32_t v = 64 * t + lane, r = v / 3;
     pp.row[t] = rbuf + r;
     pp.cell[t] = (uint32_t)(v - 3 * r);
@@ -507,7 +512,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
       // broker ids of the step's predecessor, whose final rows then go out — and makes its new requests; nothing before
       // the same point of the next step looks at them.  The requests are loads the compiler does not see
       // (kasw::gload_*_async: its own wait insertion put a vmcnt(0) behind the requests of the same iteration).
-      constexpr int NB = DUAL ? 2 : 1;
+      constexpr int NB = NBT;
       const int32_t vstride = verify_k > 0 ? (nt / verify_k > 0 ? nt / verify_k : 1) : 0;   // every vstride-th tile is verified,
       const int32_t voff = vstride > 0 ? s % vstride : 0;                                    // starting at a tile of the scenario's own
       auto row_exists = [&](int32_t t) -> bool { return ((t << 6) + lane) < P; };
@@ -531,7 +536,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
-        for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
+        for (int q = 0; q < (M32 ? 1 : W); ++q) kasw::arrived(nx[b].w[q]);
         raw[b] = mid_take<W, FULLW, M32>(nx[b], ow, row_exists(b));
       }
 #pragma unroll
@@ -551,8 +556,8 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
         }
         // the usual tile: 64 rows, three holders each, rows of the batch's width
         bool fast = false;
-        uint32_t* padr[6];
-        uint32_t padd[6] = {0u, 0u, 0u, 0u, 0u, 0u};           // what my pairs added last
+        uint32_t* padr[KAS_RELAX_MAXP];
+        uint32_t padd[KAS_RELAX_MAXP] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // what my pairs added last
         int32_t step = 1;                                      // tiles this step takes (wave-uniform)
         int32_t req_n = 0;                                     // rows per lane whose final rows this step asks the ids for
         uint32_t req_l[NB][3];                                 // ... their lists as node indices
@@ -564,9 +569,66 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
           if (FULLW && ((tile + 1) << 6) <= P)
             fast = M32 ? kasw::ballot(c[2] >= NONE_FROM) == 0ull      // (sorted: a row holds three brokers iff its last cell does)
                        : kasw::ballot(((c[0] | c[1] | c[2]) & 0x8000u) != 0u) == 0ull;
+          // ---- four usual tiles in a row: one quad tile of 256 rows, lane i evaluates rows i, 64 + i, 128 + i, 192 + i (twelve
+          // pair instructions, row-major); anything else falls through to a single tile
+          if constexpr (QUAD) if (fast && ((tile + 4) << 6) <= P) {
+            MidRaw<W> rv[4];
+            uint32_t cc[4][3];
+            rv[0] = ra;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) cc[0][q] = c[q];
+            bool short_row = false;
+#pragma unroll
+            for (int b = 1; b < 4; ++b) {
+              rv[b] = mid_view<W, FULLW, M32>(raw[b], ow);
+              cc[b][0] = rv[b].w[0] & 0xffffu; cc[b][1] = rv[b].w[0] >> 16; cc[b][2] = rv[b].w[1] & 0xffffu;
+              short_row = short_row || cc[b][2] >= NONE_FROM;
+            }
+            if (kasw::ballot(short_row) == 0ull) {
+              n_tiles += 4;
+              kasw::lockstep();                                // (the previous tile's words have been read)
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) mine[192 * b + q] = cc[b][q];
+              kasw::lockstep();
+#pragma unroll
+              for (int t = 0; t < 12; ++t) padr[t] = cnt + pp.slot[64 * t];
+              uint32_t xq[4][3];
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) xq[b][q] = cnt[cc[b][q]];
+              kasw::lockstep();
+              int32_t pq[4] = {-1, -1, -1, -1};
+              for (int32_t it = 0;; ++it) {
+                n_evals += 4;
+                if (it > 258) { stuck = true; break; }         // (row i is right after evaluation i + 1: 257 suffice)
+                int32_t oq[4];
+                bool moved = false;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { oq[b] = relax_eval3(xq[b], gsorted); moved = moved || oq[b] != pq[b]; }
+                if (kasw::ballot(moved) == 0ull) break;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) rbuf[64 * b + lane] = relax_row_word((uint32_t)oq[b] & 3u, (uint32_t)oq[b] >> 2);
+                relax_pairs<12>(pp, padr, padd, it > 0);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                  for (int q = 0; q < 3; ++q) xq[b][q] = mine[192 * b + q];
+                  pq[b] = oq[b];
+                }
+              }
+              rows1 += 256u; rows2 += 256u;
+#pragma unroll
+              for (int b = 0; b < 4; ++b) relax_list3(rv[b], pq[b] < 0 ? 4 : pq[b], req_l[b], cnt2);
+              req_n = 4;
+              step = 4;
+            }
+          }
           // ---- two usual tiles in a row: one double tile of 128 rows, lane i evaluates rows i and 64 + i.  The same
           // fixed point (row-major pairs over six instructions), twice the work per LDS round trip.
-          if constexpr (DUAL) if (fast && ((tile + 2) << 6) <= P) {
+          if constexpr (DUAL && !QUAD) if (fast && ((tile + 2) << 6) <= P) {
             const MidRaw<W> rb = mid_view<W, FULLW, M32>(raw[NB - 1], ow);
             const uint32_t cb[3] = {rb.w[0] & 0xffffu, rb.w[0] >> 16, rb.w[1] & 0xffffu};
             if ((M32 ? kasw::ballot(cb[2] >= NONE_FROM) : kasw::ballot(((cb[0] | cb[1] | cb[2]) & 0x8000u) != 0u)) == 0ull) {
@@ -715,13 +777,20 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
 #pragma unroll
-          for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
+          for (int q = 0; q < (M32 ? 1 : W); ++q) kasw::arrived(nx[b].w[q]);
 #pragma unroll
           for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
         }
         // ... the next rows move up,
         if constexpr (NB == 1) {
           raw[0] = mid_take<W, FULLW, M32>(nx[0], ow, row_exists(tile));
+        } else if constexpr (NB == 4) {
+          if (step == 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) raw[b] = mid_take<W, FULLW, M32>(nx[b], ow, row_exists(tile + b));
+          } else {
+            raw[0] = raw[1]; raw[1] = raw[2]; raw[2] = raw[3]; raw[3] = mid_take<W, FULLW, M32>(nx[0], ow, row_exists(tile + 3));
+          }
         } else {
           if (step == 2) {
             raw[0] = mid_take<W, FULLW, M32>(nx[0], ow, row_exists(tile)); raw[1] = mid_take<W, FULLW, M32>(nx[1], ow, row_exists(tile + 1));
@@ -773,7 +842,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
-        for (int q = 0; q < W; ++q) kasw::arrived(nx[b].w[q]);
+        for (int q = 0; q < (M32 ? 1 : W); ++q) kasw::arrived(nx[b].w[q]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) kasw::arrived(pend.id[b][q]);
       }
@@ -782,7 +851,7 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
     };
     if constexpr (FS) {
       // the first tiles' rows must be final before they are asked for
-      const int32_t upto0 = (2 * (DUAL ? 2 : 1)) << 6;
+      const int32_t upto0 = (2 * NBT) << 6;
       if (!rows_final(k, upto0 < P ? upto0 : P)) { aborted = true; break; }
     }
     if (ow == W) topic_rows(std::true_type{});
@@ -843,15 +912,15 @@ KAS_DEV void order_relax(const KasLaunch& a, int32_t s, unsigned char* lds_raw, 
 // (KAS_FLAG_SPLIT_P4: loads after the sticky fill, the chunks' orphan lists), and fs[] (four 8-byte words of LDS between
 // the two carve-ups) is how the first follows the second.  LDS: kas_p4_order_lds.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false>
+template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false, bool QUAD = false>
 KAS_DEV void p4_order_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw) {
   const int32_t nmax = a.n_max > 0 ? a.n_max : 1;
-  const int32_t off_fs = kas_align16(kas_order_relax_lds(nmax, DUAL ? 1 : 0, 0, (IDL && !C16) ? 1 : 0));
+  const int32_t off_fs = kas_align16(kas_order_relax_lds(nmax, QUAD ? 2 : (DUAL ? 1 : 0), 0, (IDL && !C16) ? 1 : 0));
   uint64_t* fs = reinterpret_cast<uint64_t*>(lds_raw + off_fs);
   if (kasw::tid() < 4) fs[kasw::tid()] = kasw::tid() == 1 ? 0x7fffffffull : 0ull;   // rows final: none; failed topic: none; no answer; no watchdog
   kasw::sync();                                              // (the one workgroup barrier: both wavefronts pass it exactly once)
   if (kasw::wave_id() == 0) {
-    order_relax<W, DUAL, false, false, C16, IDL, true, M32>(a, s, lds_raw, fs);
+    order_relax<W, DUAL, false, false, C16, IDL, true, M32, QUAD>(a, s, lds_raw, fs);
   } else {
     if constexpr (KAS_P4_PRIO > 0) kasw::set_priority<KAS_P4_PRIO>();
     p4_scenario<W, 1, true, M32 ? 1 : 0>(a, s, lds_raw + off_fs + 32, fs);

@@ -334,7 +334,7 @@ KAS_ABI_FN int32_t kas_order_wide_lds(int32_t n_max) {
 #endif
 KAS_ABI_FN int32_t kas_order_relax_lds(int32_t n_max, int32_t double_tiles, int32_t with_ctx, int32_t with_ids = 0) {
   int64_t n = n_max > 0 ? n_max : 1;
-  const int64_t rows = double_tiles ? 128 : 64;
+  const int64_t rows = double_tiles >= 2 ? 256 : (double_tiles ? 128 : 64);   // (2: quad tiles, round 6)
   return kas_align16(kas_align16(4 * (n + 1)) + 8 * 4 + rows * 4 + 3 * rows * 4 + (with_ctx ? 4 * n : 0) + (with_ids ? 4 * n : 0));
 }
 // relaxation form for lists 4 and 5 wide (kas_order_relax_wide.h), one wavefront per scenario: a uint64 counter word per node + the
@@ -371,6 +371,18 @@ KAS_ABI_FN int32_t kas_relax_double_tiles(uint32_t flags, int32_t n_scenarios) {
   if (flags & KAS_FLAG_RELAX_TILES_128) return 1;
   if (flags & KAS_FLAG_RELAX_TILES_64) return 0;
   return n_scenarios < KAS_RELAX_DUAL_BELOW ? 1 : 0;
+}
+// Relaxation form: quad tiles (256 rows, four rows per lane; round 6) in a launch that takes double tiles on dword mid rows?
+// Asked for by KAS_PLAN_RELAX_TILES(3) (both tile bits), or — KAS_RELAX_QUAD_BELOW — by batch size where neither bit is named.
+// Where the instances do not apply (no dword mid rows, their LDS) such a launch keeps double tiles.
+#ifndef KAS_RELAX_QUAD_BELOW
+#define KAS_RELAX_QUAD_BELOW 0
+#endif
+KAS_ABI_FN int32_t kas_relax_quad_tiles(uint32_t flags, int32_t n_scenarios) {
+  const uint32_t both = KAS_FLAG_RELAX_TILES_64 | KAS_FLAG_RELAX_TILES_128;
+  if ((flags & both) == both) return 1;
+  if (flags & both) return 0;
+  return n_scenarios < KAS_RELAX_QUAD_BELOW ? 1 : 0;
 }
 // does a flag word (KAS_PLAN_* / KAS_FLAG_*) ask for the ticket form where the relaxation form is applicable?
 KAS_ABI_FN int32_t kas_flags_want_tickets(uint32_t flags) {

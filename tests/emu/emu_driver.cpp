@@ -228,14 +228,14 @@ template <int W, bool DUAL, bool CTX, bool VERIFY = false, bool C16 = false, boo
   RunArgs* r = (RunArgs*)p;
   if constexpr (W <= 3) kas::order_relax<W, DUAL, CTX, VERIFY, C16, IDL>(*r->a, r->s, r->lds);
 }
-template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false> void run_p4_order(void* p) {
+template <int W, bool DUAL, bool C16, bool IDL, bool M32 = false, bool QUAD = false> void run_p4_order(void* p) {
   RunArgs* r = (RunArgs*)p;
-  if constexpr (W <= 3) kas::p4_order_scenario<W, DUAL, C16, IDL, M32>(*r->a, r->s, r->lds);
+  if constexpr (W <= 3) kas::p4_order_scenario<W, DUAL, C16, IDL, M32, QUAD>(*r->a, r->s, r->lds);
 }
 // the instances for dword mid rows (KAS_FLAG_MID32; kas_order_relax_m32_pick in kas_hip.hip)
-template <bool DUAL> void run_order_relax_m32(void* p) {
+template <bool DUAL, bool QUAD = false> void run_order_relax_m32(void* p) {
   RunArgs* r = (RunArgs*)p;
-  kas::order_relax<3, DUAL, false, false, false, true, false, true>(*r->a, r->s, r->lds);
+  kas::order_relax<3, DUAL, false, false, false, true, false, true, QUAD>(*r->a, r->s, r->lds);
 }
 typedef void (*relax_fn)(void*);
 template <bool VERIFY, bool C16, bool IDL> relax_fn relax_pick(int Wc, bool dual, bool ctx) {   // as kas_order_relax_pick (kas_hip.hip)
@@ -291,6 +291,7 @@ static long g_last_queue_rows = 0;
 static int g_last_p4_order = 0;       // the last solve ran first fit inside the order kernel's workgroup (kas_p4_order_kernel)
 static int g_last_relax_idl = 0;      // the last relaxation-form launch read its broker ids from the LDS
 static long g_last_slim_fill = 0;    // scenarios the slim fill kernel solved itself (not handed back) in the last kas_emu_solve_batch
+static long g_last_relax_quad = 0;   // the last kas_emu_solve_batch ran the relaxation form over quad tiles
 static long g_last_mid32 = 0;        // the last kas_emu_solve_batch moved its mid rows as one dword each (KAS_FLAG_MID32)
 static long g_last_index_rows = 0;   // topics whose fill took the index rows (fill_pass_a_fused<EMIT>) in the last kas_emu_solve_batch
 static int g_last_fused = 0;   // the last kas_emu_solve_batch ran the fill with per-chunk histograms
@@ -447,8 +448,12 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   const bool m32 = kas_mid32_launch(sh, c16, flags, relax, a.flags, relax_idl ? 1 : 0, index_rows, CH);
   if (m32) a.flags |= KAS_FLAG_MID32;
   g_last_mid32 = m32 ? 1 : 0;
+  // quad tiles (same decision as kas_launch_plan in kas_hip.hip): double tiles + dword mid rows + asked for
+  const bool relax_quad = relax_dual && m32 && kas_relax_quad_tiles(flags, b->n_scenarios) && kas_order_relax_lds(sh.n_max, 2, 0, 1) <= KAS_LDS_LIMIT;
+  const int relax_tiles = relax_quad ? 2 : (relax_dual ? 1 : 0);
+  g_last_relax_quad = relax && relax_quad ? 1 : 0;
   const bool p4_order = relax && kas_p4_with_order(sh, sh.NW, a.flags, CH, b->n_scenarios,
-                                                   !sh.any_ctx && (a.flags >> 24) == 0u && (c16 || relax_idl), relax_dual, relax_idl);
+                                                   !sh.any_ctx && (a.flags >> 24) == 0u && (c16 || relax_idl), relax_tiles, relax_idl);
   g_last_p4_order = p4_order ? 1 : 0;
   const bool split_p4 = p4_order || kas_split_p4(sh, sh.NW, a.flags, CH, b->n_scenarios);   // (the fill kernel hands first fit over)
   if (split_p4) {
@@ -505,11 +510,11 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   }
   // order kernel: one wavefront per scenario (relaxation form, round form), three per G scenarios (ticket form)
   if (relax && p4_order) {
-    run_fn f = m32 ? (relax_dual ? run_p4_order<3, true, false, true, true> : run_p4_order<3, false, false, true, true>)
+    run_fn f = m32 ? (relax_quad ? run_p4_order<3, true, false, true, true, true> : relax_dual ? run_p4_order<3, true, false, true, true> : run_p4_order<3, false, false, true, true>)
                : sh.Wc <= 2 ? (c16 ? run_p4_order<2, false, true, false> : run_p4_order<2, false, false, true>)
                : c16 ? (relax_dual ? run_p4_order<3, true, true, false> : run_p4_order<3, false, true, false>)
                      : (relax_dual ? run_p4_order<3, true, false, true> : run_p4_order<3, false, false, true>);
-    const size_t fb_bytes = (size_t)kas_p4_order_lds(sh.n_max, relax_dual, relax_idl);   // exactly the product's LDS, and a guard behind it
+    const size_t fb_bytes = (size_t)kas_p4_order_lds(sh.n_max, relax_tiles, relax_idl);   // exactly the product's LDS, and a guard behind it
     std::vector<unsigned char> rl(fb_bytes + 4096);
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(rl.data(), 0xCD, fb_bytes);
@@ -532,14 +537,14 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
       if (errbuf && errlen > 0) snprintf(errbuf, (size_t)errlen, "KAS_PLAN_VERIFY_SAMPLE: not instantiated for the gather instances");
       return KAS_E_UNSUPPORTED;
     }
-    run_fn f = m32 ? (rdual ? run_order_relax_m32<true> : run_order_relax_m32<false>)
+    run_fn f = m32 ? (relax_quad ? run_order_relax_m32<true, true> : rdual ? run_order_relax_m32<true> : run_order_relax_m32<false>)
                : c16 ? (verify ? relax_pick<true, true, false>(sh.Wc, rdual, sh.any_ctx) : relax_pick<false, true, false>(sh.Wc, rdual, sh.any_ctx))
                : idl ? (verify ? relax_pick<true, false, true>(sh.Wc, rdual, sh.any_ctx) : relax_pick<false, false, true>(sh.Wc, rdual, sh.any_ctx))
                      : relax_pick<false, false, false>(sh.Wc, rdual, sh.any_ctx);
     g_last_relax_idl = idl ? 1 : 0;
     // exactly the LDS the product launches the kernel with, and a guard behind it: the hardware drops what a
     // workgroup writes beyond its allocation and reads zeros there — here that must not pass unnoticed
-    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, rdual, sh.any_ctx, idl);
+    const size_t relax_bytes = (size_t)kas_order_relax_lds(sh.n_max, relax_quad ? 2 : (rdual ? 1 : 0), sh.any_ctx, idl);
     std::vector<unsigned char> rl(relax_bytes + 4096);
     for (int32_t s = 0; s < b->n_scenarios; ++s) {
       memset(rl.data(), 0xCD, relax_bytes);
@@ -701,6 +706,8 @@ extern "C" __attribute__((visibility("default")))
 long kas_emu_last_index_rows(void) { return g_last_index_rows; }
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_mid32(void) { return g_last_mid32; }
+extern "C" __attribute__((visibility("default")))
+long kas_emu_last_relax_quad(void) { return g_last_relax_quad; }
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_slim_fill(void) { return g_last_slim_fill; }
 

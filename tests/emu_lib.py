@@ -249,6 +249,13 @@ def last_mid32() -> int:
     return int(L.kas_emu_last_mid32())
 
 
+def last_relax_quad() -> int:
+    """1 when the last emu_solve ran the relaxation form over quad tiles (KAS_PLAN_RELAX_TILES(3) on dword mid rows)."""
+    L = lib()
+    L.kas_emu_last_relax_quad.restype = C.c_long
+    return int(L.kas_emu_last_relax_quad())
+
+
 def last_slim_fill() -> int:
     """Scenarios the slim fill kernel (kas_fill_slim_kernel) solved itself in the last emu_solve: 0 when it was not launched,
     fewer than the batch's scenarios when it handed some back to kas_fill_kernel."""
@@ -276,6 +283,7 @@ def last_relax_idl() -> int:
 
 FULL_FILL = 16             # KAS_PLAN_FULL_FILL: kas_fill_kernel for every scenario (no kas_fill_slim_kernel in front)
 NO_INDEX_ROWS = 64         # KAS_PLAN_NO_INDEX_ROWS: the fill reads `cur` in both of its row scans
+RELAX_TILES_256 = 0x20000 | 0x40000   # KAS_PLAN_RELAX_TILES(3): quad tiles (256 rows a step) where the instances apply (dword mid rows), else double tiles
 MID32 = 0x80000            # KAS_PLAN_MID32: dword mid rows (holders sorted, 11 bits each) where they apply
 NO_MID32 = 0x100000        # KAS_PLAN_NO_MID32: the packed 16-bit mid rows
 INDEX_ROWS = 128           # KAS_PLAN_INDEX_ROWS: the fill's first scan leaves node indices where the mid rows go, the second streams those

@@ -935,9 +935,9 @@ def test_emu_dword_mid_rows_where_they_apply_and_where_they_do_not():
 def dword_mid_row_cases():
     """(what, batch, plan flag words) — batches in which the dword mid rows meet everything that touches a mid row; shared with the
     GPU test (tests/test_hip_parity.py)."""
-    from emu_lib import FULL_FILL, NO_MID32, P4_WITH_ORDER, SPLIT_P4
+    from emu_lib import FULL_FILL, NO_MID32, P4_WITH_ORDER, RELAX_TILES_256, SPLIT_P4
     yield ("bench mix", _batch(4321, 5, 1777, 45, 9, 3, G.BENCH_ACTIONS),
-           (0, NO_MID32, P4_WITH_ORDER, P4_WITH_ORDER | RELAX_TILES_128, SPLIT_P4 | RELAX_TILES_64, FILL_WITH_P4, FILL_WITH_P4 | RELAX_TILES_128, FULL_FILL,
+           (0, NO_MID32, P4_WITH_ORDER, RELAX_TILES_256, P4_WITH_ORDER | RELAX_TILES_256, FILL_WITH_P4 | RELAX_TILES_256, NO_MID32 | RELAX_TILES_256, P4_WITH_ORDER | RELAX_TILES_128, SPLIT_P4 | RELAX_TILES_64, FILL_WITH_P4, FILL_WITH_P4 | RELAX_TILES_128, FULL_FILL,
             FULL_FILL | SPLIT_P4, NO_RTN_QUOTA, 8, 1, 2 << 8, 1 << 8))
     racks = (np.arange(60) % 6).astype(np.int32)
     ids = np.arange(60, dtype=np.int32)
@@ -961,8 +961,8 @@ def dword_mid_row_cases():
            for _ in range(2)]
     scs[1].brokers = [b for b in range(30) if b not in (3, 17)]
     scs[1].racks = {b: "r%d" % (b % 6) for b in scs[1].brokers}
-    yield ("topics of several widths", flatten(scs), (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4 | RELAX_TILES_64, NO_MID32))
-    yield ("failing scenarios (replace one broker at zero slack)", _batch(99, 6, 8000, 80, 8, 3, ("replace1",)), (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4))
+    yield ("topics of several widths", flatten(scs), (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4 | RELAX_TILES_64, NO_MID32, P4_WITH_ORDER | RELAX_TILES_256))
+    yield ("failing scenarios (replace one broker at zero slack)", _batch(99, 6, 8000, 80, 8, 3, ("replace1",)), (0, P4_WITH_ORDER, FILL_WITH_P4, SPLIT_P4, P4_WITH_ORDER | RELAX_TILES_256, RELAX_TILES_256))
     for N, R, P in ((1023, 11, 4000), (1025, 25, 4000), (2047, 23, 5000), (2048, 32, 5000)):
         cur = G.random_assignment(N, P, N, R, 3)
         ids = np.arange(N + 40, dtype=np.int32)
@@ -971,7 +971,7 @@ def dword_mid_row_cases():
         bs = ids[keep]
         if N == 2047:
             bs = bs[:2047]
-        yield (f"{bs.shape[0]} brokers", uniform_batch(cur.astype(np.int32)[None], bs[None, :], (bs % R).astype(np.int32)[None, :], 3), (0, P4_WITH_ORDER, NO_MID32))
+        yield (f"{bs.shape[0]} brokers", uniform_batch(cur.astype(np.int32)[None], bs[None, :], (bs % R).astype(np.int32)[None, :], 3), (0, P4_WITH_ORDER, NO_MID32, P4_WITH_ORDER | RELAX_TILES_256))
 
 
 def test_emu_dword_mid_rows_at_the_field_limits():
@@ -997,10 +997,13 @@ def test_emu_dword_mid_rows_at_the_field_limits():
 
 
 def test_emu_dword_mid_row_cases_shared_with_the_gpu_test():
-    from emu_lib import NO_MID32, last_mid32
+    """... among the plan flag words: KAS_PLAN_RELAX_TILES(3), quad tiles (256 rows a step) — the instances exist on dword mid rows;
+    anywhere else the launch keeps double tiles"""
+    from emu_lib import NO_MID32, RELAX_TILES_256, last_mid32, last_relax_quad
     for what, fb, flag_words in dword_mid_row_cases():
         want = oracle_solve(fb)
         fits = int(fb.scen["n_nodes"].max()) <= 2047
         for flags in flag_words:
             assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu dword mid rows: {what}, plan flags {flags:#x}")
             assert last_mid32() == (1 if fits and not (flags & NO_MID32) else 0), (what, hex(flags))
+            assert last_relax_quad() == (1 if (flags & RELAX_TILES_256) == RELAX_TILES_256 and last_mid32() else 0), (what, hex(flags))

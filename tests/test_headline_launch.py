@@ -86,14 +86,17 @@ def test_headline_launch_1000_x_100k_x_1k_x_20_racks_both_cell_layouts():
                                 (abi.KAS_PLAN_FULL_FILL, "kas_fill_kernel for every scenario", FULL_FILL_KERNELS % ("", m32)),
                                 (abi.KAS_PLAN_INDEX_ROWS, "index rows: cur read once", FULL_FILL_KERNELS % (", index rows", "")),
                                 (abi.KAS_PLAN_P4_WITH_ORDER, "first fit as a wavefront of the order kernel's workgroup", None),
-                                (abi.KAS_PLAN_P4_WITH_ORDER | abi.KAS_PLAN_NO_MID32, "first fit in the order kernel's workgroup, 16-bit mid rows", None)):
+                                (abi.KAS_PLAN_P4_WITH_ORDER | abi.KAS_PLAN_NO_MID32, "first fit in the order kernel's workgroup, 16-bit mid rows", None),
+                                (abi.KAS_PLAN_P4_WITH_ORDER | abi.KAS_PLAN_RELAX_TILES_64 | abi.KAS_PLAN_RELAX_TILES_128, "first fit in the order kernel's workgroup, quad tiles", None)):
         plan = native.Plan(ctx, fb)
         if flags:
             plan.set_flags(flags)
         desc = plan.describe()
         if expect is None:
             mm = "" if (flags & abi.KAS_PLAN_NO_MID32) else m32
-            assert f"kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of 64 rows, ids in LDS{mm}] in one workgroup] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
+            quad = (flags & abi.KAS_PLAN_RELAX_TILES_64) and (flags & abi.KAS_PLAN_RELAX_TILES_128) and mm
+            rows = 256 if quad else 64          # (KAS_PLAN_RELAX_TILES(3): quad tiles on dword mid rows)
+            assert f"kas_p4_order_kernel<3>[first fit beside kas_order_relax_kernel<3>[tiles of {rows} rows, ids in LDS{mm}] in one workgroup] grid=1000x128" in desc and "kas_p4_kernel" not in desc, desc
             assert desc.startswith("kas_fill_slim_kernel<3>["), desc
         else:
             assert desc == expect, desc
