@@ -35,7 +35,7 @@ echo "# global_store_dword (the dword mid row: v_med3_u32 / v_min3_u32 in front 
 python $ROOT/tools/isa_stats.py $W/slim.s kas_fill_slim | head -1
 python $ROOT/tools/isa_loops.py $W/slim.s kas_fill_slim 2
 } > $ROOT/profiles/r06_isa_census_fill_slim_kernel_3.txt
-K=_Z22kas_order_relax_kernelILi3ELb0ELb0ELb0ELb0ELb1ELb1EEv9KasLaunch
+K=_Z22kas_order_relax_kernelILi3ELb0ELb0ELb0ELb0ELb1ELb1ELb0EEv9KasLaunch
 {
 echo "# ISA census of kas_order_relax_kernel<3, DUAL=false, CTX=false, VERIFY=false, C16=false, IDL=true, M32=true> - the headline's order kernel (int32 cells, ids in the LDS, tiles of 64 rows, dword mid rows);"
 echo "# gfx950, hipcc -O3; kernel sources sha16 $SHA.  tools/isa_stats.py --blocks, then tools/isa_loops.py (depth >= 2: topic loop > tile loop > evaluation loop)."
