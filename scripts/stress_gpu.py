@@ -95,7 +95,7 @@ def thin_wide_batch(rng):
                      out_len=S * P * W), f"thin W{W} rf{rf} N{N} P{P} S{S}"
 
 
-t0 = time.time(); n = 0; q_rows = 0; n_thin = 0; n_big = 0; n_ctx = 0
+t0 = time.time(); n = 0; q_rows = 0; n_thin = 0; n_big = 0; n_ctx = 0; n_mid = 0
 while time.time() - t0 < float(argv[1]):
     kind = rng.random()
     if kind < 0.12:                                              # the checked wide form and its second solve
@@ -116,6 +116,16 @@ while time.time() - t0 < float(argv[1]):
             assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} big-N flags {flags}")
         check16(fb, f"seed {seed} S{S} P{P} N{N} big-N", (0, 0x20000))
         n += 1; n_big += 1
+        continue
+    if kind < 0.24:                                              # lists 3 wide, 900 .. 2,060 brokers: node indices on either side of 1,024 and up to
+        N = int(rng.choice([900, 1020, 1030, 1500, 2040, 2047, 2060])); P = int(rng.choice([6000, 20000]))   # the dword mid rows' 2,046 (beyond: 16-bit rows)
+        seed = int(rng.integers(1 << 30)); S = int(rng.choice([1, 2, 4]))
+        fb = _batch(seed, S, P, N, int(rng.choice([10, 25, 40])), 3, ("add_k", "mixed", "remove_k", "remove1"))
+        want = oracle_solve(fb)
+        for flags in (0, 0xC00000, 0x100000, 0xC00000 | 0x60000, 0x800000 | 0x40000):
+            got = solve(fb, flags)
+            assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} mid-N flags {flags}")
+        n += 1; n_mid += 1
         continue
     N = int(rng.choice([8, 12, 20, 33, 64, 100, 150, 300, 500]))
     R = int(rng.choice([2, 3, 5, 8, 10, 20])); R = min(R, N)
@@ -142,11 +152,11 @@ while time.time() - t0 < float(argv[1]):
     # size), 0x400000 / 0x800000 = first fit in kas_p4_kernel / inside the fill workgroup, 16 = KAS_PLAN_FULL_FILL (no slim fill kernel in front); lists 4-5 wide: 0x20000 = the relaxation
     # form for wide lists)
     for flags in ((0, 1 << 12, 4, 32, 0x20000, 0x40000, 0x200000, 0x80, 0x40 | 0x400000, 0xC00000 | 0x20000, 0xC00000 | 0x40000 | 0x80, 0x800000, 0x400000, 0x400000 | 16,
-                   0x100000, 0x100000 | 0xC00000, 0x100000 | 0x400000 | 0x20000)   # (0x100000 = KAS_PLAN_NO_MID32: the packed 16-bit mid rows where the default takes a dword a row)
+                   0x100000, 0x100000 | 0xC00000, 0x100000 | 0x400000 | 0x20000, 0x60000, 0xC00000 | 0x60000)   # (0x100000 = KAS_PLAN_NO_MID32: the packed 16-bit mid rows where the default takes a dword a row)
                   if RF <= 3 else ((0, 2, 1, 32, 0x20000, 0x20000 | 0x800000) if RF <= 5 else (0, 2, 1, 32))):
         got = solve(fb, flags)
         assert_same_outputs(fb, want, got, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts} flags {flags}")
     if RF <= 3:
         check16(fb, f"seed {seed} S{S} P{P} N{N} R{R} RF{RF} {acts}", (0, 0x20000, 0x40000, 2, 1, 0x200000, 0x400000, 0x800000, 0xC00000, 0xC00000 | 0x20000, 0x20000 | (255 << 24)))
     n += 1
-print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 1-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-12,000 brokers,", n_ctx, "with a Context in and out,", n16, "also on 16-bit cells (kas_solve_device16); seed", int(argv[2]) if len(argv) > 2 else 2026)
+print("emulator stress ok:" if EMU else "stress ok:", n, "random batches x 1-4 plan variants;", n_thin, "of them thin wide rows (checked wide form),", n_big, "with 3,000-12,000 brokers,", n_mid, "with 900-2,060 brokers (dword mid rows up to 2,047),", n_ctx, "with a Context in and out,", n16, "also on 16-bit cells (kas_solve_device16); seed", int(argv[2]) if len(argv) > 2 else 2026)
