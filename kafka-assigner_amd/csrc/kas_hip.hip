@@ -38,11 +38,48 @@
 #ifndef KAS_FILL_MIN_WAVES
 #define KAS_FILL_MIN_WAVES 4
 #endif
+// The r-th scenario (ascending) whose flag is set, or -1 past the last one; *total: their number when the answer is -1.  Every
+// wavefront of the workgroup scans the flags for itself (64 per step, a ballot and a population count: wave-uniform by
+// construction, nothing shared) and gets the same answer.
+__device__ inline int32_t kas_kth_flagged(const int32_t* flag, int32_t n, int32_t r, int32_t* total) {
+  const int32_t lane = (int32_t)(threadIdx.x & 63u);
+  int32_t seen = 0;
+  for (int32_t base = 0; base < n; base += 64) {
+    const int32_t s = base + lane;
+    unsigned long long w = kasw::ballot(s < n && flag[s] != 0);
+    const int32_t c = (int32_t)__popcll(w);
+    if (r < seen + c) {
+      for (int32_t i = seen; i < r; ++i) w &= w - 1ull;
+      return base + (int32_t)__builtin_ctzll(w);
+    }
+    seen += c;
+  }
+  *total = seen;
+  return -1;
+}
+
+// A launch for flagged scenarios only (KAS_FLAG_ONLY_FLAGGED: behind the slim kernel, behind the spread fill, the wide form's second
+// solve) deals them to its workgroups round-robin BY RANK among the flagged ones — workgroup b takes the b-th, (b + grid)-th, ... —
+// so that a tenth of 1000 scenarios handed back is a hundred workgroups with one scenario each, not 256 of which some hold three
+// (round 6: 25.9 -> 15 ms for such a batch, scripts/handback_probe.py), and workgroup 0 leaves their number where the plan sizes its
+// next such launch (KasLaunch::handback).
 template <int W, int NW>
 __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  for (int32_t s = (int32_t)blockIdx.x; s < a.n_scenarios; s += (int32_t)gridDim.x)
+  const bool by_rank = (a.flags & KAS_FLAG_ONLY_FLAGGED) != 0u && a.sp_flag != nullptr;
+  for (int32_t i = (int32_t)blockIdx.x;; i += (int32_t)gridDim.x) {
+    int32_t s = i, total = 0;
+    if (by_rank) {
+      s = kas_kth_flagged(a.sp_flag, a.n_scenarios, i, &total);
+      if (s < 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.handback != nullptr) *a.handback = total;
+        break;
+      }
+    } else if (s >= a.n_scenarios) {
+      break;
+    }
     kas::fill_scenario<W, NW>(a, s, kas_lds);
+  }
 }
 
 // The slim fill (round 6): fill_scenario<W, 4, SLIM> — only the path every BASELINE config at RF <= 3 takes (kas_solver_body.h,
@@ -67,6 +104,7 @@ __global__ __launch_bounds__(256, KAS_SLIM_MIN_WAVES) void kas_fill_slim_kernel(
 }
 static void (*kas_fill_slim_m32())(KasLaunch) { return kas_fill_slim_kernel<3, true>; }
 #define KAS_FILL_BACK_GRID 256u
+#define KAS_FILL_BACK_GRID_STEP 64u
 
 // min waves per SIMD of the ticket-form order kernel (0 = whatever the allocation comes to: 92 VGPRs, 5)
 #ifndef KAS_ORDER_MIN_WAVES
@@ -457,6 +495,8 @@ struct kas_plan {
   int single_topic;             // every scenario has exactly one topic
   int cells16;                  // kas_plan_create16: cur / out cells are uint16 node indices (KAS_FLAG_CELLS16 in every launch)
   int32_t sp_alloc_chunks;      // chunks per scenario the spread-fill scratch is sized for
+  int32_t* h_handback = nullptr; // pinned host word the device writes: scenarios the slim fill kernel handed back in the last solve that has got that far
+  int32_t* d_handback = nullptr; // ... its device address
   hipStream_t last_stream;
   int last_slot;                // timer slot of the most recent solve (-1: none yet)
   // kernel timing: event pairs recorded around every launch on the launch stream
@@ -625,6 +665,7 @@ void kas_plan_destroy(kas_plan* p) {
     if (p->ev_stop[i]) (void)hipEventDestroy(p->ev_stop[i]);
     if (p->ev_mid[i]) (void)hipEventDestroy(p->ev_mid[i]);
   }
+  if (p->h_handback) (void)hipHostFree(p->h_handback);
   delete p;
 }
 
@@ -722,6 +763,18 @@ static bool kas_plan_slim_fill(const kas_plan* p, bool split_p4, int32_t chunks)
          p->b_sp_flag.p != nullptr;
 }
 
+// workgroups of the kas_fill_kernel launch behind the slim kernel: KAS_FILL_BACK_GRID — each needs a 35 KB / 4 x 128-VGPR slot before it
+// can see that there is nothing to do — unless the plan's last solve handed more scenarios back than that: then one workgroup per
+// such scenario and a quarter more (a batch whose rows are not rack-diverse hands EVERY scenario back, and the general fill of a
+// scenario is one long chain: 1000 of them on 256 workgroups took 53 ms, on 1000 they take 20).  A rebuilt plan starts small again.
+static unsigned kas_plan_back_grid(const kas_plan* p, unsigned fill_grid) {
+  unsigned g = KAS_FILL_BACK_GRID;
+  const int32_t last = p->h_handback ? *(volatile int32_t*)p->h_handback : 0;
+  if (last > 0 && (unsigned)last + (unsigned)last / 4u > g)
+    g = (((unsigned)last + (unsigned)last / 4u + KAS_FILL_BACK_GRID_STEP - 1u) / KAS_FILL_BACK_GRID_STEP) * KAS_FILL_BACK_GRID_STEP;
+  return g < fill_grid ? g : fill_grid;
+}
+
 // chunks per scenario of the spread fill for this plan's next solve, or 0 (one-workgroup fill kernel)
 static int32_t kas_plan_spread_chunks(const kas_plan* p) {
   if (p->cells16) return 0;                                  // (the spread fill's kernels read int32 cells)
@@ -769,6 +822,7 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   p->tickets = sh.tickets_ok; p->fused = sh.fused_ok;
   p->lds = sh.lds; p->lds_fused = sh.lds_fused;
   p->flags = 0; p->index_rows_bits = 0; p->full_fill = 0; p->mid32_bits = 0;
+  if (p->h_handback) *p->h_handback = 0;                     // (another batch: the launch behind the slim kernel starts small again)
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
   p->sp_alloc_chunks = 0;
@@ -846,6 +900,15 @@ static int kas_plan_new(kas_ctx* ctx, const kas_batch_desc* batch, uint64_t* all
       kas_plan_destroy(p);
       return set_error(KAS_E_HIP, "hipEventCreate failed");
     }
+  }
+  // (the hand-back count comes back through a word of pinned host memory: no copy, no synchronisation; without it the launch
+  // behind the slim kernel keeps its small grid)
+  if (hipHostMalloc((void**)&p->h_handback, sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+    *p->h_handback = 0;
+    if (hipHostGetDevicePointer((void**)&p->d_handback, p->h_handback, 0) != hipSuccess) p->d_handback = nullptr;
+  } else {
+    (void)hipGetLastError();
+    p->h_handback = nullptr;
   }
   // (a short run of the LDS lane-order self-test again: the property is checked where and when the form is about to be used)
   if (ctx->lds_lane_order_ok) {
@@ -1023,7 +1086,7 @@ int kas_plan_describe(const kas_plan* p, char* buf, int n) {
     snprintf(p4, sizeof(p4), " + kas_p4_kernel<%d> grid=%ux%u lds=%zu", p->Wc, (unsigned)p->n_scenarios, 64u * KAS_P4_KERNEL_WAVES,
              (size_t)kas_p4_lds_layout(p->shape.n_max).total);
   if (kas_plan_slim_fill(p, kas_plan_split_p4(p) || lp.p4_order, chunks)) {
-    const unsigned back = lp.fill_grid < KAS_FILL_BACK_GRID ? lp.fill_grid : KAS_FILL_BACK_GRID;
+    const unsigned back = kas_plan_back_grid(p, lp.fill_grid);
     const int len = snprintf(buf, (size_t)n, "kas_fill_slim_kernel<%d>[quota, chunk histograms] grid=%ux%u lds=%zu (+ kas_fill_kernel<%d,%d>[quota, chunk histograms] "
                              "grid=%ux%u lds=%zu for scenarios it hands back)%s + %s", p->Wc, lp.fill_grid, lp.fill_block,
                              (size_t)kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total, p->Wc, p->NW, back,
@@ -1097,6 +1160,7 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
   a.flags = split_p4 ? (a.flags | KAS_FLAG_SPLIT_P4) : (a.flags & ~KAS_FLAG_SPLIT_P4);   // (the kernels' bit: this launch's form)
   const int slot = p->timer_next;
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
+  a.handback = nullptr;
   const int32_t chunks = kas_plan_spread_chunks(p);
   if (chunks != p->sp_alloc_chunks)
     return set_error(KAS_E_INVALID_ARG, "internal: spread-fill scratch not sized for this plan state");
@@ -1132,7 +1196,8 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
                        (size_t)kas_fill_slim_lds(p->shape.n_max, p->Wc, p->shape.idmap_entries).total + KAS_TUNE_SLIM_LDS_PAD, st, a);
     KAS_HIP_TRY(hipGetLastError());
     a.flags |= KAS_FLAG_ONLY_FLAGGED;
-    if (fill_grid > KAS_FILL_BACK_GRID) fill_grid = KAS_FILL_BACK_GRID;
+    fill_grid = kas_plan_back_grid(p, fill_grid);
+    a.handback = p->d_handback;
   }
 #if defined(KAS_TUNE_ORDER_ONLY)
   if (p->last_slot < 0)
@@ -1190,6 +1255,7 @@ static int kas_solve_device_impl(kas_plan* p, const kas_tables* t, void* hip_str
     KasLaunch af = a;
     af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~(KAS_FLAG_WIDE_CHECK | KAS_FLAG_SPLIT_P4);   // (this fill does its own first fit)
     af.sp_flag = a.ord_flag;                                 // (same meaning: != 0, this kernel takes the scenario)
+    af.handback = nullptr;
     hipLaunchKernelGGL(kas_fill_for(p->Wc, p->NW), dim3(lp.fill_grid), dim3(lp.fill_block), lp.fill_lds, st, af);
     KAS_HIP_TRY(hipGetLastError());
   }

@@ -53,6 +53,8 @@ struct KasLaunch {
   int32_t idmap_entries;        // entries of the direct broker-id -> node-index table
   int32_t need_bsearch;         // some scenario's id range exceeds idmap_entries
   uint32_t flags;               // KAS_FLAG_*
+  int32_t* handback;            // (may be null) where a fill kernel launched for flagged scenarios only leaves their number: host memory the
+                                // device can write (the plan sizes its next such launch by it, kas_hip.hip: kas_plan_back_grid)
 };
 
 #define KAS_FLAG_GENERIC_FILL 1u   // always use the general sticky fill (testing / comparison)

@@ -392,6 +392,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   };
   // spread fill (same decision as kas_solve_device): passes A and B over one-wavefront workgroups
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
+  a.handback = nullptr;                                  // (the launcher's: kas_fill_kernel's own loop over flagged scenarios is not emulated)
   g_last_spread = 0;
   const int32_t CH = (!c16 && sh.NW == 4 && sh.Wc >= 3 && sh.Wc <= 5 && !(flags & KAS_FLAG_GENERIC_FILL))
                          ? kas_spread_chunks(sh, b->n_scenarios, kas_batch_single_topic(b), (flags & KAS_FLAG_SPREAD_FILL) != 0) : 0;

@@ -704,6 +704,48 @@ def test_slim_fill_kernel_and_the_scenarios_it_hands_back():
 
 
 @pytest.mark.gpu
+def test_launch_behind_the_slim_kernel_grows_with_what_was_handed_back():
+    """The kas_fill_kernel launch behind the slim kernel deals the flagged scenarios to its workgroups by RANK among them and leaves
+    their number in a word of pinned host memory; the plan's next solve sizes that launch by it (kas_plan_back_grid: one workgroup
+    per handed-back scenario and a quarter more, in steps of 64, at most the fill's own grid).  600 scenarios of which two in three
+    start from rows that are not rack-diverse (400 handed back): the first solve launches 256 workgroups behind the slim kernel, the
+    second and third 512 — lists and records equal to the oracle's every time; a plan rebuilt for another batch starts small again."""
+    import torch
+    from kafka_assigner_amd.native import host_tables
+    S, P, N = 600, 700, 60
+    racks = (np.arange(N) % 6).astype(np.int32)
+    ids = np.arange(N, dtype=np.int32)
+    curs = [(G.cyclic_assignment(P, N, 3, s) * 6 % N) if s % 3 else G.random_assignment(500 + s, P, N, 6, 3) for s in range(S)]
+    fb = uniform_batch(np.stack(curs).astype(np.int32), np.tile(ids, (S, 1))[:, :58], np.tile(racks, (S, 1))[:, :58], 3)
+    want = oracle_solve(fb, threads=0)
+    ctx = native.default_context()
+    dev = torch.device("cuda", ctx.device)
+    plan = native.Plan(ctx, fb)
+    assert "kas_fill_kernel<3,4>[quota, chunk histograms] grid=256x256" in plan.describe(), plan.describe()
+    d_cur = torch.from_numpy(fb.cur).to(dev)
+    st = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    for turn in range(3):
+        _, ho = host_tables(fb)
+        d_out = torch.full((fb.out_len,), -2, dtype=torch.int32, device=dev)
+        d_tr = torch.zeros(fb.n_topics * 16, dtype=torch.uint8, device=dev)
+        d_sr = torch.zeros(S * 32, dtype=torch.uint8, device=dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        plan.solve_device(d_cur.data_ptr(), d_out.data_ptr(), d_tr.data_ptr(), d_sr.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        ho.out = d_out.cpu().numpy()
+        ho.topic_results = d_tr.cpu().numpy().view(abi.TOPIC_RESULT_DTYPE)
+        ho.scenario_results = d_sr.cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
+        assert_same_outputs(fb, want, ho, f"hip 400 of 600 scenarios handed back, solve {turn + 1} of one plan")
+        assert "kas_fill_kernel<3,4>[quota, chunk histograms] grid=512x256" in plan.describe(), (turn, plan.describe())
+    plan.close()
+    fbs = uniform_batch(np.stack(curs[:530]).astype(np.int32), np.tile(ids, (530, 1))[:, :58], np.tile(racks, (530, 1))[:, :58], 3)
+    plan = native.Plan(ctx, fbs)
+    assert "kas_fill_kernel<3,4>[quota, chunk histograms] grid=256x256" in plan.describe(), plan.describe()
+    plan.close()
+
+
+@pytest.mark.gpu
 def test_spread_fill_on_small_batches_and_what_it_hands_back():
     """KAS_PLAN_SPREAD_FILL: the spread fill (row scans of a scenario over several one-wavefront
     workgroups; by itself it serves batches of few scenarios of >= 131,072 rows, e.g. configs[4]) on small
