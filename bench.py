@@ -115,6 +115,10 @@ def parse_args(argv=None):
                          "(kas_plan_create; SURVEY 8(b)/(d)'s contract — the headline), 16 = uint16 node indices "
                          "(kas_plan_create16, ABI v5; lists up to 3 wide, else 32 is taken).  The other layout is measured "
                          "beside it on the same slots and reported as value_cells16 / value_int32_cells")
+    ap.add_argument("--rccl-at-1", action="store_true",
+                    help="run the data-path collective at ONE rank too (an RCCL communicator of one rank on this GPU: the library "
+                         "loads, the communicator initialises on the device, the all-gather runs on the slots' own streams inside "
+                         "the timed steps) - what a one-GPU box can exercise of the N > 1 path; never the default")
     ap.add_argument("--stub", action="store_true",
                     help="harness self-test on CPU (gloo, synthetic records): NOT a measurement")
     ap.add_argument("--config", type=int, choices=(2, 3, 4), default=0,
@@ -506,12 +510,18 @@ def run_rank(args) -> int:
 
     Run = StubRun if args.stub else HipRun
     run = Run(args, rank, world, local_rank, lo, hi, action_mix)
-    if world > 1:
+    coll = world > 1 or bool(getattr(args, "rccl_at_1", False))     # the data-path collective runs (and its process group exists)
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:           # (--rccl-at-1 without a launcher)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         if args.stub:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=run.dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=run.dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
         # which device does every rank drive?  (two ranks on one GPU would be a mislabelled run)
@@ -526,8 +536,8 @@ def run_rank(args) -> int:
 
     S = run.S
     for sl in run.slots:
-        sl["all"] = run.new_gather_buffer(total) if world > 1 else run.records_tensor(sl)
-    if world > 1:
+        sl["all"] = run.new_gather_buffer(total) if coll else run.records_tensor(sl)
+    if coll:
         # Pre-flight of the one data-path collective, before anything is timed: every slot's all-gather once, on the slot's
         # OWN stream (where the timed steps put it: a non-default HIP stream with a hardware queue of its own, which is where
         # an RCCL / IPC problem would first show), synchronised, the records of my own shard checked.  A failure ends the
@@ -554,13 +564,13 @@ def run_rank(args) -> int:
         sl = run.slots[run.step_no % run.n_slots]
         run.step_no += 1
         run.solve(sl)
-        if world > 1:                                   # the single data-path collective
+        if coll:                                   # the single data-path collective
             with run.stream_ctx(sl):
                 sl["all"] = sharding.gather_records(run.records_tensor(sl), total, out=sl["all"])
 
     def fence():
         run.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         run.synchronize()
 
@@ -575,7 +585,7 @@ def run_rank(args) -> int:
             step()
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if coll:
             t = torch.tensor([el], dtype=torch.float64, device=run.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -620,7 +630,7 @@ def run_rank(args) -> int:
     sr = slot_records[0]
     ok = int((sr["status"] == abi.KAS_OK).sum())
     gathered_ok = True
-    if world > 1:
+    if coll:
         all_sr = sl0["all"].cpu().numpy().view(abi.SCENARIO_RESULT_DTYPE)
         assert all_sr.shape[0] == total
         assert (all_sr[lo:hi] == sr).all(), "all-gather returned a different record for my own shard"
@@ -630,7 +640,7 @@ def run_rank(args) -> int:
 
     # ---- the all-gather alone (reported separately) -----------------------------------
     allgather_us = None
-    if world > 1:
+    if coll:
         fence()
         n_ag = 20
         t0 = time.perf_counter()
@@ -760,7 +770,7 @@ def run_rank(args) -> int:
                 "parity_note": "records (status, failing topic / partition, movement counts, digest of every emitted "
                                "cell) of every slot's last timed solve against the CPU solvers; every list of slot 0 "
                                "against the oracle",
-                "collective": "all_gather of 32-byte result records per step" if world > 1 else "none (1 GPU)",
+                "collective": ("all_gather of 32-byte result records per step" + ("" if world > 1 else " (an RCCL communicator of ONE rank: --rccl-at-1)")) if coll else "none (1 GPU)",
                 "allgather_alone_us": allgather_us,
                 "batches_in_flight": run.n_slots, "distinct_batches_in_flight": run.distinct,
                 "cells": ("uint16 node indices resident in HBM (kas_plan_create16 / kas_solve_device16, ABI v5): a replica is the "
@@ -806,6 +816,7 @@ def run_rank(args) -> int:
         if args.stub:
             out_line["stub"] = True
             out_line["metric"] = "STUB harness self-test - not a measurement"
+        if coll or args.stub:                                 # (this rank's own shard came back byte for byte: asserted above; the stub checks every shard)
             out_line["config"]["gathered_records_ok"] = gathered_ok
         # PMC-measured HBM traffic: only from a committed profile of the SAME kernels (the plan's own
         # description) built from the SAME sources — anything else would be a stale number
@@ -881,7 +892,7 @@ def run_rank(args) -> int:
                 out_line["other_configs"] = {"error": repr(e)}
         print(json.dumps(out_line), flush=True)
     run.close()
-    if world > 1:
+    if coll:
         dist.barrier()
         dist.destroy_process_group()
     return 0
