@@ -79,8 +79,9 @@ extern "C" {
 #define KAS_FAIL_RF_GT_BROKERS   3  /* KTA:67-69                                            */
 #define KAS_FAIL_HASH_INDEX      4  /* topic.hashCode()==Integer.MIN_VALUE: Math.abs stays
                                        negative -> ArrayIndexOutOfBounds at KAS:190-192      */
-#define KAS_FAIL_RF_MISMATCH     5  /* KTA:58-60; raised by the host mirror while resolving
-                                       rf, never by the kernels                              */
+#define KAS_FAIL_RF_MISMATCH     5  /* KTA:58-60; raised while resolving rf on the host
+                                       (kas_resolve_replication_factor, the mirrors), never by
+                                       the kernels                                           */
 #define KAS_SKIPPED              6  /* an earlier topic of the same scenario failed; the CLI
                                        run would have aborted (KAG:173-184)                  */
 #define KAS_FAIL_BAD_NODES       7  /* node_id[] not strictly ascending (KAS:80 analogue),
@@ -193,6 +194,29 @@ int         kas_abi_version(void);
 const char* kas_strerror(int code);          /* text for KAS_E_* return codes               */
 const char* kas_status_string(int status);   /* text for KAS_OK / KAS_FAIL_* status codes   */
 const char* kas_last_error(void);            /* thread-local detail of the last failure     */
+
+/* KTA:47-69 as data (host arithmetic, no device): the replication factor generateAssignment resolves from the current
+ * assignment when desiredReplicationFactor < 0, and its three precondition checks.  partition_ids[i] / list_sizes[i]: the
+ * entries of currentAssignment IN THE ORDER THE CALLER'S MAP ITERATES (KTA:50: the first entry fixes the factor, KTA:57-60: the
+ * first later entry of another size fails the topic).  Returns 0 and fills *res: status KAS_OK (rf = the factor to solve with),
+ * KAS_FAIL_RF_MISMATCH (fail_partition, fail_list_size = the entry of KTA:58-60; rf = the factor it was held against),
+ * KAS_FAIL_RF_NOT_POSITIVE (KTA:65-66) or KAS_FAIL_RF_GT_BROKERS (KTA:67-69; rf = the offending factor). */
+typedef struct kas_rf_result {
+  int32_t status;
+  int32_t rf;
+  int32_t fail_partition;   /* -1 unless KAS_FAIL_RF_MISMATCH */
+  int32_t fail_list_size;   /* -1 unless KAS_FAIL_RF_MISMATCH */
+} kas_rf_result;
+int kas_resolve_replication_factor(const int32_t* partition_ids, const int32_t* list_sizes, int32_t n_partitions,
+                                   int32_t desired_rf, int32_t n_brokers, kas_rf_result* res);
+
+/* The message of the exception the reference throws for a topic status, character for character (what a binding puts into
+ * its IllegalStateException): KAS:183-184 "Partition <p> could not be fully assigned!"; KTA:58-60 "Topic <t> has partition
+ * <p> with unexpected replication factor <n>"; KTA:65-66 "Topic <t> does not have a positive replication factor!"; KTA:67-69
+ * "Topic <t> has a higher replication factor (<rf>) than available brokers!".  `topic` is UTF-8.  `rf` and `list_size` are
+ * read only by the statuses that print them.  Returns the length written (truncated to n - 1, always terminated), 0 for KAS_OK
+ * and for statuses the reference has no message for (KAS_FAIL_HASH_INDEX is an ArrayIndexOutOfBoundsException without one). */
+int kas_failure_text(const char* topic, int32_t status, int32_t fail_partition, int32_t rf, int32_t list_size, char* buf, int n);
 
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int kas_device_count(void);

@@ -139,6 +139,11 @@ class Tables(C.Structure):
     ]
 
 
+class RfResult(C.Structure):
+    """kas_rf_result: what kas_resolve_replication_factor leaves (KTA:47-69 as data)."""
+    _fields_ = [("status", C.c_int32), ("rf", C.c_int32), ("fail_partition", C.c_int32), ("fail_list_size", C.c_int32)]
+
+
 # numpy structured dtypes with the same layout as TopicResult / ScenarioResult
 import numpy as _np  # noqa: E402
 

@@ -549,6 +549,48 @@ const char* kas_status_string(int status) {
 
 const char* kas_last_error(void) { return g_last_error.c_str(); }
 
+// KTA:47-69 (host arithmetic): see include/kas_abi.h
+int kas_resolve_replication_factor(const int32_t* partition_ids, const int32_t* list_sizes, int32_t n_partitions,
+                                   int32_t desired_rf, int32_t n_brokers, kas_rf_result* res) {
+  if (!res || n_partitions < 0 || (n_partitions > 0 && (!partition_ids || !list_sizes)))
+    return set_error(KAS_E_INVALID_ARG, "kas_resolve_replication_factor: null argument or negative count");
+  res->status = KAS_OK; res->fail_partition = -1; res->fail_list_size = -1;
+  int32_t rf = desired_rf;
+  for (int32_t i = 0; i < n_partitions; ++i) {
+    if (rf < 0) {
+      rf = list_sizes[i];                                      // KTA:55-56 (a list cannot be shorter than empty)
+    } else if (desired_rf < 0 && rf != list_sizes[i]) {        // KTA:57-60
+      res->status = KAS_FAIL_RF_MISMATCH; res->rf = rf;
+      res->fail_partition = partition_ids[i]; res->fail_list_size = list_sizes[i];
+      return 0;
+    }
+  }
+  res->rf = rf;
+  if (!(rf > 0)) res->status = KAS_FAIL_RF_NOT_POSITIVE;       // KTA:65-66
+  else if (!(rf <= n_brokers)) res->status = KAS_FAIL_RF_GT_BROKERS;   // KTA:67-69
+  return 0;
+}
+
+int kas_failure_text(const char* topic, int32_t status, int32_t fail_partition, int32_t rf, int32_t list_size, char* buf, int n) {
+  if (!buf || n <= 0) return 0;
+  buf[0] = 0;
+  const std::string t = topic ? topic : "null";               // (Java prints a null String as "null")
+  std::string m;
+  switch (status) {
+    case KAS_FAIL_UNASSIGNABLE: m = "Partition " + std::to_string(fail_partition) + " could not be fully assigned!"; break;
+    case KAS_FAIL_RF_MISMATCH:
+      m = "Topic " + t + " has partition " + std::to_string(fail_partition) + " with unexpected replication factor " + std::to_string(list_size);
+      break;
+    case KAS_FAIL_RF_NOT_POSITIVE: m = "Topic " + t + " does not have a positive replication factor!"; break;
+    case KAS_FAIL_RF_GT_BROKERS: m = "Topic " + t + " has a higher replication factor (" + std::to_string(rf) + ") than available brokers!"; break;
+    default: return 0;
+  }
+  const size_t len = m.size() < (size_t)(n - 1) ? m.size() : (size_t)(n - 1);
+  memcpy(buf, m.data(), len);
+  buf[len] = 0;
+  return (int)len;
+}
+
 int kas_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

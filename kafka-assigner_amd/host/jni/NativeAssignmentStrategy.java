@@ -81,10 +81,12 @@ final class NativeAssignmentStrategy {
                             + replicationFactor + ") than available brokers!");
                 case 4:         // KAS:190 with hashCode() == Integer.MIN_VALUE
                     return new ArrayIndexOutOfBoundsException();
-                case 5:         // KTA:58-60 (raised by host mirrors while resolving rf, never by the kernels).  The reference's
+                case 5:         // KTA:58-60 (raised while resolving rf on the host, never by the kernels).  The reference's
                                 // text names the partition and its list size ("Topic <t> has partition <p> with unexpected
-                                // replication factor <n>"); the status carries neither, so this text is an approximation —
-                                // the Java mirror below never reaches it: it resolves rf itself and throws the exact text.
+                                // replication factor <n>"); a topic status carries neither — the C ABI gives both
+                                // (kas_resolve_replication_factor -> kas_rf_result) and the exact text (kas_failure_text),
+                                // and the Java mirror below resolves rf itself and throws the exact text, so this
+                                // approximation is never reached through either.
                     return new IllegalStateException("Topic " + topic + " has a partition with unexpected replication factor");
                 case 6: return new IllegalStateException("skipped: an earlier topic of the run failed");
                 case 7: return new IllegalArgumentException("broker ids must be non-negative and distinct; at most 32768 racks");

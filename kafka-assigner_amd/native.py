@@ -25,7 +25,7 @@ SYMBOLS = [
     "kas_plan_kernel_time_us", "kas_plan_phase_times_us", "kas_plan_stats", "kas_plan_set_flags",
     "kas_plan_describe", "kas_ctx_host_stats", "kas_solve_host_select", "kas_host_alloc", "kas_host_free",
     "kas_shard_range", "kas_batch_slice", "kas_solve_host_sharded", "kas_ctx_lds_lane_order", "kas_solve_host16",
-    "kas_plan_create16", "kas_solve_device16",
+    "kas_plan_create16", "kas_solve_device16", "kas_resolve_replication_factor", "kas_failure_text",
 ]
 
 _LIB = None
@@ -105,6 +105,11 @@ def load():
     L.kas_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.kas_plan_stats.restype = C.c_int
     L.kas_plan_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64]
+    L.kas_resolve_replication_factor.restype = C.c_int
+    L.kas_resolve_replication_factor.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
+                                                 C.POINTER(abi.RfResult)]
+    L.kas_failure_text.restype = C.c_int
+    L.kas_failure_text.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int]
     if L.kas_abi_version() != abi.KAS_ABI_VERSION:
         raise ImportError("libkas_hip.so ABI version mismatch")
     _LIB = L
@@ -115,6 +120,25 @@ def _check(rc: int):
     if rc != 0:
         L = load()
         raise KasError(rc, (L.kas_last_error() or b"").decode() or L.kas_strerror(rc).decode())
+
+
+def resolve_replication_factor(partition_ids, list_sizes, desired_rf: int, n_brokers: int) -> "abi.RfResult":
+    """kas_resolve_replication_factor (KTA:47-69; host arithmetic, needs no device): entries in the caller's map order."""
+    pid = np.ascontiguousarray(partition_ids, dtype=np.int32)
+    ls = np.ascontiguousarray(list_sizes, dtype=np.int32)
+    assert pid.shape == ls.shape and pid.ndim == 1
+    res = abi.RfResult()
+    _check(load().kas_resolve_replication_factor(pid.ctypes.data_as(C.POINTER(C.c_int32)), ls.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 int(pid.size), int(desired_rf), int(n_brokers), C.byref(res)))
+    return res
+
+
+def failure_text(topic, status: int, fail_partition: int = -1, rf: int = -1, list_size: int = -1) -> str:
+    """kas_failure_text: the message of the exception the reference throws for this status ('' where it has none)."""
+    buf = C.create_string_buffer(1024)
+    n = load().kas_failure_text(None if topic is None else str(topic).encode("utf-8"), int(status), int(fail_partition), int(rf),
+                                int(list_size), buf, 1024)
+    return buf.raw[:n].decode("utf-8")
 
 
 class DeviceContext:

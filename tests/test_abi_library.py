@@ -61,6 +61,7 @@ int main(void) {
   S(kas_topic_result); S(kas_scenario_result); O(kas_scenario_result, digest);
   S(kas_batch_desc); O(kas_batch_desc, node_pool_len);
   S(kas_tables); O(kas_tables, cur_len); O(kas_tables, ctx_len);
+  S(kas_rf_result); O(kas_rf_result, fail_list_size);
   printf("digest %llu\n", (unsigned long long)kas_digest_cell(2, 77, 1, 1005));
   return 0;
 }''')
@@ -81,6 +82,8 @@ int main(void) {
     assert int(got["kas_tables"]) == C.sizeof(abi.Tables)
     assert int(got["kas_tables.cur_len"]) == abi.Tables.cur_len.offset
     assert int(got["kas_tables.ctx_len"]) == abi.Tables.ctx_len.offset
+    assert int(got["kas_rf_result"]) == C.sizeof(abi.RfResult)
+    assert int(got["kas_rf_result.fail_list_size"]) == abi.RfResult.fail_list_size.offset
     assert int(got["digest"]) == abi.digest_cell(2, 77, 1, 1005)
 
 
