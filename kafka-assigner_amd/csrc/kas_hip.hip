@@ -38,48 +38,15 @@
 #ifndef KAS_FILL_MIN_WAVES
 #define KAS_FILL_MIN_WAVES 4
 #endif
-// The r-th scenario (ascending) whose flag is set, or -1 past the last one; *total: their number when the answer is -1.  Every
-// wavefront of the workgroup scans the flags for itself (64 per step, a ballot and a population count: wave-uniform by
-// construction, nothing shared) and gets the same answer.
-__device__ inline int32_t kas_kth_flagged(const int32_t* flag, int32_t n, int32_t r, int32_t* total) {
-  const int32_t lane = (int32_t)(threadIdx.x & 63u);
-  int32_t seen = 0;
-  for (int32_t base = 0; base < n; base += 64) {
-    const int32_t s = base + lane;
-    unsigned long long w = kasw::ballot(s < n && flag[s] != 0);
-    const int32_t c = (int32_t)__popcll(w);
-    if (r < seen + c) {
-      for (int32_t i = seen; i < r; ++i) w &= w - 1ull;
-      return base + (int32_t)__builtin_ctzll(w);
-    }
-    seen += c;
-  }
-  *total = seen;
-  return -1;
-}
-
 // A launch for flagged scenarios only (KAS_FLAG_ONLY_FLAGGED: behind the slim kernel, behind the spread fill, the wide form's second
-// solve) deals them to its workgroups round-robin BY RANK among the flagged ones — workgroup b takes the b-th, (b + grid)-th, ... —
-// so that a tenth of 1000 scenarios handed back is a hundred workgroups with one scenario each, not 256 of which some hold three
-// (round 6: 25.9 -> 15 ms for such a batch, scripts/handback_probe.py), and workgroup 0 leaves their number where the plan sizes its
-// next such launch (KasLaunch::handback).
+// solve) deals them to its workgroups round-robin BY RANK among the flagged ones (kas::fill_block, kas_solver_body.h) — a tenth of
+// 1000 scenarios handed back is a hundred workgroups with one scenario each, not 256 of which some hold three (round 6: 25.9 -> 15 ms
+// for such a batch, scripts/handback_probe.py) — and workgroup 0 leaves their number where the plan sizes its next such launch
+// (KasLaunch::handback, kas_plan_back_grid).
 template <int W, int NW>
 __global__ __launch_bounds__(64 * NW, KAS_FILL_MIN_WAVES) void kas_fill_kernel(KasLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kas_lds[];
-  const bool by_rank = (a.flags & KAS_FLAG_ONLY_FLAGGED) != 0u && a.sp_flag != nullptr;
-  for (int32_t i = (int32_t)blockIdx.x;; i += (int32_t)gridDim.x) {
-    int32_t s = i, total = 0;
-    if (by_rank) {
-      s = kas_kth_flagged(a.sp_flag, a.n_scenarios, i, &total);
-      if (s < 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && a.handback != nullptr) *a.handback = total;
-        break;
-      }
-    } else if (s >= a.n_scenarios) {
-      break;
-    }
-    kas::fill_scenario<W, NW>(a, s, kas_lds);
-  }
+  kas::fill_block<W, NW>(a, (int32_t)blockIdx.x, (int32_t)gridDim.x, kas_lds);
 }
 
 // The slim fill (round 6): fill_scenario<W, 4, SLIM> — only the path every BASELINE config at RF <= 3 takes (kas_solver_body.h,

@@ -1834,6 +1834,52 @@ KAS_DEV void fill_scenario(const KasLaunch& a, int32_t s, unsigned char* lds_raw
 }
 
 // ---------------------------------------------------------------------------------------------
+// kas_fill_kernel, one workgroup: the scenarios workgroup `block` of `grid` takes.  A launch for every scenario deals them by
+// index (block, block + grid, ...).  A launch for FLAGGED scenarios only (KAS_FLAG_ONLY_FLAGGED with the flags in sp_flag: behind
+// the slim kernel, behind the spread fill, the wide form's second solve) deals them BY RANK among the flagged ones — workgroup b
+// takes the b-th, (b + grid)-th, ... flagged scenario — so that the scenarios handed back spread evenly over the workgroups
+// however they lie among the others, and workgroup 0 leaves their number in KasLaunch::handback (when given: host memory the
+// plan sizes its next such launch by).
+// ---------------------------------------------------------------------------------------------
+// The r-th scenario (ascending) whose flag is set, or -1 past the last one; total: their number when the answer is -1.  Every
+// wavefront of the workgroup scans the flags for itself (64 per step, a ballot and a population count: wave-uniform by
+// construction, nothing shared, no barrier) and gets the same answer: nothing writes the flags while this kernel runs.
+KAS_DEV int32_t kth_flagged(const int32_t* flag, int32_t n, int32_t r, int32_t& total) {
+  const int32_t lane = kasw::lane();
+  int32_t seen = 0;
+  for (int32_t base = 0; base < n; base += 64) {
+    const int32_t s = base + lane;
+    uint64_t w = kasw::ballot(s < n && flag[s < n ? s : 0] != 0);
+    const int32_t c = kasw::popc(w);
+    if (r < seen + c) {
+      for (int32_t i = seen; i < r; ++i) w &= w - 1ull;      // (drop the r - seen lowest set bits)
+      return base + kasw::first_lane(w);
+    }
+    seen += c;
+  }
+  total = seen;
+  return -1;
+}
+
+template <int W, int NW>
+KAS_DEV void fill_block(const KasLaunch& a, int32_t block, int32_t grid, unsigned char* lds_raw) {
+  const bool by_rank = (a.flags & KAS_FLAG_ONLY_FLAGGED) != 0u && a.sp_flag != nullptr;
+  for (int32_t i = block;; i += grid) {
+    int32_t s = i, total = 0;
+    if (by_rank) {
+      s = kth_flagged(a.sp_flag, a.n_scenarios, i, total);
+      if (s < 0) {
+        if (block == 0 && kasw::tid() == 0 && a.handback != nullptr) *a.handback = total;
+        break;
+      }
+    } else if (s >= a.n_scenarios) {
+      break;
+    }
+    fill_scenario<W, NW>(a, s, lds_raw);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // kas_p4_kernel, one scenario (KAS_FLAG_SPLIT_P4): first fit (P4, KAS:56, 162-186) of the topics the fill kernel handed
 // over, in order, on four wavefronts — p4_lists_parallel exactly as the fill workgroup ran it, on the loads the sticky
 // fill left (KasLaunch::p4s), the topic's orphan lists and its mid rows.  A partition that cannot be placed fails its

@@ -257,15 +257,45 @@ template <int W> void spread_quota_all(const KasLaunch& a) {
     for (int32_t n = 0; n < a.n_max; ++n) kas::spread_quota<W>(a, s, n);
 }
 
+// kas_fill_kernel as it is launched: workgroup `block` of `grid` runs kas::fill_block — its loop over the scenarios it takes (by index,
+// or by rank among the flagged ones behind the slim kernel / the spread fill / the wide form's check), the LDS NOT cleared between them
+struct BlockArgs { const KasLaunch* a; int32_t block, grid; unsigned char* lds; };
+template <int W, int NW> void run_fill_block(void* p) {
+  BlockArgs* r = (BlockArgs*)p;
+  kas::fill_block<W, NW>(*r->a, r->block, r->grid, r->lds);
+}
 typedef void (*run_fn)(void*);
 template <int NW> run_fn fill_for_w(int Wc) {
   switch (Wc) {                            // the same width classes the product launcher uses
-    case 2: return run_fill<2, NW>;
-    case 3: return run_fill<3, NW>;
-    case 4: return run_fill<4, NW>;
-    case 5: return run_fill<5, NW>;
-    default: return run_fill<8, NW>;
+    case 2: return run_fill_block<2, NW>;
+    case 3: return run_fill_block<3, NW>;
+    case 4: return run_fill_block<4, NW>;
+    case 5: return run_fill_block<5, NW>;
+    default: return run_fill_block<8, NW>;
   }
+}
+// workgroups of an emulated kas_fill_kernel launch: KAS_EMU_FILL_GRID (default 3: most batches of the suites then have workgroups
+// that take several scenarios in a row, as a launch on fewer workgroups than scenarios does on the GPU), at most one per scenario
+static int32_t emu_fill_grid(int32_t n_scenarios) {
+  const char* e = getenv("KAS_EMU_FILL_GRID");
+  int32_t g = e ? atoi(e) : 3;
+  if (g < 1) g = 1;
+  return g < n_scenarios ? g : (n_scenarios > 0 ? n_scenarios : 1);
+}
+static int g_last_handback = -1;           // what the last by-rank launch left in KasLaunch::handback (-1: there was none)
+// one emulated launch of kas_fill_kernel; returns the workgroup that failed, or -1
+static int32_t emu_launch_fill(run_fn fill, KasLaunch& a, int NW, std::vector<unsigned char>& lds, int32_t n_scenarios, bool want_handback) {
+  const int32_t G = emu_fill_grid(n_scenarios);
+  int32_t hb = -1;
+  a.handback = want_handback ? &hb : nullptr;
+  for (int32_t blk = 0; blk < G; ++blk) {
+    memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
+    BlockArgs ra{&a, blk, G, lds.data()};
+    if (kasw::run_block(fill, &ra, NW) != 0) { a.handback = nullptr; return blk; }
+  }
+  a.handback = nullptr;
+  if (want_handback) g_last_handback = hb;
+  return -1;
 }
 template <int G, bool PK> run_fn tickets_for_g(int Wc) {
   switch (Wc) {
@@ -392,7 +422,7 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
   };
   // spread fill (same decision as kas_solve_device): passes A and B over one-wavefront workgroups
   a.sp_hist = nullptr; a.sp_quota = nullptr; a.sp_node = nullptr; a.sp_flag = nullptr; a.sp_oc = nullptr; a.sp_chunks = 0;
-  a.handback = nullptr;                                  // (the launcher's: kas_fill_kernel's own loop over flagged scenarios is not emulated)
+  a.handback = nullptr;                                  // (set by emu_launch_fill for a by-rank launch)
   g_last_spread = 0;
   const int32_t CH = (!c16 && sh.NW == 4 && sh.Wc >= 3 && sh.Wc <= 5 && !(flags & KAS_FLAG_GENERIC_FILL))
                          ? kas_spread_chunks(sh, b->n_scenarios, kas_batch_single_topic(b), (flags & KAS_FLAG_SPREAD_FILL) != 0) : 0;
@@ -488,12 +518,14 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     }
     a.flags |= KAS_FLAG_ONLY_FLAGGED;
   }
-  for (int32_t s = 0; s < b->n_scenarios; ++s) {
-    memset(lds.data(), 0xCD, lds.size());   // LDS is uninitialised on hardware too
-    RunArgs ra{&a, s, lds.data()};
-    if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill", s);
-    g_last_index_rows += (long)a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 6];   // (the fill's own tally, before an order kernel writes there)
+  g_last_handback = -1;
+  {
+    const bool by_rank = (a.flags & KAS_FLAG_ONLY_FLAGGED) != 0u && a.sp_flag != nullptr;
+    const int32_t failed = emu_launch_fill(fill, a, sh.NW, lds, b->n_scenarios, by_rank);
+    if (failed >= 0) return bad("fill (workgroup)", failed);
   }
+  for (int32_t s = 0; s < b->n_scenarios; ++s)
+    g_last_index_rows += (long)a.stats[(int64_t)s * KAS_STATS_PER_SCENARIO + 6];   // (the fill's own tally, before an order kernel writes there)
   a.flags &= ~KAS_FLAG_ONLY_FLAGGED;
   if (split_p4 && !p4_order) {
     // exactly the LDS the product launches kas_p4_kernel with, and a guard behind it
@@ -640,10 +672,9 @@ static int emu_solve(const kas_batch_desc* b, const kas_tables* t, unsigned flag
     KasLaunch af = a;
     af.flags = (af.flags | KAS_FLAG_ONLY_FLAGGED) & ~(KAS_FLAG_WIDE_CHECK | KAS_FLAG_SPLIT_P4);
     af.sp_flag = ord_flag.data();
-    for (int32_t s = 0; s < b->n_scenarios; ++s) {
-      memset(lds.data(), 0xCD, lds.size());
-      RunArgs ra{&af, s, lds.data()};
-      if (kasw::run_block(fill, &ra, sh.NW) != 0) return bad("fill (flagged by the wide form)", s);
+    {
+      const int32_t failed = emu_launch_fill(fill, af, sh.NW, lds, b->n_scenarios, false);
+      if (failed >= 0) return bad("fill (flagged by the wide form; workgroup)", failed);
     }
     a.flags &= ~KAS_FLAG_WIDE_CHECK;
   }
@@ -711,6 +742,10 @@ extern "C" __attribute__((visibility("default")))
 long kas_emu_last_relax_quad(void) { return g_last_relax_quad; }
 extern "C" __attribute__((visibility("default")))
 long kas_emu_last_slim_fill(void) { return g_last_slim_fill; }
+
+// scenarios the last by-rank launch of kas_fill_kernel counted as flagged (KasLaunch::handback; -1: no such launch in the last solve)
+extern "C" __attribute__((visibility("default")))
+int kas_emu_last_handback(void) { return g_last_handback; }
 
 extern "C" __attribute__((visibility("default")))
 int kas_emu_last_relax_idl(void) { return g_last_relax_idl; }

@@ -264,6 +264,14 @@ def last_slim_fill() -> int:
     return int(L.kas_emu_last_slim_fill())
 
 
+def last_handback() -> int:
+    """What the last emu_solve's by-rank launch of kas_fill_kernel (behind the slim kernel / the spread fill) left in
+    KasLaunch::handback: the number of scenarios handed back; -1 when the solve had no such launch."""
+    L = lib()
+    L.kas_emu_last_handback.restype = C.c_int
+    return int(L.kas_emu_last_handback())
+
+
 def last_p4_order() -> int:
     """1: the last emu_solve ran first fit inside the order kernel's workgroup (kas_p4_order_kernel: KAS_PLAN_SPLIT_P4 | KAS_PLAN_FILL_WITH_P4)"""
     L = lib()

@@ -394,6 +394,34 @@ def test_emu_slim_fill_kernel_in_front_and_the_full_kernel_for_what_it_hands_bac
         assert last_slim_fill() == 4
 
 
+def test_emu_fill_kernel_deals_the_scenarios_handed_back_by_rank(monkeypatch):
+    """kas_fill_kernel's own loop (kas::fill_block, round 6): a launch for flagged scenarios only deals them to its workgroups by
+    RANK among the flagged ones and workgroup 0 leaves their number in KasLaunch::handback (the plan sizes its next such launch by it);
+    a launch for every scenario deals them by index.  Nine scenarios of which five (1, 2, 5, 7, 8) start from rows that are not
+    rack-diverse, on grids of 1, 2, 3, 4 and 9 workgroups (KAS_EMU_FILL_GRID: the emulator runs the workgroups one after another,
+    each over the scenarios it takes, its LDS not cleared between them) — lists equal to the oracle's, five counted; the same
+    batches with the slim kernel off (every scenario by index on those grids), and a batch nothing of which goes back (count 0)."""
+    from emu_lib import FULL_FILL, P4_WITH_ORDER, last_handback, last_slim_fill
+    S, P, N = 9, 500, 60
+    racks = (np.arange(N) % 6).astype(np.int32)
+    ids = np.arange(N, dtype=np.int32)
+    back = (1, 2, 5, 7, 8)
+    curs = [(G.cyclic_assignment(P, N, 3, s) * 6 % N) if s in back else G.random_assignment(300 + s, P, N, 6, 3) for s in range(S)]
+    fb = uniform_batch(np.stack(curs).astype(np.int32), np.tile(ids, (S, 1))[:, :58], np.tile(racks, (S, 1))[:, :58], 3)
+    want = oracle_solve(fb)
+    fb0 = _batch(4321, 7, 600, 45, 9, 3, G.BENCH_ACTIONS)               # rack-diverse: nothing handed back
+    want0 = oracle_solve(fb0)
+    for grid in (1, 2, 3, 4, 9):
+        monkeypatch.setenv("KAS_EMU_FILL_GRID", str(grid))
+        for flags in (0, P4_WITH_ORDER):
+            assert_same_outputs(fb, want, emu_solve(fb, flags=flags), f"emu: five of nine handed back, {grid} workgroups behind the slim kernel, plan flags {flags:#x}")
+            assert last_slim_fill() == S - len(back) and last_handback() == len(back), (grid, flags, last_slim_fill(), last_handback())
+        assert_same_outputs(fb, want, emu_solve(fb, flags=FULL_FILL), f"emu: every scenario by index on {grid} workgroups")
+        assert last_slim_fill() == 0 and last_handback() == -1
+        assert_same_outputs(fb0, want0, emu_solve(fb0), f"emu: nothing handed back, {grid} workgroups find nothing to do")
+        assert last_slim_fill() == 7 and last_handback() == 0
+
+
 def _later_topic_hands_back():
     """8 scenarios of three topics over 48-50 brokers in 10 racks; in every other one the SECOND topic's rows are not rack-diverse"""
     scs = []
