@@ -164,7 +164,7 @@ def test_bench_tables_with_16_bit_cells_are_the_index_form_of_flatten():
 
 def test_bench_collective_at_one_rank_over_gloo():
     """`--rccl-at-1`: the data-path collective inside the steps of a ONE-rank run (over gloo with the stub; over an RCCL communicator
-    of one rank on the GPU box, tests/test_bench_rccl_one_rank.py) - what a one-GPU box can exercise of the N > 1 path."""
+    of one rank on the GPU box, tests/test_zz_bench_rccl_one_rank.py) - what a one-GPU box can exercise of the N > 1 path."""
     r = _run(["--stub", "--gpus", "1", "--steps", "4", "--warmup", "1", "--scenarios", "5", "--in-flight", "2", "--rccl-at-1"])
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)

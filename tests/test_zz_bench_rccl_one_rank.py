@@ -3,7 +3,9 @@ of ONE rank on cuda:0 (backend "nccl" IS RCCL on ROCm), gathers every slot's 32-
 non-default stream before anything is timed (the pre-flight) and after every solve inside the timed steps, and checks the bytes
 that came back.  It cannot show a second GPU or an xGMI link; it shows that the library loads beside libkas_hip.so, that the
 communicator comes up with `device_id`, and that the all-gather and the solver's kernels share streams and hardware queues
-(GPU_MAX_HW_QUEUES) without upsetting each other - with the parity check of the records against the CPU solvers still on."""
+(GPU_MAX_HW_QUEUES) without upsetting each other - with the parity check of the records against the CPU solvers still on.
+(The file sorts LAST in the suite on purpose: under `pytest -x` a communicator that cannot come up on some box for reasons of
+its network set-up must not keep the parity tests from running.)"""
 import json
 import os
 import subprocess
