@@ -831,7 +831,9 @@ static int kas_plan_build(kas_plan* p, const kas_batch_desc* batch) {
   p->tickets = sh.tickets_ok; p->fused = sh.fused_ok;
   p->lds = sh.lds; p->lds_fused = sh.lds_fused;
   p->flags = 0; p->index_rows_bits = 0; p->full_fill = 0; p->mid32_bits = 0;
-  if (p->h_handback) *p->h_handback = 0;                     // (another batch: the launch behind the slim kernel starts small again)
+  // (the hand-back count of the plan's last solve stays when the plan is rebuilt in place for another batch — the host path's
+  // cached plans: a what-if caller hands over fresh broker sets on every call, and whether its rows are rack-diverse is the
+  // SNAPSHOT's property.  A stale count costs one launch with idle workgroups, then it is this batch's own.)
   p->n_scenarios = batch->n_scenarios; p->n_topics = batch->n_topics;
   p->single_topic = kas_batch_single_topic(batch) ? 1 : 0;
   p->sp_alloc_chunks = 0;
