@@ -775,14 +775,15 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
                                  uint64_t* accmask, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   const int32_t cap = T.cap, nt = T.nt;
+  if (T.P <= 0 || T.cw <= 0) return;                         // (no rows: nothing to sweep, and no row for the row stream to read)
+  // (round 6: the rows come through the row stream of the other scans — KAS_TILES_AHEAD tiles asked for before the first is used —
+  //  instead of a load per cell at the point of use: this wavefront is alone on its chain, and a tile then costs its LDS round
+  //  trips, not an HBM round trip per sweep as well; a batch of 1000 scenarios that all take this form: 20.2 -> 16.1 ms — the rest is
+  //  this one wavefront's chain of LDS round trips per tile and first fit from the ring)
   for (int32_t r = 0; r < T.cw; ++r) {
-    for (int32_t tile = 0; tile < nt; ++tile) {
-      const int32_t p = (tile << 6) + lane;
-      const bool active = p < T.P;
-      const int32_t len = active ? (T.len_arr ? T.len_arr[p] : T.cw) : 0;
-      const int64_t row = (int64_t)p * T.cw;                // (cells: cur_cell reads either width)
+    for_tiles<W>(T, 0, 1, nt, [&](int32_t tile, const int32_t (&ids)[W], int32_t len) {
       int32_t n = -1;
-      if (r < len) n = node_lookup(L, nm, cur_cell(T, row + r));   // node != null (KAS:119-120)
+      if (r < len) n = node_lookup(L, nm, sel<W>(ids, r));  // node != null (KAS:119-120)
       bool elig = n >= 0;
       const int32_t rk = elig ? (int32_t)lds_rack(L, n) : -1;
 #pragma unroll
@@ -790,7 +791,7 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
         if (r2 < r) {                                       // wave-uniform
           const uint64_t aw = kasw::load_shared_u64(accmask + (int64_t)r2 * nt + tile);
           if (elig && ((aw >> lane) & 1ull)) {
-            const int32_t n2 = node_lookup(L, nm, cur_cell(T, row + r2));
+            const int32_t n2 = node_lookup(L, nm, ids[r2]);
             if ((int32_t)lds_rack(L, n2) == rk) elig = false;    // rack.canAccept (KAS:346-348)
           }
         }
@@ -819,7 +820,7 @@ KAS_DEV_COLD void fill_generic_sweeps(const LdsView& L, const TopicView& T, cons
       }
       const uint64_t accw = kasw::ballot(accepted);
       if (lane == 0) kasw::store_shared_u64(accmask + (int64_t)r * nt + tile, accw);
-    }
+    });
     kasw::wave_sync();   // this sweep's mask words are visible to the next sweep's loads
   }
 }
@@ -831,11 +832,12 @@ KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const No
                              int32_t& moved_p, int64_t (&st)[8]) {
   const int lane = kasw::lane();
   int32_t ring_count = 0, head = 0;
-  for (int32_t tile = 0; tile < T.nt; ++tile) {
+  int32_t failed = -1;                                       // (wave-uniform: the row first fit could not place)
+  if (T.P > 0)                                               // (the row stream, as in fill_generic_sweeps)
+  for_tiles<W>(T, 0, 1, T.nt, [&](int32_t tile, const int32_t (&ids)[W], int32_t len) {
+    if (failed >= 0) return;
     const int32_t p = (tile << 6) + lane;
-    int32_t ids[W], idx[W], len;
-    if (W <= 3 && T.c16) load_row<W, false, true>(T, p, ids, len);
-    else load_row<W>(T, p, ids, len);
+    int32_t idx[W];
     uint32_t accbits = 0;
 #pragma unroll
     for (int r = 0; r < W; ++r) {
@@ -852,8 +854,9 @@ KAS_DEV_COLD int32_t p3p4_generic(const LdsView& L, const TopicView& T, const No
     p3_rows<W>(L, T, p, len, ids, idx, accbits, need, hc, hrack, moved_r, moved_p);
     ring_push<W>(L, p, need, hc, hrack, ring_count);
     const int32_t fr = drain_ring<W>(L, T, 64, live_count, head, ring_count, st);
-    if (fr >= 0) return fr;
-  }
+    if (fr >= 0) failed = fr;
+  });
+  if (failed >= 0) return failed;
   return drain_ring<W>(L, T, 1, live_count, head, ring_count, st);
 }
 
